@@ -1,0 +1,212 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the MI355X flat-search hot path.
+
+metric (BASELINE.json): queries/sec + p50 latency, brute-force IP kNN, 10M x 512 fp32, k = 10.
+
+A "step" is ONE query (nq = 1, the reference API: minivectordb/vector_database.py:473-497) = one
+pass of the scan over this rank's resident corpus shard, followed — when N > 1 — by the RCCL
+all-gather of the per-shard top-k and the k-way merge.  Weak scaling: every rank holds its own
+`--rows` x `--dim` shard (10M x 512 = 20.48 GB), generated on the device, so the searched corpus is
+N x 10M rows; `value` counts shard passes per second summed over ranks (at N = 1 this IS queries/s
+on 10M x 512), `global_qps` is the user-visible queries/s over the whole N x 10M corpus.
+
+Inputs are resident in HBM when the timed region starts (corpus and all W+K queries are generated
+on the device beforehand); results stay on the device.  The PCIe-inclusive host API rate is
+reported separately as `host_api_qps` and is never `value`.
+
+Launch: python bench.py [--gpus 1]       or, for N > 1 (the driver does this):
+        python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+               --master-port P bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+
+
+def cpu_baseline(native, idx, d, k, queries_host, full_rows, budget_s=20.0):
+    """Time the CPU oracle (oracle/flat_oracle.c, a port of faiss' nq=1 sequential scan) on a bounded
+    sample of the same workload: the first `sample` rows of the resident corpus."""
+    from oracle import flat
+    sample = int(min(full_rows, 1_000_000))
+    x = idx.get_rows(0, sample)
+    nq = 0
+    t0 = time.perf_counter()
+    while True:
+        flat.flat_search(x, queries_host[nq % len(queries_host)], k, nthreads=1)
+        nq += 1
+        if time.perf_counter() - t0 > budget_s / 2 or nq >= 64:
+            break
+    t1 = time.perf_counter() - t0
+    cores = flat.max_threads()
+    nq_mt = 0
+    t0 = time.perf_counter()
+    while True:
+        flat.flat_search(x, queries_host[nq_mt % len(queries_host)], k, nthreads=cores)
+        nq_mt += 1
+        if time.perf_counter() - t0 > budget_s / 2 or nq_mt >= 256:
+            break
+    t2 = time.perf_counter() - t0
+    scale = sample / float(full_rows)
+    return {
+        "value": round(nq / t1 * scale, 4),
+        "unit": "queries/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": (f"first {sample} of {full_rows} rows x {d} fp32, {nq} queries, 1 thread (faiss uses one thread "
+                   f"at nq=1); rate scaled x{scale:g} to the full corpus"),
+        "all_cores_value": round(nq_mt / t2 * scale, 4),
+        "all_cores": cores,
+        "gb_per_s_1thread": round(sample * d * 4 * nq / t1 / 1e9, 2),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--rows", type=int, default=10_000_000, help="rows per GPU")
+    ap.add_argument("--dim", type=int, default=512)
+    ap.add_argument("--k", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("for --gpus N > 1 launch through torch.distributed.run (one rank per GPU)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from minivectordb_amd import _native as native
+    from minivectordb_amd.distributed import ShardedSearcher
+
+    n, d, k = args.rows, args.dim, args.k
+    W, K = args.warmup, args.steps
+    idx = native.FlatIndex(d, device=local_rank)
+    idx.reserve(n)
+    idx.add_synthetic(n, 1234, first_row=rank * n, normalize=True)
+
+    # all queries on the device up front (same on every rank), normalised
+    nqs = W + K
+    queries = torch.empty((nqs, d), dtype=torch.float32, device=dev)
+    native.check(native.lib().mvdb_synth_fill_device(queries.data_ptr(), nqs, d, 5678, 0, 1, local_rank,
+                                                     torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+
+    searcher = ShardedSearcher(idx, k, rank=rank, world=world, rows_per_rank=n, device=dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for i in range(W):
+        searcher.search_device(queries[i:i + 1])
+    torch.cuda.synchronize()
+    native.prof_read("ip_scan")  # drop warm-up launches
+    native.prof_enable(True)
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(W, W + K):
+        searcher.search_device(queries[i:i + 1])
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    native.prof_enable(False)
+    launches, scan_ms = native.prof_read("ip_scan")
+
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # p50 latency: per-query wall (enqueue -> result on device), outside the timed region
+    lat = []
+    for i in range(W, W + min(K, 100)):
+        torch.cuda.synchronize()
+        a = time.perf_counter()
+        searcher.search_device(queries[i:i + 1])
+        torch.cuda.synchronize()
+        lat.append((time.perf_counter() - a) * 1e3)
+    p50 = float(np.median(lat))
+
+    out = None
+    if rank == 0:
+        bytes_per_launch = n * d * 4  # algorithmic: every stored row of this rank's shard once
+        avg_ms = scan_ms / max(launches, 1)
+        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if launches else 0.0
+        out = {
+            "metric": "queries/sec + p50 latency, brute-force IP kNN, 10M x 512 fp32, k=10",
+            "value": round(world * K / dt, 3),
+            "unit": "queries/s",
+            "n_gpus": world,
+            "steps": K,
+            "warmup": W,
+            "ms_per_step": round(dt / K * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{n} x {d} fp32 rows per GPU ({world * n} total), IP, k={k}, nq=1 per step",
+                "rows_per_gpu": n, "dim": d, "k": k, "nq": 1,
+                "parallelism": f"row-sharded x{world}" + (", RCCL all-gather of per-shard top-k" if world > 1 else ""),
+            },
+            "p50_latency_ms": round(p50, 4),
+            "global_qps": round(K / dt, 3),
+            "roofline": {
+                "bound": "hbm",
+                "achieved": round(achieved, 1),
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": None,
+                "kernel": "flat_scan_kernel",
+                "launches": launches,
+                "avg_launch_ms": round(avg_ms, 4),
+                "algorithmic_bytes_per_launch": bytes_per_launch,
+            },
+        }
+        if world == 1:
+            # PCIe-inclusive host API (numpy in, numpy out): reported, never `value`
+            qh = queries[W:W + 32].cpu().numpy()
+            t0 = time.perf_counter()
+            for i in range(qh.shape[0]):
+                idx.search(qh[i], k)
+            out["host_api_qps"] = round(qh.shape[0] / (time.perf_counter() - t0), 3)
+            if not args.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline(native, idx, d, k, qh, n)
+            else:
+                out["cpu_baseline"] = None
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    barrier()
+    idx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,184 @@
+/*
+ * mvdb.h — C-ABI of libmvdb.so, the MI355X (gfx950) replacement for the native calls on
+ * MiniVectorDB's embed+search hot path.
+ *
+ * The reference (cnmoro/MiniVectorDB @ 2024-10-08) has no FFI of its own: the hot path is
+ * executed inside third-party wheels (faiss-cpu, transformers/torch).  Each entry point below
+ * names the reference call site it replaces (paths relative to the reference tree).
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on failure; mvdb_last_error() returns a
+ *     thread-local, NUL-terminated description of the last failure on the calling thread;
+ *   - plain pointers and sizes only; "host" pointers are ordinary CPU memory owned by the caller
+ *     for the duration of the call, "dev" pointers are device memory on the index' GPU;
+ *   - the library copies on add (as faiss IndexFlatIP.add does) and owns all device memory;
+ *   - result conventions match faiss: rows sorted by score descending, labels int64,
+ *     missing slots label -1 / score -FLT_MAX (IP) or +FLT_MAX (L2);
+ *   - ties are broken by ascending row number (deterministic);
+ *   - mvdb_index_search* are re-entrant on one index from many host threads; add / reset /
+ *     free take the index exclusively.
+ *   - There is NO CPU fallback: without a usable HIP device every compute call fails.
+ */
+#ifndef MVDB_H
+#define MVDB_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MVDB_METRIC_IP 0 /* inner product, larger is better (faiss.IndexFlatIP)            */
+#define MVDB_METRIC_L2 1 /* squared L2, smaller is better (extension; not in the reference) */
+
+#define MVDB_OK 0
+#define MVDB_ERR_ARG 1     /* bad argument                       */
+#define MVDB_ERR_HIP 2     /* HIP runtime / device failure       */
+#define MVDB_ERR_NODEVICE 3 /* no usable gfx950 device            */
+#define MVDB_ERR_OOM 4     /* device allocation failed           */
+
+typedef struct mvdb_index mvdb_index;
+typedef struct mvdb_encoder mvdb_encoder;
+
+/* ---- library / device ------------------------------------------------------------------- */
+
+/* Thread-local description of the last error on this thread ("" if none). */
+const char* mvdb_last_error(void);
+
+/* ABI version of this header (bumped on incompatible change). */
+int mvdb_abi_version(void);
+
+/* Number of visible HIP devices; fails with MVDB_ERR_NODEVICE when there is none. */
+int mvdb_device_count(int* count);
+
+/* ---- flat index --------------------------------------------------------------------------
+ * Replaces faiss.IndexFlatIP(d)                  minivectordb/vector_database.py:43, :511
+ *                                                minivectordb/sharded_vector_database.py:80, :639
+ * The corpus lives in HBM as one row-major fp32 matrix, row stride = d rounded up to a
+ * multiple of 4 floats (16-byte rows), zero padded. */
+int mvdb_index_create(int d, int metric, int device, mvdb_index** out);
+int mvdb_index_free(mvdb_index* idx);
+
+/* Drop all rows (capacity is kept). */
+int mvdb_index_reset(mvdb_index* idx);
+
+/* Rows currently stored / dimension / device ordinal. */
+int64_t mvdb_index_ntotal(const mvdb_index* idx);
+int mvdb_index_dim(const mvdb_index* idx);
+int mvdb_index_device(const mvdb_index* idx);
+
+/* Reserve device capacity for at least n rows in total (amortises repeated add). */
+int mvdb_index_reserve(mvdb_index* idx, int64_t n);
+
+/* Append n rows from host memory x[n,d] (C-contiguous fp32).  normalize != 0 L2-normalises each
+ * appended row on the device first (zero-norm rows are left untouched).
+ * Replaces faiss.normalize_L2(self.embeddings) + index.add(self.embeddings)
+ *                                                minivectordb/vector_database.py:45-46, :512
+ *                                                minivectordb/sharded_vector_database.py:82-83, :640 */
+int mvdb_index_add(mvdb_index* idx, const float* x_host, int64_t n, int normalize);
+
+/* Same, rows already in device memory (x_dev[n,d], dense, same GPU). */
+int mvdb_index_add_device(mvdb_index* idx, const float* x_dev, int64_t n, int normalize);
+
+/* Append n synthetic rows generated on the device by the counter-based generator documented in
+ * DESIGN.md (element (i,j) of the stream `seed` with i = first_row + local row); bit-identical
+ * to oracle/synth.py on the host before normalisation.  Used by bench.py and the full-size
+ * tests so that 10M x 512 corpora never cross PCIe.  No reference counterpart. */
+int mvdb_index_add_synthetic(mvdb_index* idx, int64_t n, uint64_t seed, int64_t first_row,
+                             int normalize);
+
+/* Copy rows [row0,row0+n) back to host memory out[n,d] (what faiss calls reconstruct_n);
+ * used for get_vector after the in-place normalisation side effect
+ *                                                minivectordb/vector_database.py:45, :49-55 */
+int mvdb_index_get_rows(const mvdb_index* idx, int64_t row0, int64_t n, float* out_host);
+
+/* Remove the given rows (ascending or not, duplicates rejected) and compact the matrix so the
+ * remaining rows keep their relative order — the numbering np.delete leaves behind
+ *                                                minivectordb/vector_database.py:126, :139-152 */
+int mvdb_index_remove_rows(mvdb_index* idx, const int64_t* rows_host, int64_t m);
+
+/* k nearest rows for nq queries.  q_host[nq,d], D_host[nq,k], I_host[nq,k].
+ * normalize_q != 0 L2-normalises each query on the device first.
+ * Replaces faiss.normalize_L2(embedding) + index.search(embedding, search_k)
+ *                                                minivectordb/vector_database.py:475, :497
+ *                                                minivectordb/sharded_vector_database.py:604, :626 */
+int mvdb_index_search(const mvdb_index* idx, const float* q_host, int nq, int k, int normalize_q,
+                      float* D_host, int64_t* I_host);
+
+/* Same with every buffer in device memory and the work enqueued on `stream` (a hipStream_t, or
+ * NULL for the legacy default stream); returns without synchronising.  label_offset is added to
+ * every label (global row number of this shard's first row).  This is the entry point the
+ * one-process-per-GPU sharded search uses ahead of its RCCL all-gather. */
+int mvdb_index_search_device(const mvdb_index* idx, const float* q_dev, int nq, int k,
+                             int normalize_q, int64_t label_offset, float* D_dev, int64_t* I_dev,
+                             void* stream);
+
+/* Search restricted to the m listed rows of the resident corpus (labels returned are positions
+ * in rows_host[], exactly what the reference's throw-away sub-index returns).
+ * Replaces self.embeddings[list(filtered)] -> IndexFlatIP.add -> search
+ *                                                minivectordb/vector_database.py:510-514
+ *                                                minivectordb/sharded_vector_database.py:636-642 */
+int mvdb_index_search_subset(const mvdb_index* idx, const float* q_host, int nq, int k,
+                             int normalize_q, const int64_t* rows_host, int64_t m, float* D_host,
+                             int64_t* I_host);
+
+/* Merge `nlists` sorted top-k lists per query into one [nq,k] result on the device.  List l lives
+ * at D_dev + l*list_stride_D (floats, [nq,k]) and I_dev + l*list_stride_I (int64, [nq,k]) — the
+ * layout one RCCL all-gather of each rank's packed {I,D} block produces.  Labels must already be
+ * global; lists must be ordered by ascending shard base (ties resolve to the lower label).
+ * No reference counterpart (the reference never partitions a search). */
+int mvdb_merge_topk_device(int metric, int nlists, int nq, int k, const float* D_dev,
+                           int64_t list_stride_D, const int64_t* I_dev, int64_t list_stride_I,
+                           float* D_out_dev, int64_t* I_out_dev, int device, void* stream);
+
+/* In-place row-wise L2 normalisation of host matrix x[n,d] on the device.
+ * Replaces faiss.normalize_L2                     minivectordb/vector_database.py:45, :475 */
+int mvdb_normalize_l2(float* x_host, int64_t n, int d, int device);
+
+/* Device generator of the synthetic stream into dense device memory out_dev[n,d] (queries). */
+int mvdb_synth_fill_device(float* out_dev, int64_t n, int d, uint64_t seed, int64_t first_row,
+                           int normalize, int device, void* stream);
+
+/* ---- profiling hooks (bench.py's roofline leg) ---------------------------------------------
+ * When enabled, every launch of the dominant kernels is bracketed by hipEvents on the launch
+ * stream.  mvdb_prof_read drains the finished pairs of kernel `name` ("ip_scan", "ip_scan_mfma",
+ * "encoder") and returns the number of launches and their summed duration. */
+int mvdb_prof_enable(int on);
+int mvdb_prof_read(const char* name, int64_t* launches, double* total_ms);
+
+/* ---- encoder (BERT-architecture sentence encoder: e5-small / e5-large) ---------------------
+ * Replaces self.model(**batch_dict) + average_pool + F.normalize
+ *                                                minivectordb/embedding_model.py:66-70, :50-53 */
+typedef struct mvdb_encoder_cfg {
+    int vocab_size;
+    int hidden;        /* H  */
+    int layers;        /* L  */
+    int heads;         /* nh (head_dim = H / nh) */
+    int intermediate;  /* FFN width */
+    int max_positions;
+    int type_vocab;
+    int position_offset; /* 0 for BERT; padding_idx+1 for XLM-R style position ids */
+    float ln_eps;
+} mvdb_encoder_cfg;
+
+/* Weight table: device pointers (fp32, PyTorch nn.Linear layout [out,in]) in the order given by
+ * mvdb_encoder_weight_name(i) for i in [0, mvdb_encoder_weight_count(cfg)). The encoder keeps
+ * the pointers (the caller — a torch state_dict — owns the memory). */
+int mvdb_encoder_weight_count(const mvdb_encoder_cfg* cfg);
+const char* mvdb_encoder_weight_name(const mvdb_encoder_cfg* cfg, int i);
+int mvdb_encoder_create(const mvdb_encoder_cfg* cfg, const void* const* weight_ptrs_dev, int device,
+                        mvdb_encoder** out);
+int mvdb_encoder_free(mvdb_encoder* enc);
+
+/* ids[B,S], mask[B,S] (int32, host) -> out[B,H] pooled + L2-normalised (host).
+ * compute: 0 = exact-fp32 MFMA, 1 = bf16 MFMA operands with fp32 accumulate. */
+int mvdb_encoder_forward(mvdb_encoder* enc, const int32_t* ids_host, const int32_t* mask_host,
+                         int B, int S, int compute, float* out_host);
+int mvdb_encoder_forward_device(mvdb_encoder* enc, const int32_t* ids_dev, const int32_t* mask_dev,
+                                int B, int S, int compute, float* out_dev, float* hidden_dev,
+                                void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MVDB_H */

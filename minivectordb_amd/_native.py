@@ -1,0 +1,244 @@
+"""ctypes binding of libmvdb.so (include/mvdb.h).
+
+The library is the ONLY compute back end of this package: there is no CPU fallback.  Loading
+fails loudly when the in-tree shared object is missing, and every compute entry point raises
+``RuntimeError`` when no HIP device is usable.
+
+torch is imported first on purpose: PyTorch-ROCm bundles its own HIP runtime under the SONAME
+``libamdhip64.so.7``; loading it first makes libmvdb.so bind to the same runtime instance, so
+device pointers and streams can be exchanged with torch tensors (torch is used only for device
+memory, streams and torch.distributed — never for the search arithmetic).
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libmvdb.so")
+
+METRIC_IP = 0
+METRIC_L2 = 1
+
+ERR_ARG = 1
+ERR_HIP = 2
+ERR_NODEVICE = 3
+ERR_OOM = 4
+
+_lib = None
+
+c_f32p = ctypes.POINTER(ctypes.c_float)
+c_i64p = ctypes.POINTER(ctypes.c_int64)
+c_i32p = ctypes.POINTER(ctypes.c_int32)
+c_vp = ctypes.c_void_p
+
+
+class EncoderCfg(ctypes.Structure):
+    """mirror of mvdb_encoder_cfg"""
+    _fields_ = [
+        ("vocab_size", ctypes.c_int),
+        ("hidden", ctypes.c_int),
+        ("layers", ctypes.c_int),
+        ("heads", ctypes.c_int),
+        ("intermediate", ctypes.c_int),
+        ("max_positions", ctypes.c_int),
+        ("type_vocab", ctypes.c_int),
+        ("position_offset", ctypes.c_int),
+        ("ln_eps", ctypes.c_float),
+    ]
+
+
+# name -> (restype, argtypes); the single source of truth for tests that check the export table
+PROTOTYPES = {
+    "mvdb_last_error": (ctypes.c_char_p, []),
+    "mvdb_abi_version": (ctypes.c_int, []),
+    "mvdb_device_count": (ctypes.c_int, [ctypes.POINTER(ctypes.c_int)]),
+    "mvdb_index_create": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(c_vp)]),
+    "mvdb_index_free": (ctypes.c_int, [c_vp]),
+    "mvdb_index_reset": (ctypes.c_int, [c_vp]),
+    "mvdb_index_ntotal": (ctypes.c_int64, [c_vp]),
+    "mvdb_index_dim": (ctypes.c_int, [c_vp]),
+    "mvdb_index_device": (ctypes.c_int, [c_vp]),
+    "mvdb_index_reserve": (ctypes.c_int, [c_vp, ctypes.c_int64]),
+    "mvdb_index_add": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int64, ctypes.c_int]),
+    "mvdb_index_add_device": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int64, ctypes.c_int]),
+    "mvdb_index_add_synthetic": (ctypes.c_int, [c_vp, ctypes.c_int64, ctypes.c_uint64, ctypes.c_int64, ctypes.c_int]),
+    "mvdb_index_get_rows": (ctypes.c_int, [c_vp, ctypes.c_int64, ctypes.c_int64, c_vp]),
+    "mvdb_index_remove_rows": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int64]),
+    "mvdb_index_search": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_vp, c_vp]),
+    "mvdb_index_search_device": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                ctypes.c_int64, c_vp, c_vp, c_vp]),
+    "mvdb_index_search_subset": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_vp,
+                                                ctypes.c_int64, c_vp, c_vp]),
+    "mvdb_merge_topk_device": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_vp,
+                                              ctypes.c_int64, c_vp, ctypes.c_int64, c_vp, c_vp, ctypes.c_int, c_vp]),
+    "mvdb_normalize_l2": (ctypes.c_int, [c_vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int]),
+    "mvdb_synth_fill_device": (ctypes.c_int, [c_vp, ctypes.c_int64, ctypes.c_int, ctypes.c_uint64, ctypes.c_int64,
+                                              ctypes.c_int, ctypes.c_int, c_vp]),
+    "mvdb_prof_enable": (ctypes.c_int, [ctypes.c_int]),
+    "mvdb_prof_read": (ctypes.c_int, [ctypes.c_char_p, ctypes.POINTER(ctypes.c_int64),
+                                      ctypes.POINTER(ctypes.c_double)]),
+}
+
+# encoder entry points (added to PROTOTYPES once encoder.hip is part of the build)
+ENCODER_PROTOTYPES = {
+    "mvdb_encoder_weight_count": (ctypes.c_int, [ctypes.POINTER(EncoderCfg)]),
+    "mvdb_encoder_weight_name": (ctypes.c_char_p, [ctypes.POINTER(EncoderCfg), ctypes.c_int]),
+    "mvdb_encoder_create": (ctypes.c_int, [ctypes.POINTER(EncoderCfg), ctypes.POINTER(c_vp), ctypes.c_int,
+                                           ctypes.POINTER(c_vp)]),
+    "mvdb_encoder_free": (ctypes.c_int, [c_vp]),
+    "mvdb_encoder_forward": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_vp]),
+    "mvdb_encoder_forward_device": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                   c_vp, c_vp, c_vp]),
+}
+
+
+def lib():
+    """Load libmvdb.so (once).  Raises if the in-tree build is missing — never falls back."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build the HIP library first "
+            "(python -c 'import __graft_entry__ as g; g.build()' or make -C minivectordb_amd/csrc). "
+            "minivectordb_amd has no CPU fallback.")
+    import torch  # noqa: F401  (see module docstring: binds both to one HIP runtime)
+    L = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return _lib
+
+
+def last_error():
+    msg = lib().mvdb_last_error()
+    return msg.decode("utf-8", "replace") if msg else ""
+
+
+def check(rc):
+    """Map a non-zero status to the Python exception the drop-in layer promises."""
+    if rc == 0:
+        return
+    msg = last_error()
+    if rc == ERR_ARG:
+        raise ValueError(msg)
+    if rc == ERR_OOM:
+        raise MemoryError(msg)
+    raise RuntimeError(msg)
+
+
+def device_count():
+    n = ctypes.c_int(0)
+    check(lib().mvdb_device_count(ctypes.byref(n)))
+    return n.value
+
+
+def _ptr(a):
+    return ctypes.c_void_p(a.ctypes.data)
+
+
+class FlatIndex:
+    """Thin object wrapper over mvdb_index*: the device-resident flat matrix + search."""
+
+    def __init__(self, d, metric=METRIC_IP, device=0):
+        self._h = ctypes.c_void_p()
+        self.d = int(d)
+        self.metric = metric
+        self.device = device
+        check(lib().mvdb_index_create(self.d, metric, device, ctypes.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            lib().mvdb_index_free(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        return self._h
+
+    @property
+    def ntotal(self):
+        return int(lib().mvdb_index_ntotal(self._h))
+
+    def reset(self):
+        check(lib().mvdb_index_reset(self._h))
+
+    def reserve(self, n):
+        check(lib().mvdb_index_reserve(self._h, int(n)))
+
+    def add(self, x, normalize=False):
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        if x.ndim != 2 or x.shape[1] != self.d:
+            raise ValueError(f"expected [n,{self.d}] float32, got {x.shape}")
+        check(lib().mvdb_index_add(self._h, _ptr(x), x.shape[0], int(bool(normalize))))
+
+    def add_device(self, ptr, n, normalize=False):
+        check(lib().mvdb_index_add_device(self._h, ctypes.c_void_p(ptr), int(n), int(bool(normalize))))
+
+    def add_synthetic(self, n, seed, first_row=0, normalize=True):
+        check(lib().mvdb_index_add_synthetic(self._h, int(n), int(seed), int(first_row), int(bool(normalize))))
+
+    def get_rows(self, row0, n):
+        out = np.empty((int(n), self.d), dtype=np.float32)
+        check(lib().mvdb_index_get_rows(self._h, int(row0), int(n), _ptr(out)))
+        return out
+
+    def remove_rows(self, rows):
+        rows = np.ascontiguousarray(rows, dtype=np.int64)
+        check(lib().mvdb_index_remove_rows(self._h, _ptr(rows), rows.shape[0]))
+
+    def search(self, q, k, normalize_q=False):
+        q = np.ascontiguousarray(np.atleast_2d(np.asarray(q, dtype=np.float32)))
+        if q.shape[1] != self.d:
+            raise ValueError(f"query dimension {q.shape[1]} != index dimension {self.d}")
+        nq = q.shape[0]
+        D = np.empty((nq, k), dtype=np.float32)
+        I = np.empty((nq, k), dtype=np.int64)
+        check(lib().mvdb_index_search(self._h, _ptr(q), nq, int(k), int(bool(normalize_q)), _ptr(D), _ptr(I)))
+        return D, I
+
+    def search_subset(self, q, k, rows, normalize_q=False):
+        q = np.ascontiguousarray(np.atleast_2d(np.asarray(q, dtype=np.float32)))
+        if q.shape[1] != self.d:
+            raise ValueError(f"query dimension {q.shape[1]} != index dimension {self.d}")
+        rows = np.ascontiguousarray(rows, dtype=np.int64)
+        nq = q.shape[0]
+        D = np.empty((nq, k), dtype=np.float32)
+        I = np.empty((nq, k), dtype=np.int64)
+        check(lib().mvdb_index_search_subset(self._h, _ptr(q), nq, int(k), int(bool(normalize_q)), _ptr(rows),
+                                             rows.shape[0], _ptr(D), _ptr(I)))
+        return D, I
+
+    def search_device(self, q_ptr, nq, k, D_ptr, I_ptr, stream=0, normalize_q=False, label_offset=0):
+        """All buffers are device pointers (ints); enqueues on `stream` and returns."""
+        check(lib().mvdb_index_search_device(self._h, ctypes.c_void_p(q_ptr), int(nq), int(k),
+                                             int(bool(normalize_q)), int(label_offset), ctypes.c_void_p(D_ptr),
+                                             ctypes.c_void_p(I_ptr), ctypes.c_void_p(stream)))
+
+
+def normalize_l2(x, device=0):
+    """In-place faiss.normalize_L2 equivalent on the GPU for a C-contiguous float32 [n,d] array."""
+    if not (isinstance(x, np.ndarray) and x.dtype == np.float32 and x.flags["C_CONTIGUOUS"] and x.ndim == 2):
+        raise ValueError("normalize_l2 needs a C-contiguous float32 [n,d] ndarray")
+    check(lib().mvdb_normalize_l2(_ptr(x), x.shape[0], x.shape[1], device))
+    return x
+
+
+def prof_enable(on=True):
+    check(lib().mvdb_prof_enable(int(bool(on))))
+
+
+def prof_read(name):
+    n = ctypes.c_int64(0)
+    ms = ctypes.c_double(0.0)
+    check(lib().mvdb_prof_read(name.encode(), ctypes.byref(n), ctypes.byref(ms)))
+    return n.value, ms.value

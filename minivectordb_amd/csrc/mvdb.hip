@@ -1,0 +1,880 @@
+// mvdb.hip — C-ABI (include/mvdb.h) of the flat index: host orchestration + kernel launches.
+//
+// HBM layout of an index: ONE row-major fp32 matrix X[cap, ld], ld = d rounded up to a multiple
+// of 4 floats so that every row starts on a 16-byte boundary and is read as whole dwordx4 chunks;
+// the padding is zero.  Rows [0, n) are live.  Nothing else of the corpus lives on the device
+// (ids / metadata stay in the Python host layer, as in the reference).
+#include <algorithm>
+#include <map>
+#include <shared_mutex>
+
+#include "common.hpp"
+#include "scan_kernels.hpp"
+#include "select_kernels.hpp"
+#include "util_kernels.hpp"
+
+using namespace mvdb;
+
+// ================================================================================================
+// errors / device helpers / profiling
+// ================================================================================================
+namespace mvdb {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int ensure_device(int device) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(MVDB_ERR_NODEVICE, "no HIP device available (%s); libmvdb has no CPU fallback",
+                    e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+    if (device < 0 || device >= n)
+        return fail(MVDB_ERR_ARG, "device ordinal %d out of range [0,%d)", device, n);
+    return 0;
+}
+
+int device_cus(int device) {
+    static std::mutex mu;
+    static std::map<int, int> cache;
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = cache.find(device);
+    if (it != cache.end()) return it->second;
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess ||
+        cus <= 0)
+        cus = 256;
+    cache[device] = cus;
+    return cus;
+}
+
+struct ProfPair {
+    std::string name;
+    hipEvent_t a, b;
+    bool closed;
+};
+static std::mutex g_prof_mu;
+static bool g_prof_on = false;
+static std::vector<ProfPair> g_prof;
+
+bool prof_enabled() { return g_prof_on; }
+int prof_begin(const char* name, hipStream_t stream) {
+    if (!g_prof_on) return -1;
+    ProfPair p;
+    p.name = name;
+    p.closed = false;
+    if (hipEventCreate(&p.a) != hipSuccess) return -1;
+    if (hipEventCreate(&p.b) != hipSuccess) {
+        (void)hipEventDestroy(p.a);
+        return -1;
+    }
+    (void)hipEventRecord(p.a, stream);
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof.push_back(p);
+    return (int)g_prof.size() - 1;
+}
+void prof_end(int slot, hipStream_t stream) {
+    if (slot < 0) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (slot < (int)g_prof.size()) {
+        (void)hipEventRecord(g_prof[slot].b, stream);
+        g_prof[slot].closed = true;
+    }
+}
+
+}  // namespace mvdb
+
+// ================================================================================================
+// index object
+// ================================================================================================
+namespace {
+
+struct Workspace {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    DevBuf<float> q;
+    DevBuf<uint64_t> cand;
+    DevBuf<float> D;
+    DevBuf<int64_t> I;
+    DevBuf<float> scores;
+    DevBuf<uint64_t> selkeys;
+    DevBuf<int64_t> rows;
+    SelectState* st = nullptr;
+    PinnedBuf pin;
+
+    int init(int dev, hipStream_t s) {
+        device = dev;
+        if (s) {
+            stream = s;
+            own_stream = false;
+        } else {
+            MVDB_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+            own_stream = true;
+        }
+        MVDB_HIP(hipMalloc((void**)&st, sizeof(SelectState)));
+        return 0;
+    }
+    void destroy() {
+        q.release();
+        cand.release();
+        D.release();
+        I.release();
+        scores.release();
+        selkeys.release();
+        rows.release();
+        pin.release();
+        if (st) (void)hipFree(st);
+        if (own_stream && stream) (void)hipStreamDestroy(stream);
+    }
+};
+
+}  // namespace
+
+struct mvdb_index {
+    int d = 0, d4 = 0, metric = 0, device = 0;
+    int64_t ld = 0;
+    float* X = nullptr;
+    int64_t n = 0, cap = 0;
+    mutable std::shared_mutex mu;  // search: shared; add/reset/remove/free: exclusive
+    mutable std::mutex ws_mu;
+    mutable std::vector<Workspace*> free_ws;           // synchronous searches
+    mutable std::map<void*, Workspace*> stream_ws;     // async searches, one per caller stream
+    mutable Workspace* default_stream_ws = nullptr;
+
+    Workspace* acquire() const {
+        {
+            std::lock_guard<std::mutex> lk(ws_mu);
+            if (!free_ws.empty()) {
+                Workspace* w = free_ws.back();
+                free_ws.pop_back();
+                return w;
+            }
+        }
+        Workspace* w = new Workspace();
+        if (w->init(device, nullptr)) {
+            w->destroy();
+            delete w;
+            return nullptr;
+        }
+        return w;
+    }
+    void release(Workspace* w) const {
+        std::lock_guard<std::mutex> lk(ws_mu);
+        free_ws.push_back(w);
+    }
+    Workspace* for_stream(hipStream_t s) const {
+        std::lock_guard<std::mutex> lk(ws_mu);
+        if (!s) {
+            if (!default_stream_ws) {
+                // legacy default stream: work is enqueued on stream 0 itself
+                Workspace* w = new Workspace();
+                w->device = device;
+                w->stream = nullptr;
+                w->own_stream = false;
+                if (hipMalloc((void**)&w->st, sizeof(SelectState)) != hipSuccess) {
+                    delete w;
+                    return nullptr;
+                }
+                default_stream_ws = w;
+            }
+            return default_stream_ws;
+        }
+        auto it = stream_ws.find((void*)s);
+        if (it != stream_ws.end()) return it->second;
+        Workspace* w = new Workspace();
+        if (w->init(device, s)) {
+            w->destroy();
+            delete w;
+            return nullptr;
+        }
+        stream_ws[(void*)s] = w;
+        return w;
+    }
+};
+
+namespace {
+
+// ---- shape selection: G lanes per row, C chunks per lane, U rows in flight ----------------------
+struct Shape {
+    int G, C;
+};
+Shape choose_shape(int d4) {
+    if (d4 <= 64) {
+        int G = 1;
+        while (G < d4) G <<= 1;
+        return {G, 1};
+    }
+    if (d4 % 64 == 0) return {64, d4 / 64};
+    if (d4 % 32 == 0 && d4 / 32 <= 7) return {32, d4 / 32};
+    return {64, (d4 + 63) / 64};
+}
+constexpr int kMaxC = 16;  // d <= 4096
+
+template <int G, int C, int U, int METRIC, int MODE>
+int launch_scan_inst(const ScanArgs& a, int nq, int device, hipStream_t stream, int* nblocks_out) {
+    auto kern = flat_scan_kernel<G, C, U, METRIC, MODE>;
+    static int occ = 0;  // blocks per CU this instantiation sustains
+    if (occ == 0) {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, kScanThreads, 0) != hipSuccess ||
+            nb <= 0)
+            nb = 4;
+        occ = std::min(nb, 8);
+    }
+    constexpr int RB = (kWave / G) * U;
+    const int64_t nbatches = (a.n + RB - 1) / RB;
+    int64_t want = (nbatches + kScanWaves - 1) / kScanWaves;
+    int64_t cap = (int64_t)device_cus(device) * occ;
+    int nblocks = (int)std::max<int64_t>(1, std::min(want, cap));
+    if (nblocks_out && *nblocks_out > 0) nblocks = *nblocks_out;  // caller fixed the grid
+    if (nblocks_out) *nblocks_out = nblocks;
+    const char* pname = MODE == kModeTopK ? "ip_scan" : "ip_scan_scores";
+    int slot = prof_begin(pname, stream);
+    hipLaunchKernelGGL(kern, dim3(nblocks, nq), dim3(kScanThreads), 0, stream, a);
+    prof_end(slot, stream);
+    MVDB_HIP(hipGetLastError());
+    return 0;
+}
+
+template <int G, int C, int U>
+int launch_scan_gcu(int metric, int mode, const ScanArgs& a, int nq, int device, hipStream_t s,
+                    int* nb) {
+    if (metric == MVDB_METRIC_IP) {
+        if (mode == kModeTopK) return launch_scan_inst<G, C, U, 0, kModeTopK>(a, nq, device, s, nb);
+        return launch_scan_inst<G, C, U, 0, kModeScores>(a, nq, device, s, nb);
+    }
+    if (mode == kModeTopK) return launch_scan_inst<G, C, U, 1, kModeTopK>(a, nq, device, s, nb);
+    return launch_scan_inst<G, C, U, 1, kModeScores>(a, nq, device, s, nb);
+}
+
+// Grid size the scan will use for (shape, n): needed up front to size the candidate buffer.
+int scan_grid_upper_bound(int device) { return device_cus(device) * 8; }
+
+int launch_scan(int metric, int mode, const ScanArgs& a, int nq, int device, hipStream_t s,
+                int* nblocks) {
+    const Shape sh = choose_shape(a.d4);
+#define MVDB_SCAN_CASE(G_, C_, U_) \
+    if (sh.G == G_ && sh.C == C_) return launch_scan_gcu<G_, C_, U_>(metric, mode, a, nq, device, s, nblocks);
+    MVDB_SCAN_CASE(1, 1, 8)
+    MVDB_SCAN_CASE(2, 1, 8)
+    MVDB_SCAN_CASE(4, 1, 8)
+    MVDB_SCAN_CASE(8, 1, 8)
+    MVDB_SCAN_CASE(16, 1, 8)
+    MVDB_SCAN_CASE(32, 1, 8)
+    MVDB_SCAN_CASE(32, 3, 2)
+    MVDB_SCAN_CASE(32, 5, 1)
+    MVDB_SCAN_CASE(32, 7, 1)
+    MVDB_SCAN_CASE(64, 1, 8)
+    MVDB_SCAN_CASE(64, 2, 4)
+    MVDB_SCAN_CASE(64, 3, 2)
+    MVDB_SCAN_CASE(64, 4, 2)
+    MVDB_SCAN_CASE(64, 5, 1)
+    MVDB_SCAN_CASE(64, 6, 1)
+    MVDB_SCAN_CASE(64, 7, 1)
+    MVDB_SCAN_CASE(64, 8, 1)
+    MVDB_SCAN_CASE(64, 9, 1)
+    MVDB_SCAN_CASE(64, 10, 1)
+    MVDB_SCAN_CASE(64, 11, 1)
+    MVDB_SCAN_CASE(64, 12, 1)
+    MVDB_SCAN_CASE(64, 13, 1)
+    MVDB_SCAN_CASE(64, 14, 1)
+    MVDB_SCAN_CASE(64, 15, 1)
+    MVDB_SCAN_CASE(64, 16, 1)
+#undef MVDB_SCAN_CASE
+    return fail(MVDB_ERR_ARG, "dimension with %d 16-byte chunks per row is not supported (d <= 4096)",
+                a.d4);
+}
+
+__global__ void fill_missing_kernel(float* D, int64_t* I, int64_t total, int metric) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < total) {
+        D[i] = metric == 0 ? -3.402823466e+38f : 3.402823466e+38f;
+        I[i] = -1;
+    }
+}
+
+int64_t pow2ceil(int64_t v) {
+    int64_t p = 1;
+    while (p < v) p <<= 1;
+    return p;
+}
+
+// Core: queries already on the device (padded to ld), outputs on the device.  Enqueues on ws.stream.
+int search_core(const mvdb_index* idx, Workspace* ws, const float* q_dev, int nq, int k,
+                int normalize_q, const int64_t* rows_dev, int64_t m, int64_t label_offset,
+                float* D_dev, int64_t* I_dev) {
+    hipStream_t s = ws->stream;
+    const int64_t n = rows_dev ? m : idx->n;
+    if (n == 0) {
+        const int64_t total = (int64_t)nq * k;
+        hipLaunchKernelGGL(fill_missing_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                           s, D_dev, I_dev, total, idx->metric);
+        MVDB_HIP(hipGetLastError());
+        return 0;
+    }
+    ScanArgs a;
+    a.X = idx->X;
+    a.n = n;
+    a.ld = idx->ld;
+    a.d4 = idx->d4;
+    a.q = q_dev;
+    a.normalize_q = normalize_q;
+    a.k = k;
+    a.rows = rows_dev;
+    a.cand = nullptr;
+    a.scores = nullptr;
+
+    if (k <= kMaxFusedK) {
+        MVDB_TRY(ws->cand.reserve((size_t)nq * scan_grid_upper_bound(idx->device) * k));
+        a.cand = ws->cand.p;
+        int nblocks = 0;
+        MVDB_TRY(launch_scan(idx->metric, kModeTopK, a, nq, idx->device, s, &nblocks));
+        MergeArgs ma;
+        ma.keys = ws->cand.p;
+        ma.nlists = nblocks;
+        ma.k = k;
+        ma.metric = idx->metric;
+        ma.label_offset = label_offset;
+        ma.D = D_dev;
+        ma.I = I_dev;
+        hipLaunchKernelGGL(merge_keys_kernel, dim3(nq), dim3(kScanThreads), 0, s, ma);
+        MVDB_HIP(hipGetLastError());
+        return 0;
+    }
+
+    // ---- large k: scores -> radix select -> sort -------------------------------------------------
+    MVDB_TRY(ws->scores.reserve((size_t)nq * n));
+    a.scores = ws->scores.p;
+    int nblocks = 0;
+    MVDB_TRY(launch_scan(idx->metric, kModeScores, a, nq, idx->device, s, &nblocks));
+    const int64_t k_eff = std::min<int64_t>(k, n);
+    const int64_t P = pow2ceil(std::max<int64_t>(k, 2));
+    MVDB_TRY(ws->selkeys.reserve((size_t)P));
+    const int cus = device_cus(idx->device);
+    const int sel_grid = (int)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, cus * 8));
+    for (int qi = 0; qi < nq; ++qi) {
+        const float* sc = ws->scores.p + (int64_t)qi * n;
+        hipLaunchKernelGGL(select_init_kernel, dim3(1), dim3(256), 0, s, ws->st, (uint64_t)k_eff);
+        for (int shift = 56; shift >= 0; shift -= 8) {
+            hipLaunchKernelGGL(radix_hist_kernel, dim3(sel_grid), dim3(256), 0, s, sc, n, shift,
+                               ws->st);
+            hipLaunchKernelGGL(radix_pick_kernel, dim3(1), dim3(256), 0, s, shift, ws->st);
+        }
+        hipLaunchKernelGGL(radix_compact_kernel, dim3(sel_grid), dim3(256), 0, s, sc, n, ws->st,
+                           ws->selkeys.p);
+        if (P > k_eff)
+            hipLaunchKernelGGL(zero_tail_kernel, dim3((unsigned)((P - k_eff + 255) / 256)), dim3(256),
+                               0, s, ws->selkeys.p, k_eff, P);
+        if (P <= 4096) {
+            hipLaunchKernelGGL(bitonic_sort_lds_kernel, dim3(1), dim3(1024), 0, s, ws->selkeys.p,
+                               (int)P);
+        } else {
+            for (int64_t size = 2; size <= P; size <<= 1)
+                for (int64_t stride = size >> 1; stride > 0; stride >>= 1)
+                    hipLaunchKernelGGL(bitonic_step_kernel, dim3((unsigned)((P / 2 + 255) / 256)),
+                                       dim3(256), 0, s, ws->selkeys.p, P, size, stride);
+        }
+        hipLaunchKernelGGL(emit_sorted_kernel, dim3((k + 255) / 256), dim3(256), 0, s,
+                           ws->selkeys.p, k, idx->metric, label_offset, D_dev + (int64_t)qi * k,
+                           I_dev + (int64_t)qi * k);
+        MVDB_HIP(hipGetLastError());
+    }
+    return 0;
+}
+
+// Stage host queries [nq,d] into ws->q (padded to ld) on ws->stream.
+int stage_queries(const mvdb_index* idx, Workspace* ws, const float* q_host, int nq) {
+    const size_t elems = (size_t)nq * idx->ld;
+    MVDB_TRY(ws->q.reserve(elems));
+    MVDB_TRY(ws->pin.reserve(elems * sizeof(float)));
+    float* st = (float*)ws->pin.p;
+    if (idx->ld == idx->d) {
+        memcpy(st, q_host, elems * sizeof(float));
+    } else {
+        memset(st, 0, elems * sizeof(float));
+        for (int i = 0; i < nq; ++i)
+            memcpy(st + (size_t)i * idx->ld, q_host + (size_t)i * idx->d, idx->d * sizeof(float));
+    }
+    MVDB_HIP(hipMemcpyAsync(ws->q.p, st, elems * sizeof(float), hipMemcpyHostToDevice, ws->stream));
+    return 0;
+}
+
+int check_search_args(const mvdb_index* idx, const void* q, int nq, int k, const void* D,
+                      const void* I) {
+    if (!idx) return fail(MVDB_ERR_ARG, "index is NULL");
+    if (!q || !D || !I) return fail(MVDB_ERR_ARG, "NULL buffer passed to search");
+    if (nq <= 0) return fail(MVDB_ERR_ARG, "nq must be positive (got %d)", nq);
+    if (k <= 0) return fail(MVDB_ERR_ARG, "k must be positive (got %d)", k);
+    return 0;
+}
+
+int grow(mvdb_index* idx, int64_t need) {
+    if (need <= idx->cap) return 0;
+    int64_t cap = std::max<int64_t>(need, idx->cap + idx->cap / 2);
+    cap = std::max<int64_t>(cap, 1024);
+    float* nx = nullptr;
+    MVDB_HIP(hipMalloc((void**)&nx, (size_t)cap * idx->ld * sizeof(float)));
+    if (idx->n > 0) {
+        hipError_t e = hipMemcpy(nx, idx->X, (size_t)idx->n * idx->ld * sizeof(float),
+                                 hipMemcpyDeviceToDevice);
+        if (e != hipSuccess) {
+            (void)hipFree(nx);
+            return fail(MVDB_ERR_HIP, "device copy while growing index failed: %s",
+                        hipGetErrorString(e));
+        }
+    }
+    if (idx->X) (void)hipFree(idx->X);
+    idx->X = nx;
+    idx->cap = cap;
+    return 0;
+}
+
+int normalize_range(const mvdb_index* idx, float* base, int64_t n, hipStream_t s) {
+    if (n <= 0) return 0;
+    const Shape sh = choose_shape(idx->d4);
+    const int rpi = 64 / sh.G;
+    const int64_t waves = (n + rpi - 1) / rpi;
+    const int cus = device_cus(idx->device);
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((waves + 3) / 4, (int64_t)cus * 8));
+    hipLaunchKernelGGL(normalize_rows_kernel, dim3(grid), dim3(256), 0, s, base, n, idx->ld, idx->d4,
+                       sh.G);
+    MVDB_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace
+
+// ================================================================================================
+// C ABI
+// ================================================================================================
+extern "C" {
+
+const char* mvdb_last_error(void) { return g_err; }
+int mvdb_abi_version(void) { return 1; }
+
+int mvdb_device_count(int* count) {
+    if (!count) return fail(MVDB_ERR_ARG, "count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        *count = 0;
+        return fail(MVDB_ERR_NODEVICE, "no HIP device available (%s)",
+                    e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+    }
+    *count = n;
+    return 0;
+}
+
+int mvdb_index_create(int d, int metric, int device, mvdb_index** out) {
+    if (!out) return fail(MVDB_ERR_ARG, "out is NULL");
+    *out = nullptr;
+    if (d <= 0) return fail(MVDB_ERR_ARG, "dimension must be positive (got %d)", d);
+    if (d > kMaxC * 64 * 4) return fail(MVDB_ERR_ARG, "dimension %d > 4096 is not supported", d);
+    if (metric != MVDB_METRIC_IP && metric != MVDB_METRIC_L2)
+        return fail(MVDB_ERR_ARG, "unknown metric %d", metric);
+    MVDB_TRY(ensure_device(device));
+    mvdb_index* idx = new mvdb_index();
+    idx->d = d;
+    idx->ld = ((int64_t)d + 3) / 4 * 4;
+    idx->d4 = (int)(idx->ld / 4);
+    idx->metric = metric;
+    idx->device = device;
+    *out = idx;
+    return 0;
+}
+
+int mvdb_index_free(mvdb_index* idx) {
+    if (!idx) return 0;
+    {
+        std::unique_lock<std::shared_mutex> lk(idx->mu);
+        DeviceGuard dg(idx->device);
+        (void)hipDeviceSynchronize();
+        for (Workspace* w : idx->free_ws) {
+            w->destroy();
+            delete w;
+        }
+        for (auto& kv : idx->stream_ws) {
+            kv.second->destroy();
+            delete kv.second;
+        }
+        if (idx->default_stream_ws) {
+            idx->default_stream_ws->destroy();
+            delete idx->default_stream_ws;
+        }
+        if (idx->X) (void)hipFree(idx->X);
+    }
+    delete idx;
+    return 0;
+}
+
+int mvdb_index_reset(mvdb_index* idx) {
+    if (!idx) return fail(MVDB_ERR_ARG, "index is NULL");
+    std::unique_lock<std::shared_mutex> lk(idx->mu);
+    idx->n = 0;
+    return 0;
+}
+
+int64_t mvdb_index_ntotal(const mvdb_index* idx) { return idx ? idx->n : -1; }
+int mvdb_index_dim(const mvdb_index* idx) { return idx ? idx->d : -1; }
+int mvdb_index_device(const mvdb_index* idx) { return idx ? idx->device : -1; }
+
+int mvdb_index_reserve(mvdb_index* idx, int64_t n) {
+    if (!idx) return fail(MVDB_ERR_ARG, "index is NULL");
+    if (n < 0) return fail(MVDB_ERR_ARG, "negative row count");
+    std::unique_lock<std::shared_mutex> lk(idx->mu);
+    DeviceGuard dg(idx->device);
+    if (n <= idx->cap) return 0;
+    // exact-size growth (no 1.5x slack): the caller knows the final size
+    float* nx = nullptr;
+    MVDB_HIP(hipMalloc((void**)&nx, (size_t)n * idx->ld * sizeof(float)));
+    if (idx->n > 0)
+        MVDB_HIP(hipMemcpy(nx, idx->X, (size_t)idx->n * idx->ld * sizeof(float),
+                           hipMemcpyDeviceToDevice));
+    if (idx->X) (void)hipFree(idx->X);
+    idx->X = nx;
+    idx->cap = n;
+    return 0;
+}
+
+int mvdb_index_add(mvdb_index* idx, const float* x_host, int64_t n, int normalize) {
+    if (!idx) return fail(MVDB_ERR_ARG, "index is NULL");
+    if (n < 0) return fail(MVDB_ERR_ARG, "negative row count");
+    if (n == 0) return 0;
+    if (!x_host) return fail(MVDB_ERR_ARG, "x is NULL");
+    std::unique_lock<std::shared_mutex> lk(idx->mu);
+    DeviceGuard dg(idx->device);
+    if (idx->n + n > 0xFFFFFFFFll)
+        return fail(MVDB_ERR_ARG, "more than 2^32-1 rows per device index are not supported");
+    MVDB_TRY(grow(idx, idx->n + n));
+    float* dst = idx->X + idx->n * idx->ld;
+    if (idx->ld == idx->d) {
+        MVDB_HIP(hipMemcpy(dst, x_host, (size_t)n * idx->d * sizeof(float), hipMemcpyHostToDevice));
+    } else {
+        MVDB_HIP(hipMemset(dst, 0, (size_t)n * idx->ld * sizeof(float)));
+        MVDB_HIP(hipMemcpy2D(dst, idx->ld * sizeof(float), x_host, idx->d * sizeof(float),
+                             idx->d * sizeof(float), (size_t)n, hipMemcpyHostToDevice));
+    }
+    if (normalize) {
+        MVDB_TRY(normalize_range(idx, dst, n, nullptr));
+        MVDB_HIP(hipDeviceSynchronize());
+    }
+    idx->n += n;
+    return 0;
+}
+
+int mvdb_index_add_device(mvdb_index* idx, const float* x_dev, int64_t n, int normalize) {
+    if (!idx) return fail(MVDB_ERR_ARG, "index is NULL");
+    if (n < 0) return fail(MVDB_ERR_ARG, "negative row count");
+    if (n == 0) return 0;
+    if (!x_dev) return fail(MVDB_ERR_ARG, "x is NULL");
+    std::unique_lock<std::shared_mutex> lk(idx->mu);
+    DeviceGuard dg(idx->device);
+    if (idx->n + n > 0xFFFFFFFFll)
+        return fail(MVDB_ERR_ARG, "more than 2^32-1 rows per device index are not supported");
+    MVDB_TRY(grow(idx, idx->n + n));
+    float* dst = idx->X + idx->n * idx->ld;
+    if (idx->ld == idx->d) {
+        MVDB_HIP(hipMemcpy(dst, x_dev, (size_t)n * idx->d * sizeof(float), hipMemcpyDeviceToDevice));
+    } else {
+        const int cus = device_cus(idx->device);
+        const int64_t total = n * idx->ld;
+        const int grid = (int)std::min<int64_t>((total + 255) / 256, (int64_t)cus * 16);
+        hipLaunchKernelGGL(pad_rows_kernel, dim3(grid), dim3(256), 0, nullptr, dst, x_dev, n, idx->d,
+                           idx->ld);
+        MVDB_HIP(hipGetLastError());
+    }
+    if (normalize) MVDB_TRY(normalize_range(idx, dst, n, nullptr));
+    MVDB_HIP(hipDeviceSynchronize());
+    idx->n += n;
+    return 0;
+}
+
+int mvdb_index_add_synthetic(mvdb_index* idx, int64_t n, uint64_t seed, int64_t first_row,
+                             int normalize) {
+    if (!idx) return fail(MVDB_ERR_ARG, "index is NULL");
+    if (n < 0 || first_row < 0) return fail(MVDB_ERR_ARG, "negative row count / offset");
+    if (n == 0) return 0;
+    std::unique_lock<std::shared_mutex> lk(idx->mu);
+    DeviceGuard dg(idx->device);
+    if (idx->n + n > 0xFFFFFFFFll)
+        return fail(MVDB_ERR_ARG, "more than 2^32-1 rows per device index are not supported");
+    MVDB_TRY(grow(idx, idx->n + n));
+    float* dst = idx->X + idx->n * idx->ld;
+    const int cus = device_cus(idx->device);
+    const int64_t total = n * idx->d4;
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((total + 255) / 256, (int64_t)cus * 16));
+    hipLaunchKernelGGL(synth_fill_kernel, dim3(grid), dim3(256), 0, nullptr, dst, n, idx->ld, idx->d,
+                       seed, first_row);
+    MVDB_HIP(hipGetLastError());
+    if (normalize) MVDB_TRY(normalize_range(idx, dst, n, nullptr));
+    MVDB_HIP(hipDeviceSynchronize());
+    idx->n += n;
+    return 0;
+}
+
+int mvdb_index_get_rows(const mvdb_index* idx, int64_t row0, int64_t n, float* out_host) {
+    if (!idx) return fail(MVDB_ERR_ARG, "index is NULL");
+    if (n == 0) return 0;
+    if (!out_host) return fail(MVDB_ERR_ARG, "out is NULL");
+    std::shared_lock<std::shared_mutex> lk(idx->mu);
+    if (row0 < 0 || n < 0 || row0 + n > idx->n)
+        return fail(MVDB_ERR_ARG, "rows [%lld,%lld) out of range [0,%lld)", (long long)row0,
+                    (long long)(row0 + n), (long long)idx->n);
+    DeviceGuard dg(idx->device);
+    const float* src = idx->X + row0 * idx->ld;
+    if (idx->ld == idx->d)
+        MVDB_HIP(hipMemcpy(out_host, src, (size_t)n * idx->d * sizeof(float), hipMemcpyDeviceToHost));
+    else
+        MVDB_HIP(hipMemcpy2D(out_host, idx->d * sizeof(float), src, idx->ld * sizeof(float),
+                             idx->d * sizeof(float), (size_t)n, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int mvdb_index_remove_rows(mvdb_index* idx, const int64_t* rows_host, int64_t m) {
+    if (!idx) return fail(MVDB_ERR_ARG, "index is NULL");
+    if (m < 0) return fail(MVDB_ERR_ARG, "negative row count");
+    if (m == 0) return 0;
+    if (!rows_host) return fail(MVDB_ERR_ARG, "rows is NULL");
+    std::unique_lock<std::shared_mutex> lk(idx->mu);
+    std::vector<int64_t> del(rows_host, rows_host + m);
+    std::sort(del.begin(), del.end());
+    for (int64_t i = 0; i < m; ++i) {
+        if (del[i] < 0 || del[i] >= idx->n)
+            return fail(MVDB_ERR_ARG, "row %lld out of range [0,%lld)", (long long)del[i],
+                        (long long)idx->n);
+        if (i && del[i] == del[i - 1])
+            return fail(MVDB_ERR_ARG, "row %lld listed twice", (long long)del[i]);
+    }
+    DeviceGuard dg(idx->device);
+    const int64_t n_new = idx->n - m;
+    if (n_new == 0) {
+        idx->n = 0;
+        return 0;
+    }
+    // rows before the first deleted one do not move: compact only the tail [first, n)
+    const int64_t first = del[0];
+    const int64_t tail_new = n_new - first;
+    if (tail_new > 0) {
+        int64_t *del_dev = nullptr, *map_dev = nullptr;
+        float* tmp = nullptr;
+        MVDB_HIP(hipMalloc((void**)&del_dev, (size_t)m * sizeof(int64_t)));
+        hipError_t e1 = hipMalloc((void**)&map_dev, (size_t)tail_new * sizeof(int64_t));
+        hipError_t e2 = hipMalloc((void**)&tmp, (size_t)tail_new * idx->ld * sizeof(float));
+        int rc = 0;
+        if (e1 != hipSuccess || e2 != hipSuccess) {
+            rc = fail(MVDB_ERR_OOM, "device allocation for row compaction failed");
+        } else {
+            for (auto& v : del) v -= first;  // positions relative to the tail
+            hipError_t e = hipMemcpy(del_dev, del.data(), (size_t)m * sizeof(int64_t),
+                                     hipMemcpyHostToDevice);
+            if (e == hipSuccess) {
+                hipLaunchKernelGGL(build_keep_map_kernel, dim3((unsigned)((tail_new + 255) / 256)),
+                                   dim3(256), 0, nullptr, del_dev, m, tail_new, map_dev);
+                const int64_t total = tail_new * idx->d4;
+                const int grid = (int)std::max<int64_t>(
+                    1, std::min<int64_t>((total + 255) / 256, (int64_t)device_cus(idx->device) * 16));
+                float* tail = idx->X + first * idx->ld;
+                hipLaunchKernelGGL(gather_rows_kernel, dim3(grid), dim3(256), 0, nullptr, tmp, tail,
+                                   map_dev, tail_new, idx->ld);
+                e = hipMemcpyAsync(tail, tmp, (size_t)tail_new * idx->ld * sizeof(float),
+                                   hipMemcpyDeviceToDevice, nullptr);
+                if (e == hipSuccess) e = hipDeviceSynchronize();
+            }
+            if (e != hipSuccess) rc = fail(MVDB_ERR_HIP, "row compaction failed: %s", hipGetErrorString(e));
+        }
+        if (del_dev) (void)hipFree(del_dev);
+        if (map_dev) (void)hipFree(map_dev);
+        if (tmp) (void)hipFree(tmp);
+        if (rc) return rc;
+    }
+    idx->n = n_new;
+    return 0;
+}
+
+int mvdb_index_search(const mvdb_index* idx, const float* q_host, int nq, int k, int normalize_q,
+                      float* D_host, int64_t* I_host) {
+    MVDB_TRY(check_search_args(idx, q_host, nq, k, D_host, I_host));
+    std::shared_lock<std::shared_mutex> lk(idx->mu);
+    DeviceGuard dg(idx->device);
+    Workspace* ws = idx->acquire();
+    if (!ws) return MVDB_ERR_HIP;
+    int rc = 0;
+    do {
+        if ((rc = stage_queries(idx, ws, q_host, nq))) break;
+        const size_t total = (size_t)nq * k;
+        if ((rc = ws->D.reserve(total))) break;
+        if ((rc = ws->I.reserve(total))) break;
+        if ((rc = search_core(idx, ws, ws->q.p, nq, k, normalize_q, nullptr, 0, 0, ws->D.p, ws->I.p)))
+            break;
+        hipError_t e = hipMemcpyAsync(D_host, ws->D.p, total * sizeof(float), hipMemcpyDeviceToHost,
+                                      ws->stream);
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(I_host, ws->I.p, total * sizeof(int64_t), hipMemcpyDeviceToHost,
+                               ws->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ws->stream);
+        if (e != hipSuccess) rc = fail(MVDB_ERR_HIP, "search failed: %s", hipGetErrorString(e));
+    } while (0);
+    idx->release(ws);
+    return rc;
+}
+
+int mvdb_index_search_subset(const mvdb_index* idx, const float* q_host, int nq, int k,
+                             int normalize_q, const int64_t* rows_host, int64_t m, float* D_host,
+                             int64_t* I_host) {
+    MVDB_TRY(check_search_args(idx, q_host, nq, k, D_host, I_host));
+    if (m < 0) return fail(MVDB_ERR_ARG, "negative subset size");
+    if (m > 0 && !rows_host) return fail(MVDB_ERR_ARG, "rows is NULL");
+    std::shared_lock<std::shared_mutex> lk(idx->mu);
+    for (int64_t i = 0; i < m; ++i)
+        if (rows_host[i] < 0 || rows_host[i] >= idx->n)
+            return fail(MVDB_ERR_ARG, "subset row %lld out of range [0,%lld)", (long long)rows_host[i],
+                        (long long)idx->n);
+    DeviceGuard dg(idx->device);
+    Workspace* ws = idx->acquire();
+    if (!ws) return MVDB_ERR_HIP;
+    int rc = 0;
+    do {
+        if ((rc = stage_queries(idx, ws, q_host, nq))) break;
+        const size_t total = (size_t)nq * k;
+        if ((rc = ws->D.reserve(total))) break;
+        if ((rc = ws->I.reserve(total))) break;
+        if ((rc = ws->rows.reserve((size_t)std::max<int64_t>(m, 1)))) break;
+        if (m > 0) {
+            hipError_t e = hipMemcpyAsync(ws->rows.p, rows_host, (size_t)m * sizeof(int64_t),
+                                          hipMemcpyHostToDevice, ws->stream);
+            if (e != hipSuccess) {
+                rc = fail(MVDB_ERR_HIP, "subset upload failed: %s", hipGetErrorString(e));
+                break;
+            }
+        }
+        if ((rc = search_core(idx, ws, ws->q.p, nq, k, normalize_q, ws->rows.p, m, 0, ws->D.p,
+                              ws->I.p)))
+            break;
+        hipError_t e = hipMemcpyAsync(D_host, ws->D.p, total * sizeof(float), hipMemcpyDeviceToHost,
+                                      ws->stream);
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(I_host, ws->I.p, total * sizeof(int64_t), hipMemcpyDeviceToHost,
+                               ws->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ws->stream);
+        if (e != hipSuccess) rc = fail(MVDB_ERR_HIP, "search failed: %s", hipGetErrorString(e));
+    } while (0);
+    idx->release(ws);
+    return rc;
+}
+
+int mvdb_index_search_device(const mvdb_index* idx, const float* q_dev, int nq, int k,
+                             int normalize_q, int64_t label_offset, float* D_dev, int64_t* I_dev,
+                             void* stream) {
+    MVDB_TRY(check_search_args(idx, q_dev, nq, k, D_dev, I_dev));
+    std::shared_lock<std::shared_mutex> lk(idx->mu);
+    DeviceGuard dg(idx->device);
+    Workspace* ws = idx->for_stream((hipStream_t)stream);
+    if (!ws) return fail(MVDB_ERR_HIP, "workspace allocation failed");
+    const float* q = q_dev;
+    if (idx->ld != idx->d) {  // pad the dense queries to the row stride
+        MVDB_TRY(ws->q.reserve((size_t)nq * idx->ld));
+        hipLaunchKernelGGL(pad_rows_kernel, dim3((unsigned)(((int64_t)nq * idx->ld + 255) / 256)),
+                           dim3(256), 0, ws->stream, ws->q.p, q_dev, (int64_t)nq, idx->d, idx->ld);
+        MVDB_HIP(hipGetLastError());
+        q = ws->q.p;
+    }
+    return search_core(idx, ws, q, nq, k, normalize_q, nullptr, 0, label_offset, D_dev, I_dev);
+}
+
+int mvdb_merge_topk_device(int metric, int nlists, int nq, int k, const float* D_dev,
+                           int64_t list_stride_D, const int64_t* I_dev, int64_t list_stride_I,
+                           float* D_out_dev, int64_t* I_out_dev, int device, void* stream) {
+    if (!D_dev || !I_dev || !D_out_dev || !I_out_dev) return fail(MVDB_ERR_ARG, "NULL buffer");
+    if (nlists <= 0 || nq <= 0 || k <= 0) return fail(MVDB_ERR_ARG, "non-positive size");
+    if (k > kMaxFusedK) return fail(MVDB_ERR_ARG, "merge supports k <= %d (got %d)", kMaxFusedK, k);
+    MVDB_TRY(ensure_device(device));
+    DeviceGuard dg(device);
+    MergeDIArgs a{D_dev, I_dev, list_stride_D, list_stride_I, nlists, nq, k, metric, D_out_dev, I_out_dev};
+    hipLaunchKernelGGL(merge_di_kernel, dim3(nq), dim3(kWave), 0, (hipStream_t)stream, a);
+    MVDB_HIP(hipGetLastError());
+    return 0;
+}
+
+int mvdb_normalize_l2(float* x_host, int64_t n, int d, int device) {
+    if (n < 0 || d <= 0) return fail(MVDB_ERR_ARG, "bad shape");
+    if (n == 0) return 0;
+    if (!x_host) return fail(MVDB_ERR_ARG, "x is NULL");
+    mvdb_index* tmp = nullptr;
+    MVDB_TRY(mvdb_index_create(d, MVDB_METRIC_IP, device, &tmp));
+    int rc = mvdb_index_add(tmp, x_host, n, 1);
+    if (!rc) rc = mvdb_index_get_rows(tmp, 0, n, x_host);
+    mvdb_index_free(tmp);
+    return rc;
+}
+
+int mvdb_synth_fill_device(float* out_dev, int64_t n, int d, uint64_t seed, int64_t first_row,
+                           int normalize, int device, void* stream) {
+    if (!out_dev) return fail(MVDB_ERR_ARG, "out is NULL");
+    if (n < 0 || d <= 0 || first_row < 0) return fail(MVDB_ERR_ARG, "bad shape");
+    if (d % 4) return fail(MVDB_ERR_ARG, "mvdb_synth_fill_device needs d %% 4 == 0 (dense rows)");
+    if (n == 0) return 0;
+    MVDB_TRY(ensure_device(device));
+    DeviceGuard dg(device);
+    const int cus = device_cus(device);
+    const int64_t total = n * (d / 4);
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((total + 255) / 256, (int64_t)cus * 16));
+    hipLaunchKernelGGL(synth_fill_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, out_dev, n,
+                       (int64_t)d, d, seed, first_row);
+    MVDB_HIP(hipGetLastError());
+    if (normalize) {
+        mvdb_index shape;  // only the geometry fields are read
+        shape.d = d;
+        shape.ld = d;
+        shape.d4 = d / 4;
+        shape.device = device;
+        MVDB_TRY(normalize_range(&shape, out_dev, n, (hipStream_t)stream));
+    }
+    return 0;
+}
+
+int mvdb_prof_enable(int on) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_on = on != 0;
+    return 0;
+}
+
+int mvdb_prof_read(const char* name, int64_t* launches, double* total_ms) {
+    if (!name || !launches || !total_ms) return fail(MVDB_ERR_ARG, "NULL argument");
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    int64_t cnt = 0;
+    double ms = 0.0;
+    std::vector<ProfPair> keep;
+    for (auto& p : g_prof) {
+        if (p.name != name || !p.closed) {
+            keep.push_back(p);
+            continue;
+        }
+        float t = 0.f;
+        if (hipEventSynchronize(p.b) == hipSuccess && hipEventElapsedTime(&t, p.a, p.b) == hipSuccess) {
+            ++cnt;
+            ms += t;
+        }
+        (void)hipEventDestroy(p.a);
+        (void)hipEventDestroy(p.b);
+    }
+    g_prof.swap(keep);
+    *launches = cnt;
+    *total_ms = ms;
+    return 0;
+}
+
+}  // extern "C"

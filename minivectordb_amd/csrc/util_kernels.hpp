@@ -1,0 +1,128 @@
+// util_kernels.hpp — row normalisation, synthetic corpus generator, row gather.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mvdb {
+
+typedef float f32x4u __attribute__((ext_vector_type(4)));
+
+// ---- faiss.normalize_L2 on device rows (reference: minivectordb/vector_database.py:45) --------
+// One group of G lanes (runtime power of two <= 64) per row; pass 1 sums squares, pass 2 re-reads
+// the row (L1/L2 hit: a row is <= 16 KiB) and scales it.  Zero-norm rows stay untouched, as in
+// faiss fvec_renorm_L2 (`if (nr > 0)`).  HBM-bound: 1 read + 1 write of n*ld*4 bytes.
+__global__ __launch_bounds__(256) void normalize_rows_kernel(float* __restrict__ X, int64_t n,
+                                                             int64_t ld, int d4, int G) {
+    const int lane = threadIdx.x & 63;
+    const int t = lane & (G - 1);
+    const int g = lane / G;
+    const int rpi = 64 / G;
+    const int64_t gw = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t r0 = gw * rpi; r0 < n; r0 += nw * rpi) {
+        const int64_t r = r0 + g;
+        const bool rv = r < n;
+        float* row = X + (rv ? r : n - 1) * ld;
+        float nr = 0.f;
+        for (int c = t; c < d4; c += G) {
+            const f32x4u v = *reinterpret_cast<const f32x4u*>(row + c * 4);
+            nr += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+        }
+        for (int m = G >> 1; m >= 1; m >>= 1) nr += __shfl_xor(nr, m);
+        if (rv && nr > 0.f) {
+            const float inorm = 1.0f / sqrtf(nr);
+            for (int c = t; c < d4; c += G) {
+                f32x4u v = *reinterpret_cast<const f32x4u*>(row + c * 4);
+                v *= inorm;
+                *reinterpret_cast<f32x4u*>(row + c * 4) = v;
+            }
+        }
+    }
+}
+
+// ---- synthetic stream -------------------------------------------------------------------------
+// element(seed, i, j): a counter-based hash of (seed, i*d + j) split into four 16-bit uniforms,
+// summed (Irwin-Hall, bell-shaped, zero mean) and scaled by an exact power of two.  Integer
+// arithmetic + one exact int->float conversion + one exact scaling: host (oracle/synth.py) and
+// device produce identical bits.
+__host__ __device__ inline uint32_t pcg_hash32(uint32_t v) {
+    uint32_t state = v * 747796405u + 2891336453u;
+    uint32_t word = ((state >> ((state >> 28) + 4u)) ^ state) * 277803737u;
+    return (word >> 22) ^ word;
+}
+__host__ __device__ inline float synth_element(uint32_t seed_lo, uint32_t seed_hi, uint64_t ctr) {
+    const uint32_t lo = (uint32_t)ctr, hi = (uint32_t)(ctr >> 32);
+    const uint32_t h0 = pcg_hash32(lo ^ pcg_hash32(hi ^ pcg_hash32(seed_lo ^ pcg_hash32(seed_hi))));
+    const uint32_t h1 = pcg_hash32(h0 ^ 0x9E3779B9u);
+    const int32_t sum = (int32_t)((h0 & 0xFFFFu) + (h0 >> 16) + (h1 & 0xFFFFu) + (h1 >> 16));
+    return (float)(sum - 131070) * (1.0f / 131072.0f);  // in (-1, 1), exact
+}
+
+__global__ __launch_bounds__(256) void synth_fill_kernel(float* __restrict__ X, int64_t n,
+                                                         int64_t ld, int d, uint64_t seed,
+                                                         int64_t first_row) {
+    const int64_t d4 = ld / 4;
+    const int64_t total = n * d4;
+    const uint32_t slo = (uint32_t)seed, shi = (uint32_t)(seed >> 32);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / d4;
+        const int c = (int)(i - r * d4);
+        const uint64_t base = (uint64_t)(first_row + r) * (uint64_t)d + (uint64_t)c * 4;
+        f32x4u v;
+        v.x = (c * 4 + 0 < d) ? synth_element(slo, shi, base + 0) : 0.f;
+        v.y = (c * 4 + 1 < d) ? synth_element(slo, shi, base + 1) : 0.f;
+        v.z = (c * 4 + 2 < d) ? synth_element(slo, shi, base + 2) : 0.f;
+        v.w = (c * 4 + 3 < d) ? synth_element(slo, shi, base + 3) : 0.f;
+        *reinterpret_cast<f32x4u*>(X + r * ld + c * 4) = v;
+    }
+}
+
+// dst[r, :] = src[map[r], :]  (row compaction after deletes; 16-B chunks)
+__global__ __launch_bounds__(256) void gather_rows_kernel(float* __restrict__ dst,
+                                                          const float* __restrict__ src,
+                                                          const int64_t* __restrict__ map,
+                                                          int64_t n, int64_t ld) {
+    const int64_t d4 = ld / 4;
+    const int64_t total = n * d4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / d4;
+        const int64_t c = i - r * d4;
+        *reinterpret_cast<f32x4u*>(dst + r * ld + c * 4) =
+            *reinterpret_cast<const f32x4u*>(src + map[r] * ld + c * 4);
+    }
+}
+
+// new row r keeps old row r + (number of deleted rows <= that old row); del[] ascending, unique.
+__global__ __launch_bounds__(256) void build_keep_map_kernel(const int64_t* __restrict__ del,
+                                                             int64_t m, int64_t n_new,
+                                                             int64_t* __restrict__ map) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_new) return;
+    // smallest j in [0,m] with del[j] - j > r  (del[j]-j is non-decreasing)
+    int64_t lo = 0, hi = m;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (del[mid] - mid > r)
+            hi = mid;
+        else
+            lo = mid + 1;
+    }
+    map[r] = r + lo;
+}
+
+// dense [n,d] -> padded [n,ld] copy (device to device), zero padding
+__global__ __launch_bounds__(256) void pad_rows_kernel(float* __restrict__ dst,
+                                                       const float* __restrict__ src, int64_t n,
+                                                       int d, int64_t ld) {
+    const int64_t total = n * ld;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / ld;
+        const int c = (int)(i - r * ld);
+        dst[i] = c < d ? src[r * d + c] : 0.f;
+    }
+}
+
+}  // namespace mvdb

@@ -1,0 +1,269 @@
+/*
+ * flat_oracle.c — CPU restatement of the flat inner-product search on MiniVectorDB's hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is imported, linked or executed by the product
+ * (minivectordb_amd/, libmvdb.so); only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg use it, and only as the checker / the CPU number printed beside the GPU's.
+ *
+ * PARITY UNPINNED at the faiss boundary: the reference's arithmetic for this path lives in the
+ * un-vendored, unpinned `faiss-cpu` wheel (reference requirements.txt:7), which is absent from
+ * the reference tree and from this image, and none of the reference's tests asserts a score
+ * (SURVEY.md §4, §8c).  What is restated here is faiss' published algorithm as called by the
+ * reference:
+ *   - faiss.normalize_L2 (fvec_renorm_L2): nr = sum x_j^2; if nr > 0: x *= 1/sqrtf(nr)
+ *       reference call sites: minivectordb/vector_database.py:45 (corpus, in place), :475 (query)
+ *   - faiss.IndexFlatIP.search at nq < 20 (the sequential, non-BLAS path): one
+ *     fvec_inner_product per stored row, a k-min-heap with replace-if-better, results sorted by
+ *     score descending (heap_reorder); ties resolved by the lower id (faiss' cmp2 ordering)
+ *       reference call sites: minivectordb/vector_database.py:497, :514;
+ *                             minivectordb/sharded_vector_database.py:626, :642
+ * faiss lets the compiler vectorise fvec_inner_product (summation order is build dependent); this
+ * file fixes ONE order — 8 interleaved partial sums, combined pairwise — and the float64
+ * adjudicator (oracle_flat_search_f64) classifies any id difference between two fp32
+ * implementations as a near-tie or a real error.
+ *
+ * Build: gcc -O2 -ffp-contract=off -fopenmp -shared -fPIC (see oracle/Makefile).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define ORACLE_METRIC_IP 0
+#define ORACLE_METRIC_L2 1
+
+/* ---- synthetic stream (bit-identical to minivectordb_amd/csrc/util_kernels.hpp) -------------- */
+static inline uint32_t pcg_hash32(uint32_t v) {
+    uint32_t state = v * 747796405u + 2891336453u;
+    uint32_t word = ((state >> ((state >> 28) + 4u)) ^ state) * 277803737u;
+    return (word >> 22) ^ word;
+}
+static inline float synth_element(uint32_t seed_lo, uint32_t seed_hi, uint64_t ctr) {
+    const uint32_t lo = (uint32_t)ctr, hi = (uint32_t)(ctr >> 32);
+    const uint32_t h0 = pcg_hash32(lo ^ pcg_hash32(hi ^ pcg_hash32(seed_lo ^ pcg_hash32(seed_hi))));
+    const uint32_t h1 = pcg_hash32(h0 ^ 0x9E3779B9u);
+    const int32_t sum = (int32_t)((h0 & 0xFFFFu) + (h0 >> 16) + (h1 & 0xFFFFu) + (h1 >> 16));
+    return (float)(sum - 131070) * (1.0f / 131072.0f);
+}
+void oracle_synth_fill(float* out, int64_t n, int d, uint64_t seed, int64_t first_row) {
+    const uint32_t slo = (uint32_t)seed, shi = (uint32_t)(seed >> 32);
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; ++i)
+        for (int j = 0; j < d; ++j)
+            out[i * d + j] = synth_element(slo, shi, (uint64_t)(first_row + i) * (uint64_t)d + j);
+}
+
+/* ---- fp32 kernels with a fixed summation order ---------------------------------------------- */
+static inline float dot_f32(const float* x, const float* y, int d) {
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int j = 0;
+    for (; j + 8 <= d; j += 8)
+        for (int l = 0; l < 8; ++l) acc[l] += x[j + l] * y[j + l];
+    float tail = 0.f;
+    for (; j < d; ++j) tail += x[j] * y[j];
+    const float s0 = (acc[0] + acc[4]) + (acc[2] + acc[6]);
+    const float s1 = (acc[1] + acc[5]) + (acc[3] + acc[7]);
+    return (s0 + s1) + tail;
+}
+static inline float l2sqr_f32(const float* x, const float* y, int d) {
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int j = 0;
+    for (; j + 8 <= d; j += 8)
+        for (int l = 0; l < 8; ++l) {
+            const float t = x[j + l] - y[j + l];
+            acc[l] += t * t;
+        }
+    float tail = 0.f;
+    for (; j < d; ++j) {
+        const float t = x[j] - y[j];
+        tail += t * t;
+    }
+    const float s0 = (acc[0] + acc[4]) + (acc[2] + acc[6]);
+    const float s1 = (acc[1] + acc[5]) + (acc[3] + acc[7]);
+    return (s0 + s1) + tail;
+}
+
+/* faiss fvec_renorm_L2 */
+void oracle_normalize_l2(float* x, int64_t n, int d) {
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; ++i) {
+        float* r = x + i * d;
+        const float nr = dot_f32(r, r, d);
+        if (nr > 0) {
+            const float inorm = 1.0f / sqrtf(nr);
+            for (int j = 0; j < d; ++j) r[j] *= inorm;
+        }
+    }
+}
+
+/* ---- k-heap on (score, id): "better" = higher score, then lower id ------------------------- */
+typedef struct {
+    double s; /* score as double so the same heap serves the fp64 adjudicator */
+    int64_t id;
+} item_t;
+static inline int better(item_t a, item_t b) { return a.s > b.s || (a.s == b.s && a.id < b.id); }
+/* min-heap: root = worst kept item */
+static void heap_sift_down(item_t* h, int n, int i) {
+    for (;;) {
+        int l = 2 * i + 1, r = l + 1, w = i;
+        if (l < n && better(h[w], h[l])) w = l;
+        if (r < n && better(h[w], h[r])) w = r;
+        if (w == i) return;
+        item_t t = h[i];
+        h[i] = h[w];
+        h[w] = t;
+        i = w;
+    }
+}
+static void heap_sift_up(item_t* h, int i) {
+    while (i > 0) {
+        int p = (i - 1) / 2;
+        if (!better(h[p], h[i])) return;
+        item_t t = h[i];
+        h[i] = h[p];
+        h[p] = t;
+        i = p;
+    }
+}
+static inline void heap_offer(item_t* h, int* cnt, int k, item_t it) {
+    if (it.s != it.s) return; /* NaN never enters (faiss: the comparison with the root fails) */
+    if (*cnt < k) {
+        h[*cnt] = it;
+        heap_sift_up(h, (*cnt)++);
+    } else if (better(it, h[0])) {
+        h[0] = it;
+        heap_sift_down(h, k, 0);
+    }
+}
+static int cmp_desc(const void* a, const void* b) {
+    const item_t *x = (const item_t*)a, *y = (const item_t*)b;
+    if (better(*x, *y)) return -1;
+    if (better(*y, *x)) return 1;
+    return 0;
+}
+
+static void scan_range(const float* x, int64_t r0, int64_t r1, int d, const float* q, int metric,
+                       const int64_t* rows, int f64, item_t* heap, int* cnt, int k) {
+    for (int64_t i = r0; i < r1; ++i) {
+        const float* row = x + (rows ? rows[i] : i) * (int64_t)d;
+        item_t it;
+        it.id = i;
+        if (f64) {
+            double acc = 0.0;
+            if (metric == ORACLE_METRIC_IP)
+                for (int j = 0; j < d; ++j) acc += (double)row[j] * (double)q[j];
+            else
+                for (int j = 0; j < d; ++j) {
+                    const double t = (double)q[j] - (double)row[j];
+                    acc -= t * t;
+                }
+            it.s = acc;
+        } else {
+            it.s = metric == ORACLE_METRIC_IP ? (double)dot_f32(q, row, d) : -(double)l2sqr_f32(q, row, d);
+        }
+        heap_offer(heap, cnt, k, it);
+    }
+}
+
+/*
+ * x[n_phys,d], q[nq,d]; rows (optional, length n) selects/permutes the rows that form the searched
+ * set — labels are positions in rows[], as with the reference's throw-away sub-index
+ * (vector_database.py:510-523).  normalize_q applies oracle_normalize_l2 to a copy of each query.
+ * D[nq,k] fp32 (or D64[nq,k] when f64 != 0), I[nq,k]; missing slots: -1 and -FLT_MAX / +FLT_MAX.
+ * nthreads > 1 partitions the rows over OpenMP threads (per-thread heaps, merged) — results are
+ * identical to the sequential scan because the (score,id) order is total.
+ */
+static void search_impl(const float* x, int64_t n, int d, const float* q, int nq, int k, int metric,
+                        int normalize_q, const int64_t* rows, int f64, int nthreads, float* D,
+                        double* D64, int64_t* I) {
+    if (nthreads < 1) nthreads = 1;
+    float* qn = (float*)malloc((size_t)nq * d * sizeof(float));
+    memcpy(qn, q, (size_t)nq * d * sizeof(float));
+    if (normalize_q) {
+        int saved = 1;
+#ifdef _OPENMP
+        saved = omp_get_max_threads();
+        omp_set_num_threads(1);
+#endif
+        oracle_normalize_l2(qn, nq, d);
+#ifdef _OPENMP
+        omp_set_num_threads(saved);
+#endif
+    }
+    item_t* heaps = (item_t*)malloc((size_t)nthreads * k * sizeof(item_t));
+    int* cnts = (int*)malloc((size_t)nthreads * sizeof(int));
+    for (int qi = 0; qi < nq; ++qi) {
+        const float* qq = qn + (size_t)qi * d;
+        for (int t = 0; t < nthreads; ++t) cnts[t] = 0;
+        if (nthreads == 1) {
+            scan_range(x, 0, n, d, qq, metric, rows, f64, heaps, &cnts[0], k);
+        } else {
+#pragma omp parallel for num_threads(nthreads) schedule(static, 1)
+            for (int t = 0; t < nthreads; ++t) {
+                const int64_t r0 = n * t / nthreads, r1 = n * (t + 1) / nthreads;
+                scan_range(x, r0, r1, d, qq, metric, rows, f64, heaps + (size_t)t * k, &cnts[t], k);
+            }
+            for (int t = 1; t < nthreads; ++t)
+                for (int j = 0; j < cnts[t]; ++j)
+                    heap_offer(heaps, &cnts[0], k, heaps[(size_t)t * k + j]);
+        }
+        qsort(heaps, cnts[0], sizeof(item_t), cmp_desc);
+        for (int j = 0; j < k; ++j) {
+            double s;
+            int64_t id;
+            if (j < cnts[0]) {
+                s = metric == ORACLE_METRIC_IP ? heaps[j].s : -heaps[j].s;
+                id = heaps[j].id;
+            } else {
+                s = metric == ORACLE_METRIC_IP ? -3.402823466e+38 : 3.402823466e+38;
+                id = -1;
+            }
+            if (D) D[(size_t)qi * k + j] = (float)s;
+            if (D64) D64[(size_t)qi * k + j] = s;
+            I[(size_t)qi * k + j] = id;
+        }
+    }
+    free(heaps);
+    free(cnts);
+    free(qn);
+}
+
+void oracle_flat_search(const float* x, int64_t n, int d, const float* q, int nq, int k, int metric,
+                        int normalize_q, const int64_t* rows, int nthreads, float* D, int64_t* I) {
+    search_impl(x, n, d, q, nq, k, metric, normalize_q, rows, 0, nthreads, D, NULL, I);
+}
+
+void oracle_flat_search_f64(const float* x, int64_t n, int d, const float* q, int nq, int k,
+                            int metric, int normalize_q, const int64_t* rows, int nthreads,
+                            double* D64, int64_t* I) {
+    search_impl(x, n, d, q, nq, k, metric, normalize_q, rows, 1, nthreads, NULL, D64, I);
+}
+
+/* float64 scores of listed rows against ONE (already prepared) query: out[m] */
+void oracle_scores_f64(const float* x, int d, const float* q, int metric, const int64_t* rows,
+                       int64_t m, double* out) {
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < m; ++i) {
+        const float* row = x + rows[i] * (int64_t)d;
+        double acc = 0.0;
+        if (metric == ORACLE_METRIC_IP)
+            for (int j = 0; j < d; ++j) acc += (double)row[j] * (double)q[j];
+        else
+            for (int j = 0; j < d; ++j) {
+                const double t = (double)q[j] - (double)row[j];
+                acc += t * t;
+            }
+        out[i] = acc;
+    }
+}
+
+int oracle_max_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}

@@ -1,0 +1,298 @@
+"""GPU parity tests of the flat index (libmvdb.so through the C-ABI) against the CPU oracle.
+
+Bar (BASELINE.json north_star): identical top-k ids (id differences only at float64-adjudicated
+near-ties) and distances within 1e-4 (fp32) of the float64 score.
+"""
+import numpy as np
+import pytest
+
+from oracle import flat
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def native(gpu):
+    from minivectordb_amd import _native
+    assert _native.device_count() >= 1
+    return _native
+
+
+def _corpus(n, d, seed=1234, normalize=True):
+    x = flat.synth(n, d, seed)
+    if normalize:
+        flat.normalize_l2(x)
+    return x
+
+
+def _check(native, x, q, k, D, I, metric=flat.METRIC_IP, rows=None, exact_vs_oracle=True):
+    """Every query: float64 adjudication; and (when asked) id-for-id equality with the fp32 oracle
+    wherever the oracle itself agrees with float64 (i.e. away from fp32 near-ties)."""
+    Do, Io = flat.flat_search(x, q, k, metric=metric, rows=rows)
+    mism = 0
+    for i in range(q.shape[0]):
+        ok, msg = flat.adjudicate(x, q[i], k, D[i], I[i], metric=metric, rows=rows, tol=TOL)
+        assert ok, f"query {i}: {msg}"
+        if not np.array_equal(I[i], Io[i]):
+            mism += 1
+    if exact_vs_oracle:
+        # near-ties are rare on this data: allow none at small n
+        assert mism == 0, f"{mism} queries differ from the fp32 oracle in id order"
+    np.testing.assert_allclose(D[I >= 0], Do[Io >= 0], atol=TOL, rtol=0)
+
+
+def test_synth_generator_bit_exact(native):
+    for n, d, seed, first in [(1000, 512, 1234, 0), (257, 100, 99, 12345), (64, 3, 7, 1 << 33)]:
+        idx = native.FlatIndex(d)
+        idx.add_synthetic(n, seed, first_row=first, normalize=False)
+        got = idx.get_rows(0, n)
+        want = flat.synth(n, d, seed, first)
+        assert got.tobytes() == want.tobytes()
+        idx.close()
+
+
+def test_normalize_matches_oracle(native):
+    for n, d in [(1000, 512), (333, 384), (100, 3), (50, 1000)]:
+        x = flat.synth(n, d, 42)
+        x[n // 2] = 0.0  # zero row must stay zero (faiss: `if nr > 0`)
+        want = x.copy()
+        flat.normalize_l2(want)
+        got = x.copy()
+        native.normalize_l2(got)
+        np.testing.assert_allclose(got, want, atol=2e-7, rtol=0)
+        assert not got[n // 2].any()
+        np.testing.assert_allclose(np.linalg.norm(np.delete(got, n // 2, 0).astype(np.float64), axis=1), 1.0,
+                                   atol=1e-6)
+
+
+@pytest.mark.parametrize("n,d,k,nq", [
+    (1000, 512, 5, 8),      # BASELINE config 1
+    (20000, 384, 10, 4),    # e5-small width
+    (5000, 64, 10, 4),      # reference multithread test width
+    (8536, 512, 64, 2),     # largest fused k
+    (3000, 1024, 10, 2),    # e5-large / bge-m3 width
+    (777, 100, 7, 3),       # d % 64 != 0 (masked lanes)
+    (500, 3, 4, 3),         # padded rows (d % 4 != 0)
+    (500, 2, 3, 3),
+    (100, 1, 3, 2),
+    (4000, 768, 10, 2),
+    (2000, 160, 10, 2),     # G=32, C=5
+    (1000, 1100, 5, 2),     # C=5 masked
+    (300, 4096, 5, 1),      # max supported d
+])
+def test_search_matches_oracle(native, n, d, k, nq):
+    x = _corpus(n, d)
+    q = _corpus(nq, d, seed=5678)
+    idx = native.FlatIndex(d)
+    idx.add(x)
+    D, I = idx.search(q, k)
+    _check(native, x, q, k, D, I)
+    idx.close()
+
+
+def test_query_normalisation_fused(native):
+    x = _corpus(5000, 512)
+    q = flat.synth(4, 512, 5678) * 3.7  # un-normalised queries
+    idx = native.FlatIndex(512)
+    idx.add(x)
+    D, I = idx.search(q, 10, normalize_q=True)
+    qn = q.copy()
+    flat.normalize_l2(qn)
+    _check(native, x, qn, 10, D, I)
+    # zero query: normalisation leaves it alone, all scores are 0 -> ties broken by row number
+    D0, I0 = idx.search(np.zeros((1, 512), np.float32), 5, normalize_q=True)
+    assert I0[0].tolist() == [0, 1, 2, 3, 4] and not D0.any()
+    idx.close()
+
+
+def test_add_normalizes_on_device(native):
+    x = flat.synth(4000, 384, 1)
+    idx = native.FlatIndex(384)
+    idx.add(x[:1000], normalize=True)
+    idx.add(x[1000:], normalize=True)  # appended in two pieces
+    stored = idx.get_rows(0, 4000)
+    want = x.copy()
+    flat.normalize_l2(want)
+    np.testing.assert_allclose(stored, want, atol=2e-7, rtol=0)
+    q = _corpus(3, 384, seed=2)
+    D, I = idx.search(q, 10)
+    _check(native, stored, q, 10, D, I)
+    idx.close()
+
+
+@pytest.mark.parametrize("k", [65, 100, 825, 999, 5000])
+def test_large_k_select_path(native, k):
+    n = 8536 if k < 5000 else 6000
+    x = _corpus(n, 128)
+    q = _corpus(2, 128, seed=5678)
+    idx = native.FlatIndex(128)
+    idx.add(x)
+    D, I = idx.search(q, k)
+    keff = min(k, n)
+    Do, Io = flat.flat_search(x, q, k)
+    assert (I[:, keff:] == -1).all()
+    assert (I[:, :keff] >= 0).all()
+    # full-length lists: compare as sets + scores, then exact order away from ties
+    for i in range(2):
+        assert set(I[i, :keff].tolist()) == set(Io[i, :keff].tolist())
+        np.testing.assert_allclose(D[i, :keff], Do[i, :keff], atol=TOL, rtol=0)
+        assert np.all(np.diff(D[i, :keff]) <= 0)
+    idx.close()
+
+
+def test_k_larger_than_n_pads_like_faiss(native):
+    x = _corpus(7, 16)
+    idx = native.FlatIndex(16)
+    idx.add(x)
+    for k in (10, 100):
+        D, I = idx.search(x[:1], k)
+        assert sorted(I[0, :7].tolist()) == list(range(7))
+        assert (I[0, 7:] == -1).all()
+        assert np.all(D[0, 7:] == np.float32(-3.4028234663852886e38))
+    idx.close()
+
+
+def test_empty_index(native):
+    idx = native.FlatIndex(8)
+    D, I = idx.search(np.ones((2, 8), np.float32), 3)
+    assert (I == -1).all()
+    idx.close()
+
+
+def test_ties_resolve_to_lower_row(native):
+    # colinear rows (the reference tests use [0.5,0.5], [0.1,0.1], [0.7,0.7]): exact score ties
+    base = np.array([[0.5, 0.5], [0.1, 0.1], [0.7, 0.7], [0.5, -0.5], [0.2, 0.2]], np.float32)
+    x = np.tile(base, (40, 1))
+    idx = native.FlatIndex(2)
+    idx.add(x, normalize=True)
+    D, I = idx.search(np.array([[1.0, 1.0]], np.float32), 10, normalize_q=True)
+    stored = idx.get_rows(0, x.shape[0])
+    qn = np.array([[1.0, 1.0]], np.float32)
+    flat.normalize_l2(qn)
+    Do, Io = flat.flat_search(stored, qn, 10)
+    assert I[0].tolist() == Io[0].tolist()
+    np.testing.assert_allclose(D, Do, atol=1e-6)
+    # all-equal corpus, k spanning both selection paths
+    ones = np.ones((3000, 8), np.float32)
+    idx2 = native.FlatIndex(8)
+    idx2.add(ones)
+    for k in (1, 10, 64, 65, 300):
+        D, I = idx2.search(np.ones((1, 8), np.float32), k)
+        assert I[0].tolist() == list(range(k))
+    idx.close()
+    idx2.close()
+
+
+def test_subset_search(native):
+    n, d = 6000, 256
+    x = _corpus(n, d)
+    q = _corpus(3, d, seed=5678)
+    idx = native.FlatIndex(d)
+    idx.add(x)
+    rng = np.random.RandomState(0)
+    for m, k in [(1, 1), (17, 5), (2500, 10), (2500, 100), (6000, 10)]:
+        rows = rng.permutation(n)[:m].astype(np.int64)
+        D, I = idx.search_subset(q, k, rows)
+        keff = min(k, m)
+        assert (I[:, :keff] >= 0).all() and (I[:, :keff] < m).all()
+        _check(native, x, q, k, D, I, rows=rows)
+    with pytest.raises(ValueError):
+        idx.search_subset(q, 3, np.array([n], np.int64))
+    idx.close()
+
+
+def test_l2_metric_extension(native):
+    n, d = 4000, 96
+    x = flat.synth(n, d, 11)
+    q = flat.synth(3, d, 12)
+    idx = native.FlatIndex(d, metric=native.METRIC_L2)
+    idx.add(x)
+    for k in (1, 10, 100):
+        D, I = idx.search(q, k)
+        _check(native, x, q, k, D, I, metric=flat.METRIC_L2)
+        assert np.all(np.diff(D, axis=1) >= 0)
+    idx.close()
+
+
+def test_remove_rows_matches_np_delete(native):
+    n, d = 3000, 64
+    x = _corpus(n, d)
+    idx = native.FlatIndex(d)
+    idx.add(x)
+    rng = np.random.RandomState(1)
+    cur = x
+    for dels in ([5], [0], [cur.shape[0] - 3], rng.permutation(2900)[:400].tolist()):
+        idx.remove_rows(np.array(dels, np.int64))
+        cur = np.delete(cur, dels, 0)
+        assert idx.ntotal == cur.shape[0]
+        assert idx.get_rows(0, idx.ntotal).tobytes() == cur.tobytes()
+    q = _corpus(2, d, seed=3)
+    D, I = idx.search(q, 10)
+    _check(native, cur, q, 10, D, I)
+    with pytest.raises(ValueError):
+        idx.remove_rows(np.array([1, 1], np.int64))
+    idx.close()
+
+
+def test_argument_errors(native):
+    with pytest.raises(ValueError):
+        native.FlatIndex(0)
+    with pytest.raises(ValueError):
+        native.FlatIndex(5000)
+    idx = native.FlatIndex(4)
+    with pytest.raises(ValueError):
+        idx.search(np.ones((1, 4), np.float32), 0)
+    with pytest.raises(ValueError):
+        idx.search(np.ones((1, 5), np.float32), 1)
+    with pytest.raises(ValueError):
+        idx.get_rows(0, 1)
+    idx.close()
+
+
+def test_concurrent_searches_are_reentrant(native):
+    import threading
+    x = _corpus(20000, 128)
+    q = _corpus(16, 128, seed=9)
+    idx = native.FlatIndex(128)
+    idx.add(x)
+    D0, I0 = idx.search(q, 10)
+    errs = []
+
+    def worker(i):
+        try:
+            for _ in range(20):
+                D, I = idx.search(q[i:i + 1], 10)
+                assert np.array_equal(I[0], I0[i]) and np.array_equal(D[0], D0[i])
+        except Exception as e:  # pragma: no cover
+            errs.append(e)
+
+    ts = [threading.Thread(target=worker, args=(i,)) for i in range(16)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs, errs
+    idx.close()
+
+
+def test_config2_1M_x_512(native):
+    """BASELINE config 2: 1M x 512 fp32, k = 10 — corpus generated on the device, fetched once for
+    the oracle (2 GB)."""
+    n, d, k = 1_000_000, 512, 10
+    idx = native.FlatIndex(d)
+    idx.reserve(n)
+    idx.add_synthetic(n, 1234, normalize=True)
+    x = idx.get_rows(0, n)
+    q = _corpus(8, d, seed=5678)
+    D, I = idx.search(q, k)
+    Do, Io = flat.flat_search(x, q, k, nthreads=flat.max_threads())
+    np.testing.assert_allclose(D, Do, atol=TOL, rtol=0)
+    for i in range(q.shape[0]):
+        if not np.array_equal(I[i], Io[i]):
+            ok, msg = flat.adjudicate(x, q[i], k, D[i], I[i], tol=TOL)
+            assert ok, msg
+    # stored rows are what the oracle's generator + normalise produce
+    want = flat.synth(4096, d, 1234, 500_000)
+    flat.normalize_l2(want)
+    np.testing.assert_allclose(x[500_000:504_096], want, atol=2e-7, rtol=0)
+    idx.close()
