@@ -78,10 +78,7 @@ PROTOTYPES = {
     "mvdb_prof_enable": (ctypes.c_int, [ctypes.c_int]),
     "mvdb_prof_read": (ctypes.c_int, [ctypes.c_char_p, ctypes.POINTER(ctypes.c_int64),
                                       ctypes.POINTER(ctypes.c_double)]),
-}
-
-# encoder entry points (added to PROTOTYPES once encoder.hip is part of the build)
-ENCODER_PROTOTYPES = {
+    # encoder (encoder.hip)
     "mvdb_encoder_weight_count": (ctypes.c_int, [ctypes.POINTER(EncoderCfg)]),
     "mvdb_encoder_weight_name": (ctypes.c_char_p, [ctypes.POINTER(EncoderCfg), ctypes.c_int]),
     "mvdb_encoder_create": (ctypes.c_int, [ctypes.POINTER(EncoderCfg), ctypes.POINTER(c_vp), ctypes.c_int,

@@ -1,0 +1,738 @@
+// encoder.hip — BERT-architecture sentence encoder forward (multilingual-e5-small/large shape) +
+// masked mean pool + L2 normalise, hand-written for gfx950.
+//
+// Replaces, on MiniVectorDB's embed path (reference minivectordb/embedding_model.py):
+//   outputs = self.model(**batch_dict)                      :66   (HF BertModel / XLMRobertaModel)
+//   average_pool(last_hidden_state, attention_mask)         :50-53, :67
+//   F.normalize(embeddings, p=2, dim=1)                     :70
+// Op order follows transformers' modeling_bert.py (embeddings+LN; per layer QKV, scaled softmax
+// attention with key mask, out-proj + residual + LN, FFN1 + erf-GELU, FFN2 + residual + LN).
+//
+// MI355X design
+//   * varlen packing: only VALID tokens are materialised (T = sum of sequence lengths); padded
+//     positions cost nothing in the GEMMs and need no mask in attention (keys of a sequence are
+//     all valid).  Packing (counts, prefix sums, gather map) is computed on the device, so the
+//     whole forward is enqueued without a host round trip; grids are sized for B*S and tiles
+//     beyond T exit early.
+//   * GEMMs on the exact-fp32 matrix cores: v_mfma_f32_32x32x2_f32, 128x128x16 block tile, 4 waves
+//     (2x2) x (2x2) 32x32 tiles per wave, LDS tiles stored k-major so every ds_read_b32 of a
+//     fragment is conflict-free, register-staged global->LDS double buffering (T14 split).
+//     Results are bit-for-bit an fp32 fmaf chain in k order (parity with the reference's fp32).
+//   * Q/K/V projections fused into one [3H,H] GEMM (weights concatenated once at create time).
+//   * bias / erf-GELU / residual fused into the GEMM epilogue; LayerNorm and pooling are
+//     one-wave-per-row kernels (HBM/L2-bound, tiny).
+#include <cmath>
+
+#include "common.hpp"
+
+using namespace mvdb;
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// =================================================================================================
+// packing
+// =================================================================================================
+// one wave per sequence: rank of every valid token inside its sequence, and the count
+__global__ __launch_bounds__(64) void seq_rank_kernel(const int32_t* __restrict__ mask, int S,
+                                                      int* __restrict__ rank, int* __restrict__ count) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    int base = 0;
+    for (int t0 = 0; t0 < S; t0 += 64) {
+        const int t = t0 + lane;
+        const bool v = t < S && mask[(int64_t)b * S + t] != 0;
+        const unsigned long long m = __ballot(v);
+        const int r = base + __popcll(m & ((1ull << lane) - 1ull));
+        if (t < S) rank[(int64_t)b * S + t] = v ? r : -1;
+        base += __popcll(m);
+    }
+    if (lane == 0) count[b] = base;
+}
+
+// single block: exclusive scan of count[B] -> seq_start[B+1]
+__global__ __launch_bounds__(256) void seq_scan_kernel(const int* __restrict__ count, int B,
+                                                       int* __restrict__ seq_start) {
+    __shared__ int part[256];
+    const int tid = threadIdx.x;
+    const int per = (B + 255) / 256;
+    const int lo = tid * per, hi = min(B, lo + per);
+    int s = 0;
+    for (int i = lo; i < hi; ++i) s += count[i];
+    part[tid] = s;
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        for (int i = 0; i < 256; ++i) {
+            const int v = part[i];
+            part[i] = run;
+            run += v;
+        }
+        seq_start[B] = run;
+    }
+    __syncthreads();
+    int run = part[tid];
+    for (int i = lo; i < hi; ++i) {
+        seq_start[i] = run;
+        run += count[i];
+    }
+}
+
+// packed token p of sequence b: source id, position id, owning sequence
+__global__ __launch_bounds__(256) void pack_fill_kernel(const int32_t* __restrict__ ids,
+                                                        const int* __restrict__ rank,
+                                                        const int* __restrict__ seq_start, int S,
+                                                        int position_offset, int vocab,
+                                                        int* __restrict__ tok_id,
+                                                        int* __restrict__ tok_pos, int* __restrict__ tok_src) {
+    const int b = blockIdx.x;
+    const int s0 = seq_start[b];
+    for (int t = threadIdx.x; t < S; t += blockDim.x) {
+        const int r = rank[(int64_t)b * S + t];
+        if (r >= 0) {
+            const int p = s0 + r;
+            const int id = ids[(int64_t)b * S + t];
+            tok_id[p] = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);  // never read outside the table
+            // BERT: absolute position t.  XLM-R (position_offset = padding_idx + 1 > 0):
+            // cumsum(mask) + padding_idx = (r + 1) + (position_offset - 1)
+            tok_pos[p] = position_offset > 0 ? r + position_offset : t;
+            tok_src[p] = b * S + t;
+        }
+    }
+}
+
+// =================================================================================================
+// row kernels: one wave per token row, VPT = ceil(H/64) values per lane in registers
+// =================================================================================================
+template <int VPT>
+__device__ __forceinline__ void wave_layernorm(float (&v)[VPT], int H, int lane, float eps,
+                                               const float* __restrict__ gamma,
+                                               const float* __restrict__ beta, float* __restrict__ out) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) s += (lane + i * 64 < H) ? v[i] : 0.f;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
+    const float mean = s / (float)H;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+        const float dlt = (lane + i * 64 < H) ? v[i] - mean : 0.f;
+        q += dlt * dlt;
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) q += __shfl_xor(q, m);
+    const float rstd = 1.0f / sqrtf(q / (float)H + eps);  // biased variance, eps inside the sqrt
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+        const int c = lane + i * 64;
+        if (c < H) out[c] = (v[i] - mean) * rstd * gamma[c] + beta[c];
+    }
+}
+
+// x[p,:] = LN(word[id] + pos[pos_id] + type[0])
+template <int VPT>
+__global__ __launch_bounds__(256) void embed_ln_kernel(const int* __restrict__ tok_id,
+                                                       const int* __restrict__ tok_pos,
+                                                       const int* __restrict__ seq_start, int B,
+                                                       const float* __restrict__ word,
+                                                       const float* __restrict__ pos,
+                                                       const float* __restrict__ type,
+                                                       const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, float eps, int H,
+                                                       float* __restrict__ x) {
+    const int T = seq_start[B];
+    const int lane = threadIdx.x & 63;
+    const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (p >= T) return;
+    const float* w = word + (int64_t)tok_id[p] * H;
+    const float* ps = pos + (int64_t)tok_pos[p] * H;
+    float v[VPT];
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+        const int c = lane + i * 64;
+        v[i] = c < H ? (w[c] + type[c]) + ps[c] : 0.f;  // HF: inputs_embeds + token_type, then + position
+    }
+    wave_layernorm<VPT>(v, H, lane, eps, gamma, beta, x + (int64_t)p * H);
+}
+
+// x[p,:] = LN(y[p,:])   (y already holds dense(...) + bias + residual from the GEMM epilogue)
+template <int VPT>
+__global__ __launch_bounds__(256) void ln_kernel(const float* __restrict__ y,
+                                                 const int* __restrict__ seq_start, int B,
+                                                 const float* __restrict__ gamma,
+                                                 const float* __restrict__ beta, float eps, int H,
+                                                 float* __restrict__ x) {
+    const int T = seq_start[B];
+    const int lane = threadIdx.x & 63;
+    const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (p >= T) return;
+    float v[VPT];
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+        const int c = lane + i * 64;
+        v[i] = c < H ? y[(int64_t)p * H + c] : 0.f;
+    }
+    wave_layernorm<VPT>(v, H, lane, eps, gamma, beta, x + (int64_t)p * H);
+}
+
+// out[b,:] = normalize(mean over the sequence's tokens)   — average_pool + F.normalize(eps=1e-12)
+__global__ __launch_bounds__(256) void pool_norm_kernel(const float* __restrict__ x,
+                                                        const int* __restrict__ seq_start, int H,
+                                                        float* __restrict__ out) {
+    __shared__ float red[256];
+    const int b = blockIdx.x;
+    const int s0 = seq_start[b], len = seq_start[b + 1] - s0;
+    float sq = 0.f;
+    for (int c = threadIdx.x; c < H; c += blockDim.x) {
+        float s = 0.f;
+        for (int t = 0; t < len; ++t) s += x[(int64_t)(s0 + t) * H + c];
+        const float e = s / (float)len;  // len == 0 -> NaN, as the reference's 0/0
+        out[(int64_t)b * H + c] = e;
+        sq += e * e;
+    }
+    red[threadIdx.x] = sq;
+    __syncthreads();
+    for (int m = 128; m >= 1; m >>= 1) {
+        if ((int)threadIdx.x < m) red[threadIdx.x] += red[threadIdx.x + m];
+        __syncthreads();
+    }
+    const float denom = fmaxf(sqrtf(red[0]), 1e-12f);
+    for (int c = threadIdx.x; c < H; c += blockDim.x) out[(int64_t)b * H + c] /= denom;
+}
+
+// hidden[b,t,:] = x[packed(b,t),:] for valid tokens, 0 for padding
+__global__ __launch_bounds__(256) void unpack_hidden_kernel(const float* __restrict__ x,
+                                                            const int* __restrict__ rank,
+                                                            const int* __restrict__ seq_start, int S,
+                                                            int H, float* __restrict__ hidden) {
+    const int bt = blockIdx.x;
+    const int b = bt / S;
+    const int r = rank[bt];
+    const float* src = r >= 0 ? x + (int64_t)(seq_start[b] + r) * H : nullptr;
+    for (int c = threadIdx.x; c < H; c += blockDim.x) hidden[(int64_t)bt * H + c] = src ? src[c] : 0.f;
+}
+
+// =================================================================================================
+// GEMM  C[T,N] = A[T,K] · W[N,K]^T + bias (+ epilogue), exact fp32 on v_mfma_f32_32x32x2_f32
+// =================================================================================================
+enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_RESIDUAL = 2 };
+
+constexpr int GBM = 128, GBN = 128, GBK = 16, GLD = 132;  // LDS row stride (floats): 128 + 4 pad
+
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(const float* __restrict__ A,
+                                                            const float* __restrict__ W,
+                                                            const float* __restrict__ bias,
+                                                            const float* __restrict__ R,
+                                                            float* __restrict__ C,
+                                                            const int* __restrict__ Tptr, int N, int K) {
+    const int T = *Tptr;
+    const int m0 = blockIdx.y * GBM;
+    if (m0 >= T) return;
+    const int n0 = blockIdx.x * GBN;
+    __shared__ float lds[2 * 2 * GBK * GLD];  // [buf][A|B][k][row]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // global -> register staging: thread owns rows r and r+64 of each tile, 4 consecutive k
+    const int lr = tid >> 2, lk = (tid & 3) * 4;
+    const float* a_ptr[2];
+    const float* w_ptr[2];
+    bool a_ok[2], w_ok[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int ra = m0 + lr + i * 64, rw = n0 + lr + i * 64;
+        a_ok[i] = ra < T;
+        w_ok[i] = rw < N;
+        a_ptr[i] = A + (int64_t)(a_ok[i] ? ra : 0) * K + lk;
+        w_ptr[i] = W + (int64_t)(w_ok[i] ? rw : 0) * K + lk;
+    }
+    f32x4 ra[2], rw[2];
+    auto stage_load = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            ra[i] = a_ok[i] ? *reinterpret_cast<const f32x4*>(a_ptr[i] + k0) : f32x4{0, 0, 0, 0};
+            rw[i] = w_ok[i] ? *reinterpret_cast<const f32x4*>(w_ptr[i] + k0) : f32x4{0, 0, 0, 0};
+        }
+    };
+    auto stage_write = [&](int buf) {
+        float* As = lds + buf * (2 * GBK * GLD);
+        float* Bs = As + GBK * GLD;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int r = lr + i * 64;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                As[(lk + j) * GLD + r] = ra[i][j];
+                Bs[(lk + j) * GLD + r] = rw[i][j];
+            }
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = K / GBK;
+    stage_load(0);
+    stage_write(0);
+    __syncthreads();
+    const int fr = lane & 31, fk = lane >> 5;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) stage_load((kt + 1) * GBK);  // in flight during the MFMAs below
+        const float* As = lds + buf * (2 * GBK * GLD);
+        const float* Bs = As + GBK * GLD;
+#pragma unroll
+        for (int kk = 0; kk < GBK; kk += 2) {
+            const float a0 = As[(kk + fk) * GLD + wm * 64 + fr];
+            const float a1 = As[(kk + fk) * GLD + wm * 64 + 32 + fr];
+            const float b0 = Bs[(kk + fk) * GLD + wn * 64 + fr];
+            const float b1 = Bs[(kk + fk) * GLD + wn * 64 + 32 + fr];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (kt + 1 < nk) {
+            stage_write(buf ^ 1);  // the other buffer: last read two iterations ago
+            __syncthreads();
+        }
+    }
+
+    // epilogue.  C/D map of 32x32: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wn * 64 + j * 32 + fr;
+            if (col >= N) continue;
+            const float bv = bias[col];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
+                if (row < T) {
+                    float v = acc[i][j][r] + bv;
+                    if (EPI == EPI_BIAS_GELU) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+                    if (EPI == EPI_BIAS_RESIDUAL) v += R[(int64_t)row * N + col];
+                    C[(int64_t)row * N + col] = v;
+                }
+            }
+        }
+}
+
+// =================================================================================================
+// attention: one thread per query row, K/V tiles broadcast from LDS, chunked online softmax (fp32)
+// =================================================================================================
+constexpr int ATT_Q = 128;  // queries per block
+constexpr int ATT_KT = 64;  // keys per LDS tile
+constexpr int ATT_CH = 8;   // keys per softmax chunk
+
+template <int HD>
+__global__ __launch_bounds__(ATT_Q) void attention_kernel(const float* __restrict__ qkv,
+                                                          const int* __restrict__ seq_start, int H,
+                                                          float scale, float* __restrict__ ctx) {
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int s0 = seq_start[b], len = seq_start[b + 1] - s0;
+    const int q0 = blockIdx.x * ATT_Q;
+    if (q0 >= len) return;
+    __shared__ float Ks[ATT_KT * HD];
+    __shared__ float Vs[ATT_KT * HD];
+    const int qi = q0 + threadIdx.x;
+    const bool active = qi < len;
+    const int64_t ld = 3 * (int64_t)H;
+    float q[HD], o[HD];
+    {
+        const float* qp = qkv + (int64_t)(s0 + (active ? qi : 0)) * ld + h * HD;
+#pragma unroll
+        for (int c = 0; c < HD; c += 4) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(qp + c);
+            q[c] = v.x; q[c + 1] = v.y; q[c + 2] = v.z; q[c + 3] = v.w;
+        }
+#pragma unroll
+        for (int c = 0; c < HD; ++c) o[c] = 0.f;
+    }
+    float m = -INFINITY, l = 0.f;
+    for (int kt = 0; kt < len; kt += ATT_KT) {
+        const int nk = min(ATT_KT, len - kt);
+        __syncthreads();
+        for (int i = threadIdx.x; i < ATT_KT * (HD / 4); i += ATT_Q) {
+            const int j = i / (HD / 4), c = (i % (HD / 4)) * 4;
+            f32x4 kv = {0, 0, 0, 0}, vv = {0, 0, 0, 0};
+            if (j < nk) {
+                const float* base = qkv + (int64_t)(s0 + kt + j) * ld + h * HD + c;
+                kv = *reinterpret_cast<const f32x4*>(base + H);
+                vv = *reinterpret_cast<const f32x4*>(base + 2 * H);
+            }
+            *reinterpret_cast<f32x4*>(&Ks[j * HD + c]) = kv;
+            *reinterpret_cast<f32x4*>(&Vs[j * HD + c]) = vv;
+        }
+        __syncthreads();
+        for (int j0 = 0; j0 < nk; j0 += ATT_CH) {
+            float s[ATT_CH];
+            float cmax = -INFINITY;
+#pragma unroll
+            for (int jj = 0; jj < ATT_CH; ++jj) {
+                const float* kr = &Ks[(j0 + jj) * HD];
+                float acc = 0.f;
+#pragma unroll
+                for (int c = 0; c < HD; ++c) acc = fmaf(q[c], kr[c], acc);
+                s[jj] = (j0 + jj < nk) ? acc * scale : -INFINITY;
+                cmax = fmaxf(cmax, s[jj]);
+            }
+            const float mn = fmaxf(m, cmax);
+            const float alpha = expf(m - mn);  // m = -inf on the first chunk -> 0
+            l *= alpha;
+#pragma unroll
+            for (int c = 0; c < HD; ++c) o[c] *= alpha;
+#pragma unroll
+            for (int jj = 0; jj < ATT_CH; ++jj) {
+                const float p = expf(s[jj] - mn);  // masked tail: exp(-inf) = 0
+                l += p;
+                const float* vr = &Vs[(j0 + jj) * HD];
+#pragma unroll
+                for (int c = 0; c < HD; ++c) o[c] = fmaf(p, vr[c], o[c]);
+            }
+            m = mn;
+        }
+    }
+    if (active) {
+        const float inv = 1.0f / l;
+        float* op = ctx + (int64_t)(s0 + qi) * H + h * HD;
+#pragma unroll
+        for (int c = 0; c < HD; c += 4) {
+            f32x4 v = {o[c] * inv, o[c + 1] * inv, o[c + 2] * inv, o[c + 3] * inv};
+            *reinterpret_cast<f32x4*>(op + c) = v;
+        }
+    }
+}
+
+// concat Wq,Wk,Wv ([H,H] each) and their biases into one [3H,H] / [3H]
+__global__ void concat3_kernel(const float* a, const float* b, const float* c, int64_t n, float* out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        out[i] = a[i];
+        out[n + i] = b[i];
+        out[2 * n + i] = c[i];
+    }
+}
+
+struct LayerW {
+    const float *wqkv, *bqkv;  // fused (library owned)
+    const float *wo, *bo, *ln1g, *ln1b, *w1, *b1, *w2, *b2, *ln2g, *ln2b;
+};
+
+}  // namespace
+
+struct mvdb_encoder {
+    mvdb_encoder_cfg cfg;
+    int device = 0;
+    const float *word = nullptr, *pos = nullptr, *type = nullptr, *embg = nullptr, *embb = nullptr;
+    std::vector<LayerW> layers;
+    std::vector<float*> owned;  // fused qkv weights / biases
+    // workspace (grown on demand), guarded by mu: one forward at a time per encoder
+    std::mutex mu;
+    int64_t cap_tokens = 0, cap_b = 0;
+    int *rank = nullptr, *count = nullptr, *seq_start = nullptr, *tok_id = nullptr, *tok_pos = nullptr,
+        *tok_src = nullptr;
+    float *x = nullptr, *y = nullptr, *qkv = nullptr, *ctx = nullptr, *ffn = nullptr;
+    int32_t *ids_stage = nullptr, *mask_stage = nullptr;
+    float* out_stage = nullptr;
+    int64_t stage_cap = 0, out_cap = 0;
+    hipStream_t stream = nullptr;
+
+    void free_ws() {
+        void* ptrs[] = {rank, count, seq_start, tok_id, tok_pos, tok_src, x, y, qkv, ctx, ffn};
+        for (void* p : ptrs)
+            if (p) (void)hipFree(p);
+        rank = count = seq_start = tok_id = tok_pos = tok_src = nullptr;
+        x = y = qkv = ctx = ffn = nullptr;
+        cap_tokens = cap_b = 0;
+    }
+};
+
+namespace {
+
+constexpr int kFixedWeights = 5, kPerLayer = 16;
+const char* kLayerNames[kPerLayer] = {
+    "attention.self.query.weight",  "attention.self.query.bias",  "attention.self.key.weight",
+    "attention.self.key.bias",      "attention.self.value.weight", "attention.self.value.bias",
+    "attention.output.dense.weight", "attention.output.dense.bias", "attention.output.LayerNorm.weight",
+    "attention.output.LayerNorm.bias", "intermediate.dense.weight", "intermediate.dense.bias",
+    "output.dense.weight",          "output.dense.bias",          "output.LayerNorm.weight",
+    "output.LayerNorm.bias"};
+const char* kFixedNames[kFixedWeights] = {
+    "embeddings.word_embeddings.weight", "embeddings.position_embeddings.weight",
+    "embeddings.token_type_embeddings.weight", "embeddings.LayerNorm.weight", "embeddings.LayerNorm.bias"};
+
+int check_cfg(const mvdb_encoder_cfg* c) {
+    if (!c) return fail(MVDB_ERR_ARG, "cfg is NULL");
+    if (c->hidden <= 0 || c->layers <= 0 || c->heads <= 0 || c->intermediate <= 0 || c->vocab_size <= 0 ||
+        c->max_positions <= 0 || c->type_vocab <= 0)
+        return fail(MVDB_ERR_ARG, "encoder cfg has a non-positive size");
+    if (c->hidden % c->heads) return fail(MVDB_ERR_ARG, "hidden %% heads != 0");
+    const int hd = c->hidden / c->heads;
+    if (hd != 32 && hd != 64) return fail(MVDB_ERR_ARG, "head_dim %d not supported (32 or 64)", hd);
+    if (c->hidden % GBK || c->intermediate % GBK)
+        return fail(MVDB_ERR_ARG, "hidden and intermediate must be multiples of %d", GBK);
+    if (c->hidden > 1024) return fail(MVDB_ERR_ARG, "hidden > 1024 not supported");
+    return 0;
+}
+
+template <typename T>
+int dev_alloc(T** p, int64_t n) {
+    MVDB_HIP(hipMalloc((void**)p, (size_t)std::max<int64_t>(n, 1) * sizeof(T)));
+    return 0;
+}
+
+int ensure_ws(mvdb_encoder* e, int B, int S) {
+    const int64_t tokens = (int64_t)B * S;
+    if (tokens <= e->cap_tokens && B <= e->cap_b) return 0;
+    e->free_ws();
+    const int64_t H = e->cfg.hidden, F = e->cfg.intermediate;
+    MVDB_TRY(dev_alloc(&e->rank, tokens));
+    MVDB_TRY(dev_alloc(&e->count, (int64_t)B));
+    MVDB_TRY(dev_alloc(&e->seq_start, (int64_t)B + 1));
+    MVDB_TRY(dev_alloc(&e->tok_id, tokens));
+    MVDB_TRY(dev_alloc(&e->tok_pos, tokens));
+    MVDB_TRY(dev_alloc(&e->tok_src, tokens));
+    MVDB_TRY(dev_alloc(&e->x, tokens * H));
+    MVDB_TRY(dev_alloc(&e->y, tokens * H));
+    MVDB_TRY(dev_alloc(&e->qkv, tokens * 3 * H));
+    MVDB_TRY(dev_alloc(&e->ctx, tokens * H));
+    MVDB_TRY(dev_alloc(&e->ffn, tokens * F));
+    e->cap_tokens = tokens;
+    e->cap_b = B;
+    return 0;
+}
+
+template <int EPI>
+void launch_gemm(const float* A, const float* W, const float* bias, const float* R, float* C,
+                 const int* Tptr, int64_t Tmax, int N, int K, hipStream_t s) {
+    dim3 grid((N + GBN - 1) / GBN, (unsigned)((Tmax + GBM - 1) / GBM));
+    hipLaunchKernelGGL(gemm_f32_mfma_kernel<EPI>, grid, dim3(256), 0, s, A, W, bias, R, C, Tptr, N, K);
+}
+
+template <int VPT>
+void launch_ln(const float* y, const int* seq_start, int B, const float* g, const float* b, float eps,
+               int H, float* x, int64_t Tmax, hipStream_t s) {
+    hipLaunchKernelGGL(ln_kernel<VPT>, dim3((unsigned)((Tmax + 3) / 4)), dim3(256), 0, s, y, seq_start, B,
+                       g, b, eps, H, x);
+}
+
+int forward_core(mvdb_encoder* e, const int32_t* ids, const int32_t* mask, int B, int S, int compute,
+                 float* out, float* hidden, hipStream_t s) {
+    if (compute != 0)
+        return fail(MVDB_ERR_ARG, "compute mode %d not available (0 = exact-fp32 MFMA)", compute);
+    const mvdb_encoder_cfg& c = e->cfg;
+    if (B <= 0 || S <= 0) return fail(MVDB_ERR_ARG, "B and S must be positive");
+    if (S + (c.position_offset > 0 ? c.position_offset : 0) > c.max_positions)
+        return fail(MVDB_ERR_ARG, "sequence length %d exceeds max_positions %d", S, c.max_positions);
+    MVDB_TRY(ensure_ws(e, B, S));
+    const int H = c.hidden, F = c.intermediate, hd = H / c.heads;
+    const int64_t Tmax = (int64_t)B * S;
+    const int vpt = (H + 63) / 64;
+    const int* Tptr = e->seq_start + B;
+
+    hipLaunchKernelGGL(seq_rank_kernel, dim3(B), dim3(64), 0, s, mask, S, e->rank, e->count);
+    hipLaunchKernelGGL(seq_scan_kernel, dim3(1), dim3(256), 0, s, e->count, B, e->seq_start);
+    hipLaunchKernelGGL(pack_fill_kernel, dim3(B), dim3(256), 0, s, ids, e->rank, e->seq_start, S,
+                       c.position_offset, c.vocab_size, e->tok_id, e->tok_pos, e->tok_src);
+    const dim3 rowgrid((unsigned)((Tmax + 3) / 4));
+#define MVDB_VPT_SWITCH(CALL)                                      \
+    switch (vpt) {                                                 \
+        case 1: CALL(1); break;  case 2: CALL(2); break;           \
+        case 3: CALL(3); break;  case 4: CALL(4); break;           \
+        case 5: CALL(5); break;  case 6: CALL(6); break;           \
+        case 7: CALL(7); break;  case 8: CALL(8); break;           \
+        case 9: CALL(9); break;  case 10: CALL(10); break;         \
+        case 11: CALL(11); break; case 12: CALL(12); break;        \
+        case 13: CALL(13); break; case 14: CALL(14); break;        \
+        case 15: CALL(15); break; default: CALL(16); break;        \
+    }
+#define EMBED_CALL(V)                                                                                  \
+    hipLaunchKernelGGL(embed_ln_kernel<V>, rowgrid, dim3(256), 0, s, e->tok_id, e->tok_pos, e->seq_start, \
+                       B, e->word, e->pos, e->type, e->embg, e->embb, c.ln_eps, H, e->x)
+    MVDB_VPT_SWITCH(EMBED_CALL)
+#undef EMBED_CALL
+
+    const float scale = 1.0f / sqrtf((float)hd);
+    const dim3 agrid((S + ATT_Q - 1) / ATT_Q, c.heads, B);
+    int pslot = prof_begin("encoder", s);
+    for (const LayerW& L : e->layers) {
+        launch_gemm<EPI_BIAS>(e->x, L.wqkv, L.bqkv, nullptr, e->qkv, Tptr, Tmax, 3 * H, H, s);
+        if (hd == 32)
+            hipLaunchKernelGGL(attention_kernel<32>, agrid, dim3(ATT_Q), 0, s, e->qkv, e->seq_start, H, scale,
+                               e->ctx);
+        else
+            hipLaunchKernelGGL(attention_kernel<64>, agrid, dim3(ATT_Q), 0, s, e->qkv, e->seq_start, H, scale,
+                               e->ctx);
+        launch_gemm<EPI_BIAS_RESIDUAL>(e->ctx, L.wo, L.bo, e->x, e->y, Tptr, Tmax, H, H, s);
+#define LN1_CALL(V) launch_ln<V>(e->y, e->seq_start, B, L.ln1g, L.ln1b, c.ln_eps, H, e->x, Tmax, s)
+        MVDB_VPT_SWITCH(LN1_CALL)
+#undef LN1_CALL
+        launch_gemm<EPI_BIAS_GELU>(e->x, L.w1, L.b1, nullptr, e->ffn, Tptr, Tmax, F, H, s);
+        launch_gemm<EPI_BIAS_RESIDUAL>(e->ffn, L.w2, L.b2, e->x, e->y, Tptr, Tmax, H, F, s);
+#define LN2_CALL(V) launch_ln<V>(e->y, e->seq_start, B, L.ln2g, L.ln2b, c.ln_eps, H, e->x, Tmax, s)
+        MVDB_VPT_SWITCH(LN2_CALL)
+#undef LN2_CALL
+    }
+    prof_end(pslot, s);
+#undef MVDB_VPT_SWITCH
+    hipLaunchKernelGGL(pool_norm_kernel, dim3(B), dim3(256), 0, s, e->x, e->seq_start, H, out);
+    if (hidden)
+        hipLaunchKernelGGL(unpack_hidden_kernel, dim3((unsigned)Tmax), dim3(256), 0, s, e->x, e->rank,
+                           e->seq_start, S, H, hidden);
+    MVDB_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mvdb_encoder_weight_count(const mvdb_encoder_cfg* cfg) {
+    if (check_cfg(cfg)) return -1;
+    return kFixedWeights + kPerLayer * cfg->layers;
+}
+
+const char* mvdb_encoder_weight_name(const mvdb_encoder_cfg* cfg, int i) {
+    static thread_local char buf[160];
+    if (check_cfg(cfg)) return nullptr;
+    if (i < 0 || i >= kFixedWeights + kPerLayer * cfg->layers) return nullptr;
+    if (i < kFixedWeights) return kFixedNames[i];
+    const int l = (i - kFixedWeights) / kPerLayer, j = (i - kFixedWeights) % kPerLayer;
+    snprintf(buf, sizeof(buf), "encoder.layer.%d.%s", l, kLayerNames[j]);
+    return buf;
+}
+
+int mvdb_encoder_create(const mvdb_encoder_cfg* cfg, const void* const* w, int device, mvdb_encoder** out) {
+    if (!out) return fail(MVDB_ERR_ARG, "out is NULL");
+    *out = nullptr;
+    MVDB_TRY(check_cfg(cfg));
+    if (!w) return fail(MVDB_ERR_ARG, "weight table is NULL");
+    const int nw = kFixedWeights + kPerLayer * cfg->layers;
+    for (int i = 0; i < nw; ++i)
+        if (!w[i]) return fail(MVDB_ERR_ARG, "weight %d (%s) is NULL", i, mvdb_encoder_weight_name(cfg, i));
+    MVDB_TRY(ensure_device(device));
+    DeviceGuard dg(device);
+    mvdb_encoder* e = new mvdb_encoder();
+    e->cfg = *cfg;
+    e->device = device;
+    e->word = (const float*)w[0];
+    e->pos = (const float*)w[1];
+    e->type = (const float*)w[2];
+    e->embg = (const float*)w[3];
+    e->embb = (const float*)w[4];
+    const int64_t H = cfg->hidden;
+    int rc = 0;
+    for (int l = 0; l < cfg->layers && !rc; ++l) {
+        const void* const* p = w + kFixedWeights + (int64_t)l * kPerLayer;
+        float *wqkv = nullptr, *bqkv = nullptr;
+        if (hipMalloc((void**)&wqkv, 3 * H * H * sizeof(float)) != hipSuccess ||
+            hipMalloc((void**)&bqkv, 3 * H * sizeof(float)) != hipSuccess) {
+            rc = fail(MVDB_ERR_OOM, "device allocation for fused QKV weights failed");
+            if (wqkv) (void)hipFree(wqkv);
+            break;
+        }
+        e->owned.push_back(wqkv);
+        e->owned.push_back(bqkv);
+        hipLaunchKernelGGL(concat3_kernel, dim3((unsigned)((H * H + 255) / 256)), dim3(256), 0, nullptr,
+                           (const float*)p[0], (const float*)p[2], (const float*)p[4], H * H, wqkv);
+        hipLaunchKernelGGL(concat3_kernel, dim3((unsigned)((H + 255) / 256)), dim3(256), 0, nullptr,
+                           (const float*)p[1], (const float*)p[3], (const float*)p[5], H, bqkv);
+        LayerW L;
+        L.wqkv = wqkv;
+        L.bqkv = bqkv;
+        L.wo = (const float*)p[6];
+        L.bo = (const float*)p[7];
+        L.ln1g = (const float*)p[8];
+        L.ln1b = (const float*)p[9];
+        L.w1 = (const float*)p[10];
+        L.b1 = (const float*)p[11];
+        L.w2 = (const float*)p[12];
+        L.b2 = (const float*)p[13];
+        L.ln2g = (const float*)p[14];
+        L.ln2b = (const float*)p[15];
+        e->layers.push_back(L);
+    }
+    if (!rc && hipDeviceSynchronize() != hipSuccess) rc = fail(MVDB_ERR_HIP, "weight fusion failed");
+    if (!rc && hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess)
+        rc = fail(MVDB_ERR_HIP, "stream creation failed");
+    if (rc) {
+        mvdb_encoder_free(e);
+        return rc;
+    }
+    *out = e;
+    return 0;
+}
+
+int mvdb_encoder_free(mvdb_encoder* e) {
+    if (!e) return 0;
+    {
+        DeviceGuard dg(e->device);
+        (void)hipDeviceSynchronize();
+        e->free_ws();
+        for (float* p : e->owned) (void)hipFree(p);
+        if (e->ids_stage) (void)hipFree(e->ids_stage);
+        if (e->mask_stage) (void)hipFree(e->mask_stage);
+        if (e->out_stage) (void)hipFree(e->out_stage);
+        if (e->stream) (void)hipStreamDestroy(e->stream);
+    }
+    delete e;
+    return 0;
+}
+
+int mvdb_encoder_forward_device(mvdb_encoder* e, const int32_t* ids_dev, const int32_t* mask_dev, int B,
+                                int S, int compute, float* out_dev, float* hidden_dev, void* stream) {
+    if (!e) return fail(MVDB_ERR_ARG, "encoder is NULL");
+    if (!ids_dev || !mask_dev || !out_dev) return fail(MVDB_ERR_ARG, "NULL buffer");
+    std::lock_guard<std::mutex> lk(e->mu);
+    DeviceGuard dg(e->device);
+    return forward_core(e, ids_dev, mask_dev, B, S, compute, out_dev, hidden_dev, (hipStream_t)stream);
+}
+
+int mvdb_encoder_forward(mvdb_encoder* e, const int32_t* ids_host, const int32_t* mask_host, int B, int S,
+                         int compute, float* out_host) {
+    if (!e) return fail(MVDB_ERR_ARG, "encoder is NULL");
+    if (!ids_host || !mask_host || !out_host) return fail(MVDB_ERR_ARG, "NULL buffer");
+    if (B <= 0 || S <= 0) return fail(MVDB_ERR_ARG, "B and S must be positive");
+    std::lock_guard<std::mutex> lk(e->mu);
+    DeviceGuard dg(e->device);
+    const int64_t tokens = (int64_t)B * S;
+    if (tokens > e->stage_cap) {
+        if (e->ids_stage) (void)hipFree(e->ids_stage);
+        if (e->mask_stage) (void)hipFree(e->mask_stage);
+        e->ids_stage = e->mask_stage = nullptr;
+        e->stage_cap = 0;
+        MVDB_HIP(hipMalloc((void**)&e->ids_stage, tokens * sizeof(int32_t)));
+        MVDB_HIP(hipMalloc((void**)&e->mask_stage, tokens * sizeof(int32_t)));
+        e->stage_cap = tokens;
+    }
+    const int64_t outn = (int64_t)B * e->cfg.hidden;
+    if (outn > e->out_cap) {
+        if (e->out_stage) (void)hipFree(e->out_stage);
+        e->out_stage = nullptr;
+        e->out_cap = 0;
+        MVDB_HIP(hipMalloc((void**)&e->out_stage, outn * sizeof(float)));
+        e->out_cap = outn;
+    }
+    for (int64_t i = 0; i < tokens; ++i)
+        if (mask_host[i] && (ids_host[i] < 0 || ids_host[i] >= e->cfg.vocab_size))
+            return fail(MVDB_ERR_ARG, "token id %d at %lld outside the vocabulary [0,%d)", ids_host[i],
+                        (long long)i, e->cfg.vocab_size);
+    MVDB_HIP(hipMemcpyAsync(e->ids_stage, ids_host, tokens * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
+    MVDB_HIP(hipMemcpyAsync(e->mask_stage, mask_host, tokens * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
+    MVDB_TRY(forward_core(e, e->ids_stage, e->mask_stage, B, S, compute, e->out_stage, nullptr, e->stream));
+    MVDB_HIP(hipMemcpyAsync(out_host, e->out_stage, outn * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    MVDB_HIP(hipStreamSynchronize(e->stream));
+    return 0;
+}
+
+}  // extern "C"

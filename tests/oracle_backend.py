@@ -1,0 +1,61 @@
+"""Test-only stand-in for minivectordb_amd._native.FlatIndex built on the CPU oracle.
+
+Injected by CPU tests (monkeypatch) so that the HOST logic of the drop-in classes — filters, id
+maps, incremental device sync, autocut, pickle formats — can be exercised without a GPU.  The
+product never imports this module and has no such fallback.
+"""
+import numpy as np
+
+from oracle import flat
+
+
+class OracleIndex:
+    def __init__(self, d, metric=0, device=0):
+        self.d, self.metric, self.device = int(d), metric, device
+        self.x = np.zeros((0, self.d), dtype=np.float32)
+        self.calls = []
+
+    @property
+    def ntotal(self):
+        return self.x.shape[0]
+
+    def close(self):
+        pass
+
+    def reset(self):
+        self.x = np.zeros((0, self.d), dtype=np.float32)
+
+    def reserve(self, n):
+        pass
+
+    def add(self, x, normalize=False):
+        x = np.ascontiguousarray(x, dtype=np.float32).copy()
+        assert x.ndim == 2 and x.shape[1] == self.d
+        if normalize:
+            flat.normalize_l2(x)
+        self.x = np.ascontiguousarray(np.vstack([self.x, x]))
+        self.calls.append(("add", x.shape[0]))
+
+    def get_rows(self, row0, n):
+        assert 0 <= row0 and row0 + n <= self.x.shape[0]
+        return self.x[row0:row0 + n].copy()
+
+    def remove_rows(self, rows):
+        rows = np.asarray(rows, dtype=np.int64)
+        assert len(set(rows.tolist())) == len(rows)
+        self.x = np.ascontiguousarray(np.delete(self.x, rows, 0))
+        self.calls.append(("remove", len(rows)))
+
+    def search(self, q, k, normalize_q=False):
+        self.calls.append(("search", k))
+        q = np.atleast_2d(np.asarray(q, dtype=np.float32))
+        if self.x.shape[0] == 0:
+            return (np.full((q.shape[0], k), -3.4028234663852886e38, np.float32),
+                    np.full((q.shape[0], k), -1, np.int64))
+        return flat.flat_search(self.x, q, k, metric=self.metric, normalize_q=normalize_q)
+
+    def search_subset(self, q, k, rows, normalize_q=False):
+        self.calls.append(("subset", k, len(rows)))
+        q = np.atleast_2d(np.asarray(q, dtype=np.float32))
+        return flat.flat_search(self.x, q, k, metric=self.metric, normalize_q=normalize_q,
+                                rows=np.asarray(rows, dtype=np.int64))

@@ -1,0 +1,95 @@
+"""world_size-2 gloo test (CPU) of the row-partitioned search plumbing in
+minivectordb_amd/distributed.py: shard ranges, label offsets, the packed all-gather layout and the
+gather order.  The per-shard scan and the k-way merge are HIP kernels and cannot run here, so both
+are injected: the local search is the CPU oracle over the rank's row range, the merge a numpy
+restatement of mvdb_merge_topk_device.  The result on every rank must equal the oracle's top-k over
+the UNION of the shards (the reference's contract: it stacks all shards into one index,
+minivectordb/sharded_vector_database.py:45-71, :598-662)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, n, d, k, nq, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from minivectordb_amd.distributed import PackedTopK, ShardedSearcher, shard_ranges
+    from oracle import flat
+
+    x = flat.synth(n, d, 1234)
+    flat.normalize_l2(x)
+    q = flat.synth(nq, d, 5678)
+    flat.normalize_l2(q)
+    first, cnt = shard_ranges(n, world)[rank]
+    shard = np.ascontiguousarray(x[first:first + cnt])
+
+    def local_search(qt, D, I, label_offset):
+        Dl, Il = flat.flat_search(shard, qt.numpy(), k)
+        D.copy_(torch.from_numpy(Dl))
+        I.copy_(torch.from_numpy(np.where(Il >= 0, Il + label_offset, -1)))
+
+    def merge(gathered, D_out, I_out):
+        for qi in range(gathered.nq):
+            cands = []
+            for l in range(gathered.world):
+                Dl, Il = gathered.views(l)
+                for j in range(k):
+                    if int(Il[qi, j]) >= 0:
+                        cands.append((-float(Dl[qi, j]), int(Il[qi, j])))
+            cands.sort()
+            for j in range(k):
+                if j < len(cands):
+                    D_out[qi, j] = -cands[j][0]
+                    I_out[qi, j] = cands[j][1]
+                else:
+                    D_out[qi, j] = -3.4028234663852886e38
+                    I_out[qi, j] = -1
+
+    s = ShardedSearcher(None, k, rank=rank, world=world, label_offset=first, device=torch.device("cpu"),
+                        local_search=local_search, merge=merge)
+    D, I = s.search_device(torch.from_numpy(q))
+    np.save(os.path.join(out_dir, f"D{rank}.npy"), D.numpy())
+    np.save(os.path.join(out_dir, f"I{rank}.npy"), I.numpy())
+    # layout facts the HIP merge kernel relies on
+    p = PackedTopK(nq, k, torch.device("cpu"), world)
+    assert p.nbytes % 16 == 0 and p.stride_I * 8 == p.nbytes and p.stride_D * 4 == p.nbytes
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n,k,nq", [(1001, 10, 3), (64, 5, 1)])
+def test_two_rank_sharded_search_equals_union(tmp_path, n, k, nq):
+    from oracle import flat
+    world, d = 2, 64
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(world, port, n, d, k, nq, str(tmp_path)), nprocs=world, join=True)
+    x = flat.synth(n, d, 1234)
+    flat.normalize_l2(x)
+    q = flat.synth(nq, d, 5678)
+    flat.normalize_l2(q)
+    Dw, Iw = flat.flat_search(x, q, k)
+    for r in range(world):
+        D = np.load(tmp_path / f"D{r}.npy")
+        I = np.load(tmp_path / f"I{r}.npy")
+        assert np.array_equal(I, Iw), (r, I, Iw)
+        assert np.array_equal(D, Dw)
+
+
+def test_shard_ranges_and_files(tmp_path):
+    from minivectordb_amd.distributed import shard_ranges
+    from minivectordb_amd.sharded_vector_database import shard_files_for_rank
+    assert shard_ranges(10, 3) == [(0, 4), (4, 3), (7, 3)]
+    assert shard_ranges(80_000_000, 8)[7] == (70_000_000, 10_000_000)
+    for i in (0, 1, 2, 10, 3):
+        (tmp_path / f"shard_{i}.pkl").write_bytes(b"")
+    got = [shard_files_for_rank(str(tmp_path), r, 2) for r in range(2)]
+    assert got == [["shard_0.pkl", "shard_1.pkl", "shard_2.pkl"], ["shard_3.pkl", "shard_10.pkl"]]

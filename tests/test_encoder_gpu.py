@@ -1,0 +1,100 @@
+"""GPU parity of the HIP encoder (mvdb_encoder_* through the C-ABI) with transformers' own model:
+committed golden outputs + the float64 restatement.  Tolerance: 2e-5 on the unit-norm embeddings,
+1e-4 on hidden states (values up to ~6), fp32 everywhere."""
+import numpy as np
+import pytest
+
+from encoder_cases import load_cases
+from oracle import encoder as E
+
+pytestmark = pytest.mark.gpu
+CASES = load_cases()
+
+
+def _model(cfg, weights):
+    import torch
+    from minivectordb_amd.embedding_model import GpuEncoder
+    sd = {k: torch.from_numpy(v) for k, v in weights.items()}
+    return GpuEncoder(cfg, sd, device=0)
+
+
+@pytest.mark.parametrize("i", range(len(CASES)))
+def test_encoder_matches_transformers_golden(i, gpu):
+    import torch
+    c = CASES[i]
+    cfg = E.make_config(c["name"])
+    w = E.make_weights(cfg, c["wseed"])
+    enc = _model(cfg, w)
+    emb = enc.forward(c["ids"], c["mask"])
+    np.testing.assert_allclose(emb, c["emb"], atol=2e-5, rtol=0)
+    dev = torch.device("cuda", 0)
+    out, hidden = enc.forward_device(torch.from_numpy(c["ids"]).to(dev), torch.from_numpy(c["mask"]).to(dev),
+                                     want_hidden=True)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(out.cpu().numpy(), emb, atol=0, rtol=0)  # host and device entry points agree
+    hidden = hidden.cpu().numpy()
+    m = c["mask"].astype(bool)
+    np.testing.assert_allclose(hidden[m], c["hidden_valid"], atol=1e-4, rtol=0)
+    assert not hidden[~m].any()
+    enc.close()
+
+
+def test_encoder_matches_float64_and_live_transformers(gpu):
+    cfg = E.make_config("e5-small-dims")
+    w = E.make_weights(cfg, 21)
+    ids, mask = E.make_inputs(cfg, 8, 40, 22)
+    enc = _model(cfg, w)
+    emb = enc.forward(ids, mask)
+    _, e64 = E.numpy_forward(cfg, w, ids, mask)
+    np.testing.assert_allclose(emb, e64, atol=2e-5, rtol=0)
+    _, ehf = E.hf_forward(cfg, w, ids, mask)  # transformers is part of the image on the GPU box too
+    np.testing.assert_allclose(emb, ehf, atol=2e-5, rtol=0)
+    # a batched row equals the B = 1 forward of the same sentence (reference semantics are B = 1)
+    for b in (1, 5):
+        n = int(mask[b].sum())
+        e1 = enc.forward(ids[b:b + 1, :n], mask[b:b + 1, :n])
+        np.testing.assert_allclose(emb[b], e1[0], atol=2e-6, rtol=0)
+    # arbitrary (non-prefix) masks are honoured too
+    mask2 = mask.copy()
+    mask2[:, 3] = 0
+    _, e64b = E.numpy_forward(cfg, w, ids, mask2)
+    np.testing.assert_allclose(enc.forward(ids, mask2), e64b, atol=2e-5, rtol=0)
+    enc.close()
+
+
+def test_embedding_model_api(gpu):
+    """EmbeddingModel drop-in with injected weights + a stand-in tokenizer (no HF files offline)."""
+    import torch
+    from minivectordb_amd import AlternativeModel, EmbeddingModel
+
+    cfg = E.make_config("e5-small-dims")
+    w = E.make_weights(cfg, 10)
+
+    class Tok:
+        def __call__(self, texts, max_length=512, padding=True, truncation=True, return_tensors="np"):
+            rows = [[(ord(ch) % 900) + 50 for ch in t][:max_length] for t in texts]
+            S = max(len(r) for r in rows)
+            ids = np.zeros((len(rows), S), np.int64)
+            mask = np.zeros((len(rows), S), np.int64)
+            for i, r in enumerate(rows):
+                ids[i, :len(r)] = r
+                mask[i, :len(r)] = 1
+            return {"input_ids": ids, "attention_mask": mask}
+
+    m = EmbeddingModel(use_quantized_onnx_model=False, alternative_model=AlternativeModel.small,
+                       state_dict={k: torch.from_numpy(v) for k, v in w.items()}, config=cfg, tokenizer=Tok())
+    e = m.extract_embeddings("i like dogs")
+    assert isinstance(e, list) and len(e) == 384 and abs(np.linalg.norm(e) - 1.0) < 1e-5
+    ids, mask = m._tokenize(["i like dogs"])
+    assert ids.shape[1] == len("passage i like dogs")  # the reference's prompt prefix (no colon)
+    _, want = E.numpy_forward(cfg, w, ids, mask)
+    np.testing.assert_allclose(e, want[0], atol=2e-5)
+    batch = m.extract_embeddings_batch(["i like dogs", "a much longer sentence about vector databases", "x"])
+    np.testing.assert_allclose(batch[0], e, atol=2e-6)
+    with pytest.raises(NotImplementedError):
+        EmbeddingModel()  # quantised ONNX default: blob absent from the reference tree
+    with pytest.raises(NotImplementedError):
+        EmbeddingModel(use_quantized_onnx_model=False)  # bge-m3 default alternative
+    m2 = EmbeddingModel(use_quantized_onnx_model=False, e5_model_size="small",
+                        state_dict={k: torch.from_numpy(v) for k, v in w.items()}, config=cfg, tokenizer=Tok())
+    assert m2.alternative_model == AlternativeModel.small
