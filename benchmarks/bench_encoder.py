@@ -1,0 +1,77 @@
+#!/usr/bin/env python3
+"""BASELINE config 5, encoder half: multilingual-e5-small-shaped encoder forward (random-init
+weights, synthetic token ids), batch 256, S in {32, 512}.  Reports sentences/s and TFLOP/s of the
+exact-fp32 MFMA path against the 157.3 TFLOP/s fp32 matrix peak."""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from minivectordb_amd.embedding_model import GpuEncoder  # noqa: E402
+
+
+def main():
+    dev = torch.device("cuda", 0)
+    cfg = {"model_type": "bert", "vocab_size": 250037, "hidden_size": 384, "num_hidden_layers": 12,
+           "num_attention_heads": 12, "intermediate_size": 1536, "max_position_embeddings": 512,
+           "type_vocab_size": 2, "layer_norm_eps": 1e-12, "hidden_act": "gelu", "pad_token_id": 0}
+    from oracle.encoder import weight_names
+    g = torch.Generator(device="cpu").manual_seed(0)
+    H, F = 384, 1536
+    sd = {}
+    for name in weight_names(cfg):
+        if name == "embeddings.word_embeddings.weight":
+            shape = (cfg["vocab_size"], H)
+        elif name == "embeddings.position_embeddings.weight":
+            shape = (512, H)
+        elif name == "embeddings.token_type_embeddings.weight":
+            shape = (2, H)
+        elif name.endswith("intermediate.dense.weight"):
+            shape = (F, H)
+        elif name.endswith("intermediate.dense.bias"):
+            shape = (F,)
+        elif name.endswith("output.dense.weight") and "attention" not in name:
+            shape = (H, F)
+        elif name.endswith(".weight") and "LayerNorm" not in name:
+            shape = (H, H)
+        else:
+            shape = (H,)
+        t = torch.randn(shape, generator=g) * 0.05
+        if "LayerNorm.weight" in name:
+            t = t + 1.0
+        sd[name] = t
+    enc = GpuEncoder(cfg, sd, device=0)
+    B = 256
+    for S in (32, 512):
+        rs = np.random.RandomState(S)
+        ids = torch.from_numpy(rs.randint(5, 250000, size=(B, S)).astype(np.int32)).to(dev)
+        for ragged in (False, True):
+            lens = rs.randint(S // 4, S + 1, size=B) if ragged else np.full(B, S)
+            mask = torch.from_numpy((np.arange(S)[None, :] < lens[:, None]).astype(np.int32)).to(dev)
+            T = int(lens.sum())
+            for _ in range(3):
+                enc.forward_device(ids, mask)
+            torch.cuda.synchronize()
+            n = 10
+            t0 = time.perf_counter()
+            for _ in range(n):
+                enc.forward_device(ids, mask)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / n
+            gemm = T * 12 * (4 * 2 * H * H + 2 * 2 * H * F)
+            attn = float(sum(12 * 4 * int(l) * int(l) * H for l in lens))
+            print(json.dumps({"B": B, "S": S, "ragged": ragged, "tokens": T, "ms": round(dt * 1e3, 3),
+                              "sentences_per_s": round(B / dt, 1), "tflops": round((gemm + attn) / dt / 1e12, 2),
+                              "gemm_tflop": round(gemm / 1e12, 3), "attn_tflop": round(attn / 1e12, 3),
+                              "frac_of_fp32_mfma_peak": round((gemm + attn) / dt / 157.3e12, 4)}), flush=True)
+    enc.close()
+
+
+if __name__ == "__main__":
+    main()

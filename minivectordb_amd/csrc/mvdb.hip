@@ -5,6 +5,7 @@
 // the padding is zero.  Rows [0, n) are live.  Nothing else of the corpus lives on the device
 // (ids / metadata stay in the Python host layer, as in the reference).
 #include <algorithm>
+#include <cstdlib>
 #include <map>
 #include <shared_mutex>
 
@@ -224,16 +225,25 @@ Shape choose_shape(int d4) {
 }
 constexpr int kMaxC = 16;  // d <= 4096
 
-template <int G, int C, int U, int METRIC, int MODE>
+int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v && *v ? atoi(v) : dflt;
+}
+
+template <int G, int C, int U, int METRIC, int MODE, bool NT = true>
 int launch_scan_inst(const ScanArgs& a, int nq, int device, hipStream_t stream, int* nblocks_out) {
-    auto kern = flat_scan_kernel<G, C, U, METRIC, MODE>;
+    auto kern = flat_scan_kernel<G, C, U, METRIC, MODE, NT>;
     static int occ = 0;  // blocks per CU this instantiation sustains
     if (occ == 0) {
         int nb = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, kScanThreads, 0) != hipSuccess ||
             nb <= 0)
             nb = 4;
-        occ = std::min(nb, 8);
+        // measured on MI355X (benchmarks/sweep_scan.py, 10M x 512): 3-4 resident blocks per CU stream
+        // faster than 7-8 (7.19 vs 7.05 TB/s with 16 loads in flight per lane)
+        occ = std::min(nb, 3);
+        const int cap_env = env_int("MVDB_SCAN_BLOCKS_PER_CU", 0);  // tuning hook
+        if (cap_env > 0) occ = std::min(nb, cap_env);
     }
     constexpr int RB = (kWave / G) * U;
     const int64_t nbatches = (a.n + RB - 1) / RB;
@@ -267,6 +277,18 @@ int scan_grid_upper_bound(int device) { return device_cus(device) * 8; }
 int launch_scan(int metric, int mode, const ScanArgs& a, int nq, int device, hipStream_t s,
                 int* nblocks) {
     const Shape sh = choose_shape(a.d4);
+    if (sh.G == 64 && sh.C == 2 && metric == MVDB_METRIC_IP && mode == kModeTopK) {
+        // tuning hook for the headline shape (d = 512): MVDB_SCAN_VARIANT = U*10 + NT
+        switch (env_int("MVDB_SCAN_VARIANT", -1)) {
+            case 20: return launch_scan_inst<64, 2, 2, 0, kModeTopK, false>(a, nq, device, s, nblocks);
+            case 21: return launch_scan_inst<64, 2, 2, 0, kModeTopK, true>(a, nq, device, s, nblocks);
+            case 40: return launch_scan_inst<64, 2, 4, 0, kModeTopK, false>(a, nq, device, s, nblocks);
+            case 41: return launch_scan_inst<64, 2, 4, 0, kModeTopK, true>(a, nq, device, s, nblocks);
+            case 80: return launch_scan_inst<64, 2, 8, 0, kModeTopK, false>(a, nq, device, s, nblocks);
+            case 161: return launch_scan_inst<64, 2, 16, 0, kModeTopK, true>(a, nq, device, s, nblocks);
+            default: break;
+        }
+    }
 #define MVDB_SCAN_CASE(G_, C_, U_) \
     if (sh.G == G_ && sh.C == C_) return launch_scan_gcu<G_, C_, U_>(metric, mode, a, nq, device, s, nblocks);
     MVDB_SCAN_CASE(1, 1, 8)
@@ -279,7 +301,7 @@ int launch_scan(int metric, int mode, const ScanArgs& a, int nq, int device, hip
     MVDB_SCAN_CASE(32, 5, 1)
     MVDB_SCAN_CASE(32, 7, 1)
     MVDB_SCAN_CASE(64, 1, 8)
-    MVDB_SCAN_CASE(64, 2, 4)
+    MVDB_SCAN_CASE(64, 2, 8)
     MVDB_SCAN_CASE(64, 3, 2)
     MVDB_SCAN_CASE(64, 4, 2)
     MVDB_SCAN_CASE(64, 5, 1)
@@ -351,7 +373,7 @@ int search_core(const mvdb_index* idx, Workspace* ws, const float* q_dev, int nq
         ma.label_offset = label_offset;
         ma.D = D_dev;
         ma.I = I_dev;
-        hipLaunchKernelGGL(merge_keys_kernel, dim3(nq), dim3(kScanThreads), 0, s, ma);
+        hipLaunchKernelGGL(merge_keys_kernel, dim3(nq), dim3(kMergeThreads), 0, s, ma);
         MVDB_HIP(hipGetLastError());
         return 0;
     }

@@ -50,7 +50,7 @@ __device__ __forceinline__ float group_reduce_add(float v) {
 }
 
 // METRIC 0: inner product (score = q.x).  METRIC 1: squared L2 (score = -|q-x|^2).
-template <int G, int C, int U, int METRIC, int MODE>
+template <int G, int C, int U, int METRIC, int MODE, bool NT = true>
 __global__ __launch_bounds__(kScanThreads) void flat_scan_kernel(ScanArgs a) {
     constexpr int RPI = kWave / G;  // rows per wave-instruction
     constexpr int RB = RPI * U;     // rows per wave batch
@@ -103,9 +103,8 @@ __global__ __launch_bounds__(kScanThreads) void flat_scan_kernel(ScanArgs a) {
             const float* p = a.X + pr * a.ld + t * 4;
 #pragma unroll
             for (int c = 0; c < C; ++c) {
-                x[u][c] = cvalid[c] ? __builtin_nontemporal_load(
-                                          reinterpret_cast<const f32x4*>(p + c * G * 4))
-                                    : f32x4{0, 0, 0, 0};
+                const f32x4* src = reinterpret_cast<const f32x4*>(p + c * G * 4);
+                x[u][c] = cvalid[c] ? (NT ? __builtin_nontemporal_load(src) : *src) : f32x4{0, 0, 0, 0};
             }
         }
         float s[U];
@@ -159,7 +158,7 @@ __global__ __launch_bounds__(kScanThreads) void flat_scan_kernel(ScanArgs a) {
 }
 
 // ---- second stage: merge `nlists` sorted k-lists per query and emit (D, I) --------------------
-// grid = (nq), block = 256.  keys[nq, nlists, k].  Labels: position -> label_offset + row.
+// grid = (nq), block = 1024.  keys[nq, nlists, k].  Labels: position -> label_offset + row.
 // METRIC 1 stores -dist in the key; D gets +dist back.
 struct MergeArgs {
     const uint64_t* keys;
@@ -171,7 +170,11 @@ struct MergeArgs {
     int64_t* I;  // [nq, k]
 };
 
-__global__ __launch_bounds__(kScanThreads) void merge_keys_kernel(MergeArgs a) {
+constexpr int kMergeThreads = 1024;
+constexpr int kMergeWaves = kMergeThreads / kWave;
+constexpr int kMergeUnroll = 8;
+
+__global__ __launch_bounds__(kMergeThreads) void merge_keys_kernel(MergeArgs a) {
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x >> 6;
     const int qi = blockIdx.x;
@@ -179,12 +182,21 @@ __global__ __launch_bounds__(kScanThreads) void merge_keys_kernel(MergeArgs a) {
     const uint64_t* src = a.keys + (int64_t)qi * total;
     WaveTopK tk;
     tk.init(a.k);
-    for (int64_t base = (int64_t)wave * kWave; base < total; base += kScanThreads) {
-        const int64_t i = base + lane;
-        tk.offer(i < total ? src[i] : 0ull);
+    // each wave walks its slice in steps of 64 x kMergeUnroll keys: the loads of a step are
+    // independent (issued back to back), only then are the candidates offered to the list
+    for (int64_t base = (int64_t)wave * kWave * kMergeUnroll; base < total;
+         base += (int64_t)kMergeThreads * kMergeUnroll) {
+        uint64_t c[kMergeUnroll];
+#pragma unroll
+        for (int j = 0; j < kMergeUnroll; ++j) {
+            const int64_t i = base + j * kWave + lane;
+            c[j] = i < total ? src[i] : 0ull;
+        }
+#pragma unroll
+        for (int j = 0; j < kMergeUnroll; ++j) tk.offer(c[j]);
     }
-    __shared__ uint64_t sh[(kScanWaves - 1) * kWave];
-    block_merge_topk(tk, sh, kScanWaves);
+    __shared__ uint64_t sh[(kMergeWaves - 1) * kWave];
+    block_merge_topk(tk, sh, kMergeWaves);
     if (wave == 0 && lane < a.k) {
         const uint64_t key = tk.key;
         float d;

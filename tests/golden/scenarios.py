@@ -70,7 +70,7 @@ def config1():
 
 def colinear():
     """2-d colinear rows: exact/near score ties, k > n, filters with ties (reference tests' vectors)."""
-    rows = [[0.5, 0.5], [0.1, 0.1], [0.7, 0.7], [0.5, -0.5], [0.2, 0.9], [0.9, 0.2], [-0.3, -0.3], [0.0, 1.0]]
+    rows = [[0.5, 0.5], [0.1, 0.1], [0.7, 0.7], [0.5, -0.4], [0.2, 0.9], [0.9, 0.2], [-0.3, -0.3], [0.0, 1.0]]
     ops = [{"op": "wipe", "path": "co.pkl"}, {"op": "open", "kind": "flat", "path": "co.pkl"},
            {"op": "search", "q": {"list": [1.0, 1.0]}, "k": 3}]  # empty database
     for i, r in enumerate(rows):
