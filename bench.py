@@ -30,6 +30,25 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 
 
+def pmc_traffic(n, d):
+    """HBM bytes per scan launch from the committed rocprofv3 PMC passes (profiles/*_pmc_summary.json,
+    separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same command, FETCH_SIZE doubled per the
+    guide's gfx950 correction).  Counters cannot be collected from inside the timed process, so this
+    is the figure of the profiled run of the same workload, or None when no matching profile exists."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json"))):
+        try:
+            for rec in json.load(open(f)):
+                if "flat_scan_kernel" in rec["kernel"] and rec["launches_fetch_pass"] > 0:
+                    t = rec["hbm_traffic_bytes_per_launch_avg"]
+                    if abs(t / (n * d * 4.0) - 1.0) < 0.25:  # same workload size
+                        best = {"bytes": int(t), "source": os.path.basename(f)}
+        except Exception:
+            pass
+    return best
+
+
 def cpu_baseline(native, idx, d, k, queries_host, full_rows, budget_s=20.0):
     """Time the CPU oracle (oracle/flat_oracle.c, a port of faiss' nq=1 sequential scan) on a bounded
     sample of the same workload: the first `sample` rows of the resident corpus."""
@@ -44,7 +63,7 @@ def cpu_baseline(native, idx, d, k, queries_host, full_rows, budget_s=20.0):
         if time.perf_counter() - t0 > budget_s / 2 or nq >= 64:
             break
     t1 = time.perf_counter() - t0
-    cores = flat.max_threads()
+    cores = max(1, min(flat.max_threads(), len(os.sched_getaffinity(0))))
     nq_mt = 0
     t0 = time.perf_counter()
     while True:
@@ -181,7 +200,8 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": None,
+                "traffic": (pmc_traffic(n, d) or {}).get("bytes"),
+                "traffic_source": (pmc_traffic(n, d) or {}).get("source"),
                 "kernel": "flat_scan_kernel",
                 "launches": launches,
                 "avg_launch_ms": round(avg_ms, 4),
