@@ -11,6 +11,7 @@
 
 #include "common.hpp"
 #include "scan_kernels.hpp"
+#include "scan_mfma_kernels.hpp"
 #include "select_kernels.hpp"
 #include "util_kernels.hpp"
 
@@ -108,6 +109,7 @@ struct Workspace {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     DevBuf<float> q;
+    DevBuf<float> qn;  // normalised copy of the queries for the multi-query pass
     DevBuf<uint64_t> cand;
     DevBuf<float> D;
     DevBuf<int64_t> I;
@@ -131,6 +133,7 @@ struct Workspace {
     }
     void destroy() {
         q.release();
+        qn.release();
         cand.release();
         D.release();
         I.release();
@@ -335,6 +338,52 @@ int64_t pow2ceil(int64_t v) {
     return p;
 }
 
+int normalize_range(const mvdb_index* idx, float* base, int64_t n, hipStream_t s);
+
+template <int KB, int NG>
+int launch_mfma_inst(const MfmaScanArgs& a, int device, hipStream_t stream, int* nblocks_out) {
+    auto kern = flat_scan_mfma_kernel<KB, NG>;
+    const size_t lds = (size_t)NG * KB * 4 * 64 * 4 + (size_t)kScanWaves * NG * 16 * a.k * 8;
+    static size_t lds_set = 0;
+    if (lds > 48 * 1024 && lds > lds_set) {
+        MVDB_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        lds_set = lds;
+    }
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, kScanThreads, lds) != hipSuccess || nb <= 0)
+        nb = 1;
+    nb = std::min(nb, std::max(1, env_int("MVDB_MFMA_BLOCKS_PER_CU", 4)));
+    const int64_t ntiles = (a.n + 15) / 16;
+    const int64_t want = (ntiles + kScanWaves - 1) / kScanWaves;
+    const int nblocks = (int)std::max<int64_t>(1, std::min<int64_t>(want, (int64_t)device_cus(device) * nb));
+    *nblocks_out = nblocks;
+    int slot = prof_begin("ip_scan_mfma", stream);
+    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(kScanThreads), lds, stream, a);
+    prof_end(slot, stream);
+    MVDB_HIP(hipGetLastError());
+    return 0;
+}
+
+template <int NG>
+int launch_mfma_ng(int KB, const MfmaScanArgs& a, int device, hipStream_t s, int* nb) {
+    switch (KB) {
+        case 4: return launch_mfma_inst<4, NG>(a, device, s, nb);
+        case 8: return launch_mfma_inst<8, NG>(a, device, s, nb);
+        case 16: return launch_mfma_inst<16, NG>(a, device, s, nb);
+        case 24: return launch_mfma_inst<24, NG>(a, device, s, nb);
+        case 32: return launch_mfma_inst<32, NG>(a, device, s, nb);
+        default: return fail(MVDB_ERR_ARG, "no multi-query kernel for d = %d", KB * 16);
+    }
+}
+
+bool mfma_path_ok(const mvdb_index* idx, int nq, int k, const int64_t* rows_dev) {
+    if (env_int("MVDB_DISABLE_MFMA_SCAN", 0)) return false;
+    if (nq < 2 || k > kMaxFusedK || rows_dev || idx->metric != MVDB_METRIC_IP) return false;
+    if (idx->d % 16 || idx->ld != idx->d) return false;
+    const int KB = idx->d / 16;
+    return KB == 4 || KB == 8 || KB == 16 || KB == 24 || KB == 32;
+}
+
 // Core: queries already on the device (padded to ld), outputs on the device.  Enqueues on ws.stream.
 int search_core(const mvdb_index* idx, Workspace* ws, const float* q_dev, int nq, int k,
                 int normalize_q, const int64_t* rows_dev, int64_t m, int64_t label_offset,
@@ -359,6 +408,49 @@ int search_core(const mvdb_index* idx, Workspace* ws, const float* q_dev, int nq
     a.rows = rows_dev;
     a.cand = nullptr;
     a.scores = nullptr;
+
+    if (mfma_path_ok(idx, nq, k, rows_dev)) {
+        // ---- several queries per corpus pass on the fp32 matrix cores ---------------------------
+        const float* qsrc = q_dev;
+        if (normalize_q) {
+            MVDB_TRY(ws->qn.reserve((size_t)nq * idx->ld));
+            MVDB_HIP(hipMemcpyAsync(ws->qn.p, q_dev, (size_t)nq * idx->ld * sizeof(float),
+                                    hipMemcpyDeviceToDevice, s));
+            MVDB_TRY(normalize_range(idx, ws->qn.p, nq, s));
+            qsrc = ws->qn.p;
+        }
+        const int grid_ub = scan_grid_upper_bound(idx->device);
+        MVDB_TRY(ws->cand.reserve((size_t)32 * grid_ub * k));
+        for (int q0 = 0; q0 < nq;) {
+            const int left = nq - q0;
+            const int take = left > 16 ? std::min(left, 32) : left;
+            MfmaScanArgs ma;
+            ma.X = idx->X;
+            ma.n = n;
+            ma.ld = idx->ld;
+            ma.q = qsrc + (int64_t)q0 * idx->ld;
+            ma.nq = take;
+            ma.k = k;
+            ma.cand = ws->cand.p;
+            int nblocks = 0;
+            if (take > 16)
+                MVDB_TRY(launch_mfma_ng<2>(idx->d / 16, ma, idx->device, s, &nblocks));
+            else
+                MVDB_TRY(launch_mfma_ng<1>(idx->d / 16, ma, idx->device, s, &nblocks));
+            MergeArgs mg;
+            mg.keys = ws->cand.p;
+            mg.nlists = nblocks;
+            mg.k = k;
+            mg.metric = idx->metric;
+            mg.label_offset = label_offset;
+            mg.D = D_dev + (int64_t)q0 * k;
+            mg.I = I_dev + (int64_t)q0 * k;
+            hipLaunchKernelGGL(merge_keys_kernel, dim3(take), dim3(kMergeThreads), 0, s, mg);
+            MVDB_HIP(hipGetLastError());
+            q0 += take;
+        }
+        return 0;
+    }
 
     if (k <= kMaxFusedK) {
         MVDB_TRY(ws->cand.reserve((size_t)nq * scan_grid_upper_bound(idx->device) * k));

@@ -1,0 +1,147 @@
+// scan_mfma_kernels.hpp — multi-query flat scan on the exact-fp32 matrix cores.
+//
+// One pass over the corpus serves up to 32 queries: scores[query, row] = Q · Xᵀ is a skinny GEMM
+// (M = queries, N = corpus rows, K = d).  faiss.IndexFlatIP.search with nq queries
+// (reference call site minivectordb/vector_database.py:497 is nq = 1; a batch API has no
+// reference counterpart — results per query are identical to nq separate searches).
+//
+// Roofline: HBM up to nq ~ 39 (fp32 MFMA 157.3 TF / 8 TB/s = 19.7 FLOP/B; intensity = nq/2
+// FLOP/B).  Algorithmic bytes per launch = n * ld * 4 (the corpus once, for all queries).
+//
+// v_mfma_f32_16x16x4_f32:  D[16x16] += A[16x4] · B[4x16], exact fp32 (an fmaf chain in k order).
+//   A = queries      lane l holds A[i = l&15][k = l>>4]
+//   B = corpus rows  lane l holds B[k = l>>4][j = l&15] = X[row0 + (l&15)][k]
+//   D                lane l holds D[i = 4*(l>>4) + r][j = l&15], r = 0..3:
+//                    the scores of corpus row (l&15) against queries 4*(l>>4) .. +3
+// Corpus operand straight from HBM into VGPRs: lane l loads ONE float4 =
+// X[row0 + (l&15)][16*kb + 4*(l>>4) .. +3]; its 4 components feed 4 MFMAs, the j-th of which
+// contracts k in {16kb + j, +4, +8, +12}.  The query fragments are pre-arranged in LDS in exactly
+// that order ("fragment-major", lane-linear => conflict-free ds_read_b32), so no lane ever
+// shuffles.  One load instruction covers 16 rows x 64 contiguous bytes; consecutive instructions of
+// a wave walk the same 16 rows along k, so every 128-B line is consumed within two instructions.
+//
+// Selection: per wave and query a sorted k-list lives in LDS (rarely touched); lanes gate their
+// 4 scores against per-query thresholds held in registers; inserts are wave-cooperative.
+#pragma once
+#include "scan_kernels.hpp"
+
+namespace mvdb {
+
+typedef float f32x4m __attribute__((ext_vector_type(4)));
+
+struct MfmaScanArgs {
+    const float* X;
+    int64_t n;
+    int64_t ld;
+    const float* q;  // [nq, ld] (already normalised if requested)
+    int nq;          // <= 16 * NG
+    int k;           // <= kMaxFusedK
+    uint64_t* cand;  // [nq, gridDim.x, k]
+};
+
+// wave-cooperative sorted insert into an LDS list; returns the list's new k-th key
+__device__ __forceinline__ uint64_t lds_list_insert(uint64_t* list, int k, uint64_t key, int lane) {
+    const uint64_t cur = lane < k ? list[lane] : 0ull;
+    const int better = __popcll(__ballot(cur > key));
+    const uint64_t up = __shfl_up(cur, 1);
+    uint64_t nv = cur;
+    if (lane == better)
+        nv = key;
+    else if (lane > better)
+        nv = up;
+    if (lane < k && better < k) list[lane] = nv;
+    return readlane_u64(better < k ? nv : cur, k - 1);
+}
+
+template <int KB, int NG>
+__global__ __launch_bounds__(kScanThreads) void flat_scan_mfma_kernel(MfmaScanArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* Qf = reinterpret_cast<float*>(smem);                                   // [NG][KB*4][64]
+    uint64_t* lists = reinterpret_cast<uint64_t*>(smem + (size_t)NG * KB * 4 * 64 * 4);  // [4][NG*16][k]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int k = a.k;
+
+    // ---- queries -> LDS, fragment-major: Qf[g][kb*4 + j][l] = Q[g*16 + (l&15)][16kb + 4(l>>4) + j]
+    for (int e = threadIdx.x; e < NG * KB * 4 * 64; e += kScanThreads) {
+        const int l = e & 63, f = (e >> 6) % (KB * 4), g = e / (KB * 4 * 64);
+        const int kb = f >> 2, j = f & 3;
+        const int qi = g * 16 + (l & 15);
+        Qf[e] = qi < a.nq ? a.q[(int64_t)qi * a.ld + 16 * kb + 4 * (l >> 4) + j] : 0.f;
+    }
+    uint64_t* mylists = lists + (size_t)wave * NG * 16 * k;
+    for (int e = lane; e < NG * 16 * k; e += 64) mylists[e] = 0ull;
+    __syncthreads();
+
+    float thr[NG][4];
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)  // padded query slots never pass the gate
+            thr[g][r] = (g * 16 + 4 * (lane >> 4) + r) < a.nq ? -INFINITY : INFINITY;
+
+    const int64_t ntiles = (a.n + 15) / 16;
+    const int64_t nwaves_total = (int64_t)gridDim.x * kScanWaves;
+    const int64_t last = a.n - 1;
+    constexpr int PD = KB < 8 ? KB : 8;  // loads kept in flight ahead of the MFMAs (x 1 KiB each)
+
+    for (int64_t tile = (int64_t)blockIdx.x * kScanWaves + wave; tile < ntiles; tile += nwaves_total) {
+        int64_t row = tile * 16 + (lane & 15);
+        const bool rvalid = row <= last;
+        row = rvalid ? row : last;
+        const f32x4m* p = reinterpret_cast<const f32x4m*>(a.X + row * a.ld + 4 * (lane >> 4));
+        f32x4m x[KB];
+#pragma unroll
+        for (int kb = 0; kb < PD; ++kb) x[kb] = __builtin_nontemporal_load(p + kb * 4);
+        f32x4m acc[NG];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) acc[g] = f32x4m{0, 0, 0, 0};
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+            if (kb + PD < KB) x[kb + PD] = __builtin_nontemporal_load(p + (kb + PD) * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    const float qa = Qf[(g * KB * 4 + kb * 4 + j) * 64 + lane];
+                    acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa, x[kb][j], acc[g], 0, 0, 0);
+                }
+            }
+        }
+        // ---- selection -------------------------------------------------------------------------
+        const uint32_t rowid = (uint32_t)(tile * 16 + (lane & 15));
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float s = acc[g][r];
+                uint64_t mask = __ballot(rvalid && s >= thr[g][r]);
+                while (mask) {
+                    const int src = __ffsll((long long)mask) - 1;
+                    mask &= mask - 1;
+                    const int qq = g * 16 + 4 * (src >> 4) + r;
+                    if (qq >= a.nq) continue;  // padded query slot
+                    const float sv = __uint_as_float(__builtin_amdgcn_readlane((int)__float_as_uint(s), src));
+                    const uint32_t rv = (uint32_t)__builtin_amdgcn_readlane((int)rowid, src);
+                    const uint64_t kth = lds_list_insert(mylists + (size_t)qq * k, k, make_key(sv, rv), lane);
+                    const float t = kth ? key_score(kth) : -INFINITY;
+                    if ((lane >> 4) == (src >> 4)) thr[g][r] = t;
+                }
+            }
+        }
+    }
+
+    // ---- block merge: wave w owns queries qq = w, w+4, ... ---------------------------------------
+    __syncthreads();
+    for (int qq = wave; qq < a.nq; qq += kScanWaves) {
+        WaveTopK tk;
+        tk.init(k);
+#pragma unroll 1
+        for (int w = 0; w < kScanWaves; ++w) {
+            const uint64_t* l = lists + ((size_t)w * NG * 16 + qq) * k;
+            tk.offer(lane < k ? l[lane] : 0ull);
+        }
+        if (lane < k) a.cand[((int64_t)qq * gridDim.x + blockIdx.x) * k + lane] = tk.key;
+    }
+}
+
+}  // namespace mvdb

@@ -401,3 +401,29 @@ def test_config3_10M_x_512_properties(native):
         assert ci[i][order].tolist() == I[i].tolist()
         assert np.array_equal(cd[i][order], D[i])
     idx.close()
+
+
+@pytest.mark.parametrize("n,d,k,nq", [
+    (20000, 512, 10, 16), (20000, 512, 10, 17), (9000, 512, 64, 32), (9000, 512, 5, 33), (30000, 384, 10, 40),
+    (5000, 64, 10, 2), (7001, 256, 1, 9), (3000, 128, 7, 31), (15, 512, 10, 5), (16, 512, 4, 3), (17, 512, 20, 2),
+])
+def test_multi_query_mfma_pass_matches_oracle(native, n, d, k, nq):
+    """nq >= 2 on d in {64,128,256,384,512}: one corpus pass on v_mfma_f32_16x16x4_f32 serves up to 32
+    queries; every query's result must equal its own single-query search."""
+    x = _corpus(n, d)
+    q = _corpus(nq, d, seed=5678)
+    idx = native.FlatIndex(d)
+    idx.add(x)
+    D, I = idx.search(q, k)
+    _check(native, x, q, k, D, I)
+    # identical to per-query (GEMV kernel) searches up to fp32 summation order
+    for i in (0, nq - 1):
+        D1, I1 = idx.search(q[i], k)
+        assert np.array_equal(I1[0], I[i])
+        np.testing.assert_allclose(D1[0], D[i], atol=2e-6)
+    # fused normalisation + ties (duplicate rows, duplicate queries)
+    q2 = np.concatenate([q[:2] * 3.0, q[:1] * 0.5, np.zeros((1, d), np.float32)])
+    D2, I2 = idx.search(q2, k, normalize_q=True)
+    assert np.array_equal(I2[0], I2[2]) and np.array_equal(I2[0], I[0])
+    assert I2[3].tolist()[:min(k, n)] == list(range(min(k, n)))  # zero query: all scores 0, ties by row
+    idx.close()
