@@ -24,6 +24,8 @@ import os
 import sys
 import time
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (RCCL) — before any HIP init
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -112,11 +114,19 @@ def main():
         raise SystemExit("for --gpus N > 1 launch through torch.distributed.run (one rank per GPU)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    # test hook: MVDB_BENCH_SHARE_GPU=1 + MVDB_BENCH_BACKEND=gloo runs the N > 1 code path with every rank
+    # on GPU 0 of a one-GPU box (RCCL refuses two ranks on one device); never used for reported numbers
+    share_gpu = os.environ.get("MVDB_BENCH_SHARE_GPU") == "1"
+    backend = os.environ.get("MVDB_BENCH_BACKEND", "nccl")
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from minivectordb_amd import _native as native
     from minivectordb_amd.distributed import ShardedSearcher
