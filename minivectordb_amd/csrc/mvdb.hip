@@ -233,27 +233,28 @@ int env_int(const char* name, int dflt) {
     return v && *v ? atoi(v) : dflt;
 }
 
-template <int G, int C, int U, int METRIC, int MODE, bool NT = true>
-int launch_scan_inst(const ScanArgs& a, int nq, int device, hipStream_t stream, int* nblocks_out) {
-    auto kern = flat_scan_kernel<G, C, U, METRIC, MODE, NT>;
+template <int G, int C, int U, int METRIC, int MODE, bool NT, bool SUBSET, bool MASKED, bool DB>
+int launch_scan_kern(const ScanArgs& a, int nq, int device, hipStream_t stream, int* nblocks_out) {
+    auto kern = flat_scan_kernel<G, C, U, METRIC, MODE, NT, SUBSET, MASKED, DB>;
     static int occ = 0;  // blocks per CU this instantiation sustains
+    static int occ_hw = 0;
     if (occ == 0) {
         int nb = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, kScanThreads, 0) != hipSuccess ||
             nb <= 0)
             nb = 4;
-        // measured on MI355X (benchmarks/sweep_scan.py, 10M x 512): 3-4 resident blocks per CU stream
-        // faster than 7-8 (7.19 vs 7.05 TB/s with 16 loads in flight per lane)
+        occ_hw = nb;
+        // measured on MI355X (benchmarks/sweep_scan*.py, 10M x 512): 3 resident blocks (12 waves) per CU
+        // stream faster than 4+ (7.23 vs 7.09 TB/s) and much faster than 2 (5.8 TB/s)
         occ = std::min(nb, 3);
         const int cap_env = env_int("MVDB_SCAN_BLOCKS_PER_CU", 0);  // tuning hook
-        if (cap_env > 0) occ = std::min(nb, cap_env);
+        if (cap_env > 0) occ = std::min(occ_hw, cap_env);
     }
     constexpr int RB = (kWave / G) * U;
     const int64_t nbatches = (a.n + RB - 1) / RB;
     int64_t want = (nbatches + kScanWaves - 1) / kScanWaves;
     int64_t cap = (int64_t)device_cus(device) * occ;
     int nblocks = (int)std::max<int64_t>(1, std::min(want, cap));
-    if (nblocks_out && *nblocks_out > 0) nblocks = *nblocks_out;  // caller fixed the grid
     if (nblocks_out) *nblocks_out = nblocks;
     const char* pname = MODE == kModeTopK ? "ip_scan" : "ip_scan_scores";
     int slot = prof_begin(pname, stream);
@@ -261,6 +262,18 @@ int launch_scan_inst(const ScanArgs& a, int nq, int device, hipStream_t stream, 
     prof_end(slot, stream);
     MVDB_HIP(hipGetLastError());
     return 0;
+}
+
+// runtime -> compile-time switches: subset indirection, lane masking
+template <int G, int C, int U, int METRIC, int MODE, bool NT = true, bool DB = false>
+int launch_scan_inst(const ScanArgs& a, int nq, int device, hipStream_t s, int* nb) {
+    const bool masked = a.d4 != G * C;
+    if (a.rows) {
+        if (masked) return launch_scan_kern<G, C, U, METRIC, MODE, NT, true, true, DB>(a, nq, device, s, nb);
+        return launch_scan_kern<G, C, U, METRIC, MODE, NT, true, false, DB>(a, nq, device, s, nb);
+    }
+    if (masked) return launch_scan_kern<G, C, U, METRIC, MODE, NT, false, true, DB>(a, nq, device, s, nb);
+    return launch_scan_kern<G, C, U, METRIC, MODE, NT, false, false, DB>(a, nq, device, s, nb);
 }
 
 template <int G, int C, int U>
@@ -281,14 +294,16 @@ int launch_scan(int metric, int mode, const ScanArgs& a, int nq, int device, hip
                 int* nblocks) {
     const Shape sh = choose_shape(a.d4);
     if (sh.G == 64 && sh.C == 2 && metric == MVDB_METRIC_IP && mode == kModeTopK) {
-        // tuning hook for the headline shape (d = 512): MVDB_SCAN_VARIANT = U*10 + NT
+        // tuning hook for the headline shape (d = 512): MVDB_SCAN_VARIANT = U*100 + DB*10 + NT
         switch (env_int("MVDB_SCAN_VARIANT", -1)) {
-            case 20: return launch_scan_inst<64, 2, 2, 0, kModeTopK, false>(a, nq, device, s, nblocks);
-            case 21: return launch_scan_inst<64, 2, 2, 0, kModeTopK, true>(a, nq, device, s, nblocks);
-            case 40: return launch_scan_inst<64, 2, 4, 0, kModeTopK, false>(a, nq, device, s, nblocks);
-            case 41: return launch_scan_inst<64, 2, 4, 0, kModeTopK, true>(a, nq, device, s, nblocks);
-            case 80: return launch_scan_inst<64, 2, 8, 0, kModeTopK, false>(a, nq, device, s, nblocks);
-            case 161: return launch_scan_inst<64, 2, 16, 0, kModeTopK, true>(a, nq, device, s, nblocks);
+            case 201: return launch_scan_inst<64, 2, 2, 0, kModeTopK, true, false>(a, nq, device, s, nblocks);
+            case 211: return launch_scan_inst<64, 2, 2, 0, kModeTopK, true, true>(a, nq, device, s, nblocks);
+            case 400: return launch_scan_inst<64, 2, 4, 0, kModeTopK, false, false>(a, nq, device, s, nblocks);
+            case 401: return launch_scan_inst<64, 2, 4, 0, kModeTopK, true, false>(a, nq, device, s, nblocks);
+            case 411: return launch_scan_inst<64, 2, 4, 0, kModeTopK, true, true>(a, nq, device, s, nblocks);
+            case 801: return launch_scan_inst<64, 2, 8, 0, kModeTopK, true, false>(a, nq, device, s, nblocks);
+            case 811: return launch_scan_inst<64, 2, 8, 0, kModeTopK, true, true>(a, nq, device, s, nblocks);
+            case 1601: return launch_scan_inst<64, 2, 16, 0, kModeTopK, true, false>(a, nq, device, s, nblocks);
             default: break;
         }
     }

@@ -50,7 +50,13 @@ __device__ __forceinline__ float group_reduce_add(float v) {
 }
 
 // METRIC 0: inner product (score = q.x).  METRIC 1: squared L2 (score = -|q-x|^2).
-template <int G, int C, int U, int METRIC, int MODE, bool NT = true>
+// SUBSET : rows[] indirection (compile-time, so the identity path carries no branch and — crucially —
+//          no `s_waitcnt vmcnt(0)` between the row loads of a batch).
+// MASKED : the row has fewer than G*C chunks (lanes with chunk >= d4 load nothing).  When the row
+//          fills every lane the loads are unconditional: no exec-mask branches in the loop.
+// DB     : double-buffered batches: the loads of batch b+1 are in flight while batch b is reduced.
+template <int G, int C, int U, int METRIC, int MODE, bool NT = true, bool SUBSET = false, bool MASKED = true,
+          bool DB = false>
 __global__ __launch_bounds__(kScanThreads) void flat_scan_kernel(ScanArgs a) {
     constexpr int RPI = kWave / G;  // rows per wave-instruction
     constexpr int RB = RPI * U;     // rows per wave batch
@@ -67,7 +73,7 @@ __global__ __launch_bounds__(kScanThreads) void flat_scan_kernel(ScanArgs a) {
 #pragma unroll
     for (int c = 0; c < C; ++c) {
         const int chunk = c * G + t;
-        cvalid[c] = chunk < a.d4;
+        cvalid[c] = !MASKED || chunk < a.d4;
         qv[c] = cvalid[c] ? *reinterpret_cast<const f32x4*>(qptr + chunk * 4) : f32x4{0, 0, 0, 0};
     }
     if (a.normalize_q) {
@@ -92,21 +98,33 @@ __global__ __launch_bounds__(kScanThreads) void flat_scan_kernel(ScanArgs a) {
     const int64_t nbatches = (a.n + RB - 1) / RB;
     const int64_t last = a.n - 1;
 
-    for (int64_t b = gw; b < nbatches; b += nwaves_total) {
+    // issue the U*C loads of batch b (nothing waits here)
+    auto load_batch = [&](int64_t b, f32x4 (&x)[U][C]) {
         const int64_t row0 = b * RB + g;
-        f32x4 x[U][C];
+        int64_t pr[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             int64_t r = row0 + (int64_t)u * RPI;
             r = r < last ? r : last;  // clamp: tail lanes re-read the last row, result discarded
-            const int64_t pr = a.rows ? a.rows[r] : r;
-            const float* p = a.X + pr * a.ld + t * 4;
+            pr[u] = SUBSET ? a.rows[r] : r;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float* p = a.X + pr[u] * a.ld + t * 4;
 #pragma unroll
             for (int c = 0; c < C; ++c) {
                 const f32x4* src = reinterpret_cast<const f32x4*>(p + c * G * 4);
-                x[u][c] = cvalid[c] ? (NT ? __builtin_nontemporal_load(src) : *src) : f32x4{0, 0, 0, 0};
+                if (MASKED)
+                    x[u][c] = cvalid[c] ? (NT ? __builtin_nontemporal_load(src) : *src) : f32x4{0, 0, 0, 0};
+                else
+                    x[u][c] = NT ? __builtin_nontemporal_load(src) : *src;
             }
         }
+    };
+
+    // reduce batch b and offer its rows to the top-k list / write its scores
+    auto consume_batch = [&](int64_t b, f32x4 (&x)[U][C]) {
+        const int64_t row0 = b * RB + g;
         float s[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -126,8 +144,17 @@ __global__ __launch_bounds__(kScanThreads) void flat_scan_kernel(ScanArgs a) {
                     acc = fmaf(df.w, df.w, acc);
                 }
             }
-            acc = group_reduce_add<G>(acc);
-            s[u] = METRIC == 0 ? acc : -acc;
+            s[u] = acc;
+        }
+        // the U butterflies are independent: interleave them step by step
+#pragma unroll
+        for (int m = G / 2; m >= 1; m >>= 1) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) s[u] += __shfl_xor(s[u], m);
+        }
+        if (METRIC != 0) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) s[u] = -s[u];
         }
         if (MODE == kModeScores) {
 #pragma unroll
@@ -146,6 +173,28 @@ __global__ __launch_bounds__(kScanThreads) void flat_scan_kernel(ScanArgs a) {
                 const bool pass = (t == 0) && (r < a.n) && (s[u] >= tk.thr_score);
                 if (__ballot(pass)) tk.offer(pass ? make_key(s[u], (uint32_t)r) : 0ull);
             }
+        }
+    };
+
+    if (!DB) {
+        for (int64_t b = gw; b < nbatches; b += nwaves_total) {
+            f32x4 x[U][C];
+            load_batch(b, x);
+            consume_batch(b, x);
+        }
+    } else {
+        f32x4 xa[U][C], xb[U][C];
+        int64_t b = gw;
+        if (b < nbatches) load_batch(b, xa);
+        while (b < nbatches) {
+            const int64_t b1 = b + nwaves_total;
+            if (b1 < nbatches) load_batch(b1, xb);
+            consume_batch(b, xa);
+            if (b1 >= nbatches) break;
+            const int64_t b2 = b1 + nwaves_total;
+            if (b2 < nbatches) load_batch(b2, xa);
+            consume_batch(b1, xb);
+            b = b2;
         }
     }
 
