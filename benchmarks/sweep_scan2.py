@@ -6,9 +6,9 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-points = [(v, b) for v in (401, 411, 801, 811, 201, 211, 1601) for b in (2, 3, 4, 8)]
+points = [(v, b) for v in (101, 201, 301, 401, 601, 801) for b in (1, 2, 3)]
 res = {}
-for rep in range(1):
+for rep in range(2):
     for variant, bpc in points:
         env = dict(os.environ, MVDB_SCAN_VARIANT=str(variant), MVDB_SCAN_BLOCKS_PER_CU=str(bpc))
         out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "150", "--warmup", "20",

@@ -296,7 +296,10 @@ int launch_scan(int metric, int mode, const ScanArgs& a, int nq, int device, hip
     if (sh.G == 64 && sh.C == 2 && metric == MVDB_METRIC_IP && mode == kModeTopK) {
         // tuning hook for the headline shape (d = 512): MVDB_SCAN_VARIANT = U*100 + DB*10 + NT
         switch (env_int("MVDB_SCAN_VARIANT", -1)) {
+            case 101: return launch_scan_inst<64, 2, 1, 0, kModeTopK, true, false>(a, nq, device, s, nblocks);
             case 201: return launch_scan_inst<64, 2, 2, 0, kModeTopK, true, false>(a, nq, device, s, nblocks);
+            case 301: return launch_scan_inst<64, 2, 3, 0, kModeTopK, true, false>(a, nq, device, s, nblocks);
+            case 601: return launch_scan_inst<64, 2, 6, 0, kModeTopK, true, false>(a, nq, device, s, nblocks);
             case 211: return launch_scan_inst<64, 2, 2, 0, kModeTopK, true, true>(a, nq, device, s, nblocks);
             case 400: return launch_scan_inst<64, 2, 4, 0, kModeTopK, false, false>(a, nq, device, s, nblocks);
             case 401: return launch_scan_inst<64, 2, 4, 0, kModeTopK, true, false>(a, nq, device, s, nblocks);
