@@ -244,9 +244,10 @@ int launch_scan_kern(const ScanArgs& a, int nq, int device, hipStream_t stream, 
             nb <= 0)
             nb = 4;
         occ_hw = nb;
-        // measured on MI355X (benchmarks/sweep_scan*.py, 10M x 512): 3 resident blocks (12 waves) per CU
-        // stream faster than 4+ (7.23 vs 7.09 TB/s) and much faster than 2 (5.8 TB/s)
-        occ = std::min(nb, 3);
+        // measured on MI355X (benchmarks/sweep_scan2.py, 10M x 512, gpurun_out/sweep4.log): with ~4
+        // independent 16-B loads per lane, 2 resident blocks (8 waves) per CU reach 7.21-7.24 TB/s; more
+        // waves or more loads in flight per lane are 2-4 % slower, 1 block per CU is latency-starved
+        occ = std::min(nb, 2);
         const int cap_env = env_int("MVDB_SCAN_BLOCKS_PER_CU", 0);  // tuning hook
         if (cap_env > 0) occ = std::min(occ_hw, cap_env);
     }
@@ -296,35 +297,28 @@ int launch_scan(int metric, int mode, const ScanArgs& a, int nq, int device, hip
     if (sh.G == 64 && sh.C == 2 && metric == MVDB_METRIC_IP && mode == kModeTopK) {
         // tuning hook for the headline shape (d = 512): MVDB_SCAN_VARIANT = U*100 + DB*10 + NT
         switch (env_int("MVDB_SCAN_VARIANT", -1)) {
-            case 101: return launch_scan_inst<64, 2, 1, 0, kModeTopK, true, false>(a, nq, device, s, nblocks);
             case 201: return launch_scan_inst<64, 2, 2, 0, kModeTopK, true, false>(a, nq, device, s, nblocks);
-            case 301: return launch_scan_inst<64, 2, 3, 0, kModeTopK, true, false>(a, nq, device, s, nblocks);
-            case 601: return launch_scan_inst<64, 2, 6, 0, kModeTopK, true, false>(a, nq, device, s, nblocks);
-            case 211: return launch_scan_inst<64, 2, 2, 0, kModeTopK, true, true>(a, nq, device, s, nblocks);
             case 400: return launch_scan_inst<64, 2, 4, 0, kModeTopK, false, false>(a, nq, device, s, nblocks);
             case 401: return launch_scan_inst<64, 2, 4, 0, kModeTopK, true, false>(a, nq, device, s, nblocks);
-            case 411: return launch_scan_inst<64, 2, 4, 0, kModeTopK, true, true>(a, nq, device, s, nblocks);
             case 801: return launch_scan_inst<64, 2, 8, 0, kModeTopK, true, false>(a, nq, device, s, nblocks);
-            case 811: return launch_scan_inst<64, 2, 8, 0, kModeTopK, true, true>(a, nq, device, s, nblocks);
-            case 1601: return launch_scan_inst<64, 2, 16, 0, kModeTopK, true, false>(a, nq, device, s, nblocks);
             default: break;
         }
     }
 #define MVDB_SCAN_CASE(G_, C_, U_) \
     if (sh.G == G_ && sh.C == C_) return launch_scan_gcu<G_, C_, U_>(metric, mode, a, nq, device, s, nblocks);
-    MVDB_SCAN_CASE(1, 1, 8)
-    MVDB_SCAN_CASE(2, 1, 8)
-    MVDB_SCAN_CASE(4, 1, 8)
-    MVDB_SCAN_CASE(8, 1, 8)
-    MVDB_SCAN_CASE(16, 1, 8)
-    MVDB_SCAN_CASE(32, 1, 8)
+    MVDB_SCAN_CASE(1, 1, 4)
+    MVDB_SCAN_CASE(2, 1, 4)
+    MVDB_SCAN_CASE(4, 1, 4)
+    MVDB_SCAN_CASE(8, 1, 4)
+    MVDB_SCAN_CASE(16, 1, 4)
+    MVDB_SCAN_CASE(32, 1, 4)
     MVDB_SCAN_CASE(32, 3, 2)
     MVDB_SCAN_CASE(32, 5, 1)
     MVDB_SCAN_CASE(32, 7, 1)
-    MVDB_SCAN_CASE(64, 1, 8)
-    MVDB_SCAN_CASE(64, 2, 8)
+    MVDB_SCAN_CASE(64, 1, 4)
+    MVDB_SCAN_CASE(64, 2, 2)
     MVDB_SCAN_CASE(64, 3, 2)
-    MVDB_SCAN_CASE(64, 4, 2)
+    MVDB_SCAN_CASE(64, 4, 1)
     MVDB_SCAN_CASE(64, 5, 1)
     MVDB_SCAN_CASE(64, 6, 1)
     MVDB_SCAN_CASE(64, 7, 1)
