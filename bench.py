@@ -65,15 +65,21 @@ def cpu_baseline(native, idx, d, k, queries_host, full_rows, budget_s=20.0):
         if time.perf_counter() - t0 > budget_s / 2 or nq >= 64:
             break
     t1 = time.perf_counter() - t0
-    cores = max(1, min(flat.max_threads(), len(os.sched_getaffinity(0))))
-    nq_mt = 0
-    t0 = time.perf_counter()
-    while True:
-        flat.flat_search(x, queries_host[nq_mt % len(queries_host)], k, nthreads=cores)
-        nq_mt += 1
-        if time.perf_counter() - t0 > budget_s / 2 or nq_mt >= 256:
-            break
-    t2 = time.perf_counter() - t0
+    avail = max(1, min(flat.max_threads(), len(os.sched_getaffinity(0))))
+    # multi-threaded variant of the same port (rows partitioned over OpenMP threads): try a few
+    # thread counts — past the host's memory bandwidth more threads only add contention — keep the best
+    best = (0.0, 1)
+    for cores in sorted({min(avail, c) for c in (8, 16, 32, 64, avail)}):
+        nq_mt = 0
+        t0 = time.perf_counter()
+        while True:
+            flat.flat_search(x, queries_host[nq_mt % len(queries_host)], k, nthreads=cores)
+            nq_mt += 1
+            if time.perf_counter() - t0 > budget_s / 10 or nq_mt >= 64:
+                break
+        rate = nq_mt / (time.perf_counter() - t0)
+        if rate > best[0]:
+            best = (rate, cores)
     scale = sample / float(full_rows)
     return {
         "value": round(nq / t1 * scale, 4),
@@ -82,8 +88,9 @@ def cpu_baseline(native, idx, d, k, queries_host, full_rows, budget_s=20.0):
         "kind": "port",
         "sample": (f"first {sample} of {full_rows} rows x {d} fp32, {nq} queries, 1 thread (faiss uses one thread "
                    f"at nq=1); rate scaled x{scale:g} to the full corpus"),
-        "all_cores_value": round(nq_mt / t2 * scale, 4),
-        "all_cores": cores,
+        "multithread_value": round(best[0] * scale, 4),
+        "multithread_cores": best[1],
+        "host_cores_available": avail,
         "gb_per_s_1thread": round(sample * d * 4 * nq / t1 / 1e9, 2),
     }
 
