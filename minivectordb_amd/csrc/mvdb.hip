@@ -376,6 +376,40 @@ int launch_mfma_inst(const MfmaScanArgs& a, int device, hipStream_t stream, int*
     return 0;
 }
 
+template <int KB>
+int launch_mfma2_inst(const MfmaScanArgs& a, int device, hipStream_t stream, int* nblocks_out) {
+    auto kern = flat_scan_mfma2_kernel<KB>;
+    const size_t lds = (size_t)kScanWaves * kWaveLdsBytes + (size_t)kScanWaves * 16 * a.k * 8;
+    static size_t lds_set = 0;
+    if (lds > 48 * 1024 && lds > lds_set) {
+        MVDB_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        lds_set = lds;
+    }
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, kScanThreads, lds) != hipSuccess || nb <= 0)
+        nb = 1;
+    nb = std::min(nb, std::max(1, env_int("MVDB_MFMA_BLOCKS_PER_CU", 2)));
+    const int64_t ntiles = (a.n + 15) / 16;
+    const int64_t want = (ntiles + kScanWaves - 1) / kScanWaves;
+    const int nblocks = (int)std::max<int64_t>(1, std::min<int64_t>(want, (int64_t)device_cus(device) * nb));
+    *nblocks_out = nblocks;
+    int slot = prof_begin("ip_scan_mfma", stream);
+    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(kScanThreads), lds, stream, a);
+    prof_end(slot, stream);
+    MVDB_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_mfma2(int KB, const MfmaScanArgs& a, int device, hipStream_t s, int* nb) {
+    switch (KB) {
+        case 8: return launch_mfma2_inst<8>(a, device, s, nb);
+        case 16: return launch_mfma2_inst<16>(a, device, s, nb);
+        case 24: return launch_mfma2_inst<24>(a, device, s, nb);
+        case 32: return launch_mfma2_inst<32>(a, device, s, nb);
+        default: return fail(MVDB_ERR_ARG, "no staged multi-query kernel for d = %d", KB * 16);
+    }
+}
+
 template <int NG>
 int launch_mfma_ng(int KB, const MfmaScanArgs& a, int device, hipStream_t s, int* nb) {
     switch (KB) {
@@ -447,10 +481,13 @@ int search_core(const mvdb_index* idx, Workspace* ws, const float* q_dev, int nq
             ma.k = k;
             ma.cand = ws->cand.p;
             int nblocks = 0;
+            const int KB = idx->d / 16;
             if (take > 16)
-                MVDB_TRY(launch_mfma_ng<2>(idx->d / 16, ma, idx->device, s, &nblocks));
+                MVDB_TRY(launch_mfma_ng<2>(KB, ma, idx->device, s, &nblocks));
+            else if (KB % 8 == 0 && env_int("MVDB_MFMA_V", 2) == 2)
+                MVDB_TRY(launch_mfma2(KB, ma, idx->device, s, &nblocks));  // LDS-DMA staged, coalesced
             else
-                MVDB_TRY(launch_mfma_ng<1>(idx->d / 16, ma, idx->device, s, &nblocks));
+                MVDB_TRY(launch_mfma_ng<1>(KB, ma, idx->device, s, &nblocks));
             MergeArgs mg;
             mg.keys = ws->cand.p;
             mg.nlists = nblocks;
