@@ -159,6 +159,8 @@ typedef struct mvdb_encoder_cfg {
     int type_vocab;
     int position_offset; /* 0 for BERT; padding_idx+1 for XLM-R style position ids */
     float ln_eps;
+    int pooling;         /* 0 = attention-masked mean (e5, embedding_model.py:50-53);
+                            1 = first valid token / CLS (BGE-M3 dense_vecs, embedding_model.py:74-78) */
 } mvdb_encoder_cfg;
 
 /* Weight table: device pointers (fp32, PyTorch nn.Linear layout [out,in]) in the order given by
@@ -170,7 +172,7 @@ int mvdb_encoder_create(const mvdb_encoder_cfg* cfg, const void* const* weight_p
                         mvdb_encoder** out);
 int mvdb_encoder_free(mvdb_encoder* enc);
 
-/* ids[B,S], mask[B,S] (int32, host) -> out[B,H] pooled + L2-normalised (host).
+/* ids[B,S], mask[B,S] (int32, host) -> out[B,H] pooled (cfg.pooling) + L2-normalised (host).
  * compute: 0 = exact-fp32 MFMA, 1 = bf16 MFMA operands with fp32 accumulate. */
 int mvdb_encoder_forward(mvdb_encoder* enc, const int32_t* ids_host, const int32_t* mask_host,
                          int B, int S, int compute, float* out_host);

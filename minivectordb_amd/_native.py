@@ -45,6 +45,7 @@ class EncoderCfg(ctypes.Structure):
         ("type_vocab", ctypes.c_int),
         ("position_offset", ctypes.c_int),
         ("ln_eps", ctypes.c_float),
+        ("pooling", ctypes.c_int),
     ]
 
 

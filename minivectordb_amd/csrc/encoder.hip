@@ -178,17 +178,19 @@ __global__ __launch_bounds__(256) void ln_kernel(const float* __restrict__ y,
 }
 
 // out[b,:] = normalize(mean over the sequence's tokens)   — average_pool + F.normalize(eps=1e-12)
+// pooling == 1: the first valid token (CLS) instead of the mean — BGE-M3's dense_vecs
 __global__ __launch_bounds__(256) void pool_norm_kernel(const float* __restrict__ x,
                                                         const int* __restrict__ seq_start, int H,
-                                                        float* __restrict__ out) {
+                                                        int pooling, float* __restrict__ out) {
     __shared__ float red[256];
     const int b = blockIdx.x;
     const int s0 = seq_start[b], len = seq_start[b + 1] - s0;
+    const int span = pooling == 1 ? (len > 0 ? 1 : 0) : len;
     float sq = 0.f;
     for (int c = threadIdx.x; c < H; c += blockDim.x) {
         float s = 0.f;
-        for (int t = 0; t < len; ++t) s += x[(int64_t)(s0 + t) * H + c];
-        const float e = s / (float)len;  // len == 0 -> NaN, as the reference's 0/0
+        for (int t = 0; t < span; ++t) s += x[(int64_t)(s0 + t) * H + c];
+        const float e = s / (float)span;  // empty sequence -> NaN, as the reference's 0/0
         out[(int64_t)b * H + c] = e;
         sq += e * e;
     }
@@ -482,6 +484,7 @@ int check_cfg(const mvdb_encoder_cfg* c) {
     if (c->hidden % GBK || c->intermediate % GBK)
         return fail(MVDB_ERR_ARG, "hidden and intermediate must be multiples of %d", GBK);
     if (c->hidden > 1024) return fail(MVDB_ERR_ARG, "hidden > 1024 not supported");
+    if (c->pooling != 0 && c->pooling != 1) return fail(MVDB_ERR_ARG, "unknown pooling mode %d", c->pooling);
     return 0;
 }
 
@@ -585,7 +588,7 @@ int forward_core(mvdb_encoder* e, const int32_t* ids, const int32_t* mask, int B
     }
     prof_end(pslot, s);
 #undef MVDB_VPT_SWITCH
-    hipLaunchKernelGGL(pool_norm_kernel, dim3(B), dim3(256), 0, s, e->x, e->seq_start, H, out);
+    hipLaunchKernelGGL(pool_norm_kernel, dim3(B), dim3(256), 0, s, e->x, e->seq_start, H, c.pooling, out);
     if (hidden)
         hipLaunchKernelGGL(unpack_hidden_kernel, dim3((unsigned)Tmax), dim3(256), 0, s, e->x, e->rank,
                            e->seq_start, S, H, hidden);

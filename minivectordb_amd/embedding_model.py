@@ -11,10 +11,13 @@ Reference behaviour kept (minivectordb/embedding_model.py):
 PyTorch is used only as the container of the weights (state_dict -> device tensors) and the HF
 tokenizer stays on the host, as in the reference.
 
+BGE-M3 (:73-79) is served by the same encoder with XLM-R position ids and CLS pooling
+(``dense_vecs`` = normalised first-token state); its sparse / ColBERT heads are not used by the
+reference and are not built.
+
 Not available in this build (SURVEY.md §8f "next"): the quantised ONNX USE model — its blob is
-absent from the reference tree (.MISSING_LARGE_BLOBS) and cannot be restated — and BGE-M3 (XLM-R
-large with CLS pooling inside FlagEmbedding).  Selecting them raises ``NotImplementedError``
-instead of silently computing something else.
+absent from the reference tree (.MISSING_LARGE_BLOBS) and cannot be restated.  Selecting it raises
+``NotImplementedError`` instead of silently computing something else.
 
 Extras for offline / batched use: ``model_path`` (local HF directory), or ``state_dict`` +
 ``config`` (+ ``tokenizer``) to inject weights; ``extract_embeddings_batch`` and ``encode_ids``.
@@ -34,7 +37,7 @@ class AlternativeModel(str, Enum):
 class GpuEncoder:
     """mvdb_encoder* + the torch tensors that own its weights."""
 
-    def __init__(self, config, state_dict, device=0):
+    def __init__(self, config, state_dict, device=0, pooling="mean"):
         import torch
         from . import _native
         self._native = _native
@@ -51,7 +54,7 @@ class GpuEncoder:
             heads=get("num_attention_heads"), intermediate=get("intermediate_size"),
             max_positions=get("max_position_embeddings"), type_vocab=get("type_vocab_size", 2),
             position_offset=(pad + 1) if model_type in ("xlm-roberta", "roberta") else 0,
-            ln_eps=float(get("layer_norm_eps", 1e-12)))
+            ln_eps=float(get("layer_norm_eps", 1e-12)), pooling={"mean": 0, "cls": 1}[pooling])
         if get("hidden_act", "gelu") != "gelu":
             raise ValueError("only the erf-GELU activation of BERT/XLM-R is implemented")
         n = lib.mvdb_encoder_weight_count(ctypes.byref(self.cfg))
@@ -168,9 +171,18 @@ class EmbeddingModel:
             self.model = GpuEncoder(hf.config, hf.state_dict(), device=self._device)
             del hf
         elif self.alternative_model == AlternativeModel.bgem3:
-            raise NotImplementedError(
-                "BGE-M3 (FlagEmbedding's XLM-R-large with CLS pooling) is not implemented in minivectordb_amd yet; "
-                "use AlternativeModel.small or AlternativeModel.large")
+            # BGE-M3's dense vector = L2-normalised CLS state of an XLM-R-large encoder (what
+            # FlagEmbedding's BGEM3FlagModel.encode(...)['dense_vecs'] returns, embedding_model.py:74-78)
+            if self._state_dict is not None:
+                self.model = GpuEncoder(self._config, self._state_dict, device=self._device, pooling="cls")
+                return
+            from transformers import AutoModel, AutoTokenizer
+            name = self._model_path or 'BAAI/bge-m3'
+            if self.tokenizer is None:
+                self.tokenizer = AutoTokenizer.from_pretrained(name)
+            hf = AutoModel.from_pretrained(name)
+            self.model = GpuEncoder(hf.config, hf.state_dict(), device=self._device, pooling="cls")
+            del hf
 
     # ---- e5 path ---------------------------------------------------------------------------------------
     def _tokenize(self, texts):
@@ -195,7 +207,12 @@ class EmbeddingModel:
         return self.encode_ids(ids, mask)
 
     def extract_embeddings_bgem3(self, text):
-        raise NotImplementedError("BGE-M3 is not implemented in minivectordb_amd yet")
+        if self.tokenizer is None:
+            raise RuntimeError("no tokenizer loaded: pass tokenizer=... or model_path=... to EmbeddingModel")
+        batch = self.tokenizer([text], max_length=512, padding=True, truncation=True, return_tensors='np')
+        ids = np.asarray(batch['input_ids'], dtype=np.int32)
+        mask = np.asarray(batch['attention_mask'], dtype=np.int32)
+        return self.encode_ids(ids, mask)[0].tolist()
 
     def extract_embeddings_quant_onnx(self, text):
         raise NotImplementedError("the quantised ONNX model is not available in minivectordb_amd")

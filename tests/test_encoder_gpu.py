@@ -93,8 +93,26 @@ def test_embedding_model_api(gpu):
     np.testing.assert_allclose(batch[0], e, atol=2e-6)
     with pytest.raises(NotImplementedError):
         EmbeddingModel()  # quantised ONNX default: blob absent from the reference tree
-    with pytest.raises(NotImplementedError):
-        EmbeddingModel(use_quantized_onnx_model=False)  # bge-m3 default alternative
+    # bge-m3 (the reference's default alternative): XLM-R position ids + CLS pooling + normalise;
+    # no prompt prefix (embedding_model.py:74-78 passes the raw text)
+    xcfg = E.make_config("xlmr-tiny")
+    xw = E.make_weights(xcfg, 9)
+
+    class XTok(Tok):
+        def __call__(self, texts, **kw):
+            out = Tok.__call__(self, texts, **kw)
+            out["input_ids"] = np.where(out["attention_mask"] == 1, out["input_ids"] % 140 + 2, 1)
+            return out
+
+    mb = EmbeddingModel(use_quantized_onnx_model=False, state_dict={k: torch.from_numpy(v) for k, v in xw.items()},
+                        config=xcfg, tokenizer=XTok())
+    assert mb.alternative_model == AlternativeModel.bgem3
+    eb = mb.extract_embeddings("hello world")
+    assert isinstance(eb, list) and len(eb) == 128
+    tb = XTok()(["hello world"])
+    hb, _ = E.numpy_forward(xcfg, xw, tb["input_ids"].astype(np.int32), tb["attention_mask"].astype(np.int32))
+    cls = hb[0, 0] / np.linalg.norm(hb[0, 0])
+    np.testing.assert_allclose(eb, cls, atol=2e-5)
     m2 = EmbeddingModel(use_quantized_onnx_model=False, e5_model_size="small",
                         state_dict={k: torch.from_numpy(v) for k, v in w.items()}, config=cfg, tokenizer=Tok())
     assert m2.alternative_model == AlternativeModel.small
