@@ -376,10 +376,10 @@ int launch_mfma_inst(const MfmaScanArgs& a, int device, hipStream_t stream, int*
     return 0;
 }
 
-template <int KB>
+template <int KB, int NG>
 int launch_mfma2_inst(const MfmaScanArgs& a, int device, hipStream_t stream, int* nblocks_out) {
-    auto kern = flat_scan_mfma2_kernel<KB>;
-    const size_t lds = (size_t)kScanWaves * kWaveLdsBytes + (size_t)kScanWaves * 16 * a.k * 8;
+    auto kern = flat_scan_mfma2_kernel<KB, NG>;
+    const size_t lds = (size_t)kScanWaves * kWaveLdsBytes + (size_t)kScanWaves * NG * 16 * a.k * 8;
     static size_t lds_set = 0;
     if (lds > 48 * 1024 && lds > lds_set) {
         MVDB_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -400,12 +400,13 @@ int launch_mfma2_inst(const MfmaScanArgs& a, int device, hipStream_t stream, int
     return 0;
 }
 
+template <int NG>
 int launch_mfma2(int KB, const MfmaScanArgs& a, int device, hipStream_t s, int* nb) {
     switch (KB) {
-        case 8: return launch_mfma2_inst<8>(a, device, s, nb);
-        case 16: return launch_mfma2_inst<16>(a, device, s, nb);
-        case 24: return launch_mfma2_inst<24>(a, device, s, nb);
-        case 32: return launch_mfma2_inst<32>(a, device, s, nb);
+        case 8: return launch_mfma2_inst<8, NG>(a, device, s, nb);
+        case 16: return launch_mfma2_inst<16, NG>(a, device, s, nb);
+        case 24: return launch_mfma2_inst<24, NG>(a, device, s, nb);
+        case 32: return launch_mfma2_inst<32, NG>(a, device, s, nb);
         default: return fail(MVDB_ERR_ARG, "no staged multi-query kernel for d = %d", KB * 16);
     }
 }
@@ -472,6 +473,7 @@ int search_core(const mvdb_index* idx, Workspace* ws, const float* q_dev, int nq
             // two query groups per pass (NG = 2) currently run at one wave per SIMD and lose to two
             // NG = 1 passes (measured 11.8 ms vs 2 x 3.6 ms at 10M x 512); opt-in until tuned
             const int take = (left > 16 && env_int("MVDB_MFMA_NG2", 0)) ? std::min(left, 32) : std::min(left, 16);
+            const bool staged = idx->d % 128 == 0 && env_int("MVDB_MFMA_V", 2) == 2;
             MfmaScanArgs ma;
             ma.X = idx->X;
             ma.n = n;
@@ -482,10 +484,12 @@ int search_core(const mvdb_index* idx, Workspace* ws, const float* q_dev, int nq
             ma.cand = ws->cand.p;
             int nblocks = 0;
             const int KB = idx->d / 16;
-            if (take > 16)
+            if (take > 16 && staged)
+                MVDB_TRY(launch_mfma2<2>(KB, ma, idx->device, s, &nblocks));
+            else if (take > 16)
                 MVDB_TRY(launch_mfma_ng<2>(KB, ma, idx->device, s, &nblocks));
-            else if (KB % 8 == 0 && env_int("MVDB_MFMA_V", 2) == 2)
-                MVDB_TRY(launch_mfma2(KB, ma, idx->device, s, &nblocks));  // LDS-DMA staged, coalesced
+            else if (staged)
+                MVDB_TRY(launch_mfma2<1>(KB, ma, idx->device, s, &nblocks));  // LDS-DMA staged, coalesced
             else
                 MVDB_TRY(launch_mfma_ng<1>(KB, ma, idx->device, s, &nblocks));
             MergeArgs mg;

@@ -166,7 +166,7 @@ constexpr int kStageFloats = 128;                      // per row and stage (512
 constexpr int kStageBytes = 16 * kStageFloats * 4;     // 8 KiB per wave and stage
 constexpr int kWaveLdsBytes = 2 * kStageBytes;         // double buffered
 
-template <int KB>
+template <int KB, int NG>
 __global__ __launch_bounds__(kScanThreads) void flat_scan_mfma2_kernel(MfmaScanArgs a) {
     static_assert(KB % 8 == 0, "d must be a multiple of 128 for the staged kernel");
     constexpr int NS = KB / 8;  // stages per tile
@@ -174,22 +174,25 @@ __global__ __launch_bounds__(kScanThreads) void flat_scan_mfma2_kernel(MfmaScanA
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int k = a.k;
     unsigned char* wbuf = smem + (size_t)wave * kWaveLdsBytes;
-    uint64_t* lists = reinterpret_cast<uint64_t*>(smem + (size_t)kScanWaves * kWaveLdsBytes);  // [4][16][k]
-    uint64_t* mylists = lists + (size_t)wave * 16 * k;
-    for (int e = lane; e < 16 * k; e += 64) mylists[e] = 0ull;
+    uint64_t* lists = reinterpret_cast<uint64_t*>(smem + (size_t)kScanWaves * kWaveLdsBytes);  // [4][NG*16][k]
+    uint64_t* mylists = lists + (size_t)wave * NG * 16 * k;
+    for (int e = lane; e < NG * 16 * k; e += 64) mylists[e] = 0ull;
 
     // ---- query fragments -> registers: qa[kb] = Q[l&15][16kb + 4(l>>4) .. +3] -----------------------
-    f32x4m qa[KB];
-    {
-        const int qi = lane & 15;
+    f32x4m qa[NG][KB];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const int qi = g * 16 + (lane & 15);
         const float* qp = a.q + (int64_t)qi * a.ld + 4 * (lane >> 4);
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb)
-            qa[kb] = qi < a.nq ? *reinterpret_cast<const f32x4m*>(qp + 16 * kb) : f32x4m{0, 0, 0, 0};
+            qa[g][kb] = qi < a.nq ? *reinterpret_cast<const f32x4m*>(qp + 16 * kb) : f32x4m{0, 0, 0, 0};
     }
-    float thr[4];
+    float thr[NG][4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) thr[r] = (4 * (lane >> 4) + r) < a.nq ? -INFINITY : INFINITY;
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) thr[g][r] = (g * 16 + 4 * (lane >> 4) + r) < a.nq ? -INFINITY : INFINITY;
 
     const int64_t ntiles = (a.n + 15) / 16;
     const int64_t nwaves_total = (int64_t)gridDim.x * kScanWaves;
@@ -217,7 +220,9 @@ __global__ __launch_bounds__(kScanThreads) void flat_scan_mfma2_kernel(MfmaScanA
     if (tile < ntiles) issue_stage(tile, 0, 0);
     while (tile < ntiles) {
         const int64_t next_tile = tile + nwaves_total;
-        f32x4m acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+        f32x4m acc0[NG], acc1[NG];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) acc0[g] = acc1[g] = f32x4m{0, 0, 0, 0};
 #pragma unroll
         for (int ks = 0; ks < NS; ++ks) {
             const int buf = cnt & 1;
@@ -238,36 +243,40 @@ __global__ __launch_bounds__(kScanThreads) void flat_scan_mfma2_kernel(MfmaScanA
             for (int kbl = 0; kbl < 8; ++kbl) {
                 const f32x4m xb = *reinterpret_cast<const f32x4m*>(sb + (((4 * kbl + fkg) ^ fr) << 4));
                 const int kb = ks * 8 + kbl;
-                if (kbl & 1) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[kb][j], xb[j], acc1, 0, 0, 0);
-                } else {
+                for (int j = 0; j < 4; ++j) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[kb][j], xb[j], acc0, 0, 0, 0);
+                    for (int g = 0; g < NG; ++g) {
+                        if (kbl & 1)
+                            acc1[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[g][kb][j], xb[j], acc1[g], 0, 0, 0);
+                        else
+                            acc0[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[g][kb][j], xb[j], acc0[g], 0, 0, 0);
+                    }
                 }
             }
             ++cnt;
         }
-        const f32x4m acc = acc0 + acc1;
         // ---- selection (as in v1) -----------------------------------------------------------------
         const bool rvalid = tile * 16 + fr <= last;
         const uint32_t rowid = (uint32_t)(tile * 16 + fr);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float s = acc[r];
-            uint64_t mask = __ballot(rvalid && s >= thr[r]);
-            while (mask) {
-                const int src = __ffsll((long long)mask) - 1;
-                mask &= mask - 1;
-                const int qq = 4 * (src >> 4) + r;
-                if (qq >= a.nq) continue;
-                const float sv = __uint_as_float(__builtin_amdgcn_readlane((int)__float_as_uint(s), src));
-                const uint32_t rv = (uint32_t)__builtin_amdgcn_readlane((int)rowid, src);
-                const uint64_t kth = lds_list_insert(mylists + (size_t)qq * k, k, make_key(sv, rv), lane);
-                const float t = kth ? key_score(kth) : -INFINITY;
-                if ((lane >> 4) == (src >> 4)) thr[r] = t;
+        for (int g = 0; g < NG; ++g) {
+            const f32x4m acc = acc0[g] + acc1[g];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float s = acc[r];
+                uint64_t mask = __ballot(rvalid && s >= thr[g][r]);
+                while (mask) {
+                    const int src = __ffsll((long long)mask) - 1;
+                    mask &= mask - 1;
+                    const int qq = g * 16 + 4 * (src >> 4) + r;
+                    if (qq >= a.nq) continue;
+                    const float sv = __uint_as_float(__builtin_amdgcn_readlane((int)__float_as_uint(s), src));
+                    const uint32_t rv = (uint32_t)__builtin_amdgcn_readlane((int)rowid, src);
+                    const uint64_t kth = lds_list_insert(mylists + (size_t)qq * k, k, make_key(sv, rv), lane);
+                    const float t = kth ? key_score(kth) : -INFINITY;
+                    if ((lane >> 4) == (src >> 4)) thr[g][r] = t;
+                }
             }
         }
         tile = next_tile;
@@ -279,7 +288,7 @@ __global__ __launch_bounds__(kScanThreads) void flat_scan_mfma2_kernel(MfmaScanA
         tk.init(k);
 #pragma unroll 1
         for (int w = 0; w < kScanWaves; ++w) {
-            const uint64_t* l = lists + ((size_t)w * 16 + qq) * k;
+            const uint64_t* l = lists + ((size_t)w * NG * 16 + qq) * k;
             tk.offer(lane < k ? l[lane] : 0ull);
         }
         if (lane < k) a.cand[((int64_t)qq * gridDim.x + blockIdx.x) * k + lane] = tk.key;
