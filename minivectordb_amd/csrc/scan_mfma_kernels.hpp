@@ -226,6 +226,11 @@ __global__ __launch_bounds__(kScanThreads) void flat_scan_mfma2_kernel(MfmaScanA
 #pragma unroll
         for (int ks = 0; ks < NS; ++ks) {
             const int buf = cnt & 1;
+            // Pin the order: every ds_read/MFMA of the previous stage stays ABOVE this point (that stage
+            // read the buffer the DMAs below overwrite), and nothing of this stage's compute moves above
+            // the counted wait.  Without the fences hipcc hoisted some LDS-DMA instructions into the
+            // previous stage's read sequence (seen in the ISA; nondeterministic wrong scores).
+            __builtin_amdgcn_sched_barrier(0);
             // prefetch the following stage (of this tile or of the next one) into the other buffer
             bool more = true;
             if (ks + 1 < NS)
@@ -238,6 +243,7 @@ __global__ __launch_bounds__(kScanThreads) void flat_scan_mfma2_kernel(MfmaScanA
                 asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // this stage landed, next one in flight
             else
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
             const unsigned char* sb = wbuf + buf * kStageBytes + fr * (kStageFloats * 4);
 #pragma unroll
             for (int kbl = 0; kbl < 8; ++kbl) {
