@@ -470,10 +470,11 @@ int search_core(const mvdb_index* idx, Workspace* ws, const float* q_dev, int nq
         MVDB_TRY(ws->cand.reserve((size_t)32 * grid_ub * k));
         for (int q0 = 0; q0 < nq;) {
             const int left = nq - q0;
-            // two query groups per pass (NG = 2) currently run at one wave per SIMD and lose to two
-            // NG = 1 passes (measured 11.8 ms vs 2 x 3.6 ms at 10M x 512); opt-in until tuned
-            const int take = (left > 16 && env_int("MVDB_MFMA_NG2", 0)) ? std::min(left, 32) : std::min(left, 16);
+            // staged kernel: 32 queries per pass (two query groups share each B fragment); the v1
+            // kernel with two groups runs at one wave per SIMD and loses to two 16-query passes
             const bool staged = idx->d % 128 == 0 && env_int("MVDB_MFMA_V", 2) == 2;
+            const int take = (left > 16 && env_int("MVDB_MFMA_NG2", staged ? 1 : 0)) ? std::min(left, 32)
+                                                                                     : std::min(left, 16);
             MfmaScanArgs ma;
             ma.X = idx->X;
             ma.n = n;

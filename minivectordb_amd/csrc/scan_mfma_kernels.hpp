@@ -215,9 +215,21 @@ __global__ __launch_bounds__(kScanThreads) void flat_scan_mfma2_kernel(MfmaScanA
         }
     };
 
+    // Stage pipeline (per wave, private buffers, no block barrier): stage s = (tile, ks).
+    //   wait until stage s has landed (stage s+1's 8 DMAs may stay in flight: vmcnt(8))
+    //   read its 8 B fragments LDS -> registers, wait for them (lgkmcnt(0))
+    //   -> buffer (s & 1) is free again: issue the DMAs of stage s+2 into it
+    //   64*NG... MFMAs on the fragments (the DMA issue slots hide among them)
+    // The sched_barriers pin that order: hipcc otherwise hoists LDS-DMA instructions into the reads of
+    // the buffer they overwrite (seen in the ISA; nondeterministic wrong scores).
     int64_t tile = (int64_t)blockIdx.x * kScanWaves + wave;
-    unsigned cnt = 0;  // stages issued so far (buffer = cnt & 1)
-    if (tile < ntiles) issue_stage(tile, 0, 0);
+    unsigned cnt = 0;  // stages consumed so far (buffer = cnt & 1)
+    auto stage_tile = [&](int64_t t, int ks_abs) { return t + (int64_t)(ks_abs / NS) * nwaves_total; };
+    if (tile < ntiles) {
+        issue_stage(tile, 0, 0);
+        const int64_t t1 = stage_tile(tile, 1);
+        if (t1 < ntiles) issue_stage(t1, 1 % NS, 1);
+    }
     while (tile < ntiles) {
         const int64_t next_tile = tile + nwaves_total;
         f32x4m acc0[NG], acc1[NG];
@@ -226,37 +238,32 @@ __global__ __launch_bounds__(kScanThreads) void flat_scan_mfma2_kernel(MfmaScanA
 #pragma unroll
         for (int ks = 0; ks < NS; ++ks) {
             const int buf = cnt & 1;
-            // Pin the order: every ds_read/MFMA of the previous stage stays ABOVE this point (that stage
-            // read the buffer the DMAs below overwrite), and nothing of this stage's compute moves above
-            // the counted wait.  Without the fences hipcc hoisted some LDS-DMA instructions into the
-            // previous stage's read sequence (seen in the ISA; nondeterministic wrong scores).
+            const int64_t t1 = stage_tile(tile, ks + 1), t2 = stage_tile(tile, ks + 2);
             __builtin_amdgcn_sched_barrier(0);
-            // prefetch the following stage (of this tile or of the next one) into the other buffer
-            bool more = true;
-            if (ks + 1 < NS)
-                issue_stage(tile, ks + 1, buf ^ 1);
-            else if (next_tile < ntiles)
-                issue_stage(next_tile, 0, buf ^ 1);
-            else
-                more = false;
-            if (more)
-                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // this stage landed, next one in flight
+            if (t1 < ntiles)
+                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // this stage landed, s+1 still in flight
             else
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
             const unsigned char* sb = wbuf + buf * kStageBytes + fr * (kStageFloats * 4);
+            f32x4m xb[8];
+#pragma unroll
+            for (int kbl = 0; kbl < 8; ++kbl)
+                xb[kbl] = *reinterpret_cast<const f32x4m*>(sb + (((4 * kbl + fkg) ^ fr) << 4));
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            if (t2 < ntiles) issue_stage(t2, (ks + 2) % NS, buf);  // refill the buffer just drained
 #pragma unroll
             for (int kbl = 0; kbl < 8; ++kbl) {
-                const f32x4m xb = *reinterpret_cast<const f32x4m*>(sb + (((4 * kbl + fkg) ^ fr) << 4));
                 const int kb = ks * 8 + kbl;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
 #pragma unroll
                     for (int g = 0; g < NG; ++g) {
                         if (kbl & 1)
-                            acc1[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[g][kb][j], xb[j], acc1[g], 0, 0, 0);
+                            acc1[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[g][kb][j], xb[kbl][j], acc1[g], 0, 0, 0);
                         else
-                            acc0[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[g][kb][j], xb[j], acc0[g], 0, 0, 0);
+                            acc0[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[g][kb][j], xb[kbl][j], acc0[g], 0, 0, 0);
                     }
                 }
             }
