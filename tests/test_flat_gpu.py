@@ -438,3 +438,24 @@ def test_multi_query_mfma_pass_matches_oracle(native, n, d, k, nq):
     assert np.array_equal(I2[0], I2[2]) and np.array_equal(I2[0], I[0])
     assert I2[3].tolist()[:min(k, n)] == list(range(min(k, n)))  # zero query: all scores 0, ties by row
     idx.close()
+
+
+def test_multi_query_pass_is_deterministic(native):
+    """Regression for a scheduling race in the LDS-DMA staged kernel (hipcc hoisted DMA instructions
+    into the reads of the buffer they overwrite): repeated 32-query passes must return bit-identical
+    results, equal to the per-query searches."""
+    n, d, k = 40000, 512, 10
+    x = _corpus(n, d)
+    idx = native.FlatIndex(d)
+    idx.add(x)
+    for nq in (17, 32):
+        q = _corpus(nq, d, seed=4242)
+        ref = [idx.search(q[i], k) for i in range(nq)]
+        D0, I0 = idx.search(q, k)
+        for _ in range(6):
+            D, I = idx.search(q, k)
+            assert np.array_equal(I, I0) and np.array_equal(D, D0)
+        for i in range(nq):
+            assert np.array_equal(ref[i][1][0], I0[i])
+            np.testing.assert_allclose(ref[i][0][0], D0[i], atol=2e-6, rtol=0)
+    idx.close()
