@@ -199,7 +199,81 @@ def mixed_dims():
     return ops
 
 
+def _fuzz(kind, seed, nops=140):
+    """Seeded random mix of stores, batch stores, deletes and searches with random filters (flat or
+    sharded): exercises interleavings the hand-written scenarios do not."""
+    import random
+    rnd = random.Random(seed)
+    d = 48
+    path = f"fuzz_{kind}_{seed}" + ("" if kind == "sharded" else ".pkl")
+    kw = {"shard_size": 9} if kind == "sharded" else {}
+    ops = [{"op": "wipe", "path": path}, {"op": "open", "kind": kind, "path": path, "kw": kw}]
+    live, next_id = [], 0
+    colours = ["red", "green", "blue"]
+
+    def meta(i):
+        m = {"g": i % 4, "score": (i * 37) % 101, "colour": colours[i % 3]}
+        if i % 2:
+            m["tags"] = [f"t{i % 5}", "x"]
+        return m
+
+    def rand_filter():
+        c = rnd.randrange(7)
+        if c == 0:
+            return {"filter": {"g": rnd.randrange(4)}}
+        if c == 1:
+            return {"filter": {"score": {rnd.choice(["$gt", "$gte", "$lt", "$lte", "$ne"]): rnd.randrange(101)}}}
+        if c == 2:
+            return {"or": [{"colour": rnd.choice(colours)}, {"g": rnd.randrange(4)}]}
+        if c == 3:
+            return {"exclude": {"colour": rnd.choice(colours)}}
+        if c == 4:
+            return {"filter": {"tags": {"$in": f"t{rnd.randrange(5)}"}}, "exclude": [{"g": rnd.randrange(4)}]}
+        if c == 5:
+            return {"filter": [{"g": rnd.randrange(4)}, {"colour": rnd.choice(colours)}],
+                    "or": {"score": {"$gte": rnd.randrange(101)}}}
+        return {}
+
+    for step in range(nops):
+        r = rnd.random()
+        if r < 0.30 or not live:
+            ops.append({"op": "store", "id": next_id, "vec": {"synth": [900 + seed, next_id, d]}, "meta": meta(next_id)})
+            live.append(next_id)
+            next_id += 1
+        elif r < 0.40:
+            n = rnd.randrange(1, 12)
+            ids = list(range(next_id, next_id + n))
+            ops.append({"op": "store_batch", "ids": ids, "vecs": {"synth_block": [900 + seed, next_id, n, d]},
+                        "metas": [meta(i) for i in ids]})
+            live += ids
+            next_id += n
+        elif r < 0.52:
+            victim = live.pop(rnd.randrange(len(live)))
+            if kind == "sharded":
+                extra = [live.pop(rnd.randrange(len(live)))] if live and rnd.random() < 0.4 else []
+                ops.append({"op": "delete_batch", "ids": [victim] + extra})
+            else:
+                ops.append({"op": "delete", "id": victim})
+        elif r < 0.56:
+            ops.append({"op": "state"})
+        elif r < 0.60 and kind == "flat":
+            ops += [{"op": "persist"}, {"op": "reopen"}]
+        elif r < 0.60:
+            ops.append({"op": "reopen"})
+        else:
+            op = {"op": "search", "q": q(rnd.randrange(10_000), d), "k": rnd.choice([1, 3, 5, 10, 70])}
+            op.update(rand_filter())
+            if rnd.random() < 0.2:
+                op["autocut"] = True
+            ops.append(op)
+    ops.append({"op": "state"})
+    return ops
+
+
 SCENARIOS = {
+    "fuzz_flat_1": lambda: _fuzz("flat", 1),
+    "fuzz_flat_2": lambda: _fuzz("flat", 2),
+    "fuzz_sharded_3": lambda: _fuzz("sharded", 3),
     "config1": config1,
     "colinear": colinear,
     "deletes": deletes,
