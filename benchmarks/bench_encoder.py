@@ -55,21 +55,23 @@ def main():
             lens = rs.randint(S // 4, S + 1, size=B) if ragged else np.full(B, S)
             mask = torch.from_numpy((np.arange(S)[None, :] < lens[:, None]).astype(np.int32)).to(dev)
             T = int(lens.sum())
-            for _ in range(3):
-                enc.forward_device(ids, mask)
-            torch.cuda.synchronize()
-            n = 10
-            t0 = time.perf_counter()
-            for _ in range(n):
-                enc.forward_device(ids, mask)
-            torch.cuda.synchronize()
-            dt = (time.perf_counter() - t0) / n
-            gemm = T * 12 * (4 * 2 * H * H + 2 * 2 * H * F)
-            attn = float(sum(12 * 4 * int(l) * int(l) * H for l in lens))
-            print(json.dumps({"B": B, "S": S, "ragged": ragged, "tokens": T, "ms": round(dt * 1e3, 3),
-                              "sentences_per_s": round(B / dt, 1), "tflops": round((gemm + attn) / dt / 1e12, 2),
-                              "gemm_tflop": round(gemm / 1e12, 3), "attn_tflop": round(attn / 1e12, 3),
-                              "frac_of_fp32_mfma_peak": round((gemm + attn) / dt / 157.3e12, 4)}), flush=True)
+            for compute in (0, 1):
+                for _ in range(3):
+                    enc.forward_device(ids, mask, compute=compute)
+                torch.cuda.synchronize()
+                n = 10
+                t0 = time.perf_counter()
+                for _ in range(n):
+                    enc.forward_device(ids, mask, compute=compute)
+                torch.cuda.synchronize()
+                dt = (time.perf_counter() - t0) / n
+                gemm = T * 12 * (4 * 2 * H * H + 2 * 2 * H * F)
+                attn = float(sum(12 * 4 * int(l) * int(l) * H for l in lens))
+                print(json.dumps({"B": B, "S": S, "ragged": ragged, "compute": "bf16" if compute else "fp32",
+                                  "tokens": T, "ms": round(dt * 1e3, 3), "sentences_per_s": round(B / dt, 1),
+                                  "tflops": round((gemm + attn) / dt / 1e12, 2), "gemm_tflop": round(gemm / 1e12, 3),
+                                  "attn_tflop": round(attn / 1e12, 3),
+                                  "frac_of_fp32_mfma_peak": round((gemm + attn) / dt / 157.3e12, 4)}), flush=True)
     enc.close()
 
 

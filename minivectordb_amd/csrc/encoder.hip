@@ -330,6 +330,124 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(const float* __restr
 }
 
 // =================================================================================================
+// opt-in bf16 GEMM (compute = 1): operands rounded to bf16 (RNE), fp32 accumulate on
+// v_mfma_f32_32x32x16_bf16 (16x the fp32 MFMA rate).  NOT parity-exact: the reference computes in
+// fp32; embeddings move by ~1e-3.  Activations stay fp32 in memory (converted while staging into
+// LDS); weights are converted once (library-owned bf16 copies).
+// =================================================================================================
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+constexpr int HBK = 32;       // k per LDS tile
+constexpr int HROW = 80;      // LDS row stride in bytes: 64 B of bf16 + 16 B pad => conflict-free b128 reads
+
+__global__ void f32_to_bf16_kernel(const float* __restrict__ in, __bf16* __restrict__ out, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (__bf16)in[i];
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_bf16_mfma_kernel(const float* __restrict__ A,
+                                                             const __bf16* __restrict__ W,
+                                                             const float* __restrict__ bias,
+                                                             const float* __restrict__ R,
+                                                             float* __restrict__ C,
+                                                             const int* __restrict__ Tptr, int N, int K) {
+    const int T = *Tptr;
+    const int m0 = blockIdx.y * GBM;
+    if (m0 >= T) return;
+    const int n0 = blockIdx.x * GBN;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 2 * GBM * HROW];  // [buf][A|B][row][80 B]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // staging roles: thread -> (row = tid/2, half = tid%2): 16 consecutive k of that row
+    const int lr = tid >> 1, lh = tid & 1;
+    const bool a_ok = m0 + lr < T, w_ok = n0 + lr < N;
+    const float* a_ptr = A + (int64_t)(a_ok ? m0 + lr : 0) * K + lh * 16;
+    const __bf16* w_ptr = W + (int64_t)(w_ok ? n0 + lr : 0) * K + lh * 16;
+    f32x4 ra[4];
+    uint4 rw[2];
+    auto stage_load = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            ra[i] = a_ok ? *reinterpret_cast<const f32x4*>(a_ptr + k0 + 4 * i) : f32x4{0, 0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            rw[i] = w_ok ? *reinterpret_cast<const uint4*>(w_ptr + k0 + 8 * i) : uint4{0, 0, 0, 0};
+    };
+    auto stage_write = [&](int buf) {
+        unsigned char* As = lds + buf * (2 * GBM * HROW);
+        unsigned char* Bs = As + GBM * HROW;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            bf16x8 v;
+            v[0] = (__bf16)ra[2 * i][0]; v[1] = (__bf16)ra[2 * i][1];
+            v[2] = (__bf16)ra[2 * i][2]; v[3] = (__bf16)ra[2 * i][3];
+            v[4] = (__bf16)ra[2 * i + 1][0]; v[5] = (__bf16)ra[2 * i + 1][1];
+            v[6] = (__bf16)ra[2 * i + 1][2]; v[7] = (__bf16)ra[2 * i + 1][3];
+            *reinterpret_cast<bf16x8*>(As + lr * HROW + lh * 32 + i * 16) = v;
+            *reinterpret_cast<uint4*>(Bs + lr * HROW + lh * 32 + i * 16) = rw[i];
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = K / HBK;
+    stage_load(0);
+    stage_write(0);
+    __syncthreads();
+    const int fr = lane & 31, fh = lane >> 5;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) stage_load((kt + 1) * HBK);
+        const unsigned char* As = lds + buf * (2 * GBM * HROW);
+        const unsigned char* Bs = As + GBM * HROW;
+#pragma unroll
+        for (int ks = 0; ks < HBK / 16; ++ks) {
+            // lane l: A[row = l&31][k = 8*(l>>5) .. +7] of this 16-deep step
+            const int off = ks * 32 + fh * 16;
+            const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(As + (wm * 64 + fr) * HROW + off);
+            const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(As + (wm * 64 + 32 + fr) * HROW + off);
+            const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(Bs + (wn * 64 + fr) * HROW + off);
+            const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(Bs + (wn * 64 + 32 + fr) * HROW + off);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (kt + 1 < nk) {
+            stage_write(buf ^ 1);
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wn * 64 + j * 32 + fr;
+            if (col >= N) continue;
+            const float bv = bias[col];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                if (row < T) {
+                    float v = acc[i][j][r] + bv;
+                    if (EPI == EPI_BIAS_GELU) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+                    if (EPI == EPI_BIAS_RESIDUAL) v += R[(int64_t)row * N + col];
+                    C[(int64_t)row * N + col] = v;
+                }
+            }
+        }
+}
+
+// =================================================================================================
 // attention: one thread per query row, K/V tiles broadcast from LDS, chunked online softmax (fp32)
 // =================================================================================================
 constexpr int ATT_Q = 128;  // queries per block
@@ -428,6 +546,7 @@ __global__ void concat3_kernel(const float* a, const float* b, const float* c, i
 struct LayerW {
     const float *wqkv, *bqkv;  // fused (library owned)
     const float *wo, *bo, *ln1g, *ln1b, *w1, *b1, *w2, *b2, *ln2g, *ln2b;
+    __bf16 *wqkv_h = nullptr, *wo_h = nullptr, *w1_h = nullptr, *w2_h = nullptr;  // lazily made bf16 copies
 };
 
 }  // namespace
@@ -438,6 +557,8 @@ struct mvdb_encoder {
     const float *word = nullptr, *pos = nullptr, *type = nullptr, *embg = nullptr, *embb = nullptr;
     std::vector<LayerW> layers;
     std::vector<float*> owned;  // fused qkv weights / biases
+    std::vector<void*> owned_h; // bf16 weight copies (compute = 1)
+    bool have_bf16 = false;
     // workspace (grown on demand), guarded by mu: one forward at a time per encoder
     std::mutex mu;
     int64_t cap_tokens = 0, cap_b = 0;
@@ -522,6 +643,36 @@ void launch_gemm(const float* A, const float* W, const float* bias, const float*
     hipLaunchKernelGGL(gemm_f32_mfma_kernel<EPI>, grid, dim3(256), 0, s, A, W, bias, R, C, Tptr, N, K);
 }
 
+template <int EPI>
+void launch_gemm_h(const float* A, const __bf16* W, const float* bias, const float* R, float* C,
+                   const int* Tptr, int64_t Tmax, int N, int K, hipStream_t s) {
+    dim3 grid((N + GBN - 1) / GBN, (unsigned)((Tmax + GBM - 1) / GBM));
+    hipLaunchKernelGGL(gemm_bf16_mfma_kernel<EPI>, grid, dim3(256), 0, s, A, W, bias, R, C, Tptr, N, K);
+}
+
+int make_bf16(mvdb_encoder* e, const float* src, int64_t n, __bf16** out, hipStream_t s) {
+    __bf16* p = nullptr;
+    MVDB_HIP(hipMalloc((void**)&p, (size_t)n * sizeof(__bf16)));
+    e->owned_h.push_back(p);
+    hipLaunchKernelGGL(f32_to_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, p, n);
+    *out = p;
+    return 0;
+}
+
+int ensure_bf16_weights(mvdb_encoder* e, hipStream_t s) {
+    if (e->have_bf16) return 0;
+    const int64_t H = e->cfg.hidden, F = e->cfg.intermediate;
+    for (LayerW& L : e->layers) {
+        MVDB_TRY(make_bf16(e, L.wqkv, 3 * H * H, &L.wqkv_h, s));
+        MVDB_TRY(make_bf16(e, L.wo, H * H, &L.wo_h, s));
+        MVDB_TRY(make_bf16(e, L.w1, F * H, &L.w1_h, s));
+        MVDB_TRY(make_bf16(e, L.w2, H * F, &L.w2_h, s));
+    }
+    MVDB_HIP(hipGetLastError());
+    e->have_bf16 = true;
+    return 0;
+}
+
 template <int VPT>
 void launch_ln(const float* y, const int* seq_start, int B, const float* g, const float* b, float eps,
                int H, float* x, int64_t Tmax, hipStream_t s) {
@@ -531,8 +682,13 @@ void launch_ln(const float* y, const int* seq_start, int B, const float* g, cons
 
 int forward_core(mvdb_encoder* e, const int32_t* ids, const int32_t* mask, int B, int S, int compute,
                  float* out, float* hidden, hipStream_t s) {
-    if (compute != 0)
-        return fail(MVDB_ERR_ARG, "compute mode %d not available (0 = exact-fp32 MFMA)", compute);
+    if (compute != 0 && compute != 1)
+        return fail(MVDB_ERR_ARG, "unknown compute mode %d (0 = exact-fp32 MFMA, 1 = bf16 MFMA operands)", compute);
+    if (compute == 1) {
+        if (e->cfg.hidden % HBK || e->cfg.intermediate % HBK)
+            return fail(MVDB_ERR_ARG, "bf16 mode needs hidden and intermediate to be multiples of %d", HBK);
+        MVDB_TRY(ensure_bf16_weights(e, s));
+    }
     const mvdb_encoder_cfg& c = e->cfg;
     if (B <= 0 || S <= 0) return fail(MVDB_ERR_ARG, "B and S must be positive");
     if (S + (c.position_offset > 0 ? c.position_offset : 0) > c.max_positions)
@@ -569,19 +725,30 @@ int forward_core(mvdb_encoder* e, const int32_t* ids, const int32_t* mask, int B
     const dim3 agrid((S + ATT_Q - 1) / ATT_Q, c.heads, B);
     int pslot = prof_begin("encoder", s);
     for (const LayerW& L : e->layers) {
-        launch_gemm<EPI_BIAS>(e->x, L.wqkv, L.bqkv, nullptr, e->qkv, Tptr, Tmax, 3 * H, H, s);
+        if (compute == 1)
+            launch_gemm_h<EPI_BIAS>(e->x, L.wqkv_h, L.bqkv, nullptr, e->qkv, Tptr, Tmax, 3 * H, H, s);
+        else
+            launch_gemm<EPI_BIAS>(e->x, L.wqkv, L.bqkv, nullptr, e->qkv, Tptr, Tmax, 3 * H, H, s);
         if (hd == 32)
             hipLaunchKernelGGL(attention_kernel<32>, agrid, dim3(ATT_Q), 0, s, e->qkv, e->seq_start, H, scale,
                                e->ctx);
         else
             hipLaunchKernelGGL(attention_kernel<64>, agrid, dim3(ATT_Q), 0, s, e->qkv, e->seq_start, H, scale,
                                e->ctx);
-        launch_gemm<EPI_BIAS_RESIDUAL>(e->ctx, L.wo, L.bo, e->x, e->y, Tptr, Tmax, H, H, s);
+        if (compute == 1)
+            launch_gemm_h<EPI_BIAS_RESIDUAL>(e->ctx, L.wo_h, L.bo, e->x, e->y, Tptr, Tmax, H, H, s);
+        else
+            launch_gemm<EPI_BIAS_RESIDUAL>(e->ctx, L.wo, L.bo, e->x, e->y, Tptr, Tmax, H, H, s);
 #define LN1_CALL(V) launch_ln<V>(e->y, e->seq_start, B, L.ln1g, L.ln1b, c.ln_eps, H, e->x, Tmax, s)
         MVDB_VPT_SWITCH(LN1_CALL)
 #undef LN1_CALL
-        launch_gemm<EPI_BIAS_GELU>(e->x, L.w1, L.b1, nullptr, e->ffn, Tptr, Tmax, F, H, s);
-        launch_gemm<EPI_BIAS_RESIDUAL>(e->ffn, L.w2, L.b2, e->x, e->y, Tptr, Tmax, H, F, s);
+        if (compute == 1) {
+            launch_gemm_h<EPI_BIAS_GELU>(e->x, L.w1_h, L.b1, nullptr, e->ffn, Tptr, Tmax, F, H, s);
+            launch_gemm_h<EPI_BIAS_RESIDUAL>(e->ffn, L.w2_h, L.b2, e->x, e->y, Tptr, Tmax, H, F, s);
+        } else {
+            launch_gemm<EPI_BIAS_GELU>(e->x, L.w1, L.b1, nullptr, e->ffn, Tptr, Tmax, F, H, s);
+            launch_gemm<EPI_BIAS_RESIDUAL>(e->ffn, L.w2, L.b2, e->x, e->y, Tptr, Tmax, H, F, s);
+        }
 #define LN2_CALL(V) launch_ln<V>(e->y, e->seq_start, B, L.ln2g, L.ln2b, c.ln_eps, H, e->x, Tmax, s)
         MVDB_VPT_SWITCH(LN2_CALL)
 #undef LN2_CALL
@@ -683,6 +850,7 @@ int mvdb_encoder_free(mvdb_encoder* e) {
         (void)hipDeviceSynchronize();
         e->free_ws();
         for (float* p : e->owned) (void)hipFree(p);
+        for (void* p : e->owned_h) (void)hipFree(p);
         if (e->ids_stage) (void)hipFree(e->ids_stage);
         if (e->mask_stage) (void)hipFree(e->mask_stage);
         if (e->out_stage) (void)hipFree(e->out_stage);

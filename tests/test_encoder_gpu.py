@@ -116,3 +116,22 @@ def test_embedding_model_api(gpu):
     m2 = EmbeddingModel(use_quantized_onnx_model=False, e5_model_size="small",
                         state_dict={k: torch.from_numpy(v) for k, v in w.items()}, config=cfg, tokenizer=Tok())
     assert m2.alternative_model == AlternativeModel.small
+
+
+def test_bf16_mode_is_close_but_opt_in(gpu):
+    """compute = 1 (bf16 MFMA operands, fp32 accumulate) is an opt-in speed mode, not the parity
+    path: embeddings stay within 5e-3 of the float64 restatement (cosine to the fp32 result > 0.9999)."""
+    cfg = E.make_config("e5-small-dims")
+    w = E.make_weights(cfg, 21)
+    ids, mask = E.make_inputs(cfg, 8, 40, 22)
+    enc = _model(cfg, w)
+    e32 = enc.forward(ids, mask)
+    e16 = enc.forward(ids, mask, compute=1)
+    _, e64 = E.numpy_forward(cfg, w, ids, mask)
+    assert np.abs(e32 - e64).max() < 2e-5
+    assert np.abs(e16 - e64).max() < 5e-3
+    assert (e16 * e32).sum(1).min() > 0.9999
+    assert np.abs(e16 - e32).max() > 1e-6  # it really is a different arithmetic
+    with pytest.raises(ValueError):
+        enc.forward(ids, mask, compute=2)
+    enc.close()
