@@ -22,6 +22,9 @@
 //   * bias / erf-GELU / residual fused into the GEMM epilogue; LayerNorm and pooling are
 //     one-wave-per-row kernels (HBM/L2-bound, tiny).
 #include <cmath>
+#include <cstdlib>
+#include <map>
+#include <tuple>
 
 #include "common.hpp"
 
@@ -551,8 +554,21 @@ struct LayerW {
 
 }  // namespace
 
+struct GraphKey {
+    int B, S, compute;
+    const void *ids, *mask, *out;
+    bool operator<(const GraphKey& o) const {
+        return std::tie(B, S, compute, ids, mask, out) < std::tie(o.B, o.S, o.compute, o.ids, o.mask, o.out);
+    }
+};
+
 struct mvdb_encoder {
     mvdb_encoder_cfg cfg;
+    std::map<GraphKey, hipGraphExec_t> graphs;  // captured forwards, keyed by shape + buffer addresses
+    void drop_graphs() {
+        for (auto& kv : graphs) (void)hipGraphExecDestroy(kv.second);
+        graphs.clear();
+    }
     int device = 0;
     const float *word = nullptr, *pos = nullptr, *type = nullptr, *embg = nullptr, *embb = nullptr;
     std::vector<LayerW> layers;
@@ -680,20 +696,10 @@ void launch_ln(const float* y, const int* seq_start, int B, const float* g, cons
                        g, b, eps, H, x);
 }
 
-int forward_core(mvdb_encoder* e, const int32_t* ids, const int32_t* mask, int B, int S, int compute,
-                 float* out, float* hidden, hipStream_t s) {
-    if (compute != 0 && compute != 1)
-        return fail(MVDB_ERR_ARG, "unknown compute mode %d (0 = exact-fp32 MFMA, 1 = bf16 MFMA operands)", compute);
-    if (compute == 1) {
-        if (e->cfg.hidden % HBK || e->cfg.intermediate % HBK)
-            return fail(MVDB_ERR_ARG, "bf16 mode needs hidden and intermediate to be multiples of %d", HBK);
-        MVDB_TRY(ensure_bf16_weights(e, s));
-    }
+// Enqueue every kernel of one forward on `s` (no allocation, no host sync: capturable in a hipGraph).
+int enqueue_forward(mvdb_encoder* e, const int32_t* ids, const int32_t* mask, int B, int S, int compute,
+                    float* out, float* hidden, hipStream_t s) {
     const mvdb_encoder_cfg& c = e->cfg;
-    if (B <= 0 || S <= 0) return fail(MVDB_ERR_ARG, "B and S must be positive");
-    if (S + (c.position_offset > 0 ? c.position_offset : 0) > c.max_positions)
-        return fail(MVDB_ERR_ARG, "sequence length %d exceeds max_positions %d", S, c.max_positions);
-    MVDB_TRY(ensure_ws(e, B, S));
     const int H = c.hidden, F = c.intermediate, hd = H / c.heads;
     const int64_t Tmax = (int64_t)B * S;
     const int vpt = (H + 63) / 64;
@@ -723,7 +729,6 @@ int forward_core(mvdb_encoder* e, const int32_t* ids, const int32_t* mask, int B
 
     const float scale = 1.0f / sqrtf((float)hd);
     const dim3 agrid((S + ATT_Q - 1) / ATT_Q, c.heads, B);
-    int pslot = prof_begin("encoder", s);
     for (const LayerW& L : e->layers) {
         if (compute == 1)
             launch_gemm_h<EPI_BIAS>(e->x, L.wqkv_h, L.bqkv, nullptr, e->qkv, Tptr, Tmax, 3 * H, H, s);
@@ -753,7 +758,6 @@ int forward_core(mvdb_encoder* e, const int32_t* ids, const int32_t* mask, int B
         MVDB_VPT_SWITCH(LN2_CALL)
 #undef LN2_CALL
     }
-    prof_end(pslot, s);
 #undef MVDB_VPT_SWITCH
     hipLaunchKernelGGL(pool_norm_kernel, dim3(B), dim3(256), 0, s, e->x, e->seq_start, H, c.pooling, out);
     if (hidden)
@@ -761,6 +765,58 @@ int forward_core(mvdb_encoder* e, const int32_t* ids, const int32_t* mask, int B
                            e->seq_start, S, H, hidden);
     MVDB_HIP(hipGetLastError());
     return 0;
+}
+
+int forward_core(mvdb_encoder* e, const int32_t* ids, const int32_t* mask, int B, int S, int compute,
+                 float* out, float* hidden, hipStream_t s) {
+    if (compute != 0 && compute != 1)
+        return fail(MVDB_ERR_ARG, "unknown compute mode %d (0 = exact-fp32 MFMA, 1 = bf16 MFMA operands)", compute);
+    const mvdb_encoder_cfg& c = e->cfg;
+    if (B <= 0 || S <= 0) return fail(MVDB_ERR_ARG, "B and S must be positive");
+    if (S + (c.position_offset > 0 ? c.position_offset : 0) > c.max_positions)
+        return fail(MVDB_ERR_ARG, "sequence length %d exceeds max_positions %d", S, c.max_positions);
+    if (compute == 1) {
+        if (c.hidden % HBK || c.intermediate % HBK)
+            return fail(MVDB_ERR_ARG, "bf16 mode needs hidden and intermediate to be multiples of %d", HBK);
+        MVDB_TRY(ensure_bf16_weights(e, s));
+    }
+    const int64_t cap_before = e->cap_tokens;
+    MVDB_TRY(ensure_ws(e, B, S));
+    if (e->cap_tokens != cap_before) e->drop_graphs();  // workspace moved: captured pointers are stale
+
+    // ~90 short launches per forward: replay them as ONE hipGraph per (shape, buffers) instead of paying
+    // the host launch path per kernel (the S = 32 forward is launch-bound otherwise)
+    static const bool use_graph = []() {
+        const char* v = getenv("MVDB_ENCODER_GRAPH");
+        return !(v && *v == '0');
+    }();
+    int pslot = prof_begin("encoder", s);
+    int rc = 0;
+    if (use_graph && !hidden) {
+        const GraphKey key{B, S, compute, ids, mask, out};
+        auto it = e->graphs.find(key);
+        if (it == e->graphs.end()) {
+            hipGraph_t graph = nullptr;
+            hipGraphExec_t exec = nullptr;
+            MVDB_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+            rc = enqueue_forward(e, ids, mask, B, S, compute, out, nullptr, s);
+            hipError_t ec = hipStreamEndCapture(s, &graph);
+            if (!rc && ec != hipSuccess) rc = fail(MVDB_ERR_HIP, "graph capture failed: %s", hipGetErrorString(ec));
+            if (!rc) {
+                ec = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+                if (ec != hipSuccess) rc = fail(MVDB_ERR_HIP, "graph instantiate failed: %s", hipGetErrorString(ec));
+            }
+            if (graph) (void)hipGraphDestroy(graph);
+            if (rc) return rc;
+            if (e->graphs.size() >= 64) e->drop_graphs();
+            it = e->graphs.emplace(key, exec).first;
+        }
+        MVDB_HIP(hipGraphLaunch(it->second, s));
+    } else {
+        rc = enqueue_forward(e, ids, mask, B, S, compute, out, hidden, s);
+    }
+    prof_end(pslot, s);
+    return rc;
 }
 
 }  // namespace
@@ -848,6 +904,7 @@ int mvdb_encoder_free(mvdb_encoder* e) {
     {
         DeviceGuard dg(e->device);
         (void)hipDeviceSynchronize();
+        e->drop_graphs();
         e->free_ws();
         for (float* p : e->owned) (void)hipFree(p);
         for (void* p : e->owned_h) (void)hipFree(p);
@@ -878,6 +935,7 @@ int mvdb_encoder_forward(mvdb_encoder* e, const int32_t* ids_host, const int32_t
     DeviceGuard dg(e->device);
     const int64_t tokens = (int64_t)B * S;
     if (tokens > e->stage_cap) {
+        e->drop_graphs();
         if (e->ids_stage) (void)hipFree(e->ids_stage);
         if (e->mask_stage) (void)hipFree(e->mask_stage);
         e->ids_stage = e->mask_stage = nullptr;
@@ -888,6 +946,7 @@ int mvdb_encoder_forward(mvdb_encoder* e, const int32_t* ids_host, const int32_t
     }
     const int64_t outn = (int64_t)B * e->cfg.hidden;
     if (outn > e->out_cap) {
+        e->drop_graphs();
         if (e->out_stage) (void)hipFree(e->out_stage);
         e->out_stage = nullptr;
         e->out_cap = 0;
