@@ -21,6 +21,7 @@ from oracle.encoder import weight_names  # noqa: E402
 
 def main():
     dev = torch.device("cuda", 0)
+    torch.cuda.set_stream(torch.cuda.Stream(dev))  # a real stream: the encoder replays hipGraphs on it
     H, F, V = 384, 1536, 250037
     cfg = {"model_type": "bert", "vocab_size": V, "hidden_size": H, "num_hidden_layers": 12,
            "num_attention_heads": 12, "intermediate_size": F, "max_position_embeddings": 512,

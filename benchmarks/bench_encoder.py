@@ -18,6 +18,7 @@ from minivectordb_amd.embedding_model import GpuEncoder  # noqa: E402
 
 def main():
     dev = torch.device("cuda", 0)
+    torch.cuda.set_stream(torch.cuda.Stream(dev))  # a real stream: the encoder replays hipGraphs on it
     cfg = {"model_type": "bert", "vocab_size": 250037, "hidden_size": 384, "num_hidden_layers": 12,
            "num_attention_heads": 12, "intermediate_size": 1536, "max_position_embeddings": 512,
            "type_vocab_size": 2, "layer_norm_eps": 1e-12, "hidden_act": "gelu", "pad_token_id": 0}

@@ -792,13 +792,18 @@ int forward_core(mvdb_encoder* e, const int32_t* ids, const int32_t* mask, int B
     }();
     int pslot = prof_begin("encoder", s);
     int rc = 0;
-    if (use_graph && !hidden) {
+    if (use_graph && !hidden && s) {
         const GraphKey key{B, S, compute, ids, mask, out};
         auto it = e->graphs.find(key);
         if (it == e->graphs.end()) {
             hipGraph_t graph = nullptr;
             hipGraphExec_t exec = nullptr;
-            MVDB_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+            if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+                (void)hipGetLastError();  // stream not capturable: plain launches
+                rc = enqueue_forward(e, ids, mask, B, S, compute, out, nullptr, s);
+                prof_end(pslot, s);
+                return rc;
+            }
             rc = enqueue_forward(e, ids, mask, B, S, compute, out, nullptr, s);
             hipError_t ec = hipStreamEndCapture(s, &graph);
             if (!rc && ec != hipSuccess) rc = fail(MVDB_ERR_HIP, "graph capture failed: %s", hipGetErrorString(ec));
@@ -917,23 +922,7 @@ int mvdb_encoder_free(mvdb_encoder* e) {
     return 0;
 }
 
-int mvdb_encoder_forward_device(mvdb_encoder* e, const int32_t* ids_dev, const int32_t* mask_dev, int B,
-                                int S, int compute, float* out_dev, float* hidden_dev, void* stream) {
-    if (!e) return fail(MVDB_ERR_ARG, "encoder is NULL");
-    if (!ids_dev || !mask_dev || !out_dev) return fail(MVDB_ERR_ARG, "NULL buffer");
-    std::lock_guard<std::mutex> lk(e->mu);
-    DeviceGuard dg(e->device);
-    return forward_core(e, ids_dev, mask_dev, B, S, compute, out_dev, hidden_dev, (hipStream_t)stream);
-}
-
-int mvdb_encoder_forward(mvdb_encoder* e, const int32_t* ids_host, const int32_t* mask_host, int B, int S,
-                         int compute, float* out_host) {
-    if (!e) return fail(MVDB_ERR_ARG, "encoder is NULL");
-    if (!ids_host || !mask_host || !out_host) return fail(MVDB_ERR_ARG, "NULL buffer");
-    if (B <= 0 || S <= 0) return fail(MVDB_ERR_ARG, "B and S must be positive");
-    std::lock_guard<std::mutex> lk(e->mu);
-    DeviceGuard dg(e->device);
-    const int64_t tokens = (int64_t)B * S;
+static int ensure_stage(mvdb_encoder* e, int64_t tokens, int64_t outn) {
     if (tokens > e->stage_cap) {
         e->drop_graphs();
         if (e->ids_stage) (void)hipFree(e->ids_stage);
@@ -944,7 +933,6 @@ int mvdb_encoder_forward(mvdb_encoder* e, const int32_t* ids_host, const int32_t
         MVDB_HIP(hipMalloc((void**)&e->mask_stage, tokens * sizeof(int32_t)));
         e->stage_cap = tokens;
     }
-    const int64_t outn = (int64_t)B * e->cfg.hidden;
     if (outn > e->out_cap) {
         e->drop_graphs();
         if (e->out_stage) (void)hipFree(e->out_stage);
@@ -953,6 +941,40 @@ int mvdb_encoder_forward(mvdb_encoder* e, const int32_t* ids_host, const int32_t
         MVDB_HIP(hipMalloc((void**)&e->out_stage, outn * sizeof(float)));
         e->out_cap = outn;
     }
+    return 0;
+}
+
+int mvdb_encoder_forward_device(mvdb_encoder* e, const int32_t* ids_dev, const int32_t* mask_dev, int B,
+                                int S, int compute, float* out_dev, float* hidden_dev, void* stream) {
+    if (!e) return fail(MVDB_ERR_ARG, "encoder is NULL");
+    if (!ids_dev || !mask_dev || !out_dev) return fail(MVDB_ERR_ARG, "NULL buffer");
+    if (B <= 0 || S <= 0) return fail(MVDB_ERR_ARG, "B and S must be positive");
+    std::lock_guard<std::mutex> lk(e->mu);
+    DeviceGuard dg(e->device);
+    hipStream_t s = (hipStream_t)stream;
+    if (hidden_dev || !s)  // diagnostic output, or the legacy NULL stream (not capturable): plain launches
+        return forward_core(e, ids_dev, mask_dev, B, S, compute, out_dev, hidden_dev, s);
+    // Route through the encoder's own staging buffers so that the captured graph (keyed by buffer
+    // addresses) is reused whatever tensors the caller passes: three small device-to-device copies.
+    const int64_t tokens = (int64_t)B * S, outn = (int64_t)B * e->cfg.hidden;
+    MVDB_TRY(ensure_stage(e, tokens, outn));
+    MVDB_HIP(hipMemcpyAsync(e->ids_stage, ids_dev, tokens * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+    MVDB_HIP(hipMemcpyAsync(e->mask_stage, mask_dev, tokens * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+    MVDB_TRY(forward_core(e, e->ids_stage, e->mask_stage, B, S, compute, e->out_stage, nullptr, s));
+    MVDB_HIP(hipMemcpyAsync(out_dev, e->out_stage, outn * sizeof(float), hipMemcpyDeviceToDevice, s));
+    return 0;
+}
+
+int mvdb_encoder_forward(mvdb_encoder* e, const int32_t* ids_host, const int32_t* mask_host, int B, int S,
+                         int compute, float* out_host) {
+    if (!e) return fail(MVDB_ERR_ARG, "encoder is NULL");
+    if (!ids_host || !mask_host || !out_host) return fail(MVDB_ERR_ARG, "NULL buffer");
+    if (B <= 0 || S <= 0) return fail(MVDB_ERR_ARG, "B and S must be positive");
+    std::lock_guard<std::mutex> lk(e->mu);
+    DeviceGuard dg(e->device);
+    const int64_t tokens = (int64_t)B * S;
+    const int64_t outn = (int64_t)B * e->cfg.hidden;
+    MVDB_TRY(ensure_stage(e, tokens, outn));
     for (int64_t i = 0; i < tokens; ++i)
         if (mask_host[i] && (ids_host[i] < 0 || ids_host[i] >= e->cfg.vocab_size))
             return fail(MVDB_ERR_ARG, "token id %d at %lld outside the vocabulary [0,%d)", ids_host[i],
