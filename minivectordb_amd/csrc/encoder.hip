@@ -224,63 +224,66 @@ __global__ __launch_bounds__(256) void unpack_hidden_kernel(const float* __restr
 // =================================================================================================
 enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_RESIDUAL = 2 };
 
-constexpr int GBM = 128, GBN = 128, GBK = 16, GLD = 132;  // LDS row stride (floats): 128 + 4 pad
+constexpr int GBM = 128, GBN = 128, GBK = 16;  // GBM/GBN: the bf16 kernel's tile; fp32 tiles are 64*TI
 
-template <int EPI>
+// TI = 32x32 MFMA tiles per wave and dimension: TI = 2 -> 128x128 block tile (best reuse), TI = 1 ->
+// 64x64 (4x the blocks: used when the 128x128 grid would leave CUs idle, e.g. N = 384 at T = 8192).
+template <int EPI, int TI>
 __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(const float* __restrict__ A,
                                                             const float* __restrict__ W,
                                                             const float* __restrict__ bias,
                                                             const float* __restrict__ R,
                                                             float* __restrict__ C,
                                                             const int* __restrict__ Tptr, int N, int K) {
+    constexpr int BM = 64 * TI, BN = 64 * TI, LD = BM + 4;  // LDS row stride (floats): +4 pad
     const int T = *Tptr;
-    const int m0 = blockIdx.y * GBM;
+    const int m0 = blockIdx.y * BM;
     if (m0 >= T) return;
-    const int n0 = blockIdx.x * GBN;
-    __shared__ float lds[2 * 2 * GBK * GLD];  // [buf][A|B][k][row]
+    const int n0 = blockIdx.x * BN;
+    __shared__ float lds[2 * 2 * GBK * LD];  // [buf][A|B][k][row]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
 
-    // global -> register staging: thread owns rows r and r+64 of each tile, 4 consecutive k
+    // global -> register staging: thread owns rows lr + 64*i of each tile, 4 consecutive k
     const int lr = tid >> 2, lk = (tid & 3) * 4;
-    const float* a_ptr[2];
-    const float* w_ptr[2];
-    bool a_ok[2], w_ok[2];
+    const float* a_ptr[TI];
+    const float* w_ptr[TI];
+    bool a_ok[TI], w_ok[TI];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < TI; ++i) {
         const int ra = m0 + lr + i * 64, rw = n0 + lr + i * 64;
         a_ok[i] = ra < T;
         w_ok[i] = rw < N;
         a_ptr[i] = A + (int64_t)(a_ok[i] ? ra : 0) * K + lk;
         w_ptr[i] = W + (int64_t)(w_ok[i] ? rw : 0) * K + lk;
     }
-    f32x4 ra[2], rw[2];
+    f32x4 ra[TI], rw[TI];
     auto stage_load = [&](int k0) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < TI; ++i) {
             ra[i] = a_ok[i] ? *reinterpret_cast<const f32x4*>(a_ptr[i] + k0) : f32x4{0, 0, 0, 0};
             rw[i] = w_ok[i] ? *reinterpret_cast<const f32x4*>(w_ptr[i] + k0) : f32x4{0, 0, 0, 0};
         }
     };
     auto stage_write = [&](int buf) {
-        float* As = lds + buf * (2 * GBK * GLD);
-        float* Bs = As + GBK * GLD;
+        float* As = lds + buf * (2 * GBK * LD);
+        float* Bs = As + GBK * LD;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < TI; ++i) {
             const int r = lr + i * 64;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                As[(lk + j) * GLD + r] = ra[i][j];
-                Bs[(lk + j) * GLD + r] = rw[i][j];
+                As[(lk + j) * LD + r] = ra[i][j];
+                Bs[(lk + j) * LD + r] = rw[i][j];
             }
         }
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[TI][TI];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TI; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -292,18 +295,21 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(const float* __restr
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
         if (kt + 1 < nk) stage_load((kt + 1) * GBK);  // in flight during the MFMAs below
-        const float* As = lds + buf * (2 * GBK * GLD);
-        const float* Bs = As + GBK * GLD;
+        const float* As = lds + buf * (2 * GBK * LD);
+        const float* Bs = As + GBK * LD;
 #pragma unroll
         for (int kk = 0; kk < GBK; kk += 2) {
-            const float a0 = As[(kk + fk) * GLD + wm * 64 + fr];
-            const float a1 = As[(kk + fk) * GLD + wm * 64 + 32 + fr];
-            const float b0 = Bs[(kk + fk) * GLD + wn * 64 + fr];
-            const float b1 = Bs[(kk + fk) * GLD + wn * 64 + 32 + fr];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            float av[TI], bv[TI];
+#pragma unroll
+            for (int i = 0; i < TI; ++i) {
+                av[i] = As[(kk + fk) * LD + wm * 32 * TI + i * 32 + fr];
+                bv[i] = Bs[(kk + fk) * LD + wn * 32 * TI + i * 32 + fr];
+            }
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < TI; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
         }
         if (kt + 1 < nk) {
             stage_write(buf ^ 1);  // the other buffer: last read two iterations ago
@@ -313,17 +319,17 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(const float* __restr
 
     // epilogue.  C/D map of 32x32: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = n0 + wn * 64 + j * 32 + fr;
+        for (int j = 0; j < TI; ++j) {
+            const int col = n0 + wn * 32 * TI + j * 32 + fr;
             if (col >= N) continue;
-            const float bv = bias[col];
+            const float bvv = bias[col];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
+                const int row = m0 + wm * 32 * TI + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
                 if (row < T) {
-                    float v = acc[i][j][r] + bv;
+                    float v = acc[i][j][r] + bvv;
                     if (EPI == EPI_BIAS_GELU) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
                     if (EPI == EPI_BIAS_RESIDUAL) v += R[(int64_t)row * N + col];
                     C[(int64_t)row * N + col] = v;
@@ -654,9 +660,15 @@ int ensure_ws(mvdb_encoder* e, int B, int S) {
 
 template <int EPI>
 void launch_gemm(const float* A, const float* W, const float* bias, const float* R, float* C,
-                 const int* Tptr, int64_t Tmax, int N, int K, hipStream_t s) {
-    dim3 grid((N + GBN - 1) / GBN, (unsigned)((Tmax + GBM - 1) / GBM));
-    hipLaunchKernelGGL(gemm_f32_mfma_kernel<EPI>, grid, dim3(256), 0, s, A, W, bias, R, C, Tptr, N, K);
+                 const int* Tptr, int64_t Tmax, int N, int K, int cus, hipStream_t s) {
+    const int64_t big = (int64_t)((N + 127) / 128) * ((Tmax + 127) / 128);
+    if (big >= 2 * (int64_t)cus) {  // enough 128x128 tiles to fill the chip twice
+        dim3 grid((N + 127) / 128, (unsigned)((Tmax + 127) / 128));
+        hipLaunchKernelGGL((gemm_f32_mfma_kernel<EPI, 2>), grid, dim3(256), 0, s, A, W, bias, R, C, Tptr, N, K);
+    } else {
+        dim3 grid((N + 63) / 64, (unsigned)((Tmax + 63) / 64));
+        hipLaunchKernelGGL((gemm_f32_mfma_kernel<EPI, 1>), grid, dim3(256), 0, s, A, W, bias, R, C, Tptr, N, K);
+    }
 }
 
 template <int EPI>
@@ -728,12 +740,13 @@ int enqueue_forward(mvdb_encoder* e, const int32_t* ids, const int32_t* mask, in
 #undef EMBED_CALL
 
     const float scale = 1.0f / sqrtf((float)hd);
+    const int cus = device_cus(e->device);
     const dim3 agrid((S + ATT_Q - 1) / ATT_Q, c.heads, B);
     for (const LayerW& L : e->layers) {
         if (compute == 1)
             launch_gemm_h<EPI_BIAS>(e->x, L.wqkv_h, L.bqkv, nullptr, e->qkv, Tptr, Tmax, 3 * H, H, s);
         else
-            launch_gemm<EPI_BIAS>(e->x, L.wqkv, L.bqkv, nullptr, e->qkv, Tptr, Tmax, 3 * H, H, s);
+            launch_gemm<EPI_BIAS>(e->x, L.wqkv, L.bqkv, nullptr, e->qkv, Tptr, Tmax, 3 * H, H, cus, s);
         if (hd == 32)
             hipLaunchKernelGGL(attention_kernel<32>, agrid, dim3(ATT_Q), 0, s, e->qkv, e->seq_start, H, scale,
                                e->ctx);
@@ -743,7 +756,7 @@ int enqueue_forward(mvdb_encoder* e, const int32_t* ids, const int32_t* mask, in
         if (compute == 1)
             launch_gemm_h<EPI_BIAS_RESIDUAL>(e->ctx, L.wo_h, L.bo, e->x, e->y, Tptr, Tmax, H, H, s);
         else
-            launch_gemm<EPI_BIAS_RESIDUAL>(e->ctx, L.wo, L.bo, e->x, e->y, Tptr, Tmax, H, H, s);
+            launch_gemm<EPI_BIAS_RESIDUAL>(e->ctx, L.wo, L.bo, e->x, e->y, Tptr, Tmax, H, H, cus, s);
 #define LN1_CALL(V) launch_ln<V>(e->y, e->seq_start, B, L.ln1g, L.ln1b, c.ln_eps, H, e->x, Tmax, s)
         MVDB_VPT_SWITCH(LN1_CALL)
 #undef LN1_CALL
@@ -751,8 +764,8 @@ int enqueue_forward(mvdb_encoder* e, const int32_t* ids, const int32_t* mask, in
             launch_gemm_h<EPI_BIAS_GELU>(e->x, L.w1_h, L.b1, nullptr, e->ffn, Tptr, Tmax, F, H, s);
             launch_gemm_h<EPI_BIAS_RESIDUAL>(e->ffn, L.w2_h, L.b2, e->x, e->y, Tptr, Tmax, H, F, s);
         } else {
-            launch_gemm<EPI_BIAS_GELU>(e->x, L.w1, L.b1, nullptr, e->ffn, Tptr, Tmax, F, H, s);
-            launch_gemm<EPI_BIAS_RESIDUAL>(e->ffn, L.w2, L.b2, e->x, e->y, Tptr, Tmax, H, F, s);
+            launch_gemm<EPI_BIAS_GELU>(e->x, L.w1, L.b1, nullptr, e->ffn, Tptr, Tmax, F, H, cus, s);
+            launch_gemm<EPI_BIAS_RESIDUAL>(e->ffn, L.w2, L.b2, e->x, e->y, Tptr, Tmax, H, F, cus, s);
         }
 #define LN2_CALL(V) launch_ln<V>(e->y, e->seq_start, B, L.ln2g, L.ln2b, c.ln_eps, H, e->x, Tmax, s)
         MVDB_VPT_SWITCH(LN2_CALL)
