@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """BASELINE config 5 end to end on one MI355X: e5-small-shaped encoder forward (batch 256
 sentences, random-init weights, synthetic token ids) -> pooled, normalised 384-d embeddings (never
-leave the device) -> kNN (k = 10) over a resident 10M x 384 fp32 corpus, 16 queries per MFMA pass.
+leave the device) -> kNN (k = 10) over a resident 10M x 384 fp32 corpus, 32 queries per MFMA pass.
 Prints one JSON line per sequence length."""
 import json
 import os
@@ -82,8 +82,8 @@ def main():
                           "tokens": int(lens.sum()), "encoder_ms": round(t_enc * 1e3, 3),
                           "knn_ms": round((t_all - t_enc) * 1e3, 3), "end_to_end_ms": round(t_all * 1e3, 3),
                           "sentences_per_s": round(B / t_all, 1),
-                          "knn_corpus_passes": (B + 15) // 16,
-                          "knn_GBps": round(((B + 15) // 16) * n * H * 4 / (t_all - t_enc) / 1e9, 1)}), flush=True)
+                          "knn_corpus_passes": (B + 31) // 32,
+                          "knn_GBps": round(((B + 31) // 32) * n * H * 4 / (t_all - t_enc) / 1e9, 1)}), flush=True)
     idx.close()
     enc.close()
 
