@@ -49,13 +49,17 @@ class OracleIndex:
     def search(self, q, k, normalize_q=False):
         self.calls.append(("search", k))
         q = np.atleast_2d(np.asarray(q, dtype=np.float32))
-        if self.x.shape[0] == 0:
+        x = self.x
+        if x.shape[0] == 0:
             return (np.full((q.shape[0], k), -3.4028234663852886e38, np.float32),
                     np.full((q.shape[0], k), -1, np.int64))
-        return flat.flat_search(self.x, q, k, metric=self.metric, normalize_q=normalize_q)
+        return flat.flat_search(x, q, k, metric=self.metric, normalize_q=normalize_q)
 
     def search_subset(self, q, k, rows, normalize_q=False):
         self.calls.append(("subset", k, len(rows)))
         q = np.atleast_2d(np.asarray(q, dtype=np.float32))
-        return flat.flat_search(self.x, q, k, metric=self.metric, normalize_q=normalize_q,
-                                rows=np.asarray(rows, dtype=np.int64))
+        x = self.x  # one snapshot: a concurrent remove_rows replaces self.x
+        rows = np.asarray(rows, dtype=np.int64)
+        if rows.size and (rows.min() < 0 or rows.max() >= x.shape[0]):
+            raise ValueError("subset row out of range")  # what mvdb_index_search_subset reports
+        return flat.flat_search(x, q, k, metric=self.metric, normalize_q=normalize_q, rows=rows)

@@ -36,8 +36,13 @@ def _stress(db, delete):
                 ids, dist, meta = db.find_most_similar(q[i], k=7)
                 assert len(ids) == len(dist) == len(meta) <= 7
                 # (like the reference, a search racing a delete may map a row that has just been
-                # renumbered — only the shape of the result is asserted while writers are active)
-                ids, dist, meta = db.find_most_similar(q[i], k=5, metadata_filter={"w": sidx})
+                # renumbered, or hold a row list that the delete has shortened — the reference's
+                # `self.embeddings[list(filtered)]` raises IndexError there, the device library
+                # ValueError; only the shape of successful results is asserted while writers run)
+                try:
+                    ids, dist, meta = db.find_most_similar(q[i], k=5, metadata_filter={"w": sidx})
+                except (ValueError, IndexError):
+                    continue
                 assert len(ids) == len(dist) == len(meta) <= 5
         except Exception as e:  # pragma: no cover
             errs.append(("s", e))
