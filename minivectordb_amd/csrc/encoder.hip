@@ -542,6 +542,135 @@ __global__ __launch_bounds__(ATT_Q) void attention_kernel(const float* __restric
     }
 }
 
+// =================================================================================================
+// attention on the exact-fp32 matrix cores (default): "swapped" formulation, softmax in registers
+// =================================================================================================
+// One wave owns 32 query rows of one (sequence, head); the 4 waves of a block share K/V tiles in LDS.
+//   S^T[key][query] = K · Q^T        v_mfma_f32_32x32x2_f32, A = K tile (k-major in LDS), B = Q^T (registers,
+//                                    pre-scaled by 1/sqrt(hd)): the QUERY ends up on the lane (col = lane&31),
+//                                    16 of the block's 32 keys on the registers of each lane half
+//   softmax over keys                per lane: 16-register max/sum + one exchange with lane^32; online rescale
+//   O^T[d][query] += V^T · P^T       A = V^T (V tile row-major in LDS: lane reads V[key][d = lane&31]),
+//                                    B = P^T = accumulator register t AS IT STANDS: MFMA step t contracts the
+//                                    two keys (t&3) + 8(t>>2) + {0,4} that the two lane halves hold in register t
+// No P tile ever goes through LDS and no lane shuffles for the second product.
+constexpr int AM_KT = 64;  // keys per LDS tile (2 MFMA key blocks)
+
+template <int HD>
+__global__ __launch_bounds__(256) void attention_mfma_kernel(const float* __restrict__ qkv,
+                                                             const int* __restrict__ seq_start, int H,
+                                                             float scale, float* __restrict__ ctx) {
+    constexpr int DT = HD / 32;         // 32-wide d tiles of the output
+    constexpr int KLD = AM_KT + 1;      // Kt row stride (floats): +1 => the transposing writes are <= 2-way
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int s0 = seq_start[b], len = seq_start[b + 1] - s0;
+    const int q0 = blockIdx.x * 128;
+    if (q0 >= len) return;
+    __shared__ float Kt[HD * KLD];      // [k][key]
+    __shared__ float Vs[AM_KT * HD];    // [key][d]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 31, fh = lane >> 5;
+    const int64_t ld = 3 * (int64_t)H;
+
+    // Q^T fragments: step kk (k = 2kk + fh) of query q0 + 32*wave + fr, pre-scaled
+    const int qrow = q0 + wave * 32 + fr;
+    const bool qvalid = qrow < len;
+    float qf[HD / 2];
+    {
+        const float* qp = qkv + (int64_t)(s0 + (qvalid ? qrow : 0)) * ld + h * HD;
+#pragma unroll
+        for (int kk = 0; kk < HD / 2; ++kk) qf[kk] = qvalid ? qp[2 * kk + fh] * scale : 0.f;
+    }
+    f32x16 o[DT];
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
+    float m = -INFINITY, l = 0.f;
+    const bool wave_active = q0 + wave * 32 < len;  // wave-uniform
+
+    for (int kt = 0; kt < len; kt += AM_KT) {
+        const int nk = min(AM_KT, len - kt);
+        __syncthreads();
+        // cooperative tile load: thread -> (key = e / (HD/4), float4 chunk c); K transposed, V straight
+        for (int e = tid; e < AM_KT * (HD / 4); e += 256) {
+            const int key = e / (HD / 4), c = (e % (HD / 4)) * 4;
+            f32x4 kv = {0, 0, 0, 0}, vv = {0, 0, 0, 0};
+            if (key < nk) {
+                const float* base = qkv + (int64_t)(s0 + kt + key) * ld + h * HD + c;
+                kv = *reinterpret_cast<const f32x4*>(base + H);
+                vv = *reinterpret_cast<const f32x4*>(base + 2 * H);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) Kt[(c + j) * KLD + key] = kv[j];
+            *reinterpret_cast<f32x4*>(&Vs[key * HD + c]) = vv;
+        }
+        __syncthreads();
+        if (!wave_active) continue;
+#pragma unroll
+        for (int kb = 0; kb < AM_KT / 32; ++kb) {
+            if (kb * 32 >= nk) break;
+            // ---- S^T block: 32 keys x 32 queries ----------------------------------------------------
+            f32x16 st;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[r] = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < HD / 2; ++kk) {
+                const float ka = Kt[(2 * kk + fh) * KLD + kb * 32 + fr];  // A[i = key fr][k = fh]
+                st = __builtin_amdgcn_mfma_f32_32x32x2f32(ka, qf[kk], st, 0, 0, 0);
+            }
+            // ---- online softmax, query on the lane --------------------------------------------------
+            float cmax = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                st[r] = key < nk ? st[r] : -INFINITY;
+                cmax = fmaxf(cmax, st[r]);
+            }
+            cmax = fmaxf(cmax, __shfl_xor(cmax, 32));
+            const float mn = fmaxf(m, cmax);
+            const float alpha = expf(m - mn);
+            float psum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                st[r] = expf(st[r] - mn);  // masked keys: exp(-inf) = 0
+                psum += st[r];
+            }
+            psum += __shfl_xor(psum, 32);
+            l = l * alpha + psum;
+            m = mn;
+#pragma unroll
+            for (int t = 0; t < DT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+            // ---- O^T += V^T · P^T ----------------------------------------------------------------------
+#pragma unroll
+            for (int t16 = 0; t16 < 16; ++t16) {
+                const int key = kb * 32 + (t16 & 3) + 8 * (t16 >> 2) + 4 * fh;
+#pragma unroll
+                for (int t = 0; t < DT; ++t) {
+                    const float va = Vs[key * HD + t * 32 + fr];  // A[i = d fr][k = fh] = V[key][d]
+                    o[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(va, st[t16], o[t], 0, 0, 0);
+                }
+            }
+        }
+    }
+    if (!wave_active) return;
+    // O^T tile t: col = query fr (lane), row d = t*32 + (r&3) + 8(r>>2) + 4fh
+    if (qvalid) {
+        const float inv = 1.0f / l;
+        float* op = ctx + (int64_t)(s0 + qrow) * H + h * HD;
+#pragma unroll
+        for (int t = 0; t < DT; ++t)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                f32x4 v = {o[t][4 * r4] * inv, o[t][4 * r4 + 1] * inv, o[t][4 * r4 + 2] * inv,
+                           o[t][4 * r4 + 3] * inv};
+                *reinterpret_cast<f32x4*>(op + t * 32 + 8 * r4 + 4 * fh) = v;  // d = 8*r4 + 4fh + 0..3
+            }
+    }
+}
+
 // concat Wq,Wk,Wv ([H,H] each) and their biases into one [3H,H] / [3H]
 __global__ void concat3_kernel(const float* a, const float* b, const float* c, int64_t n, float* out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -741,18 +870,30 @@ int enqueue_forward(mvdb_encoder* e, const int32_t* ids, const int32_t* mask, in
 
     const float scale = 1.0f / sqrtf((float)hd);
     const int cus = device_cus(e->device);
+    static const bool attn_valu = []() {
+        const char* v = getenv("MVDB_ENCODER_ATTENTION");
+        return v && v[0] == 'v';
+    }();
     const dim3 agrid((S + ATT_Q - 1) / ATT_Q, c.heads, B);
     for (const LayerW& L : e->layers) {
         if (compute == 1)
             launch_gemm_h<EPI_BIAS>(e->x, L.wqkv_h, L.bqkv, nullptr, e->qkv, Tptr, Tmax, 3 * H, H, s);
         else
             launch_gemm<EPI_BIAS>(e->x, L.wqkv, L.bqkv, nullptr, e->qkv, Tptr, Tmax, 3 * H, H, cus, s);
-        if (hd == 32)
-            hipLaunchKernelGGL(attention_kernel<32>, agrid, dim3(ATT_Q), 0, s, e->qkv, e->seq_start, H, scale,
+        if (attn_valu) {  // MVDB_ENCODER_ATTENTION=valu: the thread-per-query VALU kernel (A/B reference)
+            if (hd == 32)
+                hipLaunchKernelGGL(attention_kernel<32>, agrid, dim3(ATT_Q), 0, s, e->qkv, e->seq_start, H, scale,
+                                   e->ctx);
+            else
+                hipLaunchKernelGGL(attention_kernel<64>, agrid, dim3(ATT_Q), 0, s, e->qkv, e->seq_start, H, scale,
+                                   e->ctx);
+        } else if (hd == 32) {
+            hipLaunchKernelGGL(attention_mfma_kernel<32>, agrid, dim3(256), 0, s, e->qkv, e->seq_start, H, scale,
                                e->ctx);
-        else
-            hipLaunchKernelGGL(attention_kernel<64>, agrid, dim3(ATT_Q), 0, s, e->qkv, e->seq_start, H, scale,
+        } else {
+            hipLaunchKernelGGL(attention_mfma_kernel<64>, agrid, dim3(256), 0, s, e->qkv, e->seq_start, H, scale,
                                e->ctx);
+        }
         if (compute == 1)
             launch_gemm_h<EPI_BIAS_RESIDUAL>(e->ctx, L.wo_h, L.bo, e->x, e->y, Tptr, Tmax, H, H, s);
         else
