@@ -14,10 +14,13 @@
 //     all valid).  Packing (counts, prefix sums, gather map) is computed on the device, so the
 //     whole forward is enqueued without a host round trip; grids are sized for B*S and tiles
 //     beyond T exit early.
-//   * GEMMs on the exact-fp32 matrix cores: v_mfma_f32_32x32x2_f32, 128x128x16 block tile, 4 waves
-//     (2x2) x (2x2) 32x32 tiles per wave, LDS tiles stored k-major so every ds_read_b32 of a
-//     fragment is conflict-free, register-staged global->LDS double buffering (T14 split).
-//     Results are bit-for-bit an fp32 fmaf chain in k order (parity with the reference's fp32).
+//   * GEMMs on the exact-fp32 matrix cores: v_mfma_f32_32x32x2_f32, 128x128x16 (or 64x64x16) block
+//     tile, 4 waves, LDS tiles stored k-major so every ds_read_b32 of a fragment is conflict-free,
+//     register-staged global->LDS double buffering (T14 split).  Results are bit-for-bit an fp32
+//     fmaf chain in k order (parity with the reference's fp32).
+//   * attention on the same MFMA ("swapped" K·Q^T, softmax in registers, P^T taken from the
+//     accumulator as the next product's operand); an opt-in bf16-operand GEMM mode (compute = 1).
+//   * the whole forward is captured once per shape and replayed as one hipGraph.
 //   * Q/K/V projections fused into one [3H,H] GEMM (weights concatenated once at create time).
 //   * bias / erf-GELU / residual fused into the GEMM epilogue; LayerNorm and pooling are
 //     one-wave-per-row kernels (HBM/L2-bound, tiny).
