@@ -1,0 +1,85 @@
+#!/usr/bin/env python3
+"""Secondary measurements on one MI355X (10M x 512 fp32 resident unless noted), host API (numpy in /
+numpy out, PCIe-inclusive): filtered (subset) search at several selectivities,
+large-k select path, L2 metric, add+normalise, remove_rows.  One JSON line each."""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+from minivectordb_amd import _native as native  # noqa: E402
+from oracle import flat  # noqa: E402
+
+
+def timeit(fn, reps):
+    fn()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    return (time.perf_counter() - t0) / reps
+
+
+def main():
+    n, d = 10_000_000, 512
+    idx = native.FlatIndex(d)
+    idx.reserve(n)
+    t0 = time.perf_counter()
+    idx.add_synthetic(n, 1234, normalize=True)
+    print(json.dumps({"what": "generate + normalise 10M x 512 on device", "ms": round((time.perf_counter() - t0) * 1e3, 2)}),
+          flush=True)
+    q = flat.synth(8, d, 5678)
+    flat.normalize_l2(q)
+    row_bytes = d * 4
+
+    dt = timeit(lambda: idx.search(q[0], 10), 30)
+    print(json.dumps({"what": "full search k=10 (host API)", "ms": round(dt * 1e3, 3), "GBps": round(n * row_bytes / dt / 1e9, 1)}),
+          flush=True)
+    rs = np.random.RandomState(0)
+    for frac in (0.5, 0.1, 0.01, 0.001):
+        m = int(n * frac)
+        rows = np.sort(rs.choice(n, m, replace=False)).astype(np.int64)
+        dt = timeit(lambda: idx.search_subset(q[0], 10, rows), 10)
+        # includes the H2D copy of the row list (8 B per row) — what find_most_similar's filtered branch pays
+        print(json.dumps({"what": f"subset search, {frac:g} of the rows (sorted ids), k=10", "rows": m,
+                          "ms": round(dt * 1e3, 3), "GBps_rows_touched": round(m * row_bytes / dt / 1e9, 1)}), flush=True)
+    rows = rs.permutation(n)[:n // 10].astype(np.int64)
+    dt = timeit(lambda: idx.search_subset(q[0], 10, rows), 10)
+    print(json.dumps({"what": "subset search, 0.1 of the rows (random order), k=10", "rows": len(rows),
+                      "ms": round(dt * 1e3, 3), "GBps_rows_touched": round(len(rows) * row_bytes / dt / 1e9, 1)}), flush=True)
+    for k in (64, 100, 1000, 10000):
+        dt = timeit(lambda: idx.search(q[0], k), 10)
+        print(json.dumps({"what": f"full search k={k}" + (" (fused select)" if k <= 64 else " (scores + radix select)"),
+                          "ms": round(dt * 1e3, 3)}), flush=True)
+    dt = timeit(lambda: idx.search(q, 10), 10)
+    print(json.dumps({"what": "8 queries in one call, k=10 (MFMA pass)", "ms": round(dt * 1e3, 3)}), flush=True)
+    t0 = time.perf_counter()
+    idx.remove_rows(np.array([5, 5_000_000, 9_999_999], np.int64))
+    print(json.dumps({"what": "remove 3 rows (compaction of the tail after row 5)", "ms": round((time.perf_counter() - t0) * 1e3, 2)}),
+          flush=True)
+    idx.close()
+
+    n2 = 2_000_000
+    x = flat.synth(n2, d, 7)
+    idx = native.FlatIndex(d)
+    t0 = time.perf_counter()
+    idx.add(x, normalize=True)
+    dt = time.perf_counter() - t0
+    print(json.dumps({"what": "add 2M x 512 from host memory + normalise (PCIe)", "ms": round(dt * 1e3, 1),
+                      "GBps": round(n2 * row_bytes / dt / 1e9, 2)}), flush=True)
+    idx.close()
+    idxl = native.FlatIndex(d, metric=native.METRIC_L2)
+    idxl.reserve(n)
+    idxl.add_synthetic(n, 1234, normalize=True)
+    dt = timeit(lambda: idxl.search(q[0], 10), 20)
+    print(json.dumps({"what": "L2 metric full search k=10", "ms": round(dt * 1e3, 3), "GBps": round(n * row_bytes / dt / 1e9, 1)}),
+          flush=True)
+    idxl.close()
+
+
+if __name__ == "__main__":
+    main()
