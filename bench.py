@@ -32,6 +32,15 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 
 
+def baseline_metric():
+    """The metric string exactly as BASELINE.json spells it."""
+    try:
+        with open(os.path.join(ROOT, "BASELINE.json")) as f:
+            return json.load(f)["metric"]
+    except Exception:
+        return "queries/sec + p50 latency, brute-force IP kNN, 10M\u00d7512 fp32, k=10"
+
+
 def pmc_traffic(n, d):
     """HBM bytes per scan launch from the committed rocprofv3 PMC passes (profiles/*_pmc_summary.json,
     separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same command, FETCH_SIZE doubled per the
@@ -195,7 +204,7 @@ def main():
         avg_ms = scan_ms / max(launches, 1)
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if launches else 0.0
         out = {
-            "metric": "queries/sec + p50 latency, brute-force IP kNN, 10M x 512 fp32, k=10",
+            "metric": baseline_metric(),
             "value": round(world * K * nq / dt, 3),
             "unit": "queries/s",
             "n_gpus": world,
