@@ -73,6 +73,18 @@ class _HostMatrix:
         self.n = need
 
     def delete(self, rows):
+        rows = list(rows)
+        if len(rows) == 1:
+            # one row (delete_embedding): shift the tail in place instead of re-copying the matrix
+            r = int(rows[0])
+            tail = self.n - 1 - r
+            if tail > 0:
+                import ctypes
+                row_bytes = self.d * 4
+                base = self.buf.ctypes.data
+                ctypes.memmove(base + r * row_bytes, base + (r + 1) * row_bytes, tail * row_bytes)
+            self.n -= 1
+            return
         keep = np.ones(self.n, dtype=bool)
         keep[np.asarray(rows, dtype=np.int64)] = False
         kept = self.buf[:self.n][keep]
@@ -130,6 +142,10 @@ class FilterAndRerankMixin:
             if func is None:
                 raise ValueError(f"Invalid operator: {op}")
             predicate = lambda field: func(field, operand)  # noqa: E731
+        if predicate is None:
+            fast = self._rows_equal_cached(key, value)
+            if fast is not None:
+                return fast
         rows = set()
         try:
             for uid in self.inverted_index.get(key, set()).copy():
@@ -142,6 +158,40 @@ class FilterAndRerankMixin:
         except KeyError:
             rows = set()
         return rows
+
+    def _rows_equal_cached(self, key, value):
+        """Equality filters through a per-key value index built on first use and dropped on every write
+        (`_invalidate_filter_cache`).  The reference walks every id that has `key` for each query
+        (vector_database.py:283-302: O(N) Python per filtered search); the index keeps, per value, the
+        matching rows IN THAT SAME ORDER, so the returned set is built by the same sequence of
+        insertions (identical tie order downstream).  Returns None when the value is unhashable."""
+        try:
+            hash(value)
+        except TypeError:
+            return None
+        cache = self.__dict__.setdefault("_value_index", {})
+        entry = cache.get(key)
+        if entry is None:
+            by_value, unhashable = {}, []
+            for uid in self.inverted_index.get(key, set()).copy():
+                if uid not in self.inverse_id_map:
+                    continue
+                row = self.inverse_id_map[uid]
+                field = self.metadata[row].get(key, None)
+                try:
+                    by_value.setdefault(field, []).append(row)
+                except TypeError:  # list / dict metadata value: compared with == at query time
+                    unhashable.append((row, field))
+            entry = cache[key] = (by_value, unhashable)
+        by_value, unhashable = entry
+        rows = set(by_value.get(value, ()))
+        for row, field in unhashable:
+            if field == value:
+                rows.add(row)
+        return rows
+
+    def _invalidate_filter_cache(self):
+        self.__dict__["_value_index"] = {}
 
     def _apply_or_filter(self, or_filters):
         result_indices = set()

@@ -169,6 +169,7 @@ class ShardedVectorDatabase(FilterAndRerankMixin):
             for key in metadata_dict:
                 self.inverted_index[key].add(unique_id)
 
+            self._invalidate_filter_cache()
             self._embeddings_changed = True
             shard_id = self._get_available_shard_id()
             self.box_item_map.setdefault(shard_id, []).append(unique_id)
@@ -219,6 +220,7 @@ class ShardedVectorDatabase(FilterAndRerankMixin):
                 for key in metadata_dict:
                     self.inverted_index[key].add(uid)
 
+            self._invalidate_filter_cache()
             self._embeddings_changed = True
 
             shard_groups = defaultdict(list)
@@ -294,6 +296,7 @@ class ShardedVectorDatabase(FilterAndRerankMixin):
                         del self.inverted_index[key]
 
             self.inverse_id_map = {uid: i for i, uid in enumerate(self.unique_ids)}
+            self._invalidate_filter_cache()
             self._embeddings_changed = True
 
     # ---- search (sharded_vector_database.py:598-662) --------------------------------------------------------

@@ -78,6 +78,7 @@ class VectorDatabase(FilterAndRerankMixin):
                 self.id_map = data['id_map']
                 self.inverse_id_map = data['inverse_id_map']
                 self.inverted_index = data.get('inverted_index', defaultdict(set))
+                self._invalidate_filter_cache()
                 self._synced_rows = 0
                 if self.embedding_size is not None:
                     self._build_index()
@@ -123,6 +124,7 @@ class VectorDatabase(FilterAndRerankMixin):
             for key in metadata_dict:
                 self.inverted_index[key].add(unique_id)
 
+            self._invalidate_filter_cache()
             self._embeddings_changed = True
 
     def store_embeddings_batch(self, unique_ids, embeddings, metadata_dicts=[]):
@@ -157,6 +159,7 @@ class VectorDatabase(FilterAndRerankMixin):
                 for key in metadata_dict:
                     self.inverted_index[key].add(unique_ids[i])
 
+            self._invalidate_filter_cache()
             self._embeddings_changed = True
 
     def delete_embedding(self, unique_id):
@@ -179,20 +182,16 @@ class VectorDatabase(FilterAndRerankMixin):
 
             del self.inverse_id_map[unique_id]
 
-            # renumber: rows after the deleted one move up by one (reference :139-152)
-            new_id_map = {}
-            new_inverse_id_map = {}
-            current_index = 0
-            for old_index in sorted(self.id_map.keys()):
+            # renumber: rows after the deleted one move up by one.  Same resulting maps as the
+            # reference's rebuild over sorted(id_map) (:139-152), done in place over the shifted tail only.
+            n_old = len(self.id_map)
+            for old_index in range(row_num + 1, n_old):
                 uid = self.id_map[old_index]
-                if uid == unique_id:
-                    continue
-                new_id_map[current_index] = uid
-                new_inverse_id_map[uid] = current_index
-                current_index += 1
-            self.id_map = new_id_map
-            self.inverse_id_map = new_inverse_id_map
+                self.id_map[old_index - 1] = uid
+                self.inverse_id_map[uid] = old_index - 1
+            del self.id_map[n_old - 1]
 
+            self._invalidate_filter_cache()
             self._embeddings_changed = True
 
     # ---- search (vector_database.py:466-536) -----------------------------------------------------------------
