@@ -126,7 +126,7 @@ class FilterAndRerankMixin:
             if self._synced_rows < n:
                 start = self._synced_rows
                 self.index.add(self._mat.buf[start:n], normalize=True)
-                self._mat.buf[start:n] = self.index.get_rows(start, n - start)
+                self.index.get_rows(start, n - start, out=self._mat.buf[start:n])  # in-place side effect
                 self._synced_rows = n
             self._embeddings_changed = False
 

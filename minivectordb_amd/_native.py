@@ -185,8 +185,14 @@ class FlatIndex:
     def add_synthetic(self, n, seed, first_row=0, normalize=True):
         check(lib().mvdb_index_add_synthetic(self._h, int(n), int(seed), int(first_row), int(bool(normalize))))
 
-    def get_rows(self, row0, n):
-        out = np.empty((int(n), self.d), dtype=np.float32)
+    def get_rows(self, row0, n, out=None):
+        """Rows [row0, row0+n) as float32 [n,d]; `out` (C-contiguous float32 [n,d]) is filled in place
+        when given (no temporary for multi-GB read-backs)."""
+        if out is None:
+            out = np.empty((int(n), self.d), dtype=np.float32)
+        elif not (isinstance(out, np.ndarray) and out.dtype == np.float32 and out.flags["C_CONTIGUOUS"]
+                  and out.shape == (int(n), self.d)):
+            raise ValueError("out must be a C-contiguous float32 array of shape [n, d]")
         check(lib().mvdb_index_get_rows(self._h, int(row0), int(n), _ptr(out)))
         return out
 

@@ -36,9 +36,12 @@ class OracleIndex:
         self.x = np.ascontiguousarray(np.vstack([self.x, x]))
         self.calls.append(("add", x.shape[0]))
 
-    def get_rows(self, row0, n):
+    def get_rows(self, row0, n, out=None):
         assert 0 <= row0 and row0 + n <= self.x.shape[0]
-        return self.x[row0:row0 + n].copy()
+        if out is None:
+            return self.x[row0:row0 + n].copy()
+        out[...] = self.x[row0:row0 + n]
+        return out
 
     def remove_rows(self, rows):
         rows = np.asarray(rows, dtype=np.int64)
