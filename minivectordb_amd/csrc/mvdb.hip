@@ -376,10 +376,10 @@ int launch_mfma_inst(const MfmaScanArgs& a, int device, hipStream_t stream, int*
     return 0;
 }
 
-template <int KB, int NG>
+template <int KB, int NG, int SKB>
 int launch_mfma2_inst(const MfmaScanArgs& a, int device, hipStream_t stream, int* nblocks_out) {
-    auto kern = flat_scan_mfma2_kernel<KB, NG>;
-    const size_t lds = (size_t)kScanWaves * kWaveLdsBytes + (size_t)kScanWaves * NG * 16 * a.k * 8;
+    auto kern = flat_scan_mfma2_kernel<KB, NG, SKB>;
+    const size_t lds = (size_t)kScanWaves * mfma2_wave_lds_bytes(SKB) + (size_t)kScanWaves * NG * 16 * a.k * 8;
     static size_t lds_set = 0;
     if (lds > 48 * 1024 && lds > lds_set) {
         MVDB_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -402,11 +402,14 @@ int launch_mfma2_inst(const MfmaScanArgs& a, int device, hipStream_t stream, int
 
 template <int NG>
 int launch_mfma2(int KB, const MfmaScanArgs& a, int device, hipStream_t s, int* nb) {
+    const bool deep = env_int("MVDB_MFMA_STAGE", 8) == 16;  // tuning hook: 1-KiB-per-row stages
     switch (KB) {
-        case 8: return launch_mfma2_inst<8, NG>(a, device, s, nb);
-        case 16: return launch_mfma2_inst<16, NG>(a, device, s, nb);
-        case 24: return launch_mfma2_inst<24, NG>(a, device, s, nb);
-        case 32: return launch_mfma2_inst<32, NG>(a, device, s, nb);
+        case 8: return launch_mfma2_inst<8, NG, 8>(a, device, s, nb);
+        case 16: return deep ? launch_mfma2_inst<16, NG, 16>(a, device, s, nb)
+                             : launch_mfma2_inst<16, NG, 8>(a, device, s, nb);
+        case 24: return launch_mfma2_inst<24, NG, 8>(a, device, s, nb);
+        case 32: return deep ? launch_mfma2_inst<32, NG, 16>(a, device, s, nb)
+                             : launch_mfma2_inst<32, NG, 8>(a, device, s, nb);
         default: return fail(MVDB_ERR_ARG, "no staged multi-query kernel for d = %d", KB * 16);
     }
 }

@@ -162,14 +162,17 @@ namespace mvdb {
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
-constexpr int kStageFloats = 128;                      // per row and stage (512 B)
-constexpr int kStageBytes = 16 * kStageFloats * 4;     // 8 KiB per wave and stage
-constexpr int kWaveLdsBytes = 2 * kStageBytes;         // double buffered
+// SKB = 16-float k-blocks per row and stage: 8 -> 512 B per row, 8-KiB stage, a DMA instruction moves
+// 2 rows x 512 B; 16 -> 1 KiB per row, 16-KiB stage, a DMA instruction moves ONE row's contiguous KiB
+// (the GEMV kernel's access shape).
+constexpr int mfma2_stage_bytes(int skb) { return 16 * skb * 64; }
+constexpr int mfma2_wave_lds_bytes(int skb) { return 2 * mfma2_stage_bytes(skb); }
 
-template <int KB, int NG>
+template <int KB, int NG, int SKB>
 __global__ __launch_bounds__(kScanThreads) void flat_scan_mfma2_kernel(MfmaScanArgs a) {
-    static_assert(KB % 8 == 0, "d must be a multiple of 128 for the staged kernel");
-    constexpr int NS = KB / 8;  // stages per tile
+    static_assert(KB % SKB == 0 && (SKB == 8 || SKB == 16), "d must be a multiple of the stage depth");
+    constexpr int NS = KB / SKB;  // stages per tile
+    constexpr int kStageFloats = SKB * 16, kStageBytes = mfma2_stage_bytes(SKB), kWaveLdsBytes = mfma2_wave_lds_bytes(SKB);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int k = a.k;
@@ -197,16 +200,17 @@ __global__ __launch_bounds__(kScanThreads) void flat_scan_mfma2_kernel(MfmaScanA
     const int64_t ntiles = (a.n + 15) / 16;
     const int64_t nwaves_total = (int64_t)gridDim.x * kScanWaves;
     const int64_t last = a.n - 1;
-    // DMA lane roles: instruction i (0..7) of a stage moves rows 2i and 2i+1; lane ln -> row 2i + (ln>>5),
-    // LDS chunk position p = ln & 31 of that row, which must receive global chunk p ^ (row & 15)
-    const int dma_rsel = lane >> 5, dma_p = lane & 31;
+    // DMA lane roles.  SKB = 8: instruction i (0..7) moves rows 2i and 2i+1; lane ln -> row 2i + (ln>>5),
+    // LDS chunk position p = ln & 31.  SKB = 16: instruction i (0..15) moves row i, p = ln.  Position p of
+    // row r must receive global chunk p ^ (r & 15).
+    const int dma_rsel = SKB == 8 ? lane >> 5 : 0, dma_p = SKB == 8 ? (lane & 31) : lane;
     // fragment read: row (l&15), k-group (l>>4)
     const int fr = lane & 15, fkg = lane >> 4;
 
     auto issue_stage = [&](int64_t tile, int ks, int buf) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int r = 2 * i + dma_rsel;
+        for (int i = 0; i < SKB; ++i) {
+            const int r = (SKB == 8 ? 2 * i : i) + dma_rsel;
             int64_t row = tile * 16 + r;
             row = row <= last ? row : last;
             const float* src = a.X + row * a.ld + ks * kStageFloats + 4 * (dma_p ^ (r & 15));
@@ -240,22 +244,25 @@ __global__ __launch_bounds__(kScanThreads) void flat_scan_mfma2_kernel(MfmaScanA
             const int buf = cnt & 1;
             const int64_t t1 = stage_tile(tile, ks + 1), t2 = stage_tile(tile, ks + 2);
             __builtin_amdgcn_sched_barrier(0);
-            if (t1 < ntiles)
-                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // this stage landed, s+1 still in flight
-            else
+            if (t1 < ntiles) {  // this stage landed, the SKB DMAs of stage s+1 still in flight
+                if (SKB == 8)
+                    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else
+                    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            } else
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
             const unsigned char* sb = wbuf + buf * kStageBytes + fr * (kStageFloats * 4);
-            f32x4m xb[8];
+            f32x4m xb[SKB];
 #pragma unroll
-            for (int kbl = 0; kbl < 8; ++kbl)
+            for (int kbl = 0; kbl < SKB; ++kbl)
                 xb[kbl] = *reinterpret_cast<const f32x4m*>(sb + (((4 * kbl + fkg) ^ fr) << 4));
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
             if (t2 < ntiles) issue_stage(t2, (ks + 2) % NS, buf);  // refill the buffer just drained
 #pragma unroll
-            for (int kbl = 0; kbl < 8; ++kbl) {
-                const int kb = ks * 8 + kbl;
+            for (int kbl = 0; kbl < SKB; ++kbl) {
+                const int kb = ks * SKB + kbl;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
 #pragma unroll
