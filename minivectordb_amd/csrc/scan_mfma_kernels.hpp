@@ -53,6 +53,49 @@ __device__ __forceinline__ uint64_t lds_list_insert(uint64_t* list, int k, uint6
     return readlane_u64(better < k ? nv : cur, k - 1);
 }
 
+// Offer one 16-row tile's scores to the per-wave, per-query LDS lists.  acc[g][r] of lane l is the score
+// of corpus row (tile*16 + (l&15)) against query g*16 + 4*(l>>4) + r.  thr[g][r] gates (score only);
+// the exact 64-bit order is decided by the insert.  Wave-uniform control flow.
+template <int NG>
+__device__ __forceinline__ void mfma_tile_select(const f32x4m (&acc)[NG], float (&thr)[NG][4], bool rvalid,
+                                                 uint32_t rowid, int nq, int k, uint64_t* mylists, int lane) {
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float s = acc[g][r];
+            uint64_t mask = __ballot(rvalid && s >= thr[g][r]);
+            while (mask) {
+                const int src = __ffsll((long long)mask) - 1;
+                mask &= mask - 1;
+                const int qq = g * 16 + 4 * (src >> 4) + r;
+                if (qq >= nq) continue;  // padded query slot
+                const float sv = __uint_as_float(__builtin_amdgcn_readlane((int)__float_as_uint(s), src));
+                const uint32_t rv = (uint32_t)__builtin_amdgcn_readlane((int)rowid, src);
+                const uint64_t kth = lds_list_insert(mylists + (size_t)qq * k, k, make_key(sv, rv), lane);
+                const float t = kth ? key_score(kth) : -INFINITY;
+                if ((lane >> 4) == (src >> 4)) thr[g][r] = t;
+            }
+        }
+    }
+}
+
+// After the scan: wave w merges, for queries w, w+4, ..., the lists of all waves and writes the block's list.
+template <int NG>
+__device__ __forceinline__ void mfma_block_merge(const uint64_t* lists, int nq, int k, uint64_t* cand, int lane,
+                                                 int wave) {
+    for (int qq = wave; qq < nq; qq += kScanWaves) {
+        WaveTopK tk;
+        tk.init(k);
+#pragma unroll 1
+        for (int w = 0; w < kScanWaves; ++w) {
+            const uint64_t* l = lists + ((size_t)w * NG * 16 + qq) * k;
+            tk.offer(lane < k ? l[lane] : 0ull);
+        }
+        if (lane < k) cand[((int64_t)qq * gridDim.x + blockIdx.x) * k + lane] = tk.key;
+    }
+}
+
 template <int KB, int NG>
 __global__ __launch_bounds__(kScanThreads) void flat_scan_mfma_kernel(MfmaScanArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -107,41 +150,11 @@ __global__ __launch_bounds__(kScanThreads) void flat_scan_mfma_kernel(MfmaScanAr
                 }
             }
         }
-        // ---- selection -------------------------------------------------------------------------
-        const uint32_t rowid = (uint32_t)(tile * 16 + (lane & 15));
-#pragma unroll
-        for (int g = 0; g < NG; ++g) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float s = acc[g][r];
-                uint64_t mask = __ballot(rvalid && s >= thr[g][r]);
-                while (mask) {
-                    const int src = __ffsll((long long)mask) - 1;
-                    mask &= mask - 1;
-                    const int qq = g * 16 + 4 * (src >> 4) + r;
-                    if (qq >= a.nq) continue;  // padded query slot
-                    const float sv = __uint_as_float(__builtin_amdgcn_readlane((int)__float_as_uint(s), src));
-                    const uint32_t rv = (uint32_t)__builtin_amdgcn_readlane((int)rowid, src);
-                    const uint64_t kth = lds_list_insert(mylists + (size_t)qq * k, k, make_key(sv, rv), lane);
-                    const float t = kth ? key_score(kth) : -INFINITY;
-                    if ((lane >> 4) == (src >> 4)) thr[g][r] = t;
-                }
-            }
-        }
+        mfma_tile_select<NG>(acc, thr, rvalid, (uint32_t)(tile * 16 + (lane & 15)), a.nq, k, mylists, lane);
     }
 
-    // ---- block merge: wave w owns queries qq = w, w+4, ... ---------------------------------------
     __syncthreads();
-    for (int qq = wave; qq < a.nq; qq += kScanWaves) {
-        WaveTopK tk;
-        tk.init(k);
-#pragma unroll 1
-        for (int w = 0; w < kScanWaves; ++w) {
-            const uint64_t* l = lists + ((size_t)w * NG * 16 + qq) * k;
-            tk.offer(lane < k ? l[lane] : 0ull);
-        }
-        if (lane < k) a.cand[((int64_t)qq * gridDim.x + blockIdx.x) * k + lane] = tk.key;
-    }
+    mfma_block_merge<NG>(lists, a.nq, k, a.cand, lane, wave);
 }
 
 }  // namespace mvdb
@@ -276,43 +289,15 @@ __global__ __launch_bounds__(kScanThreads) void flat_scan_mfma2_kernel(MfmaScanA
             }
             ++cnt;
         }
-        // ---- selection (as in v1) -----------------------------------------------------------------
-        const bool rvalid = tile * 16 + fr <= last;
-        const uint32_t rowid = (uint32_t)(tile * 16 + fr);
+        f32x4m acc[NG];
 #pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            const f32x4m acc = acc0[g] + acc1[g];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float s = acc[r];
-                uint64_t mask = __ballot(rvalid && s >= thr[g][r]);
-                while (mask) {
-                    const int src = __ffsll((long long)mask) - 1;
-                    mask &= mask - 1;
-                    const int qq = g * 16 + 4 * (src >> 4) + r;
-                    if (qq >= a.nq) continue;
-                    const float sv = __uint_as_float(__builtin_amdgcn_readlane((int)__float_as_uint(s), src));
-                    const uint32_t rv = (uint32_t)__builtin_amdgcn_readlane((int)rowid, src);
-                    const uint64_t kth = lds_list_insert(mylists + (size_t)qq * k, k, make_key(sv, rv), lane);
-                    const float t = kth ? key_score(kth) : -INFINITY;
-                    if ((lane >> 4) == (src >> 4)) thr[g][r] = t;
-                }
-            }
-        }
+        for (int g = 0; g < NG; ++g) acc[g] = acc0[g] + acc1[g];
+        mfma_tile_select<NG>(acc, thr, tile * 16 + fr <= last, (uint32_t)(tile * 16 + fr), a.nq, k, mylists, lane);
         tile = next_tile;
     }
 
     __syncthreads();
-    for (int qq = wave; qq < a.nq; qq += kScanWaves) {
-        WaveTopK tk;
-        tk.init(k);
-#pragma unroll 1
-        for (int w = 0; w < kScanWaves; ++w) {
-            const uint64_t* l = lists + ((size_t)w * NG * 16 + qq) * k;
-            tk.offer(lane < k ? l[lane] : 0ull);
-        }
-        if (lane < k) a.cand[((int64_t)qq * gridDim.x + blockIdx.x) * k + lane] = tk.key;
-    }
+    mfma_block_merge<NG>(lists, a.nq, k, a.cand, lane, wave);
 }
 
 }  // namespace mvdb
