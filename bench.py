@@ -239,11 +239,16 @@ def main():
         }
         if world == 1:
             # PCIe-inclusive host API (numpy in, numpy out): reported, never `value`
-            qh = queries[W:W + 32].cpu().numpy()
-            t0 = time.perf_counter()
+            qh = queries[W * nq:W * nq + 64].cpu().numpy()
+            for i in range(3):
+                idx.search(qh[i], k)  # first calls allocate the host-path workspace
+            hl = []
             for i in range(qh.shape[0]):
+                a = time.perf_counter()
                 idx.search(qh[i], k)
-            out["host_api_qps"] = round(qh.shape[0] / (time.perf_counter() - t0), 3)
+                hl.append(time.perf_counter() - a)
+            out["host_api_qps"] = round(len(hl) / sum(hl), 3)
+            out["host_api_p50_ms"] = round(float(np.median(hl)) * 1e3, 4)
             if not args.no_cpu_baseline and nq == 1:
                 out["cpu_baseline"] = cpu_baseline(native, idx, d, k, qh, n)
             else:
