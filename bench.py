@@ -41,17 +41,20 @@ def baseline_metric():
         return "queries/sec + p50 latency, brute-force IP kNN, 10M\u00d7512 fp32, k=10"
 
 
-def pmc_traffic(n, d):
+def pmc_traffic(n, d, nq=1):
     """HBM bytes per scan launch from the committed rocprofv3 PMC passes (profiles/*_pmc_summary.json,
     separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same command, FETCH_SIZE doubled per the
     guide's gfx950 correction).  Counters cannot be collected from inside the timed process, so this
     is the figure of the profiled run of the same workload, or None when no matching profile exists."""
     import glob
     best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json"))):
+    kern = "flat_scan_kernel" if nq == 1 else "flat_scan_mfma"
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")))
+    files.sort(key=lambda f: f"nq{nq}_" in os.path.basename(f))  # the pass profiled at this nq wins
+    for f in files:
         try:
             for rec in json.load(open(f)):
-                if "flat_scan_kernel" in rec["kernel"] and rec["launches_fetch_pass"] > 0:
+                if kern in rec["kernel"] and rec["launches_fetch_pass"] > 0:
                     t = rec["hbm_traffic_bytes_per_launch_avg"]
                     if abs(t / (n * d * 4.0) - 1.0) < 0.25:  # same workload size
                         best = {"bytes": int(t), "source": os.path.basename(f)}
@@ -229,8 +232,8 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": (pmc_traffic(n, d) or {}).get("bytes"),
-                "traffic_source": (pmc_traffic(n, d) or {}).get("source"),
+                "traffic": (pmc_traffic(n, d, nq) or {}).get("bytes"),
+                "traffic_source": (pmc_traffic(n, d, nq) or {}).get("source"),
                 "kernel": "flat_scan_kernel" if nq == 1 else "flat_scan_mfma_kernel",
                 "launches": launches,
                 "avg_launch_ms": round(avg_ms, 4),
