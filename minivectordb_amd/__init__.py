@@ -5,7 +5,8 @@ Public surface mirrors the reference package (minivectordb/): ``VectorDatabase``
 hand-written HIP kernels behind the C-ABI in include/mvdb.h; there is no CPU fallback.
 """
 
-__all__ = ["VectorDatabase", "ShardedVectorDatabase", "EmbeddingModel", "AlternativeModel"]
+__all__ = ["VectorDatabase", "ShardedVectorDatabase", "DistributedShardedVectorDatabase", "EmbeddingModel",
+           "AlternativeModel"]
 
 
 def __getattr__(name):  # lazy: importing the package must not require a GPU
@@ -15,6 +16,9 @@ def __getattr__(name):  # lazy: importing the package must not require a GPU
     if name == "ShardedVectorDatabase":
         from .sharded_vector_database import ShardedVectorDatabase
         return ShardedVectorDatabase
+    if name == "DistributedShardedVectorDatabase":
+        from .distributed import DistributedShardedVectorDatabase
+        return DistributedShardedVectorDatabase
     if name in ("EmbeddingModel", "AlternativeModel"):
         from . import embedding_model
         return getattr(embedding_model, name)

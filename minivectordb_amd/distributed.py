@@ -123,3 +123,146 @@ class ShardedSearcher:
         dist.all_gather_into_tensor(gathered.buf, local.buf, group=self.group)
         self._merge(gathered, D_out, I_out)
         return D_out, I_out
+
+
+class DistributedShardedVectorDatabase:
+    """Multi-GPU, read-only serving of a reference ``db_shards/`` directory: the drop-in
+    ``find_most_similar`` of ``ShardedVectorDatabase`` with the stacked matrix row-partitioned over the
+    ranks of a ``torch.distributed`` job (one process per GPU).
+
+    Every rank loads the bookkeeping of ALL shard files (ids, metadata, inverted index — global row
+    numbers are the reference's stacking order, sharded_vector_database.py:45-71) but keeps only the
+    embeddings of its own contiguous run of shard files (``shard_files_for_rank``) resident in HBM.
+    ``find_most_similar`` is SPMD: every rank calls it with the same arguments and gets the same,
+    global answer — local scan (full, or restricted to the filtered rows this rank owns), ONE
+    all-gather of the per-shard top-k, k-way merge on every rank.  Exact score ties resolve to the
+    lower global row number.  Writes are not supported in this mode (build the directory with
+    ``ShardedVectorDatabase``); k <= 64 (the merge kernel's limit).
+
+    `index_factory` / `merge` exist for the world_size-2 ``gloo`` test on CPU.
+    """
+
+    def __init__(self, storage_dir='db_shards', rank=None, world=None, device=None, group=None,
+                 index_factory=None, merge=None):
+        import os
+        import pickle
+        from collections import defaultdict
+
+        import numpy as np
+
+        from ._dbcore import FilterAndRerankMixin, _AllRows
+        from .sharded_vector_database import shard_files_for_rank
+
+        self._np = np
+        self._AllRows = _AllRows
+        if world is None:
+            world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        if rank is None:
+            rank = dist.get_rank(group) if world > 1 else 0
+        self.rank, self.world, self.group = int(rank), int(world), group
+        self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self.storage_dir = storage_dir
+
+        files = [f for f in os.listdir(storage_dir) if f.endswith('.pkl')]
+        files.sort(key=lambda x: int(x.split('_')[1].split('.')[0]))
+        mine = set(shard_files_for_rank(storage_dir, self.rank, self.world))
+        self.metadata, self.unique_ids = [], []
+        self.inverted_index = defaultdict(set)
+        pieces, self.first_row, self.local_rows = [], None, 0
+        for fname in files:
+            with open(os.path.join(storage_dir, fname), 'rb') as f:
+                data = pickle.load(f)
+            if fname in mine:
+                if self.first_row is None:
+                    self.first_row = len(self.unique_ids)
+                pieces.append(np.asarray(data['embeddings'], dtype=np.float32))
+                self.local_rows += len(data['unique_ids'])
+            self.metadata.extend(data['metadata'])
+            self.unique_ids.extend(data['unique_ids'])
+            for key, value in data['inverted_index'].items():
+                self.inverted_index[key].update(value)
+            del data
+        if self.first_row is None:
+            self.first_row = len(self.unique_ids)
+        self.inverse_id_map = {uid: i for i, uid in enumerate(self.unique_ids)}
+        self.embedding_size = pieces[0].shape[1] if pieces else None
+        if self.world > 1:  # ranks without rows still need the dimension
+            dims = [None] * self.world
+            dist.all_gather_object(dims, self.embedding_size, group=group)
+            self.embedding_size = next((x for x in dims if x), None)
+
+        # the reference's filter engine, bound to this object's bookkeeping
+        class _Filters(FilterAndRerankMixin):
+            pass
+        self._filters = _Filters()
+        self._filters.inverted_index = self.inverted_index
+        self._filters.inverse_id_map = self.inverse_id_map
+        self._filters.metadata = self.metadata
+        self._filters.hash_vectorizer = None
+
+        self.index = None
+        if self.embedding_size is not None:
+            if index_factory is None:
+                from . import _native
+                index_factory = lambda d: _native.FlatIndex(d, device=self.device.index or 0)  # noqa: E731
+            self.index = index_factory(self.embedding_size)
+            if pieces:
+                self.index.add(np.ascontiguousarray(np.concatenate(pieces, axis=0)), normalize=True)
+        self._merge = merge
+        self._searchers = {}
+
+    def autocut_scores(self, score_list):
+        return self._filters.autocut_scores(score_list)
+
+    def _searcher(self, k):
+        s = self._searchers.get(k)
+        if s is None:
+            s = ShardedSearcher(self.index, k, rank=self.rank, world=self.world, label_offset=self.first_row,
+                                device=self.device, group=self.group, local_search=self._fill_local, merge=self._merge)
+            self._searchers[k] = s
+        return s
+
+    def _fill_local(self, q, D, I, label_offset):
+        D.copy_(torch.from_numpy(self._local_D))
+        I.copy_(torch.from_numpy(self._local_I))
+
+    def find_most_similar(self, embedding, metadata_filter=None, exclude_filter=None, or_filters=None, k=5,
+                          autocut=False):
+        np = self._np
+        n_total = len(self.unique_ids)
+        if n_total == 0 or self.index is None:
+            return [], [], []
+        q = np.array([np.array(embedding, dtype=np.float32)])
+        filtered = self._filters._get_filtered_indices(metadata_filter, exclude_filter, or_filters)
+        if not filtered:
+            return [], [], []
+        search_k = min(k, len(filtered))
+        if search_k > 64:
+            raise NotImplementedError("DistributedShardedVectorDatabase merges at most 64 results per query")
+        lo, hi = self.first_row, self.first_row + self.local_rows
+        miss_d, miss_i = np.float32(-3.4028234663852886e38), -1
+        D = np.full((1, search_k), miss_d, np.float32)
+        I = np.full((1, search_k), miss_i, np.int64)
+        if len(filtered) == n_total:
+            if self.local_rows:
+                kk = min(search_k, self.local_rows)
+                Dl, Il = self.index.search(q, kk, normalize_q=True)
+                D[0, :kk], I[0, :kk] = Dl[0], np.where(Il[0] >= 0, Il[0] + lo, -1)
+        else:
+            mine = np.array(sorted(r for r in filtered if lo <= r < hi), dtype=np.int64)
+            if mine.size:
+                kk = min(search_k, mine.size)
+                Dl, Il = self.index.search_subset(q, kk, mine - lo, normalize_q=True)
+                D[0, :kk], I[0, :kk] = Dl[0], np.where(Il[0] >= 0, mine[np.maximum(Il[0], 0)], -1)
+        self._local_D, self._local_I = D, I
+        Dg, Ig = self._searcher(search_k).search_device(torch.from_numpy(q))
+        Dg, Ig = Dg.cpu().numpy()[0], Ig.cpu().numpy()[0]
+        found = [(self.unique_ids[i], d, self.metadata[i]) for i, d in zip(Ig, Dg) if i >= 0]
+        ids, distances, metadatas = zip(*found) if found else ([], [], [])
+        if autocut and len(distances) > 1:
+            remove = self.autocut_scores(distances)
+            if remove:
+                ids = [ids[i] for i in range(len(ids)) if i not in remove]
+                distances = [distances[i] for i in range(len(distances)) if i not in remove]
+                metadatas = [metadatas[i] for i in range(len(metadatas)) if i not in remove]
+        return ids, distances, metadatas

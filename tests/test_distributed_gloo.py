@@ -93,3 +93,87 @@ def test_shard_ranges_and_files(tmp_path):
         (tmp_path / f"shard_{i}.pkl").write_bytes(b"")
     got = [shard_files_for_rank(str(tmp_path), r, 2) for r in range(2)]
     assert got == [["shard_0.pkl", "shard_1.pkl", "shard_2.pkl"], ["shard_3.pkl", "shard_10.pkl"]]
+
+
+# ---- DistributedShardedVectorDatabase: SPMD find_most_similar over a reference-format db_shards/ -------
+QUERIES = [
+    dict(k=5),
+    dict(k=12, metadata_filter={"bucket": 3}),
+    dict(k=4, or_filters=[{"colour": "red"}, {"bucket": 1}], exclude_filter={"bucket": 4}),
+    dict(k=7, metadata_filter={"price": {"$gte": 40}}, autocut=True),
+    dict(k=3, metadata_filter={"nokey": 1}),
+    dict(k=64),
+]
+
+
+def _np_merge(gathered, D_out, I_out):
+    k = gathered.k
+    for qi in range(gathered.nq):
+        cands = []
+        for l in range(gathered.world):
+            Dl, Il = gathered.views(l)
+            cands += [(-float(Dl[qi, j]), int(Il[qi, j])) for j in range(k) if int(Il[qi, j]) >= 0]
+        cands.sort()
+        for j in range(k):
+            D_out[qi, j] = -cands[j][0] if j < len(cands) else -3.4028234663852886e38
+            I_out[qi, j] = cands[j][1] if j < len(cands) else -1
+
+
+def _build_shards(path, n=95, d=48):
+    from minivectordb_amd import ShardedVectorDatabase, _native
+    from oracle import flat
+    from oracle_backend import OracleIndex
+    _native.FlatIndex = OracleIndex  # this process only builds / checks with the stand-in
+    db = ShardedVectorDatabase(storage_dir=path, shard_size=10)
+    x = flat.synth(n, d, 321)
+    colours = ["red", "green", "blue"]
+    db.store_embeddings_batch([f"id{i}" for i in range(n)], list(x),
+                              [{"bucket": i % 5, "price": i, "colour": colours[i % 3]} for i in range(n)])
+    return db
+
+
+def _dist_worker(rank, world, port, path, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import pickle
+    from minivectordb_amd.distributed import DistributedShardedVectorDatabase
+    from oracle import flat
+    from oracle_backend import OracleIndex
+    db = DistributedShardedVectorDatabase(path, device=torch.device("cpu"), index_factory=OracleIndex, merge=_np_merge)
+    assert db.world == world and db.local_rows > 0
+    q = flat.synth(len(QUERIES), 48, 654)
+    res = []
+    for i, kw in enumerate(QUERIES):
+        ids, dists, metas = db.find_most_similar(q[i], **kw)
+        res.append((list(ids), [float(v) for v in dists], list(metas)))
+    with open(os.path.join(out_dir, f"res{rank}.pkl"), "wb") as f:
+        pickle.dump((res, db.first_row, db.local_rows), f)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_distributed_database_equals_single_process(tmp_path):
+    import pickle
+    from oracle import flat
+    path = str(tmp_path / "shards")
+    ref = _build_shards(path)
+    world = 2
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_dist_worker, args=(world, port, path, str(tmp_path)), nprocs=world, join=True)
+    q = flat.synth(len(QUERIES), 48, 654)
+    want = []
+    for i, kw in enumerate(QUERIES):
+        ids, dists, metas = ref.find_most_similar(q[i], **kw)
+        want.append((list(ids), [float(v) for v in dists], list(metas)))
+    spans = []
+    for r in range(world):
+        res, first, count = pickle.load(open(tmp_path / f"res{r}.pkl", "rb"))
+        spans.append((first, count))
+        for got, exp in zip(res, want):
+            assert got[0] == exp[0]
+            np.testing.assert_allclose(got[1], exp[1], atol=1e-6)
+            assert got[2] == exp[2]
+    assert spans[0] == (0, 50) and spans[1] == (50, 45)  # whole shard files per rank: 5 + 5 files of 10 rows

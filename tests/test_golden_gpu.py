@@ -26,3 +26,26 @@ def test_scenario_matches_reference_on_gpu(name, tmp_path, gpu):
     sc = GOLDEN[name]
     got = replay.run(make_db, sc["ops"], str(tmp_path))
     golden_compare.compare(got, sc["expected"], tol=1e-4, exact=False)
+
+
+def test_distributed_database_single_rank_on_gpu(tmp_path, gpu):
+    """world == 1 path of DistributedShardedVectorDatabase with the real HIP back end: same answers as
+    ShardedVectorDatabase on the same db_shards/ directory (no process group needed)."""
+    import numpy as np
+    import torch
+    from minivectordb_amd import ShardedVectorDatabase
+    from minivectordb_amd.distributed import DistributedShardedVectorDatabase
+    from oracle import flat
+    path = str(tmp_path / "shards")
+    db = ShardedVectorDatabase(storage_dir=path, shard_size=16)
+    n, d = 150, 64
+    x = flat.synth(n, d, 11)
+    db.store_embeddings_batch(list(range(n)), list(x), [{"g": i % 4, "v": i} for i in range(n)])
+    ddb = DistributedShardedVectorDatabase(path, rank=0, world=1, device=torch.device("cuda", 0))
+    q = flat.synth(4, d, 12)
+    for i, kw in enumerate([dict(k=5), dict(k=9, metadata_filter={"g": 2}), dict(k=6, exclude_filter={"g": 0}, autocut=True),
+                            dict(k=64)]):
+        a = db.find_most_similar(q[i], **kw)
+        b = ddb.find_most_similar(q[i], **kw)
+        assert list(a[0]) == list(b[0]) and list(a[2]) == list(b[2])
+        np.testing.assert_allclose(np.array(a[1], np.float32), np.array(b[1], np.float32), atol=1e-6)
