@@ -130,6 +130,68 @@ class FilterAndRerankMixin:
                 self._synced_rows = n
             self._embeddings_changed = False
 
+    # ---- shared ingest / search plumbing ------------------------------------------------------------
+    def _admit(self, unique_ids, vectors, metadata_dicts):
+        """Append rows + bookkeeping common to both database classes (caller holds the lock, has
+        validated ids).  `vectors` is a sequence of float32 1-D arrays.  Returns the first new row."""
+        if self.embedding_size is None:
+            self.embedding_size = vectors[0].shape[0]
+        if self._mat is None:
+            self._mat = _HostMatrix(self.embedding_size)
+        first = self._mat.n
+        if len(vectors):
+            self._mat.append(vectors[0] if len(vectors) == 1 else np.vstack(vectors))
+        self.metadata.extend(metadata_dicts)
+        for row, uid in enumerate(unique_ids, start=first):
+            self.inverse_id_map[uid] = row
+        for uid, meta in zip(unique_ids, metadata_dicts):
+            for key in meta:
+                self.inverted_index[key].add(uid)
+        self._invalidate_filter_cache()
+        self._embeddings_changed = True
+        return first
+
+    def _subset_order(self, wanted):
+        """Enumeration of a filtered row set handed to the device (positions come back).  The flat class
+        uses list(set) like the reference's `self.embeddings[list(filtered)]` (vector_database.py:510)."""
+        return list(wanted)
+
+    def _nearest_rows(self, embedding, metadata_filter, exclude_filter, or_filters, k):
+        """Device half of find_most_similar: [(row, score)] best first, rows of the stacked matrix.
+        Query prep, lazy device sync, filter evaluation, k clamp and the full / filtered branch follow
+        vector_database.py:470-523; the arithmetic is libmvdb's."""
+        if self._mat is None:
+            return []
+        query = np.array([np.array(embedding, dtype=np.float32)])  # [1, d]; normalised on the device
+        if self._embeddings_changed:
+            with self.lock:
+                self._build_index()
+        with self.lock:
+            wanted = self._get_filtered_indices(metadata_filter, exclude_filter, or_filters)
+            index, n_rows = self.index, self._mat.n
+        if not wanted or index is None:
+            return []
+        take = min(k, len(wanted))
+        if len(wanted) == n_rows:
+            scores, rows = index.search(query, take, normalize_q=True)
+            return [(int(r), s) for r, s in zip(rows[0], scores[0]) if r != -1]
+        subset = self._subset_order(wanted)
+        scores, positions = index.search_subset(query, take, subset, normalize_q=True)
+        return [(int(subset[p]), s) for p, s in zip(positions[0], scores[0]) if p != -1]
+
+    def _package(self, hits, autocut):
+        """[(id, score, metadata)] -> (ids, distances, metadatas): tuples, three empty lists when there
+        is nothing, lists after an autocut (the reference's conventions, vector_database.py:526-536)."""
+        if not hits:
+            return [], [], []
+        ids, distances, metadatas = zip(*hits)
+        if autocut and len(distances) > 1:
+            dropped = set(self.autocut_scores(distances))
+            if dropped:
+                keep = [i for i in range(len(ids)) if i not in dropped]
+                return [ids[i] for i in keep], [distances[i] for i in keep], [metadatas[i] for i in keep]
+        return ids, distances, metadatas
+
     # ---- metadata filters (semantics of vector_database.py:157-386) ------------------------------------
     def _rows_matching(self, key, value, operators_allowed=True):
         """Rows whose metadata[key] satisfies `value` (plain equality, or {"$op": operand} — only the

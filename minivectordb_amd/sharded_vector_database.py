@@ -149,32 +149,27 @@ class ShardedVectorDatabase(FilterAndRerankMixin):
         return len(self.box_item_map)
 
     # ---- ingest (sharded_vector_database.py:104-132, :243-287) -----------------------------------------
+    def _assign_to_shards(self, unique_ids, vectors, metadata_dicts):
+        """First non-full shard (dict order) per row, then ONE rewrite per touched shard file
+        (sharded_vector_database.py:98-102, :276-287)."""
+        groups = defaultdict(list)
+        for uid, vec, meta in zip(unique_ids, vectors, metadata_dicts):
+            shard_id = self._get_available_shard_id()
+            groups[shard_id].append((uid, vec, meta))
+            self.box_item_map.setdefault(shard_id, []).append(uid)
+            self.inverse_box_item_map[uid] = shard_id
+        for shard_id, items in groups.items():
+            uids, vecs, metas = zip(*items)
+            self._persist_to_shard_multiple(shard_id, list(uids), list(vecs), list(metas))
+
     def store_embedding(self, unique_id, embedding, metadata_dict={}):
         with self.lock:
             if unique_id in self.inverse_id_map:
                 raise ValueError("Unique ID already exists.")
-
-            embedding = self._convert_ndarray_float32(embedding)
-
-            if self.embedding_size is None:
-                self.embedding_size = embedding.shape[0]
-            if self._mat is None:
-                self._mat = _HostMatrix(self.embedding_size)
-
-            self._mat.append(embedding)
-            self.metadata.append(metadata_dict)
+            vector = self._convert_ndarray_float32(embedding)
+            self._admit([unique_id], [vector], [metadata_dict])
             self.unique_ids.append(unique_id)
-            self.inverse_id_map[unique_id] = len(self.unique_ids) - 1
-
-            for key in metadata_dict:
-                self.inverted_index[key].add(unique_id)
-
-            self._invalidate_filter_cache()
-            self._embeddings_changed = True
-            shard_id = self._get_available_shard_id()
-            self.box_item_map.setdefault(shard_id, []).append(unique_id)
-            self.inverse_box_item_map[unique_id] = shard_id
-            self._persist_to_shard_multiple(shard_id, [unique_id], [embedding], [metadata_dict])
+            self._assign_to_shards([unique_id], [vector], [metadata_dict])
 
     def _persist_to_shard(self, shard_id, unique_id, embedding, metadata_dict):
         self._persist_to_shard_multiple(shard_id, [unique_id], [embedding], [metadata_dict])
@@ -193,46 +188,16 @@ class ShardedVectorDatabase(FilterAndRerankMixin):
         with self.lock:
             if len(unique_ids) != len(embeddings):
                 raise ValueError("Number of unique IDs must match number of embeddings.")
-
-            embeddings = self._convert_ndarray_float32_batch(embeddings)
-
+            vectors = self._convert_ndarray_float32_batch(embeddings)
             for uid in unique_ids:
                 if uid in self.inverse_id_map:
                     raise ValueError(f"Unique ID {uid} already exists.")
-
-            if self.embedding_size is None:
-                self.embedding_size = embeddings[0].shape[0]
-            if self._mat is None:
-                self._mat = _HostMatrix(self.embedding_size)
-
-            if len(metadata_dicts) < len(unique_ids):
-                # pads the caller's list in place, like the reference (:260-261)
-                metadata_dicts.extend([{} for _ in range(len(unique_ids) - len(metadata_dicts))])
-
-            current_count = len(self.unique_ids)
-            if len(embeddings):
-                self._mat.append(np.vstack(embeddings))
-            self.metadata.extend(metadata_dicts)
+            missing = len(unique_ids) - len(metadata_dicts)
+            if missing > 0:  # pads the CALLER's list in place, like the reference (:260-261)
+                metadata_dicts.extend({} for _ in range(missing))
+            self._admit(unique_ids, vectors, metadata_dicts)
             self.unique_ids.extend(unique_ids)
-            self.inverse_id_map.update({uid: i for i, uid in enumerate(unique_ids, start=current_count)})
-
-            for uid, metadata_dict in zip(unique_ids, metadata_dicts):
-                for key in metadata_dict:
-                    self.inverted_index[key].add(uid)
-
-            self._invalidate_filter_cache()
-            self._embeddings_changed = True
-
-            shard_groups = defaultdict(list)
-            for uid, embedding, metadata_dict in zip(unique_ids, embeddings, metadata_dicts):
-                shard_id = self._get_available_shard_id()
-                shard_groups[shard_id].append((uid, embedding, metadata_dict))
-                self.box_item_map.setdefault(shard_id, []).append(uid)
-                self.inverse_box_item_map[uid] = shard_id
-
-            for shard_id, shard_data in shard_groups.items():
-                uids, embs, metas = zip(*shard_data)
-                self._persist_to_shard_multiple(shard_id, list(uids), list(embs), list(metas))
+            self._assign_to_shards(unique_ids, vectors, metadata_dicts)
 
     # ---- delete (sharded_vector_database.py:180-241) ------------------------------------------------------
     def _remove_embeddings_from_shard(self, shard_id, unique_ids):
@@ -300,52 +265,11 @@ class ShardedVectorDatabase(FilterAndRerankMixin):
             self._embeddings_changed = True
 
     # ---- search (sharded_vector_database.py:598-662) --------------------------------------------------------
+    def _subset_order(self, wanted):
+        return np.array(list(wanted), dtype=np.int32)  # the int32 row list the reference feeds np.take (:636)
+
     def find_most_similar(self, embedding, metadata_filter=None, exclude_filter=None, or_filters=None, k=5,
                           autocut=False):
-        if self._mat is None:
-            return [], [], []
-
-        embedding = self._convert_ndarray_float32(embedding)
-        embedding = np.array([embedding])
-
-        if self._embeddings_changed:
-            with self.lock:
-                self._build_index()
-
-        with self.lock:
-            filtered_indices = self._get_filtered_indices(metadata_filter, exclude_filter, or_filters)
-            index = self.index
-            n_rows = self._mat.n
-
-        if not filtered_indices:
-            return [], [], []
-        if index is None:
-            return [], [], []
-
-        search_k = min(k, len(filtered_indices))
-        found_results = []
-
-        if len(filtered_indices) == n_rows:
-            distances, indices = index.search(embedding, search_k, normalize_q=True)
-            for idx, dist in zip(indices[0], distances[0]):
-                if idx == -1:
-                    continue
-                found_results.append((self.unique_ids[idx], dist, self.metadata[idx]))
-        else:
-            rows = np.array(list(filtered_indices), dtype=np.int32)  # int32 list, as np.take in the reference
-            distances, indices = index.search_subset(embedding, search_k, rows, normalize_q=True)
-            for idx, dist in zip(indices[0], distances[0]):
-                if idx == -1:
-                    continue
-                found_results.append((self.unique_ids[rows[idx]], dist, self.metadata[rows[idx]]))
-
-        ids, distances, metadatas = zip(*found_results) if found_results else ([], [], [])
-
-        if autocut and len(distances) > 1:
-            remove_indexes = self.autocut_scores(distances)
-            if remove_indexes:
-                ids = [ids[i] for i in range(len(ids)) if i not in remove_indexes]
-                distances = [distances[i] for i in range(len(distances)) if i not in remove_indexes]
-                metadatas = [metadatas[i] for i in range(len(metadatas)) if i not in remove_indexes]
-
-        return ids, distances, metadatas
+        hits = [(self.unique_ids[row], score, self.metadata[row])
+                for row, score in self._nearest_rows(embedding, metadata_filter, exclude_filter, or_filters, k)]
+        return self._package(hits, autocut)

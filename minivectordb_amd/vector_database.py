@@ -107,60 +107,21 @@ class VectorDatabase(FilterAndRerankMixin):
         with self.lock:
             if unique_id in self.inverse_id_map:
                 raise ValueError("Unique ID already exists.")
-
-            embedding = self._convert_ndarray_float32(embedding)
-
-            if self.embedding_size is None:
-                self.embedding_size = embedding.shape[0]
-            if self._mat is None:
-                self._mat = _HostMatrix(self.embedding_size)
-
-            row_num = self._mat.n
-            self._mat.append(embedding)
-            self.metadata.append(metadata_dict)
-            self.id_map[row_num] = unique_id
-            self.inverse_id_map[unique_id] = row_num
-
-            for key in metadata_dict:
-                self.inverted_index[key].add(unique_id)
-
-            self._invalidate_filter_cache()
-            self._embeddings_changed = True
+            row = self._admit([unique_id], [self._convert_ndarray_float32(embedding)], [metadata_dict])
+            self.id_map[row] = unique_id
 
     def store_embeddings_batch(self, unique_ids, embeddings, metadata_dicts=[]):
         with self.lock:
-            for uid in unique_ids:
-                if uid in self.inverse_id_map:
-                    raise ValueError("Unique ID already exists.")
-
-            embeddings = self._convert_ndarray_float32_batch(embeddings)
-
-            if self.embedding_size is None:
-                self.embedding_size = embeddings[0].shape[0]
-            if self._mat is None:
-                self._mat = _HostMatrix(self.embedding_size)
-
-            if len(metadata_dicts) < len(unique_ids) and len(metadata_dicts) > 0:
+            if any(uid in self.inverse_id_map for uid in unique_ids):
+                raise ValueError("Unique ID already exists.")
+            vectors = self._convert_ndarray_float32_batch(embeddings)
+            # like the reference: a partial metadata list is an error, an empty one means "no metadata"
+            if 0 < len(metadata_dicts) < len(unique_ids):
                 raise ValueError("Metadata dictionaries must be provided for all unique IDs.")
-
             if metadata_dicts == []:
-                metadata_dicts = [{} for _ in range(len(unique_ids))]
-
-            first = self._mat.n
-            row_nums = list(range(first, first + len(embeddings)))
-
-            if len(embeddings):
-                self._mat.append(np.vstack(embeddings))
-            self.metadata.extend(metadata_dicts)
-            self.id_map.update(dict(zip(row_nums, unique_ids)))
-            self.inverse_id_map.update({uid: row for row, uid in zip(row_nums, unique_ids)})
-
-            for i, metadata_dict in enumerate(metadata_dicts):
-                for key in metadata_dict:
-                    self.inverted_index[key].add(unique_ids[i])
-
-            self._invalidate_filter_cache()
-            self._embeddings_changed = True
+                metadata_dicts = [{} for _ in unique_ids]
+            first = self._admit(unique_ids, vectors, metadata_dicts)
+            self.id_map.update(zip(range(first, first + len(vectors)), unique_ids))
 
     def delete_embedding(self, unique_id):
         if unique_id not in self.inverse_id_map:
@@ -199,59 +160,10 @@ class VectorDatabase(FilterAndRerankMixin):
                           autocut=False):
         """ or_filters could be a list of dictionaries, where each dictionary contains key-value pairs for OR
         filters, or a single dictionary, which is equivalent to a list with a single dictionary."""
-        if self._mat is None:
-            return [], [], []
-
-        embedding = self._convert_ndarray_float32(embedding)
-        embedding = np.array([embedding])  # [1, d]; normalised on the device (faiss.normalize_L2, :475)
-
-        if self._embeddings_changed:
-            with self.lock:
-                self._build_index()
-
-        with self.lock:
-            filtered_indices = self._get_filtered_indices(metadata_filter, exclude_filter, or_filters)
-            index = self.index
-            n_rows = self._mat.n
-
-        if not filtered_indices:
-            return [], [], []
-        if index is None:
-            return [], [], []
-
-        search_k = min(k, len(filtered_indices))
-        found_results = []
-
-        if len(filtered_indices) == n_rows:
-            distances, indices = index.search(embedding, search_k, normalize_q=True)
-
-            for idx, dist in zip(indices[0], distances[0]):
-                if idx == -1:
-                    continue
-                if idx in self.id_map:
-                    try:
-                        found_results.append((self.id_map[idx], dist, self.metadata[idx]))
-                    except (KeyError, IndexError):
-                        pass
-        else:
-            rows = list(filtered_indices)  # same enumeration order as the reference's sub-index
-            distances, indices = index.search_subset(embedding, search_k, rows, normalize_q=True)
-
-            for idx, dist in zip(indices[0], distances[0]):
-                if idx == -1:
-                    continue
-                try:
-                    found_results.append((self.id_map[rows[idx]], dist, self.metadata[rows[idx]]))
-                except (KeyError, IndexError):
-                    pass
-
-        ids, distances, metadatas = zip(*found_results) if found_results else ([], [], [])
-
-        if autocut and len(distances) > 1:
-            remove_indexes = self.autocut_scores(distances)
-            if remove_indexes:
-                ids = [ids[i] for i in range(len(ids)) if i not in remove_indexes]
-                distances = [distances[i] for i in range(len(distances)) if i not in remove_indexes]
-                metadatas = [metadatas[i] for i in range(len(metadatas)) if i not in remove_indexes]
-
-        return ids, distances, metadatas
+        hits = []
+        for row, score in self._nearest_rows(embedding, metadata_filter, exclude_filter, or_filters, k):
+            try:  # a row a concurrent delete has just renumbered away is skipped, as in the reference
+                hits.append((self.id_map[row], score, self.metadata[row]))
+            except (KeyError, IndexError):
+                pass
+        return self._package(hits, autocut)
