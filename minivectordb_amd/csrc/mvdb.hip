@@ -233,9 +233,9 @@ int env_int(const char* name, int dflt) {
     return v && *v ? atoi(v) : dflt;
 }
 
-template <int G, int C, int U, int METRIC, int MODE, bool NT, bool SUBSET, bool MASKED, bool DB>
+template <int G, int C, int U, int METRIC, int MODE, bool NT, bool SUBSET, bool MASKED>
 int launch_scan_kern(const ScanArgs& a, int nq, int device, hipStream_t stream, int* nblocks_out) {
-    auto kern = flat_scan_kernel<G, C, U, METRIC, MODE, NT, SUBSET, MASKED, DB>;
+    auto kern = flat_scan_kernel<G, C, U, METRIC, MODE, NT, SUBSET, MASKED>;
     static int occ = 0;  // blocks per CU this instantiation sustains
     static int occ_hw = 0;
     if (occ == 0) {
@@ -266,15 +266,15 @@ int launch_scan_kern(const ScanArgs& a, int nq, int device, hipStream_t stream, 
 }
 
 // runtime -> compile-time switches: subset indirection, lane masking
-template <int G, int C, int U, int METRIC, int MODE, bool NT = true, bool DB = false>
+template <int G, int C, int U, int METRIC, int MODE, bool NT = true>
 int launch_scan_inst(const ScanArgs& a, int nq, int device, hipStream_t s, int* nb) {
     const bool masked = a.d4 != G * C;
     if (a.rows) {
-        if (masked) return launch_scan_kern<G, C, U, METRIC, MODE, NT, true, true, DB>(a, nq, device, s, nb);
-        return launch_scan_kern<G, C, U, METRIC, MODE, NT, true, false, DB>(a, nq, device, s, nb);
+        if (masked) return launch_scan_kern<G, C, U, METRIC, MODE, NT, true, true>(a, nq, device, s, nb);
+        return launch_scan_kern<G, C, U, METRIC, MODE, NT, true, false>(a, nq, device, s, nb);
     }
-    if (masked) return launch_scan_kern<G, C, U, METRIC, MODE, NT, false, true, DB>(a, nq, device, s, nb);
-    return launch_scan_kern<G, C, U, METRIC, MODE, NT, false, false, DB>(a, nq, device, s, nb);
+    if (masked) return launch_scan_kern<G, C, U, METRIC, MODE, NT, false, true>(a, nq, device, s, nb);
+    return launch_scan_kern<G, C, U, METRIC, MODE, NT, false, false>(a, nq, device, s, nb);
 }
 
 template <int G, int C, int U>
@@ -295,12 +295,12 @@ int launch_scan(int metric, int mode, const ScanArgs& a, int nq, int device, hip
                 int* nblocks) {
     const Shape sh = choose_shape(a.d4);
     if (sh.G == 64 && sh.C == 2 && metric == MVDB_METRIC_IP && mode == kModeTopK) {
-        // tuning hook for the headline shape (d = 512): MVDB_SCAN_VARIANT = U*100 + DB*10 + NT
+        // tuning hook for the headline shape (d = 512): MVDB_SCAN_VARIANT = U*100 + NT
         switch (env_int("MVDB_SCAN_VARIANT", -1)) {
-            case 201: return launch_scan_inst<64, 2, 2, 0, kModeTopK, true, false>(a, nq, device, s, nblocks);
-            case 400: return launch_scan_inst<64, 2, 4, 0, kModeTopK, false, false>(a, nq, device, s, nblocks);
-            case 401: return launch_scan_inst<64, 2, 4, 0, kModeTopK, true, false>(a, nq, device, s, nblocks);
-            case 801: return launch_scan_inst<64, 2, 8, 0, kModeTopK, true, false>(a, nq, device, s, nblocks);
+            case 201: return launch_scan_inst<64, 2, 2, 0, kModeTopK, true>(a, nq, device, s, nblocks);
+            case 400: return launch_scan_inst<64, 2, 4, 0, kModeTopK, false>(a, nq, device, s, nblocks);
+            case 401: return launch_scan_inst<64, 2, 4, 0, kModeTopK, true>(a, nq, device, s, nblocks);
+            case 801: return launch_scan_inst<64, 2, 8, 0, kModeTopK, true>(a, nq, device, s, nblocks);
             default: break;
         }
     }

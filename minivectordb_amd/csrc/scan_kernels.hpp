@@ -54,9 +54,9 @@ __device__ __forceinline__ float group_reduce_add(float v) {
 //          no `s_waitcnt vmcnt(0)` between the row loads of a batch).
 // MASKED : the row has fewer than G*C chunks (lanes with chunk >= d4 load nothing).  When the row
 //          fills every lane the loads are unconditional: no exec-mask branches in the loop.
-// DB     : double-buffered batches: the loads of batch b+1 are in flight while batch b is reduced.
-template <int G, int C, int U, int METRIC, int MODE, bool NT = true, bool SUBSET = false, bool MASKED = true,
-          bool DB = false>
+// (Explicit register double-buffering of batches was measured and dropped: 3-5 % slower than relying
+//  on the other resident waves, profiles/r01_sweep_scan_variants.txt lineage.)
+template <int G, int C, int U, int METRIC, int MODE, bool NT = true, bool SUBSET = false, bool MASKED = true>
 __global__ __launch_bounds__(kScanThreads) void flat_scan_kernel(ScanArgs a) {
     constexpr int RPI = kWave / G;  // rows per wave-instruction
     constexpr int RB = RPI * U;     // rows per wave batch
@@ -176,26 +176,10 @@ __global__ __launch_bounds__(kScanThreads) void flat_scan_kernel(ScanArgs a) {
         }
     };
 
-    if (!DB) {
-        for (int64_t b = gw; b < nbatches; b += nwaves_total) {
-            f32x4 x[U][C];
-            load_batch(b, x);
-            consume_batch(b, x);
-        }
-    } else {
-        f32x4 xa[U][C], xb[U][C];
-        int64_t b = gw;
-        if (b < nbatches) load_batch(b, xa);
-        while (b < nbatches) {
-            const int64_t b1 = b + nwaves_total;
-            if (b1 < nbatches) load_batch(b1, xb);
-            consume_batch(b, xa);
-            if (b1 >= nbatches) break;
-            const int64_t b2 = b1 + nwaves_total;
-            if (b2 < nbatches) load_batch(b2, xa);
-            consume_batch(b1, xb);
-            b = b2;
-        }
+    for (int64_t b = gw; b < nbatches; b += nwaves_total) {
+        f32x4 x[U][C];
+        load_batch(b, x);
+        consume_batch(b, x);
     }
 
     if (MODE == kModeTopK) {
