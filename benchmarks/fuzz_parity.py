@@ -1,0 +1,44 @@
+"""Randomised GPU parity fuzz: random (n, d, nq, k, metric, subset, normalisation) cases through the C-ABI,
+each query adjudicated against the float64 oracle.  usage: fuzz_parity.py SEED SECONDS (on a GPU box)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from oracle import flat
+from minivectordb_amd import _native as native
+rs = np.random.RandomState(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
+dims = [1,2,3,4,5,7,8,16,31,32,33,48,64,96,100,128,160,192,224,256,300,384,512,640,768,1000,1024,1100,2048,4096]
+t_end = time.time() + float(sys.argv[2]) if len(sys.argv) > 2 else time.time() + 120
+cases = fails = 0
+while time.time() < t_end:
+    d = int(rs.choice(dims))
+    n = int(rs.choice([1,2,15,16,17,63,64,65,255,256,257,1000,4097, rs.randint(1, 5000)]))
+    if n * d > 30_000_000: n = 30_000_000 // d
+    nq = int(rs.choice([1,1,1,2,3,5,15,16,17,31,32,33,40]))
+    k = int(rs.choice([1,2,5,10,63,64,65,100,300, rs.randint(1, 200)]))
+    metric = int(rs.choice([0,0,0,1]))
+    x = flat.synth(n, d, rs.randint(1<<30)); 
+    if rs.rand() < 0.7: flat.normalize_l2(x)
+    if rs.rand() < 0.2 and n > 4: x[rs.randint(n)] = x[rs.randint(n)]   # duplicate row -> exact tie
+    q = flat.synth(nq, d, rs.randint(1<<30))
+    normq = bool(rs.rand() < 0.5)
+    idx = native.FlatIndex(d, metric=metric)
+    idx.add(x)
+    subset = None
+    if rs.rand() < 0.3 and n > 1:
+        m = rs.randint(1, n+1); subset = rs.permutation(n)[:m].astype(np.int64)
+        D, I = idx.search_subset(q, k, subset, normalize_q=normq)
+    else:
+        D, I = idx.search(q, k, normalize_q=normq)
+    qq = q.copy()
+    if normq: flat.normalize_l2(qq)
+    Do, Io = flat.flat_search(x, qq, k, metric=metric, rows=subset)
+    cases += 1
+    bad = None
+    for i in range(nq):
+        ok, msg = flat.adjudicate(x, qq[i], k, D[i], I[i], metric=metric, rows=subset, tol=1e-4 if metric == 0 else 1e-4 * max(1.0, float(np.abs(Do[i][Io[i]>=0]).max()) if (Io[i]>=0).any() else 1.0))
+        if not ok: bad = (i, msg); break
+    if bad:
+        fails += 1
+        print("FAIL", dict(n=n, d=d, nq=nq, k=k, metric=metric, normq=normq, subset=None if subset is None else len(subset)), bad, flush=True)
+    idx.close()
+print("cases", cases, "fails", fails)
