@@ -400,30 +400,6 @@ int launch_mfma2_inst(const MfmaScanArgs& a, int device, hipStream_t stream, int
     return 0;
 }
 
-template <int KB>
-int launch_mfma3_inst(const MfmaScanArgs& a, int device, hipStream_t stream, int* nblocks_out) {
-    auto kern = flat_scan_mfma3_kernel<KB>;
-    const size_t lds = (size_t)kScanWaves * mfma2_wave_lds_bytes(8) + 2 * 2 * 64 * 2 * 16 + (size_t)2 * 32 * a.k * 8;
-    static size_t lds_set = 0;
-    if (lds > 48 * 1024 && lds > lds_set) {
-        MVDB_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        lds_set = lds;
-    }
-    int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, kScanThreads, lds) != hipSuccess || nb <= 0)
-        nb = 1;
-    nb = std::min(nb, std::max(1, env_int("MVDB_MFMA_BLOCKS_PER_CU", 2)));
-    const int64_t ntiles = (a.n + 15) / 16;
-    const int64_t want = (ntiles + 1) / 2;  // two tiles (pairs) per block and iteration
-    const int nblocks = (int)std::max<int64_t>(1, std::min<int64_t>(want, (int64_t)device_cus(device) * nb));
-    *nblocks_out = nblocks;
-    int slot = prof_begin("ip_scan_mfma", stream);
-    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(kScanThreads), lds, stream, a);
-    prof_end(slot, stream);
-    MVDB_HIP(hipGetLastError());
-    return 0;
-}
-
 template <int NG>
 int launch_mfma2(int KB, const MfmaScanArgs& a, int device, hipStream_t s, int* nb) {
     // 1-KiB-per-row stages (one contiguous KiB per DMA instruction) measured 2-5 % faster than 512-B
@@ -515,11 +491,7 @@ int search_core(const mvdb_index* idx, Workspace* ws, const float* q_dev, int nq
             ma.cand = ws->cand.p;
             int nblocks = 0;
             const int KB = idx->d / 16;
-            if (take > 16 && staged && KB == 32 && env_int("MVDB_MFMA_V3", 0))
-                MVDB_TRY(launch_mfma3_inst<32>(ma, idx->device, s, &nblocks));  // pair-split, 2 waves/SIMD
-            else if (take > 16 && staged && KB == 16 && env_int("MVDB_MFMA_V3", 0))
-                MVDB_TRY(launch_mfma3_inst<16>(ma, idx->device, s, &nblocks));
-            else if (take > 16 && staged)
+            if (take > 16 && staged)
                 MVDB_TRY(launch_mfma2<2>(KB, ma, idx->device, s, &nblocks));
             else if (take > 16)
                 MVDB_TRY(launch_mfma_ng<2>(KB, ma, idx->device, s, &nblocks));

@@ -301,155 +301,3 @@ __global__ __launch_bounds__(kScanThreads) void flat_scan_mfma2_kernel(MfmaScanA
 }
 
 }  // namespace mvdb
-
-// =================================================================================================
-// v3: 32 queries per pass at TWO waves per SIMD — a pair of waves shares each 16-row tile, one K half each
-// =================================================================================================
-// The v2 kernel with two query groups needs 256 registers for the query fragments alone and runs at
-// one wave per SIMD: its LDS-DMA issue slots (16 per stage, ~60-100 cycles each) and waits are then
-// exposed and the pass is MFMA-issue-bound at ~50 %.  Here a tile is computed by a PAIR of waves: wave h
-// of the pair holds the query fragments of K half h only (128 registers for both groups) and streams
-// only that half of the 16 rows (its own 2-buffer LDS-DMA ring of 8-KiB stages, as in v2).  The partial
-// accumulators of the h = 1 wave cross LDS once per tile (2 KiB), the h = 0 wave adds them and does the
-// selection.  One raw s_barrier per tile (never __syncthreads(): its fence would drain the DMA ring),
-// exchange slots double buffered.  ~200 registers => two waves per SIMD, two blocks per CU.
-namespace mvdb {
-
-template <int KB>
-__global__ __launch_bounds__(kScanThreads, 2) void flat_scan_mfma3_kernel(MfmaScanArgs a) {  // 2 waves per SIMD
-    static_assert(KB % 16 == 0, "d must be a multiple of 256 for the pair-split kernel");
-    constexpr int NG = 2, SKB = 8, HKB = KB / 2;  // k-blocks per half
-    constexpr int NS = HKB / SKB;                  // stages per tile and wave
-    constexpr int kStageBytes = mfma2_stage_bytes(SKB), kWaveLdsBytes = mfma2_wave_lds_bytes(SKB);
-    constexpr int kXchBytes = 2 /*pairs*/ * 2 /*parity*/ * 64 * NG * 16;  // partial accumulators
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int pair = wave >> 1, half = wave & 1;
-    const int k = a.k;
-    unsigned char* wbuf = smem + (size_t)wave * kWaveLdsBytes;
-    f32x4m* xch = reinterpret_cast<f32x4m*>(smem + (size_t)kScanWaves * kWaveLdsBytes);  // [pair][parity][g][lane]
-    uint64_t* lists = reinterpret_cast<uint64_t*>(smem + (size_t)kScanWaves * kWaveLdsBytes + kXchBytes);  // [2][32][k]
-    uint64_t* mylists = lists + (size_t)pair * NG * 16 * k;
-    if (half == 0)
-        for (int e = lane; e < NG * 16 * k; e += 64) mylists[e] = 0ull;
-
-    // query fragments of this wave's K half
-    f32x4m qa[NG][HKB];
-#pragma unroll
-    for (int g = 0; g < NG; ++g) {
-        const int qi = g * 16 + (lane & 15);
-        const float* qp = a.q + (int64_t)qi * a.ld + half * (HKB * 16) + 4 * (lane >> 4);
-#pragma unroll
-        for (int kb = 0; kb < HKB; ++kb)
-            qa[g][kb] = qi < a.nq ? *reinterpret_cast<const f32x4m*>(qp + 16 * kb) : f32x4m{0, 0, 0, 0};
-    }
-    float thr[NG][4];
-#pragma unroll
-    for (int g = 0; g < NG; ++g)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) thr[g][r] = (g * 16 + 4 * (lane >> 4) + r) < a.nq ? -INFINITY : INFINITY;
-
-    const int64_t ntiles = (a.n + 15) / 16;
-    const int64_t last = a.n - 1;
-    const int dma_rsel = lane >> 5, dma_p = lane & 31;
-    const int fr = lane & 15, fkg = lane >> 4;
-
-    auto issue_stage = [&](int64_t tile, int ks, int buf) {
-#pragma unroll
-        for (int i = 0; i < SKB; ++i) {
-            const int r = 2 * i + dma_rsel;
-            int64_t row = tile * 16 + r;
-            row = row <= last ? row : last;
-            const float* src = a.X + row * a.ld + half * (HKB * 16) + ks * (SKB * 16) + 4 * (dma_p ^ (r & 15));
-            unsigned char* dst = wbuf + buf * kStageBytes + i * 1024;
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)dst, 16, 0, 2 /* nt */);
-        }
-    };
-    // stage s of this wave = (iteration it, ks); tile(it) = (it * gridDim.x + blockIdx.x) * 2 + pair
-    auto tile_of = [&](int64_t it) { return (it * gridDim.x + blockIdx.x) * 2 + pair; };
-    auto stage_tile = [&](int64_t it, int ks_abs) { return tile_of(it + ks_abs / NS); };
-
-    unsigned cnt = 0;
-    {
-        const int64_t t0 = tile_of(0);
-        if (t0 < ntiles) issue_stage(t0, 0, 0);
-        const int64_t t1 = stage_tile(0, 1);
-        if (t1 < ntiles) issue_stage(t1, 1 % NS, 1);
-    }
-    for (int64_t it = 0;; ++it) {
-        if ((it * gridDim.x + blockIdx.x) * 2 >= ntiles) break;  // block-uniform: both pairs stop together
-        const int64_t tile = tile_of(it);
-        const bool tvalid = tile < ntiles;  // pair-uniform (the last iteration may leave pair 1 idle)
-        f32x4m acc0[NG], acc1[NG];
-#pragma unroll
-        for (int g = 0; g < NG; ++g) acc0[g] = acc1[g] = f32x4m{0, 0, 0, 0};
-        if (tvalid) {
-#pragma unroll
-            for (int ks = 0; ks < NS; ++ks) {
-                const int buf = cnt & 1;
-                const int64_t t1 = stage_tile(it, ks + 1), t2 = stage_tile(it, ks + 2);
-                __builtin_amdgcn_sched_barrier(0);
-                if (t1 < ntiles)
-                    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-                else
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __builtin_amdgcn_sched_barrier(0);
-                const unsigned char* sb = wbuf + buf * kStageBytes + fr * (SKB * 64);
-                f32x4m xb[SKB];
-#pragma unroll
-                for (int kbl = 0; kbl < SKB; ++kbl)
-                    xb[kbl] = *reinterpret_cast<const f32x4m*>(sb + (((4 * kbl + fkg) ^ fr) << 4));
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_sched_barrier(0);
-                if (t2 < ntiles) issue_stage(t2, (ks + 2) % NS, buf);
-#pragma unroll
-                for (int kbl = 0; kbl < SKB; ++kbl) {
-                    const int kb = ks * SKB + kbl;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-#pragma unroll
-                        for (int g = 0; g < NG; ++g) {
-                            if (kbl & 1)
-                                acc1[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[g][kb][j], xb[kbl][j], acc1[g], 0, 0, 0);
-                            else
-                                acc0[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[g][kb][j], xb[kbl][j], acc0[g], 0, 0, 0);
-                        }
-                    }
-                }
-                ++cnt;
-            }
-        }
-        // ---- exchange the K-half partials: h = 1 publishes, barrier, h = 0 sums and selects ------------
-        f32x4m* slot = xch + ((size_t)(pair * 2 + (it & 1)) * NG) * 64;
-        if (half == 1 && tvalid) {
-#pragma unroll
-            for (int g = 0; g < NG; ++g) slot[g * 64 + lane] = acc0[g] + acc1[g];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // LDS writes done; the DMA ring stays in flight
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        if (half == 0 && tvalid) {
-            f32x4m acc[NG];
-#pragma unroll
-            for (int g = 0; g < NG; ++g) acc[g] = (acc0[g] + acc1[g]) + slot[g * 64 + lane];
-            mfma_tile_select<NG>(acc, thr, tile * 16 + fr <= last, (uint32_t)(tile * 16 + fr), a.nq, k, mylists, lane);
-        }
-    }
-
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __syncthreads();
-    // block merge: 2 lists per query (one per pair); waves split the queries
-    for (int qq = wave; qq < a.nq; qq += kScanWaves) {
-        WaveTopK tk;
-        tk.init(k);
-#pragma unroll 1
-        for (int p = 0; p < 2; ++p) {
-            const uint64_t* l = lists + ((size_t)p * NG * 16 + qq) * k;
-            tk.offer(lane < k ? l[lane] : 0ull);
-        }
-        if (lane < k) a.cand[((int64_t)qq * gridDim.x + blockIdx.x) * k + lane] = tk.key;
-    }
-}
-
-}  // namespace mvdb
