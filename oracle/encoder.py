@@ -20,6 +20,8 @@ CONFIGS = {
     "hd64": ("bert", 120, 128, 2, 2, 256, 64),
     "e5-small-dims": ("bert", 1000, 384, 12, 12, 1536, 512),
     "xlmr-tiny": ("xlm-roberta", 150, 128, 2, 4, 256, 80),
+    # multilingual-e5-large / bge-m3 widths (XLM-R large: H 1024, 16 heads of 64, FFN 4096), 2 layers
+    "xlmr-large-dims": ("xlm-roberta", 300, 1024, 2, 16, 4096, 600),
 }
 
 

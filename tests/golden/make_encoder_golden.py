@@ -20,6 +20,8 @@ CASES = [  # (config, weight seed, B, S, input seed)
     ("xlmr-tiny", 9, 3, 11, 6),
     ("e5-small-dims", 10, 4, 32, 7),
     ("e5-small-dims", 10, 2, 130, 8),  # more than one attention key tile / query tile
+    ("xlmr-large-dims", 12, 3, 70, 9),  # H = 1024 row kernels, head_dim 64 attention, XLM-R positions
+    ("e5-small-dims", 10, 2, 512, 13),  # the reference's truncation cap (max_length = 512)
 ]
 
 
