@@ -429,6 +429,47 @@ int launch_mfma_ng(int KB, const MfmaScanArgs& a, int device, hipStream_t s, int
     }
 }
 
+// nq >= 64, k <= 16: compute-bound tiled GEMM + top-k (scan_mfma_kernels.hpp, last section)
+bool gemm_path_ok(const mvdb_index* idx, int nq, int k, const int64_t* rows_dev) {
+    if (env_int("MVDB_DISABLE_GEMM_SCAN", 0)) return false;
+    if (nq < env_int("MVDB_GEMM_SCAN_MIN_NQ", 64) || k > kGemmScanMaxK || rows_dev || idx->metric != MVDB_METRIC_IP)
+        return false;
+    return idx->d % 16 == 0 && idx->ld == idx->d;
+}
+
+int launch_gemm_scan(const mvdb_index* idx, const float* q, int nq, int k, int64_t n, uint64_t* cand,
+                     hipStream_t stream, int* nblocks_out) {
+    GemmScanArgs a;
+    a.X = idx->X;
+    a.n = n;
+    a.ld = idx->ld;
+    a.K = idx->d;
+    a.q = q;
+    a.nq = nq;
+    a.k = k;
+    a.cand = cand;
+    const size_t lds = (size_t)2 * 2 * 16 * 132 * 4 + (size_t)4 * 64 * k * 8;
+    static size_t lds_set = 0;
+    if (lds > 48 * 1024 && lds > lds_set) {
+        MVDB_HIP(hipFuncSetAttribute((const void*)flat_scan_gemm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)lds));
+        lds_set = lds;
+    }
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, flat_scan_gemm_kernel, 256, lds) != hipSuccess || nb <= 0)
+        nb = 1;
+    nb = std::min(nb, std::max(1, env_int("MVDB_GEMM_SCAN_BLOCKS_PER_CU", 2)));
+    const int qtiles = (nq + 127) / 128;
+    const int64_t ntiles = (n + 127) / 128;
+    const int gx = (int)std::max<int64_t>(1, std::min<int64_t>(ntiles, (int64_t)device_cus(idx->device) * nb / qtiles));
+    *nblocks_out = gx;
+    int slot = prof_begin("ip_scan_gemm", stream);
+    hipLaunchKernelGGL(flat_scan_gemm_kernel, dim3(gx, qtiles), dim3(256), lds, stream, a);
+    prof_end(slot, stream);
+    MVDB_HIP(hipGetLastError());
+    return 0;
+}
+
 bool mfma_path_ok(const mvdb_index* idx, int nq, int k, const int64_t* rows_dev) {
     if (env_int("MVDB_DISABLE_MFMA_SCAN", 0)) return false;
     if (nq < 2 || k > kMaxFusedK || rows_dev || idx->metric != MVDB_METRIC_IP) return false;
@@ -461,6 +502,32 @@ int search_core(const mvdb_index* idx, Workspace* ws, const float* q_dev, int nq
     a.rows = rows_dev;
     a.cand = nullptr;
     a.scores = nullptr;
+
+    if (gemm_path_ok(idx, nq, k, rows_dev)) {
+        // ---- large batch: compute-bound tiled GEMM with an in-register top-k gate ------------------
+        const float* qsrc = q_dev;
+        if (normalize_q) {
+            MVDB_TRY(ws->qn.reserve((size_t)nq * idx->ld));
+            MVDB_HIP(hipMemcpyAsync(ws->qn.p, q_dev, (size_t)nq * idx->ld * sizeof(float),
+                                    hipMemcpyDeviceToDevice, s));
+            MVDB_TRY(normalize_range(idx, ws->qn.p, nq, s));
+            qsrc = ws->qn.p;
+        }
+        MVDB_TRY(ws->cand.reserve((size_t)nq * scan_grid_upper_bound(idx->device) * k));
+        int nblocks = 0;
+        MVDB_TRY(launch_gemm_scan(idx, qsrc, nq, k, n, ws->cand.p, s, &nblocks));
+        MergeArgs mg;
+        mg.keys = ws->cand.p;
+        mg.nlists = nblocks;
+        mg.k = k;
+        mg.metric = idx->metric;
+        mg.label_offset = label_offset;
+        mg.D = D_dev;
+        mg.I = I_dev;
+        hipLaunchKernelGGL(merge_keys_kernel, dim3(nq), dim3(kMergeThreads), 0, s, mg);
+        MVDB_HIP(hipGetLastError());
+        return 0;
+    }
 
     if (mfma_path_ok(idx, nq, k, rows_dev)) {
         // ---- several queries per corpus pass on the fp32 matrix cores ---------------------------

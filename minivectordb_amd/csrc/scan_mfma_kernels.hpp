@@ -301,3 +301,173 @@ __global__ __launch_bounds__(kScanThreads) void flat_scan_mfma2_kernel(MfmaScanA
 }
 
 }  // namespace mvdb
+
+// =================================================================================================
+// large batches (nq >= 64): compute-bound tiled GEMM + in-register top-k gate
+// =================================================================================================
+// Beyond ~39 queries per pass the scan leaves the HBM roofline for the fp32 MFMA one (157.3 TFLOP/s),
+// so the corpus is tiled like a GEMM: block tile = 128 corpus rows x 128 queries, K streamed in
+// 16-deep steps through LDS (k-major tiles, conflict-free ds_read_b32 fragments, register-staged
+// double buffering — the encoder's GEMM main loop), v_mfma_f32_32x32x2_f32 (exact fp32).  The
+// accumulator tile D[row][query] keeps the QUERY on the lane (col = lane&31), so each lane gates its
+// 64 scores against two per-query thresholds held in registers; the rare survivors are inserted
+// wave-cooperatively into per-wave, per-query sorted lists in LDS (k <= 16).  Corpus traffic =
+// ceil(nq/128) passes; algorithmic FLOPs per launch = 2 * n * d * 128.
+namespace mvdb {
+
+typedef float f32x16m __attribute__((ext_vector_type(16)));
+constexpr int kGemmScanMaxK = 16;
+
+struct GemmScanArgs {
+    const float* X;
+    int64_t n;
+    int64_t ld;
+    int K;           // = d (multiple of 16)
+    const float* q;  // [nq, ld]
+    int nq;
+    int k;           // <= kGemmScanMaxK
+    uint64_t* cand;  // [nq, gridDim.x, k]
+};
+
+__global__ __launch_bounds__(256) void flat_scan_gemm_kernel(GemmScanArgs a) {
+    constexpr int BM = 128, BN = 128, BK = 16, LD = BM + 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* tiles = reinterpret_cast<float*>(smem);                                   // [2][A|B][BK][LD]
+    uint64_t* lists = reinterpret_cast<uint64_t*>(smem + 2 * 2 * BK * LD * 4);       // [4 waves][64 queries][k]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int fr = lane & 31, fk = lane >> 5;
+    const int k = a.k;
+    const int n0 = blockIdx.y * BN;  // first query of this block's query tile
+    uint64_t* mylists = lists + (size_t)wave * 64 * k;
+    for (int e = lane; e < 64 * k; e += 64) mylists[e] = 0ull;
+
+    // thresholds of this lane's two queries (query = n0 + wn*64 + j*32 + fr)
+    float thr[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) thr[j] = (n0 + wn * 64 + j * 32 + fr) < a.nq ? -INFINITY : INFINITY;
+
+    // staging roles (as the encoder GEMM): thread -> rows lr, lr+64 of each tile, 4 consecutive k
+    const int lr = tid >> 2, lk = (tid & 3) * 4;
+    const float* w_ptr[2];
+    bool w_ok[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int qrow = n0 + lr + i * 64;
+        w_ok[i] = qrow < a.nq;
+        w_ptr[i] = a.q + (int64_t)(w_ok[i] ? qrow : 0) * a.ld + lk;
+    }
+    const int64_t ntiles = (a.n + BM - 1) / BM;
+    const int nk = a.K / BK;
+
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t m0 = tile * BM;
+        const float* a_ptr[2];
+        bool a_ok[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int64_t row = m0 + lr + i * 64;
+            a_ok[i] = row < a.n;
+            a_ptr[i] = a.X + (a_ok[i] ? row : 0) * a.ld + lk;
+        }
+        f32x4m ra[2], rw[2];
+        auto stage_load = [&](int k0) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                ra[i] = a_ok[i] ? __builtin_nontemporal_load(reinterpret_cast<const f32x4m*>(a_ptr[i] + k0))
+                                : f32x4m{0, 0, 0, 0};
+                rw[i] = w_ok[i] ? *reinterpret_cast<const f32x4m*>(w_ptr[i] + k0) : f32x4m{0, 0, 0, 0};
+            }
+        };
+        auto stage_write = [&](int buf) {
+            float* As = tiles + buf * (2 * BK * LD);
+            float* Bs = As + BK * LD;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int r = lr + i * 64;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    As[(lk + j) * LD + r] = ra[i][j];
+                    Bs[(lk + j) * LD + r] = rw[i][j];
+                }
+            }
+        };
+        f32x16m acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+        __syncthreads();  // previous tile's last LDS reads are done before buffer 0 is overwritten
+        stage_load(0);
+        stage_write(0);
+        __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            const int buf = kt & 1;
+            if (kt + 1 < nk) stage_load((kt + 1) * BK);
+            const float* As = tiles + buf * (2 * BK * LD);
+            const float* Bs = As + BK * LD;
+#pragma unroll
+            for (int kk = 0; kk < BK; kk += 2) {
+                float av[2], bv[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    av[i] = As[(kk + fk) * LD + wm * 64 + i * 32 + fr];  // A[i = row fr][k = fk]
+                    bv[i] = Bs[(kk + fk) * LD + wn * 64 + i * 32 + fr];  // B[k = fk][j = query fr]
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+            }
+            if (kt + 1 < nk) {
+                stage_write(buf ^ 1);
+                __syncthreads();
+            }
+        }
+        // ---- selection: D[row][query], query on the lane -------------------------------------------------
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int ql = j * 32 + fr;  // this lane's query inside the wave's 64
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int64_t row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
+                    const float s = acc[i][j][r];
+                    uint64_t mask = __ballot(row < a.n && s >= thr[j]);
+                    while (mask) {
+                        const int src = __ffsll((long long)mask) - 1;
+                        mask &= mask - 1;
+                        const int sq = j * 32 + (src & 31);
+                        const float sv = __uint_as_float(__builtin_amdgcn_readlane((int)__float_as_uint(s), src));
+                        const uint32_t rv = (uint32_t)(m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (src >> 5));
+                        const uint64_t kth = lds_list_insert(mylists + (size_t)sq * k, k, make_key(sv, rv), lane);
+                        const float t = kth ? key_score(kth) : -INFINITY;
+                        if (ql == sq) thr[j] = t;  // both lane halves of that query
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- block merge: query column c (0..127) has one list in each of the two waves with wn = c / 64 ------
+    __syncthreads();
+    for (int c = wave; c < BN; c += 4) {
+        const int qq = n0 + c;
+        if (qq >= a.nq) continue;
+        WaveTopK tk;
+        tk.init(k);
+#pragma unroll 1
+        for (int m = 0; m < 2; ++m) {
+            const uint64_t* l = lists + ((size_t)(m * 2 + c / 64) * 64 + (c % 64)) * k;
+            tk.offer(lane < k ? l[lane] : 0ull);
+        }
+        if (lane < k) a.cand[((int64_t)qq * gridDim.x + blockIdx.x) * k + lane] = tk.key;
+    }
+}
+
+}  // namespace mvdb

@@ -459,3 +459,29 @@ def test_multi_query_pass_is_deterministic(native):
             assert np.array_equal(ref[i][1][0], I0[i])
             np.testing.assert_allclose(ref[i][0][0], D0[i], atol=2e-6, rtol=0)
     idx.close()
+
+
+@pytest.mark.parametrize("n,d,k,nq", [
+    (20000, 512, 10, 64), (9000, 384, 16, 100), (5000, 512, 1, 128), (12345, 256, 10, 129), (300, 64, 5, 200),
+    (127, 512, 10, 70), (128, 128, 16, 64), (129, 512, 3, 65), (4000, 512, 17, 64),
+])
+def test_large_batch_gemm_scan_matches_oracle(native, n, d, k, nq):
+    """nq >= 64 and k <= 16: the compute-bound tiled GEMM + in-register top-k gate (k = 17 falls back to the
+    32-query passes).  Every query's result must equal its own single-query search."""
+    x = _corpus(n, d)
+    q = _corpus(nq, d, seed=777)
+    idx = native.FlatIndex(d)
+    idx.add(x)
+    D, I = idx.search(q, k)
+    _check(native, x, q, k, D, I)
+    D2, I2 = idx.search(q * 2.5, k, normalize_q=True)  # fused normalisation path
+    assert np.array_equal(I2, I)
+    np.testing.assert_allclose(D2, D, atol=2e-6)
+    for i in (0, nq // 2, nq - 1):
+        D1, I1 = idx.search(q[i], k)
+        assert np.array_equal(I1[0], I[i])
+    # determinism across repeats
+    for _ in range(3):
+        Dr, Ir = idx.search(q, k)
+        assert np.array_equal(Ir, I) and np.array_equal(Dr, D)
+    idx.close()
