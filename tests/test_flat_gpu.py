@@ -468,12 +468,20 @@ def test_multi_query_pass_is_deterministic(native):
 def test_large_batch_gemm_scan_matches_oracle(native, n, d, k, nq):
     """nq >= 64 and k <= 16: the compute-bound tiled GEMM + in-register top-k gate (k = 17 falls back to the
     32-query passes).  Every query's result must equal its own single-query search."""
+    import os
     x = _corpus(n, d)
     q = _corpus(nq, d, seed=777)
     idx = native.FlatIndex(d)
     idx.add(x)
-    D, I = idx.search(q, k)
-    _check(native, x, q, k, D, I)
+    os.environ["MVDB_GEMM_SCAN_MIN_NQ"] = "64"  # the library reads it per call: also cover half-filled query tiles
+    try:
+        D, I = idx.search(q, k)
+        _check(native, x, q, k, D, I)
+    finally:
+        del os.environ["MVDB_GEMM_SCAN_MIN_NQ"]
+    Dd, Id = idx.search(q, k)  # default chunking (GEMM launches of up to 128 + 32-query passes for the rest)
+    assert np.array_equal(Id, I)
+    np.testing.assert_allclose(Dd, D, atol=2e-6)
     D2, I2 = idx.search(q * 2.5, k, normalize_q=True)  # fused normalisation path
     assert np.array_equal(I2, I)
     np.testing.assert_allclose(D2, D, atol=2e-6)
