@@ -448,7 +448,7 @@ int launch_gemm_scan(const mvdb_index* idx, const float* q, int nq, int k, int64
     a.nq = nq;
     a.k = k;
     a.cand = cand;
-    const size_t lds = (size_t)2 * 2 * 16 * kGemmScanLD * 4 + (size_t)4 * 64 * k * 8;
+    const size_t lds = (size_t)2 * 2 * 16 * 132 * 4 + (size_t)4 * 64 * k * 8;
     static size_t lds_set = 0;
     if (lds > 48 * 1024 && lds > lds_set) {
         MVDB_HIP(hipFuncSetAttribute((const void*)flat_scan_gemm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -458,7 +458,7 @@ int launch_gemm_scan(const mvdb_index* idx, const float* q, int nq, int k, int64
     int nb = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, flat_scan_gemm_kernel, 256, lds) != hipSuccess || nb <= 0)
         nb = 1;
-    nb = std::min(nb, std::max(1, env_int("MVDB_GEMM_SCAN_BLOCKS_PER_CU", 3)));
+    nb = std::min(nb, std::max(1, env_int("MVDB_GEMM_SCAN_BLOCKS_PER_CU", 2)));
     const int qtiles = (nq + 127) / 128;
     const int64_t ntiles = (n + 127) / 128;
     const int gx = (int)std::max<int64_t>(1, std::min<int64_t>(ntiles, (int64_t)device_cus(idx->device) * nb / qtiles));

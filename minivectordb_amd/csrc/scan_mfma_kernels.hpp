@@ -317,8 +317,6 @@ namespace mvdb {
 
 typedef float f32x16m __attribute__((ext_vector_type(16)));
 constexpr int kGemmScanMaxK = 16;
-constexpr int kGemmScanLD = 129;  // LDS row stride (floats): 128 + 1 pad (2-way ds_write conflicts are free);
-                                  // keeps tiles + k=10 lists under 53 KiB => three blocks per CU
 
 struct GemmScanArgs {
     const float* X;
@@ -332,7 +330,7 @@ struct GemmScanArgs {
 };
 
 __global__ __launch_bounds__(256) void flat_scan_gemm_kernel(GemmScanArgs a) {
-    constexpr int BM = 128, BN = 128, BK = 16, LD = kGemmScanLD;
+    constexpr int BM = 128, BN = 128, BK = 16, LD = BM + 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* tiles = reinterpret_cast<float*>(smem);                                   // [2][A|B][BK][LD]
     uint64_t* lists = reinterpret_cast<uint64_t*>(smem + 2 * 2 * BK * LD * 4);       // [4 waves][64 queries][k]
