@@ -370,20 +370,16 @@ __global__ __launch_bounds__(256) void flat_scan_gemm_kernel(GemmScanArgs a) {
             a_ok[i] = row < a.n;
             a_ptr[i] = a.X + (a_ok[i] ? row : 0) * a.ld + lk;
         }
-        // Register ring TWO k-tiles deep for the corpus operand: its loads come from HBM (~2-4k cycles),
-        // a k-step is ~2k cycles of MFMA, so a one-tile-ahead prefetch (enough for the encoder, whose
-        // operands sit in L2) would stall every step.  Set s is re-loaded right after it has been written
-        // to LDS, i.e. two steps before it is needed again.
-        f32x4m ra[2][2], rw[2][2];
-        auto stage_load = [&](int set, int k0) {
+        f32x4m ra[2], rw[2];
+        auto stage_load = [&](int k0) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                ra[set][i] = a_ok[i] ? __builtin_nontemporal_load(reinterpret_cast<const f32x4m*>(a_ptr[i] + k0))
-                                     : f32x4m{0, 0, 0, 0};
-                rw[set][i] = w_ok[i] ? *reinterpret_cast<const f32x4m*>(w_ptr[i] + k0) : f32x4m{0, 0, 0, 0};
+                ra[i] = a_ok[i] ? __builtin_nontemporal_load(reinterpret_cast<const f32x4m*>(a_ptr[i] + k0))
+                                : f32x4m{0, 0, 0, 0};
+                rw[i] = w_ok[i] ? *reinterpret_cast<const f32x4m*>(w_ptr[i] + k0) : f32x4m{0, 0, 0, 0};
             }
         };
-        auto stage_write = [&](int set, int buf) {
+        auto stage_write = [&](int buf) {
             float* As = tiles + buf * (2 * BK * LD);
             float* Bs = As + BK * LD;
 #pragma unroll
@@ -391,12 +387,26 @@ __global__ __launch_bounds__(256) void flat_scan_gemm_kernel(GemmScanArgs a) {
                 const int r = lr + i * 64;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    As[(lk + j) * LD + r] = ra[set][i][j];
-                    Bs[(lk + j) * LD + r] = rw[set][i][j];
+                    As[(lk + j) * LD + r] = ra[i][j];
+                    Bs[(lk + j) * LD + r] = rw[i][j];
                 }
             }
         };
-        auto compute = [&](int buf, f32x16m (&acc)[2][2]) {
+        f32x16m acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+        __syncthreads();  // previous tile's last LDS reads are done before buffer 0 is overwritten
+        stage_load(0);
+        stage_write(0);
+        __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            const int buf = kt & 1;
+            if (kt + 1 < nk) stage_load((kt + 1) * BK);
             const float* As = tiles + buf * (2 * BK * LD);
             const float* Bs = As + BK * LD;
 #pragma unroll
@@ -413,35 +423,9 @@ __global__ __launch_bounds__(256) void flat_scan_gemm_kernel(GemmScanArgs a) {
                     for (int j = 0; j < 2; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
             }
-        };
-        f32x16m acc[2][2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-        __syncthreads();  // previous tile's last LDS reads are done before buffer 0 is overwritten
-        stage_load(0, 0);
-        stage_write(0, 0);
-        if (nk > 1) stage_load(1, BK);
-        if (nk > 2) stage_load(0, 2 * BK);
-        __syncthreads();
-        for (int kt = 0; kt < nk; kt += 2) {
-            // even step: tile kt in buffer 0; set 1 holds tile kt+1
-            compute(0, acc);
             if (kt + 1 < nk) {
-                stage_write(1, 1);
+                stage_write(buf ^ 1);
                 __syncthreads();
-                if (kt + 3 < nk) stage_load(1, (kt + 3) * BK);
-                // odd step: tile kt+1 in buffer 1; set 0 holds tile kt+2
-                compute(1, acc);
-                if (kt + 2 < nk) {
-                    stage_write(0, 0);
-                    __syncthreads();
-                    if (kt + 4 < nk) stage_load(0, (kt + 4) * BK);
-                }
             }
         }
         // ---- selection: D[row][query], query on the lane -------------------------------------------------
