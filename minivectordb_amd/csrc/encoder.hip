@@ -794,7 +794,14 @@ template <int EPI>
 void launch_gemm(const float* A, const float* W, const float* bias, const float* R, float* C,
                  const int* Tptr, int64_t Tmax, int N, int K, int cus, hipStream_t s) {
     const int64_t big = (int64_t)((N + 127) / 128) * ((Tmax + 127) / 128);
-    if (big >= 2 * (int64_t)cus) {  // enough 128x128 tiles to fill the chip twice
+    // 128x128 tiles only when they fill the chip's resident slots (2 blocks per CU) several times over;
+    // otherwise the last, partly filled round dominates (T = 8192: 576-768 tiles = 1.1-1.5 rounds) and
+    // 64x64 tiles (4x the blocks) are faster despite their lower per-block reuse.
+    static const int rounds = []() {
+        const char* v = getenv("MVDB_GEMM_BIG_TILE_ROUNDS");
+        return v && *v ? atoi(v) : 3;
+    }();
+    if (big >= (int64_t)rounds * 2 * cus) {
         dim3 grid((N + 127) / 128, (unsigned)((Tmax + 127) / 128));
         hipLaunchKernelGGL((gemm_f32_mfma_kernel<EPI, 2>), grid, dim3(256), 0, s, A, W, bias, R, C, Tptr, N, K);
     } else {
