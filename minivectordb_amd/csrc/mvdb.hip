@@ -413,8 +413,17 @@ int launch_mfma2(int KB, const MfmaScanArgs& a, int device, hipStream_t s, int* 
         case 24: return launch_mfma2_inst<24, NG, 8>(a, device, s, nb);
         case 32: return deep ? launch_mfma2_inst<32, NG, 16>(a, device, s, nb)
                              : launch_mfma2_inst<32, NG, 8>(a, device, s, nb);
-        default: return fail(MVDB_ERR_ARG, "no staged multi-query kernel for d = %d", KB * 16);
+        // d = 768 / 1024 (e5-large, bge-m3 widths): one query group only — the 192 / 256 registers of
+        // query fragments leave one wave per SIMD, like two groups at d = 512
+        case 48: if (NG == 1) return deep ? launch_mfma2_inst<48, 1, 16>(a, device, s, nb)
+                                          : launch_mfma2_inst<48, 1, 8>(a, device, s, nb);
+                 break;
+        case 64: if (NG == 1) return deep ? launch_mfma2_inst<64, 1, 16>(a, device, s, nb)
+                                          : launch_mfma2_inst<64, 1, 8>(a, device, s, nb);
+                 break;
+        default: break;
     }
+    return fail(MVDB_ERR_ARG, "no staged multi-query kernel for d = %d with %d query group(s)", KB * 16, NG);
 }
 
 template <int NG>
@@ -475,7 +484,7 @@ bool mfma_path_ok(const mvdb_index* idx, int nq, int k, const int64_t* rows_dev)
     if (nq < 2 || k > kMaxFusedK || rows_dev || idx->metric != MVDB_METRIC_IP) return false;
     if (idx->d % 16 || idx->ld != idx->d) return false;
     const int KB = idx->d / 16;
-    return KB == 4 || KB == 8 || KB == 16 || KB == 24 || KB == 32;
+    return KB == 4 || KB == 8 || KB == 16 || KB == 24 || KB == 32 || KB == 48 || KB == 64;
 }
 
 // Core: queries already on the device (padded to ld), outputs on the device.  Enqueues on ws.stream.
@@ -556,8 +565,8 @@ int search_core(const mvdb_index* idx, Workspace* ws, const float* q_dev, int nq
             // staged kernel: 32 queries per pass (two query groups share each B fragment); the v1
             // kernel with two groups runs at one wave per SIMD and loses to two 16-query passes
             const bool staged = idx->d % 128 == 0 && env_int("MVDB_MFMA_V", 2) == 2;
-            const int take = (left > 16 && env_int("MVDB_MFMA_NG2", staged ? 1 : 0)) ? std::min(left, 32)
-                                                                                     : std::min(left, 16);
+            const bool two_groups = left > 16 && idx->d <= 512 && env_int("MVDB_MFMA_NG2", staged ? 1 : 0);
+            const int take = two_groups ? std::min(left, 32) : std::min(left, 16);
             MfmaScanArgs ma;
             ma.X = idx->X;
             ma.n = n;

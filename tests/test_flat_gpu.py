@@ -417,6 +417,7 @@ def test_config3_10M_x_512_properties(native):
 @pytest.mark.parametrize("n,d,k,nq", [
     (20000, 512, 10, 16), (20000, 512, 10, 17), (9000, 512, 64, 32), (9000, 512, 5, 33), (30000, 384, 10, 40),
     (5000, 64, 10, 2), (7001, 256, 1, 9), (3000, 128, 7, 31), (15, 512, 10, 5), (16, 512, 4, 3), (17, 512, 20, 2),
+    (6000, 1024, 10, 16), (6000, 1024, 10, 35), (5000, 768, 64, 9),  # e5-large / bge-m3 widths: one group per pass
 ])
 def test_multi_query_mfma_pass_matches_oracle(native, n, d, k, nq):
     """nq >= 2 on d in {64,128,256,384,512}: one corpus pass on v_mfma_f32_16x16x4_f32 serves up to 32
