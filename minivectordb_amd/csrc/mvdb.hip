@@ -1001,10 +1001,19 @@ int mvdb_index_search_subset(const mvdb_index* idx, const float* q_host, int nq,
     if (m < 0) return fail(MVDB_ERR_ARG, "negative subset size");
     if (m > 0 && !rows_host) return fail(MVDB_ERR_ARG, "rows is NULL");
     std::shared_lock<std::shared_mutex> lk(idx->mu);
-    for (int64_t i = 0; i < m; ++i)
-        if (rows_host[i] < 0 || rows_host[i] >= idx->n)
-            return fail(MVDB_ERR_ARG, "subset row %lld out of range [0,%lld)", (long long)rows_host[i],
+    {   // range check as a branch-free min/max reduction (vectorises; the list can hold millions of rows)
+        int64_t lo = 0, hi = -1;
+        if (m > 0) {
+            lo = hi = rows_host[0];
+            for (int64_t i = 1; i < m; ++i) {
+                lo = rows_host[i] < lo ? rows_host[i] : lo;
+                hi = rows_host[i] > hi ? rows_host[i] : hi;
+            }
+        }
+        if (m > 0 && (lo < 0 || hi >= idx->n))
+            return fail(MVDB_ERR_ARG, "subset row %lld out of range [0,%lld)", (long long)(lo < 0 ? lo : hi),
                         (long long)idx->n);
+    }
     DeviceGuard dg(idx->device);
     Workspace* ws = idx->acquire();
     if (!ws) return MVDB_ERR_HIP;
