@@ -231,7 +231,7 @@ constexpr int GBM = 128, GBN = 128, GBK = 16;  // GBM/GBN: the bf16 kernel's til
 
 // TI = 32x32 MFMA tiles per wave and dimension: TI = 2 -> 128x128 block tile (best reuse), TI = 1 ->
 // 64x64 (4x the blocks: used when the 128x128 grid would leave CUs idle, e.g. N = 384 at T = 8192).
-template <int EPI, int TI>
+template <int EPI, int TI, int BKT>
 __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(const float* __restrict__ A,
                                                             const float* __restrict__ W,
                                                             const float* __restrict__ bias,
@@ -239,11 +239,12 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(const float* __restr
                                                             float* __restrict__ C,
                                                             const int* __restrict__ Tptr, int N, int K) {
     constexpr int BM = 64 * TI, BN = 64 * TI, LD = BM + 4;  // LDS row stride (floats): +4 pad
+    constexpr int KQ = BKT / 16;                             // 16-float k groups per LDS tile
     const int T = *Tptr;
     const int m0 = blockIdx.y * BM;
     if (m0 >= T) return;
     const int n0 = blockIdx.x * BN;
-    __shared__ float lds[2 * 2 * GBK * LD];  // [buf][A|B][k][row]
+    __shared__ float lds[2 * 2 * BKT * LD];  // [buf][A|B][k][row]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
 
@@ -260,25 +261,29 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(const float* __restr
         a_ptr[i] = A + (int64_t)(a_ok[i] ? ra : 0) * K + lk;
         w_ptr[i] = W + (int64_t)(w_ok[i] ? rw : 0) * K + lk;
     }
-    f32x4 ra[TI], rw[TI];
+    f32x4 ra[TI][KQ], rw[TI][KQ];
     auto stage_load = [&](int k0) {
 #pragma unroll
-        for (int i = 0; i < TI; ++i) {
-            ra[i] = a_ok[i] ? *reinterpret_cast<const f32x4*>(a_ptr[i] + k0) : f32x4{0, 0, 0, 0};
-            rw[i] = w_ok[i] ? *reinterpret_cast<const f32x4*>(w_ptr[i] + k0) : f32x4{0, 0, 0, 0};
-        }
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int g = 0; g < KQ; ++g) {
+                ra[i][g] = a_ok[i] ? *reinterpret_cast<const f32x4*>(a_ptr[i] + k0 + 16 * g) : f32x4{0, 0, 0, 0};
+                rw[i][g] = w_ok[i] ? *reinterpret_cast<const f32x4*>(w_ptr[i] + k0 + 16 * g) : f32x4{0, 0, 0, 0};
+            }
     };
     auto stage_write = [&](int buf) {
-        float* As = lds + buf * (2 * GBK * LD);
-        float* Bs = As + GBK * LD;
+        float* As = lds + buf * (2 * BKT * LD);
+        float* Bs = As + BKT * LD;
 #pragma unroll
         for (int i = 0; i < TI; ++i) {
             const int r = lr + i * 64;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                As[(lk + j) * LD + r] = ra[i][j];
-                Bs[(lk + j) * LD + r] = rw[i][j];
-            }
+            for (int g = 0; g < KQ; ++g)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    As[(16 * g + lk + j) * LD + r] = ra[i][g][j];
+                    Bs[(16 * g + lk + j) * LD + r] = rw[i][g][j];
+                }
         }
     };
 
@@ -290,18 +295,18 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(const float* __restr
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int nk = K / GBK;
+    const int nk = K / BKT;
     stage_load(0);
     stage_write(0);
     __syncthreads();
     const int fr = lane & 31, fk = lane >> 5;
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) stage_load((kt + 1) * GBK);  // in flight during the MFMAs below
-        const float* As = lds + buf * (2 * GBK * LD);
-        const float* Bs = As + GBK * LD;
+        if (kt + 1 < nk) stage_load((kt + 1) * BKT);  // in flight during the MFMAs below
+        const float* As = lds + buf * (2 * BKT * LD);
+        const float* Bs = As + BKT * LD;
 #pragma unroll
-        for (int kk = 0; kk < GBK; kk += 2) {
+        for (int kk = 0; kk < BKT; kk += 2) {
             float av[TI], bv[TI];
 #pragma unroll
             for (int i = 0; i < TI; ++i) {
@@ -801,12 +806,20 @@ void launch_gemm(const float* A, const float* W, const float* bias, const float*
         const char* v = getenv("MVDB_GEMM_BIG_TILE_ROUNDS");
         return v && *v ? atoi(v) : 3;
     }();
+    static const bool small_bk32 = []() {
+        const char* v = getenv("MVDB_GEMM_SMALL_BK32");
+        return !(v && *v == '0');
+    }();
     if (big >= (int64_t)rounds * 2 * cus) {
         dim3 grid((N + 127) / 128, (unsigned)((Tmax + 127) / 128));
-        hipLaunchKernelGGL((gemm_f32_mfma_kernel<EPI, 2>), grid, dim3(256), 0, s, A, W, bias, R, C, Tptr, N, K);
+        hipLaunchKernelGGL((gemm_f32_mfma_kernel<EPI, 2, 16>), grid, dim3(256), 0, s, A, W, bias, R, C, Tptr, N, K);
     } else {
         dim3 grid((N + 63) / 64, (unsigned)((Tmax + 63) / 64));
-        hipLaunchKernelGGL((gemm_f32_mfma_kernel<EPI, 1>), grid, dim3(256), 0, s, A, W, bias, R, C, Tptr, N, K);
+        // 64x64 tiles do 8 MFMAs per wave and 16-deep step: step twice as deep to halve the barriers
+        if (K % 32 == 0 && small_bk32)
+            hipLaunchKernelGGL((gemm_f32_mfma_kernel<EPI, 1, 32>), grid, dim3(256), 0, s, A, W, bias, R, C, Tptr, N, K);
+        else
+            hipLaunchKernelGGL((gemm_f32_mfma_kernel<EPI, 1, 16>), grid, dim3(256), 0, s, A, W, bias, R, C, Tptr, N, K);
     }
 }
 
