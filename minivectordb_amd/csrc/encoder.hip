@@ -806,13 +806,20 @@ void launch_gemm(const float* A, const float* W, const float* bias, const float*
         const char* v = getenv("MVDB_GEMM_BIG_TILE_ROUNDS");
         return v && *v ? atoi(v) : 3;
     }();
+    static const bool big_bk32 = []() {
+        const char* v = getenv("MVDB_GEMM_BIG_BK32");
+        return v && *v == '1';
+    }();
     static const bool small_bk32 = []() {
         const char* v = getenv("MVDB_GEMM_SMALL_BK32");
         return !(v && *v == '0');
     }();
     if (big >= (int64_t)rounds * 2 * cus) {
         dim3 grid((N + 127) / 128, (unsigned)((Tmax + 127) / 128));
-        hipLaunchKernelGGL((gemm_f32_mfma_kernel<EPI, 2, 16>), grid, dim3(256), 0, s, A, W, bias, R, C, Tptr, N, K);
+        if (K % 32 == 0 && big_bk32)
+            hipLaunchKernelGGL((gemm_f32_mfma_kernel<EPI, 2, 32>), grid, dim3(256), 0, s, A, W, bias, R, C, Tptr, N, K);
+        else
+            hipLaunchKernelGGL((gemm_f32_mfma_kernel<EPI, 2, 16>), grid, dim3(256), 0, s, A, W, bias, R, C, Tptr, N, K);
     } else {
         dim3 grid((N + 63) / 64, (unsigned)((Tmax + 63) / 64));
         // 64x64 tiles do 8 MFMAs per wave and 16-deep step: step twice as deep to halve the barriers
