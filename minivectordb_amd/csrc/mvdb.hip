@@ -304,6 +304,21 @@ int launch_scan(int metric, int mode, const ScanArgs& a, int nq, int device, hip
             default: break;
         }
     }
+    {   // tuning hook for other shapes: MVDB_SCAN_U in {1,2,4,8} overrides the rows in flight per wave
+        const int u = env_int("MVDB_SCAN_U", 0);
+#define MVDB_SCAN_U_CASE(G_, C_)                                                                        \
+    if (u && sh.G == G_ && sh.C == C_) {                                                                \
+        if (u == 1) return launch_scan_gcu<G_, C_, 1>(metric, mode, a, nq, device, s, nblocks);          \
+        if (u == 2) return launch_scan_gcu<G_, C_, 2>(metric, mode, a, nq, device, s, nblocks);          \
+        if (u == 4) return launch_scan_gcu<G_, C_, 4>(metric, mode, a, nq, device, s, nblocks);          \
+        if (u == 8) return launch_scan_gcu<G_, C_, 8>(metric, mode, a, nq, device, s, nblocks);          \
+    }
+        MVDB_SCAN_U_CASE(32, 3)
+        MVDB_SCAN_U_CASE(64, 1)
+        MVDB_SCAN_U_CASE(64, 4)
+        MVDB_SCAN_U_CASE(16, 1)
+#undef MVDB_SCAN_U_CASE
+    }
 #define MVDB_SCAN_CASE(G_, C_, U_) \
     if (sh.G == G_ && sh.C == C_) return launch_scan_gcu<G_, C_, U_>(metric, mode, a, nq, device, s, nblocks);
     MVDB_SCAN_CASE(1, 1, 4)
