@@ -247,7 +247,9 @@ int launch_scan_kern(const ScanArgs& a, int nq, int device, hipStream_t stream, 
         // measured on MI355X (benchmarks/sweep_scan2.py, 10M x 512, gpurun_out/sweep4.log): with ~4
         // independent 16-B loads per lane, 2 resident blocks (8 waves) per CU reach 7.21-7.24 TB/s; more
         // waves or more loads in flight per lane are 2-4 % slower, 1 block per CU is latency-starved
-        occ = std::min(nb, 2);
+        // (gpurun_out/sweep_dims.log: the one- and three-chunk shapes — d = 64 / 256 / 384 — prefer U = 4 with
+        //  3 resident blocks: 7.0-7.1 TB/s vs 6.5-6.9 at 2)
+        occ = std::min(nb, (C == 1 || C == 3) ? 3 : 2);
         const int cap_env = env_int("MVDB_SCAN_BLOCKS_PER_CU", 0);  // tuning hook
         if (cap_env > 0) occ = std::min(occ_hw, cap_env);
     }
@@ -327,7 +329,7 @@ int launch_scan(int metric, int mode, const ScanArgs& a, int nq, int device, hip
     MVDB_SCAN_CASE(8, 1, 4)
     MVDB_SCAN_CASE(16, 1, 4)
     MVDB_SCAN_CASE(32, 1, 4)
-    MVDB_SCAN_CASE(32, 3, 2)
+    MVDB_SCAN_CASE(32, 3, 4)
     MVDB_SCAN_CASE(32, 5, 1)
     MVDB_SCAN_CASE(32, 7, 1)
     MVDB_SCAN_CASE(64, 1, 4)
