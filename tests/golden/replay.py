@@ -74,6 +74,12 @@ def run(make_db, ops, workdir):
                 db = make_db(*last_args[:2], **last_args[2])
             elif name == "reopen":
                 db = make_db(*last_args[:2], **last_args[2])
+            elif name == "migrate":  # flat -> sharded through _convert_from_non_sharded_db
+                path = os.path.join(workdir, op["path"])
+                last_args = ("sharded", path, op.get("kw", {}))
+                new_db = make_db(*last_args[:2], **last_args[2])
+                new_db._convert_from_non_sharded_db(db)
+                db = new_db
             elif name == "wipe":
                 path = os.path.join(workdir, op["path"])
                 if os.path.isdir(path):

@@ -270,7 +270,49 @@ def _fuzz(kind, seed, nops=140):
     return ops
 
 
+def delete_everything(kind):
+    """Delete every row, reload from disk, search the empty database, store again (the situations of the
+    reference's test_index_then_delete_everything_and_reload and of deleting unknown + known ids together)."""
+    d = 32
+    path = "wipeout" if kind == "sharded" else "wipeout.pkl"
+    kw = {"shard_size": 4} if kind == "sharded" else {}
+    ops = [{"op": "wipe", "path": path}, {"op": "open", "kind": kind, "path": path, "kw": kw}]
+    for i in range(9):
+        ops.append({"op": "store", "id": f"k{i}", "vec": {"synth": [41, i, d]}, "meta": {"even": i % 2 == 0}})
+    ops.append({"op": "search", "q": q(0, d), "k": 4})
+    if kind == "sharded":
+        ops += [{"op": "delete_batch", "ids": ["k0", "missing"]},  # a known and an unknown id together
+                {"op": "delete_batch", "ids": [f"k{i}" for i in range(9)]}]
+    else:
+        ops += [{"op": "delete", "id": f"k{i}"} for i in range(9)]
+    ops += [{"op": "state"}, {"op": "search", "q": q(0, d), "k": 4},
+            {"op": "search", "q": q(0, d), "k": 4, "filter": {"even": True}}]
+    if kind == "flat":
+        ops.append({"op": "persist"})
+    ops += [{"op": "reopen"}, {"op": "state"}, {"op": "search", "q": q(1, d), "k": 4},
+            {"op": "store", "id": "again", "vec": {"synth": [41, 100, d]}, "meta": {"even": True}},
+            {"op": "search", "q": q(1, d), "k": 4}, {"op": "search", "q": q(1, d), "k": 4, "filter": {"even": True}},
+            {"op": "state"}]
+    return ops
+
+
+def migrate():
+    """VectorDatabase -> ShardedVectorDatabase via _convert_from_non_sharded_db, then search / reload."""
+    d = 40
+    ops = [{"op": "wipe", "path": "mig.pkl"}, {"op": "wipe", "path": "mig_shards"},
+           {"op": "open", "kind": "flat", "path": "mig.pkl"}, _items(23, d=d, seed=51)]
+    ops += [{"op": "search", "q": q(2, d), "k": 5},
+            {"op": "migrate", "path": "mig_shards", "kw": {"shard_size": 5}},
+            {"op": "state"}, {"op": "search", "q": q(2, d), "k": 5},
+            {"op": "search", "q": q(3, d), "k": 5, "filter": {"colour": "blue"}},
+            {"op": "reopen"}, {"op": "state"}, {"op": "search", "q": q(2, d), "k": 5}]
+    return ops
+
+
 SCENARIOS = {
+    "migrate": migrate,
+    "delete_everything_flat": lambda: delete_everything("flat"),
+    "delete_everything_sharded": lambda: delete_everything("sharded"),
     "fuzz_flat_1": lambda: _fuzz("flat", 1),
     "fuzz_flat_2": lambda: _fuzz("flat", 2),
     "fuzz_sharded_3": lambda: _fuzz("sharded", 3),
