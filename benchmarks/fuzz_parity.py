@@ -13,7 +13,7 @@ while time.time() < t_end:
     d = int(rs.choice(dims))
     n = int(rs.choice([1,2,15,16,17,63,64,65,255,256,257,1000,4097, rs.randint(1, 5000)]))
     if n * d > 30_000_000: n = 30_000_000 // d
-    nq = int(rs.choice([1,1,1,2,3,5,15,16,17,31,32,33,40]))
+    nq = int(rs.choice([1,1,1,2,3,5,15,16,17,31,32,33,40,104,128,150,260]))
     k = int(rs.choice([1,2,5,10,63,64,65,100,300, rs.randint(1, 200)]))
     metric = int(rs.choice([0,0,0,1]))
     x = flat.synth(n, d, rs.randint(1<<30)); 
