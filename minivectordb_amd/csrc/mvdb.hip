@@ -70,7 +70,8 @@ struct ProfPair {
 };
 static std::mutex g_prof_mu;
 static bool g_prof_on = false;
-static std::vector<ProfPair> g_prof;
+static int g_prof_next = 0;
+static std::map<int, ProfPair> g_prof;  // keyed by a ticket that stays valid across mvdb_prof_read
 
 bool prof_enabled() { return g_prof_on; }
 int prof_begin(const char* name, hipStream_t stream) {
@@ -85,15 +86,17 @@ int prof_begin(const char* name, hipStream_t stream) {
     }
     (void)hipEventRecord(p.a, stream);
     std::lock_guard<std::mutex> lk(g_prof_mu);
-    g_prof.push_back(p);
-    return (int)g_prof.size() - 1;
+    const int ticket = g_prof_next++;
+    g_prof[ticket] = p;
+    return ticket;
 }
-void prof_end(int slot, hipStream_t stream) {
-    if (slot < 0) return;
+void prof_end(int ticket, hipStream_t stream) {
+    if (ticket < 0) return;
     std::lock_guard<std::mutex> lk(g_prof_mu);
-    if (slot < (int)g_prof.size()) {
-        (void)hipEventRecord(g_prof[slot].b, stream);
-        g_prof[slot].closed = true;
+    auto it = g_prof.find(ticket);
+    if (it != g_prof.end()) {
+        (void)hipEventRecord(it->second.b, stream);
+        it->second.closed = true;
     }
 }
 
@@ -1145,10 +1148,10 @@ int mvdb_prof_read(const char* name, int64_t* launches, double* total_ms) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
     int64_t cnt = 0;
     double ms = 0.0;
-    std::vector<ProfPair> keep;
-    for (auto& p : g_prof) {
+    for (auto it = g_prof.begin(); it != g_prof.end();) {
+        ProfPair& p = it->second;
         if (p.name != name || !p.closed) {
-            keep.push_back(p);
+            ++it;
             continue;
         }
         float t = 0.f;
@@ -1158,8 +1161,8 @@ int mvdb_prof_read(const char* name, int64_t* launches, double* total_ms) {
         }
         (void)hipEventDestroy(p.a);
         (void)hipEventDestroy(p.b);
+        it = g_prof.erase(it);
     }
-    g_prof.swap(keep);
     *launches = cnt;
     *total_ms = ms;
     return 0;
