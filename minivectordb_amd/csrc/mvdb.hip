@@ -114,8 +114,8 @@ struct Workspace {
     DevBuf<float> q;
     DevBuf<float> qn;  // normalised copy of the queries for the multi-query pass
     DevBuf<uint64_t> cand;
-    DevBuf<float> D;
-    DevBuf<int64_t> I;
+    DevBuf<int64_t> out;  // packed results of the host API: [I: total int64 | D: total fp32] -> ONE D2H copy
+    PinnedBuf pin_out;
     DevBuf<float> scores;
     DevBuf<uint64_t> selkeys;
     DevBuf<int64_t> rows;
@@ -138,8 +138,8 @@ struct Workspace {
         q.release();
         qn.release();
         cand.release();
-        D.release();
-        I.release();
+        out.release();
+        pin_out.release();
         scores.release();
         selkeys.release();
         rows.release();
@@ -695,6 +695,18 @@ int stage_queries(const mvdb_index* idx, Workspace* ws, const float* q_host, int
     return 0;
 }
 
+// Host API epilogue: results sit packed in ws->out ([I | D]); one async D2H into pinned staging, sync, unpack.
+int fetch_results(Workspace* ws, size_t total, float* D_host, int64_t* I_host) {
+    const size_t bytes = total * (sizeof(int64_t) + sizeof(float));
+    MVDB_TRY(ws->pin_out.reserve(bytes));
+    hipError_t e = hipMemcpyAsync(ws->pin_out.p, ws->out.p, bytes, hipMemcpyDeviceToHost, ws->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ws->stream);
+    if (e != hipSuccess) return fail(MVDB_ERR_HIP, "search failed: %s", hipGetErrorString(e));
+    memcpy(I_host, ws->pin_out.p, total * sizeof(int64_t));
+    memcpy(D_host, (const char*)ws->pin_out.p + total * sizeof(int64_t), total * sizeof(float));
+    return 0;
+}
+
 int check_search_args(const mvdb_index* idx, const void* q, int nq, int k, const void* D,
                       const void* I) {
     if (!idx) return fail(MVDB_ERR_ARG, "index is NULL");
@@ -998,17 +1010,10 @@ int mvdb_index_search(const mvdb_index* idx, const float* q_host, int nq, int k,
     do {
         if ((rc = stage_queries(idx, ws, q_host, nq))) break;
         const size_t total = (size_t)nq * k;
-        if ((rc = ws->D.reserve(total))) break;
-        if ((rc = ws->I.reserve(total))) break;
-        if ((rc = search_core(idx, ws, ws->q.p, nq, k, normalize_q, nullptr, 0, 0, ws->D.p, ws->I.p)))
-            break;
-        hipError_t e = hipMemcpyAsync(D_host, ws->D.p, total * sizeof(float), hipMemcpyDeviceToHost,
-                                      ws->stream);
-        if (e == hipSuccess)
-            e = hipMemcpyAsync(I_host, ws->I.p, total * sizeof(int64_t), hipMemcpyDeviceToHost,
-                               ws->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(ws->stream);
-        if (e != hipSuccess) rc = fail(MVDB_ERR_HIP, "search failed: %s", hipGetErrorString(e));
+        if ((rc = ws->out.reserve(total + (total + 1) / 2))) break;  // total int64 + total fp32
+        float* D_dev = reinterpret_cast<float*>(ws->out.p + total);
+        if ((rc = search_core(idx, ws, ws->q.p, nq, k, normalize_q, nullptr, 0, 0, D_dev, ws->out.p))) break;
+        rc = fetch_results(ws, total, D_host, I_host);
     } while (0);
     idx->release(ws);
     return rc;
@@ -1041,8 +1046,8 @@ int mvdb_index_search_subset(const mvdb_index* idx, const float* q_host, int nq,
     do {
         if ((rc = stage_queries(idx, ws, q_host, nq))) break;
         const size_t total = (size_t)nq * k;
-        if ((rc = ws->D.reserve(total))) break;
-        if ((rc = ws->I.reserve(total))) break;
+        if ((rc = ws->out.reserve(total + (total + 1) / 2))) break;
+        float* D_dev = reinterpret_cast<float*>(ws->out.p + total);
         if ((rc = ws->rows.reserve((size_t)std::max<int64_t>(m, 1)))) break;
         if (m > 0) {
             hipError_t e = hipMemcpyAsync(ws->rows.p, rows_host, (size_t)m * sizeof(int64_t),
@@ -1052,16 +1057,8 @@ int mvdb_index_search_subset(const mvdb_index* idx, const float* q_host, int nq,
                 break;
             }
         }
-        if ((rc = search_core(idx, ws, ws->q.p, nq, k, normalize_q, ws->rows.p, m, 0, ws->D.p,
-                              ws->I.p)))
-            break;
-        hipError_t e = hipMemcpyAsync(D_host, ws->D.p, total * sizeof(float), hipMemcpyDeviceToHost,
-                                      ws->stream);
-        if (e == hipSuccess)
-            e = hipMemcpyAsync(I_host, ws->I.p, total * sizeof(int64_t), hipMemcpyDeviceToHost,
-                               ws->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(ws->stream);
-        if (e != hipSuccess) rc = fail(MVDB_ERR_HIP, "search failed: %s", hipGetErrorString(e));
+        if ((rc = search_core(idx, ws, ws->q.p, nq, k, normalize_q, ws->rows.p, m, 0, D_dev, ws->out.p))) break;
+        rc = fetch_results(ws, total, D_host, I_host);
     } while (0);
     idx->release(ws);
     return rc;
