@@ -26,7 +26,7 @@ import threading
 from collections import defaultdict
 import numpy as np
 
-from ._dbcore import FilterAndRerankMixin, _AllRows, _HostMatrix
+from ._dbcore import FilterAndRerankMixin, _HostMatrix
 
 
 class VectorDatabase(FilterAndRerankMixin):

@@ -3,7 +3,6 @@ reference's tests/test_multithreaded_operations.py (5 writer threads, 5 searcher
 asserts the final bookkeeping), and hybrid_rerank_results.  Device back end = oracle stand-in."""
 import threading
 
-import numpy as np
 import pytest
 
 from oracle import flat
