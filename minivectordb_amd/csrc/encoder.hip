@@ -574,8 +574,8 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const float* __rest
     const int s0 = seq_start[b], len = seq_start[b + 1] - s0;
     const int q0 = blockIdx.x * 128;
     if (q0 >= len) return;
-    __shared__ float Kt[2][HD * KLD];   // [buf][k][key]   double buffered: one barrier per key tile
-    __shared__ float Vs[2][AM_KT * HD]; // [buf][key][d]
+    __shared__ float Kt[HD * KLD];      // [k][key]
+    __shared__ float Vs[AM_KT * HD];    // [key][d]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 31, fh = lane >> 5;
     const int64_t ld = 3 * (int64_t)H;
@@ -597,42 +597,23 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const float* __rest
     float m = -INFINITY, l = 0.f;
     const bool wave_active = q0 + wave * 32 < len;  // wave-uniform
 
-    // cooperative K/V tile staging, register prefetch one tile ahead: thread -> NLD (key, float4 chunk) pairs
-    constexpr int NLD = AM_KT * (HD / 4) / 256;
-    f32x4 kreg[NLD], vreg[NLD];
-    auto tile_load = [&](int kt) {
-        const int nk_ = min(AM_KT, len - kt);
-#pragma unroll
-        for (int i = 0; i < NLD; ++i) {
-            const int e = tid + i * 256;
-            const int key = e / (HD / 4), c = (e % (HD / 4)) * 4;
-            kreg[i] = f32x4{0, 0, 0, 0};
-            vreg[i] = f32x4{0, 0, 0, 0};
-            if (key < nk_) {
-                const float* base = qkv + (int64_t)(s0 + kt + key) * ld + h * HD + c;
-                kreg[i] = *reinterpret_cast<const f32x4*>(base + H);
-                vreg[i] = *reinterpret_cast<const f32x4*>(base + 2 * H);
-            }
-        }
-    };
-    auto tile_write = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < NLD; ++i) {
-            const int e = tid + i * 256;
-            const int key = e / (HD / 4), c = (e % (HD / 4)) * 4;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) Kt[buf][(c + j) * KLD + key] = kreg[i][j];  // K transposed
-            *reinterpret_cast<f32x4*>(&Vs[buf][key * HD + c]) = vreg[i];
-        }
-    };
-
-    tile_load(0);
-    int buf = 0;
-    for (int kt = 0; kt < len; kt += AM_KT, buf ^= 1) {
+    for (int kt = 0; kt < len; kt += AM_KT) {
         const int nk = min(AM_KT, len - kt);
-        tile_write(buf);
-        __syncthreads();  // tile kt visible; buffer buf^1 (read two tiles ago) is free for the next write
-        if (kt + AM_KT < len) tile_load(kt + AM_KT);  // in flight under the MFMAs below
+        __syncthreads();
+        // cooperative tile load: thread -> (key = e / (HD/4), float4 chunk c); K transposed, V straight
+        for (int e = tid; e < AM_KT * (HD / 4); e += 256) {
+            const int key = e / (HD / 4), c = (e % (HD / 4)) * 4;
+            f32x4 kv = {0, 0, 0, 0}, vv = {0, 0, 0, 0};
+            if (key < nk) {
+                const float* base = qkv + (int64_t)(s0 + kt + key) * ld + h * HD + c;
+                kv = *reinterpret_cast<const f32x4*>(base + H);
+                vv = *reinterpret_cast<const f32x4*>(base + 2 * H);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) Kt[(c + j) * KLD + key] = kv[j];
+            *reinterpret_cast<f32x4*>(&Vs[key * HD + c]) = vv;
+        }
+        __syncthreads();
         if (!wave_active) continue;
 #pragma unroll
         for (int kb = 0; kb < AM_KT / 32; ++kb) {
@@ -643,7 +624,7 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const float* __rest
             for (int r = 0; r < 16; ++r) st[r] = 0.f;
 #pragma unroll
             for (int kk = 0; kk < HD / 2; ++kk) {
-                const float ka = Kt[buf][(2 * kk + fh) * KLD + kb * 32 + fr];  // A[i = key fr][k = fh]
+                const float ka = Kt[(2 * kk + fh) * KLD + kb * 32 + fr];  // A[i = key fr][k = fh]
                 st = __builtin_amdgcn_mfma_f32_32x32x2f32(ka, qf[kk], st, 0, 0, 0);
             }
             // ---- online softmax, query on the lane --------------------------------------------------
@@ -676,7 +657,7 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const float* __rest
                 const int key = kb * 32 + (t16 & 3) + 8 * (t16 >> 2) + 4 * fh;
 #pragma unroll
                 for (int t = 0; t < DT; ++t) {
-                    const float va = Vs[buf][key * HD + t * 32 + fr];  // A[i = d fr][k = fh] = V[key][d]
+                    const float va = Vs[key * HD + t * 32 + fr];  // A[i = d fr][k = fh] = V[key][d]
                     o[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(va, st[t16], o[t], 0, 0, 0);
                 }
             }
