@@ -563,6 +563,11 @@ __global__ __launch_bounds__(ATT_Q) void attention_kernel(const float* __restric
 //                                    two keys (t&3) + 8(t>>2) + {0,4} that the two lane halves hold in register t
 // No P tile ever goes through LDS and no lane shuffles for the second product.
 constexpr int AM_KT = 64;  // keys per LDS tile (2 MFMA key blocks)
+// Scores are kept in the log2 domain (Q pre-scaled by log2(e)/sqrt(hd)) so that the softmax exponentials are
+// single v_exp_f32 instructions: softmax(s) = 2^(s*log2e - max) / sum — the same function, ~1e-6 relative
+// rounding difference from a libm expf (the precise expf expanded to ~15 instructions per element and cost
+// as much as the MFMAs).
+constexpr float kLog2e = 1.4426950408889634f;
 
 template <int HD>
 __global__ __launch_bounds__(256) void attention_mfma_kernel(const float* __restrict__ qkv,
@@ -587,7 +592,7 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const float* __rest
     {
         const float* qp = qkv + (int64_t)(s0 + (qvalid ? qrow : 0)) * ld + h * HD;
 #pragma unroll
-        for (int kk = 0; kk < HD / 2; ++kk) qf[kk] = qvalid ? qp[2 * kk + fh] * scale : 0.f;
+        for (int kk = 0; kk < HD / 2; ++kk) qf[kk] = qvalid ? qp[2 * kk + fh] * (scale * kLog2e) : 0.f;
     }
     f32x16 o[DT];
 #pragma unroll
@@ -637,11 +642,11 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const float* __rest
             }
             cmax = fmaxf(cmax, __shfl_xor(cmax, 32));
             const float mn = fmaxf(m, cmax);
-            const float alpha = expf(m - mn);
+            const float alpha = __builtin_amdgcn_exp2f(m - mn);
             float psum = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                st[r] = expf(st[r] - mn);  // masked keys: exp(-inf) = 0
+                st[r] = __builtin_amdgcn_exp2f(st[r] - mn);  // masked keys: 2^(-inf) = 0
                 psum += st[r];
             }
             psum += __shfl_xor(psum, 32);
