@@ -142,9 +142,14 @@ int mvdb_synth_fill_device(float* out_dev, int64_t n, int d, uint64_t seed, int6
 /* ---- profiling hooks (bench.py's roofline leg) ---------------------------------------------
  * When enabled, every launch of the dominant kernels is bracketed by hipEvents on the launch
  * stream.  mvdb_prof_read drains the finished pairs of kernel `name` ("ip_scan", "ip_scan_mfma",
- * "encoder") and returns the number of launches and their summed duration. */
+ * "ip_scan_gemm", "ip_scan_split", "encoder") and returns the number of launches and their summed duration. */
 int mvdb_prof_enable(int on);
 int mvdb_prof_read(const char* name, int64_t* launches, double* total_ms);
+
+/* Number of 128-query chunks of the split-precision batch pass (bf16 matrix cores, results certified
+ * against exact fp32 re-scores) that failed certification and were re-run on the exact fp32 kernels
+ * since the library was loaded.  Diagnostic only. */
+int64_t mvdb_split_rerun_count(void);
 
 /* ---- encoder (BERT-architecture sentence encoder: e5-small / e5-large) ---------------------
  * Replaces self.model(**batch_dict) + average_pool + F.normalize

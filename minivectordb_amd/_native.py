@@ -76,6 +76,7 @@ PROTOTYPES = {
     "mvdb_normalize_l2": (ctypes.c_int, [c_vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int]),
     "mvdb_synth_fill_device": (ctypes.c_int, [c_vp, ctypes.c_int64, ctypes.c_int, ctypes.c_uint64, ctypes.c_int64,
                                               ctypes.c_int, ctypes.c_int, c_vp]),
+    "mvdb_split_rerun_count": (ctypes.c_int64, []),
     "mvdb_prof_enable": (ctypes.c_int, [ctypes.c_int]),
     "mvdb_prof_read": (ctypes.c_int, [ctypes.c_char_p, ctypes.POINTER(ctypes.c_int64),
                                       ctypes.POINTER(ctypes.c_double)]),
@@ -239,6 +240,10 @@ def normalize_l2(x, device=0):
 
 def prof_enable(on=True):
     check(lib().mvdb_prof_enable(int(bool(on))))
+
+
+def split_rerun_count():
+    return int(lib().mvdb_split_rerun_count())
 
 
 def prof_read(name):

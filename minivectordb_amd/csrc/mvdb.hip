@@ -5,13 +5,16 @@
 // the padding is zero.  Rows [0, n) are live.  Nothing else of the corpus lives on the device
 // (ids / metadata stay in the Python host layer, as in the reference).
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
+#include <atomic>
 #include <map>
 #include <shared_mutex>
 
 #include "common.hpp"
 #include "scan_kernels.hpp"
 #include "scan_mfma_kernels.hpp"
+#include "scan_split_kernels.hpp"
 #include "select_kernels.hpp"
 #include "util_kernels.hpp"
 
@@ -119,6 +122,10 @@ struct Workspace {
     DevBuf<float> scores;
     DevBuf<uint64_t> selkeys;
     DevBuf<int64_t> rows;
+    DevBuf<__bf16> qsplit;  // bf16 (hi | lo) images of one 128-query chunk (split-precision pass)
+    DevBuf<float> qnorm;
+    DevBuf<int> flags;      // per-chunk count of uncertified queries
+    PinnedBuf pin_flags;
     SelectState* st = nullptr;
     PinnedBuf pin;
 
@@ -143,6 +150,10 @@ struct Workspace {
         scores.release();
         selkeys.release();
         rows.release();
+        qsplit.release();
+        qnorm.release();
+        flags.release();
+        pin_flags.release();
         pin.release();
         if (st) (void)hipFree(st);
         if (own_stream && stream) (void)hipStreamDestroy(stream);
@@ -156,6 +167,7 @@ struct mvdb_index {
     int64_t ld = 0;
     float* X = nullptr;
     int64_t n = 0, cap = 0;
+    float row_norm_bound = 0.f;  // upper bound of |row| over the stored rows (INFINITY: unknown, raw adds)
     mutable std::shared_mutex mu;  // search: shared; add/reset/remove/free: exclusive
     mutable std::mutex ws_mu;
     mutable std::vector<Workspace*> free_ws;           // synchronous searches
@@ -499,6 +511,96 @@ int launch_gemm_scan(const mvdb_index* idx, const float* q, int nq, int k, int64
     return 0;
 }
 
+// nq >= 24, k <= 12, rows of known norm: split-precision bf16 pass + exact certification (scan_split_kernels.hpp)
+constexpr float kSplitEps = 1.0e-4f;  // >= 3 * 2^-16 operand bound (4.6e-5) + fp32 accumulation allowance
+std::atomic<long> g_split_reruns{0};
+
+bool split_path_ok(const mvdb_index* idx, int nq, int k, const int64_t* rows_dev) {
+    if (env_int("MVDB_DISABLE_SPLIT_SCAN", 0)) return false;
+    if (nq < env_int("MVDB_SPLIT_SCAN_MIN_NQ", 24) || k > kSplitMaxK || rows_dev || idx->metric != MVDB_METRIC_IP)
+        return false;
+    if (!(idx->row_norm_bound > 0.f) || std::isinf(idx->row_norm_bound)) return false;
+    return idx->d % 32 == 0 && idx->ld == idx->d;
+}
+
+int launch_split_scan(const mvdb_index* idx, Workspace* ws, const float* q, int nq, int k, int64_t n,
+                      int64_t label_offset, float* D, int64_t* I, int* flag) {
+    hipStream_t stream = ws->stream;
+    __bf16* qh = ws->qsplit.p;
+    __bf16* ql = qh + (size_t)128 * idx->d;
+    hipLaunchKernelGGL(split_queries_kernel, dim3(128), dim3(256), 0, stream, q, idx->ld, idx->d, nq, qh, ql,
+                       ws->qnorm.p);
+    MVDB_HIP(hipGetLastError());
+    SplitScanArgs a;
+    a.X = idx->X;
+    a.n = n;
+    a.ld = idx->ld;
+    a.K = idx->d;
+    a.qh = qh;
+    a.ql = ql;
+    a.nq = nq;
+    void (*kern)(SplitScanArgs) = flat_scan_split_kernel<0>;
+    switch (env_int("MVDB_SPLIT_DBG", 0)) {  // timing ablations (invalid results), benchmarks/split_probe.py
+        case 1: kern = flat_scan_split_kernel<1>; break;
+        case 3: kern = flat_scan_split_kernel<3>; break;
+        case 5: kern = flat_scan_split_kernel<5>; break;
+        case 7: kern = flat_scan_split_kernel<7>; break;
+        case 9: kern = flat_scan_split_kernel<9>; break;
+        case 17: kern = flat_scan_split_kernel<17>; break;
+        case 25: kern = flat_scan_split_kernel<25>; break;
+        case 33: kern = flat_scan_split_kernel<33>; break;
+        default: break;
+    }
+    MVDB_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSplitLds));
+    const int64_t ntiles = (n + 127) / 128;
+    const int cus = device_cus(idx->device);
+    // Large corpora: a seed launch over the first tile of every block learns each query's admission floor (the
+    // 16th best score of those rows), the main launch then inserts only the rows above it.
+    const bool seeded = ntiles >= (int64_t)cus * env_int("MVDB_SPLIT_SEED_MIN_TILES_PER_CU", 8);
+    uint64_t* seed_keys = ws->cand.p;                                // [128][16]
+    uint64_t* cand = ws->cand.p + (size_t)128 * kSplitKeep;          // [nq][gx][16]
+    const uint64_t* seed_arg = nullptr;
+    a.cand = cand;
+    a.tile0 = 0;
+    a.tile1 = ntiles;
+    a.thr0 = nullptr;
+    if (seeded) {
+        a.tile1 = cus;
+        int slot = prof_begin("ip_scan_split_seed", stream);
+        hipLaunchKernelGGL(kern, dim3(cus, 1), dim3(kSplitThreads), kSplitLds, stream, a);
+        hipLaunchKernelGGL(split_seed_kernel, dim3(nq), dim3(1024), 0, stream, cand, cus, seed_keys, ws->qnorm.p + 128);
+        prof_end(slot, stream);
+        MVDB_HIP(hipGetLastError());
+        a.tile0 = cus;
+        a.tile1 = ntiles;
+        a.thr0 = ws->qnorm.p + 128;
+        seed_arg = seed_keys;
+    }
+    const int gx = (int)std::max<int64_t>(1, std::min<int64_t>(a.tile1 - a.tile0, (int64_t)cus));
+    int slot = prof_begin("ip_scan_split", stream);
+    hipLaunchKernelGGL(kern, dim3(gx, 1), dim3(kSplitThreads), kSplitLds, stream, a);
+    prof_end(slot, stream);
+    MVDB_HIP(hipGetLastError());
+    SplitCertifyArgs c;
+    c.keys = cand;
+    c.nlists = gx;
+    c.seed = seed_arg;
+    c.X = idx->X;
+    c.ld = idx->ld;
+    c.d4 = idx->d4;
+    c.q = q;
+    c.qnorm = ws->qnorm.p;
+    c.eps = kSplitEps * idx->row_norm_bound;
+    c.k = k;
+    c.label_offset = label_offset;
+    c.D = D;
+    c.I = I;
+    c.uncertified = flag;
+    hipLaunchKernelGGL(split_certify_kernel, dim3(nq), dim3(1024), 0, stream, c);
+    MVDB_HIP(hipGetLastError());
+    return 0;
+}
+
 bool mfma_path_ok(const mvdb_index* idx, int nq, int k, const int64_t* rows_dev) {
     if (env_int("MVDB_DISABLE_MFMA_SCAN", 0)) return false;
     if (nq < 2 || k > kMaxFusedK || rows_dev || idx->metric != MVDB_METRIC_IP) return false;
@@ -510,7 +612,7 @@ bool mfma_path_ok(const mvdb_index* idx, int nq, int k, const int64_t* rows_dev)
 // Core: queries already on the device (padded to ld), outputs on the device.  Enqueues on ws.stream.
 int search_core(const mvdb_index* idx, Workspace* ws, const float* q_dev, int nq, int k,
                 int normalize_q, const int64_t* rows_dev, int64_t m, int64_t label_offset,
-                float* D_dev, int64_t* I_dev) {
+                float* D_dev, int64_t* I_dev, bool allow_split = true) {
     hipStream_t s = ws->stream;
     const int64_t n = rows_dev ? m : idx->n;
     if (n == 0) {
@@ -531,6 +633,49 @@ int search_core(const mvdb_index* idx, Workspace* ws, const float* q_dev, int nq
     a.rows = rows_dev;
     a.cand = nullptr;
     a.scores = nullptr;
+
+    // Batches of >= 24 queries, k <= 12, rows of known norm: split-precision pass on the bf16 matrix cores
+    // (scan_split_kernels.hpp), 128 queries per corpus pass, every result certified against exact fp32
+    // re-scores; chunks holding an uncertified query are re-run on the exact paths below.
+    if (allow_split && split_path_ok(idx, nq, k, rows_dev)) {
+        const float* qsrc = q_dev;
+        if (normalize_q) {
+            MVDB_TRY(ws->qn.reserve((size_t)nq * idx->ld));
+            MVDB_HIP(hipMemcpyAsync(ws->qn.p, q_dev, (size_t)nq * idx->ld * sizeof(float),
+                                    hipMemcpyDeviceToDevice, s));
+            MVDB_TRY(normalize_range(idx, ws->qn.p, nq, s));
+            qsrc = ws->qn.p;
+        }
+        const int min_nq = env_int("MVDB_SPLIT_SCAN_MIN_NQ", 24);
+        const int nchunks = (nq + 127) / 128;
+        MVDB_TRY(ws->qsplit.reserve((size_t)2 * 128 * idx->d));
+        MVDB_TRY(ws->qnorm.reserve(256));  // [0,128): |q|, [128,256): admission floors of the seed pass
+        MVDB_TRY(ws->flags.reserve((size_t)nchunks));
+        MVDB_TRY(ws->pin_flags.reserve((size_t)nchunks * sizeof(int)));
+        MVDB_TRY(ws->cand.reserve((size_t)128 * (scan_grid_upper_bound(idx->device) + 1) * kSplitKeep));
+        MVDB_HIP(hipMemsetAsync(ws->flags.p, 0, (size_t)nchunks * sizeof(int), s));
+        int q0 = 0, done_chunks = 0;
+        while (nq - q0 >= min_nq) {
+            const int take = std::min(nq - q0, 128);
+            MVDB_TRY(launch_split_scan(idx, ws, qsrc + (int64_t)q0 * idx->ld, take, k, n, label_offset,
+                                       D_dev + (int64_t)q0 * k, I_dev + (int64_t)q0 * k, ws->flags.p + done_chunks));
+            q0 += take;
+            ++done_chunks;
+        }
+        int* hflags = static_cast<int*>(ws->pin_flags.p);
+        MVDB_HIP(hipMemcpyAsync(hflags, ws->flags.p, (size_t)done_chunks * sizeof(int), hipMemcpyDeviceToHost, s));
+        MVDB_HIP(hipStreamSynchronize(s));
+        for (int c = 0; c < done_chunks; ++c) {
+            if (!hflags[c]) continue;
+            const int c0 = c * 128, take = std::min(q0 - c0, 128);
+            g_split_reruns.fetch_add(1, std::memory_order_relaxed);
+            MVDB_TRY(search_core(idx, ws, qsrc + (int64_t)c0 * idx->ld, take, k, 0, rows_dev, m, label_offset,
+                                 D_dev + (int64_t)c0 * k, I_dev + (int64_t)c0 * k, false));
+        }
+        if (q0 == nq) return 0;
+        return search_core(idx, ws, qsrc + (int64_t)q0 * idx->ld, nq - q0, k, 0, rows_dev, m, label_offset,
+                           D_dev + (int64_t)q0 * k, I_dev + (int64_t)q0 * k, false);
+    }
 
     // Large batches are cut into chunks: >= 104 queries left -> one 128-query GEMM-tiled launch (compute-
     // bound, 13.7 ms at 10M x 512), fewer -> 32-query MFMA passes (4.0 ms each); measured crossover ~100.
@@ -819,6 +964,7 @@ int mvdb_index_reset(mvdb_index* idx) {
     if (!idx) return fail(MVDB_ERR_ARG, "index is NULL");
     std::unique_lock<std::shared_mutex> lk(idx->mu);
     idx->n = 0;
+    idx->row_norm_bound = 0.f;
     return 0;
 }
 
@@ -844,6 +990,32 @@ int mvdb_index_reserve(mvdb_index* idx, int64_t n) {
     return 0;
 }
 
+// Keeps idx->row_norm_bound >= |row| for every stored row: 1 for rows normalised on the device, one
+// extra read of the new rows otherwise (non-finite rows leave the bound non-finite).
+static int note_row_norms(mvdb_index* idx, const float* dst, int64_t n, int normalize) {
+    if (normalize) {
+        idx->row_norm_bound = std::max(idx->row_norm_bound, 1.000001f);
+        return 0;
+    }
+    unsigned int* dmax = nullptr;
+    MVDB_HIP(hipMalloc((void**)&dmax, sizeof(unsigned int)));
+    unsigned int bits = 0;
+    hipError_t e = hipMemset(dmax, 0, sizeof(unsigned int));
+    if (e == hipSuccess) {
+        const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((n + 3) / 4, (int64_t)device_cus(idx->device) * 16));
+        hipLaunchKernelGGL(max_row_norm2_kernel, dim3(grid), dim3(256), 0, nullptr, dst, n, idx->ld, idx->d4, dmax);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(&bits, dmax, sizeof(bits), hipMemcpyDeviceToHost);
+    (void)hipFree(dmax);
+    MVDB_HIP(e);
+    float n2;
+    memcpy(&n2, &bits, sizeof(n2));
+    const float bound = std::isfinite(n2) ? std::sqrt(n2) * 1.000001f : INFINITY;
+    idx->row_norm_bound = std::max(idx->row_norm_bound, bound);
+    return 0;
+}
+
 int mvdb_index_add(mvdb_index* idx, const float* x_host, int64_t n, int normalize) {
     if (!idx) return fail(MVDB_ERR_ARG, "index is NULL");
     if (n < 0) return fail(MVDB_ERR_ARG, "negative row count");
@@ -866,6 +1038,7 @@ int mvdb_index_add(mvdb_index* idx, const float* x_host, int64_t n, int normaliz
         MVDB_TRY(normalize_range(idx, dst, n, nullptr));
         MVDB_HIP(hipDeviceSynchronize());
     }
+    MVDB_TRY(note_row_norms(idx, dst, n, normalize));
     idx->n += n;
     return 0;
 }
@@ -893,6 +1066,7 @@ int mvdb_index_add_device(mvdb_index* idx, const float* x_dev, int64_t n, int no
     }
     if (normalize) MVDB_TRY(normalize_range(idx, dst, n, nullptr));
     MVDB_HIP(hipDeviceSynchronize());
+    MVDB_TRY(note_row_norms(idx, dst, n, normalize));
     idx->n += n;
     return 0;
 }
@@ -916,6 +1090,7 @@ int mvdb_index_add_synthetic(mvdb_index* idx, int64_t n, uint64_t seed, int64_t 
     MVDB_HIP(hipGetLastError());
     if (normalize) MVDB_TRY(normalize_range(idx, dst, n, nullptr));
     MVDB_HIP(hipDeviceSynchronize());
+    MVDB_TRY(note_row_norms(idx, dst, n, normalize));
     idx->n += n;
     return 0;
 }
@@ -1133,6 +1308,8 @@ int mvdb_synth_fill_device(float* out_dev, int64_t n, int d, uint64_t seed, int6
     }
     return 0;
 }
+
+int64_t mvdb_split_rerun_count(void) { return (int64_t)g_split_reruns.load(std::memory_order_relaxed); }
 
 int mvdb_prof_enable(int on) {
     std::lock_guard<std::mutex> lk(g_prof_mu);

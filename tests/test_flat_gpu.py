@@ -474,23 +474,124 @@ def test_large_batch_gemm_scan_matches_oracle(native, n, d, k, nq):
     q = _corpus(nq, d, seed=777)
     idx = native.FlatIndex(d)
     idx.add(x)
+    os.environ["MVDB_DISABLE_SPLIT_SCAN"] = "1"  # this test pins the exact-fp32 tiled kernel (the fallback of the split pass)
     os.environ["MVDB_GEMM_SCAN_MIN_NQ"] = "64"  # the library reads it per call: also cover half-filled query tiles
     try:
         D, I = idx.search(q, k)
         _check(native, x, q, k, D, I)
-    finally:
         del os.environ["MVDB_GEMM_SCAN_MIN_NQ"]
-    Dd, Id = idx.search(q, k)  # default chunking (GEMM launches of up to 128 + 32-query passes for the rest)
-    assert np.array_equal(Id, I)
-    np.testing.assert_allclose(Dd, D, atol=2e-6)
-    D2, I2 = idx.search(q * 2.5, k, normalize_q=True)  # fused normalisation path
-    assert np.array_equal(I2, I)
-    np.testing.assert_allclose(D2, D, atol=2e-6)
+        Dd, Id = idx.search(q, k)  # default chunking (GEMM launches of up to 128 + 32-query passes for the rest)
+        assert np.array_equal(Id, I)
+        np.testing.assert_allclose(Dd, D, atol=2e-6)
+        D2, I2 = idx.search(q * 2.5, k, normalize_q=True)  # fused normalisation path
+        assert np.array_equal(I2, I)
+        np.testing.assert_allclose(D2, D, atol=2e-6)
+        for i in (0, nq // 2, nq - 1):
+            D1, I1 = idx.search(q[i], k)
+            assert np.array_equal(I1[0], I[i])
+        # determinism across repeats (same path each time)
+        for _ in range(3):
+            Dr, Ir = idx.search(q, k)
+            assert np.array_equal(Ir, Id) and np.array_equal(Dr, Dd)
+    finally:
+        os.environ.pop("MVDB_GEMM_SCAN_MIN_NQ", None)
+        del os.environ["MVDB_DISABLE_SPLIT_SCAN"]
+    idx.close()
+
+
+def _split_launches(native):
+    return native.prof_read("ip_scan_split")[0]
+
+
+@pytest.mark.parametrize("n,d,k,nq", [
+    (20000, 512, 10, 64), (9000, 384, 12, 100), (5000, 512, 1, 128), (12345, 256, 10, 129), (300, 64, 5, 200),
+    (127, 512, 10, 70), (15, 512, 10, 30), (16, 128, 10, 24), (17, 96, 12, 33), (6000, 1024, 10, 130),
+    (30000, 384, 10, 256),
+])
+def test_split_precision_batch_pass_matches_oracle(native, n, d, k, nq):
+    """nq >= 24, k <= 12: the bf16 split-precision pass nominates 16 rows per query, exact fp32 re-scores decide and
+    certify (scan_split_kernels.hpp).  Results must equal the oracle's and every query's own single-query search."""
+    x = _corpus(n, d)
+    q = _corpus(nq, d, seed=777)
+    idx = native.FlatIndex(d)
+    idx.add(x)  # raw add: the row-norm bound is measured on the device
+    native.prof_enable(True)
+    reruns = native.split_rerun_count()
+    try:
+        _split_launches(native)  # drain
+        D, I = idx.search(q, k)
+        assert _split_launches(native) >= nq // 128, "the split-precision pass did not run"
+    finally:
+        native.prof_enable(False)
+    _check(native, x, q, k, D, I)
+    if n > 16:
+        assert native.split_rerun_count() == reruns, "well-separated scores must certify"
     for i in (0, nq // 2, nq - 1):
         D1, I1 = idx.search(q[i], k)
         assert np.array_equal(I1[0], I[i])
-    # determinism across repeats (same path each time)
+        np.testing.assert_allclose(D1[0], D[i], atol=2e-6, rtol=0)
+    D2, I2 = idx.search(q * 2.5, k, normalize_q=True)
+    assert np.array_equal(I2, I)
+    np.testing.assert_allclose(D2, D, atol=2e-6)
     for _ in range(3):
         Dr, Ir = idx.search(q, k)
-        assert np.array_equal(Ir, Id) and np.array_equal(Dr, Dd)
+        assert np.array_equal(Ir, I) and np.array_equal(Dr, D)
+    idx.close()
+
+
+def test_split_precision_pass_unnormalised_rows_and_queries(native):
+    """Raw rows of very different norms and raw queries: the certification margin scales with |q| * max|row|."""
+    n, d, k, nq = 8000, 256, 10, 48
+    x = flat.synth(n, d, 99)
+    x *= np.linspace(0.01, 30.0, n, dtype=np.float32)[:, None]
+    q = flat.synth(nq, d, 100) * np.float32(7.0)
+    idx = native.FlatIndex(d)
+    idx.add(x)
+    native.prof_enable(True)
+    try:
+        _split_launches(native)
+        D, I = idx.search(q, k)
+        assert _split_launches(native) == 1
+    finally:
+        native.prof_enable(False)
+    Do, Io = flat.flat_search(x, q, k)
+    for i in range(nq):
+        ok, msg = flat.adjudicate(x, q[i], k, D[i], I[i], tol=1e-4 * 30.0 * float(np.linalg.norm(q[i])))
+        assert ok, msg
+    assert (I == Io).mean() > 0.99
+    np.testing.assert_allclose(D, Do, rtol=1e-5, atol=1e-3)
+    idx.close()
+
+
+def test_split_precision_pass_falls_back_when_it_cannot_certify(native):
+    """40 copies of each query's best row: more than 16 - k rows tie with the k-th score, the certificate fails
+    and the chunk is re-run on the exact kernels; ties still resolve to the lowest row numbers."""
+    n, d, k, nq = 6000, 128, 10, 32
+    x = _corpus(n, d)
+    q = _corpus(nq, d, seed=31)
+    x[100:140] = q[0]          # 40 exact copies of query 0
+    x[2000:2011] = x[5]        # a smaller cluster elsewhere
+    idx = native.FlatIndex(d)
+    idx.add(x)
+    before = native.split_rerun_count()
+    D, I = idx.search(q, k)
+    assert native.split_rerun_count() == before + 1
+    assert I[0].tolist() == list(range(100, 110))
+    _check(native, x, q, k, D, I)
+    for i in range(nq):
+        D1, I1 = idx.search(q[i], k)
+        assert np.array_equal(I1[0], I[i])
+    # non-finite rows switch the pass off for the index instead of poisoning the margin
+    y = _corpus(500, d)
+    y[7, 3] = np.inf
+    idx2 = native.FlatIndex(d)
+    idx2.add(y)
+    native.prof_enable(True)
+    try:
+        _split_launches(native)
+        idx2.search(q, k)
+        assert _split_launches(native) == 0
+    finally:
+        native.prof_enable(False)
+    idx2.close()
     idx.close()
