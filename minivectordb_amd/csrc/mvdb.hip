@@ -511,13 +511,13 @@ int launch_gemm_scan(const mvdb_index* idx, const float* q, int nq, int k, int64
     return 0;
 }
 
-// nq >= 24, k <= 12, rows of known norm: split-precision bf16 pass + exact certification (scan_split_kernels.hpp)
+// nq >= 40, k <= 12, rows of known norm: split-precision bf16 pass + exact certification (scan_split_kernels.hpp)
 constexpr float kSplitEps = 1.0e-4f;  // >= 3 * 2^-16 operand bound (4.6e-5) + fp32 accumulation allowance
 std::atomic<long> g_split_reruns{0};
 
 bool split_path_ok(const mvdb_index* idx, int nq, int k, const int64_t* rows_dev) {
     if (env_int("MVDB_DISABLE_SPLIT_SCAN", 0)) return false;
-    if (nq < env_int("MVDB_SPLIT_SCAN_MIN_NQ", 24) || k > kSplitMaxK || rows_dev || idx->metric != MVDB_METRIC_IP)
+    if (nq < env_int("MVDB_SPLIT_SCAN_MIN_NQ", 40) || k > kSplitMaxK || rows_dev || idx->metric != MVDB_METRIC_IP)
         return false;
     if (!(idx->row_norm_bound > 0.f) || std::isinf(idx->row_norm_bound)) return false;
     return idx->d % 32 == 0 && idx->ld == idx->d;
@@ -542,6 +542,12 @@ int launch_split_scan(const mvdb_index* idx, Workspace* ws, const float* q, int 
     void (*kern)(SplitScanArgs) = flat_scan_split_kernel<0>;
     switch (env_int("MVDB_SPLIT_DBG", 0)) {  // timing ablations (invalid results), benchmarks/split_probe.py
         case 1: kern = flat_scan_split_kernel<1>; break;
+        case 2: kern = flat_scan_split_kernel<2>; break;
+        case 4: kern = flat_scan_split_kernel<4>; break;
+        case 6: kern = flat_scan_split_kernel<6>; break;
+        case 16: kern = flat_scan_split_kernel<16>; break;
+        case 24: kern = flat_scan_split_kernel<24>; break;
+        case 32: kern = flat_scan_split_kernel<32>; break;
         case 3: kern = flat_scan_split_kernel<3>; break;
         case 5: kern = flat_scan_split_kernel<5>; break;
         case 7: kern = flat_scan_split_kernel<7>; break;
@@ -549,6 +555,9 @@ int launch_split_scan(const mvdb_index* idx, Workspace* ws, const float* q, int 
         case 17: kern = flat_scan_split_kernel<17>; break;
         case 25: kern = flat_scan_split_kernel<25>; break;
         case 33: kern = flat_scan_split_kernel<33>; break;
+        case 64: kern = flat_scan_split_kernel<64>; break;
+        case 128: kern = flat_scan_split_kernel<128>; break;
+        case 256: kern = flat_scan_split_kernel<256>; break;
         default: break;
     }
     MVDB_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSplitLds));
@@ -564,14 +573,17 @@ int launch_split_scan(const mvdb_index* idx, Workspace* ws, const float* q, int 
     a.tile0 = 0;
     a.tile1 = ntiles;
     a.thr0 = nullptr;
+    a.stats = env_int("MVDB_SPLIT_STATS", 0) ? reinterpret_cast<unsigned int*>(ws->flags.p) + 64 : nullptr;
+    if (a.stats) MVDB_HIP(hipMemsetAsync(a.stats, 0, 8, stream));
+    const int64_t seed_tiles = (int64_t)cus * std::max(1, env_int("MVDB_SPLIT_SEED_TILES_PER_CU", 1));
     if (seeded) {
-        a.tile1 = cus;
+        a.tile1 = seed_tiles;
         int slot = prof_begin("ip_scan_split_seed", stream);
         hipLaunchKernelGGL(kern, dim3(cus, 1), dim3(kSplitThreads), kSplitLds, stream, a);
         hipLaunchKernelGGL(split_seed_kernel, dim3(nq), dim3(1024), 0, stream, cand, cus, seed_keys, ws->qnorm.p + 128);
         prof_end(slot, stream);
         MVDB_HIP(hipGetLastError());
-        a.tile0 = cus;
+        a.tile0 = seed_tiles;
         a.tile1 = ntiles;
         a.thr0 = ws->qnorm.p + 128;
         seed_arg = seed_keys;
@@ -598,6 +610,12 @@ int launch_split_scan(const mvdb_index* idx, Workspace* ws, const float* q, int 
     c.uncertified = flag;
     hipLaunchKernelGGL(split_certify_kernel, dim3(nq), dim3(1024), 0, stream, c);
     MVDB_HIP(hipGetLastError());
+    if (a.stats) {
+        unsigned int st[2] = {0, 0};
+        MVDB_HIP(hipMemcpyAsync(st, a.stats, 8, hipMemcpyDeviceToHost, stream));
+        MVDB_HIP(hipStreamSynchronize(stream));
+        fprintf(stderr, "[mvdb split] list inserts %u, slow-path wave-tiles %u (seed + main launch)\n", st[0], st[1]);
+    }
     return 0;
 }
 
@@ -634,7 +652,7 @@ int search_core(const mvdb_index* idx, Workspace* ws, const float* q_dev, int nq
     a.cand = nullptr;
     a.scores = nullptr;
 
-    // Batches of >= 24 queries, k <= 12, rows of known norm: split-precision pass on the bf16 matrix cores
+    // Batches of >= 40 queries, k <= 12, rows of known norm: split-precision pass on the bf16 matrix cores
     // (scan_split_kernels.hpp), 128 queries per corpus pass, every result certified against exact fp32
     // re-scores; chunks holding an uncertified query are re-run on the exact paths below.
     if (allow_split && split_path_ok(idx, nq, k, rows_dev)) {
@@ -646,11 +664,11 @@ int search_core(const mvdb_index* idx, Workspace* ws, const float* q_dev, int nq
             MVDB_TRY(normalize_range(idx, ws->qn.p, nq, s));
             qsrc = ws->qn.p;
         }
-        const int min_nq = env_int("MVDB_SPLIT_SCAN_MIN_NQ", 24);
+        const int min_nq = env_int("MVDB_SPLIT_SCAN_MIN_NQ", 40);
         const int nchunks = (nq + 127) / 128;
         MVDB_TRY(ws->qsplit.reserve((size_t)2 * 128 * idx->d));
         MVDB_TRY(ws->qnorm.reserve(256));  // [0,128): |q|, [128,256): admission floors of the seed pass
-        MVDB_TRY(ws->flags.reserve((size_t)nchunks));
+        MVDB_TRY(ws->flags.reserve((size_t)std::max(nchunks, 64) + 4));  // + diagnostics counters at [64]
         MVDB_TRY(ws->pin_flags.reserve((size_t)nchunks * sizeof(int)));
         MVDB_TRY(ws->cand.reserve((size_t)128 * (scan_grid_upper_bound(idx->device) + 1) * kSplitKeep));
         MVDB_HIP(hipMemsetAsync(ws->flags.p, 0, (size_t)nchunks * sizeof(int), s));

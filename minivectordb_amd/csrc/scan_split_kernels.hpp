@@ -39,7 +39,7 @@ constexpr int kSplitMaxK = 12;   // results per query this path certifies
 constexpr int kSplitThreads = 512;
 constexpr int kSplitStages = 3;                          // LDS ring depth (K-steps)
 constexpr int kSplitStageBytes = 32768;                  // 128 rows x 32 fp32 + 128 queries x 32 x (bf16 hi + lo)
-constexpr size_t kSplitLds = (size_t)kSplitStages * kSplitStageBytes + (size_t)8 * 64 * kSplitKeep * 8;
+constexpr size_t kSplitLds = (size_t)kSplitStages * kSplitStageBytes;  // dynamic part (the ring); the lists are static
 
 struct SplitScanArgs {
     const float* X;
@@ -53,6 +53,7 @@ struct SplitScanArgs {
     int64_t tile0;      // this launch scans the 128-row tiles [tile0, tile1)
     int64_t tile1;
     const float* thr0;  // [nq] admission floor per query (seed pass, see launch_split_scan) or NULL
+    unsigned int* stats; // NULL, or [2]: list inserts, tiles that reached the slow path (diagnostics)
 };
 
 typedef __bf16 sbf16x2 __attribute__((ext_vector_type(2)));
@@ -88,13 +89,16 @@ __global__ __launch_bounds__(256) void split_queries_kernel(const float* __restr
 }
 
 // DBG != 0: timing ablations only (benchmarks/split_probe.py, MVDB_SPLIT_DBG) — results are NOT valid.
-//   1 no nomination, 2 no hi/lo split, 4 no MFMA, 8 no query DMA, 16 no corpus DMA, 32 no barrier
+//   1 no nomination, 2 no hi/lo split, 4 no MFMA, 8 no query DMA, 16 no corpus DMA, 32 no barrier,
+//   64 nomination always fast-rejects, 128 nomination never inserts, 256 inserts without the LDS list
 template <int DBG>
 __global__ __launch_bounds__(kSplitThreads) void flat_scan_split_kernel(SplitScanArgs a) {
     constexpr int BM = 128, BN = 128, BK = 32, NST = kSplitStages, SB = kSplitStageBytes;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // smem: NST stages of [A raw fp32 128 x 128 B | Bh 128 x 64 B | Bl 128 x 64 B], then [8 waves][64 queries][16] keys
-    uint64_t* lists = reinterpret_cast<uint64_t*>(smem + NST * SB);
+    // The DMA ring and the nominee lists are SEPARATE LDS objects: with both carved from one array hipcc cannot
+    // prove that a list read does not alias an in-flight LDS-DMA and drains the ring (s_waitcnt vmcnt(0)) at
+    // every tile end — measured +50 % kernel time.
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // NST stages of [A raw fp32 128 x 128 B | Bh 128 x 64 B | Bl 128 x 64 B]
+    __shared__ uint64_t lists[8 * 64 * kSplitKeep];                         // [8 waves][64 queries][16] keys
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave & 3, wq = wave >> 2;  // row group (32 rows), query half (64 queries)
     const int fr = lane & 31, fk = lane >> 5;
@@ -108,6 +112,9 @@ __global__ __launch_bounds__(kSplitThreads) void flat_scan_split_kernel(SplitSca
         floor0[j] = qq < a.nq ? (a.thr0 ? a.thr0[qq] : -INFINITY) : INFINITY;
         thr[j] = floor0[j];
     }
+    // Consume the floor loads HERE: hipcc cannot see the hand-placed vmcnt waits below, so a first use inside the
+    // loop would get its own s_waitcnt vmcnt(0) — which also drains the DMA ring at every tile end (+50 % time).
+    asm volatile("" : "+v"(floor0[0]), "+v"(floor0[1]), "+v"(thr[0]), "+v"(thr[1]));
 
     const int64_t ntiles = a.tile1 - a.tile0;
     const int nk = a.K / BK;
@@ -178,6 +185,7 @@ __global__ __launch_bounds__(kSplitThreads) void flat_scan_split_kernel(SplitSca
     // the matrix cores work on step g - 1.
     sbf16x8 ah[2][2], al[2][2], bh[2][2][2], bl[2][2][2];  // [set][kk] / [set][j][kk]
 
+    unsigned int n_ins = 0, n_slow = 0;
     auto nominate = [&](int64_t m0) {
         if (DBG & 1) {
             if (acc[0][0] + acc[1][3] == 1.2345f) thr[0] = 0.f;
@@ -190,20 +198,29 @@ __global__ __launch_bounds__(kSplitThreads) void flat_scan_split_kernel(SplitSca
             float mx = acc[j][0];
 #pragma unroll
             for (int r = 1; r < 16; ++r) mx = fmaxf(mx, acc[j][r]);
-            if (__ballot(mx >= thr[j]) != 0ull) {
+            if (__ballot(mx >= thr[j]) != 0ull && !(DBG & 64)) {
+                ++n_slow;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int rl = wr * 32 + (r & 3) + 8 * (r >> 2);
                     const float s = acc[j][r];
                     uint64_t mask = __ballot(m0 + rl + 4 * fk <= last && s >= thr[j]);
+                    if (DBG & 128) {
+                        if (mask == 0x123456789ull) thr[j] = 1.f;
+                        mask = 0;
+                    }
                     while (mask) {
                         const int src = __ffsll((long long)mask) - 1;
                         mask &= mask - 1;
+                        ++n_ins;
                         const int sq = j * 32 + (src & 31);
                         const float sv = __uint_as_float(__builtin_amdgcn_readlane((int)__float_as_uint(s), src));
                         const uint32_t rv = (uint32_t)(m0 + rl + 4 * (src >> 5));
-                        const uint64_t kth = lds_list_insert(mylists + (size_t)sq * kSplitKeep, kSplitKeep,
-                                                             make_key(sv, rv), lane);
+                        uint64_t kth;
+                        if (DBG & 256)
+                            kth = make_key(sv * 0.5f, rv);  // ablation: no LDS round trips
+                        else
+                            kth = lds_list_insert(mylists + (size_t)sq * kSplitKeep, kSplitKeep, make_key(sv, rv), lane);
                         if (ql == sq) thr[j] = kth ? fmaxf(key_score(kth), floor0[j]) : floor0[j];  // both lane halves
                     }
                 }
@@ -338,6 +355,10 @@ __global__ __launch_bounds__(kSplitThreads) void flat_scan_split_kernel(SplitSca
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the clamped look-ahead DMAs must land before the LDS is released
 
+    if (a.stats && lane == 0) {
+        atomicAdd(a.stats, n_ins);
+        atomicAdd(a.stats + 1, n_slow);
+    }
     // ---- block merge: query column c has one list in each of the four waves (wr = 0..3) with wq = c / 64 ----------
     __syncthreads();
     for (int c = wave; c < BN; c += 8) {
