@@ -41,14 +41,15 @@ def baseline_metric():
         return "queries/sec + p50 latency, brute-force IP kNN, 10M\u00d7512 fp32, k=10"
 
 
-def pmc_traffic(n, d, nq=1):
+def pmc_traffic(n, d, nq=1, scan_name=None):
     """HBM bytes per scan launch from the committed rocprofv3 PMC passes (profiles/*_pmc_summary.json,
     separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same command, FETCH_SIZE doubled per the
     guide's gfx950 correction).  Counters cannot be collected from inside the timed process, so this
     is the figure of the profiled run of the same workload, or None when no matching profile exists."""
     import glob
     best = None
-    kern = "flat_scan_kernel" if nq == 1 else "flat_scan_mfma"
+    kern = {"ip_scan": "flat_scan_kernel", "ip_scan_mfma": "flat_scan_mfma", "ip_scan_gemm": "flat_scan_gemm",
+            "ip_scan_split": "flat_scan_split"}.get(scan_name, "flat_scan_kernel" if nq == 1 else "flat_scan_mfma")
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")))
     files.sort(key=lambda f: f"nq{nq}_" in os.path.basename(f))  # the pass profiled at this nq wins
     for f in files:
@@ -56,6 +57,9 @@ def pmc_traffic(n, d, nq=1):
             for rec in json.load(open(f)):
                 if kern in rec["kernel"] and rec["launches_fetch_pass"] > 0:
                     t = rec["hbm_traffic_bytes_per_launch_avg"]
+                    if kern == "flat_scan_split":
+                        # seed and main launch share the kernel name: the main launch is the largest one
+                        t = rec["FETCH_SIZE_KiB_max"] * 2048.0 + rec["WRITE_SIZE_KiB_max"] * 1024.0
                     if abs(t / (n * d * 4.0) - 1.0) < 0.25:  # same workload size
                         best = {"bytes": int(t), "source": os.path.basename(f)}
         except Exception:
@@ -210,6 +214,12 @@ def main():
     out = None
     if rank == 0:
         bytes_per_launch = n * d * 4  # algorithmic: every stored row of this rank's shard once
+        if scan_name == "ip_scan_split":
+            # the seed launch (first 128-row tile of every CU, timed separately as ip_scan_split_seed) takes
+            # its rows out of the main launch when the corpus has >= 8 tiles per CU
+            cus = torch.cuda.get_device_properties(dev).multi_processor_count
+            if (n + 127) // 128 >= 8 * cus:
+                bytes_per_launch = (n - cus * 128) * d * 4
         avg_ms = scan_ms / max(launches, 1)
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if launches else 0.0
         out = {
@@ -250,8 +260,8 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": (pmc_traffic(n, d, nq) or {}).get("bytes"),
-                "traffic_source": (pmc_traffic(n, d, nq) or {}).get("source"),
+                "traffic": (pmc_traffic(n, d, nq, scan_name) or {}).get("bytes"),
+                "traffic_source": (pmc_traffic(n, d, nq, scan_name) or {}).get("source"),
                 "kernel": {"ip_scan": "flat_scan_kernel", "ip_scan_mfma": "flat_scan_mfma2_kernel",
                            "ip_scan_split": "flat_scan_split_kernel"}[scan_name],
                 "launches": launches,

@@ -541,26 +541,17 @@ int launch_split_scan(const mvdb_index* idx, Workspace* ws, const float* q, int 
     a.nq = nq;
     void (*kern)(SplitScanArgs) = flat_scan_split_kernel<0>;
     switch (env_int("MVDB_SPLIT_DBG", 0)) {  // timing ablations (invalid results), benchmarks/split_probe.py
-        case 1: kern = flat_scan_split_kernel<1>; break;
         case 2: kern = flat_scan_split_kernel<2>; break;
         case 4: kern = flat_scan_split_kernel<4>; break;
         case 6: kern = flat_scan_split_kernel<6>; break;
         case 16: kern = flat_scan_split_kernel<16>; break;
         case 24: kern = flat_scan_split_kernel<24>; break;
         case 32: kern = flat_scan_split_kernel<32>; break;
-        case 3: kern = flat_scan_split_kernel<3>; break;
-        case 5: kern = flat_scan_split_kernel<5>; break;
-        case 7: kern = flat_scan_split_kernel<7>; break;
-        case 9: kern = flat_scan_split_kernel<9>; break;
-        case 17: kern = flat_scan_split_kernel<17>; break;
-        case 25: kern = flat_scan_split_kernel<25>; break;
-        case 33: kern = flat_scan_split_kernel<33>; break;
-        case 64: kern = flat_scan_split_kernel<64>; break;
-        case 128: kern = flat_scan_split_kernel<128>; break;
-        case 256: kern = flat_scan_split_kernel<256>; break;
         default: break;
     }
+    void (*seed_kern)(SplitScanArgs) = flat_scan_split_kernel<0, true>;
     MVDB_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSplitLds));
+    MVDB_HIP(hipFuncSetAttribute((const void*)seed_kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSplitLds));
     const int64_t ntiles = (n + 127) / 128;
     const int cus = device_cus(idx->device);
     // Large corpora: a seed launch over the first tile of every block learns each query's admission floor (the
@@ -579,7 +570,7 @@ int launch_split_scan(const mvdb_index* idx, Workspace* ws, const float* q, int 
     if (seeded) {
         a.tile1 = seed_tiles;
         int slot = prof_begin("ip_scan_split_seed", stream);
-        hipLaunchKernelGGL(kern, dim3(cus, 1), dim3(kSplitThreads), kSplitLds, stream, a);
+        hipLaunchKernelGGL(seed_kern, dim3(cus, 1), dim3(kSplitThreads), kSplitLds, stream, a);
         hipLaunchKernelGGL(split_seed_kernel, dim3(nq), dim3(1024), 0, stream, cand, cus, seed_keys, ws->qnorm.p + 128);
         prof_end(slot, stream);
         MVDB_HIP(hipGetLastError());
