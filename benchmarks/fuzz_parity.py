@@ -1,5 +1,7 @@
 """Randomised GPU parity fuzz: random (n, d, nq, k, metric, subset, normalisation) cases through the C-ABI,
-each query adjudicated against the float64 oracle.  usage: fuzz_parity.py SEED SECONDS (on a GPU box)."""
+each query adjudicated against the float64 oracle.  usage: fuzz_parity.py SEED SECONDS [split] (on a GPU box);
+`split` biases the cases towards the split-precision batch pass (nq >= 40, k <= 12, d % 32 == 0, up to 400k rows so
+that the seed launch runs too) and reports how many chunks fell back to the exact kernels."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -8,14 +10,22 @@ from minivectordb_amd import _native as native
 rs = np.random.RandomState(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 dims = [1,2,3,4,5,7,8,16,31,32,33,48,64,96,100,128,160,192,224,256,300,384,512,640,768,1000,1024,1100,2048,4096]
 t_end = time.time() + float(sys.argv[2]) if len(sys.argv) > 2 else time.time() + 120
+split_mode = len(sys.argv) > 3 and sys.argv[3] == "split"
 cases = fails = 0
+reruns0 = native.split_rerun_count()
 while time.time() < t_end:
     d = int(rs.choice(dims))
     n = int(rs.choice([1,2,15,16,17,63,64,65,255,256,257,1000,4097, rs.randint(1, 5000)]))
-    if n * d > 30_000_000: n = 30_000_000 // d
     nq = int(rs.choice([1,1,1,2,3,5,15,16,17,31,32,33,40,104,128,150,260]))
     k = int(rs.choice([1,2,5,10,63,64,65,100,300, rs.randint(1, 200)]))
     metric = int(rs.choice([0,0,0,1]))
+    if split_mode:
+        d = int(rs.choice([32, 64, 96, 128, 256, 384, 512, 768, 1024]))
+        n = int(rs.choice([15, 16, 17, 127, 128, 129, 1000, rs.randint(1, 20000), rs.randint(262144, 400000)]))
+        nq = int(rs.choice([40, 41, 64, 127, 128, 129, 200, 256, rs.randint(40, 300)]))
+        k = int(rs.randint(1, 13))
+        metric = 0
+    if n * d > 30_000_000: n = 30_000_000 // d
     x = flat.synth(n, d, rs.randint(1<<30)); 
     if rs.rand() < 0.7: flat.normalize_l2(x)
     if rs.rand() < 0.2 and n > 4: x[rs.randint(n)] = x[rs.randint(n)]   # duplicate row -> exact tie
@@ -41,4 +51,4 @@ while time.time() < t_end:
         fails += 1
         print("FAIL", dict(n=n, d=d, nq=nq, k=k, metric=metric, normq=normq, subset=None if subset is None else len(subset)), bad, flush=True)
     idx.close()
-print("cases", cases, "fails", fails)
+print("cases", cases, "fails", fails, "split chunks re-run on the exact kernels", native.split_rerun_count() - reruns0)
