@@ -511,13 +511,13 @@ int launch_gemm_scan(const mvdb_index* idx, const float* q, int nq, int k, int64
     return 0;
 }
 
-// nq >= 40, k <= 12, rows of known norm: split-precision bf16 pass + exact certification (scan_split_kernels.hpp)
+// nq >= 33, k <= 12, rows of known norm: split-precision bf16 pass + exact certification (scan_split_kernels.hpp)
 constexpr float kSplitEps = 1.0e-4f;  // >= 3 * 2^-16 operand bound (4.6e-5) + fp32 accumulation allowance
 std::atomic<long> g_split_reruns{0};
 
 bool split_path_ok(const mvdb_index* idx, int nq, int k, const int64_t* rows_dev) {
     if (env_int("MVDB_DISABLE_SPLIT_SCAN", 0)) return false;
-    if (nq < env_int("MVDB_SPLIT_SCAN_MIN_NQ", 40) || k > kSplitMaxK || rows_dev || idx->metric != MVDB_METRIC_IP)
+    if (nq < env_int("MVDB_SPLIT_SCAN_MIN_NQ", 33) || k > kSplitMaxK || rows_dev || idx->metric != MVDB_METRIC_IP)
         return false;
     if (!(idx->row_norm_bound > 0.f) || std::isinf(idx->row_norm_bound)) return false;
     return idx->d % 32 == 0 && idx->ld == idx->d;
@@ -643,7 +643,7 @@ int search_core(const mvdb_index* idx, Workspace* ws, const float* q_dev, int nq
     a.cand = nullptr;
     a.scores = nullptr;
 
-    // Batches of >= 40 queries, k <= 12, rows of known norm: split-precision pass on the bf16 matrix cores
+    // Batches of >= 33 queries (past one 32-query fp32 pass), k <= 12, rows of known norm: split-precision pass on the bf16 matrix cores
     // (scan_split_kernels.hpp), 128 queries per corpus pass, every result certified against exact fp32
     // re-scores; chunks holding an uncertified query are re-run on the exact paths below.
     if (allow_split && split_path_ok(idx, nq, k, rows_dev)) {
@@ -655,7 +655,7 @@ int search_core(const mvdb_index* idx, Workspace* ws, const float* q_dev, int nq
             MVDB_TRY(normalize_range(idx, ws->qn.p, nq, s));
             qsrc = ws->qn.p;
         }
-        const int min_nq = env_int("MVDB_SPLIT_SCAN_MIN_NQ", 40);
+        const int min_nq = env_int("MVDB_SPLIT_SCAN_MIN_NQ", 33);
         const int nchunks = (nq + 127) / 128;
         MVDB_TRY(ws->qsplit.reserve((size_t)2 * 128 * idx->d));
         MVDB_TRY(ws->qnorm.reserve(256));  // [0,128): |q|, [128,256): admission floors of the seed pass

@@ -348,14 +348,47 @@ __global__ __launch_bounds__(kSplitThreads) void flat_scan_split_kernel(SplitSca
             }
         }
     }
+    // Seed launch with ONE tile per block (the normal case): no thresholds to learn and nothing to merge into, so
+    // instead of ~1,700 serial list inserts per wave the 32 scores every wave holds per query are dumped to LDS
+    // (the idle ring + the list array) and the block merge below picks each query's 16 best of 4 x 32.
+    const bool dump = SEED && my_tiles == 1;
     if (total > 0) {  // the last step's products
         if ((total - 1) & 1)
             mfma_step(1);
         else
             mfma_step(0);
-        nominate(cs_tile * BM);
+        if (!dump) nominate(cs_tile * BM);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the clamped look-ahead DMAs must land before the LDS is released
+    if (dump) {
+        auto scratch = [&](int w) {  // [64 queries][32 keys] of wave w
+            return w < 6 ? reinterpret_cast<uint64_t*>(smem) + (size_t)w * 2048 : lists + (size_t)(w - 6) * 2048;
+        };
+        __syncthreads();  // every wave is done with the ring and the lists
+        uint64_t* mine = scratch(wave);
+        const int64_t m0 = cs_tile * BM;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t row = m0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
+                mine[(j * 32 + fr) * 32 + fk * 16 + r] = row <= last ? make_key(acc[j][r], (uint32_t)row) : 0ull;
+            }
+        __syncthreads();
+        for (int c = wave; c < BN; c += 8) {
+            const int qq = n0 + c;
+            if (qq >= a.nq) continue;
+            WaveTopK tk;
+            tk.init(kSplitKeep);
+#pragma unroll 1
+            for (int m = 0; m < 4; ++m) {
+                const uint64_t* l = scratch((c / 64) * 4 + m) + (c % 64) * 32;
+                tk.offer(lane < 32 ? l[lane] : 0ull);
+            }
+            if (lane < kSplitKeep) a.cand[((int64_t)qq * gridDim.x + blockIdx.x) * kSplitKeep + lane] = tk.key;
+        }
+        return;
+    }
 
     if (a.stats && lane == 0) {
         atomicAdd(a.stats, n_ins);

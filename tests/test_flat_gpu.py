@@ -510,7 +510,7 @@ def _split_launches(native):
     (300000, 64, 10, 64), (270001, 128, 5, 130),  # >= 8 tiles per CU: seed launch + admission floors
 ])
 def test_split_precision_batch_pass_matches_oracle(native, monkeypatch, n, d, k, nq):
-    """nq >= 40 (24 here), k <= 12: the bf16 split-precision pass nominates 16 rows per query, exact fp32 re-scores
+    """nq >= 33 (24 here), k <= 12: the bf16 split-precision pass nominates 16 rows per query, exact fp32 re-scores
     decide and certify (scan_split_kernels.hpp).  Results must equal the oracle's and every query's own single-query
     search."""
     monkeypatch.setenv("MVDB_SPLIT_SCAN_MIN_NQ", "24")  # read per call: also cover sparsely filled query tiles
