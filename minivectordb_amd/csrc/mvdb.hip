@@ -308,6 +308,21 @@ int launch_scan_gcu(int metric, int mode, const ScanArgs& a, int nq, int device,
 // Grid size the scan will use for (shape, n): needed up front to size the candidate buffer.
 int scan_grid_upper_bound(int device) { return device_cus(device) * 8; }
 
+// Raises a kernel's dynamic-LDS limit once per (kernel, device): the attribute is per device, and one process may
+// hold indexes on several GPUs.
+int ensure_dynamic_lds(const void* kern, size_t lds, int device) {
+    if (lds <= 48 * 1024) return 0;
+    static std::mutex mu;
+    static std::map<std::pair<const void*, int>, size_t> done;
+    std::lock_guard<std::mutex> lk(mu);
+    size_t& have = done[{kern, device}];
+    if (lds > have) {
+        MVDB_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        have = lds;
+    }
+    return 0;
+}
+
 int launch_scan(int metric, int mode, const ScanArgs& a, int nq, int device, hipStream_t s,
                 int* nblocks) {
     const Shape sh = choose_shape(a.d4);
@@ -388,11 +403,7 @@ template <int KB, int NG>
 int launch_mfma_inst(const MfmaScanArgs& a, int device, hipStream_t stream, int* nblocks_out) {
     auto kern = flat_scan_mfma_kernel<KB, NG>;
     const size_t lds = (size_t)NG * KB * 4 * 64 * 4 + (size_t)kScanWaves * NG * 16 * a.k * 8;
-    static size_t lds_set = 0;
-    if (lds > 48 * 1024 && lds > lds_set) {
-        MVDB_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        lds_set = lds;
-    }
+    MVDB_TRY(ensure_dynamic_lds((const void*)kern, lds, device));
     int nb = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, kScanThreads, lds) != hipSuccess || nb <= 0)
         nb = 1;
@@ -412,11 +423,7 @@ template <int KB, int NG, int SKB>
 int launch_mfma2_inst(const MfmaScanArgs& a, int device, hipStream_t stream, int* nblocks_out) {
     auto kern = flat_scan_mfma2_kernel<KB, NG, SKB>;
     const size_t lds = (size_t)kScanWaves * mfma2_wave_lds_bytes(SKB) + (size_t)kScanWaves * NG * 16 * a.k * 8;
-    static size_t lds_set = 0;
-    if (lds > 48 * 1024 && lds > lds_set) {
-        MVDB_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        lds_set = lds;
-    }
+    MVDB_TRY(ensure_dynamic_lds((const void*)kern, lds, device));
     int nb = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, kScanThreads, lds) != hipSuccess || nb <= 0)
         nb = 1;
@@ -490,12 +497,7 @@ int launch_gemm_scan(const mvdb_index* idx, const float* q, int nq, int k, int64
     a.k = k;
     a.cand = cand;
     const size_t lds = (size_t)2 * 2 * 16 * 132 * 4 + (size_t)4 * 64 * k * 8;
-    static size_t lds_set = 0;
-    if (lds > 48 * 1024 && lds > lds_set) {
-        MVDB_HIP(hipFuncSetAttribute((const void*)flat_scan_gemm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)lds));
-        lds_set = lds;
-    }
+    MVDB_TRY(ensure_dynamic_lds((const void*)flat_scan_gemm_kernel, lds, idx->device));
     int nb = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, flat_scan_gemm_kernel, 256, lds) != hipSuccess || nb <= 0)
         nb = 1;
@@ -550,8 +552,8 @@ int launch_split_scan(const mvdb_index* idx, Workspace* ws, const float* q, int 
         default: break;
     }
     void (*seed_kern)(SplitScanArgs) = flat_scan_split_kernel<0, true>;
-    MVDB_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSplitLds));
-    MVDB_HIP(hipFuncSetAttribute((const void*)seed_kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSplitLds));
+    MVDB_TRY(ensure_dynamic_lds((const void*)kern, kSplitLds, idx->device));
+    MVDB_TRY(ensure_dynamic_lds((const void*)seed_kern, kSplitLds, idx->device));
     const int64_t ntiles = (n + 127) / 128;
     const int cus = device_cus(idx->device);
     // Large corpora: a seed launch over the first tile of every block learns each query's admission floor (the

@@ -101,7 +101,8 @@ __global__ __launch_bounds__(kSplitThreads) void flat_scan_split_kernel(SplitSca
     // every tile end — measured +50 % kernel time.
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // NST stages of [A raw fp32 128 x 128 B | Bh 128 x 64 B | Bl 128 x 64 B]
     __shared__ uint64_t lists[8 * 64 * kSplitKeep];                         // [8 waves][64 queries][16] keys
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // SGPR: LDS-DMA bases (M0) stay scalar
     const int wr = wave & 3, wq = wave >> 2;  // row group (32 rows), query half (64 queries)
     const int fr = lane & 31, fk = lane >> 5;
     const int n0 = blockIdx.y * BN;
