@@ -49,7 +49,7 @@ def pmc_traffic(n, d, nq=1, scan_name=None):
     import glob
     best = None
     kern = {"ip_scan": "flat_scan_kernel", "ip_scan_mfma": "flat_scan_mfma", "ip_scan_gemm": "flat_scan_gemm",
-            "ip_scan_split": "flat_scan_split"}.get(scan_name, "flat_scan_kernel" if nq == 1 else "flat_scan_mfma")
+            "ip_scan_split": "flat_scan_split_kernel", "ip_scan_split32": "flat_scan_split32"}.get(scan_name, "flat_scan_kernel" if nq == 1 else "flat_scan_mfma")
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")))
     files.sort(key=lambda f: f"nq{nq}_" in os.path.basename(f))  # the pass profiled at this nq wins
     for f in files:
@@ -57,7 +57,7 @@ def pmc_traffic(n, d, nq=1, scan_name=None):
             for rec in json.load(open(f)):
                 if kern in rec["kernel"] and rec["launches_fetch_pass"] > 0:
                     t = rec["hbm_traffic_bytes_per_launch_avg"]
-                    if kern == "flat_scan_split":
+                    if kern == "flat_scan_split_kernel":
                         # seed and main launch share the kernel name: the main launch is the largest one
                         t = rec["FETCH_SIZE_KiB_max"] * 2048.0 + rec["WRITE_SIZE_KiB_max"] * 1024.0
                     if abs(t / (n * d * 4.0) - 1.0) < 0.25:  # same workload size
@@ -157,7 +157,7 @@ def main():
     n, d, k, nq = args.rows, args.dim, args.k, args.nq
     W, K = args.warmup, args.steps
     # dominant kernel by batch size: GEMV scan (nq = 1), 16/32-query MFMA pass, 128-query GEMM-tiled scan
-    scan_names = ("ip_scan", "ip_scan_mfma", "ip_scan_gemm", "ip_scan_split")
+    scan_names = ("ip_scan", "ip_scan_mfma", "ip_scan_gemm", "ip_scan_split", "ip_scan_split32")
     idx = native.FlatIndex(d, device=local_rank)
     idx.reserve(n)
     idx.add_synthetic(n, 1234, first_row=rank * n, normalize=True)
@@ -190,8 +190,8 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     native.prof_enable(False)
-    # dominant kernel by batch size: GEMV scan (nq = 1), 16/32-query fp32-MFMA pass, 128-query split-precision
-    # bf16 pass (k <= 12) or exact fp32 GEMM-tiled scan — whichever took the most time in the timed region
+    # dominant kernel by batch size: GEMV scan (nq = 1), 16-query fp32-MFMA pass, 32- / 128-query split-precision
+    # bf16 passes (k <= 12) or their exact fp32 fallbacks — whichever took the most time in the timed region
     prof = {name: native.prof_read(name) for name in scan_names}
     scan_name = max(prof, key=lambda name: prof[name][1])
     launches, scan_ms = prof[scan_name]
@@ -214,7 +214,7 @@ def main():
     out = None
     if rank == 0:
         bytes_per_launch = n * d * 4  # algorithmic: every stored row of this rank's shard once
-        if scan_name == "ip_scan_split":
+        if scan_name in ("ip_scan_split", "ip_scan_split32"):
             # the seed launch (first 128-row tile of every CU, timed separately as ip_scan_split_seed) takes
             # its rows out of the main launch when the corpus has >= 8 tiles per CU
             cus = torch.cuda.get_device_properties(dev).multi_processor_count
@@ -263,7 +263,8 @@ def main():
                 "traffic": (pmc_traffic(n, d, nq, scan_name) or {}).get("bytes"),
                 "traffic_source": (pmc_traffic(n, d, nq, scan_name) or {}).get("source"),
                 "kernel": {"ip_scan": "flat_scan_kernel", "ip_scan_mfma": "flat_scan_mfma2_kernel",
-                           "ip_scan_split": "flat_scan_split_kernel"}[scan_name],
+                           "ip_scan_split": "flat_scan_split_kernel",
+                           "ip_scan_split32": "flat_scan_split32_kernel"}[scan_name],
                 "launches": launches,
                 "avg_launch_ms": round(avg_ms, 4),
                 "algorithmic_bytes_per_launch": bytes_per_launch,

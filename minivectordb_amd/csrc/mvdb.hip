@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <atomic>
 #include <map>
+#include <vector>
 #include <shared_mutex>
 
 #include "common.hpp"
@@ -519,10 +520,45 @@ std::atomic<long> g_split_reruns{0};
 
 bool split_path_ok(const mvdb_index* idx, int nq, int k, const int64_t* rows_dev) {
     if (env_int("MVDB_DISABLE_SPLIT_SCAN", 0)) return false;
-    if (nq < env_int("MVDB_SPLIT_SCAN_MIN_NQ", 33) || k > kSplitMaxK || rows_dev || idx->metric != MVDB_METRIC_IP)
-        return false;
+    if (nq < 17 || k > kSplitMaxK || rows_dev || idx->metric != MVDB_METRIC_IP) return false;
     if (!(idx->row_norm_bound > 0.f) || std::isinf(idx->row_norm_bound)) return false;
     return idx->d % 32 == 0 && idx->ld == idx->d;
+}
+
+bool split32_ok(const mvdb_index* idx) {
+    if (env_int("MVDB_DISABLE_SPLIT32", 0)) return false;
+    const int KB = idx->d / 16;
+    return idx->d % 64 == 0 && (KB == 4 || KB == 8 || KB == 16 || KB == 24 || KB == 32);
+}
+
+template <int KB>
+int launch_split32_inst(const Split32Args& b, int device, hipStream_t stream, int* nblocks_out) {
+    auto kern = flat_scan_split32_kernel<KB>;
+    const size_t lds = (size_t)kScanWaves * 2 * 8192;
+    MVDB_TRY(ensure_dynamic_lds((const void*)kern, lds, device));
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, kScanThreads, lds) != hipSuccess || nb <= 0) nb = 1;
+    nb = std::min(nb, std::max(1, env_int("MVDB_SPLIT32_BLOCKS_PER_CU", 2)));
+    const int64_t ntiles = b.tile1 - b.tile0;
+    const int64_t want = (ntiles + kScanWaves - 1) / kScanWaves;
+    const int nblocks = (int)std::max<int64_t>(1, std::min<int64_t>(want, (int64_t)device_cus(device) * nb));
+    *nblocks_out = nblocks;
+    int slot = prof_begin("ip_scan_split32", stream);
+    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(kScanThreads), lds, stream, b);
+    prof_end(slot, stream);
+    MVDB_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_split32(int KB, const Split32Args& b, int device, hipStream_t s, int* nb) {
+    switch (KB) {
+        case 4: return launch_split32_inst<4>(b, device, s, nb);
+        case 8: return launch_split32_inst<8>(b, device, s, nb);
+        case 16: return launch_split32_inst<16>(b, device, s, nb);
+        case 24: return launch_split32_inst<24>(b, device, s, nb);
+        case 32: return launch_split32_inst<32>(b, device, s, nb);
+        default: return fail(MVDB_ERR_ARG, "no 32-query split kernel for d = %d", KB * 16);
+    }
 }
 
 int launch_split_scan(const mvdb_index* idx, Workspace* ws, const float* q, int nq, int k, int64_t n,
@@ -581,10 +617,27 @@ int launch_split_scan(const mvdb_index* idx, Workspace* ws, const float* q, int 
         a.thr0 = ws->qnorm.p + 128;
         seed_arg = seed_keys;
     }
-    const int gx = (int)std::max<int64_t>(1, std::min<int64_t>(a.tile1 - a.tile0, (int64_t)cus));
-    int slot = prof_begin("ip_scan_split", stream);
-    hipLaunchKernelGGL(kern, dim3(gx, 1), dim3(kSplitThreads), kSplitLds, stream, a);
-    prof_end(slot, stream);
+    int gx;
+    if (nq <= 32 && split32_ok(idx)) {
+        // 17..32 queries: per-wave rings, query fragments in registers (flat_scan_split32_kernel), 32-row tiles
+        Split32Args b;
+        b.X = idx->X;
+        b.n = n;
+        b.ld = idx->ld;
+        b.qh = qh;
+        b.ql = ql;
+        b.nq = nq;
+        b.cand = cand;
+        b.tile0 = a.tile0 * 4;
+        b.tile1 = (n + 31) / 32;
+        b.thr0 = a.thr0;
+        MVDB_TRY(launch_split32(idx->d / 16, b, idx->device, stream, &gx));
+    } else {
+        gx = (int)std::max<int64_t>(1, std::min<int64_t>(a.tile1 - a.tile0, (int64_t)cus));
+        int slot = prof_begin("ip_scan_split", stream);
+        hipLaunchKernelGGL(kern, dim3(gx, 1), dim3(kSplitThreads), kSplitLds, stream, a);
+        prof_end(slot, stream);
+    }
     MVDB_HIP(hipGetLastError());
     SplitCertifyArgs c;
     c.keys = cand;
@@ -657,31 +710,41 @@ int search_core(const mvdb_index* idx, Workspace* ws, const float* q_dev, int nq
             MVDB_TRY(normalize_range(idx, ws->qn.p, nq, s));
             qsrc = ws->qn.p;
         }
+        // chunk plan: 128 queries per pass while >= 33 remain, then one 17..32-query pass where that kernel exists
         const int min_nq = env_int("MVDB_SPLIT_SCAN_MIN_NQ", 33);
-        const int nchunks = (nq + 127) / 128;
-        MVDB_TRY(ws->qsplit.reserve((size_t)2 * 128 * idx->d));
-        MVDB_TRY(ws->qnorm.reserve(256));  // [0,128): |q|, [128,256): admission floors of the seed pass
-        MVDB_TRY(ws->flags.reserve((size_t)std::max(nchunks, 64) + 4));  // + diagnostics counters at [64]
-        MVDB_TRY(ws->pin_flags.reserve((size_t)nchunks * sizeof(int)));
-        MVDB_TRY(ws->cand.reserve((size_t)128 * (scan_grid_upper_bound(idx->device) + 1) * kSplitKeep));
-        MVDB_HIP(hipMemsetAsync(ws->flags.p, 0, (size_t)nchunks * sizeof(int), s));
-        int q0 = 0, done_chunks = 0;
+        std::vector<std::pair<int, int>> plan;  // (first query, count)
+        int q0 = 0;
         while (nq - q0 >= min_nq) {
-            const int take = std::min(nq - q0, 128);
-            MVDB_TRY(launch_split_scan(idx, ws, qsrc + (int64_t)q0 * idx->ld, take, k, n, label_offset,
-                                       D_dev + (int64_t)q0 * k, I_dev + (int64_t)q0 * k, ws->flags.p + done_chunks));
-            q0 += take;
-            ++done_chunks;
+            plan.emplace_back(q0, std::min(nq - q0, 128));
+            q0 += plan.back().second;
         }
-        int* hflags = static_cast<int*>(ws->pin_flags.p);
-        MVDB_HIP(hipMemcpyAsync(hflags, ws->flags.p, (size_t)done_chunks * sizeof(int), hipMemcpyDeviceToHost, s));
-        MVDB_HIP(hipStreamSynchronize(s));
-        for (int c = 0; c < done_chunks; ++c) {
-            if (!hflags[c]) continue;
-            const int c0 = c * 128, take = std::min(q0 - c0, 128);
-            g_split_reruns.fetch_add(1, std::memory_order_relaxed);
-            MVDB_TRY(search_core(idx, ws, qsrc + (int64_t)c0 * idx->ld, take, k, 0, rows_dev, m, label_offset,
-                                 D_dev + (int64_t)c0 * k, I_dev + (int64_t)c0 * k, false));
+        if (nq - q0 >= 17 && nq - q0 <= 32 && split32_ok(idx)) {
+            plan.emplace_back(q0, nq - q0);
+            q0 = nq;
+        }
+        const int nchunks = (int)plan.size();
+        if (nchunks > 0) {
+            MVDB_TRY(ws->qsplit.reserve((size_t)2 * 128 * idx->d));
+            MVDB_TRY(ws->qnorm.reserve(256));  // [0,128): |q|, [128,256): admission floors of the seed pass
+            MVDB_TRY(ws->flags.reserve((size_t)std::max(nchunks, 64) + 4));  // + diagnostics counters at [64]
+            MVDB_TRY(ws->pin_flags.reserve((size_t)nchunks * sizeof(int)));
+            MVDB_TRY(ws->cand.reserve((size_t)128 * (scan_grid_upper_bound(idx->device) + 1) * kSplitKeep));
+            MVDB_HIP(hipMemsetAsync(ws->flags.p, 0, (size_t)nchunks * sizeof(int), s));
+            for (int c = 0; c < nchunks; ++c) {
+                const int c0 = plan[c].first, take = plan[c].second;
+                MVDB_TRY(launch_split_scan(idx, ws, qsrc + (int64_t)c0 * idx->ld, take, k, n, label_offset,
+                                           D_dev + (int64_t)c0 * k, I_dev + (int64_t)c0 * k, ws->flags.p + c));
+            }
+            int* hflags = static_cast<int*>(ws->pin_flags.p);
+            MVDB_HIP(hipMemcpyAsync(hflags, ws->flags.p, (size_t)nchunks * sizeof(int), hipMemcpyDeviceToHost, s));
+            MVDB_HIP(hipStreamSynchronize(s));
+            for (int c = 0; c < nchunks; ++c) {
+                if (!hflags[c]) continue;
+                const int c0 = plan[c].first, take = plan[c].second;
+                g_split_reruns.fetch_add(1, std::memory_order_relaxed);
+                MVDB_TRY(search_core(idx, ws, qsrc + (int64_t)c0 * idx->ld, take, k, 0, rows_dev, m, label_offset,
+                                     D_dev + (int64_t)c0 * k, I_dev + (int64_t)c0 * k, false));
+            }
         }
         if (q0 == nq) return 0;
         return search_core(idx, ws, qsrc + (int64_t)q0 * idx->ld, nq - q0, k, 0, rows_dev, m, label_offset,

@@ -411,6 +411,167 @@ __global__ __launch_bounds__(kSplitThreads) void flat_scan_split_kernel(SplitSca
     }
 }
 
+// ---- 17..32 queries per pass: per-wave rings, query fragments in registers --------------------------------------
+// The fp32 32-query pass (flat_scan_mfma2_kernel<KB, 2>) is MFMA-issue-bound at one wave per SIMD (4.0 ms at
+// 10M x 512 against a 2.9 ms HBM floor).  Same nominate-and-certify scheme as above on the bf16 cores, in that
+// kernel's shape: every wave owns 32-row tiles and streams them through a private two-stage LDS-DMA ring (no block
+// barriers), its 32 queries' (hi, lo) bf16 fragments for the whole K live in registers (8 VGPRs per 16-k block),
+// D[row][query] keeps the query on the lane.  Stage = 32 rows x 64 floats (8 KiB, eight 1-KiB DMA instructions of
+// 4 rows x 256 B); 16-byte slot p of row r receives the row's logical slot p ^ (r & 15) so that the fragment reads
+// (row on the lane, 32-byte k-slices) are conflict-free.
+struct Split32Args {
+    const float* X;
+    int64_t n;
+    int64_t ld;
+    const __bf16* qh;   // K-step-major image of split_queries_kernel: [K / 32][128][32]
+    const __bf16* ql;
+    int nq;             // <= 32
+    uint64_t* cand;     // [nq, gridDim.x, kSplitKeep]
+    int64_t tile0;      // 32-row tiles [tile0, tile1)
+    int64_t tile1;
+    const float* thr0;  // admission floors of the seed launch, or NULL
+};
+
+template <int KB>  // K / 16
+__global__ __launch_bounds__(kScanThreads) void flat_scan_split32_kernel(Split32Args a) {
+    static_assert(KB % 4 == 0, "d must be a multiple of 64");
+    constexpr int NS = KB / 4, kStageBytes = 8192, kWaveLds = 2 * kStageBytes;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [4 waves][2 stages][8 KiB]
+    __shared__ uint64_t lists[kScanWaves * 32 * kSplitKeep];               // [4 waves][32 queries][16] keys
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int fr = lane & 31, fk = lane >> 5;
+    unsigned char* wbuf = smem + (size_t)wave * kWaveLds;
+    uint64_t* mylists = lists + (size_t)wave * 32 * kSplitKeep;
+    for (int e = lane; e < 32 * kSplitKeep; e += 64) mylists[e] = 0ull;
+
+    // ---- query fragments: B[k = 16 kb + 8 fk + j][query fr], (hi, lo) ------------------------------------------------
+    sbf16x8 qh[KB], ql[KB];
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+        const int64_t o = ((int64_t)(kb >> 1) * 128 + fr) * 32 + (kb & 1) * 16 + fk * 8;
+        qh[kb] = *reinterpret_cast<const sbf16x8*>(a.qh + o);
+        ql[kb] = *reinterpret_cast<const sbf16x8*>(a.ql + o);
+    }
+    float floor0 = fr < a.nq ? (a.thr0 ? a.thr0[fr] : -INFINITY) : INFINITY;
+    float thr = floor0;
+    // consume every load here: the hand-placed vmcnt waits below are invisible to hipcc (see the kernel above)
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) asm volatile("" : "+v"(qh[kb]), "+v"(ql[kb]));
+    asm volatile("" : "+v"(floor0), "+v"(thr));
+
+    const int64_t ntiles = a.tile1 - a.tile0;
+    const int64_t nwaves_total = (int64_t)gridDim.x * kScanWaves;
+    const int64_t last = a.n - 1;
+    // DMA roles: instruction i (0..7) of a stage moves rows 4i .. 4i+3; lane -> row 4i + (lane >> 4), slot lane & 15
+    const int dma_r = lane >> 4, dma_p = lane & 15;
+    auto issue_stage = [&](int64_t tile, int ks, int buf) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int r = 4 * i + dma_r;
+            int64_t row = (a.tile0 + tile) * 32 + r;
+            row = row <= last ? row : last;
+            const float* src = a.X + row * a.ld + ks * 64 + 4 * (dma_p ^ (r & 15));
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(wbuf + buf * kStageBytes + i * 1024), 16, 0, 2 /* nt */);
+        }
+    };
+    // fragment read: row fr, 16-k block b of the stage (k = 16 b + 8 fk .. + 7) -> logical slots 4 b + 2 fk (+1)
+    int f_off[4][2];
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) f_off[b][h] = fr * 256 + (((4 * b + 2 * fk + h) ^ (fr & 15)) << 4);
+
+    int64_t tile = (int64_t)blockIdx.x * kScanWaves + wave;
+    unsigned cnt = 0;
+    auto stage_tile = [&](int64_t t, int ks_abs) { return t + (int64_t)(ks_abs / NS) * nwaves_total; };
+    if (tile < ntiles) {
+        issue_stage(tile, 0, 0);
+        const int64_t t1 = stage_tile(tile, 1);
+        if (t1 < ntiles) issue_stage(t1, 1 % NS, 1);
+    }
+    while (tile < ntiles) {
+        f32x16m acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < NS; ++ks) {
+            const int buf = cnt & 1;
+            const int64_t t1 = stage_tile(tile, ks + 1), t2 = stage_tile(tile, ks + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            if (t1 < ntiles)
+                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // this stage landed, the next one stays in flight
+            else
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned char* sb = wbuf + buf * kStageBytes;
+            f32x4m xa[4][2];
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) xa[b][h] = *reinterpret_cast<const f32x4m*>(sb + f_off[b][h]);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            if (t2 < ntiles) issue_stage(t2, (ks + 2) % NS, buf);  // refill the buffer just drained
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int kb = ks * 4 + b;
+                union { sbf16x8 v; uint32_t w[4]; } ahu, alu;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float x0 = xa[b][e >> 1][(e & 1) * 2], x1 = xa[b][e >> 1][(e & 1) * 2 + 1];
+                    const uint32_t hp = pack_bf16x2(x0, x1);
+                    ahu.w[e] = hp;
+                    alu.w[e] = pack_bf16x2(x0 - __uint_as_float(hp << 16), x1 - __uint_as_float(hp & 0xFFFF0000u));
+                }
+                // small cross terms first, the leading product last (the order of the 128-query kernel)
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alu.v, qh[kb], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahu.v, ql[kb], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahu.v, qh[kb], acc, 0, 0, 0);
+            }
+            ++cnt;
+        }
+        // ---- nomination: D[row][query], query on the lane (fr), rows in the 16 registers --------------------------
+        {
+            const int64_t m0 = (a.tile0 + tile) * 32;
+            float mx = acc[0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, acc[r]);
+            if (__ballot(mx >= thr) != 0ull) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int rl = (r & 3) + 8 * (r >> 2);
+                    const float s = acc[r];
+                    uint64_t mask = __ballot(m0 + rl + 4 * fk <= last && s >= thr);
+                    while (mask) {
+                        const int src = __ffsll((long long)mask) - 1;
+                        mask &= mask - 1;
+                        const int sq = src & 31;
+                        const float sv = __uint_as_float(__builtin_amdgcn_readlane((int)__float_as_uint(s), src));
+                        const uint32_t rv = (uint32_t)(m0 + rl + 4 * (src >> 5));
+                        const uint64_t kth = lds_list_insert(mylists + (size_t)sq * kSplitKeep, kSplitKeep,
+                                                             make_key(sv, rv), lane);
+                        if (fr == sq) thr = kth ? fmaxf(key_score(kth), floor0) : floor0;  // both lane halves
+                    }
+                }
+            }
+        }
+        tile += nwaves_total;
+    }
+    __syncthreads();
+    for (int qq = wave; qq < a.nq; qq += kScanWaves) {
+        WaveTopK tk;
+        tk.init(kSplitKeep);
+#pragma unroll 1
+        for (int w = 0; w < kScanWaves; ++w) {
+            const uint64_t* l = lists + ((size_t)w * 32 + qq) * kSplitKeep;
+            tk.offer(lane < kSplitKeep ? l[lane] : 0ull);
+        }
+        if (lane < kSplitKeep) a.cand[((int64_t)qq * gridDim.x + blockIdx.x) * kSplitKeep + lane] = tk.key;
+    }
+}
+
 // Seed pass epilogue: merge the per-block lists of the first launch (one tile per block) into each query's 16
 // best approximate keys, and publish the 16th score as the admission floor of the main launch — every row of the
 // global approximate top-16 scores at least that much, so the main pass only has to insert the few rows above it
