@@ -233,7 +233,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f32" if not scan_name.startswith("ip_scan_split") else "f32 (bf16 split-precision nomination, f32 re-score + certificate)",
             "data": "synthetic",
             "config": {
                 "workload": f"{n} x {d} fp32 rows per GPU ({world * n} total), IP, k={k}, nq={nq} per step",
