@@ -592,33 +592,36 @@ int launch_split_scan(const mvdb_index* idx, Workspace* ws, const float* q, int 
     MVDB_TRY(ensure_dynamic_lds((const void*)seed_kern, kSplitLds, idx->device));
     const int64_t ntiles = (n + 127) / 128;
     const int cus = device_cus(idx->device);
-    // Large corpora: a seed launch over the first tile of every block learns each query's admission floor (the
-    // 16th best score of those rows), the main launch then inserts only the rows above it.
-    const bool seeded = ntiles >= (int64_t)cus * env_int("MVDB_SPLIT_SEED_MIN_TILES_PER_CU", 8);
+    // Every pass starts with a SEED launch over the first min(ntiles, CUs) tiles, one per block: each wave dumps its
+    // 32 scores per query, the block keeps the 16 best per query, split_seed_kernel merges the blocks and publishes
+    // each query's 16th-best score as the admission floor.  Corpora of up to one tile per CU are finished at that
+    // point; otherwise the MAIN launch scans the remaining tiles and inserts only rows at or above the floor (without
+    // it every wave learns its thresholds through thousands of serial LDS list inserts).
     uint64_t* seed_keys = ws->cand.p;                                // [128][16]
     uint64_t* cand = ws->cand.p + (size_t)128 * kSplitKeep;          // [nq][gx][16]
-    const uint64_t* seed_arg = nullptr;
     a.cand = cand;
-    a.tile0 = 0;
-    a.tile1 = ntiles;
     a.thr0 = nullptr;
     a.stats = env_int("MVDB_SPLIT_STATS", 0) ? reinterpret_cast<unsigned int*>(ws->flags.p) + 64 : nullptr;
     if (a.stats) MVDB_HIP(hipMemsetAsync(a.stats, 0, 8, stream));
-    const int64_t seed_tiles = (int64_t)cus * std::max(1, env_int("MVDB_SPLIT_SEED_TILES_PER_CU", 1));
-    if (seeded) {
+    const int64_t seed_tiles = std::min<int64_t>(ntiles, cus);
+    {
+        a.tile0 = 0;
         a.tile1 = seed_tiles;
         int slot = prof_begin("ip_scan_split_seed", stream);
-        hipLaunchKernelGGL(seed_kern, dim3(cus, 1), dim3(kSplitThreads), kSplitLds, stream, a);
-        hipLaunchKernelGGL(split_seed_kernel, dim3(nq), dim3(1024), 0, stream, cand, cus, seed_keys, ws->qnorm.p + 128);
+        hipLaunchKernelGGL(seed_kern, dim3((unsigned)seed_tiles, 1), dim3(kSplitThreads), kSplitLds, stream, a);
+        hipLaunchKernelGGL(split_seed_kernel, dim3(nq), dim3(1024), 0, stream, cand, (int)seed_tiles, seed_keys,
+                           ws->qnorm.p + 128);
         prof_end(slot, stream);
         MVDB_HIP(hipGetLastError());
-        a.tile0 = seed_tiles;
-        a.tile1 = ntiles;
-        a.thr0 = ws->qnorm.p + 128;
-        seed_arg = seed_keys;
     }
-    int gx;
-    if (nq <= 32 && split32_ok(idx)) {
+    const uint64_t* seed_arg = seed_keys;
+    a.tile0 = seed_tiles;
+    a.tile1 = ntiles;
+    a.thr0 = ws->qnorm.p + 128;
+    int gx = 0;
+    if (ntiles == seed_tiles) {
+        // nothing left: the seed list is the nominee list
+    } else if (nq <= 32 && split32_ok(idx)) {
         // 17..32 queries: per-wave rings, query fragments in registers (flat_scan_split32_kernel), 32-row tiles
         Split32Args b;
         b.X = idx->X;

@@ -501,14 +501,17 @@ def test_large_batch_gemm_scan_matches_oracle(native, n, d, k, nq):
 
 
 def _split_launches(native):
-    return native.prof_read("ip_scan_split")[0]
+    """Chunks that went through the split-precision pass: each one starts with a seed launch."""
+    native.prof_read("ip_scan_split")
+    native.prof_read("ip_scan_split32")
+    return native.prof_read("ip_scan_split_seed")[0]
 
 
 @pytest.mark.parametrize("n,d,k,nq", [
     (20000, 512, 10, 64), (9000, 384, 12, 100), (5000, 512, 1, 128), (12345, 256, 10, 129), (300, 64, 5, 200),
     (127, 512, 10, 70), (15, 512, 10, 30), (16, 128, 10, 24), (17, 96, 12, 33), (6000, 1024, 10, 130),
     (30000, 384, 10, 256),
-    (300000, 64, 10, 64), (270001, 128, 5, 130),  # >= 8 tiles per CU: seed launch + admission floors
+    (300000, 64, 10, 64), (270001, 128, 5, 130), (300000, 64, 10, 24), (70000, 128, 12, 100), (70001, 128, 12, 24), (40003, 256, 3, 129),  # seed + main launch
 ])
 def test_split_precision_batch_pass_matches_oracle(native, monkeypatch, n, d, k, nq):
     """nq >= 33 (24 here), k <= 12: the bf16 split-precision pass nominates 16 rows per query, exact fp32 re-scores
@@ -524,7 +527,7 @@ def test_split_precision_batch_pass_matches_oracle(native, monkeypatch, n, d, k,
     try:
         _split_launches(native)  # drain
         D, I = idx.search(q, k)
-        assert _split_launches(native) >= nq // 128, "the split-precision pass did not run"
+        assert _split_launches(native) >= max(1, nq // 128), "the split-precision pass did not run"
     finally:
         native.prof_enable(False)
     _check(native, x, q, k, D, I, exact_vs_oracle=n < 100000)
@@ -543,7 +546,7 @@ def test_split_precision_batch_pass_matches_oracle(native, monkeypatch, n, d, k,
     idx.close()
 
 
-def test_split_precision_pass_unnormalised_rows_and_queries(native):
+def test_split_precision_pass_unnormalised_rows_and_queries(native, monkeypatch):
     """Raw rows of very different norms and raw queries: the certification margin scales with |q| * max|row|."""
     n, d, k, nq = 8000, 256, 10, 48
     x = flat.synth(n, d, 99)
@@ -567,7 +570,7 @@ def test_split_precision_pass_unnormalised_rows_and_queries(native):
     idx.close()
 
 
-def test_split_precision_pass_falls_back_when_it_cannot_certify(native):
+def test_split_precision_pass_falls_back_when_it_cannot_certify(native, monkeypatch):
     """40 copies of each query's best row: more than 16 - k rows tie with the k-th score, the certificate fails
     and the chunk is re-run on the exact kernels; ties still resolve to the lowest row numbers."""
     n, d, k, nq = 6000, 128, 10, 48
