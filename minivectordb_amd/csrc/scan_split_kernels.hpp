@@ -1,4 +1,4 @@
-// scan_split_kernels.hpp — large query batches on the bf16 matrix cores, results certified exact.
+// scan_split_kernels.hpp — query batches (>= 17 per call) on the bf16 matrix cores, results certified exact.
 //
 // The fp32 MFMA rate (157 TFLOP/s) caps a 128-query corpus pass at ~13 ms on 10M x 512.  The bf16
 // MFMA rate is 16x higher, so the pass is run as a SPLIT-PRECISION product instead:
@@ -21,11 +21,20 @@
 // its k-th score: duplicate-heavy corpora) raises a flag and its chunk is re-run on the exact fp32
 // kernels (mvdb.hip: search_core), so the path never returns an uncertified answer.
 //
-// Block = 128 corpus rows x 128 queries, 8 waves (2 per SIMD), wave tile 64 rows x 32 queries;
-// K streamed 32 deep through double-buffered LDS (80-byte rows: conflict-free ds_read_b128
-// fragments).  D[row][query] keeps the query on the lane, so the top-16 gate is the GEMM-tiled
-// fp32 kernel's (scan_mfma_kernels.hpp): one threshold register per lane, survivors inserted
-// wave-cooperatively into per-wave, per-query sorted LDS lists.
+// Kernels of a pass (host side: mvdb.hip, launch_split_scan):
+//   split_queries_kernel        q -> K-step-major bf16 (hi, lo) images + |q|
+//   flat_scan_split_kernel      33..128 queries: block = 128 rows x 128 queries, 8 waves (2 per SIMD), wave tile
+//                               32 rows x 64 queries, K streamed 32 deep through a 3-stage LDS-DMA ring (raw fp32
+//                               rows + query images, bank swizzle on the DMA source), one bare s_barrier per step,
+//                               MFMAs of step g-1 and the hi/lo split of step g in one scheduling region.
+//                               <0, true> = the SEED launch every pass starts with (first min(tiles, CUs) tiles,
+//                               one per block, scores dumped and merged instead of inserted)
+//   flat_scan_split32_kernel    17..32 queries: per-wave 32-row tiles through private LDS-DMA rings (no block
+//                               barriers), query fragments in registers; HBM-bound
+//   split_seed_kernel           merges the seed launch's per-block lists, publishes the admission floors
+//   split_certify_kernel        merges the nominees, exact fp32 re-scores, top-k, certificate
+// In all of them D[row][query] keeps the query on the lane: one threshold register per lane gates the scores,
+// survivors are inserted wave-cooperatively into per-wave, per-query sorted LDS lists.
 #pragma once
 #include "scan_mfma_kernels.hpp"
 
