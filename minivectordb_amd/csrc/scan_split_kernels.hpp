@@ -375,6 +375,10 @@ __global__ __launch_bounds__(kSplitThreads) void flat_scan_split_kernel(SplitSca
             return w < 6 ? reinterpret_cast<uint64_t*>(smem) + (size_t)w * 2048 : lists + (size_t)(w - 6) * 2048;
         };
         __syncthreads();  // every wave is done with the ring and the lists
+        // Lane-owned selection, no wave-cooperative inserts: the wave dumps its keys TRANSPOSED ([key 0..31][query
+        // 0..63], conflict-free both ways), then lane q keeps the 16 best of query q's 32 keys in registers
+        // (branch-free insertion, skipped when no lane's key beats its 16th); one wave per query half merges the
+        // four row groups' lists the same way.
         uint64_t* mine = scratch(wave);
         const int64_t m0 = cs_tile * BM;
 #pragma unroll
@@ -382,20 +386,42 @@ __global__ __launch_bounds__(kSplitThreads) void flat_scan_split_kernel(SplitSca
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int64_t row = m0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
-                mine[(j * 32 + fr) * 32 + fk * 16 + r] = row <= last ? make_key(acc[j][r], (uint32_t)row) : 0ull;
+                mine[(fk * 16 + r) * 64 + j * 32 + fr] = row <= last ? make_key(acc[j][r], (uint32_t)row) : 0ull;
             }
+        uint64_t best[kSplitKeep];
+        auto keep_best = [&](uint64_t c) {
+            if (c > best[kSplitKeep - 1]) {
+#pragma unroll
+                for (int t = 0; t < kSplitKeep; ++t) {
+                    const bool up = best[t] > c;
+                    const uint64_t hi = up ? best[t] : c;
+                    c = up ? c : best[t];
+                    best[t] = hi;
+                }
+            }
+        };
+#pragma unroll
+        for (int t = 0; t < kSplitKeep; ++t) best[t] = 0ull;
+#pragma unroll 1
+        for (int i = 0; i < 32; ++i) keep_best(mine[i * 64 + lane]);
+#pragma unroll
+        for (int t = 0; t < kSplitKeep; ++t) mine[t * 64 + lane] = best[t];  // over the keys already consumed
         __syncthreads();
-        for (int c = wave; c < BN; c += 8) {
-            const int qq = n0 + c;
-            if (qq >= a.nq) continue;
-            WaveTopK tk;
-            tk.init(kSplitKeep);
+        if (wr == 0) {
+#pragma unroll
+            for (int t = 0; t < kSplitKeep; ++t) best[t] = 0ull;
 #pragma unroll 1
             for (int m = 0; m < 4; ++m) {
-                const uint64_t* l = scratch((c / 64) * 4 + m) + (c % 64) * 32;
-                tk.offer(lane < 32 ? l[lane] : 0ull);
+                const uint64_t* l = scratch(wq * 4 + m);
+#pragma unroll 1
+                for (int t = 0; t < kSplitKeep; ++t) keep_best(l[t * 64 + lane]);
             }
-            if (lane < kSplitKeep) a.cand[((int64_t)qq * gridDim.x + blockIdx.x) * kSplitKeep + lane] = tk.key;
+            const int qq = n0 + wq * 64 + lane;
+            if (qq < a.nq) {
+#pragma unroll
+                for (int t = 0; t < kSplitKeep; ++t)
+                    a.cand[((int64_t)qq * gridDim.x + blockIdx.x) * kSplitKeep + t] = best[t];
+            }
         }
         return;
     }
