@@ -99,7 +99,7 @@ int mvdb_index_remove_rows(mvdb_index* idx, const int64_t* rows_host, int64_t m)
 
 /* k nearest rows for nq queries.  q_host[nq,d], D_host[nq,k], I_host[nq,k].
  * normalize_q != 0 L2-normalises each query on the device first.
- * Every path returns exact-fp32 scores of the exact top-k: batches of >= 17 queries (k <= 12) are
+ * Every path returns exact-fp32 scores of the exact top-k: batches of >= 14 queries (k <= 12) are
  * NOMINATED on the bf16 matrix cores from a split-precision product, then re-scored in fp32 and
  * certified per query against the nomination's error bound; a chunk that cannot be certified is
  * re-run on the exact fp32 kernels (mvdb_split_rerun_count counts those).

@@ -520,7 +520,7 @@ std::atomic<long> g_split_reruns{0};
 
 bool split_path_ok(const mvdb_index* idx, int nq, int k, const int64_t* rows_dev) {
     if (env_int("MVDB_DISABLE_SPLIT_SCAN", 0)) return false;
-    if (nq < 17 || k > kSplitMaxK || rows_dev || idx->metric != MVDB_METRIC_IP) return false;
+    if (nq < 2 || k > kSplitMaxK || rows_dev || idx->metric != MVDB_METRIC_IP) return false;
     if (!(idx->row_norm_bound > 0.f) || std::isinf(idx->row_norm_bound)) return false;
     return idx->d % 32 == 0 && idx->ld == idx->d;
 }
@@ -713,7 +713,9 @@ int search_core(const mvdb_index* idx, Workspace* ws, const float* q_dev, int nq
             MVDB_TRY(normalize_range(idx, ws->qn.p, nq, s));
             qsrc = ws->qn.p;
         }
-        // chunk plan: 128 queries per pass while >= 33 remain, then one 17..32-query pass where that kernel exists
+        // chunk plan: 128 queries per pass while >= 33 remain, then one 14..32-query pass where that kernel exists
+        // (below ~14 queries the fp32 pass, whose cost grows with the query count, is faster than the fixed seed +
+        // certification overhead: measured crossover 11 queries at 100k rows, 14 at 10M)
         const int min_nq = env_int("MVDB_SPLIT_SCAN_MIN_NQ", 33);
         std::vector<std::pair<int, int>> plan;  // (first query, count)
         int q0 = 0;
@@ -721,7 +723,7 @@ int search_core(const mvdb_index* idx, Workspace* ws, const float* q_dev, int nq
             plan.emplace_back(q0, std::min(nq - q0, 128));
             q0 += plan.back().second;
         }
-        if (nq - q0 >= 17 && nq - q0 <= 32 && split32_ok(idx)) {
+        if (nq - q0 >= env_int("MVDB_SPLIT32_MIN_NQ", 14) && nq - q0 <= 32 && split32_ok(idx)) {
             plan.emplace_back(q0, nq - q0);
             q0 = nq;
         }

@@ -1,4 +1,4 @@
-// scan_split_kernels.hpp — query batches (>= 17 per call) on the bf16 matrix cores, results certified exact.
+// scan_split_kernels.hpp — query batches (>= 14 per call) on the bf16 matrix cores, results certified exact.
 //
 // The fp32 MFMA rate (157 TFLOP/s) caps a 128-query corpus pass at ~13 ms on 10M x 512.  The bf16
 // MFMA rate is 16x higher, so the pass is run as a SPLIT-PRECISION product instead:
@@ -29,7 +29,7 @@
 //                               MFMAs of step g-1 and the hi/lo split of step g in one scheduling region.
 //                               <0, true> = the SEED launch every pass starts with (first min(tiles, CUs) tiles,
 //                               one per block, scores dumped and merged instead of inserted)
-//   flat_scan_split32_kernel    17..32 queries: per-wave 32-row tiles through private LDS-DMA rings (no block
+//   flat_scan_split32_kernel    14..32 queries: per-wave 32-row tiles through private LDS-DMA rings (no block
 //                               barriers), query fragments in registers; HBM-bound
 //   split_seed_kernel           merges the seed launch's per-block lists, publishes the admission floors
 //   split_certify_kernel        merges the nominees, exact fp32 re-scores, top-k, certificate
@@ -446,7 +446,7 @@ __global__ __launch_bounds__(kSplitThreads) void flat_scan_split_kernel(SplitSca
     }
 }
 
-// ---- 17..32 queries per pass: per-wave rings, query fragments in registers --------------------------------------
+// ---- 14..32 queries per pass: per-wave rings, query fragments in registers --------------------------------------
 // The fp32 32-query pass (flat_scan_mfma2_kernel<KB, 2>) is MFMA-issue-bound at one wave per SIMD (4.0 ms at
 // 10M x 512 against a 2.9 ms HBM floor).  Same nominate-and-certify scheme as above on the bf16 cores, in that
 // kernel's shape: every wave owns 32-row tiles and streams them through a private two-stage LDS-DMA ring (no block
