@@ -622,7 +622,7 @@ int launch_split_scan(const mvdb_index* idx, Workspace* ws, const float* q, int 
     if (ntiles == seed_tiles) {
         // nothing left: the seed list is the nominee list
     } else if (nq <= 32 && split32_ok(idx)) {
-        // 17..32 queries: per-wave rings, query fragments in registers (flat_scan_split32_kernel), 32-row tiles
+        // 14..32 queries: per-wave rings, query fragments in registers (flat_scan_split32_kernel), 32-row tiles
         Split32Args b;
         b.X = idx->X;
         b.n = n;

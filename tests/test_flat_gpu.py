@@ -420,8 +420,8 @@ def test_config3_10M_x_512_properties(native):
     (6000, 1024, 10, 16), (6000, 1024, 10, 35), (5000, 768, 64, 9),  # e5-large / bge-m3 widths: one group per pass
 ])
 def test_multi_query_mfma_pass_matches_oracle(native, n, d, k, nq):
-    """nq >= 2: one corpus pass serves up to 32 queries — on v_mfma_f32_16x16x4_f32 (exact fp32) for up to 16
-    queries, k > 12 or d > 512, on the bf16 cores with exact certification (flat_scan_split32_kernel) for 17..32
+    """nq >= 2: one corpus pass serves up to 32 queries — on v_mfma_f32_16x16x4_f32 (exact fp32) for up to 13
+    queries, k > 12 or d > 512, on the bf16 cores with exact certification (flat_scan_split32_kernel) for 14..32
     queries; every query's result must equal its own single-query search."""
     x = _corpus(n, d)
     q = _corpus(nq, d, seed=5678)
