@@ -7,8 +7,11 @@ A "step" is ONE query (nq = 1, the reference API: minivectordb/vector_database.p
 pass of the scan over this rank's resident corpus shard, followed — when N > 1 — by the RCCL
 all-gather of the per-shard top-k and the k-way merge.  Weak scaling: every rank holds its own
 `--rows` x `--dim` shard (10M x 512 = 20.48 GB), generated on the device, so the searched corpus is
-N x 10M rows; `value` counts shard passes per second summed over ranks (at N = 1 this IS queries/s
-on 10M x 512), `global_qps` is the user-visible queries/s over the whole N x 10M corpus.
+N x 10M rows (BASELINE config 4 at N = 8: 80M x 512).  `value` is the user-visible rate: queries
+per second answered over the WHOLE N x rows corpus (every query is scanned by all ranks jointly, so
+it does not grow with N — the corpus does); `corpus_rows_per_s` and `roofline.achieved` carry the
+aggregate scan rate (rows/s and GB/s summed over ranks, against N x the HBM peak), with the
+per-rank kernel times beside them.
 
 Inputs are resident in HBM when the timed region starts (corpus and all W+K queries are generated
 on the device beforehand); results stay on the device.  The PCIe-inclusive host API rate is
@@ -97,6 +100,7 @@ def cpu_baseline(native, idx, d, k, queries_host, full_rows, budget_s=20.0):
         if rate > best[0]:
             best = (rate, cores)
     scale = sample / float(full_rows)
+    mt_gbs = round(sample * d * 4 * best[0] / 1e9, 2)
     return {
         "value": round(nq / t1 * scale, 4),
         "unit": "queries/s",
@@ -108,6 +112,7 @@ def cpu_baseline(native, idx, d, k, queries_host, full_rows, budget_s=20.0):
         "multithread_cores": best[1],
         "host_cores_available": avail,
         "gb_per_s_1thread": round(sample * d * 4 * nq / t1 / 1e9, 2),
+        "gb_per_s_multithread": mt_gbs,
     }
 
 
@@ -122,6 +127,8 @@ def main():
     ap.add_argument("--nq", type=int, default=1, help="queries per step (1 = the reference API shape; >1 = one "
                     "multi-query MFMA pass per step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dump", default=None, help="rank 0 writes the merged (D, I) of the first 16 timed steps to this "
+                    ".npz (tests/test_config4_gpu.py compares them with a single-index search)")
     args = ap.parse_args()
 
     import numpy as np
@@ -196,10 +203,23 @@ def main():
     scan_name = max(prof, key=lambda name: prof[name][1])
     launches, scan_ms = prof[scan_name]
 
+    rank_ms = [scan_ms / max(launches, 1)]  # this rank's mean launch duration of the dominant kernel
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        g = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(world)]
+        dist.all_gather(g, torch.tensor(rank_ms, dtype=torch.float64, device=dev))
+        rank_ms = [float(v.item()) for v in g]
+
+    if args.dump:
+        got = []
+        for i in range(W, W + min(K, 16)):
+            D_, I_ = searcher.search_device(queries[i * nq:(i + 1) * nq])
+            got.append((D_.cpu().numpy().copy(), I_.cpu().numpy().copy()))
+        if rank == 0:
+            np.savez(args.dump, D=np.stack([g[0] for g in got]), I=np.stack([g[1] for g in got]),
+                     first_query=W * nq, nq=nq, rows_per_rank=n, world=world)
 
     # p50 latency: per-query wall (enqueue -> result on device), outside the timed region
     lat = []
@@ -221,10 +241,11 @@ def main():
             if (n + 127) // 128 >= 8 * cus:
                 bytes_per_launch = (n - cus * 128) * d * 4
         avg_ms = scan_ms / max(launches, 1)
-        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if launches else 0.0
+        # aggregate over ranks: every rank streams its own shard once per launch
+        achieved = sum(bytes_per_launch / (ms * 1e-3) / 1e9 for ms in rank_ms if ms > 0) if launches else 0.0
         out = {
             "metric": baseline_metric(),
-            "value": round(world * K * nq / dt, 3),
+            "value": round(K * nq / dt, 3),
             "unit": "queries/s",
             "n_gpus": world,
             "steps": K,
@@ -236,12 +257,16 @@ def main():
             "dtype": "f32" if not scan_name.startswith("ip_scan_split") else "f32 (bf16 split-precision nomination, f32 re-score + certificate)",
             "data": "synthetic",
             "config": {
-                "workload": f"{n} x {d} fp32 rows per GPU ({world * n} total), IP, k={k}, nq={nq} per step",
+                "workload": (f"{world * n} x {d} fp32 corpus ({n} rows resident per GPU), IP, k={k}, "
+                             f"nq={nq} per step"),
                 "rows_per_gpu": n, "dim": d, "k": k, "nq": nq,
                 "parallelism": f"row-sharded x{world}" + (", RCCL all-gather of per-shard top-k" if world > 1 else ""),
             },
             "p50_latency_ms": round(p50, 4),
-            "global_qps": round(K * nq / dt, 3),
+            "corpus_rows": world * n,
+            "corpus_rows_per_s": round(world * n * K * nq / dt, 1),
+            "shard_passes_per_s": round(world * K * (1 if nq <= 128 else (nq + 127) // 128) / dt, 3),
+            "collective": searcher.collective,
             "roofline": None,
         }
         if scan_name == "ip_scan_gemm":
@@ -257,9 +282,9 @@ def main():
             out["roofline"] = {
                 "bound": "hbm",
                 "achieved": round(achieved, 1),
-                "peak": HBM_PEAK_GBS,
+                "peak": HBM_PEAK_GBS * world,
                 "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "frac": round(achieved / (HBM_PEAK_GBS * world), 4),
                 "traffic": (pmc_traffic(n, d, nq, scan_name) or {}).get("bytes"),
                 "traffic_source": (pmc_traffic(n, d, nq, scan_name) or {}).get("source"),
                 "kernel": {"ip_scan": "flat_scan_kernel", "ip_scan_mfma": "flat_scan_mfma2_kernel",
@@ -268,6 +293,8 @@ def main():
                 "launches": launches,
                 "avg_launch_ms": round(avg_ms, 4),
                 "algorithmic_bytes_per_launch": bytes_per_launch,
+                "per_rank_avg_launch_ms": [round(v, 4) for v in rank_ms],
+                "per_rank_launch_ms_min_max": [round(min(rank_ms), 4), round(max(rank_ms), 4)],
             }
         if world == 1:
             # PCIe-inclusive host API (numpy in, numpy out): reported, never `value`
@@ -289,6 +316,7 @@ def main():
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
     barrier()
+    searcher.close()
     idx.close()
     if world > 1:
         dist.destroy_process_group()

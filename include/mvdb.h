@@ -126,14 +126,46 @@ int mvdb_index_search_subset(const mvdb_index* idx, const float* q_host, int nq,
                              int normalize_q, const int64_t* rows_host, int64_t m, float* D_host,
                              int64_t* I_host);
 
+/* Device-resident variant of mvdb_index_search_subset for the one-process-per-GPU sharded search: queries, the row
+ * list (rows_dev[m], int64, every entry in [0, ntotal) — validated by the caller, this entry point does not
+ * synchronise) and outputs live in device memory, work is enqueued on `stream`.  map_labels == 0: labels are
+ * positions in rows_dev[] (+ label_offset), as above; map_labels != 0: labels are rows_dev[position] + label_offset,
+ * i.e. global row numbers of a shard whose first row is label_offset.
+ * Replaces the per-shard half of             minivectordb/sharded_vector_database.py:634-649 */
+int mvdb_index_search_subset_device(const mvdb_index* idx, const float* q_dev, int nq, int k, int normalize_q,
+                                    const int64_t* rows_dev, int64_t m, int map_labels, int64_t label_offset,
+                                    float* D_dev, int64_t* I_dev, void* stream);
+
 /* Merge `nlists` sorted top-k lists per query into one [nq,k] result on the device.  List l lives
  * at D_dev + l*list_stride_D (floats, [nq,k]) and I_dev + l*list_stride_I (int64, [nq,k]) — the
  * layout one RCCL all-gather of each rank's packed {I,D} block produces.  Labels must already be
  * global; lists must be ordered by ascending shard base (ties resolve to the lower label).
+ * k <= 64: one wave per query; larger k: nlists * k <= 16384 keys sorted in LDS by one block per query.
  * No reference counterpart (the reference never partitions a search). */
 int mvdb_merge_topk_device(int metric, int nlists, int nq, int k, const float* D_dev,
                            int64_t list_stride_D, const int64_t* I_dev, int64_t list_stride_I,
                            float* D_out_dev, int64_t* I_out_dev, int device, void* stream);
+
+/* ---- exchange step of the row-partitioned multi-GPU search -------------------------
+ * One process per GPU; rank r holds rows [base_r, base_r + n_r) resident and answers from them
+ * (mvdb_index_search_device with label_offset = base_r); ONE all-gather of every rank's packed result block
+ * ([I: nq*k int64 | D: nq*k fp32], 12*k bytes per query) over xGMI; mvdb_merge_topk_device on every rank.
+ * The communicator is RCCL's: rank 0 draws a unique id (mvdb_comm_unique_id), the launcher hands the 128 bytes
+ * to every rank (torch.distributed / a file / MPI — any side channel), every rank calls mvdb_comm_create.
+ * RCCL is bound at run time (dlopen); a single-GPU process never loads it.  No reference counterpart: the
+ * reference searches one stacked matrix (minivectordb/sharded_vector_database.py:598-662); the contract kept is
+ * that function's result — top-k of the union, ties to the lower global row. */
+typedef struct mvdb_comm mvdb_comm;
+int mvdb_comm_unique_id(unsigned char* out128);
+int mvdb_comm_create(const unsigned char* id128, int rank, int world, int device, mvdb_comm** out);
+int mvdb_comm_free(mvdb_comm* comm);
+int mvdb_comm_rank(const mvdb_comm* comm);
+int mvdb_comm_world(const mvdb_comm* comm);
+
+/* ncclAllGather of nbytes_per_rank bytes from local_dev into gathered_dev[world * nbytes_per_rank] (rank order),
+ * enqueued on `stream`; returns without synchronising. */
+int mvdb_allgather_topk(mvdb_comm* comm, const void* local_dev, void* gathered_dev, int64_t nbytes_per_rank,
+                        void* stream);
 
 /* In-place row-wise L2 normalisation of host matrix x[n,d] on the device.
  * Replaces faiss.normalize_L2                     minivectordb/vector_database.py:45, :475 */
@@ -154,6 +186,11 @@ int mvdb_prof_read(const char* name, int64_t* launches, double* total_ms);
  * against exact fp32 re-scores) that failed certification and were re-run on the exact fp32 kernels
  * since the library was loaded.  Diagnostic only. */
 int64_t mvdb_split_rerun_count(void);
+
+/* The certificate's error bound per unit |q| * max|x| at dimension d: operand truncation of the bf16 split,
+ * worst-case fp32 accumulation of the 3 d products in any order, the fp32 re-score, |q| and the comparison's own
+ * rounding (tests/test_split_bound.py restates and checks the formula).  Diagnostic. */
+double mvdb_split_eps(int d);
 
 /* ---- encoder (BERT-architecture sentence encoder: e5-small / e5-large) ---------------------
  * Replaces self.model(**batch_dict) + average_pool + F.normalize

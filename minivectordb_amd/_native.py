@@ -71,12 +71,21 @@ PROTOTYPES = {
                                                 ctypes.c_int64, c_vp, c_vp, c_vp]),
     "mvdb_index_search_subset": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_vp,
                                                 ctypes.c_int64, c_vp, c_vp]),
+    "mvdb_index_search_subset_device": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_vp,
+                                                       ctypes.c_int64, ctypes.c_int, ctypes.c_int64, c_vp, c_vp, c_vp]),
+    "mvdb_comm_unique_id": (ctypes.c_int, [c_vp]),
+    "mvdb_comm_create": (ctypes.c_int, [c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(c_vp)]),
+    "mvdb_comm_free": (ctypes.c_int, [c_vp]),
+    "mvdb_comm_rank": (ctypes.c_int, [c_vp]),
+    "mvdb_comm_world": (ctypes.c_int, [c_vp]),
+    "mvdb_allgather_topk": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int64, c_vp]),
     "mvdb_merge_topk_device": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_vp,
                                               ctypes.c_int64, c_vp, ctypes.c_int64, c_vp, c_vp, ctypes.c_int, c_vp]),
     "mvdb_normalize_l2": (ctypes.c_int, [c_vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int]),
     "mvdb_synth_fill_device": (ctypes.c_int, [c_vp, ctypes.c_int64, ctypes.c_int, ctypes.c_uint64, ctypes.c_int64,
                                               ctypes.c_int, ctypes.c_int, c_vp]),
     "mvdb_split_rerun_count": (ctypes.c_int64, []),
+    "mvdb_split_eps": (ctypes.c_double, [ctypes.c_int]),
     "mvdb_prof_enable": (ctypes.c_int, [ctypes.c_int]),
     "mvdb_prof_read": (ctypes.c_int, [ctypes.c_char_p, ctypes.POINTER(ctypes.c_int64),
                                       ctypes.POINTER(ctypes.c_double)]),
@@ -230,6 +239,47 @@ class FlatIndex:
                                              ctypes.c_void_p(I_ptr), ctypes.c_void_p(stream)))
 
 
+    def search_subset_device(self, q_ptr, nq, k, rows_ptr, m, D_ptr, I_ptr, stream=0, normalize_q=False,
+                             map_labels=False, label_offset=0):
+        """Device-pointer variant of search_subset (rows already validated and resident on the device)."""
+        check(lib().mvdb_index_search_subset_device(
+            self._h, ctypes.c_void_p(q_ptr), int(nq), int(k), int(bool(normalize_q)), ctypes.c_void_p(rows_ptr), int(m),
+            int(bool(map_labels)), int(label_offset), ctypes.c_void_p(D_ptr), ctypes.c_void_p(I_ptr),
+            ctypes.c_void_p(stream)))
+
+
+class Comm:
+    """RCCL communicator owned by libmvdb.so (mvdb_comm*): one all-gather of packed top-k blocks per query batch."""
+
+    def __init__(self, unique_id, rank, world, device=0):
+        self._h = ctypes.c_void_p()
+        buf = (ctypes.c_ubyte * 128).from_buffer_copy(bytes(unique_id))
+        check(lib().mvdb_comm_create(ctypes.cast(buf, ctypes.c_void_p), int(rank), int(world), int(device),
+                                     ctypes.byref(self._h)))
+        self.rank, self.world = int(rank), int(world)
+
+    @staticmethod
+    def unique_id():
+        buf = (ctypes.c_ubyte * 128)()
+        check(lib().mvdb_comm_unique_id(ctypes.cast(buf, ctypes.c_void_p)))
+        return bytes(buf)
+
+    def allgather(self, local_ptr, gathered_ptr, nbytes_per_rank, stream=0):
+        check(lib().mvdb_allgather_topk(self._h, ctypes.c_void_p(local_ptr), ctypes.c_void_p(gathered_ptr),
+                                        int(nbytes_per_rank), ctypes.c_void_p(stream)))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            lib().mvdb_comm_free(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def normalize_l2(x, device=0):
     """In-place faiss.normalize_L2 equivalent on the GPU for a C-contiguous float32 [n,d] array."""
     if not (isinstance(x, np.ndarray) and x.dtype == np.float32 and x.flags["C_CONTIGUOUS"] and x.ndim == 2):
@@ -244,6 +294,10 @@ def prof_enable(on=True):
 
 def split_rerun_count():
     return int(lib().mvdb_split_rerun_count())
+
+
+def split_eps(d):
+    return float(lib().mvdb_split_eps(int(d)))
 
 
 def prof_read(name):

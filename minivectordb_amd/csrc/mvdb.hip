@@ -26,6 +26,9 @@ using namespace mvdb;
 // ================================================================================================
 namespace mvdb {
 
+int launch_merge_di_sort(int metric, int nlists, int nq, int k, const float* D, int64_t strideD, const int64_t* I,
+                         int64_t strideI, float* Dout, int64_t* Iout, int device, hipStream_t stream);  // collective.hip
+
 static thread_local char g_err[512] = "";
 
 void set_error(const char* fmt, ...) {
@@ -129,6 +132,7 @@ struct Workspace {
     PinnedBuf pin_flags;
     SelectState* st = nullptr;
     PinnedBuf pin;
+    std::mutex use_mu;  // stream workspaces are shared by every host thread that names the stream: one search at a time
 
     int init(int dev, hipStream_t s) {
         device = dev;
@@ -400,6 +404,14 @@ int64_t pow2ceil(int64_t v) {
 
 int normalize_range(const mvdb_index* idx, float* base, int64_t n, hipStream_t s);
 
+// Mutators (add / remove_rows / reset) hold the index exclusively, which only excludes HOST calls: scans enqueued
+// earlier by mvdb_index_search_device on non-blocking streams may still be reading the matrix.  Drain the device
+// before touching it (the mutators then work on the legacy stream and finish with a device sync of their own).
+int quiesce() {
+    MVDB_HIP(hipDeviceSynchronize());
+    return 0;
+}
+
 template <int KB, int NG>
 int launch_mfma_inst(const MfmaScanArgs& a, int device, hipStream_t stream, int* nblocks_out) {
     auto kern = flat_scan_mfma_kernel<KB, NG>;
@@ -515,13 +527,37 @@ int launch_gemm_scan(const mvdb_index* idx, const float* q, int nq, int k, int64
 }
 
 // nq >= 33, k <= 12, rows of known norm: split-precision bf16 pass + exact certification (scan_split_kernels.hpp)
-constexpr float kSplitEps = 1.0e-4f;  // >= 3 * 2^-16 operand bound (4.6e-5) + fp32 accumulation allowance
 std::atomic<long> g_split_reruns{0};
+
+// Worst-case bound, per unit |q| * max|x|, on everything that separates the quantities the certificate compares
+// from the real-number scores t(x) = q.x (derivation: DESIGN.md section 4.3b; checked in tests/test_split_bound.py):
+//   (1) the products the split drops:  q x - (qh xh + qh xl + ql xh) = rq (x - rx) + ql xl + rx q  with
+//       |rx| <= 2^-16 |x|, |xl| <= 2^-8 (1 + 2^-8) |x| (bf16 = 8 significand bits, RNE) and the same for q;
+//       summed with Cauchy-Schwarz:  <= 2^-16 (3 + 2^-7 + 2^-15) |q| |x|;
+//   (2) the fp32 accumulation of the 3 d exact bf16 x bf16 products on the matrix cores, in ANY order, every
+//       addition rounded or truncated at fp32 width (unit 2^-23):  gamma(3 d) * sum|terms|, sum|terms| <=
+//       (1 + 2^-8)^2 (1 + 2^-7) |q| |x|;
+//   (3) the fp32 re-score of the nominees (split_certify_kernel): per lane ceil(d4 / 64) * 4 fused multiply-adds,
+//       then a 6-step butterfly:  gamma(depth) at unit 2^-24;
+//   (4) |q| itself (fp32 tree sum + sqrt, <= 4e-6 relative) and the rounding of the certificate's own
+//       comparison (<= 4 * 2^-24 |q| max|x|).
+// A row that was not nominated has t <= approx(16th nominee) + (1) + (2); the k-th result has t >= rescore - (3).
+double split_eps(int d) {
+    const double u8 = std::ldexp(1.0, -8), u16 = std::ldexp(1.0, -16), u23 = std::ldexp(1.0, -23), u24 = std::ldexp(1.0, -24);
+    const double e_op = u16 * ((1.0 + u16) + (1.0 + u8) * (1.0 + u8) + 1.0);
+    const double n = 3.0 * d;
+    const double e_acc = n * u23 / (1.0 - n * u23) * (1.0 + u8) * (1.0 + u8) * (1.0 + 2.0 * u8);
+    const double depth = ((d + 3) / 4 + 63) / 64 * 4 + 6;
+    const double e_re = depth * u24 / (1.0 - depth * u24);
+    return (e_op + e_acc + e_re) * (1.0 + 4e-6) + 4.0 * u24;
+}
 
 bool split_path_ok(const mvdb_index* idx, int nq, int k, const int64_t* rows_dev) {
     if (env_int("MVDB_DISABLE_SPLIT_SCAN", 0)) return false;
     if (nq < 2 || k > kSplitMaxK || rows_dev || idx->metric != MVDB_METRIC_IP) return false;
-    if (!(idx->row_norm_bound > 0.f) || std::isinf(idx->row_norm_bound)) return false;
+    // rows of known, sane norm only: the bound scales with max|x|, and bf16 keeps fp32's exponent range only up
+    // to 3.39e38 (a split of larger elements would overflow to infinity)
+    if (!(idx->row_norm_bound > 0.f) || !(idx->row_norm_bound < 1.0e30f)) return false;
     return idx->d % 32 == 0 && idx->ld == idx->d;
 }
 
@@ -651,7 +687,7 @@ int launch_split_scan(const mvdb_index* idx, Workspace* ws, const float* q, int 
     c.d4 = idx->d4;
     c.q = q;
     c.qnorm = ws->qnorm.p;
-    c.eps = kSplitEps * idx->row_norm_bound;
+    c.eps = (float)(split_eps(idx->d) * (double)idx->row_norm_bound * (1.0 + 1e-6));  // rounded up
     c.k = k;
     c.label_offset = label_offset;
     c.D = D;
@@ -1042,6 +1078,8 @@ int mvdb_index_free(mvdb_index* idx) {
 int mvdb_index_reset(mvdb_index* idx) {
     if (!idx) return fail(MVDB_ERR_ARG, "index is NULL");
     std::unique_lock<std::shared_mutex> lk(idx->mu);
+    DeviceGuard dg(idx->device);
+    MVDB_TRY(quiesce());
     idx->n = 0;
     idx->row_norm_bound = 0.f;
     return 0;
@@ -1073,7 +1111,9 @@ int mvdb_index_reserve(mvdb_index* idx, int64_t n) {
 // extra read of the new rows otherwise (non-finite rows leave the bound non-finite).
 static int note_row_norms(mvdb_index* idx, const float* dst, int64_t n, int normalize) {
     if (normalize) {
-        idx->row_norm_bound = std::max(idx->row_norm_bound, 1.000001f);
+        // |row| after normalize_rows_kernel: |x| / sqrt(fl(|x|^2)) with an fp32 sum of depth <= 4 * 16 + 6 (d <= 4096),
+        // one sqrt, one divide, one multiply: <= 1 + (70 / 2 + 3) * 2^-24 = 1 + 2.3e-6
+        idx->row_norm_bound = std::max(idx->row_norm_bound, 1.000004f);
         return 0;
     }
     unsigned int* dmax = nullptr;
@@ -1104,6 +1144,7 @@ int mvdb_index_add(mvdb_index* idx, const float* x_host, int64_t n, int normaliz
     DeviceGuard dg(idx->device);
     if (idx->n + n > 0xFFFFFFFFll)
         return fail(MVDB_ERR_ARG, "more than 2^32-1 rows per device index are not supported");
+    MVDB_TRY(quiesce());
     MVDB_TRY(grow(idx, idx->n + n));
     float* dst = idx->X + idx->n * idx->ld;
     if (idx->ld == idx->d) {
@@ -1131,6 +1172,7 @@ int mvdb_index_add_device(mvdb_index* idx, const float* x_dev, int64_t n, int no
     DeviceGuard dg(idx->device);
     if (idx->n + n > 0xFFFFFFFFll)
         return fail(MVDB_ERR_ARG, "more than 2^32-1 rows per device index are not supported");
+    MVDB_TRY(quiesce());
     MVDB_TRY(grow(idx, idx->n + n));
     float* dst = idx->X + idx->n * idx->ld;
     if (idx->ld == idx->d) {
@@ -1159,6 +1201,7 @@ int mvdb_index_add_synthetic(mvdb_index* idx, int64_t n, uint64_t seed, int64_t 
     DeviceGuard dg(idx->device);
     if (idx->n + n > 0xFFFFFFFFll)
         return fail(MVDB_ERR_ARG, "more than 2^32-1 rows per device index are not supported");
+    MVDB_TRY(quiesce());
     MVDB_TRY(grow(idx, idx->n + n));
     float* dst = idx->X + idx->n * idx->ld;
     const int cus = device_cus(idx->device);
@@ -1208,6 +1251,7 @@ int mvdb_index_remove_rows(mvdb_index* idx, const int64_t* rows_host, int64_t m)
             return fail(MVDB_ERR_ARG, "row %lld listed twice", (long long)del[i]);
     }
     DeviceGuard dg(idx->device);
+    MVDB_TRY(quiesce());
     const int64_t n_new = idx->n - m;
     if (n_new == 0) {
         idx->n = 0;
@@ -1326,6 +1370,7 @@ int mvdb_index_search_device(const mvdb_index* idx, const float* q_dev, int nq, 
     DeviceGuard dg(idx->device);
     Workspace* ws = idx->for_stream((hipStream_t)stream);
     if (!ws) return fail(MVDB_ERR_HIP, "workspace allocation failed");
+    std::lock_guard<std::mutex> use(ws->use_mu);
     const float* q = q_dev;
     if (idx->ld != idx->d) {  // pad the dense queries to the row stride
         MVDB_TRY(ws->q.reserve((size_t)nq * idx->ld));
@@ -1337,14 +1382,56 @@ int mvdb_index_search_device(const mvdb_index* idx, const float* q_dev, int nq, 
     return search_core(idx, ws, q, nq, k, normalize_q, nullptr, 0, label_offset, D_dev, I_dev);
 }
 
+__global__ void map_subset_labels_kernel(int64_t* I, int64_t total, const int64_t* __restrict__ rows,
+                                         int64_t label_offset) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < total) {
+        const int64_t p = I[i];
+        I[i] = p >= 0 ? rows[p] + label_offset : -1;
+    }
+}
+
+int mvdb_index_search_subset_device(const mvdb_index* idx, const float* q_dev, int nq, int k, int normalize_q,
+                                    const int64_t* rows_dev, int64_t m, int map_labels, int64_t label_offset,
+                                    float* D_dev, int64_t* I_dev, void* stream) {
+    MVDB_TRY(check_search_args(idx, q_dev, nq, k, D_dev, I_dev));
+    if (m < 0) return fail(MVDB_ERR_ARG, "negative subset size");
+    if (m > 0 && !rows_dev) return fail(MVDB_ERR_ARG, "rows is NULL");
+    std::shared_lock<std::shared_mutex> lk(idx->mu);
+    DeviceGuard dg(idx->device);
+    Workspace* ws = idx->for_stream((hipStream_t)stream);
+    if (!ws) return fail(MVDB_ERR_HIP, "workspace allocation failed");
+    std::lock_guard<std::mutex> use(ws->use_mu);
+    const float* q = q_dev;
+    if (idx->ld != idx->d) {
+        MVDB_TRY(ws->q.reserve((size_t)nq * idx->ld));
+        hipLaunchKernelGGL(pad_rows_kernel, dim3((unsigned)(((int64_t)nq * idx->ld + 255) / 256)),
+                           dim3(256), 0, ws->stream, ws->q.p, q_dev, (int64_t)nq, idx->d, idx->ld);
+        MVDB_HIP(hipGetLastError());
+        q = ws->q.p;
+    }
+    // m == 0: search_core's empty-corpus branch needs a non-NULL row list to take the subset meaning
+    const int64_t* rows = m > 0 ? rows_dev : reinterpret_cast<const int64_t*>(ws->st);
+    MVDB_TRY(search_core(idx, ws, q, nq, k, normalize_q, rows, m, map_labels ? 0 : label_offset, D_dev, I_dev));
+    if (map_labels && m > 0) {
+        const int64_t total = (int64_t)nq * k;
+        hipLaunchKernelGGL(map_subset_labels_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ws->stream,
+                           I_dev, total, rows_dev, label_offset);
+        MVDB_HIP(hipGetLastError());
+    }
+    return 0;
+}
+
 int mvdb_merge_topk_device(int metric, int nlists, int nq, int k, const float* D_dev,
                            int64_t list_stride_D, const int64_t* I_dev, int64_t list_stride_I,
                            float* D_out_dev, int64_t* I_out_dev, int device, void* stream) {
     if (!D_dev || !I_dev || !D_out_dev || !I_out_dev) return fail(MVDB_ERR_ARG, "NULL buffer");
     if (nlists <= 0 || nq <= 0 || k <= 0) return fail(MVDB_ERR_ARG, "non-positive size");
-    if (k > kMaxFusedK) return fail(MVDB_ERR_ARG, "merge supports k <= %d (got %d)", kMaxFusedK, k);
     MVDB_TRY(ensure_device(device));
     DeviceGuard dg(device);
+    if (k > kMaxFusedK)  // more results than one wave holds: sort the gathered lists in LDS (collective.hip)
+        return launch_merge_di_sort(metric, nlists, nq, k, D_dev, list_stride_D, I_dev, list_stride_I, D_out_dev,
+                                    I_out_dev, device, (hipStream_t)stream);
     MergeDIArgs a{D_dev, I_dev, list_stride_D, list_stride_I, nlists, nq, k, metric, D_out_dev, I_out_dev};
     hipLaunchKernelGGL(merge_di_kernel, dim3(nq), dim3(kWave), 0, (hipStream_t)stream, a);
     MVDB_HIP(hipGetLastError());
@@ -1387,6 +1474,8 @@ int mvdb_synth_fill_device(float* out_dev, int64_t n, int d, uint64_t seed, int6
     }
     return 0;
 }
+
+double mvdb_split_eps(int d) { return d > 0 ? split_eps(d) : 0.0; }
 
 int64_t mvdb_split_rerun_count(void) { return (int64_t)g_split_reruns.load(std::memory_order_relaxed); }
 

@@ -8,10 +8,17 @@ one all-gather of ``k`` (score, label) pairs per query and shard — 12*k bytes 
 latency-bound on xGMI — followed by a k-way merge that every rank runs redundantly (no second
 collective).  With world == 1 no collective is initialised or issued.
 
+The collective is RCCL's ``ncclAllGather`` issued from inside libmvdb.so (``mvdb_allgather_topk``, a communicator
+created from a unique id that rank 0 draws and the launcher's process group hands around) — torch is then not on the
+search path at all.  ``MVDB_COLLECTIVE=torch`` (or a non-RCCL process group, e.g. the gloo tests) routes the same
+buffer through ``torch.distributed.all_gather_into_tensor`` instead; which one ran is reported by ``.collective``.
+
 The local scan and the merge are injected callables so that the exchange plumbing (packing layout,
 label offsets, gather order) is exercised by world_size-2 ``gloo`` tests on CPU, where the HIP
 kernels cannot run; the defaults bind to libmvdb.so and have no CPU fallback.
 """
+import os
+import sys
 import ctypes
 
 import torch
@@ -67,12 +74,13 @@ class ShardedSearcher:
     index          minivectordb_amd._native.FlatIndex holding this rank's rows (or None when
                    `local_search` is injected)
     label_offset   global row number of this rank's first row (default rank * rows_per_rank)
-    local_search   callable(q, D_view, I_view, label_offset): fills the views (device tensors)
+    local_search   callable(q, D_view, I_view, label_offset, rows=None, normalize_q=False): fills the views
+                   (device tensors); `rows` = int64 device tensor of LOCAL row numbers to restrict the scan to
     merge          callable(gathered: PackedTopK, D_out, I_out): merges `world` lists
     """
 
     def __init__(self, index, k, rank=0, world=1, rows_per_rank=None, label_offset=None, device=None, group=None,
-                 metric=0, local_search=None, merge=None):
+                 metric=0, local_search=None, merge=None, collective=None):
         self.index, self.k, self.rank, self.world = index, int(k), int(rank), int(world)
         self.group = group
         self.metric = metric
@@ -83,12 +91,63 @@ class ShardedSearcher:
         self._local_search = local_search or self._hip_local_search
         self._merge = merge or self._hip_merge
         self._bufs = {}
+        self._comm = None
+        self.collective = "none"
+        if self.world > 1:
+            self.collective = self._pick_collective(collective)
+
+    # ---- the exchange: ncclAllGather inside libmvdb.so, or the process group's all-gather -------
+    def _pick_collective(self, want):
+        want = want or os.environ.get("MVDB_COLLECTIVE")
+        on_gpu = self.device.type == "cuda"
+        backend = dist.get_backend(self.group) if dist.is_initialized() else None
+        if want is None:
+            want = "native" if (on_gpu and backend == "nccl") else "torch"
+        if want == "torch":
+            return "torch.distributed.all_gather_into_tensor"
+        if want != "native":
+            raise ValueError(f"MVDB_COLLECTIVE must be 'native' or 'torch' (got {want!r})")
+        from . import _native
+        try:
+            # rank 0 draws the RCCL unique id; the launcher's process group is only the side channel for it
+            box = [_native.Comm.unique_id() if self.rank == 0 else None]
+            dist.broadcast_object_list(box, src=dist.get_global_rank(self.group, 0) if self.group else 0,
+                                       group=self.group)
+            self._comm = _native.Comm(box[0], self.rank, self.world, device=self.device.index or 0)
+            # one probe gather: every rank must see every rank's block in rank order
+            mine = torch.full((16,), self.rank, dtype=torch.uint8, device=self.device)
+            allb = torch.full((16 * self.world,), 255, dtype=torch.uint8, device=self.device)
+            stream = torch.cuda.current_stream().cuda_stream
+            self._comm.allgather(mine.data_ptr(), allb.data_ptr(), 16, stream=stream)
+            torch.cuda.synchronize()
+            want_t = torch.arange(self.world, dtype=torch.uint8, device=self.device).repeat_interleave(16)
+            if not torch.equal(allb, want_t):
+                raise RuntimeError("probe all-gather returned the wrong blocks")
+            return "ncclAllGather (mvdb_allgather_topk, libmvdb.so)"
+        except Exception as e:  # both routes are RCCL over xGMI; say loudly which one is in use
+            print(f"[mvdb] rank {self.rank}: native RCCL communicator unavailable ({e}); "
+                  "using torch.distributed.all_gather_into_tensor", file=sys.stderr, flush=True)
+            self._comm = None
+            return "torch.distributed.all_gather_into_tensor"
+
+    def _all_gather(self, gathered, local):
+        if self._comm is not None:
+            self._comm.allgather(local.buf.data_ptr(), gathered.buf.data_ptr(), local.nbytes,
+                                 stream=torch.cuda.current_stream().cuda_stream)
+        else:
+            dist.all_gather_into_tensor(gathered.buf, local.buf, group=self.group)
 
     # ---- defaults: HIP kernels through the C-ABI ------------------------------------------------
-    def _hip_local_search(self, q, D, I, label_offset):
+    def _hip_local_search(self, q, D, I, label_offset, rows=None, normalize_q=False):
         stream = torch.cuda.current_stream().cuda_stream
-        self.index.search_device(q.data_ptr(), q.shape[0], self.k, D.data_ptr(), I.data_ptr(), stream=stream,
-                                 label_offset=label_offset)
+        k = D.shape[1]
+        if rows is None:
+            self.index.search_device(q.data_ptr(), q.shape[0], k, D.data_ptr(), I.data_ptr(), stream=stream,
+                                     label_offset=label_offset, normalize_q=normalize_q)
+        else:
+            self.index.search_subset_device(q.data_ptr(), q.shape[0], k, rows.data_ptr(), rows.shape[0],
+                                            D.data_ptr(), I.data_ptr(), stream=stream, normalize_q=normalize_q,
+                                            map_labels=True, label_offset=label_offset)
 
     def _hip_merge(self, gathered, D_out, I_out):
         from . import _native
@@ -110,19 +169,28 @@ class ShardedSearcher:
             self._bufs[nq] = b
         return b
 
-    def search_device(self, q):
-        """q: [nq, d] float32 tensor on this rank's device (identical on every rank).
+    def search_device(self, q, rows=None, normalize_q=False):
+        """q: [nq, d] float32 tensor on this rank's device (identical on every rank); rows: None, or an int64
+        device tensor of this rank's LOCAL row numbers to restrict the scan to (may be empty).
         Returns (D [nq,k], I [nq,k]) device tensors holding the GLOBAL top-k (valid until the next
-        call with the same nq)."""
+        call with the same nq).  Nothing on this path touches the host."""
         nq = q.shape[0]
         local, gathered, D_out, I_out = self._buffers(nq)
         D_loc, I_loc = local.views(0)
-        self._local_search(q, D_loc, I_loc, self.label_offset)
+        if rows is None and not normalize_q:
+            self._local_search(q, D_loc, I_loc, self.label_offset)
+        else:
+            self._local_search(q, D_loc, I_loc, self.label_offset, rows=rows, normalize_q=normalize_q)
         if self.world == 1:
             return D_loc, I_loc
-        dist.all_gather_into_tensor(gathered.buf, local.buf, group=self.group)
+        self._all_gather(gathered, local)
         self._merge(gathered, D_out, I_out)
         return D_out, I_out
+
+    def close(self):
+        if self._comm is not None:
+            self._comm.close()
+            self._comm = None
 
 
 class DistributedShardedVectorDatabase:
@@ -134,17 +202,17 @@ class DistributedShardedVectorDatabase:
     numbers are the reference's stacking order, sharded_vector_database.py:45-71) but keeps only the
     embeddings of its own contiguous run of shard files (``shard_files_for_rank``) resident in HBM.
     ``find_most_similar`` is SPMD: every rank calls it with the same arguments and gets the same,
-    global answer — local scan (full, or restricted to the filtered rows this rank owns), ONE
-    all-gather of the per-shard top-k, k-way merge on every rank.  Exact score ties resolve to the
-    lower global row number.  Writes are not supported in this mode (build the directory with
-    ``ShardedVectorDatabase``); k <= 64 (the merge kernel's limit).
+    global answer — local scan (full, or restricted to the filtered rows this rank owns) written straight
+    into the packed exchange block on the device, ONE all-gather of the per-shard top-k, k-way merge on
+    every rank, one copy of the k results to the host.  Exact score ties resolve to the lower global row
+    number.  Writes are not supported in this mode (build the directory with ``ShardedVectorDatabase``);
+    world * k <= 16384 (one block sorts the gathered lists in LDS).
 
-    `index_factory` / `merge` exist for the world_size-2 ``gloo`` test on CPU.
+    `index_factory` / `local_search` / `merge` exist for the world_size-2 ``gloo`` test on CPU.
     """
 
     def __init__(self, storage_dir='db_shards', rank=None, world=None, device=None, group=None,
-                 index_factory=None, merge=None):
-        import os
+                 index_factory=None, local_search=None, merge=None):
         import pickle
         from collections import defaultdict
 
@@ -208,6 +276,7 @@ class DistributedShardedVectorDatabase:
             self.index = index_factory(self.embedding_size)
             if pieces:
                 self.index.add(np.ascontiguousarray(np.concatenate(pieces, axis=0)), normalize=True)
+        self._local_search = local_search
         self._merge = merge
         self._searchers = {}
 
@@ -218,13 +287,10 @@ class DistributedShardedVectorDatabase:
         s = self._searchers.get(k)
         if s is None:
             s = ShardedSearcher(self.index, k, rank=self.rank, world=self.world, label_offset=self.first_row,
-                                device=self.device, group=self.group, local_search=self._fill_local, merge=self._merge)
+                                device=self.device, group=self.group, local_search=self._local_search,
+                                merge=self._merge)
             self._searchers[k] = s
         return s
-
-    def _fill_local(self, q, D, I, label_offset):
-        D.copy_(torch.from_numpy(self._local_D))
-        I.copy_(torch.from_numpy(self._local_I))
 
     def find_most_similar(self, embedding, metadata_filter=None, exclude_filter=None, or_filters=None, k=5,
                           autocut=False):
@@ -232,30 +298,21 @@ class DistributedShardedVectorDatabase:
         n_total = len(self.unique_ids)
         if n_total == 0 or self.index is None:
             return [], [], []
-        q = np.array([np.array(embedding, dtype=np.float32)])
+        q = np.array([np.array(embedding, dtype=np.float32)])  # query prep of sharded_vector_database.py:602-604
         filtered = self._filters._get_filtered_indices(metadata_filter, exclude_filter, or_filters)
         if not filtered:
             return [], [], []
         search_k = min(k, len(filtered))
-        if search_k > 64:
-            raise NotImplementedError("DistributedShardedVectorDatabase merges at most 64 results per query")
-        lo, hi = self.first_row, self.first_row + self.local_rows
-        miss_d, miss_i = np.float32(-3.4028234663852886e38), -1
-        D = np.full((1, search_k), miss_d, np.float32)
-        I = np.full((1, search_k), miss_i, np.int64)
-        if len(filtered) == n_total:
-            if self.local_rows:
-                kk = min(search_k, self.local_rows)
-                Dl, Il = self.index.search(q, kk, normalize_q=True)
-                D[0, :kk], I[0, :kk] = Dl[0], np.where(Il[0] >= 0, Il[0] + lo, -1)
-        else:
-            mine = np.array(sorted(r for r in filtered if lo <= r < hi), dtype=np.int64)
-            if mine.size:
-                kk = min(search_k, mine.size)
-                Dl, Il = self.index.search_subset(q, kk, mine - lo, normalize_q=True)
-                D[0, :kk], I[0, :kk] = Dl[0], np.where(Il[0] >= 0, mine[np.maximum(Il[0], 0)], -1)
-        self._local_D, self._local_I = D, I
-        Dg, Ig = self._searcher(search_k).search_device(torch.from_numpy(q))
+        if self.world * search_k > 16384:
+            raise NotImplementedError("DistributedShardedVectorDatabase merges at most 16384 / world results per query")
+        q_dev = torch.from_numpy(q).to(self.device)
+        rows = None
+        if len(filtered) != n_total:
+            # the filtered rows this rank owns, as LOCAL row numbers, ascending (ties -> lower global row)
+            lo, hi = self.first_row, self.first_row + self.local_rows
+            mine = np.array(sorted(r for r in filtered if lo <= r < hi), dtype=np.int64) - lo
+            rows = torch.from_numpy(mine).to(self.device)
+        Dg, Ig = self._searcher(search_k).search_device(q_dev, rows=rows, normalize_q=True)
         Dg, Ig = Dg.cpu().numpy()[0], Ig.cpu().numpy()[0]
         found = [(self.unique_ids[i], d, self.metadata[i]) for i, d in zip(Ig, Dg) if i >= 0]
         ids, distances, metadatas = zip(*found) if found else ([], [], [])

@@ -101,7 +101,10 @@ class VectorDatabase(FilterAndRerankMixin):
             if unique_id not in self.inverse_id_map:
                 raise ValueError("Unique ID does not exist.")
             row_num = self.inverse_id_map[unique_id]
-            return self._mat.view[row_num]
+            # a copy: the reference hands out a view of an array that np.delete/np.vstack REPLACE on every
+            # write (vector_database.py:72,126), so an earlier result never changes under the caller; the
+            # growable buffer here is edited in place
+            return self._mat.view[row_num].copy()
 
     def store_embedding(self, unique_id, embedding, metadata_dict={}):
         with self.lock:

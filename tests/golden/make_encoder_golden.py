@@ -22,7 +22,10 @@ CASES = [  # (config, weight seed, B, S, input seed)
     ("e5-small-dims", 10, 2, 130, 8),  # more than one attention key tile / query tile
     ("xlmr-large-dims", 12, 3, 70, 9),  # H = 1024 row kernels, head_dim 64 attention, XLM-R positions
     ("e5-small-dims", 10, 2, 512, 13),  # the reference's truncation cap (max_length = 512)
+    ("e5-small-dims", 10, 256, 32, 31),  # BASELINE config 5's batch: 256 ragged sentences (embeddings only)
+    ("xlmr-large-dims", 12, 4, 33, 41),  # bge-m3: CLS state of XLMRobertaModel, right-padded batch
 ]
+EMB_ONLY = {8}  # cases whose hidden states are not stored (size)
 
 
 def main():
@@ -39,7 +42,13 @@ def main():
         out[f"case{i}_ids"] = ids
         out[f"case{i}_mask"] = mask
         out[f"case{i}_emb"] = emb.astype(np.float32)
-        out[f"case{i}_hidden_valid"] = hidden[m].astype(np.float32)
+        if i not in EMB_ONLY:
+            out[f"case{i}_hidden_valid"] = hidden[m].astype(np.float32)
+        if cfg["model_type"] != "bert":
+            # FlagEmbedding's BGEM3FlagModel.encode(...)['dense_vecs'] (minivectordb/embedding_model.py:74-78):
+            # last_hidden_state[:, 0] of the XLM-R encoder, L2-normalised
+            cls = hidden[:, 0]
+            out[f"case{i}_cls_emb"] = (cls / np.linalg.norm(cls, axis=1, keepdims=True)).astype(np.float32)
     np.savez_compressed(os.path.join(HERE, "encoder_golden.npz"), **out)
     print("wrote encoder_golden.npz", os.path.getsize(os.path.join(HERE, "encoder_golden.npz")))
 

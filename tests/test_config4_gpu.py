@@ -1,0 +1,96 @@
+"""BASELINE config 4 under -m gpu: "80M x 512 fp32 sharded across 8 x MI355X, RCCL all-gather top-k, k = 10".
+The driver's fresh box has ONE GPU, so two halves are checked here:
+
+  * the whole 80M x 512 corpus (163.84 GB of the 288 GB) resident on one GPU — every row of the config is scanned
+    by every search path, needles planted past row 80,000,000 must come back first, nq = 1 / 32 / 128 must agree;
+  * bench.py's N > 1 code path (local scan -> all-gather of packed top-k -> k-way merge kernel -> global q/s) as
+    two child processes sharing the GPU over gloo (RCCL refuses two ranks on one device), merged ids compared with
+    a single index holding both shards.
+
+The 8-GPU run itself is the driver's (SCALE_rNN.json).  Reference contract: top-k of the union of all shards
+(minivectordb/sharded_vector_database.py:598-662)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from oracle import flat
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_config4_whole_corpus_80m_x_512_on_one_gpu(gpu):
+    from minivectordb_amd import _native as native
+    n, d, k, nq = 80_000_000, 512, 10, 128
+    idx = native.FlatIndex(d, device=0)
+    idx.reserve(n + nq)     # one allocation: growing by reallocation would need old + new side by side
+    for first in range(0, n, 10_000_000):   # the 8 shards of the config, back to back
+        idx.add_synthetic(10_000_000, 1234, first_row=first, normalize=True)
+    q = flat.synth(nq, d, 5678)
+    flat.normalize_l2(q)
+    idx.add(q, normalize=True)              # needles: rows n .. n+nq-1 hold the queries themselves
+    assert idx.ntotal == n + nq
+    want = n + np.arange(nq)
+    reruns = native.split_rerun_count()
+    results = {}
+    for label, qs in (("batch128", q), ("batch32", q[:32]), ("single", q[:1])):
+        D, I = idx.search(qs, k)
+        assert np.array_equal(I[:, 0], want[:len(qs)]), (label, I[:4, :3])
+        assert np.allclose(D[:, 0], 1.0, atol=1e-5)
+        assert (I >= 0).all() and (I < n + nq).all() and (np.diff(D, axis=1) <= 0).all()
+        for i in (0, len(qs) - 1):          # returned scores == float64 dot products of the rows fetched back
+            rows = np.stack([idx.get_rows(int(r), 1)[0] for r in I[i]])
+            ref = rows.astype(np.float64) @ qs[i].astype(np.float64)
+            assert np.abs(ref - D[i]).max() <= 1e-4, (label, i)
+        results[label] = (D, I)
+    assert native.split_rerun_count() == reruns
+    # the three paths (split-precision 128, split-precision 32, exact fp32 GEMV) agree id for id
+    assert np.array_equal(results["batch128"][1][:32], results["batch32"][1])
+    assert np.array_equal(results["batch128"][1][:1], results["single"][1])
+    np.testing.assert_allclose(results["batch128"][0][:32], results["batch32"][0], atol=2e-6, rtol=0)
+    # rows from every one of the 8 shards show up among the results (the scan really covers 80M rows)
+    shards = set((results["batch128"][1][:, 1:] // 10_000_000).ravel().tolist())
+    assert shards >= set(range(8)), shards
+    idx.close()
+
+
+def test_config4_two_rank_bench_path_on_a_shared_gpu(gpu, tmp_path):
+    from minivectordb_amd import _native as native
+    rows, d, k, steps, warmup = 1_000_000, 512, 10, 12, 2
+    dump = str(tmp_path / "dump.npz")
+    env = dict(os.environ, MVDB_BENCH_SHARE_GPU="1", MVDB_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    port = 23000 + os.getpid() % 4000
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", str(steps),
+           "--warmup", str(warmup), "--rows", str(rows), "--dim", str(d), "--k", str(k), "--dump", dump]
+    p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["corpus_rows"] == 2 * rows
+    # headline = queries/s over the WHOLE corpus (not shard passes summed over ranks)
+    assert out["value"] == pytest.approx(steps / (out["ms_per_step"] * steps / 1e3), rel=1e-3)
+    assert out["shard_passes_per_s"] == pytest.approx(2 * out["value"], rel=1e-3)
+    assert out["roofline"]["peak"] == 16000.0 and len(out["roofline"]["per_rank_avg_launch_ms"]) == 2
+    assert out["collective"].startswith("torch.distributed")   # gloo group: the RCCL route is not selectable here
+    z = np.load(dump)
+    assert int(z["world"]) == 2 and int(z["rows_per_rank"]) == rows
+    # the same corpus in ONE index: rank r generated rows [r * rows, (r + 1) * rows) of stream 1234
+    idx = native.FlatIndex(d, device=0)
+    idx.add_synthetic(rows, 1234, first_row=0, normalize=True)
+    idx.add_synthetic(rows, 1234, first_row=rows, normalize=True)
+    qall = flat.synth(warmup + steps, d, 5678)
+    flat.normalize_l2(qall)
+    seen_shards = set()
+    for s in range(z["I"].shape[0]):
+        D1, I1 = idx.search(qall[warmup + s], k)
+        assert np.array_equal(z["I"][s, 0], I1[0]), (s, z["I"][s, 0], I1[0])
+        np.testing.assert_allclose(z["D"][s, 0], D1[0], atol=2e-6, rtol=0)
+        seen_shards |= set((I1[0] // rows).tolist())
+    assert seen_shards == {0, 1}
+    idx.close()

@@ -1,0 +1,78 @@
+"""BASELINE config 5 under -m gpu: "e5-small embedding forward (batch 256 sentences) on MI355X MFMA + 10M x 384 kNN
+end-to-end".  The 256-sentence batch is a committed golden (transformers' BertModel on CPU, tests/golden/
+make_encoder_golden.py); the embeddings never leave the device between mvdb_encoder_forward_device and
+mvdb_index_search_device; the corpus is the synthetic stream (10M x 384, generated on the device) with copies of
+8 of the embeddings planted behind it.  Reference path: minivectordb/embedding_model.py:62-71 ->
+vector_database.py:473-497."""
+import numpy as np
+import pytest
+
+from encoder_cases import load_cases
+from oracle import encoder as E
+
+pytestmark = pytest.mark.gpu
+
+
+def test_config5_encoder_batch256_then_knn_10m_x_384(gpu):
+    import torch
+    from minivectordb_amd import _native as native
+    from minivectordb_amd.embedding_model import GpuEncoder
+
+    case = next(c for c in load_cases() if c["B"] == 256)
+    assert case["name"] == "e5-small-dims" and case["S"] == 32
+    cfg = E.make_config(case["name"])
+    w = E.make_weights(cfg, case["wseed"])
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_stream(torch.cuda.Stream(dev))
+    enc = GpuEncoder(cfg, {k: torch.from_numpy(v) for k, v in w.items()}, device=0)
+    ids = torch.from_numpy(case["ids"]).to(dev)
+    mask = torch.from_numpy(case["mask"]).to(dev)
+    emb, _ = enc.forward_device(ids, mask)
+    torch.cuda.synchronize()
+    emb_host = emb.cpu().numpy()
+    np.testing.assert_allclose(emb_host, case["emb"], atol=2e-5, rtol=0)      # vs transformers, all 256 rows
+
+    n, d, k, B = 10_000_000, 384, 10, 256
+    idx = native.FlatIndex(d, device=0)
+    idx.reserve(n + 8)
+    idx.add_synthetic(n, 1234, normalize=True)
+    needles = [0, 1, 31, 100, 127, 128, 200, 255]
+    idx.add(emb_host[needles], normalize=True)                                 # rows n .. n+7
+    assert idx.ntotal == n + 8
+
+    D = torch.empty((B, k), dtype=torch.float32, device=dev)
+    I = torch.empty((B, k), dtype=torch.int64, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    reruns = native.split_rerun_count()
+    native.prof_enable(True)
+    try:
+        for name in ("ip_scan_split_seed", "ip_scan_split"):
+            native.prof_read(name)
+        # the chain: encoder output tensor -> search, same stream, nothing touches the host in between
+        emb2, _ = enc.forward_device(ids, mask)
+        idx.search_device(emb2.data_ptr(), B, k, D.data_ptr(), I.data_ptr(), stream=stream)
+        torch.cuda.synchronize()
+        assert native.prof_read("ip_scan_split_seed")[0] == 2, "256 queries = two 128-query split-precision passes"
+    finally:
+        native.prof_enable(False)
+    assert native.split_rerun_count() == reruns, "random corpus: every query must certify"
+    Dh, Ih = D.cpu().numpy(), I.cpu().numpy()
+    for j, b in enumerate(needles):                                            # needles first
+        assert Ih[b, 0] == n + j, (b, Ih[b, :3], Dh[b, :3])
+        assert abs(Dh[b, 0] - 1.0) < 1e-5
+    assert (Ih >= 0).all() and (np.diff(Dh, axis=1) <= 0).all()
+    for b in range(B):
+        assert len(set(Ih[b].tolist())) == k
+    # returned scores == float64 dot products of the rows fetched back (<= 1e-4), on a sample of queries
+    sample = [0, 1, 77, 128, 129, 255]
+    for b in sample:
+        rows = np.stack([idx.get_rows(int(r), 1)[0] for r in Ih[b]])
+        ref = rows.astype(np.float64) @ emb_host[b].astype(np.float64)
+        assert np.abs(ref - Dh[b]).max() <= 1e-4
+    # batch == per-query (the exact fp32 single-query scan) ids
+    for b in sample:
+        D1, I1 = idx.search(emb_host[b], k)
+        assert np.array_equal(I1[0], Ih[b]), (b, I1[0], Ih[b])
+        np.testing.assert_allclose(D1[0], Dh[b], atol=2e-6, rtol=0)
+    idx.close()
+    enc.close()

@@ -103,6 +103,8 @@ QUERIES = [
     dict(k=7, metadata_filter={"price": {"$gte": 40}}, autocut=True),
     dict(k=3, metadata_filter={"nokey": 1}),
     dict(k=64),
+    dict(k=90),                                        # > 64 results and > rows per shard: the sorted-merge path
+    dict(k=80, metadata_filter={"colour": "green"}),   # more than the filter passes
 ]
 
 
@@ -142,7 +144,31 @@ def _dist_worker(rank, world, port, path, out_dir):
     from minivectordb_amd.distributed import DistributedShardedVectorDatabase
     from oracle import flat
     from oracle_backend import OracleIndex
-    db = DistributedShardedVectorDatabase(path, device=torch.device("cpu"), index_factory=OracleIndex, merge=_np_merge)
+    holder = {}
+
+    def local_search(q, D, I, label_offset, rows=None, normalize_q=False):
+        # CPU stand-in of mvdb_index_search_device / mvdb_index_search_subset_device(map_labels=1): same contract
+        index, k = holder["db"].index, D.shape[1]
+        miss_d, miss_i = np.float32(-3.4028234663852886e38), -1
+        Dl = np.full((q.shape[0], k), miss_d, np.float32)
+        Il = np.full((q.shape[0], k), miss_i, np.int64)
+        if rows is None:
+            kk = min(k, index.ntotal)
+            if kk:
+                d_, i_ = index.search(q.numpy(), kk, normalize_q=normalize_q)
+                Dl[:, :kk], Il[:, :kk] = d_, np.where(i_ >= 0, i_ + label_offset, -1)
+        elif rows.numel():
+            r = rows.numpy()
+            kk = min(k, r.size)
+            d_, p_ = index.search_subset(q.numpy(), kk, r, normalize_q=normalize_q)
+            Dl[:, :kk], Il[:, :kk] = d_, np.where(p_ >= 0, r[np.maximum(p_, 0)] + label_offset, -1)
+        D.copy_(torch.from_numpy(Dl))
+        I.copy_(torch.from_numpy(Il))
+
+    db = DistributedShardedVectorDatabase(path, device=torch.device("cpu"), index_factory=OracleIndex,
+                                          local_search=local_search, merge=_np_merge)
+    holder["db"] = db
+    assert db._searcher(5).collective == "torch.distributed.all_gather_into_tensor"
     assert db.world == world and db.local_rows > 0
     q = flat.synth(len(QUERIES), 48, 654)
     res = []

@@ -34,9 +34,17 @@ def test_encoder_matches_transformers_golden(i, gpu):
     np.testing.assert_allclose(out.cpu().numpy(), emb, atol=0, rtol=0)  # host and device entry points agree
     hidden = hidden.cpu().numpy()
     m = c["mask"].astype(bool)
-    np.testing.assert_allclose(hidden[m], c["hidden_valid"], atol=1e-4, rtol=0)
+    if c["hidden_valid"] is not None:
+        np.testing.assert_allclose(hidden[m], c["hidden_valid"], atol=1e-4, rtol=0)
     assert not hidden[~m].any()
     enc.close()
+    if c["cls_emb"] is not None:
+        # bge-m3 dense path (minivectordb/embedding_model.py:73-79): CLS pooling of the same XLM-R encoder, pinned
+        # by transformers' XLMRobertaModel last_hidden_state[:, 0] (normalised as FlagEmbedding does)
+        from minivectordb_amd.embedding_model import GpuEncoder
+        encc = GpuEncoder(cfg, {k: torch.from_numpy(v) for k, v in w.items()}, device=0, pooling="cls")
+        np.testing.assert_allclose(encc.forward(c["ids"], c["mask"]), c["cls_emb"], atol=2e-5, rtol=0)
+        encc.close()
 
 
 def test_encoder_matches_float64_and_live_transformers(gpu):

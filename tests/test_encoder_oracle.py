@@ -12,7 +12,7 @@ CASES = load_cases()
 @pytest.mark.parametrize("i", range(len(CASES)))
 def test_restatement_matches_transformers_golden(i):
     c = CASES[i]
-    if c["name"] == "e5-small-dims" and c["S"] > 64:
+    if c["name"] == "e5-small-dims" and (c["S"] > 64 or c["B"] > 16):
         pytest.skip("kept for the GPU suite (slow in float64 numpy)")
     cfg = E.make_config(c["name"])
     w = E.make_weights(cfg, c["wseed"])
@@ -20,7 +20,11 @@ def test_restatement_matches_transformers_golden(i):
     assert np.array_equal(ids, c["ids"]) and np.array_equal(mask, c["mask"])  # generators are stable
     hidden, emb = E.numpy_forward(cfg, w, ids, mask)
     np.testing.assert_allclose(emb, c["emb"], atol=2e-6, rtol=0)
-    np.testing.assert_allclose(hidden[mask.astype(bool)], c["hidden_valid"], atol=5e-5, rtol=0)
+    if c["hidden_valid"] is not None:
+        np.testing.assert_allclose(hidden[mask.astype(bool)], c["hidden_valid"], atol=5e-5, rtol=0)
+    if c["cls_emb"] is not None:  # bge-m3 dense vector: normalised CLS state
+        cls = hidden[:, 0] / np.linalg.norm(hidden[:, 0], axis=1, keepdims=True)
+        np.testing.assert_allclose(cls, c["cls_emb"], atol=2e-6, rtol=0)
 
 
 def test_batched_row_equals_single_sentence():

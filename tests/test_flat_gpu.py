@@ -570,6 +570,57 @@ def test_split_precision_pass_unnormalised_rows_and_queries(native, monkeypatch)
     idx.close()
 
 
+def _graded_rows(q, cosines, rs):
+    """Unit rows whose score against unit query q is cosines[j] (to fp32 rounding): c q + sqrt(1 - c^2) w, w _|_ q."""
+    d = q.shape[0]
+    q64 = q.astype(np.float64)
+    q64 /= np.linalg.norm(q64)
+    out = np.empty((len(cosines), d), np.float32)
+    for j, c in enumerate(cosines):
+        w = rs.randn(d)
+        w -= (w @ q64) * q64
+        w /= np.linalg.norm(w)
+        out[j] = (c * q64 + np.sqrt(1.0 - c * c) * w).astype(np.float32)
+    return out
+
+
+@pytest.mark.parametrize("d", [512, 1024])
+@pytest.mark.parametrize("spacing,must_rerun", [(2.0e-5, True), (5.0e-6, True), (2.0e-4, False)])
+def test_split_certificate_at_the_margin(native, d, spacing, must_rerun):
+    """Rows engineered to sit within +-eps(d) of the k-th score (30 rows graded `spacing` apart around 0.9): the
+    pass must either certify a correct answer or re-run the chunk — never return a wrong id.  With 2e-5 / 5e-6
+    steps more than 16 - k rows lie inside the margin (eps(512) = 2.3e-4), so the certificate MUST refuse; with
+    2e-4 steps the 16th nominee is 1.2e-3 below the k-th result and the pass must certify on its own."""
+    n, k, nq = 20000, 10, 40
+    rs = np.random.RandomState(d + int(spacing * 1e7))
+    x = _corpus(n, d)
+    q = _corpus(nq, d, seed=4242)
+    cos = 0.9 - spacing * np.arange(30)
+    for qi, base in ((0, 500), (17, 9000), (39, 15000)):
+        rows = _graded_rows(q[qi], cos, rs)
+        order = rs.permutation(30)            # row numbers must not follow the score order
+        x[base:base + 30] = rows[order]
+    idx = native.FlatIndex(d)
+    idx.add(x)                                # raw add: max|x| measured on the device (1 + 1e-6)
+    eps = native.split_eps(d)
+    assert 3 * 2.0 ** -16 < eps < 1e-3
+    before = native.split_rerun_count()
+    D, I = idx.search(q, k)
+    reran = native.split_rerun_count() - before
+    assert (reran >= 1) == must_rerun, (reran, eps)
+    x64 = x.astype(np.float64)
+    for qi in range(nq):
+        t = x64 @ q[qi].astype(np.float64)
+        want = np.argsort(-t, kind="stable")[:k]
+        if spacing >= 1e-5 or qi not in (0, 17, 39):
+            assert I[qi].tolist() == want.tolist(), (qi, I[qi], want)
+        else:   # 5e-6 steps: fp32 re-scores (1e-7) still order them; float64 adjudicates anything closer
+            ok, msg = flat.adjudicate(x, q[qi], k, D[qi], I[qi], tol=TOL)
+            assert ok, msg
+        np.testing.assert_allclose(D[qi], t[I[qi]], atol=TOL, rtol=0)
+    idx.close()
+
+
 def test_split_precision_pass_falls_back_when_it_cannot_certify(native, monkeypatch):
     """40 copies of each query's best row: more than 16 - k rows tie with the k-th score, the certificate fails
     and the chunk is re-run on the exact kernels; ties still resolve to the lowest row numbers."""

@@ -3,8 +3,12 @@
     |q.x - (qh.xh + qh.xl + ql.xh)| <= 3 * 2^-16 * sum|q_i x_i| <= 4.6e-5 * |q| * |x|
 
 with (h, l) the bf16 round-to-nearest-even split of an fp32 value.  Checked here in numpy (bf16 emulated bit-exactly,
-sums in float64 so that only the operand error is measured) on random and adversarial inputs; the GPU kernels add the
-fp32 accumulation error, which kSplitEps = 1e-4 leaves room for.
+sums in float64 so that only the operand error is measured) on random and adversarial inputs.
+
+The certificate itself uses eps(d) (mvdb.hip: split_eps, exported as mvdb_split_eps): operand term + the WORST-CASE
+fp32 accumulation of the 3 d products in any order + the fp32 re-score + |q| and comparison rounding.  The second
+half of this file restates that formula, pins the library's value to it, and checks it against emulations of the
+matrix cores' accumulation (sequential fp32 chains in the kernel's product order, rounded to nearest and truncated).
 """
 import numpy as np
 import pytest
@@ -62,3 +66,91 @@ def test_bf16_rne_matches_torch():
     x = (rs.randn(10000) * 10.0 ** rs.randint(-10, 10, 10000)).astype(np.float32)
     want = torch.from_numpy(x).to(torch.bfloat16).to(torch.float32).numpy()
     assert np.array_equal(bf16_rne(x), want)
+
+
+# ---- eps(d): the whole certificate bound -----------------------------------------------------------------------------
+def split_eps(d):
+    """Restatement of mvdb.hip: split_eps (per unit |q| * max|x|)."""
+    u8, u16, u23, u24 = 2.0 ** -8, 2.0 ** -16, 2.0 ** -23, 2.0 ** -24
+    e_op = u16 * ((1 + u16) + (1 + u8) ** 2 + 1)
+    n = 3.0 * d
+    e_acc = n * u23 / (1 - n * u23) * (1 + u8) ** 2 * (1 + 2 * u8)
+    depth = ((d + 3) // 4 + 63) // 64 * 4 + 6
+    e_re = depth * u24 / (1 - depth * u24)
+    return (e_op + e_acc + e_re) * (1 + 4e-6) + 4 * u24
+
+
+@pytest.mark.parametrize("d", [32, 64, 128, 256, 384, 512, 768, 1024, 4096])
+def test_library_eps_is_the_documented_formula(d):
+    from minivectordb_amd import _native
+    got = _native.split_eps(d)          # host-only entry point: no device needed
+    assert got == pytest.approx(split_eps(d), rel=1e-12)
+    # the operand term alone (4.6e-5) is not enough: the bound must grow with d
+    assert got > 3 * 2.0 ** -16 + 3 * d * 2.0 ** -24
+    if d >= 64:
+        assert _native.split_eps(d) > _native.split_eps(d // 2)
+
+
+def _fp32_chain(terms, mode):
+    """Sequential fp32 accumulation of float64 `terms` [..., n] along the last axis.  mode 'rne': every addition
+    rounded to nearest (IEEE); 'trunc': every addition truncated toward zero at fp32 width (the pessimistic model of
+    a matrix-core adder)."""
+    acc = np.zeros(terms.shape[:-1], dtype=np.float32)
+    for i in range(terms.shape[-1]):
+        exact = acc.astype(np.float64) + terms[..., i]
+        r = exact.astype(np.float32)
+        if mode == "trunc":
+            over = np.abs(r.astype(np.float64)) > np.abs(exact)
+            r = np.where(over, np.nextafter(r, np.float32(0)), r).astype(np.float32)
+        acc = r
+    return acc
+
+
+def _kernel_order_terms(q, x):
+    """The 3 d products in the order flat_scan_split*_kernel issues them: per 16-element block, xl.qh, xh.ql,
+    xh.qh (scan_split_kernels.hpp: mfma_step); within an instruction the elements are taken in k order."""
+    qh, ql = split(q)
+    xh, xl = split(x)
+    f = lambda a: a.astype(np.float64)
+    d = q.shape[-1]
+    out = []
+    for b in range(0, d, 16):
+        sl = slice(b, b + 16)
+        out += [f(xl[..., sl]) * f(qh[..., sl]), f(xh[..., sl]) * f(ql[..., sl]), f(xh[..., sl]) * f(qh[..., sl])]
+    return np.concatenate(out, axis=-1)
+
+
+def _bound_cases(d):
+    rs = np.random.RandomState(100 + d)
+    unit = lambda a: (a / np.linalg.norm(a.astype(np.float64), axis=-1, keepdims=True)).astype(np.float32)
+    g = unit(rs.randn(24, d))
+    yield "gaussian unit", unit(rs.randn(24, d)), g
+    p = unit(rs.rand(24, d) + 0.5)
+    yield "all positive (every addition rounds the same way)", unit(rs.rand(24, d) + 0.5), p
+    yield "parallel (|q.x| = |q||x|)", g, g
+    m = np.float32(1.0) + np.float32(2.0 ** -8) * (1 - 2.0 ** -10)
+    yield "bf16 midpoints", unit(np.full((2, d), m, np.float32)), unit(np.full((2, d), m, np.float32))
+    big_first = unit(np.sort(rs.rand(8, d).astype(np.float32) ** 4, axis=-1)[:, ::-1].copy())
+    yield "decaying magnitudes", big_first, big_first
+
+
+@pytest.mark.parametrize("d", [512, 1024])
+@pytest.mark.parametrize("mode", ["rne", "trunc"])
+def test_eps_covers_emulated_accumulation(d, mode):
+    """approx (fp32 chain over the kernel's 3 d products) and re-score (fp32 chain over the d exact products) both
+    stay within their share of eps(d) of the real-number score — for nearest and for truncating adders."""
+    eps = split_eps(d)
+    worst = 0.0
+    for name, q, x in _bound_cases(d):
+        t = np.sum(q.astype(np.float64) * x.astype(np.float64), axis=-1)
+        approx = _fp32_chain(_kernel_order_terms(q, x), mode).astype(np.float64)
+        scale = np.linalg.norm(q.astype(np.float64), axis=-1) * np.linalg.norm(x.astype(np.float64), axis=-1)
+        e_nom = np.abs(approx - t) / scale
+        # the re-score: fp32 fused multiply-adds = one rounding per exact product added (a d-deep chain here, deeper
+        # than the kernel's per-lane chains + butterfly)
+        resc = _fp32_chain(q.astype(np.float64) * x.astype(np.float64), "rne").astype(np.float64)
+        e_re = np.abs(resc - t) / scale
+        assert np.all(e_nom + e_re <= eps), (name, mode, float((e_nom + e_re).max()), eps)
+        worst = max(worst, float((e_nom + e_re).max()))
+    # the bound is a worst case, not a fit: it must hold with room, and the operand term alone must NOT explain it
+    assert worst < eps

@@ -116,3 +116,24 @@ def test_hybrid_rerank_results(tmp_path, oracle_backend):
     # ONE string array and the scores are sorted AS STRINGS, so '33.0' ranks above '100.0'
     s3, c3 = db.hybrid_rerank_results(sentences, scores, "quantum physics", k=1, weights=(0.0, 0.0, 1.0))
     assert s3[0] == "dogs are animals" and str(c3[0]) == "33.0"
+
+
+def test_get_vector_result_survives_delete(oracle_backend, tmp_path):
+    """get -> delete -> re-store (rename) must store the vector that was read (the growable host
+    matrix is edited in place, so a live view would silently turn into the following row).  The reference's
+    np.delete allocates a new array, an earlier get_vector result keeps its data (vector_database.py:104,126)."""
+    import numpy as np
+    from minivectordb_amd import VectorDatabase
+    db = VectorDatabase(storage_file=str(tmp_path / "db.pkl"))
+    x = flat.synth(4, 32, 5)
+    for uid, row in zip("abcd", x):
+        db.store_embedding(uid, row)
+    db.find_most_similar(x[0], k=2)          # build: rows are normalised now
+    v = db.get_vector("b")
+    want = v.copy()
+    db.delete_embedding("b")
+    assert np.array_equal(v, want)
+    db.store_embedding("b2", v)
+    db.find_most_similar(x[0], k=2)
+    assert np.allclose(db.get_vector("b2"), want, atol=1e-6)
+    assert not np.allclose(db.get_vector("b2"), db.get_vector("c"), atol=1e-3)
