@@ -39,20 +39,6 @@ struct MfmaScanArgs {
     uint64_t* cand;  // [nq, gridDim.x, k]
 };
 
-// wave-cooperative sorted insert into an LDS list; returns the list's new k-th key
-__device__ __forceinline__ uint64_t lds_list_insert(uint64_t* list, int k, uint64_t key, int lane) {
-    const uint64_t cur = lane < k ? list[lane] : 0ull;
-    const int better = __popcll(__ballot(cur > key));
-    const uint64_t up = __shfl_up(cur, 1);
-    uint64_t nv = cur;
-    if (lane == better)
-        nv = key;
-    else if (lane > better)
-        nv = up;
-    if (lane < k && better < k) list[lane] = nv;
-    return readlane_u64(better < k ? nv : cur, k - 1);
-}
-
 // Offer one 16-row tile's scores to the per-wave, per-query LDS lists.  acc[g][r] of lane l is the score
 // of corpus row (tile*16 + (l&15)) against query g*16 + 4*(l>>4) + r.  thr[g][r] gates (score only);
 // the exact 64-bit order is decided by the insert.  Wave-uniform control flow.

@@ -77,6 +77,20 @@ struct WaveTopK {
     }
 };
 
+// wave-cooperative sorted insert into an LDS list; returns the list's new k-th key
+__device__ __forceinline__ uint64_t lds_list_insert(uint64_t* list, int k, uint64_t key, int lane) {
+    const uint64_t cur = lane < k ? list[lane] : 0ull;
+    const int better = __popcll(__ballot(cur > key));
+    const uint64_t up = __shfl_up(cur, 1);
+    uint64_t nv = cur;
+    if (lane == better)
+        nv = key;
+    else if (lane > better)
+        nv = up;
+    if (lane < k && better < k) list[lane] = nv;
+    return readlane_u64(better < k ? nv : cur, k - 1);
+}
+
 // Merge the sorted lists of all waves of the block into wave 0's list.
 // sh must hold (nwaves-1)*64 keys.  Must be called by every thread of the block.
 __device__ __forceinline__ void block_merge_topk(WaveTopK& tk, uint64_t* sh, int nwaves) {

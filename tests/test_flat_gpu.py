@@ -310,7 +310,7 @@ def test_merge_topk_device_matches_numpy(native):
     from minivectordb_amd.distributed import PackedTopK
     dev = torch.device("cuda", 0)
     rs = np.random.RandomState(0)
-    for world, nq, k in [(8, 1, 10), (2, 5, 7), (8, 3, 64), (3, 2, 1)]:
+    for world, nq, k in [(8, 1, 10), (2, 5, 7), (8, 3, 64), (3, 2, 1), (8, 2, 65), (2, 3, 999), (8, 1, 2048)]:  # k > 64: LDS sort
         g = PackedTopK(nq, k, dev, world)
         lists = []
         for l in range(world):
