@@ -17,6 +17,7 @@
 #include "scan_mfma_kernels.hpp"
 #include "scan_split_kernels.hpp"
 #include "select_kernels.hpp"
+#include "split128.hpp"
 #include "util_kernels.hpp"
 
 using namespace mvdb;
@@ -638,46 +639,82 @@ int launch_split_scan(const mvdb_index* idx, Workspace* ws, const float* q, int 
     a.cand = cand;
     a.thr0 = nullptr;
     a.stats = env_int("MVDB_SPLIT_STATS", 0) ? reinterpret_cast<unsigned int*>(ws->flags.p) + 64 : nullptr;
-    if (a.stats) MVDB_HIP(hipMemsetAsync(a.stats, 0, 8, stream));
+    if (a.stats) MVDB_HIP(hipMemsetAsync(a.stats, 0, 8 + 12 * 8, stream));
     const int64_t seed_tiles = std::min<int64_t>(ntiles, cus);
     {
         a.tile0 = 0;
         a.tile1 = seed_tiles;
         int slot = prof_begin("ip_scan_split_seed", stream);
         hipLaunchKernelGGL(seed_kern, dim3((unsigned)seed_tiles, 1), dim3(kSplitThreads), kSplitLds, stream, a);
-        hipLaunchKernelGGL(split_seed_kernel, dim3(nq), dim3(1024), 0, stream, cand, (int)seed_tiles, seed_keys,
-                           ws->qnorm.p + 128);
+        hipLaunchKernelGGL(split_seed_kernel, dim3(nq), dim3(1024), 0, stream, cand, (int)seed_tiles,
+                           (const uint64_t*)nullptr, seed_keys, ws->qnorm.p + 128);
         prof_end(slot, stream);
         MVDB_HIP(hipGetLastError());
     }
     const uint64_t* seed_arg = seed_keys;
-    a.tile0 = seed_tiles;
-    a.tile1 = ntiles;
     a.thr0 = ws->qnorm.p + 128;
+    // The rest of the corpus is scanned in PHASES of growing size (each covers up to 8x the rows seen before it).
+    // Between phases split_seed_kernel merges the phase's per-block lists into the running 16 best per query and
+    // raises the admission floors to the 16th best of ALL rows seen so far.  A block alone sees only n / CUs rows, so
+    // with the seed launch's floors (16th best of 32k rows) its lists take ~600 inserts per wave over a 10M-row scan
+    // — each one a serial LDS round trip that also stalls the three waves it shares an exchange barrier with (1.4 ms
+    // of a 5.2 ms launch); with floors refreshed after 0.26M and 2.1M rows it takes ~35.
     int gx = 0;
-    if (ntiles == seed_tiles) {
-        // nothing left: the seed list is the nominee list
-    } else if (nq <= 32 && split32_ok(idx)) {
-        // 14..32 queries: per-wave rings, query fragments in registers (flat_scan_split32_kernel), 32-row tiles
-        Split32Args b;
-        b.X = idx->X;
-        b.n = n;
-        b.ld = idx->ld;
-        b.qh = qh;
-        b.ql = ql;
-        b.nq = nq;
-        b.cand = cand;
-        b.tile0 = a.tile0 * 4;
-        b.tile1 = (n + 31) / 32;
-        b.thr0 = a.thr0;
-        MVDB_TRY(launch_split32(idx->d / 16, b, idx->device, stream, &gx));
-    } else {
-        gx = (int)std::max<int64_t>(1, std::min<int64_t>(a.tile1 - a.tile0, (int64_t)cus));
-        int slot = prof_begin("ip_scan_split", stream);
-        hipLaunchKernelGGL(kern, dim3(gx, 1), dim3(kSplitThreads), kSplitLds, stream, a);
-        prof_end(slot, stream);
+    const int phase_growth = std::max(2, env_int("MVDB_SPLIT_PHASE_GROWTH", 8));
+    int64_t covered = seed_tiles;  // 128-row tiles scanned so far
+    while (covered < ntiles) {
+        int64_t upto = ntiles;
+        if (!env_int("MVDB_SPLIT_ONE_PHASE", 0) && covered * phase_growth * 2 <= ntiles) upto = covered * phase_growth;
+        a.tile0 = covered;
+        a.tile1 = upto;
+        const int64_t rows_upto = std::min<int64_t>(n, upto * 128);
+        if (nq <= 32 && split32_ok(idx)) {
+            // 14..32 queries: per-wave rings, query fragments in registers (flat_scan_split32_kernel), 32-row tiles
+            Split32Args b;
+            b.X = idx->X;
+            b.n = rows_upto;
+            b.ld = idx->ld;
+            b.qh = qh;
+            b.ql = ql;
+            b.nq = nq;
+            b.cand = cand;
+            b.tile0 = a.tile0 * 4;
+            b.tile1 = (rows_upto + 31) / 32;
+            b.thr0 = a.thr0;
+            MVDB_TRY(launch_split32(idx->d / 16, b, idx->device, stream, &gx));
+        } else if (split128_supported(idx->d) && !env_int("MVDB_DISABLE_SPLIT128", 0)) {
+            // 33..128 queries: K split over the four waves of a block, query fragments in registers (split128.hip)
+            Split128Args b;
+            b.X = idx->X;
+            b.n = rows_upto;
+            b.ld = idx->ld;
+            b.qh = qh;
+            b.ql = ql;
+            b.nq = nq;
+            b.cand = cand;
+            b.tile0 = a.tile0 * 4;
+            b.tile1 = (rows_upto + 31) / 32;
+            b.thr0 = a.thr0;
+            b.stats = a.stats;
+            MVDB_TRY(launch_split128(idx->d, b, idx->device, stream, &gx));
+        } else {
+            SplitScanArgs c = a;
+            c.n = rows_upto;
+            gx = (int)std::max<int64_t>(1, std::min<int64_t>(a.tile1 - a.tile0, (int64_t)cus));
+            int slot = prof_begin("ip_scan_split", stream);
+            hipLaunchKernelGGL(kern, dim3(gx, 1), dim3(kSplitThreads), kSplitLds, stream, c);
+            prof_end(slot, stream);
+        }
+        MVDB_HIP(hipGetLastError());
+        covered = upto;
+        if (covered < ntiles) {
+            // fold this phase's lists into the running nominees (seed_keys is both an input list and the output)
+            hipLaunchKernelGGL(split_seed_kernel, dim3(nq), dim3(1024), 0, stream, cand, gx, seed_keys, seed_keys,
+                               ws->qnorm.p + 128);
+            MVDB_HIP(hipGetLastError());
+            gx = 0;
+        }
     }
-    MVDB_HIP(hipGetLastError());
     SplitCertifyArgs c;
     c.keys = cand;
     c.nlists = gx;
@@ -696,10 +733,15 @@ int launch_split_scan(const mvdb_index* idx, Workspace* ws, const float* q, int 
     hipLaunchKernelGGL(split_certify_kernel, dim3(nq), dim3(1024), 0, stream, c);
     MVDB_HIP(hipGetLastError());
     if (a.stats) {
-        unsigned int st[2] = {0, 0};
-        MVDB_HIP(hipMemcpyAsync(st, a.stats, 8, hipMemcpyDeviceToHost, stream));
+        unsigned int st[2 + 24] = {0};
+        MVDB_HIP(hipMemcpyAsync(st, a.stats, sizeof(st), hipMemcpyDeviceToHost, stream));
         MVDB_HIP(hipStreamSynchronize(stream));
         fprintf(stderr, "[mvdb split] list inserts %u, slow-path wave-tiles %u (seed + main launch)\n", st[0], st[1]);
+        const unsigned long long* t = reinterpret_cast<const unsigned long long*>(st + 2);
+        if (t[2])  // MVDB_SPLIT128_DBG=2048: s_memtime sums of block 7, per wave
+            for (int w = 0; w < 4; ++w)
+                fprintf(stderr, "[mvdb split128 timers] wave %d: vmcnt wait %llu, DMA issue %llu, stages %llu cycles\n", w,
+                        t[3 * w], t[3 * w + 1], t[3 * w + 2]);
     }
     return 0;
 }
@@ -767,7 +809,7 @@ int search_core(const mvdb_index* idx, Workspace* ws, const float* q_dev, int nq
         if (nchunks > 0) {
             MVDB_TRY(ws->qsplit.reserve((size_t)2 * 128 * idx->d));
             MVDB_TRY(ws->qnorm.reserve(256));  // [0,128): |q|, [128,256): admission floors of the seed pass
-            MVDB_TRY(ws->flags.reserve((size_t)std::max(nchunks, 64) + 4));  // + diagnostics counters at [64]
+            MVDB_TRY(ws->flags.reserve((size_t)std::max(nchunks, 64) + 32));  // + diagnostics counters at [64]
             MVDB_TRY(ws->pin_flags.reserve((size_t)nchunks * sizeof(int)));
             MVDB_TRY(ws->cand.reserve((size_t)128 * (scan_grid_upper_bound(idx->device) + 1) * kSplitKeep));
             MVDB_HIP(hipMemsetAsync(ws->flags.p, 0, (size_t)nchunks * sizeof(int), s));
@@ -976,12 +1018,16 @@ int check_search_args(const mvdb_index* idx, const void* q, int nq, int k, const
     return 0;
 }
 
+// Rows of readable slack allocated behind the matrix: the tiled batch kernels fetch whole 32-row tiles (rows past n - 1
+// are read, scored and never nominated) so that their DMA issue needs no per-lane bounds handling.
+constexpr int64_t kRowSlack = 32;
+
 int grow(mvdb_index* idx, int64_t need) {
     if (need <= idx->cap) return 0;
     int64_t cap = std::max<int64_t>(need, idx->cap + idx->cap / 2);
     cap = std::max<int64_t>(cap, 1024);
     float* nx = nullptr;
-    MVDB_HIP(hipMalloc((void**)&nx, (size_t)cap * idx->ld * sizeof(float)));
+    MVDB_HIP(hipMalloc((void**)&nx, (size_t)(cap + kRowSlack) * idx->ld * sizeof(float)));
     if (idx->n > 0) {
         hipError_t e = hipMemcpy(nx, idx->X, (size_t)idx->n * idx->ld * sizeof(float),
                                  hipMemcpyDeviceToDevice);
@@ -1097,7 +1143,7 @@ int mvdb_index_reserve(mvdb_index* idx, int64_t n) {
     if (n <= idx->cap) return 0;
     // exact-size growth (no 1.5x slack): the caller knows the final size
     float* nx = nullptr;
-    MVDB_HIP(hipMalloc((void**)&nx, (size_t)n * idx->ld * sizeof(float)));
+    MVDB_HIP(hipMalloc((void**)&nx, (size_t)(n + kRowSlack) * idx->ld * sizeof(float)));
     if (idx->n > 0)
         MVDB_HIP(hipMemcpy(nx, idx->X, (size_t)idx->n * idx->ld * sizeof(float),
                            hipMemcpyDeviceToDevice));

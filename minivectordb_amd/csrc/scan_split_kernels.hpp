@@ -613,7 +613,8 @@ __global__ __launch_bounds__(kScanThreads) void flat_scan_split32_kernel(Split32
 // (without the floor each wave re-learns its threshold from scratch: ~7,000 LDS list inserts per wave at 10M rows,
 // more time than the MFMAs).
 __global__ __launch_bounds__(1024) void split_seed_kernel(const uint64_t* __restrict__ keys, int nlists,
-                                                          uint64_t* __restrict__ seed, float* __restrict__ thr0) {
+                                                          const uint64_t* prev, uint64_t* seed, float* __restrict__ thr0) {
+    // prev: NULL, or the [nq][16] running nominees of the earlier phases (may alias `seed`: read before written)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int qi = blockIdx.x;
     const int64_t total = (int64_t)nlists * kSplitKeep;
@@ -624,6 +625,7 @@ __global__ __launch_bounds__(1024) void split_seed_kernel(const uint64_t* __rest
         const int64_t i = base + lane;
         tk.offer(i < total ? src[i] : 0ull);
     }
+    if (prev && wave == 0) tk.offer(lane < kSplitKeep ? prev[(int64_t)qi * kSplitKeep + lane] : 0ull);
     __shared__ uint64_t sh[15 * 64];
     block_merge_topk(tk, sh, 16);
     if (wave == 0) {

@@ -16,6 +16,7 @@ struct Split128Args {
     int64_t tile0;      // 32-row tiles [tile0, tile1)
     int64_t tile1;
     const float* thr0;  // [nq] admission floors of the seed launch, or NULL
+    unsigned int* stats; // NULL, or [2]: list inserts, wave-tiles that reached the slow path (diagnostics)
 };
 
 // true when flat_scan_split128_kernel has an instantiation for dimension d
