@@ -47,21 +47,56 @@ def main():
     flat.normalize_l2(qn)
     Do, Io = flat.flat_search(db.embeddings, qn, 10, nthreads=flat.max_threads())
     assert list(ids) == Io[0].tolist(), (ids, Io[0])
+    # writes followed by a query: the next query uploads only the new row / the delete compacts the device tail
+    app, dele, dele_early = [], [], []
+    for j in range(5):
+        t0 = time.perf_counter()
+        db.store_embedding(f"new{j}", x[j] * 0.5 + x[j + 1], {"bucket": 7})
+        ids2, _, _ = db.find_most_similar(q[j], k=10)
+        app.append(time.perf_counter() - t0)
+    assert ids2 is not None and len(db.inverse_id_map) == n + 5
+    for j, uid in enumerate((123456, 700001, 999999, 500000, 250000)):
+        t0 = time.perf_counter()
+        db.delete_embedding(uid)
+        ids3, _, _ = db.find_most_similar(q[j], k=10)
+        dele.append(time.perf_counter() - t0)
+        assert uid not in ids3
+    for j, uid in enumerate((5, 6, 7)):   # the whole matrix moves up
+        t0 = time.perf_counter()
+        db.delete_embedding(uid)
+        ids3, _, _ = db.find_most_similar(q[j], k=10)
+        dele_early.append(time.perf_counter() - t0)
     t0 = time.perf_counter()
-    db.store_embedding("new", x[0] * 0.5 + x[1], {"bucket": 7})
-    ids2, _, _ = db.find_most_similar(q[0], k=10)
-    t_append_query = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    db.delete_embedding(123456)
-    ids3, _, _ = db.find_most_similar(q[0], k=10)
-    t_delete_query = time.perf_counter() - t0
+    idsf, _, metaf = db.find_most_similar(q[0], k=10, metadata_filter={"bucket": 31})  # first filter after deletes
+    t_filter_after_delete = time.perf_counter() - t0
+    assert all(m["bucket"] == 31 for m in metaf)
+    v = db.get_vector("new0")
+    assert abs(float(np.linalg.norm(v)) - 1.0) < 1e-5   # read back from the device, normalised there
+    t_append_query, t_delete_query = float(np.median(app)), float(np.median(dele))
+    # the device half alone at 10M x 512 (C-ABI): append one row, delete row 5, one query after each
+    from minivectordb_amd import _native
+    big = _native.FlatIndex(d)
+    big.reserve(10_000_100)
+    big.add_synthetic(10_000_000, 1234, normalize=True)
+    big.search(q[0], 10, normalize_q=True)
+    dev = {}
+    t0 = time.perf_counter(); big.add(x[:1], normalize=True); big.search(q[0], 10, normalize_q=True)
+    dev["append_one_then_query_ms"] = round((time.perf_counter() - t0) * 1e3, 2)
+    t0 = time.perf_counter(); big.remove_rows([5]); big.search(q[0], 10, normalize_q=True)
+    dev["delete_row5_then_query_ms"] = round((time.perf_counter() - t0) * 1e3, 2)
+    t0 = time.perf_counter(); big.remove_rows([9_999_000]); big.search(q[0], 10, normalize_q=True)
+    dev["delete_late_row_then_query_ms"] = round((time.perf_counter() - t0) * 1e3, 2)
+    big.close()
     print(json.dumps({
         "config": "VectorDatabase drop-in, 1M x 512, k=10",
         "ingest_s": round(t_ingest, 2), "first_query_ms": round(t_first * 1e3, 1),
         "query_p50_ms": round(float(np.median(lat)) * 1e3, 3), "query_qps": round(1.0 / float(np.mean(lat)), 1),
         "filtered_query_p50_ms (1% of rows, Python filter + device subset search)": round(float(np.median(latf)) * 1e3, 3),
         "append_one_then_query_ms": round(t_append_query * 1e3, 2),
-        "delete_one_then_query_ms": round(t_delete_query * 1e3, 2)}), flush=True)
+        "delete_one_then_query_ms": round(t_delete_query * 1e3, 2),
+        "delete_early_row_then_query_ms": round(float(np.median(dele_early)) * 1e3, 2),
+        "first_filtered_query_after_deletes_ms": round(t_filter_after_delete * 1e3, 2),
+        "device_only_10M_x_512": dev}), flush=True)
 
 
 if __name__ == "__main__":

@@ -33,25 +33,37 @@ class _AllRows:
         return set(range(self.n))
 
 
-class _HostMatrix:
-    """float32 [n,d] matrix with amortised append; `.view` is the ndarray the reference exposes."""
+class _RowStore:
+    """The stacked embedding matrix of a database, WITHOUT a host mirror of what the device already holds.
+
+    Rows [0, synced) live — normalised — in the device index only; rows stored since the last index build wait,
+    un-normalised, in `pending` host blocks and are uploaded by the next build (`flush`).  `materialize` reads the
+    device rows back when somebody asks for the whole matrix (the reference exposes it as ``self.embeddings`` and
+    pickles it), `row` fetches one row (``get_vector``), `delete` compacts the device matrix and/or drops pending
+    rows.  The reference keeps one numpy matrix that it re-stacks on every insert (``np.vstack``,
+    vector_database.py:72) and copies on every delete (``np.delete``, :126); a growable host mirror of that (round 1)
+    still paid a 2 GB copy for an append after a batch load and a host memmove per delete at 1M x 512.
+    """
 
     def __init__(self, d):
         self.d = d
-        self.n = 0
-        self.buf = np.zeros((0, d), dtype=np.float32)
+        self.synced = 0      # leading rows resident on the device
+        self.pending = []    # float32 [m_i, d] blocks stored since the last build, in row order
+        self.npending = 0
+        self._cache = None   # materialised matrix, valid until the next mutation
 
     @classmethod
     def adopt(cls, arr):
         arr = np.ascontiguousarray(arr, dtype=np.float32)
         m = cls(arr.shape[1])
-        m.buf = arr
-        m.n = arr.shape[0]
+        if arr.shape[0]:
+            m.pending.append(arr)
+            m.npending = arr.shape[0]
         return m
 
     @property
-    def view(self):
-        return self.buf[:self.n]
+    def n(self):
+        return self.synced + self.npending
 
     def append(self, rows):
         rows = np.asarray(rows, dtype=np.float32)
@@ -63,33 +75,120 @@ class _HostMatrix:
                 f"all the input array dimensions except for the concatenation axis must match exactly, "
                 f"but along dimension 1, the array at index 0 has size {self.d} and the array at index 1 "
                 f"has size {rows.shape[1]}")
-        need = self.n + rows.shape[0]
-        if need > self.buf.shape[0]:
-            cap = max(need, int(self.buf.shape[0] * 1.5) + 16)
-            nb = np.empty((cap, self.d), dtype=np.float32)
-            nb[:self.n] = self.buf[:self.n]
-            self.buf = nb
-        self.buf[self.n:need] = rows
-        self.n = need
+        self.pending.append(rows)
+        self.npending += rows.shape[0]
+        self._cache = None
 
-    def delete(self, rows):
-        rows = list(rows)
-        if len(rows) == 1:
-            # one row (delete_embedding): shift the tail in place instead of re-copying the matrix
-            r = int(rows[0])
-            tail = self.n - 1 - r
-            if tail > 0:
-                import ctypes
-                row_bytes = self.d * 4
-                base = self.buf.ctypes.data
-                ctypes.memmove(base + r * row_bytes, base + (r + 1) * row_bytes, tail * row_bytes)
-            self.n -= 1
-            return
-        keep = np.ones(self.n, dtype=bool)
-        keep[np.asarray(rows, dtype=np.int64)] = False
-        kept = self.buf[:self.n][keep]
-        self.buf = np.ascontiguousarray(kept)
-        self.n = kept.shape[0]
+    def flush(self, index):
+        """Upload the pending rows (normalised on the device, vector_database.py:45-46) and forget the host copies."""
+        for block in self.pending:
+            index.add(block, normalize=True)
+            self.synced += block.shape[0]
+        if self.pending:
+            self._cache = None
+        self.pending, self.npending = [], 0
+
+    def delete(self, rows, index):
+        """Remove the given stacked row numbers (np.delete semantics: later rows move up)."""
+        rows = sorted(int(r) for r in rows)
+        dev = [r for r in rows if r < self.synced]
+        host = [r - self.synced for r in rows if r >= self.synced]
+        if host:
+            stacked = self.pending[0] if len(self.pending) == 1 else np.vstack(self.pending)
+            kept = np.delete(stacked, host, axis=0)
+            self.pending = [kept] if kept.shape[0] else []
+            self.npending = kept.shape[0]
+        if dev:
+            index.remove_rows(dev)
+            self.synced -= len(dev)
+        self._cache = None
+
+    def row(self, r, index):
+        """A fresh copy of stacked row r (the reference hands out a view of an array that every write REPLACES, so
+        an earlier result never changes under the caller, vector_database.py:72,104,126)."""
+        if r < self.synced:
+            return index.get_rows(r, 1)[0]
+        r -= self.synced
+        for block in self.pending:
+            if r < block.shape[0]:
+                return block[r].copy()
+            r -= block.shape[0]
+        raise IndexError("row out of range")
+
+    def materialize(self, index):
+        if self._cache is None:
+            out = np.empty((self.n, self.d), dtype=np.float32)
+            if self.synced:
+                index.get_rows(0, self.synced, out=out[:self.synced])
+            at = self.synced
+            for block in self.pending:
+                out[at:at + block.shape[0]] = block
+                at += block.shape[0]
+            self._cache = out
+        return self._cache
+
+
+class _IdIndex:
+    """row <-> unique id bookkeeping of VectorDatabase with O(tail memmove) deletes.
+
+    The reference keeps two dicts (``id_map`` row -> id, ``inverse_id_map`` id -> row) and rebuilds both over
+    ``sorted(id_map)`` at every delete (vector_database.py:139-152): a Python loop over every row behind the deleted
+    one, ~0.4 s at 1M rows.  Here the order lives in ONE list (``uids``, row -> id: ``list.pop`` is a C memmove) and
+    ids map to stable HANDLES (insertion counters); the current row of a handle is the handle minus the number of
+    deleted handles below it (bisect over a short sorted list).  The two dicts the reference exposes are produced on
+    demand (`inverse_dict`, `row_dict`) and cached until the next write.
+    """
+
+    def __init__(self, uids=()):
+        import bisect
+        self._bisect = bisect
+        self.uids = list(uids)
+        self.handle = {u: i for i, u in enumerate(self.uids)}
+        self.next = len(self.uids)
+        self.deleted = []       # sorted handles removed since the last compaction
+        self._row_dict = None
+
+    def __len__(self):
+        return len(self.uids)
+
+    def __contains__(self, uid):
+        return uid in self.handle
+
+    def append(self, uid):
+        self.handle[uid] = self.next
+        self.next += 1
+        self.uids.append(uid)
+        self._row_dict = None
+
+    def row(self, uid):
+        h = self.handle[uid]
+        return h - self._bisect.bisect_left(self.deleted, h) if self.deleted else h
+
+    def pop(self, uid):
+        r = self.row(uid)
+        self._bisect.insort(self.deleted, self.handle.pop(uid))
+        self.uids.pop(r)
+        self._row_dict = None
+        if len(self.deleted) > 4096:
+            self.compact()
+        return r
+
+    def compact(self):
+        self.handle = {u: i for i, u in enumerate(self.uids)}
+        self.next = len(self.uids)
+        self.deleted = []
+
+    def inverse_dict(self):
+        """id -> row as a plain dict (what the reference calls inverse_id_map; the filter engine walks it)."""
+        if self.deleted:
+            self.compact()
+        return self.handle
+
+    def row_dict(self):
+        """row -> id as a plain dict (the reference's id_map)."""
+        if self._row_dict is None:
+            self._row_dict = dict(enumerate(self.uids))
+        return self._row_dict
 
 
 class _ExclusionProbe:
@@ -108,26 +207,22 @@ class _ExclusionProbe:
 
 class FilterAndRerankMixin:
     """Needs: self.inverted_index, self.inverse_id_map, self.metadata, self.hash_vectorizer,
-    self._mat, self.index, self._synced_rows, self.embedding_size, self._device."""
+    self._mat (_RowStore), self.index, self.embedding_size, self._device."""
 
     # ---- device mirror -----------------------------------------------------------------------------
     def _build_index(self):
-        """Bring the device matrix up to date with the host matrix (caller holds the lock).
+        """Bring the device matrix up to date (caller holds the lock).
 
-        Reference: IndexFlatIP(d); normalize_L2(self.embeddings) in place; index.add
-        (vector_database.py:42-47).  Only rows appended since the last build are uploaded; they are
-        normalised on the device and read back so the host matrix shows the same normalised rows.
+        Reference: IndexFlatIP(d); normalize_L2(self.embeddings) in place; index.add (vector_database.py:42-47).
+        Only rows stored since the last build are uploaded; they are normalised on the device, which from then on
+        is their only home (`_RowStore`): ``get_vector`` / ``embeddings`` / ``persist_to_disk`` read them back, so the
+        in-place normalisation the reference performs on its host matrix stays visible.
         """
         from . import _native
         if self.index is None:
             self.index = _native.FlatIndex(self.embedding_size, metric=_native.METRIC_IP, device=self._device)
-        n = self._mat.n
-        if n > 0:
-            if self._synced_rows < n:
-                start = self._synced_rows
-                self.index.add(self._mat.buf[start:n], normalize=True)
-                self.index.get_rows(start, n - start, out=self._mat.buf[start:n])  # in-place side effect
-                self._synced_rows = n
+        if self._mat.n > 0:
+            self._mat.flush(self.index)
             self._embeddings_changed = False
 
     # ---- shared ingest / search plumbing ------------------------------------------------------------
@@ -137,19 +232,26 @@ class FilterAndRerankMixin:
         if self.embedding_size is None:
             self.embedding_size = vectors[0].shape[0]
         if self._mat is None:
-            self._mat = _HostMatrix(self.embedding_size)
+            self._mat = _RowStore(self.embedding_size)
         first = self._mat.n
         if len(vectors):
             self._mat.append(vectors[0] if len(vectors) == 1 else np.vstack(vectors))
         self.metadata.extend(metadata_dicts)
-        for row, uid in enumerate(unique_ids, start=first):
-            self.inverse_id_map[uid] = row
+        self._note_ids(unique_ids, first)
         for uid, meta in zip(unique_ids, metadata_dicts):
             for key in meta:
                 self.inverted_index[key].add(uid)
         self._invalidate_filter_cache()
         self._embeddings_changed = True
         return first
+
+    def _row_count(self):
+        return len(self.inverse_id_map)
+
+    def _note_ids(self, unique_ids, first_row):
+        """id -> row bookkeeping of newly admitted rows (the sharded class keeps the reference's plain dict)."""
+        for row, uid in enumerate(unique_ids, start=first_row):
+            self.inverse_id_map[uid] = row
 
     def _subset_order(self, wanted):
         """Enumeration of a filtered row set handed to the device (positions come back).  The flat class
@@ -209,11 +311,12 @@ class FilterAndRerankMixin:
             if fast is not None:
                 return fast
         rows = set()
+        inverse = self.inverse_id_map
         try:
             for uid in self.inverted_index.get(key, set()).copy():
-                if uid not in self.inverse_id_map:
+                if uid not in inverse:
                     continue
-                row = self.inverse_id_map[uid]
+                row = inverse[uid]
                 field = self.metadata[row].get(key, None)
                 if (predicate(field) if predicate is not None else field == value):
                     rows.add(row)
@@ -223,7 +326,10 @@ class FilterAndRerankMixin:
 
     def _rows_equal_cached(self, key, value):
         """Equality filters through a per-key value index built on first use and dropped on every write
-        (`_invalidate_filter_cache`).  The reference walks every id that has `key` for each query
+        (`_invalidate_filter_cache`).  CONTRACT: metadata dicts are treated as immutable once stored — the reference
+        re-reads ``self.metadata[row]`` at every query, so an in-place edit of a stored dict is honoured there and is
+        NOT seen here until the next store / delete (re-checking every hit costs 4 ms per query at 10,000 hits, ten
+        times the search itself).  The reference walks every id that has `key` for each query
         (vector_database.py:283-302: O(N) Python per filtered search); the index keeps, per value, the
         matching rows IN THAT SAME ORDER, so the returned set is built by the same sequence of
         insertions (identical tie order downstream).  Returns None when the value is unhashable."""
@@ -235,10 +341,11 @@ class FilterAndRerankMixin:
         entry = cache.get(key)
         if entry is None:
             by_value, unhashable = {}, []
+            inverse = self.inverse_id_map
             for uid in self.inverted_index.get(key, set()).copy():
-                if uid not in self.inverse_id_map:
+                if uid not in inverse:
                     continue
-                row = self.inverse_id_map[uid]
+                row = inverse[uid]
                 field = self.metadata[row].get(key, None)
                 try:
                     by_value.setdefault(field, []).append(row)
@@ -246,6 +353,8 @@ class FilterAndRerankMixin:
                     unhashable.append((row, field))
             entry = cache[key] = (by_value, unhashable)
         by_value, unhashable = entry
+        if value != value:  # NaN never equals anything under the reference's `==`; a dict lookup matches it by identity
+            return set()
         rows = set(by_value.get(value, ()))
         for row, field in unhashable:
             if field == value:
@@ -283,7 +392,7 @@ class FilterAndRerankMixin:
         return filtered_indices
 
     def _get_filtered_indices(self, metadata_filters, exclude_filter, or_filters):
-        filtered_indices = _AllRows(len(self.inverse_id_map)) if not metadata_filters else None
+        filtered_indices = _AllRows(self._row_count()) if not metadata_filters else None
 
         if isinstance(metadata_filters, dict):
             metadata_filters = [metadata_filters]

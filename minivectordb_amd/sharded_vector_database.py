@@ -19,7 +19,7 @@ from collections import defaultdict
 
 import numpy as np
 
-from ._dbcore import FilterAndRerankMixin, _HostMatrix
+from ._dbcore import FilterAndRerankMixin, _RowStore
 
 
 def shard_files_for_rank(storage_dir, rank, world):
@@ -44,7 +44,6 @@ class ShardedVectorDatabase(FilterAndRerankMixin):
         self.inverse_id_map = {}
         self.inverted_index = defaultdict(set)
         self.index = None
-        self._synced_rows = 0
         self._embeddings_changed = False
         self._device = device
         self.lock = threading.Lock()
@@ -54,12 +53,11 @@ class ShardedVectorDatabase(FilterAndRerankMixin):
 
     @property
     def embeddings(self):
-        return None if self._mat is None else self._mat.view
+        return None if self._mat is None else self._mat.materialize(self.index)
 
     @embeddings.setter
     def embeddings(self, value):
-        self._mat = None if value is None else _HostMatrix.adopt(value)
-        self._synced_rows = 0
+        self._mat = None if value is None else _RowStore.adopt(value)
         if self.index is not None:
             self.index.reset()
         self._embeddings_changed = True
@@ -118,7 +116,7 @@ class ShardedVectorDatabase(FilterAndRerankMixin):
                 self._update_box_item_map(data['unique_ids'], shard_file)
         if pieces:
             # one concatenation instead of the reference's vstack per shard (O(shards^2) copying)
-            self._mat = _HostMatrix.adopt(np.concatenate(pieces, axis=0))
+            self._mat = _RowStore.adopt(np.concatenate(pieces, axis=0))
 
         self.inverse_id_map = {uid: i for i, uid in enumerate(self.unique_ids)}
 
@@ -245,11 +243,7 @@ class ShardedVectorDatabase(FilterAndRerankMixin):
 
             doomed = set(unique_ids)
             rows = sorted({self.inverse_id_map[uid] for uid in doomed})
-            self._mat.delete(rows)
-            on_device = [r for r in rows if r < self._synced_rows]
-            if on_device:
-                self.index.remove_rows(on_device)
-                self._synced_rows -= len(on_device)
+            self._mat.delete(rows, self.index)
             keep = [i for i, uid in enumerate(self.unique_ids) if uid not in doomed]
             self.metadata = [self.metadata[i] for i in keep]
             self.unique_ids = [self.unique_ids[i] for i in keep]

@@ -26,7 +26,7 @@ import threading
 from collections import defaultdict
 import numpy as np
 
-from ._dbcore import FilterAndRerankMixin, _HostMatrix
+from ._dbcore import FilterAndRerankMixin, _IdIndex, _RowStore
 
 
 class VectorDatabase(FilterAndRerankMixin):
@@ -34,30 +34,44 @@ class VectorDatabase(FilterAndRerankMixin):
         self.hash_vectorizer = None  # built lazily (sklearn) by hybrid_rerank_results
         self.embedding_size = None
         self.storage_file = storage_file
-        self._mat = None
+        self._mat = None  # _RowStore: device-resident rows + rows waiting for the next build
         self.metadata = []  # Stores dictionaries of metadata
-        self.id_map = {}  # Maps embedding row number to unique id
-        self.inverse_id_map = {}  # Maps unique id to embedding row number
+        self._ids = _IdIndex()  # row <-> unique id (what the reference keeps as id_map / inverse_id_map)
         self.inverted_index = defaultdict(set)  # Inverted index for metadata
         self.index = None  # device-resident FlatIndex (created on first build)
-        self._synced_rows = 0  # leading host rows mirrored (normalised) on the device
         self._embeddings_changed = False
         self._device = device
         self.lock = threading.Lock()
         self._load_database()
 
-    # ---- the reference exposes the matrix as a plain attribute -----------------------------------
+    # ---- the reference exposes the matrix and both id maps as plain attributes --------------------
     @property
     def embeddings(self):
-        return None if self._mat is None else self._mat.view
+        return None if self._mat is None else self._mat.materialize(self.index)
 
     @embeddings.setter
     def embeddings(self, value):
-        self._mat = None if value is None else _HostMatrix.adopt(value)
-        self._synced_rows = 0
+        self._mat = None if value is None else _RowStore.adopt(value)
         if self.index is not None:
             self.index.reset()
         self._embeddings_changed = True
+
+    @property
+    def id_map(self):
+        """Maps embedding row number to unique id (a dict rebuilt on demand after a write)."""
+        return self._ids.row_dict()
+
+    @property
+    def inverse_id_map(self):
+        """Maps unique id to embedding row number (a dict brought up to date on demand after a delete)."""
+        return self._ids.inverse_dict()
+
+    def _note_ids(self, unique_ids, first_row):
+        for uid in unique_ids:
+            self._ids.append(uid)
+
+    def _row_count(self):
+        return len(self._ids)
 
     def _convert_ndarray_float32(self, ndarray):
         return np.array(ndarray, dtype=np.float32)
@@ -72,14 +86,13 @@ class VectorDatabase(FilterAndRerankMixin):
                 with open(self.storage_file, 'rb') as f:
                     data = pickle.load(f)
                 emb = data['embeddings']
-                self._mat = None if emb is None else _HostMatrix.adopt(emb)
+                self._mat = None if emb is None else _RowStore.adopt(emb)
                 self.embedding_size = emb.shape[1] if emb is not None else None
                 self.metadata = data['metadata']
-                self.id_map = data['id_map']
-                self.inverse_id_map = data['inverse_id_map']
+                id_map = data['id_map']
+                self._ids = _IdIndex(id_map[i] for i in range(len(id_map)))
                 self.inverted_index = data.get('inverted_index', defaultdict(set))
                 self._invalidate_filter_cache()
-                self._synced_rows = 0
                 if self.embedding_size is not None:
                     self._build_index()
 
@@ -87,10 +100,10 @@ class VectorDatabase(FilterAndRerankMixin):
         with self.lock:
             with open(self.storage_file, 'wb') as f:
                 data = {
-                    'embeddings': None if self._mat is None else np.array(self._mat.view),
+                    'embeddings': None if self._mat is None else np.array(self._mat.materialize(self.index)),
                     'metadata': self.metadata,
-                    'id_map': self.id_map,
-                    'inverse_id_map': self.inverse_id_map,
+                    'id_map': dict(self._ids.row_dict()),
+                    'inverse_id_map': dict(self._ids.inverse_dict()),
                     'inverted_index': self.inverted_index
                 }
                 pickle.dump(data, f)
@@ -98,24 +111,19 @@ class VectorDatabase(FilterAndRerankMixin):
     # ---- ingest / delete (vector_database.py:49-155) -------------------------------------------------
     def get_vector(self, unique_id):
         with self.lock:
-            if unique_id not in self.inverse_id_map:
+            if unique_id not in self._ids:
                 raise ValueError("Unique ID does not exist.")
-            row_num = self.inverse_id_map[unique_id]
-            # a copy: the reference hands out a view of an array that np.delete/np.vstack REPLACE on every
-            # write (vector_database.py:72,126), so an earlier result never changes under the caller; the
-            # growable buffer here is edited in place
-            return self._mat.view[row_num].copy()
+            return self._mat.row(self._ids.row(unique_id), self.index)
 
     def store_embedding(self, unique_id, embedding, metadata_dict={}):
         with self.lock:
-            if unique_id in self.inverse_id_map:
+            if unique_id in self._ids:
                 raise ValueError("Unique ID already exists.")
-            row = self._admit([unique_id], [self._convert_ndarray_float32(embedding)], [metadata_dict])
-            self.id_map[row] = unique_id
+            self._admit([unique_id], [self._convert_ndarray_float32(embedding)], [metadata_dict])
 
     def store_embeddings_batch(self, unique_ids, embeddings, metadata_dicts=[]):
         with self.lock:
-            if any(uid in self.inverse_id_map for uid in unique_ids):
+            if any(uid in self._ids for uid in unique_ids):
                 raise ValueError("Unique ID already exists.")
             vectors = self._convert_ndarray_float32_batch(embeddings)
             # like the reference: a partial metadata list is an error, an empty one means "no metadata"
@@ -123,37 +131,23 @@ class VectorDatabase(FilterAndRerankMixin):
                 raise ValueError("Metadata dictionaries must be provided for all unique IDs.")
             if metadata_dicts == []:
                 metadata_dicts = [{} for _ in unique_ids]
-            first = self._admit(unique_ids, vectors, metadata_dicts)
-            self.id_map.update(zip(range(first, first + len(vectors)), unique_ids))
+            self._admit(unique_ids, vectors, metadata_dicts)
 
     def delete_embedding(self, unique_id):
-        if unique_id not in self.inverse_id_map:
+        if unique_id not in self._ids:
             raise ValueError("Unique ID does not exist.")
 
         with self.lock:
-            row_num = self.inverse_id_map[unique_id]
-            self._mat.delete([row_num])
-            if row_num < self._synced_rows:
-                # keep the device mirror aligned with np.delete's renumbering
-                self.index.remove_rows([row_num])
-                self._synced_rows -= 1
+            # rows behind the deleted one move up by one — on the device (tail compaction), in the metadata list
+            # and in the id list (C memmoves); the reference rebuilds both of its dicts row by row (:139-152)
+            row_num = self._ids.pop(unique_id)
+            self._mat.delete([row_num], self.index)
             metadata_to_delete = self.metadata.pop(row_num)
 
             for key in metadata_to_delete:
                 self.inverted_index[key].discard(unique_id)
                 if not self.inverted_index[key]:
                     del self.inverted_index[key]
-
-            del self.inverse_id_map[unique_id]
-
-            # renumber: rows after the deleted one move up by one.  Same resulting maps as the
-            # reference's rebuild over sorted(id_map) (:139-152), done in place over the shifted tail only.
-            n_old = len(self.id_map)
-            for old_index in range(row_num + 1, n_old):
-                uid = self.id_map[old_index]
-                self.id_map[old_index - 1] = uid
-                self.inverse_id_map[uid] = old_index - 1
-            del self.id_map[n_old - 1]
 
             self._invalidate_filter_cache()
             self._embeddings_changed = True
@@ -164,9 +158,10 @@ class VectorDatabase(FilterAndRerankMixin):
         """ or_filters could be a list of dictionaries, where each dictionary contains key-value pairs for OR
         filters, or a single dictionary, which is equivalent to a list with a single dictionary."""
         hits = []
+        uids = self._ids.uids
         for row, score in self._nearest_rows(embedding, metadata_filter, exclude_filter, or_filters, k):
             try:  # a row a concurrent delete has just renumbered away is skipped, as in the reference
-                hits.append((self.id_map[row], score, self.metadata[row]))
+                hits.append((uids[row], score, self.metadata[row]))
             except (KeyError, IndexError):
                 pass
         return self._package(hits, autocut)

@@ -1,0 +1,77 @@
+"""Host bookkeeping that replaced the reference's per-write rebuilds (minivectordb_amd/_dbcore.py): `_IdIndex`
+(id <-> row with handle arithmetic instead of renumbering loops, vector_database.py:139-152) and `_RowStore` (device
+rows + pending host rows instead of np.vstack / np.delete on one host matrix, :72, :126) against naive models."""
+import numpy as np
+
+from minivectordb_amd._dbcore import _IdIndex, _RowStore
+from oracle_backend import OracleIndex
+
+
+def test_id_index_matches_naive_renumbering():
+    rs = np.random.RandomState(0)
+    ids, model = _IdIndex(), []
+    nxt = 0
+    for step in range(6000):
+        op = rs.rand()
+        if op < 0.55 or not model:
+            uid = f"u{nxt}" if nxt % 3 else nxt
+            nxt += 1
+            ids.append(uid)
+            model.append(uid)
+        else:
+            uid = model[rs.randint(len(model))]
+            assert ids.row(uid) == model.index(uid)
+            r = ids.pop(uid)
+            assert r == model.index(uid)
+            model.remove(uid)
+            assert uid not in ids
+        if step % 500 == 0:
+            for uid in (model[0], model[len(model) // 2], model[-1]):
+                assert ids.row(uid) == model.index(uid) and uid in ids
+    assert ids.uids == model and len(ids) == len(model)
+    assert ids.row_dict() == dict(enumerate(model))
+    assert ids.inverse_dict() == {u: i for i, u in enumerate(model)}
+    for uid in model[::97]:
+        assert ids.row(uid) == model.index(uid)
+    # compaction keeps everything consistent and appends continue after it
+    ids.append("tail")
+    assert ids.row("tail") == len(model)
+
+
+def test_row_store_matches_numpy_model():
+    rs = np.random.RandomState(1)
+    d = 8
+    idx = OracleIndex(d)
+    st = _RowStore(d)
+    model_raw = np.zeros((0, d), np.float32)     # what the reference's matrix would hold
+    synced = 0
+
+    def normed(a):
+        out = a.copy()
+        nz = np.linalg.norm(out, axis=1) > 0
+        out[nz] /= np.linalg.norm(out[nz], axis=1, keepdims=True)
+        return out
+
+    for step in range(300):
+        op = rs.rand()
+        if op < 0.5:
+            rows = rs.randn(rs.randint(1, 5), d).astype(np.float32)
+            st.append(rows if rows.shape[0] > 1 else rows[0])
+            model_raw = np.vstack([model_raw, rows])
+        elif op < 0.7:
+            st.flush(idx)
+            model_raw[synced:] = normed(model_raw[synced:])   # the in-place normalisation of a build
+            synced = model_raw.shape[0]
+        elif model_raw.shape[0] > 2:
+            kill = sorted(set(rs.randint(0, model_raw.shape[0], size=rs.randint(1, 3)).tolist()))
+            st.delete(kill, idx)
+            synced -= sum(1 for r in kill if r < synced)
+            model_raw = np.delete(model_raw, kill, axis=0)
+        assert st.n == model_raw.shape[0] and st.synced == synced == idx.ntotal
+        if step % 10 == 0 and st.n:
+            np.testing.assert_allclose(st.materialize(idx), model_raw, atol=1e-6)
+            r = rs.randint(st.n)
+            got = st.row(r, idx)
+            np.testing.assert_allclose(got, model_raw[r], atol=1e-6)
+            got[:] = 123.0                     # a copy: the store must not change under the caller's edit
+            np.testing.assert_allclose(st.row(r, idx), model_raw[r], atol=1e-6)
