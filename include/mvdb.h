@@ -110,9 +110,15 @@ int mvdb_index_search(const mvdb_index* idx, const float* q_host, int nq, int k,
                       float* D_host, int64_t* I_host);
 
 /* Same with every buffer in device memory and the work enqueued on `stream` (a hipStream_t, or
- * NULL for the legacy default stream); returns without synchronising.  label_offset is added to
- * every label (global row number of this shard's first row).  This is the entry point the
- * one-process-per-GPU sharded search uses ahead of its RCCL all-gather. */
+ * NULL for the legacy default stream).  label_offset is added to every label (global row number of
+ * this shard's first row).  This is the entry point the one-process-per-GPU sharded search uses
+ * ahead of its RCCL all-gather.
+ * Synchronisation: calls with fewer than 14 queries, k > 12, or a corpus of unknown row norms return
+ * without synchronising.  Batches served by the split-precision pass (>= 14 queries, k <= 12)
+ * synchronise `stream` ONCE per call, after the last pass, to read the per-chunk certification flags
+ * (a chunk that failed is re-run on the exact kernels before the call returns); while `stream` is
+ * being captured into a hipGraph that pass is not used, so the call stays capturable.
+ * One search at a time per (index, stream): concurrent calls naming the same stream are serialised. */
 int mvdb_index_search_device(const mvdb_index* idx, const float* q_dev, int nq, int k,
                              int normalize_q, int64_t label_offset, float* D_dev, int64_t* I_dev,
                              void* stream);

@@ -1425,7 +1425,12 @@ int mvdb_index_search_device(const mvdb_index* idx, const float* q_dev, int nq, 
         MVDB_HIP(hipGetLastError());
         q = ws->q.p;
     }
-    return search_core(idx, ws, q, nq, k, normalize_q, nullptr, 0, label_offset, D_dev, I_dev);
+    // The split-precision batch pass reads its certification flags on the host (one stream synchronise per call) and
+    // may re-launch: not legal while `stream` is being captured into a graph — the exact kernels are used there.
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    const bool capturing = stream && hipStreamIsCapturing((hipStream_t)stream, &cap) == hipSuccess &&
+                           cap != hipStreamCaptureStatusNone;
+    return search_core(idx, ws, q, nq, k, normalize_q, nullptr, 0, label_offset, D_dev, I_dev, !capturing);
 }
 
 __global__ void map_subset_labels_kernel(int64_t* I, int64_t total, const int64_t* __restrict__ rows,

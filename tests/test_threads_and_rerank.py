@@ -113,9 +113,9 @@ def test_hybrid_rerank_results(tmp_path, oracle_backend):
     s2, c2 = db.hybrid_rerank_results(sentences, scores, "dogs", k=5, weights=(1.0, 0.0, 0.0))
     assert list(s2) == ["i like dogs", "dogs are animals", "cats and dogs", "the stock market fell", "quantum physics"]
     # reference quirk kept on purpose (vector_database.py:429-432): sentences and scores are stacked into
-    # ONE string array and the scores are sorted AS STRINGS, so '33.0' ranks above '100.0'
+    # ONE string array and the scores are sorted AS STRINGS, so '36.0' ranks above '100.0'
     s3, c3 = db.hybrid_rerank_results(sentences, scores, "quantum physics", k=1, weights=(0.0, 0.0, 1.0))
-    assert s3[0] == "dogs are animals" and str(c3[0]) == "33.0"
+    assert s3[0] == "dogs are animals" and str(c3[0]) == "36.0"
 
 
 def test_get_vector_result_survives_delete(oracle_backend, tmp_path):
@@ -137,3 +137,19 @@ def test_get_vector_result_survives_delete(oracle_backend, tmp_path):
     db.find_most_similar(x[0], k=2)
     assert np.allclose(db.get_vector("b2"), want, atol=1e-6)
     assert not np.allclose(db.get_vector("b2"), db.get_vector("c"), atol=1e-3)
+
+
+def test_partial_ratio_hand_computed_values():
+    """Values worked out by hand from rapidfuzz's published algorithm (windows of the shorter string's length plus
+    the overhanging ones, Indel ratio 2 LCS / (len a + len b), thefuzz's int(round(.))); see minivectordb_amd/_fuzz.py.
+    The library itself is absent here: parity unpinned."""
+    from minivectordb_amd._fuzz import partial_ratio
+    assert partial_ratio("this is a test", "this is a test!") == 100      # thefuzz README example
+    assert partial_ratio("abcd", "xxabcdxx") == 100
+    assert partial_ratio("abcd", "abxcd") == 75       # best windows "abxc" / "bxcd": LCS 3 -> 6 / 8
+    assert partial_ratio("abxcd", "abcd") == 75       # argument order does not matter
+    assert partial_ratio("abc", "bcd") == 80          # window "bc": LCS 2 -> 4 / 5
+    assert partial_ratio("abc", "xyz") == 0
+    assert partial_ratio("", "abc") == 0 and partial_ratio("abc", "") == 0 and partial_ratio(None, "a") == 0
+    assert partial_ratio("dogs", "i like dogs") == 100
+    assert partial_ratio("dogs", "cats and dog") == 86  # window " dog" -> LCS 3 -> 6/8 = 75; overhang "dog" -> 6/7 = 85.7
