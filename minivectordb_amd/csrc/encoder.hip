@@ -347,6 +347,136 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(const float* __restr
 }
 
 // =================================================================================================
+// The same GEMM with LDS-DMA staging (default when K % 32 == 0): tiles go global -> LDS by global_load_lds (no
+// VGPR staging, no ds_write: the register-staged kernel above pays 16 ds_write_b32 per thread and K-step, 9 % of the
+// S = 32 forward), ROW-major in LDS (128 B = 32 k per row; the DMA image is lane-linear, so the bank swizzle is
+// applied to the source: 16-byte slot p of row r receives the row's logical slot p ^ (r & 7)), three stages
+// in flight, ONE bare s_barrier per K-step.  A fragment read is one ds_read_b128 per 32-row tile and four MFMA
+// steps: lane (fr, fk) takes k = 8 c + 4 fk .. + 3 of row fr, MFMA step j pairs k = 8 c + j with 8 c + 4 + j.  Still an
+// exact-fp32 product; only the order of the k terms inside each group of eight differs from the kernel above.
+// =================================================================================================
+typedef __attribute__((address_space(3))) void* enc_lds_ptr;
+typedef const __attribute__((address_space(1))) void* enc_gbl_ptr;
+
+template <int EPI, int TI>
+__global__ __launch_bounds__(256) void gemm_f32_dma_kernel(const float* __restrict__ A, const float* __restrict__ W,
+                                                           const float* __restrict__ bias, const float* __restrict__ R,
+                                                           float* __restrict__ C, const int* __restrict__ Tptr, int N,
+                                                           int K) {
+    constexpr int BM = 64 * TI, BN = 64 * TI;
+    constexpr int NST = 3;                          // ring depth
+    constexpr int kStage = (BM + BN) * 128;         // bytes: BM + BN rows of 32 floats
+    constexpr int NI = (BM + BN) / 8 / 4;           // DMA instructions per wave and stage (8 rows each)
+    extern __shared__ __attribute__((aligned(16))) unsigned char gsm[];
+    const int T = *Tptr;
+    const int m0 = blockIdx.y * BM;
+    if (m0 >= T) return;
+    const int n0 = blockIdx.x * BN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int fr = lane & 31, fk = lane >> 5;
+
+    // DMA roles: instruction q (0 .. 4 NI - 1) of a stage moves tile rows 8 q .. 8 q + 7 (A rows first, then W rows);
+    // wave w issues q = w NI .. w NI + NI - 1.  Per-lane source offsets never change: bases are scalars.
+    uint32_t voff[NI];
+    const float* sbase[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int q = wave * NI + i;
+        const int row = 8 * q + (lane >> 3);        // row inside the stage image
+        const int slot = (lane & 7) ^ (row & 7);
+        const bool isA = 8 * q < BM;                // wave-uniform
+        int g = isA ? m0 + row : n0 + (row - BM);   // global row of A / W
+        const int lim = isA ? T : N;
+        g = g < lim ? g : lim - 1;                  // rows past the edge: clamped (masked in the epilogue)
+        sbase[i] = isA ? A : W;
+        voff[i] = (uint32_t)(((int64_t)g * K + 4 * slot) * 4);
+    }
+    auto issue = [&](int kt, int stage) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const char* src = reinterpret_cast<const char*>(sbase[i]) + (int64_t)kt * 128;
+            __builtin_amdgcn_global_load_lds((enc_gbl_ptr)(src + voff[i]),
+                                             (enc_lds_ptr)(gsm + stage * kStage + (wave * NI + i) * 1024), 16, 0, 0);
+        }
+    };
+    // fragment byte offsets inside a stage: A tile i of this wave, W tile j
+    int a_off[TI], b_off[TI];
+#pragma unroll
+    for (int i = 0; i < TI; ++i) {
+        const int ra = wm * 32 * TI + i * 32 + fr;
+        const int rb = BM + wn * 32 * TI + i * 32 + fr;
+        a_off[i] = ra * 128;
+        b_off[i] = rb * 128;
+    }
+    const int sw = fr & 7;  // (row & 7) of every fragment row of this lane: tile bases are multiples of 32
+
+    f32x16 acc[TI][TI];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TI; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = K / 32;
+    issue(0, 0);
+    if (nk > 1) issue(1, 1);
+    int st = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 1 < nk)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI) : "memory");  // this wave's part of stage kt has landed
+        else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // every wave's part has; and every wave is done reading stage kt - 1
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 2 < nk) issue(kt + 2, st == 0 ? 2 : st - 1);  // into the buffer of stage kt - 1
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned char* sb = gsm + st * kStage;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            f32x4 av[TI], bv[TI];
+            const int so = ((2 * c + fk) ^ sw) << 4;
+#pragma unroll
+            for (int i = 0; i < TI; ++i) {
+                av[i] = *reinterpret_cast<const f32x4*>(sb + a_off[i] + so);
+                bv[i] = *reinterpret_cast<const f32x4*>(sb + b_off[i] + so);
+            }
+#pragma unroll
+            for (int j4 = 0; j4 < 4; ++j4)
+#pragma unroll
+                for (int i = 0; i < TI; ++i)
+#pragma unroll
+                    for (int j = 0; j < TI; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][j4], bv[j][j4], acc[i][j], 0, 0, 0);
+        }
+        st = st == NST - 1 ? 0 : st + 1;
+    }
+
+    // epilogue.  C/D map of 32x32: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TI; ++j) {
+            const int col = n0 + wn * 32 * TI + j * 32 + fr;
+            if (col >= N) continue;
+            const float bvv = bias[col];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 32 * TI + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
+                if (row < T) {
+                    float v = acc[i][j][r] + bvv;
+                    if (EPI == EPI_BIAS_GELU) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+                    if (EPI == EPI_BIAS_RESIDUAL) v += R[(int64_t)row * N + col];
+                    C[(int64_t)row * N + col] = v;
+                }
+            }
+        }
+}
+
+// =================================================================================================
 // opt-in bf16 GEMM (compute = 1): operands rounded to bf16 (RNE), fp32 accumulate on
 // v_mfma_f32_32x32x16_bf16 (16x the fp32 MFMA rate).  NOT parity-exact: the reference computes in
 // fp32; embeddings move by ~1e-3.  Activations stay fp32 in memory (converted while staging into
@@ -819,6 +949,20 @@ void launch_gemm(const float* A, const float* W, const float* bias, const float*
         const char* v = getenv("MVDB_GEMM_SMALL_BK32");
         return !(v && *v == '0');
     }();
+    static const bool use_dma = []() {
+        const char* v = getenv("MVDB_GEMM_DMA");
+        return !(v && *v == '0');
+    }();
+    if (use_dma && K % 32 == 0 && big < (int64_t)rounds * 2 * cus) {
+        // 64x64 tiles, LDS-DMA staged, three 16-KiB stages: 3 blocks per CU — T = 8192: 9 / 12 / 3 tiles per CU for
+        // N = 1152 / 1536 / 384, whole rounds in every GEMM (the register-staged kernel fits 4 blocks: 2.25 rounds
+        // at N = 1152).  Measured 4.12 vs 4.26 ms per forward at B = 256, S = 32.  With 128x128 tiles (96 KiB of LDS,
+        // one block per CU) it loses to the register-staged kernel (81 vs 67 ms at S = 512): not used there.
+        dim3 grid((N + 63) / 64, (unsigned)((Tmax + 63) / 64));
+        constexpr int lds = 3 * 128 * 128;
+        hipLaunchKernelGGL((gemm_f32_dma_kernel<EPI, 1>), grid, dim3(256), lds, s, A, W, bias, R, C, Tptr, N, K);
+        return;
+    }
     if (big >= (int64_t)rounds * 2 * cus) {
         dim3 grid((N + 127) / 128, (unsigned)((Tmax + 127) / 128));
         if (K % 32 == 0 && big_bk32)
