@@ -1,0 +1,31 @@
+# Collects the round's evidence on the GPU box into gpurun_out/<tag>/ (copied into profiles/ afterwards):
+# bench lines, rocprofv3 kernel traces and separate PMC passes (FETCH_SIZE / WRITE_SIZE / MFMA busy) per batch size.
+# usage: bash benchmarks/collect_profiles.sh <tag>
+TAG=${1:-r02}
+R=$GRAFT_REPO_ROOT
+OUT=$R/gpurun_out/$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+python3 $R/bench.py > $OUT/${TAG}_bench_default.json 2> $OUT/bench_default.err
+for nq in 32 128; do
+  python3 $R/bench.py --nq $nq --steps 60 --warmup 10 --no-cpu-baseline > $OUT/${TAG}_bench_nq$nq.json 2>> $OUT/bench.err
+done
+python3 $R/bench.py --nq 128 --dim 384 --steps 60 --warmup 10 --no-cpu-baseline > $OUT/${TAG}_bench_nq128_d384.json 2>> $OUT/bench.err
+python3 $R/bench.py --rows 1000000 --steps 500 --warmup 50 --no-cpu-baseline > $OUT/${TAG}_config2_1M.json 2>> $OUT/bench.err
+for nq in 1 32 128; do
+  steps=60; [ $nq = 1 ] && steps=200
+  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/tr_$nq -- python3 $R/bench.py --nq $nq --steps $steps --warmup 10 --no-cpu-baseline > $OUT/${TAG}_final_nq${nq}_bench_under_rocprof.json 2>/dev/null
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/fe_$nq -- python3 $R/bench.py --nq $nq --steps 20 --warmup 5 --no-cpu-baseline > /dev/null 2>&1
+  rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/wr_$nq -- python3 $R/bench.py --nq $nq --steps 20 --warmup 5 --no-cpu-baseline > /dev/null 2>&1
+  (cd $R/profiles && python3 summarize_pmc.py ${TAG}_final_nq$nq /tmp/tr_$nq /tmp/fe_$nq /tmp/wr_$nq) > $OUT/summarize_nq$nq.log 2>&1
+  mv $R/profiles/${TAG}_final_nq${nq}_kernel_stats.csv $R/profiles/${TAG}_final_nq${nq}_pmc_summary.json $OUT/ 2>/dev/null
+done
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d /tmp/mf_128 -- python3 $R/bench.py --nq 128 --steps 20 --warmup 5 --no-cpu-baseline > /dev/null 2>&1
+python3 $R/profiles/summarize_mfma.py /tmp/mf_128 $OUT/${TAG}_mfma_util_nq128.json > $OUT/mfma_nq128.log 2>&1
+python3 $R/benchmarks/bench_config5.py > $OUT/${TAG}_config5_end_to_end.jsonl 2>> $OUT/bench.err
+python3 $R/benchmarks/bench_encoder.py > $OUT/${TAG}_encoder_bench.jsonl 2>> $OUT/bench.err
+python3 $R/benchmarks/scale_check.py > $OUT/${TAG}_scale_check_80M.json 2>> $OUT/bench.err
+python3 $R/benchmarks/bench_dropin.py > $OUT/${TAG}_dropin_1M.json 2>> $OUT/bench.err
+python3 $R/benchmarks/bench_variants.py > $OUT/${TAG}_secondary_paths.jsonl 2>> $OUT/bench.err
+python3 $R/benchmarks/split128_probe.py > $OUT/${TAG}_split128_ablations.jsonl 2>> $OUT/bench.err
+ls -la $OUT
