@@ -23,6 +23,9 @@ B, S = 256, 32
 rs = np.random.RandomState(0)
 ids = torch.from_numpy(rs.randint(5, 30000, size=(B, S)).astype(np.int32)).to(dev)
 mask = torch.ones((B, S), dtype=torch.int32, device=dev)
+if len(sys.argv) > 2 and sys.argv[2] == "ragged":
+    lens = rs.randint(S // 4, S + 1, size=B)
+    mask = torch.from_numpy((np.arange(S)[None, :] < lens[:, None]).astype(np.int32)).to(dev)
 os.environ["MVDB_ENCODER_GRAPH"] = "0"
 for _ in range(int(sys.argv[1]) if len(sys.argv) > 1 else 20):
     enc.forward_device(ids, mask)

@@ -3,8 +3,8 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/${1:-r2enc}
 mkdir -p $OUT
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/enc_trace -- python3 $R/benchmarks/bench_encoder_s32.py 30 > /tmp/enc_trace.log 2>&1
-f=$(find /tmp/enc_trace -name "*_kernel_stats.csv" | head -1)
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/enc_trace_${1:-r2enc} -- python3 $R/benchmarks/bench_encoder_s32.py 30 $2 > /tmp/enc_trace.log 2>&1
+f=$(find /tmp/enc_trace_${1:-r2enc} -name "*_kernel_stats.csv" | head -1)
 cp $f $OUT/encoder_s32_kernel_stats.csv
 python3 - <<PY
 import csv

@@ -231,6 +231,23 @@ constexpr int GBM = 128, GBN = 128, GBK = 16;  // GBM/GBN: the bf16 kernel's til
 
 // TI = 32x32 MFMA tiles per wave and dimension: TI = 2 -> 128x128 block tile (best reuse), TI = 1 ->
 // 64x64 (4x the blocks: used when the 128x128 grid would leave CUs idle, e.g. N = 384 at T = 8192).
+// XCD-aware tile mapping: workgroups are dealt round-robin to the 8 XCDs (linear id % 8), each with its own 4-MiB L2.
+// With the natural order the tiles of one A row band land on all 8 XCDs and every L2 ends up streaming the whole of A
+// and W (15 MB at T = 8192, H = 384); remapped, XCD k works on the k-th contiguous eighth of the ACTIVE tile list
+// (row bands below T: a ragged batch must not leave the last XCDs idle), i.e. on 1/8 of A's rows plus W.
+// Returns false for workgroups beyond the active tiles.
+__device__ __forceinline__ bool xcd_tile(int T, int BM, int& bx, int& by) {
+    const unsigned gx = gridDim.x;
+    const unsigned active = gx * (unsigned)((T + BM - 1) / BM);
+    unsigned lin = blockIdx.y * gx + blockIdx.x;
+    if (lin >= active) return false;
+    const unsigned chunk = active >> 3;
+    if (lin < (chunk << 3)) lin = (lin & 7u) * chunk + (lin >> 3);
+    bx = (int)(lin % gx);
+    by = (int)(lin / gx);
+    return true;
+}
+
 template <int EPI, int TI, int BKT>
 __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(const float* __restrict__ A,
                                                             const float* __restrict__ W,
@@ -241,9 +258,10 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(const float* __restr
     constexpr int BM = 64 * TI, BN = 64 * TI, LD = BM + 4;  // LDS row stride (floats): +4 pad
     constexpr int KQ = BKT / 16;                             // 16-float k groups per LDS tile
     const int T = *Tptr;
-    const int m0 = blockIdx.y * BM;
-    if (m0 >= T) return;
-    const int n0 = blockIdx.x * BN;
+    int bx, by;
+    if (!xcd_tile(T, BM, bx, by)) return;
+    const int m0 = by * BM;
+    const int n0 = bx * BN;
     __shared__ float lds[2 * 2 * BKT * LD];  // [buf][A|B][k][row]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -369,9 +387,10 @@ __global__ __launch_bounds__(256) void gemm_f32_dma_kernel(const float* __restri
     constexpr int NI = (BM + BN) / 8 / 4;           // DMA instructions per wave and stage (8 rows each)
     extern __shared__ __attribute__((aligned(16))) unsigned char gsm[];
     const int T = *Tptr;
-    const int m0 = blockIdx.y * BM;
-    if (m0 >= T) return;
-    const int n0 = blockIdx.x * BN;
+    int bx, by;
+    if (!xcd_tile(T, BM, bx, by)) return;
+    const int m0 = by * BM;
+    const int n0 = bx * BN;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
@@ -420,6 +439,9 @@ __global__ __launch_bounds__(256) void gemm_f32_dma_kernel(const float* __restri
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    f32x16 acc2;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
     const int nk = K / 32;
     issue(0, 0);
     if (nk > 1) issue(1, 1);
@@ -435,25 +457,37 @@ __global__ __launch_bounds__(256) void gemm_f32_dma_kernel(const float* __restri
         if (kt + 2 < nk) issue(kt + 2, st == 0 ? 2 : st - 1);  // into the buffer of stage kt - 1
         __builtin_amdgcn_sched_barrier(0);
         const unsigned char* sb = gsm + st * kStage;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            f32x4 av[TI], bv[TI];
+        // fragments of chunk c + 1 are read under the MFMAs of chunk c (register double buffer)
+        f32x4 av[2][TI], bv[2][TI];
+        auto read_chunk = [&](int c, int set) {
             const int so = ((2 * c + fk) ^ sw) << 4;
 #pragma unroll
             for (int i = 0; i < TI; ++i) {
-                av[i] = *reinterpret_cast<const f32x4*>(sb + a_off[i] + so);
-                bv[i] = *reinterpret_cast<const f32x4*>(sb + b_off[i] + so);
+                av[set][i] = *reinterpret_cast<const f32x4*>(sb + a_off[i] + so);
+                bv[set][i] = *reinterpret_cast<const f32x4*>(sb + b_off[i] + so);
             }
+        };
+        read_chunk(0, 0);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (c + 1 < 4) read_chunk(c + 1, (c + 1) & 1);
 #pragma unroll
             for (int j4 = 0; j4 < 4; ++j4)
 #pragma unroll
                 for (int i = 0; i < TI; ++i)
 #pragma unroll
-                    for (int j = 0; j < TI; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][j4], bv[j][j4], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < TI; ++j) {
+                        if (TI == 1 && (j4 & 1))  // two independent accumulation chains per tile (summed at the end)
+                            acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c & 1][i][j4], bv[c & 1][j][j4], acc2, 0, 0, 0);
+                        else
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c & 1][i][j4], bv[c & 1][j][j4], acc[i][j], 0, 0, 0);
+                    }
         }
         st = st == NST - 1 ? 0 : st + 1;
     }
+    if (TI == 1)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][0][r] += acc2[r];
 
     // epilogue.  C/D map of 32x32: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
 #pragma unroll
@@ -474,6 +508,141 @@ __global__ __launch_bounds__(256) void gemm_f32_dma_kernel(const float* __restri
                 }
             }
         }
+}
+
+// Persistent form of the kernel above (64x64 tiles), used when there are at least two tiles per resident workgroup
+// (N = 1152 / 1536 at T = 8192): gridDim.x = 3 per CU workgroups, each walking a strided share of its XCD's contiguous
+// band of the ACTIVE tiles (XCD k serves the k-th eighth of the tile list: its L2 holds 1/8 of A's rows plus W) with
+// ONE DMA ring that runs across tile boundaries — the first two K-steps of the next tile are in flight while the
+// current tile finishes and writes its epilogue, so the pipeline fill (2 us of a 25 us tile at K = 384) is paid once
+// per workgroup instead of once per tile.  The split is static.  (Tried: tiles drawn from per-XCD ticket counters —
+// 288 returning atomics on one address per XCD and launch cost more than they balance: 5.1 vs 3.9 ms per forward.
+// Not used where tiles < 2 x workgroups: a ragged batch then leaves workgroups without a tile and the busy ones
+// end up unevenly spread over the CUs, 76 vs 43 us per N = 384 GEMM.)
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_f32_dma_persistent_kernel(const float* __restrict__ A, const float* __restrict__ W,
+                                                                      const float* __restrict__ bias,
+                                                                      const float* __restrict__ R, float* __restrict__ C,
+                                                                      const int* __restrict__ Tptr, int N, int K) {
+    constexpr int BM = 64, BN = 64, NST = 3, kStage = (BM + BN) * 128, NI = 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char gsm[];
+    const int T = *Tptr;
+    const unsigned gx = (unsigned)((N + BN - 1) / BN);
+    const unsigned active = gx * (unsigned)((T + BM - 1) / BM);
+    const unsigned G = gridDim.x, b = blockIdx.x;  // G is a multiple of 8
+    const unsigned xcd = b & 7u, chunk = active >> 3, nb = G >> 3;
+    const unsigned first = xcd * chunk + (b >> 3), band_end = (xcd + 1u) * chunk;
+    const unsigned my_tiles = first < band_end ? (band_end - first + nb - 1) / nb : 0;
+    const unsigned tail0 = chunk << 3;
+    const bool tail_tile = tail0 + b < active;  // the < 8 leftover tiles go to the first workgroups
+    const unsigned ntl = my_tiles + (tail_tile ? 1u : 0u);
+    if (ntl == 0) return;
+    auto tile_lin = [&](unsigned u) { return u < my_tiles ? first + u * nb : tail0 + b; };
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int fr = lane & 31, fk = lane >> 5;
+    const int nk = K / 32;
+
+    // DMA roles as above; offsets are recomputed when the issue cursor enters a new tile
+    const bool isA = wave < 2;  // waves 0, 1 move the 64 A rows, waves 2, 3 the 64 W rows
+    const float* sbase = isA ? A : W;
+    const int lim = isA ? T : N;
+    uint32_t voff[NI];
+    auto set_tile = [&](unsigned lin) {
+        const int m0 = (int)(lin / gx) * BM, n0 = (int)(lin % gx) * BN;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int row = 8 * (wave * NI + i) + (lane >> 3);
+            const int slot = (lane & 7) ^ (row & 7);
+            int g = isA ? m0 + row : n0 + (row - BM);
+            g = g < lim ? g : lim - 1;
+            voff[i] = (uint32_t)(((int64_t)g * K + 4 * slot) * 4);
+        }
+    };
+    unsigned iu = 0;  // issue cursor: tile ordinal, K-step, ring stage
+    int ikt = 0, ist = 0;
+    auto issue_next = [&]() {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const char* src = reinterpret_cast<const char*>(sbase) + (int64_t)ikt * 128;
+            __builtin_amdgcn_global_load_lds((enc_gbl_ptr)(src + voff[i]),
+                                             (enc_lds_ptr)(gsm + ist * kStage + (wave * NI + i) * 1024), 16, 0, 0);
+        }
+        ist = ist == NST - 1 ? 0 : ist + 1;
+        if (++ikt == nk) {
+            ikt = 0;
+            ++iu;
+            if (iu < ntl) set_tile(tile_lin(iu));
+        }
+    };
+    const int a_off = (wm * 32 + fr) * 128, b_off = (BM + wn * 32 + fr) * 128;
+    const int sw = fr & 7;
+
+    set_tile(tile_lin(0));
+    issue_next();
+    if (iu < ntl) issue_next();
+    int st = 0;
+    for (unsigned u = 0; u < ntl; ++u) {
+        const unsigned lin = tile_lin(u);
+        const int m0 = (int)(lin / gx) * BM, n0 = (int)(lin % gx) * BN;
+        f32x16 acc, acc2;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = acc2[r] = 0.f;
+        for (int kt = 0; kt < nk; ++kt) {
+            const bool last_step = u + 1 == ntl && kt + 1 == nk;
+            __builtin_amdgcn_sched_barrier(0);
+            if (!last_step)
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI) : "memory");  // this wave's part of the current stage landed
+            else
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();  // every wave's part has; every wave is done with the stage before it
+            __builtin_amdgcn_sched_barrier(0);
+            if (iu < ntl) issue_next();    // two stages ahead, into the buffer just released
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned char* sb = gsm + st * kStage;
+            f32x4 av[2], bv[2];
+            av[0] = *reinterpret_cast<const f32x4*>(sb + a_off + ((fk ^ sw) << 4));
+            bv[0] = *reinterpret_cast<const f32x4*>(sb + b_off + ((fk ^ sw) << 4));
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if (c + 1 < 4) {  // fragments of chunk c + 1 are read under the MFMAs of chunk c
+                    const int so = ((2 * (c + 1) + fk) ^ sw) << 4;
+                    av[(c + 1) & 1] = *reinterpret_cast<const f32x4*>(sb + a_off + so);
+                    bv[(c + 1) & 1] = *reinterpret_cast<const f32x4*>(sb + b_off + so);
+                }
+#pragma unroll
+                for (int j4 = 0; j4 < 4; ++j4) {  // two accumulation chains, summed in the epilogue
+                    if (j4 & 1)
+                        acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c & 1][j4], bv[c & 1][j4], acc2, 0, 0, 0);
+                    else
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c & 1][j4], bv[c & 1][j4], acc, 0, 0, 0);
+                }
+            }
+            st = st == NST - 1 ? 0 : st + 1;
+        }
+        // epilogue of this tile; the next tile's first stages are already in flight
+        const int col = n0 + wn * 32 + fr;
+        if (col < N) {
+            const float bvv = bias[col];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
+                if (row < T) {
+                    float v = (acc[r] + acc2[r]) + bvv;
+                    if (EPI == EPI_BIAS_GELU) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+                    if (EPI == EPI_BIAS_RESIDUAL) v += R[(int64_t)row * N + col];
+                    C[(int64_t)row * N + col] = v;
+                }
+            }
+        }
+        // The epilogue's loads and stores went through the vector-memory counter the ring is paced by: drain them, so
+        // that the counted wait of the next K-step sees ring traffic only.
+        __builtin_amdgcn_sched_barrier(0);
+        if (u + 1 < ntl) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    }
 }
 
 // =================================================================================================
@@ -958,8 +1127,20 @@ void launch_gemm(const float* A, const float* W, const float* bias, const float*
         // N = 1152 / 1536 / 384, whole rounds in every GEMM (the register-staged kernel fits 4 blocks: 2.25 rounds
         // at N = 1152).  Measured 4.12 vs 4.26 ms per forward at B = 256, S = 32.  With 128x128 tiles (96 KiB of LDS,
         // one block per CU) it loses to the register-staged kernel (81 vs 67 ms at S = 512): not used there.
-        dim3 grid((N + 63) / 64, (unsigned)((Tmax + 63) / 64));
         constexpr int lds = 3 * 128 * 128;
+        // opt-in (MVDB_GEMM_PERSISTENT = 1: every small-tile GEMM, 2: only those with >= 2 tiles per workgroup): the
+        // persistent form gains 4 % on a FULL batch (3.90 vs 4.05 ms at B = 256, S = 32) and loses 30 % on a ragged one
+        // (3.78 vs 2.91 ms) when applied to the N = 384 GEMMs; restricted to the wide GEMMs it is within 1-3 % either way
+        static const int persistent = []() { const char* v = getenv("MVDB_GEMM_PERSISTENT"); return v ? atoi(v) : 0; }();
+        if (persistent) {
+            const int64_t tiles = (int64_t)((N + 63) / 64) * ((Tmax + 63) / 64);
+            const unsigned g = (unsigned)std::min<int64_t>(tiles, (int64_t)3 * cus) & ~7u;
+            if (g >= 8 && (persistent == 1 || tiles >= 2 * (int64_t)g)) {
+                hipLaunchKernelGGL((gemm_f32_dma_persistent_kernel<EPI>), dim3(g), dim3(256), lds, s, A, W, bias, R, C, Tptr, N, K);
+                return;
+            }
+        }
+        dim3 grid((N + 63) / 64, (unsigned)((Tmax + 63) / 64));
         hipLaunchKernelGGL((gemm_f32_dma_kernel<EPI, 1>), grid, dim3(256), lds, s, A, W, bias, R, C, Tptr, N, K);
         return;
     }
