@@ -162,6 +162,7 @@ int mvdb_merge_topk_device(int metric, int nlists, int nq, int k, const float* D
  * reference searches one stacked matrix (minivectordb/sharded_vector_database.py:598-662); the contract kept is
  * that function's result — top-k of the union, ties to the lower global row. */
 typedef struct mvdb_comm mvdb_comm;
+int mvdb_comm_available(void); /* 0 when librccl could be bound in this process (every rank checks BEFORE the collective init) */
 int mvdb_comm_unique_id(unsigned char* out128);
 int mvdb_comm_create(const unsigned char* id128, int rank, int world, int device, mvdb_comm** out);
 int mvdb_comm_free(mvdb_comm* comm);

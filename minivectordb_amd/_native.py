@@ -73,6 +73,7 @@ PROTOTYPES = {
                                                 ctypes.c_int64, c_vp, c_vp]),
     "mvdb_index_search_subset_device": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_vp,
                                                        ctypes.c_int64, ctypes.c_int, ctypes.c_int64, c_vp, c_vp, c_vp]),
+    "mvdb_comm_available": (ctypes.c_int, []),
     "mvdb_comm_unique_id": (ctypes.c_int, [c_vp]),
     "mvdb_comm_create": (ctypes.c_int, [c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(c_vp)]),
     "mvdb_comm_free": (ctypes.c_int, [c_vp]),

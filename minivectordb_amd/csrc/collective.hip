@@ -172,6 +172,12 @@ int launch_merge_di_sort(int metric, int nlists, int nq, int k, const float* D, 
 
 extern "C" {
 
+int mvdb_comm_available(void) {
+    Rccl* r = rccl();
+    if (!r->handle) return fail(MVDB_ERR_HIP, "%s", r->why.c_str());
+    return 0;
+}
+
 int mvdb_comm_unique_id(unsigned char* out128) {
     if (!out128) return fail(MVDB_ERR_ARG, "out is NULL");
     Rccl* r = rccl();

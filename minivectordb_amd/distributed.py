@@ -108,6 +108,14 @@ class ShardedSearcher:
         if want != "native":
             raise ValueError(f"MVDB_COLLECTIVE must be 'native' or 'torch' (got {want!r})")
         from . import _native
+        # Agree FIRST: ncclCommInitRank blocks until every rank has joined, so a rank that cannot bind librccl must be
+        # known to all before anybody enters it.
+        ok = torch.tensor([1 if _native.lib().mvdb_comm_available() == 0 else 0], dtype=torch.int32, device=self.device)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.group)
+        if int(ok.item()) == 0:
+            print(f"[mvdb] rank {self.rank}: librccl could not be bound on every rank ({_native.last_error()}); "
+                  "using torch.distributed.all_gather_into_tensor", file=sys.stderr, flush=True)
+            return "torch.distributed.all_gather_into_tensor"
         try:
             # rank 0 draws the RCCL unique id; the launcher's process group is only the side channel for it
             box = [_native.Comm.unique_id() if self.rank == 0 else None]
@@ -121,8 +129,10 @@ class ShardedSearcher:
             self._comm.allgather(mine.data_ptr(), allb.data_ptr(), 16, stream=stream)
             torch.cuda.synchronize()
             want_t = torch.arange(self.world, dtype=torch.uint8, device=self.device).repeat_interleave(16)
-            if not torch.equal(allb, want_t):
-                raise RuntimeError("probe all-gather returned the wrong blocks")
+            good = torch.tensor([1 if torch.equal(allb, want_t) else 0], dtype=torch.int32, device=self.device)
+            dist.all_reduce(good, op=dist.ReduceOp.MIN, group=self.group)
+            if int(good.item()) == 0:
+                raise RuntimeError("probe all-gather returned the wrong blocks on some rank")
             return "ncclAllGather (mvdb_allgather_topk, libmvdb.so)"
         except Exception as e:  # both routes are RCCL over xGMI; say loudly which one is in use
             print(f"[mvdb] rank {self.rank}: native RCCL communicator unavailable ({e}); "

@@ -19,6 +19,7 @@ def native(gpu):
 def test_native_rccl_communicator_single_rank(native):
     import torch
     dev = torch.device("cuda", 0)
+    assert native.lib().mvdb_comm_available() == 0, native.last_error()
     uid = native.Comm.unique_id()
     assert isinstance(uid, bytes) and len(uid) == 128 and any(uid)
     comm = native.Comm(uid, 0, 1, device=0)
