@@ -48,6 +48,8 @@ def lib():
         L.oracle_scores_f64.argtypes = [f32p, ctypes.c_int, f32p, ctypes.c_int, i64p, ctypes.c_int64, f64p]
         L.oracle_scores_f64.restype = None
         L.oracle_max_threads.restype = ctypes.c_int
+        L.oracle_first_touch_copy.argtypes = [f32p, f32p, ctypes.c_int64, ctypes.c_int, ctypes.c_int]
+        L.oracle_first_touch_copy.restype = None
         _LIB = L
     return _LIB
 
@@ -110,6 +112,16 @@ def scores_f64(x, q, rows, metric=METRIC_IP):
     out = np.empty(rows.shape[0], dtype=np.float64)
     lib().oracle_scores_f64(xp, x.shape[1], qp, metric, rp, rows.shape[0],
                             out.ctypes.data_as(ctypes.POINTER(ctypes.c_double)))
+    return out
+
+
+def first_touch_copy(x, nthreads):
+    """Copy of x whose pages are first touched by the thread that scans them in flat_search(..., nthreads=nthreads)
+    (NUMA placement for the multi-threaded CPU baseline)."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    out = np.empty_like(x)   # untouched pages
+    lib().oracle_first_touch_copy(out.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
+                                  x.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), x.shape[0], x.shape[1], int(nthreads))
     return out
 
 

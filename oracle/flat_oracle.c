@@ -267,3 +267,17 @@ int oracle_max_threads(void) {
     return 1;
 #endif
 }
+
+/* NUMA-friendly copy for the multi-threaded leg of bench.py's cpu_baseline: thread t of `nthreads` copies (first
+ * touches) exactly the row range [n t / nthreads, n (t + 1) / nthreads) that it will scan in oracle_flat_search with
+ * the same thread count, so each thread's rows sit in memory local to it (one thread touching the whole matrix puts
+ * it behind a single memory controller). */
+void oracle_first_touch_copy(float* dst, const float* src, int64_t n, int d, int nthreads) {
+    if (nthreads < 1) nthreads = 1;
+#pragma omp parallel for num_threads(nthreads) schedule(static, 1)
+    for (int t = 0; t < nthreads; ++t) {
+        const int64_t r0 = n * t / nthreads, r1 = n * (t + 1) / nthreads;
+        memcpy(dst + r0 * d, src + r0 * d, (size_t)(r1 - r0) * d * sizeof(float));
+    }
+}
+
