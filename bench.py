@@ -53,7 +53,8 @@ def pmc_traffic(n, d, nq=1, scan_name=None):
     best = None
     kern = {"ip_scan": "flat_scan_kernel", "ip_scan_mfma": "flat_scan_mfma", "ip_scan_gemm": "flat_scan_gemm",
             "ip_scan_split": "flat_scan_split128_kernel" if d == 512 else "flat_scan_split_kernel",
-            "ip_scan_split32": "flat_scan_split32"}.get(scan_name, "flat_scan_kernel" if nq == 1 else "flat_scan_mfma")
+            "ip_scan_split32": "flat_scan_split32", "ip_scan_half": "flat_scan_half_kernel"}.get(
+                scan_name, "flat_scan_kernel" if nq == 1 else "flat_scan_mfma")
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")))
     files.sort(key=lambda f: f"nq{nq}_" in os.path.basename(f))  # the pass profiled at this nq wins
     for f in files:
@@ -63,7 +64,7 @@ def pmc_traffic(n, d, nq=1, scan_name=None):
                     t = rec["hbm_traffic_bytes_per_launch_avg"]
                     # a corpus pass of the split-precision kernels is up to four main launches (phases): the profile
                     # holds the average over those launches, like `algorithmic_bytes_per_launch`
-                    for per_pass in ((1, 2, 3, 4) if "split" in kern else (1,)):
+                    for per_pass in ((1, 2, 3, 4) if ("split" in kern or "half" in kern) else (1,)):
                         if abs(t * per_pass / (n * d * 4.0) - 1.0) < 0.25:  # same workload size
                             best = {"bytes": int(t), "source": os.path.basename(f)}
         except Exception:
@@ -170,7 +171,7 @@ def main():
     n, d, k, nq = args.rows, args.dim, args.k, args.nq
     W, K = args.warmup, args.steps
     # dominant kernel by batch size: GEMV scan (nq = 1), 16/32-query MFMA pass, 128-query GEMM-tiled scan
-    scan_names = ("ip_scan", "ip_scan_mfma", "ip_scan_gemm", "ip_scan_split", "ip_scan_split32")
+    scan_names = ("ip_scan", "ip_scan_mfma", "ip_scan_gemm", "ip_scan_split", "ip_scan_split32", "ip_scan_half")
     idx = native.FlatIndex(d, device=local_rank)
     idx.reserve(n)
     idx.add_synthetic(n, 1234, first_row=rank * n, normalize=True)
@@ -240,16 +241,22 @@ def main():
     out = None
     if rank == 0:
         bytes_per_launch = n * d * 4  # algorithmic: every stored row of this rank's shard once
+        cus = torch.cuda.get_device_properties(dev).multi_processor_count
+        chunk = 128  # queries per corpus pass of the batch passes
         if scan_name in ("ip_scan_split", "ip_scan_split32"):
             # the seed launch (first 128-row tile of every CU, timed separately as ip_scan_split_seed) takes
             # its rows out of the main launch when the corpus has >= 8 tiles per CU
-            cus = torch.cuda.get_device_properties(dev).multi_processor_count
             if (n + 127) // 128 >= 8 * cus:
                 bytes_per_launch = (n - cus * 128) * d * 4
-        if scan_name in ("ip_scan_split", "ip_scan_split32"):
+        if scan_name == "ip_scan_half":
+            # fp16 nomination pass: the seed launch (ip_scan_half_seed) covers the first 32-row tile of every CU
+            chunk = native.half_max_queries(d)
+            bytes_per_launch = (n - min((n + 31) // 32, cus) * 32) * d * 4
+        passes = K * ((nq + chunk - 1) // chunk)
+        if scan_name in ("ip_scan_split", "ip_scan_split32", "ip_scan_half"):
             # one corpus pass = the seed launch + up to three main launches of growing size (phases, admission floors
             # refreshed in between): the per-launch figures below are averages over those launches
-            bytes_per_launch = bytes_per_launch * (K * ((nq + 127) // 128)) / max(launches, 1)
+            bytes_per_launch = bytes_per_launch * passes / max(launches, 1)
         avg_ms = scan_ms / max(launches, 1)
         # aggregate over ranks: every rank streams its own shard once per launch
         achieved = sum(bytes_per_launch / (ms * 1e-3) / 1e9 for ms in rank_ms if ms > 0) if launches else 0.0
@@ -264,7 +271,8 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32" if not scan_name.startswith("ip_scan_split") else "f32 (bf16 split-precision nomination, f32 re-score + certificate)",
+            "dtype": ("f32 (fp16 single-product nomination, f32 re-score + certificate)" if scan_name == "ip_scan_half" else
+                      "f32 (bf16 split-precision nomination, f32 re-score + certificate)" if scan_name.startswith("ip_scan_split") else "f32"),
             "data": "synthetic",
             "config": {
                 "workload": (f"{world * n} x {d} fp32 corpus ({n} rows resident per GPU), IP, k={k}, "
@@ -275,7 +283,7 @@ def main():
             "p50_latency_ms": round(p50, 4),
             "corpus_rows": world * n,
             "corpus_rows_per_s": round(world * n * K * nq / dt, 1),
-            "shard_passes_per_s": round(world * K * (1 if nq <= 128 else (nq + 127) // 128) / dt, 3),
+            "shard_passes_per_s": round(world * passes / dt, 3),
             "collective": searcher.collective,
             "roofline": None,
         }
@@ -299,11 +307,12 @@ def main():
                 "traffic_source": (pmc_traffic(n, d, nq, scan_name) or {}).get("source"),
                 "kernel": {"ip_scan": "flat_scan_kernel", "ip_scan_mfma": "flat_scan_mfma2_kernel",
                            "ip_scan_split": "flat_scan_split128_kernel" if d == 512 else "flat_scan_split_kernel",
-                           "ip_scan_split32": "flat_scan_split32_kernel"}[scan_name],
+                           "ip_scan_split32": "flat_scan_split32_kernel", "ip_scan_half": "flat_scan_half_kernel"}[scan_name],
                 "launches": launches,
                 "avg_launch_ms": round(avg_ms, 4),
                 "algorithmic_bytes_per_launch": int(bytes_per_launch),
-                "launches_per_corpus_pass": round(launches / max(K * ((nq + 127) // 128), 1), 2),
+                "launches_per_corpus_pass": round(launches / max(passes, 1), 2),
+                "queries_per_corpus_pass": min(nq, chunk),
                 "per_rank_avg_launch_ms": [round(v, 4) for v in rank_ms],
                 "per_rank_launch_ms_min_max": [round(min(rank_ms), 4), round(max(rank_ms), 4)],
             }

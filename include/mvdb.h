@@ -199,6 +199,14 @@ int64_t mvdb_split_rerun_count(void);
  * rounding (tests/test_split_bound.py restates and checks the formula).  Diagnostic. */
 double mvdb_split_eps(int d);
 
+/* Same for the fp16 single-product nomination pass that serves chunks of >= 33 queries where it has a kernel
+ * (half_scan.hip: both operands rounded to fp16, d products accumulated in fp32, 64 nominees per query re-scored
+ * in fp32): rounding of both operands, elements below fp16's normal range, worst-case fp32 accumulation, the fp32
+ * re-score, |q| and the comparison (tests/test_split_bound.py).  Diagnostic.
+ * mvdb_half_max_queries: queries per corpus pass of that pass at dimension d, 0 where it has no kernel. */
+double mvdb_half_eps(int d);
+int mvdb_half_max_queries(int d);
+
 /* ---- encoder (BERT-architecture sentence encoder: e5-small / e5-large) ---------------------
  * Replaces self.model(**batch_dict) + average_pool + F.normalize
  *                                                minivectordb/embedding_model.py:66-70, :50-53 */

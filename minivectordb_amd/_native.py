@@ -87,6 +87,8 @@ PROTOTYPES = {
                                               ctypes.c_int, ctypes.c_int, c_vp]),
     "mvdb_split_rerun_count": (ctypes.c_int64, []),
     "mvdb_split_eps": (ctypes.c_double, [ctypes.c_int]),
+    "mvdb_half_eps": (ctypes.c_double, [ctypes.c_int]),
+    "mvdb_half_max_queries": (ctypes.c_int, [ctypes.c_int]),
     "mvdb_prof_enable": (ctypes.c_int, [ctypes.c_int]),
     "mvdb_prof_read": (ctypes.c_int, [ctypes.c_char_p, ctypes.POINTER(ctypes.c_int64),
                                       ctypes.POINTER(ctypes.c_double)]),
@@ -299,6 +301,14 @@ def split_rerun_count():
 
 def split_eps(d):
     return float(lib().mvdb_split_eps(int(d)))
+
+
+def half_eps(d):
+    return float(lib().mvdb_half_eps(int(d)))
+
+
+def half_max_queries(d):
+    return int(lib().mvdb_half_max_queries(int(d)))
 
 
 def prof_read(name):

@@ -1,0 +1,528 @@
+// half_scan.hip — query batches of 33+ per corpus pass: ONE fp16 product nominates, fp32 decides, a worst-case
+// bound certifies.
+//
+// The bf16 (hi, lo) split passes (scan_split_kernels.hpp, split128.hip) spend three matrix-core products per
+// corpus element to get a nomination error of 2.3e-4 and then keep 16 nominees per query.  With both units busy the
+// chip sits at its power limit (shader clock 1.77 GHz, 0.58 of the HBM roofline at 128 queries).  This pass trades
+// precision of the NOMINATING score for matrix-core work and makes up for it with more nominees:
+//
+//      a(x) = fp16(s_q q) . fp16(s_x x) / (s_q s_x)        one v_mfma_f32_32x32x16_f16 per 16-k block, fp32 accumulate
+//      |a(x) - q.x| <= half_eps(d) |q| max|x|              (1.04e-3 at d = 512; derivation at half_eps below)
+//
+// s_q, s_x are powers of two that put the largest element at 2^14..2^15 (fp16's range is 2^-14..65504, so elements
+// down to 2^-29 of the largest keep their 11 significant bits; what falls below is bounded as if flushed to zero).
+// One product instead of three, one query image instead of two: the queries of a 128-query pass take 128 VGPRs
+// instead of 256, the matrix cores run a third of the time, and the kernel goes back to being HBM-bound.
+//
+// Nomination and certificate (per query):
+//   * every block keeps a sorted list of its 16 best rows (LDS, gated by a threshold register: the larger of the
+//     list's 16th score and the admission floor of the phase); the corpus is scanned in phases of growing size and
+//     between phases split_seed_kernel folds the lists into the running 16 best and raises the floors (as in the
+//     bf16 passes);
+//   * U = max(floor of the last phase, 16th score of every block list that filled up) bounds a(x) of every row that
+//     was ever dropped;
+//   * half_certify_kernel takes the 64 best candidates by a() from (running nominees + last phase's lists) — the set
+//     R —, raises U to a(64th) when more than 64 candidates sit above it, re-scores R in fp32 (score r), emits the
+//     top-k by r and certifies it with
+//         r(k-th) > U + eps |q| max|x|
+//     Every row outside R has a <= U, hence a true score below the k-th result's.  On exchangeable data the last
+//     phase's floor leaves ~100 candidates, so the test compares the k-th score with the ~64th instead of the 16th:
+//     the margin it needs (1.04e-3) is 4.5x the bf16 passes', the margin it has is ~4x theirs.  Queries that fail
+//     (duplicate-heavy neighbourhoods) flag their chunk for a re-run on the exact fp32 kernels (mvdb.hip).
+//
+// Kernel shape (flat_scan_half_kernel<NW, NG, NST, SEED>), d = 128 NW:
+//   K is split over the NW waves of a block (one wave per SIMD): wave w owns columns [128 w, 128 w + 128) of every
+//   row and ALL 32 NG queries of the pass, whose fp16 fragments stay in registers for the whole launch (32 NG VGPRs).
+//   It streams its 512-byte slice of a 32-row tile through a PRIVATE LDS-DMA ring (NST stages of 32 rows x 256 B,
+//   global_load_lds, non-temporal, bank swizzle on the source address), converts the slice to fp16 fragments
+//   (v_pk_mul_f32 + v_cvt_pk_f16_f32: 1 VALU op per element), and accumulates 32 x 32 partial score tiles, NW query
+//   groups per ROUND.  A round ends with the exchange: wave w keeps the group it owns and hands the NW - 1 others
+//   to their owners through LDS (two bare s_barriers per round), sums the NW partials of its own group and gates
+//   the 32 x 32 finished scores (query on the lane, one threshold register per owned group).
+//   No barrier inside the streaming part; NG / NW rounds per tile.
+//   SEED = one tile per block, every score dumped (no lists, no floors): the first launch of a pass.
+//
+// Algorithmic bytes per launch = rows scanned x ld x 4 (the corpus once for all queries of the pass).
+#include <cmath>
+#include <cstdlib>
+#include <map>
+#include <mutex>
+#include <type_traits>
+
+#include "common.hpp"
+#include "half_scan.hpp"
+#include "topk_device.hpp"
+
+namespace mvdb {
+
+typedef _Float16 hs_h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 hs_h2 __attribute__((ext_vector_type(2)));
+typedef float hs_f2 __attribute__((ext_vector_type(2)));
+typedef float hs_f4 __attribute__((ext_vector_type(4)));
+typedef float hs_f16 __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(3))) void* hs_lds_ptr;
+typedef const __attribute__((address_space(1))) void* hs_gbl_ptr;
+
+constexpr int kHsStage = 8192;  // 32 rows x 256 B (four 16-k blocks of the wave's column slice)
+
+// ---- queries: fp16 image, |q|, scale -----------------------------------------------------------------------------
+// One block per (padded) query.  s_q = 2^(15 - e) with max|q_i| = m 2^e, m in [0.5, 1): the largest element lands in
+// [2^14, 2^15).  Queries whose largest element is outside 2^-40 .. 2^40 (or not finite) get |q| = +inf, which fails
+// the certificate and sends them to the exact path; a zero query scores 0 everywhere and needs no scale.
+__global__ __launch_bounds__(256) void half_queries_kernel(const float* __restrict__ q, int64_t ld, int d, int nq,
+                                                           int xexp, _Float16* __restrict__ qf,
+                                                           float* __restrict__ qnorm, float* __restrict__ qinv) {
+    const int row = blockIdx.x;
+    float ss = 0.f, mx = 0.f;
+    if (row < nq) {
+        for (int c = threadIdx.x; c < d; c += 256) {
+            const float v = q[(int64_t)row * ld + c];
+            ss += v * v;
+            mx = fmaxf(mx, fabsf(v));
+            if (!(fabsf(v) <= 3.0e38f)) mx = INFINITY;  // NaN / inf
+        }
+    }
+    __shared__ float red[8];
+    for (int off = 32; off; off >>= 1) {
+        ss += __shfl_xor(ss, off);
+        mx = fmaxf(mx, __shfl_xor(mx, off));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        red[threadIdx.x >> 6] = ss;
+        red[4 + (threadIdx.x >> 6)] = mx;
+    }
+    __syncthreads();
+    ss = red[0] + red[1] + red[2] + red[3];
+    mx = fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7]));
+    int e = 0;
+    bool ok = true;
+    if (mx > 0.f) {
+        if (mx <= 3.0e38f)
+            (void)frexpf(mx, &e);
+        else
+            ok = false;
+        if (e < -40 || e > 40) ok = false;
+    }
+    const int qexp = (mx > 0.f && ok) ? 15 - e : 0;
+    const float sq = ldexpf(1.f, qexp);
+    for (int c = threadIdx.x; c < d; c += 256) {
+        const float v = (row < nq && ok) ? q[(int64_t)row * ld + c] * sq : 0.f;
+        qf[(int64_t)row * d + c] = (_Float16)v;  // RNE
+    }
+    if (threadIdx.x == 0) {
+        qinv[row] = ldexpf(1.f, -(qexp + xexp));
+        if (row < nq) qnorm[row] = ok ? sqrtf(ss) : INFINITY;
+    }
+}
+
+// ---- the scan ---------------------------------------------------------------------------------------------------
+template <int NW, int NG, int NST, bool SEED>
+__global__ __launch_bounds__(NW * 64) void flat_scan_half_kernel(HalfScanArgs a) {
+    static_assert(NG % NW == 0 && NW >= 2 && NW <= 4 && NST >= 2 && NST <= 7, "shape");
+    constexpr int NR = NG / NW;  // rounds per tile = query groups a wave owns
+    constexpr int KQ = 8;        // 16-k blocks per wave (128 columns)
+    constexpr int SKB = 4;       // 16-k blocks per ring stage
+    constexpr int NS = KQ / SKB; // stages per tile
+    constexpr int kRing = NST * kHsStage;
+    constexpr int K = NW * 128;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // NW rings | exchange window
+    __shared__ uint64_t lists[SEED ? 16 : NG * 32 * kHalfKeep];             // [owner wave][round][32 queries][16] keys
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int fr = lane & 31, fk = lane >> 5;
+    unsigned char* wbuf = smem + (size_t)wave * kRing;
+    unsigned char* exch = smem + (size_t)NW * kRing;
+    uint64_t* mylists = lists + (size_t)wave * NR * 32 * kHalfKeep;
+    if (!SEED)
+        for (int e = lane; e < NR * 32 * kHalfKeep; e += 64) mylists[e] = 0ull;
+
+    // ---- query fragments of this wave's columns.  In round r the wave works on the NW physical groups
+    // r NW .. r NW + NW - 1, rotated so that local group j = 0 is the one it OWNS (physical r NW + wave) and local
+    // group j goes to wave (wave + j) % NW: no run-time register indexing anywhere.
+    hs_h8 Q[KQ][NR][NW];
+#pragma unroll
+    for (int kb = 0; kb < KQ; ++kb)
+#pragma unroll
+        for (int r = 0; r < NR; ++r)
+#pragma unroll
+            for (int j = 0; j < NW; ++j) {
+                const int query = (r * NW + (wave + j) % NW) * 32 + fr;
+                Q[kb][r][j] = *reinterpret_cast<const hs_h8*>(a.qf + (int64_t)query * K + wave * 128 + kb * 16 + fk * 8);
+            }
+    float floor0[NR], thr[NR], inv[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const int myq = (r * NW + wave) * 32 + fr;
+        floor0[r] = myq < a.nq ? (a.thr0 ? a.thr0[myq] : -INFINITY) : INFINITY;
+        thr[r] = floor0[r];
+        inv[r] = a.qinv[myq];
+    }
+    // consume every global load here: the hand-placed vmcnt waits below are invisible to hipcc, a first use inside
+    // the loop would get a compiler-made s_waitcnt vmcnt(0) that also drains the DMA ring
+#pragma unroll
+    for (int kb = 0; kb < KQ; ++kb)
+#pragma unroll
+        for (int r = 0; r < NR; ++r)
+#pragma unroll
+            for (int j = 0; j < NW; ++j) asm volatile("" : "+v"(Q[kb][r][j]));
+#pragma unroll
+    for (int r = 0; r < NR; ++r) asm volatile("" : "+v"(floor0[r]), "+v"(thr[r]), "+v"(inv[r]));
+
+    const int64_t ntiles = a.tile1 - a.tile0;
+    const int64_t last = a.n - 1;
+    // ---- DMA roles: instruction i (0..7) of a stage moves rows 4i .. 4i+3; lane -> row 4i + (lane >> 4), 16-byte slot
+    // lane & 15 of the 256-byte LDS row, which receives the row's LOGICAL slot p ^ (r & 15) (bank swizzle on the
+    // source).  Source address = wave-uniform base of (tile, stage) + a per-lane byte offset that never changes.
+    uint32_t voff[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int r = 4 * i + (lane >> 4);
+        const int slot = (lane & 15) ^ (r & 15);
+        voff[i] = (uint32_t)(((int64_t)r * a.ld + 4 * slot) * 4);
+    }
+    // Rows past the end of the corpus (last tile) are READ like any other — the index keeps 32 rows of slack behind
+    // row n - 1 (mvdb.hip: grow) — and never nominated.
+    auto issue_stage = [&](int64_t tile, int ks, int buf) {
+        const int64_t row0 = (a.tile0 + tile) * 32;
+        const char* sbase = reinterpret_cast<const char*>(a.X + row0 * a.ld + wave * 128 + ks * SKB * 16);
+        unsigned char* dst = wbuf + buf * kHsStage;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            __builtin_amdgcn_global_load_lds((hs_gbl_ptr)(sbase + voff[i]), (hs_lds_ptr)(dst + i * 1024), 16, 0, 2 /* nt */);
+    };
+    // fragment read: row fr, 16-k block b of the stage (k = 16 b + 8 fk .. + 7) -> logical slots 4 b + 2 fk (+1)
+    int f_off[SKB][2];
+#pragma unroll
+    for (int b = 0; b < SKB; ++b)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) f_off[b][h] = fr * 256 + (((4 * b + 2 * fk + h) ^ (fr & 15)) << 4);
+
+    const int64_t step = gridDim.x;
+    int64_t tile = blockIdx.x;
+    const hs_f2 xs = {a.xscale, a.xscale};
+    unsigned n_ins = 0, n_slow = 0;
+    int rb = 0;  // ring buffer of the stage consumed next
+    // Stages past the block's last tile are issued too (clamped to its current tile, landing in buffers nobody
+    // reads): the loop body is branch-free and every counted wait sees a full ring.
+    if (tile < ntiles) {
+#pragma unroll
+        for (int g = 0; g < NST; ++g) {
+            const int64_t t = tile + (int64_t)(g / NS) * step;
+            issue_stage(t < ntiles ? t : tile, g % NS, g);
+        }
+    }
+    while (tile < ntiles) {
+        hs_h8 F[KQ];  // the wave's slice of the tile as fp16 A fragments: row fr, k = 16 kb + 8 fk .. + 7
+#pragma unroll
+        for (int ks = 0; ks < NS; ++ks) {
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 1) * 8) : "memory");  // oldest stage landed, the others stay in flight
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned char* sb = wbuf + rb * kHsStage;
+            hs_f4 x[SKB][2];
+#pragma unroll
+            for (int b = 0; b < SKB; ++b)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) x[b][h] = *reinterpret_cast<const hs_f4*>(sb + f_off[b][h]);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // fragments are in registers: the buffer may be refilled
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                const int64_t t = tile + (int64_t)((ks + NST) / NS) * step;
+                issue_stage(t < ntiles ? t : tile, (ks + NST) % NS, rb);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            rb = rb + 1 == NST ? 0 : rb + 1;
+#pragma unroll
+            for (int b = 0; b < SKB; ++b) {
+                union {
+                    hs_h8 v;
+                    hs_h2 p[4];
+                } u;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const hs_f2 lo = {x[b][h][0], x[b][h][1]}, hi = {x[b][h][2], x[b][h][3]};
+                    u.p[2 * h] = __builtin_convertvector(lo * xs, hs_h2);      // RNE
+                    u.p[2 * h + 1] = __builtin_convertvector(hi * xs, hs_h2);
+                }
+                F[ks * SKB + b] = u.v;
+            }
+        }
+        const int64_t m0 = (a.tile0 + tile) * 32;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            hs_f16 acc[NW];
+#pragma unroll
+            for (int j = 0; j < NW; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < KQ; ++kb)
+#pragma unroll
+                for (int j = 0; j < NW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F[kb], Q[kb][r][j], acc[j], 0, 0, 0);
+            // ---- exchange: local group j goes to wave (wave + j) % NW, which finds it in its source slot j - 1
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();  // every wave has read what the previous round left in the window
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 1; j < NW; ++j) {
+                unsigned char* dst = exch + (((wave + j) % NW) * (NW - 1) + (j - 1)) * 4096 + lane * 16;
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4)
+                    *reinterpret_cast<hs_f4*>(dst + r4 * 1024) =
+                        hs_f4{acc[j][4 * r4], acc[j][4 * r4 + 1], acc[j][4 * r4 + 2], acc[j][4 * r4 + 3]};
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();  // all partial tiles are in LDS
+            __builtin_amdgcn_sched_barrier(0);
+            float sc[16];
+            {
+                const unsigned char* src = exch + wave * (NW - 1) * 4096 + lane * 16;
+                hs_f4 part[NW - 1][4];
+#pragma unroll
+                for (int s = 0; s < NW - 1; ++s)
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; ++r4) part[s][r4] = *reinterpret_cast<const hs_f4*>(src + s * 4096 + r4 * 1024);
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    float s = acc[0][e];
+#pragma unroll
+                    for (int p = 0; p < NW - 1; ++p) s += part[p][e >> 2][e & 3];
+                    sc[e] = s * inv[r];  // exact: 1 / (s_q s_x) is a power of two
+                }
+            }
+            // ---- D[row][query]: query on the lane (fr), rows rl + 4 fk in the 16 registers
+            if (SEED) {
+                const int myq = (r * NW + wave) * 32 + fr;
+                if (myq < a.nq) {
+                    uint64_t* out = a.cand + ((int64_t)myq * gridDim.x + blockIdx.x) * 32;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int rl = (e & 3) + 8 * (e >> 2) + 4 * fk;
+                        out[rl] = m0 + rl <= last ? make_key(sc[e], (uint32_t)(m0 + rl)) : 0ull;
+                    }
+                }
+            } else {
+                float mx = sc[0];
+#pragma unroll
+                for (int e = 1; e < 16; ++e) mx = fmaxf(mx, sc[e]);
+                if (__ballot(mx >= thr[r]) != 0ull) {
+                    ++n_slow;
+                    uint64_t* rl_lists = mylists + (size_t)r * 32 * kHalfKeep;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int rl = (e & 3) + 8 * (e >> 2);
+                        const float s = sc[e];
+                        uint64_t mask = __ballot(m0 + rl + 4 * fk <= last && s >= thr[r]);
+                        while (mask) {
+                            const int srcl = __ffsll((long long)mask) - 1;
+                            mask &= mask - 1;
+                            ++n_ins;
+                            const int sq = srcl & 31;
+                            const float sv = __uint_as_float(__builtin_amdgcn_readlane((int)__float_as_uint(s), srcl));
+                            const uint32_t rv = (uint32_t)(m0 + rl + 4 * (srcl >> 5));
+                            const uint64_t kth = lds_list_insert(rl_lists + (size_t)sq * kHalfKeep, kHalfKeep, make_key(sv, rv), lane);
+                            if (fr == sq) thr[r] = kth ? fmaxf(key_score(kth), floor0[r]) : floor0[r];  // both lane halves
+                        }
+                    }
+                }
+            }
+        }
+        tile += step;
+        if (SEED) break;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the clamped look-ahead DMAs must land before the LDS is released
+    if (SEED) return;
+    if (a.stats && lane == 0) {
+        atomicAdd(a.stats, n_ins);
+        atomicAdd(a.stats + 1, n_slow);
+    }
+    // every query's list lives in exactly one wave: write the block's nominee lists
+#pragma unroll 1
+    for (int r = 0; r < NR; ++r)
+        for (int q = 0; q < 32; ++q) {
+            const int qq = (r * NW + wave) * 32 + q;
+            if (qq >= a.nq) break;
+            if (lane < kHalfKeep)
+                a.cand[((int64_t)qq * gridDim.x + blockIdx.x) * kHalfKeep + lane] = mylists[((size_t)r * 32 + q) * kHalfKeep + lane];
+        }
+}
+
+// ---- certification ------------------------------------------------------------------------------------------------
+// One block per query.  U = max(last floor, 16th score of every full block list); R = the 64 best candidates by
+// approximate score; U is raised to a(64th) when R is full; fp32 re-score of R (one wave per nominee, the arithmetic
+// of split_certify_kernel); top-k by exact score; certificate r(k-th) > U + eps |q|.
+__global__ __launch_bounds__(1024) void half_certify_kernel(HalfCertifyArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int qi = blockIdx.x;
+    const int64_t total = (int64_t)a.nlists * kHalfKeep;
+    const uint64_t* src = a.keys + (int64_t)qi * total;
+    __shared__ uint64_t sh[15 * 64];
+    __shared__ uint64_t nominee[kHalfRescore];
+    __shared__ uint64_t exact[kHalfRescore];
+    __shared__ float ured[16];
+    float u = a.thr0 ? a.thr0[qi] : -INFINITY;
+    for (int b = threadIdx.x; b < a.nlists; b += 1024) {
+        const uint64_t l = src[(int64_t)b * kHalfKeep + kHalfKeep - 1];
+        if (l) u = fmaxf(u, key_score(l));
+    }
+    for (int off = 32; off; off >>= 1) u = fmaxf(u, __shfl_xor(u, off));
+    if (lane == 0) ured[wave] = u;
+    WaveTopK tk;
+    tk.init(kHalfRescore);
+    for (int64_t base = (int64_t)wave * 64; base < total; base += 1024) {
+        const int64_t i = base + lane;
+        tk.offer(i < total ? src[i] : 0ull);
+    }
+    if (a.base && wave == 0) tk.offer(lane < kHalfKeep ? a.base[(int64_t)qi * kHalfKeep + lane] : 0ull);
+    block_merge_topk(tk, sh, 16);  // holds a __syncthreads(): ured is visible after it
+    if (wave == 0) nominee[lane] = tk.key;
+    __syncthreads();
+    // wave w re-scores nominees w, w + 16, w + 32, w + 48: lane-strided 16-byte loads, butterfly sum (deterministic)
+    for (int i = wave; i < kHalfRescore; i += 16) {
+        const uint64_t key = nominee[i];
+        uint64_t ek = 0ull;
+        if (key) {
+            const uint32_t row = key_row(key);
+            const hs_f4* xr = reinterpret_cast<const hs_f4*>(a.X + (int64_t)row * a.ld);
+            const hs_f4* qr = reinterpret_cast<const hs_f4*>(a.q + (int64_t)qi * a.ld);
+            float s = 0.f;
+            for (int c = lane; c < a.d4; c += 64) {
+                const hs_f4 x = xr[c], w = qr[c];
+                s = fmaf(x[0], w[0], s);
+                s = fmaf(x[1], w[1], s);
+                s = fmaf(x[2], w[2], s);
+                s = fmaf(x[3], w[3], s);
+            }
+            for (int off = 32; off; off >>= 1) s += __shfl_xor(s, off);
+            ek = make_key(s, row);
+        }
+        if (lane == 0) exact[i] = ek;
+    }
+    __syncthreads();
+    if (wave == 0) {
+        u = ured[0];
+#pragma unroll
+        for (int w = 1; w < 16; ++w) u = fmaxf(u, ured[w]);
+        const uint64_t worst = nominee[kHalfRescore - 1];
+        if (worst) u = fmaxf(u, key_score(worst));  // R is full: candidates left out of it score at most a(64th)
+        const uint64_t mine = exact[lane];
+        int rank = 0;
+#pragma unroll 8
+        for (int j = 0; j < kHalfRescore; ++j) rank += exact[j] > mine;
+        if (mine && rank < a.k) {
+            a.D[(int64_t)qi * a.k + rank] = key_score(mine);
+            a.I[(int64_t)qi * a.k + rank] = a.label_offset + (int64_t)key_row(mine);
+        }
+        const int valid = __popcll(__ballot(mine != 0ull));
+        if (lane >= valid && lane < a.k) {  // fewer rows than k: faiss' missing-result convention
+            a.D[(int64_t)qi * a.k + lane] = -3.402823466e+38f;
+            a.I[(int64_t)qi * a.k + lane] = -1;
+        }
+        // certification: needed as soon as any row was left out (u > -inf)
+        const uint64_t holder = __ballot(mine && rank == a.k - 1);
+        if (lane == 0 && u > -INFINITY) {
+            bool ok = false;
+            if (holder) {
+                const int hl = __ffsll((long long)holder) - 1;
+                const float t = key_score(exact[hl]);
+                ok = t > u + a.eps * a.qnorm[qi];
+            }
+            if (!ok) atomicAdd(a.uncertified, 1);
+        }
+    }
+}
+
+// ---- host side ----------------------------------------------------------------------------------------------------
+// Worst-case bound, per unit |q| * max|x|, on |a(x) - q.x| plus the error of the fp32 re-score and of the
+// certificate's own arithmetic (tests/test_split_bound.py restates and checks it):
+//   (1) both operands rounded to fp16 (11 significant bits, RNE):  (1 + 2^-11)^2 - 1 = 2^-10 + 2^-22, summed with
+//       Cauchy-Schwarz over the d products;
+//   (2) elements of the scaled images below fp16's normal range (2^-14): absolute error <= 2^-14 each whether the
+//       matrix cores keep subnormals or flush them; with the largest element of each image >= 2^14 that is
+//       sqrt(d) 2^-27 (1 + 2^-11) + d 2^-56;
+//   (3) fp32 accumulation of the d exact fp16 x fp16 products (22 significant bits each) and the NW - 1 <= 3
+//       additions of the exchange, in ANY order, every addition rounded or truncated at fp32 width (unit 2^-23):
+//       gamma(d + 4) (1 + 2^-11)^2;
+//   (4) the fp32 re-score of the nominees and (5) |q| and the comparison, as in split_eps (mvdb.hip).
+double half_eps(int d) {
+    const double u11 = std::ldexp(1.0, -11), u23 = std::ldexp(1.0, -23), u24 = std::ldexp(1.0, -24);
+    const double e_op = 2.0 * u11 + u11 * u11;
+    const double e_uf = std::sqrt((double)d) * std::ldexp(1.0, -27) * (1.0 + u11) + d * std::ldexp(1.0, -56);
+    const double n = d + 4.0;
+    const double e_acc = n * u23 / (1.0 - n * u23) * (1.0 + u11) * (1.0 + u11);
+    const double depth = ((d + 3) / 4 + 63) / 64 * 4 + 6;
+    const double e_re = depth * u24 / (1.0 - depth * u24);
+    return (e_op + e_uf + e_acc + e_re) * (1.0 + 4e-6) + 4.0 * u24;
+}
+
+// s_x = 2^(15 - e) with bound = m 2^e, m in [0.5, 1): every corpus element times s_x is below 2^15.
+// 0 when the bound is outside 2^-40 .. 2^40 (the pass is not used then).
+float half_xscale(float row_norm_bound) {
+    if (!(row_norm_bound > 0.f) || !(row_norm_bound < 1.0e30f)) return 0.f;
+    int e = 0;
+    (void)std::frexp(row_norm_bound, &e);
+    if (e < -40 || e > 40) return 0.f;
+    return std::ldexp(1.f, 15 - e);
+}
+
+int half_max_queries(int d) {
+    switch (d) {
+        case 512: return 128;
+        default: return 0;
+    }
+}
+
+int half_chunk_queries(int d, int nq) {
+    const int mx = half_max_queries(d);
+    (void)nq;
+    return mx;
+}
+
+int launch_half_queries(const float* q, int64_t ld, int d, int nq, int nqpad, float xscale, _Float16* qf, float* qnorm,
+                        float* qinv, hipStream_t stream) {
+    int xexp = 0;
+    (void)std::frexp(xscale, &xexp);  // xscale = 0.5 * 2^xexp
+    hipLaunchKernelGGL(half_queries_kernel, dim3(nqpad), dim3(256), 0, stream, q, ld, d, nq, xexp - 1, qf, qnorm, qinv);
+    MVDB_HIP(hipGetLastError());
+    return 0;
+}
+
+template <int NW, int NG, int NST, bool SEED>
+static int launch_half_inst(const HalfScanArgs& a, int device, hipStream_t stream, int* nblocks_out) {
+    auto kern = flat_scan_half_kernel<NW, NG, NST, SEED>;
+    constexpr size_t lds = (size_t)NW * NST * kHsStage + (size_t)NW * (NW - 1) * 4096;
+    {
+        static std::mutex mu;
+        static std::map<int, bool> done;
+        std::lock_guard<std::mutex> lk(mu);
+        if (!done[device]) {
+            MVDB_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            done[device] = true;
+        }
+    }
+    const int64_t ntiles = a.tile1 - a.tile0;
+    const int nblocks = (int)std::max<int64_t>(1, std::min<int64_t>(ntiles, (int64_t)device_cus(device)));
+    *nblocks_out = nblocks;
+    int slot = prof_begin(SEED ? "ip_scan_half_seed" : "ip_scan_half", stream);
+    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(NW * 64), lds, stream, a);
+    prof_end(slot, stream);
+    MVDB_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_half_scan(int d, int nqpad, bool seed, const HalfScanArgs& a, int device, hipStream_t stream, int* nblocks_out) {
+    if (d == 512 && nqpad == 128) {
+        if (seed) return launch_half_inst<4, 4, 3, true>(a, device, stream, nblocks_out);
+        return launch_half_inst<4, 4, 3, false>(a, device, stream, nblocks_out);
+    }
+    return fail(MVDB_ERR_ARG, "no fp16 nomination kernel for d = %d, %d queries per pass", d, nqpad);
+}
+
+int launch_half_certify(const HalfCertifyArgs& a, int nq, hipStream_t stream) {
+    hipLaunchKernelGGL(half_certify_kernel, dim3(nq), dim3(1024), 0, stream, a);
+    MVDB_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace mvdb

@@ -1,0 +1,58 @@
+// half_scan.hpp — interface of half_scan.hip (the fp16 single-product nomination pass) to mvdb.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mvdb {
+
+constexpr int kHalfKeep = 16;      // nominees per (block, query) list and in the running list between phases
+constexpr int kHalfRescore = 64;   // nominees per query re-scored in fp32 by half_certify_kernel
+constexpr int kHalfMaxK = 12;      // results per query this pass certifies (floors are 16th-best scores: k must stay below 16)
+
+struct HalfScanArgs {
+    const float* X;
+    int64_t n;            // rows [0, n) may be nominated (rows up to the end of the last tile are READ: index slack)
+    int64_t ld;
+    const _Float16* qf;   // [nqpad][d] fp16 image of s_q * q (half_queries_kernel), rows >= nq zero
+    const float* qinv;    // [nqpad] 1 / (s_q * s_x): scaled score -> score
+    float xscale;         // s_x (power of two): corpus elements are multiplied by it before the fp16 rounding
+    int nq;
+    uint64_t* cand;       // [nq, gridDim.x, 16] nominee keys per block (seed launch: [nq, gridDim.x, 32])
+    int64_t tile0;        // 32-row tiles [tile0, tile1)
+    int64_t tile1;
+    const float* thr0;    // [nq] admission floors, or NULL
+    unsigned int* stats;  // NULL, or [2]: list inserts, wave-tiles that reached the slow path (diagnostics)
+};
+
+struct HalfCertifyArgs {
+    const uint64_t* keys;  // [nq, nlists, 16] gated, sorted per-block lists of the last phase (nlists may be 0)
+    int nlists;
+    const uint64_t* base;  // [nq, 16] running nominees of the earlier phases, or NULL
+    const float* thr0;     // [nq] the floor the last phase was gated with (= 16th score of `base`), or NULL
+    const float* X;
+    int64_t ld;
+    int d4;
+    const float* q;        // [nq, ld] fp32
+    const float* qnorm;    // [nq]
+    float eps;             // half_eps(d) * max|x|, rounded up
+    int k;
+    int64_t label_offset;
+    float* D;
+    int64_t* I;
+    int* uncertified;
+};
+
+// queries per corpus pass of the widest instantiation for dimension d (0: no kernel for this d)
+int half_max_queries(int d);
+// queries per pass the launcher will use for a chunk of `nq` queries (a multiple of 32 * d / 128)
+int half_chunk_queries(int d, int nq);
+double half_eps(int d);
+float half_xscale(float row_norm_bound);
+
+int launch_half_queries(const float* q, int64_t ld, int d, int nq, int nqpad, float xscale, _Float16* qf, float* qnorm,
+                        float* qinv, hipStream_t stream);
+// seed: one tile per block over [tile0, tile1), every score dumped ([nq, blocks, 32] keys); *nblocks_out = blocks
+int launch_half_scan(int d, int nqpad, bool seed, const HalfScanArgs& a, int device, hipStream_t stream, int* nblocks_out);
+int launch_half_certify(const HalfCertifyArgs& a, int nq, hipStream_t stream);
+
+}  // namespace mvdb

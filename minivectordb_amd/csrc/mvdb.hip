@@ -18,6 +18,7 @@
 #include "scan_split_kernels.hpp"
 #include "select_kernels.hpp"
 #include "split128.hpp"
+#include "half_scan.hpp"
 #include "util_kernels.hpp"
 
 using namespace mvdb;
@@ -746,6 +747,101 @@ int launch_split_scan(const mvdb_index* idx, Workspace* ws, const float* q, int 
     return 0;
 }
 
+// ---- fp16 single-product nomination pass (half_scan.hip): 33+ queries per corpus pass where a kernel exists ----------
+bool half_path_ok(const mvdb_index* idx) {
+    if (env_int("MVDB_DISABLE_HALF_SCAN", 0)) return false;
+    return half_max_queries(idx->d) > 0 && idx->ld == idx->d && half_xscale(idx->row_norm_bound) > 0.f;
+}
+
+int launch_half_pass(const mvdb_index* idx, Workspace* ws, const float* q, int nq, int nqpad, int k, int64_t n,
+                     int64_t label_offset, float* D, int64_t* I, int* flag) {
+    hipStream_t stream = ws->stream;
+    _Float16* qf = reinterpret_cast<_Float16*>(ws->qsplit.p);
+    float* qnorm = ws->qnorm.p;
+    float* floors = qnorm + nqpad;
+    float* qinv = qnorm + 2 * nqpad;
+    const float xscale = half_xscale(idx->row_norm_bound);
+    MVDB_TRY(launch_half_queries(q, idx->ld, idx->d, nq, nqpad, xscale, qf, qnorm, qinv, stream));
+    HalfScanArgs a;
+    a.X = idx->X;
+    a.n = n;
+    a.ld = idx->ld;
+    a.qf = qf;
+    a.qinv = qinv;
+    a.xscale = xscale;
+    a.nq = nq;
+    a.stats = env_int("MVDB_SPLIT_STATS", 0) ? reinterpret_cast<unsigned int*>(ws->flags.p) + 64 : nullptr;
+    if (a.stats) MVDB_HIP(hipMemsetAsync(a.stats, 0, 8, stream));
+    const int64_t ntiles = (n + 31) / 32;
+    const int cus = device_cus(idx->device);
+    uint64_t* seed_keys = ws->cand.p;                           // [nqpad][16] running nominees
+    uint64_t* cand = ws->cand.p + (size_t)nqpad * kHalfKeep;   // [nq][lists][16]
+    a.cand = cand;
+    // SEED launch: the first min(tiles, CUs) tiles, one per block, every score dumped (32 keys per block and query);
+    // split_seed_kernel keeps each query's 16 best and publishes the 16th score as the first admission floor.
+    const int64_t seed_tiles = std::min<int64_t>(ntiles, cus);
+    int gx = 0;
+    a.tile0 = 0;
+    a.tile1 = seed_tiles;
+    a.thr0 = nullptr;
+    MVDB_TRY(launch_half_scan(idx->d, nqpad, true, a, idx->device, stream, &gx));
+    hipLaunchKernelGGL(split_seed_kernel, dim3(nq), dim3(1024), 0, stream, cand, 2 * gx, (const uint64_t*)nullptr,
+                       seed_keys, floors);
+    MVDB_HIP(hipGetLastError());
+    a.thr0 = floors;
+    // The rest of the corpus is scanned in PHASES of growing size; between phases split_seed_kernel folds the
+    // per-block lists into the running 16 best and raises the floors (a block alone sees n / CUs rows: without the
+    // refreshed floors its lists take hundreds of serial LDS inserts per wave).  Planned backwards: the LAST phase
+    // covers at most `last_growth` times the rows before it — that leaves ~16 x last_growth candidates above its
+    // floor for the 64-nominee certificate —, the earlier ones up to `growth` times.
+    const int growth = std::max(2, env_int("MVDB_HALF_PHASE_GROWTH", 16));
+    const int last_growth = std::max(2, env_int("MVDB_HALF_LAST_GROWTH", 6));
+    std::vector<int64_t> ends;
+    for (int64_t b = ntiles, g = last_growth; b > seed_tiles; g = growth) {
+        ends.push_back(b);
+        b = (b + g - 1) / g;
+        if (b <= 2 * seed_tiles) break;
+    }
+    int last_lists = 0;
+    int64_t covered = seed_tiles;
+    for (size_t p = ends.size(); p-- > 0;) {
+        a.tile0 = covered;
+        a.tile1 = ends[p];
+        MVDB_TRY(launch_half_scan(idx->d, nqpad, false, a, idx->device, stream, &gx));
+        covered = ends[p];
+        if (p > 0) {
+            hipLaunchKernelGGL(split_seed_kernel, dim3(nq), dim3(1024), 0, stream, cand, gx, seed_keys, seed_keys, floors);
+            MVDB_HIP(hipGetLastError());
+        } else {
+            last_lists = gx;
+        }
+    }
+    HalfCertifyArgs c;
+    c.keys = cand;
+    c.nlists = last_lists;
+    c.base = seed_keys;
+    c.thr0 = floors;
+    c.X = idx->X;
+    c.ld = idx->ld;
+    c.d4 = idx->d4;
+    c.q = q;
+    c.qnorm = qnorm;
+    c.eps = (float)(half_eps(idx->d) * (double)idx->row_norm_bound * (1.0 + 1e-6));  // rounded up
+    c.k = k;
+    c.label_offset = label_offset;
+    c.D = D;
+    c.I = I;
+    c.uncertified = flag;
+    MVDB_TRY(launch_half_certify(c, nq, stream));
+    if (a.stats) {
+        unsigned int st[2] = {0, 0};
+        MVDB_HIP(hipMemcpyAsync(st, a.stats, sizeof(st), hipMemcpyDeviceToHost, stream));
+        MVDB_HIP(hipStreamSynchronize(stream));
+        fprintf(stderr, "[mvdb half] list inserts %u, slow-path wave-rounds %u, %zu main launches\n", st[0], st[1], ends.size());
+    }
+    return 0;
+}
+
 bool mfma_path_ok(const mvdb_index* idx, int nq, int k, const int64_t* rows_dev) {
     if (env_int("MVDB_DISABLE_MFMA_SCAN", 0)) return false;
     if (nq < 2 || k > kMaxFusedK || rows_dev || idx->metric != MVDB_METRIC_IP) return false;
@@ -795,10 +891,13 @@ int search_core(const mvdb_index* idx, Workspace* ws, const float* q_dev, int nq
         // (below ~14 queries the fp32 pass, whose cost grows with the query count, is faster than the fixed seed +
         // certification overhead: measured crossover 11 queries at 100k rows, 14 at 10M)
         const int min_nq = env_int("MVDB_SPLIT_SCAN_MIN_NQ", 33);
+        // where the fp16 single-product pass has a kernel (half_scan.hip) it serves the >= 33-query chunks
+        const bool use_half = half_path_ok(idx);
+        const int chunk = use_half ? half_max_queries(idx->d) : 128;
         std::vector<std::pair<int, int>> plan;  // (first query, count)
         int q0 = 0;
         while (nq - q0 >= min_nq) {
-            plan.emplace_back(q0, std::min(nq - q0, 128));
+            plan.emplace_back(q0, std::min(nq - q0, chunk));
             q0 += plan.back().second;
         }
         if (nq - q0 >= env_int("MVDB_SPLIT32_MIN_NQ", 14) && nq - q0 <= 32 && split32_ok(idx)) {
@@ -807,16 +906,20 @@ int search_core(const mvdb_index* idx, Workspace* ws, const float* q_dev, int nq
         }
         const int nchunks = (int)plan.size();
         if (nchunks > 0) {
-            MVDB_TRY(ws->qsplit.reserve((size_t)2 * 128 * idx->d));
-            MVDB_TRY(ws->qnorm.reserve(256));  // [0,128): |q|, [128,256): admission floors of the seed pass
+            MVDB_TRY(ws->qsplit.reserve((size_t)std::max(2 * 128, chunk) * idx->d));
+            MVDB_TRY(ws->qnorm.reserve((size_t)std::max(256, 3 * chunk)));  // |q|, admission floors (, fp16 pass: 1 / scale)
             MVDB_TRY(ws->flags.reserve((size_t)std::max(nchunks, 64) + 32));  // + diagnostics counters at [64]
             MVDB_TRY(ws->pin_flags.reserve((size_t)nchunks * sizeof(int)));
-            MVDB_TRY(ws->cand.reserve((size_t)128 * (scan_grid_upper_bound(idx->device) + 1) * kSplitKeep));
+            MVDB_TRY(ws->cand.reserve((size_t)std::max(128, chunk) * (scan_grid_upper_bound(idx->device) + 1) * kSplitKeep));
             MVDB_HIP(hipMemsetAsync(ws->flags.p, 0, (size_t)nchunks * sizeof(int), s));
             for (int c = 0; c < nchunks; ++c) {
                 const int c0 = plan[c].first, take = plan[c].second;
-                MVDB_TRY(launch_split_scan(idx, ws, qsrc + (int64_t)c0 * idx->ld, take, k, n, label_offset,
-                                           D_dev + (int64_t)c0 * k, I_dev + (int64_t)c0 * k, ws->flags.p + c));
+                if (use_half && take >= min_nq)
+                    MVDB_TRY(launch_half_pass(idx, ws, qsrc + (int64_t)c0 * idx->ld, take, chunk, k, n, label_offset,
+                                              D_dev + (int64_t)c0 * k, I_dev + (int64_t)c0 * k, ws->flags.p + c));
+                else
+                    MVDB_TRY(launch_split_scan(idx, ws, qsrc + (int64_t)c0 * idx->ld, take, k, n, label_offset,
+                                               D_dev + (int64_t)c0 * k, I_dev + (int64_t)c0 * k, ws->flags.p + c));
             }
             int* hflags = static_cast<int*>(ws->pin_flags.p);
             MVDB_HIP(hipMemcpyAsync(hflags, ws->flags.p, (size_t)nchunks * sizeof(int), hipMemcpyDeviceToHost, s));
@@ -1527,6 +1630,8 @@ int mvdb_synth_fill_device(float* out_dev, int64_t n, int d, uint64_t seed, int6
 }
 
 double mvdb_split_eps(int d) { return d > 0 ? split_eps(d) : 0.0; }
+double mvdb_half_eps(int d) { return d > 0 ? half_eps(d) : 0.0; }
+int mvdb_half_max_queries(int d) { return d > 0 ? half_max_queries(d) : 0; }
 
 int64_t mvdb_split_rerun_count(void) { return (int64_t)g_split_reruns.load(std::memory_order_relaxed); }
 

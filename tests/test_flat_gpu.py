@@ -504,7 +504,8 @@ def _split_launches(native):
     """Chunks that went through the split-precision pass: each one starts with a seed launch."""
     native.prof_read("ip_scan_split")
     native.prof_read("ip_scan_split32")
-    return native.prof_read("ip_scan_split_seed")[0]
+    native.prof_read("ip_scan_half")
+    return native.prof_read("ip_scan_split_seed")[0] + native.prof_read("ip_scan_half_seed")[0]
 
 
 @pytest.mark.parametrize("n,d,k,nq", [
@@ -586,14 +587,20 @@ def _graded_rows(q, cosines, rs):
 
 
 @pytest.mark.parametrize("d", [512, 1024])
-@pytest.mark.parametrize("spacing,must_rerun", [(2.0e-5, True), (5.0e-6, True), (2.0e-4, False)])
-def test_split_certificate_at_the_margin(native, d, spacing, must_rerun):
-    """Rows engineered to sit within +-eps(d) of the k-th score (30 rows graded `spacing` apart around 0.9): the
-    pass must either certify a correct answer or re-run the chunk — never return a wrong id.  With 2e-5 / 5e-6
-    steps more than 16 - k rows lie inside the margin (eps(512) = 2.3e-4), so the certificate MUST refuse; with
-    2e-4 steps the 16th nominee is 1.2e-3 below the k-th result and the pass must certify on its own."""
+@pytest.mark.parametrize("frac,must_rerun", [(1 / 12, True), (1 / 48, True), (0.9, False)])
+def test_split_certificate_at_the_margin(native, d, frac, must_rerun):
+    """Rows engineered to sit within +-eps(d) of the k-th score (30 rows graded `frac * eps` apart around 0.9, stored
+    contiguously so that ONE block list holds them all): the pass must either certify a correct answer or re-run the
+    chunk — never return a wrong id.  With steps of eps / 12 and eps / 48 more than 16 - k rows lie inside the
+    margin of the 16 that a block list (or the running list) keeps, so the certificate MUST refuse; with 0.9 eps
+    steps the 16th is 5.4 eps below the k-th result and the pass must certify on its own.  eps is the bound of
+    the pass that serves 40 queries at this d: the fp16 nomination pass (1.04e-3 at d = 512) where it has a kernel,
+    the bf16 split (4.2e-4 at d = 1024) otherwise."""
     n, k, nq = 20000, 10, 40
-    rs = np.random.RandomState(d + int(spacing * 1e7))
+    eps = native.half_eps(d) if native.half_max_queries(d) >= nq else native.split_eps(d)
+    assert 3 * 2.0 ** -16 < eps < 2e-3
+    spacing = frac * eps
+    rs = np.random.RandomState(d + int(frac * 1e4))
     x = _corpus(n, d)
     q = _corpus(nq, d, seed=4242)
     cos = 0.9 - spacing * np.arange(30)
@@ -603,8 +610,6 @@ def test_split_certificate_at_the_margin(native, d, spacing, must_rerun):
         x[base:base + 30] = rows[order]
     idx = native.FlatIndex(d)
     idx.add(x)                                # raw add: max|x| measured on the device (1 + 1e-6)
-    eps = native.split_eps(d)
-    assert 3 * 2.0 ** -16 < eps < 1e-3
     before = native.split_rerun_count()
     D, I = idx.search(q, k)
     reran = native.split_rerun_count() - before
@@ -615,7 +620,7 @@ def test_split_certificate_at_the_margin(native, d, spacing, must_rerun):
         want = np.argsort(-t, kind="stable")[:k]
         if spacing >= 1e-5 or qi not in (0, 17, 39):
             assert I[qi].tolist() == want.tolist(), (qi, I[qi], want)
-        else:   # 5e-6 steps: fp32 re-scores (1e-7) still order them; float64 adjudicates anything closer
+        else:   # finer steps: fp32 re-scores (1e-7) still order them; float64 adjudicates anything closer
             ok, msg = flat.adjudicate(x, q[qi], k, D[qi], I[qi], tol=TOL)
             assert ok, msg
         np.testing.assert_allclose(D[qi], t[I[qi]], atol=TOL, rtol=0)
