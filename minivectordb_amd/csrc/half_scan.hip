@@ -63,8 +63,6 @@ typedef float hs_f16 __attribute__((ext_vector_type(16)));
 typedef __attribute__((address_space(3))) void* hs_lds_ptr;
 typedef const __attribute__((address_space(1))) void* hs_gbl_ptr;
 
-constexpr int kHsStage = 8192;  // 32 rows x 256 B (four 16-k blocks of the wave's column slice)
-
 // ---- queries: fp16 image, |q|, scale -----------------------------------------------------------------------------
 // One block per (padded) query.  s_q = 2^(15 - e) with max|q_i| = m 2^e, m in [0.5, 1): the largest element lands in
 // [2^14, 2^15).  Queries whose largest element is outside 2^-40 .. 2^40 (or not finite) get |q| = +inf, which fails
@@ -116,15 +114,32 @@ __global__ __launch_bounds__(256) void half_queries_kernel(const float* __restri
 }
 
 // ---- the scan ---------------------------------------------------------------------------------------------------
-template <int NW, int NG, int NST, bool SEED>
-__global__ __launch_bounds__(NW * 64) void flat_scan_half_kernel(HalfScanArgs a) {
-    static_assert(NG % NW == 0 && NW >= 2 && NW <= 4 && NST >= 2 && NST <= 7, "shape");
-    constexpr int NR = NG / NW;  // rounds per tile = query groups a wave owns
-    constexpr int KQ = 8;        // 16-k blocks per wave (128 columns)
-    constexpr int SKB = 4;       // 16-k blocks per ring stage
-    constexpr int NS = KQ / SKB; // stages per tile
-    constexpr int kRing = NST * kHsStage;
-    constexpr int K = NW * 128;
+// KQ  = 16-k blocks per wave (d = 64 KQ: the four waves of a block split K evenly)
+// SKB = 16-k blocks per ring stage: 4 -> 32 rows x 256 B (8 KiB, eight DMA instructions of 4 rows), 2 -> 32 rows x 128 B
+//       (4 KiB, four DMA instructions of 8 rows); KQ / SKB stages per tile
+// NG  = 32-query groups per pass (4 or 8), NST = ring depth in stages
+template <int SKB>
+struct HsStage {
+    static constexpr int kBytes = 2048 * SKB;  // 32 rows x SKB x 64 B
+    static constexpr int kDma = 2 * SKB;       // 1-KiB DMA instructions per stage
+    static constexpr int kPitch = 64 * SKB;    // bytes per row in LDS
+    static constexpr int kRowsPerDma = 1024 / kPitch;
+    static constexpr int kSlots = 4 * SKB;     // 16-byte slots per row
+    // bank swizzle: 16-byte slot p of row r holds the row's logical slot p ^ g(r)
+    __device__ static __forceinline__ int g(int r) { return SKB == 4 ? (r & 15) : ((r >> 1) & 7); }
+};
+
+template <int KQ, int SKB, int NG, int NST, bool SEED>
+__global__ __launch_bounds__(256) void flat_scan_half_kernel(HalfScanArgs a) {
+    constexpr int NW = 4;
+    static_assert(NG % NW == 0 && (SKB == 2 || SKB == 4) && KQ % SKB == 0 && NST >= 2, "shape");
+    using St = HsStage<SKB>;
+    static_assert((NST - 1) * St::kDma <= 63, "vmcnt is a 6-bit counter");
+    constexpr int NR = NG / NW;   // rounds per tile = query groups a wave owns
+    constexpr int NS = KQ / SKB;  // stages per tile
+    constexpr int HB = SKB / 2;   // 16-k blocks per half stage
+    constexpr int kRing = NST * St::kBytes;
+    constexpr int K = NW * KQ * 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // NW rings | exchange window
     __shared__ uint64_t lists[SEED ? 16 : NG * 32 * kHalfKeep];             // [owner wave][round][32 queries][16] keys
     const int lane = threadIdx.x & 63;
@@ -147,7 +162,7 @@ __global__ __launch_bounds__(NW * 64) void flat_scan_half_kernel(HalfScanArgs a)
 #pragma unroll
             for (int j = 0; j < NW; ++j) {
                 const int query = (r * NW + (wave + j) % NW) * 32 + fr;
-                Q[kb][r][j] = *reinterpret_cast<const hs_h8*>(a.qf + (int64_t)query * K + wave * 128 + kb * 16 + fk * 8);
+                Q[kb][r][j] = *reinterpret_cast<const hs_h8*>(a.qf + (int64_t)query * K + (wave * KQ + kb) * 16 + fk * 8);
             }
     float floor0[NR], thr[NR], inv[NR];
 #pragma unroll
@@ -170,24 +185,25 @@ __global__ __launch_bounds__(NW * 64) void flat_scan_half_kernel(HalfScanArgs a)
 
     const int64_t ntiles = a.tile1 - a.tile0;
     const int64_t last = a.n - 1;
-    // ---- DMA roles: instruction i (0..7) of a stage moves rows 4i .. 4i+3; lane -> row 4i + (lane >> 4), 16-byte slot
-    // lane & 15 of the 256-byte LDS row, which receives the row's LOGICAL slot p ^ (r & 15) (bank swizzle on the
-    // source).  Source address = wave-uniform base of (tile, stage) + a per-lane byte offset that never changes.
-    uint32_t voff[8];
+    // ---- DMA roles: instruction i of a stage moves kRowsPerDma rows; lane -> row, 16-byte LDS slot p of that row,
+    // which receives the row's LOGICAL slot p ^ g(row) (bank swizzle on the source: the LDS image of a DMA
+    // instruction is lane-linear).  Source address = wave-uniform base of (tile, stage) + a per-lane byte offset
+    // that never changes.
+    uint32_t voff[St::kDma];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int r = 4 * i + (lane >> 4);
-        const int slot = (lane & 15) ^ (r & 15);
+    for (int i = 0; i < St::kDma; ++i) {
+        const int r = St::kRowsPerDma * i + lane / St::kSlots;
+        const int slot = (lane % St::kSlots) ^ St::g(r);
         voff[i] = (uint32_t)(((int64_t)r * a.ld + 4 * slot) * 4);
     }
     // Rows past the end of the corpus (last tile) are READ like any other — the index keeps 32 rows of slack behind
     // row n - 1 (mvdb.hip: grow) — and never nominated.
     auto issue_stage = [&](int64_t tile, int ks, int buf) {
         const int64_t row0 = (a.tile0 + tile) * 32;
-        const char* sbase = reinterpret_cast<const char*>(a.X + row0 * a.ld + wave * 128 + ks * SKB * 16);
-        unsigned char* dst = wbuf + buf * kHsStage;
+        const char* sbase = reinterpret_cast<const char*>(a.X + row0 * a.ld + (wave * KQ + ks * SKB) * 16);
+        unsigned char* dst = wbuf + buf * St::kBytes;
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
+        for (int i = 0; i < St::kDma; ++i)
             __builtin_amdgcn_global_load_lds((hs_gbl_ptr)(sbase + voff[i]), (hs_lds_ptr)(dst + i * 1024), 16, 0, 2 /* nt */);
     };
     // fragment read: row fr, 16-k block b of the stage (k = 16 b + 8 fk .. + 7) -> logical slots 4 b + 2 fk (+1)
@@ -195,59 +211,170 @@ __global__ __launch_bounds__(NW * 64) void flat_scan_half_kernel(HalfScanArgs a)
 #pragma unroll
     for (int b = 0; b < SKB; ++b)
 #pragma unroll
-        for (int h = 0; h < 2; ++h) f_off[b][h] = fr * 256 + (((4 * b + 2 * fk + h) ^ (fr & 15)) << 4);
+        for (int h = 0; h < 2; ++h) f_off[b][h] = fr * St::kPitch + (((4 * b + 2 * fk + h) ^ St::g(fr)) << 4);
 
     const int64_t step = gridDim.x;
     int64_t tile = blockIdx.x;
     const hs_f2 xs = {a.xscale, a.xscale};
     unsigned n_ins = 0, n_slow = 0;
     int rb = 0;  // ring buffer of the stage consumed next
-    // Stages past the block's last tile are issued too (clamped to its current tile, landing in buffers nobody
-    // reads): the loop body is branch-free and every counted wait sees a full ring.
+    struct Raw {
+        hs_f4 v[SKB][2];
+    };
+    // -- the four steps that bring stage ks of a tile from the ring into fp16 A fragments (row fr, k = 16 kb + 8 fk ..)
+    auto wait_stage = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 1) * St::kDma) : "memory");  // oldest stage landed, the others stay in flight
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto read_stage = [&](Raw& x) {
+        const unsigned char* sb = wbuf + rb * St::kBytes;
+#pragma unroll
+        for (int b = 0; b < SKB; ++b)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) x.v[b][h] = *reinterpret_cast<const hs_f4*>(sb + f_off[b][h]);
+    };
+    // refills the buffer just drained with the stage NST ahead.  Stages past the block's last tile are issued too
+    // (clamped to its current tile, landing in buffers nobody reads): the loop body is branch-free and every counted
+    // wait sees a full ring.
+    auto refill = [&](int64_t cur, int ks) {
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the fragments are in registers
+        __builtin_amdgcn_sched_barrier(0);
+        const int64_t t = cur + (int64_t)((ks + NST) / NS) * step;
+        issue_stage(t < ntiles ? t : (cur < ntiles ? cur : tile), (ks + NST) % NS, rb);
+        rb = rb + 1 == NST ? 0 : rb + 1;
+    };
+    auto convert = [&](const Raw& x, hs_h8* F, int ks) {
+#pragma unroll
+        for (int b = 0; b < SKB; ++b) {
+            union {
+                hs_h8 v;
+                hs_h2 p[4];
+            } u;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const hs_f2 lo = {x.v[b][h][0], x.v[b][h][1]}, hi = {x.v[b][h][2], x.v[b][h][3]};
+                u.p[2 * h] = __builtin_convertvector(lo * xs, hs_h2);  // RNE
+                u.p[2 * h + 1] = __builtin_convertvector(hi * xs, hs_h2);
+            }
+            F[ks * SKB + b] = u.v;
+        }
+    };
+    // -- exchange: local group j goes to wave (wave + j) % NW, which finds it in its source slot j - 1
+    auto exch_write = [&](hs_f16 (&acc)[NW]) {
+#pragma unroll
+        for (int j = 1; j < NW; ++j) {
+            unsigned char* dst = exch + (((wave + j) % NW) * (NW - 1) + (j - 1)) * 4096 + lane * 16;
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4)
+                *reinterpret_cast<hs_f4*>(dst + r4 * 1024) =
+                    hs_f4{acc[j][4 * r4], acc[j][4 * r4 + 1], acc[j][4 * r4 + 2], acc[j][4 * r4 + 3]};
+        }
+    };
+    struct Parts {
+        hs_f4 v[NW - 1][4];
+    };
+    auto exch_read = [&](Parts& p) {
+        const unsigned char* src = exch + wave * (NW - 1) * 4096 + lane * 16;
+#pragma unroll
+        for (int s = 0; s < NW - 1; ++s)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) p.v[s][r4] = *reinterpret_cast<const hs_f4*>(src + s * 4096 + r4 * 1024);
+    };
+    // the NW partial tiles of the group this wave owns -> 16 scores per lane (query fr, rows rl + 4 fk)
+    auto sum_parts = [&](auto rc, const hs_f16& own, const Parts& p, float (&sc)[16]) {
+        constexpr int r = decltype(rc)::value;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            float s = own[e];
+#pragma unroll
+            for (int t = 0; t < NW - 1; ++t) s += p.v[t][e >> 2][e & 3];
+            sc[e] = s * inv[r];  // exact: 1 / (s_q s_x) is a power of two
+        }
+    };
+    // the gate: D[row][query] with the query on the lane (fr), rows rl + 4 fk in the 16 registers
+    auto gate = [&](auto rc, const float (&sc)[16], int64_t m0) {
+        constexpr int r = decltype(rc)::value;
+        if (SEED) {
+            const int myq = (r * NW + wave) * 32 + fr;
+            if (myq < a.nq) {
+                uint64_t* out = a.cand + ((int64_t)myq * gridDim.x + blockIdx.x) * 32;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int rl = (e & 3) + 8 * (e >> 2) + 4 * fk;
+                    out[rl] = m0 + rl <= last ? make_key(sc[e], (uint32_t)(m0 + rl)) : 0ull;
+                }
+            }
+        } else {
+            float mx = sc[0];
+#pragma unroll
+            for (int e = 1; e < 16; ++e) mx = fmaxf(mx, sc[e]);
+            if (__ballot(mx >= thr[r]) != 0ull) {
+                ++n_slow;
+                uint64_t* rl_lists = mylists + (size_t)r * 32 * kHalfKeep;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int rl = (e & 3) + 8 * (e >> 2);
+                    const float s = sc[e];
+                    uint64_t mask = __ballot(m0 + rl + 4 * fk <= last && s >= thr[r]);
+                    while (mask) {
+                        const int srcl = __ffsll((long long)mask) - 1;
+                        mask &= mask - 1;
+                        ++n_ins;
+                        const int sq = srcl & 31;
+                        const float sv = __uint_as_float(__builtin_amdgcn_readlane((int)__float_as_uint(s), srcl));
+                        const uint32_t rv = (uint32_t)(m0 + rl + 4 * (srcl >> 5));
+                        const uint64_t kth = lds_list_insert(rl_lists + (size_t)sq * kHalfKeep, kHalfKeep, make_key(sv, rv), lane);
+                        if (fr == sq) thr[r] = kth ? fmaxf(key_score(kth), floor0[r]) : floor0[r];  // both lane halves
+                    }
+                }
+            }
+        }
+    };
+    // whole exchange of one finished round, nothing overlapped (seed launch, and the last round of a block)
+    auto finish_round = [&](auto rc, hs_f16 (&acc)[NW], int64_t m0) {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();  // every wave has read what the previous round left in the window
+        __builtin_amdgcn_sched_barrier(0);
+        exch_write(acc);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();  // all partial tiles are in LDS
+        __builtin_amdgcn_sched_barrier(0);
+        Parts p;
+        exch_read(p);
+        float sc[16];
+        sum_parts(rc, acc[0], p, sc);
+        gate(rc, sc, m0);
+    };
+
+    hs_h8 F[2][KQ];  // the wave's slice of the current / the next tile as fp16 A fragments
     if (tile < ntiles) {
 #pragma unroll
         for (int g = 0; g < NST; ++g) {
             const int64_t t = tile + (int64_t)(g / NS) * step;
             issue_stage(t < ntiles ? t : tile, g % NS, g);
         }
-    }
-    while (tile < ntiles) {
-        hs_h8 F[KQ];  // the wave's slice of the tile as fp16 A fragments: row fr, k = 16 kb + 8 fk .. + 7
+        // the first tile's fragments: nothing to overlap with yet
 #pragma unroll
         for (int ks = 0; ks < NS; ++ks) {
-            __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 1) * 8) : "memory");  // oldest stage landed, the others stay in flight
-            __builtin_amdgcn_sched_barrier(0);
-            const unsigned char* sb = wbuf + rb * kHsStage;
-            hs_f4 x[SKB][2];
-#pragma unroll
-            for (int b = 0; b < SKB; ++b)
-#pragma unroll
-                for (int h = 0; h < 2; ++h) x[b][h] = *reinterpret_cast<const hs_f4*>(sb + f_off[b][h]);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // fragments are in registers: the buffer may be refilled
-            __builtin_amdgcn_sched_barrier(0);
-            {
-                const int64_t t = tile + (int64_t)((ks + NST) / NS) * step;
-                issue_stage(t < ntiles ? t : tile, (ks + NST) % NS, rb);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            rb = rb + 1 == NST ? 0 : rb + 1;
-#pragma unroll
-            for (int b = 0; b < SKB; ++b) {
-                union {
-                    hs_h8 v;
-                    hs_h2 p[4];
-                } u;
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const hs_f2 lo = {x[b][h][0], x[b][h][1]}, hi = {x[b][h][2], x[b][h][3]};
-                    u.p[2 * h] = __builtin_convertvector(lo * xs, hs_h2);      // RNE
-                    u.p[2 * h + 1] = __builtin_convertvector(hi * xs, hs_h2);
-                }
-                F[ks * SKB + b] = u.v;
-            }
+            Raw x;
+            wait_stage();
+            read_stage(x);
+            refill(tile, ks);
+            convert(x, F[0], ks);
         }
+    }
+    // One tile: the MFMAs of round 0 run while the NEXT tile's stages are read, converted and refilled (each half
+    // stage of MFMAs shares a scheduling region with the LDS reads / the DMA issue + conversion it hides).
+    // (Tried and dropped, same speed or slower: a second accumulator set so that a round's exchange runs under the
+    //  MFMAs of the round after it, with F overwritten in place — at 256 queries the query fragments then no longer
+    //  fit beside two accumulator sets: 40 spilled registers at d = 512.)
+    auto tile_body = [&](auto pc) {
+        constexpr int P = decltype(pc)::value;
         const int64_t m0 = (a.tile0 + tile) * 32;
+        const int64_t next = tile + step;
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
             hs_f16 acc[NW];
@@ -255,81 +382,39 @@ __global__ __launch_bounds__(NW * 64) void flat_scan_half_kernel(HalfScanArgs a)
             for (int j = 0; j < NW; ++j)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+            auto mfma_kb = [&](int kb) {
 #pragma unroll
-            for (int kb = 0; kb < KQ; ++kb)
+                for (int j = 0; j < NW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F[P][kb], Q[kb][r][j], acc[j], 0, 0, 0);
+            };
+            if (r == 0 && !SEED) {
 #pragma unroll
-                for (int j = 0; j < NW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F[kb], Q[kb][r][j], acc[j], 0, 0, 0);
-            // ---- exchange: local group j goes to wave (wave + j) % NW, which finds it in its source slot j - 1
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();  // every wave has read what the previous round left in the window
-            __builtin_amdgcn_sched_barrier(0);
+                for (int ks = 0; ks < NS; ++ks) {
+                    Raw x;
+                    wait_stage();
+                    read_stage(x);
 #pragma unroll
-            for (int j = 1; j < NW; ++j) {
-                unsigned char* dst = exch + (((wave + j) % NW) * (NW - 1) + (j - 1)) * 4096 + lane * 16;
+                    for (int b = 0; b < HB; ++b) mfma_kb(ks * SKB + b);
+                    refill(next, ks);
 #pragma unroll
-                for (int r4 = 0; r4 < 4; ++r4)
-                    *reinterpret_cast<hs_f4*>(dst + r4 * 1024) =
-                        hs_f4{acc[j][4 * r4], acc[j][4 * r4 + 1], acc[j][4 * r4 + 2], acc[j][4 * r4 + 3]};
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();  // all partial tiles are in LDS
-            __builtin_amdgcn_sched_barrier(0);
-            float sc[16];
-            {
-                const unsigned char* src = exch + wave * (NW - 1) * 4096 + lane * 16;
-                hs_f4 part[NW - 1][4];
-#pragma unroll
-                for (int s = 0; s < NW - 1; ++s)
-#pragma unroll
-                    for (int r4 = 0; r4 < 4; ++r4) part[s][r4] = *reinterpret_cast<const hs_f4*>(src + s * 4096 + r4 * 1024);
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    float s = acc[0][e];
-#pragma unroll
-                    for (int p = 0; p < NW - 1; ++p) s += part[p][e >> 2][e & 3];
-                    sc[e] = s * inv[r];  // exact: 1 / (s_q s_x) is a power of two
-                }
-            }
-            // ---- D[row][query]: query on the lane (fr), rows rl + 4 fk in the 16 registers
-            if (SEED) {
-                const int myq = (r * NW + wave) * 32 + fr;
-                if (myq < a.nq) {
-                    uint64_t* out = a.cand + ((int64_t)myq * gridDim.x + blockIdx.x) * 32;
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const int rl = (e & 3) + 8 * (e >> 2) + 4 * fk;
-                        out[rl] = m0 + rl <= last ? make_key(sc[e], (uint32_t)(m0 + rl)) : 0ull;
-                    }
+                    for (int b = HB; b < SKB; ++b) mfma_kb(ks * SKB + b);
+                    convert(x, F[P ^ 1], ks);
                 }
             } else {
-                float mx = sc[0];
 #pragma unroll
-                for (int e = 1; e < 16; ++e) mx = fmaxf(mx, sc[e]);
-                if (__ballot(mx >= thr[r]) != 0ull) {
-                    ++n_slow;
-                    uint64_t* rl_lists = mylists + (size_t)r * 32 * kHalfKeep;
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const int rl = (e & 3) + 8 * (e >> 2);
-                        const float s = sc[e];
-                        uint64_t mask = __ballot(m0 + rl + 4 * fk <= last && s >= thr[r]);
-                        while (mask) {
-                            const int srcl = __ffsll((long long)mask) - 1;
-                            mask &= mask - 1;
-                            ++n_ins;
-                            const int sq = srcl & 31;
-                            const float sv = __uint_as_float(__builtin_amdgcn_readlane((int)__float_as_uint(s), srcl));
-                            const uint32_t rv = (uint32_t)(m0 + rl + 4 * (srcl >> 5));
-                            const uint64_t kth = lds_list_insert(rl_lists + (size_t)sq * kHalfKeep, kHalfKeep, make_key(sv, rv), lane);
-                            if (fr == sq) thr[r] = kth ? fmaxf(key_score(kth), floor0[r]) : floor0[r];  // both lane halves
-                        }
-                    }
-                }
+                for (int kb = 0; kb < KQ; ++kb) mfma_kb(kb);
             }
+            if (r == 0)
+                finish_round(std::integral_constant<int, 0>{}, acc, m0);
+            else
+                finish_round(std::integral_constant<int, (NR > 1 ? 1 : 0)>{}, acc, m0);
         }
-        tile += step;
-        if (SEED) break;
+        tile = next;
+    };
+    static_assert(NR <= 2, "finish_round dispatch covers two rounds");
+    while (tile < ntiles) {
+        tile_body(std::integral_constant<int, 0>{});
+        if (SEED || tile >= ntiles) break;
+        tile_body(std::integral_constant<int, 1>{});
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the clamped look-ahead DMAs must land before the LDS is released
     if (SEED) return;
@@ -466,17 +551,24 @@ float half_xscale(float row_norm_bound) {
     return std::ldexp(1.f, 15 - e);
 }
 
-int half_max_queries(int d) {
+// Instantiations: d = 64 KQ.  128 queries per pass: 8-KiB stages x 3 at d = 512 / 768, 4-KiB stages x 6 otherwise;
+// 256 queries per pass (two exchange rounds per tile, 32 KiB of lists): 4-KiB stages x 5.
+static int half_kq(int d) {
     switch (d) {
-        case 512: return 128;
+        case 256: case 384: case 512: case 768: return d / 64;
         default: return 0;
     }
 }
 
+int half_max_queries(int d) {
+    if (!half_kq(d)) return 0;
+    return d <= 512 ? 256 : 128;
+}
+
 int half_chunk_queries(int d, int nq) {
     const int mx = half_max_queries(d);
-    (void)nq;
-    return mx;
+    if (!mx) return 0;
+    return nq > 128 && mx >= 256 ? 256 : 128;
 }
 
 int launch_half_queries(const float* q, int64_t ld, int d, int nq, int nqpad, float xscale, _Float16* qf, float* qnorm,
@@ -488,10 +580,11 @@ int launch_half_queries(const float* q, int64_t ld, int d, int nq, int nqpad, fl
     return 0;
 }
 
-template <int NW, int NG, int NST, bool SEED>
+template <int KQ, int SKB, int NG, int NST, bool SEED>
 static int launch_half_inst(const HalfScanArgs& a, int device, hipStream_t stream, int* nblocks_out) {
-    auto kern = flat_scan_half_kernel<NW, NG, NST, SEED>;
-    constexpr size_t lds = (size_t)NW * NST * kHsStage + (size_t)NW * (NW - 1) * 4096;
+    auto kern = flat_scan_half_kernel<KQ, SKB, NG, NST, SEED>;
+    constexpr size_t lds = (size_t)4 * NST * HsStage<SKB>::kBytes + (size_t)4 * 3 * 4096;
+    static_assert(lds + (SEED ? 128 : NG * 32 * kHalfKeep * 8) <= 160 * 1024, "LDS budget of a CU");
     {
         static std::mutex mu;
         static std::map<int, bool> done;
@@ -505,18 +598,38 @@ static int launch_half_inst(const HalfScanArgs& a, int device, hipStream_t strea
     const int nblocks = (int)std::max<int64_t>(1, std::min<int64_t>(ntiles, (int64_t)device_cus(device)));
     *nblocks_out = nblocks;
     int slot = prof_begin(SEED ? "ip_scan_half_seed" : "ip_scan_half", stream);
-    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(NW * 64), lds, stream, a);
+    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(256), lds, stream, a);
     prof_end(slot, stream);
     MVDB_HIP(hipGetLastError());
     return 0;
 }
 
-int launch_half_scan(int d, int nqpad, bool seed, const HalfScanArgs& a, int device, hipStream_t stream, int* nblocks_out) {
-    if (d == 512 && nqpad == 128) {
-        if (seed) return launch_half_inst<4, 4, 3, true>(a, device, stream, nblocks_out);
-        return launch_half_inst<4, 4, 3, false>(a, device, stream, nblocks_out);
+template <int KQ, int SKB4>
+static int launch_half_kq(int nqpad, bool seed, const HalfScanArgs& a, int device, hipStream_t stream, int* nb) {
+    // SKB4: 8-KiB stages for the 128-query main launch where KQ % 4 == 0 (d = 512: same speed as 4-KiB stages, 0.81 of
+    // the HBM peak; d = 768: 0.84)
+    if (nqpad == 128) {
+        if (seed) return launch_half_inst<KQ, 2, 4, 6, true>(a, device, stream, nb);
+        if (SKB4 && !getenv("MVDB_HALF_SMALL_STAGES")) return launch_half_inst<KQ, (SKB4 ? 4 : 2), 4, (SKB4 ? 3 : 6), false>(a, device, stream, nb);
+        return launch_half_inst<KQ, 2, 4, 6, false>(a, device, stream, nb);
     }
-    return fail(MVDB_ERR_ARG, "no fp16 nomination kernel for d = %d, %d queries per pass", d, nqpad);
+    if constexpr (KQ <= 8) {
+        if (nqpad == 256) {
+            if (seed) return launch_half_inst<KQ, 2, 8, 5, true>(a, device, stream, nb);
+            return launch_half_inst<KQ, 2, 8, 5, false>(a, device, stream, nb);
+        }
+    }
+    return fail(MVDB_ERR_ARG, "no fp16 nomination kernel for %d queries per pass at d = %d", nqpad, KQ * 64);
+}
+
+int launch_half_scan(int d, int nqpad, bool seed, const HalfScanArgs& a, int device, hipStream_t stream, int* nblocks_out) {
+    switch (half_kq(d)) {
+        case 4: return launch_half_kq<4, 0>(nqpad, seed, a, device, stream, nblocks_out);
+        case 6: return launch_half_kq<6, 0>(nqpad, seed, a, device, stream, nblocks_out);
+        case 8: return launch_half_kq<8, 1>(nqpad, seed, a, device, stream, nblocks_out);
+        case 12: return launch_half_kq<12, 1>(nqpad, seed, a, device, stream, nblocks_out);
+        default: return fail(MVDB_ERR_ARG, "no fp16 nomination kernel for d = %d", d);
+    }
 }
 
 int launch_half_certify(const HalfCertifyArgs& a, int nq, hipStream_t stream) {

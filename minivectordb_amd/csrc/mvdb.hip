@@ -915,7 +915,7 @@ int search_core(const mvdb_index* idx, Workspace* ws, const float* q_dev, int nq
             for (int c = 0; c < nchunks; ++c) {
                 const int c0 = plan[c].first, take = plan[c].second;
                 if (use_half && take >= min_nq)
-                    MVDB_TRY(launch_half_pass(idx, ws, qsrc + (int64_t)c0 * idx->ld, take, chunk, k, n, label_offset,
+                    MVDB_TRY(launch_half_pass(idx, ws, qsrc + (int64_t)c0 * idx->ld, take, half_chunk_queries(idx->d, take), k, n, label_offset,
                                               D_dev + (int64_t)c0 * k, I_dev + (int64_t)c0 * k, ws->flags.p + c));
                 else
                     MVDB_TRY(launch_split_scan(idx, ws, qsrc + (int64_t)c0 * idx->ld, take, k, n, label_offset,

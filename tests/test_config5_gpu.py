@@ -46,13 +46,13 @@ def test_config5_encoder_batch256_then_knn_10m_x_384(gpu):
     reruns = native.split_rerun_count()
     native.prof_enable(True)
     try:
-        for name in ("ip_scan_split_seed", "ip_scan_split"):
+        for name in ("ip_scan_split_seed", "ip_scan_split", "ip_scan_half_seed", "ip_scan_half"):
             native.prof_read(name)
         # the chain: encoder output tensor -> search, same stream, nothing touches the host in between
         emb2, _ = enc.forward_device(ids, mask)
         idx.search_device(emb2.data_ptr(), B, k, D.data_ptr(), I.data_ptr(), stream=stream)
         torch.cuda.synchronize()
-        assert native.prof_read("ip_scan_split_seed")[0] == 2, "256 queries = two 128-query split-precision passes"
+        assert native.prof_read("ip_scan_half_seed")[0] == 1, "256 queries = ONE certified fp16-nomination pass over the corpus"
     finally:
         native.prof_enable(False)
     assert native.split_rerun_count() == reruns, "random corpus: every query must certify"

@@ -529,7 +529,7 @@ def test_split_precision_batch_pass_matches_oracle(native, monkeypatch, n, d, k,
     try:
         _split_launches(native)  # drain
         D, I = idx.search(q, k)
-        assert _split_launches(native) >= max(1, nq // 128), "the split-precision pass did not run"
+        assert _split_launches(native) >= max(1, nq // 256), "the split-precision pass did not run"
     finally:
         native.prof_enable(False)
     _check(native, x, q, k, D, I, exact_vs_oracle=n < 100000)
