@@ -49,14 +49,14 @@ def main():
         sd[name] = t
     enc = GpuEncoder(cfg, sd, device=0)
     B = 256
-    for S in (32, 512):
+    for S in [int(v) for v in os.environ.get("MVDB_BENCH_S", "32,512").split(",")]:
         rs = np.random.RandomState(S)
         ids = torch.from_numpy(rs.randint(5, 250000, size=(B, S)).astype(np.int32)).to(dev)
         for ragged in (False, True):
             lens = rs.randint(S // 4, S + 1, size=B) if ragged else np.full(B, S)
             mask = torch.from_numpy((np.arange(S)[None, :] < lens[:, None]).astype(np.int32)).to(dev)
             T = int(lens.sum())
-            for compute in (0, 1):
+            for compute in (0, 2, 1):
                 for _ in range(3):
                     enc.forward_device(ids, mask, compute=compute)
                 torch.cuda.synchronize()
@@ -68,7 +68,7 @@ def main():
                 dt = (time.perf_counter() - t0) / n
                 gemm = T * 12 * (4 * 2 * H * H + 2 * 2 * H * F)
                 attn = float(sum(12 * 4 * int(l) * int(l) * H for l in lens))
-                print(json.dumps({"B": B, "S": S, "ragged": ragged, "compute": "bf16" if compute else "fp32",
+                print(json.dumps({"B": B, "S": S, "ragged": ragged, "compute": {0: "fp32", 1: "bf16", 2: "bf16x3"}[compute],
                                   "tokens": T, "ms": round(dt * 1e3, 3), "sentences_per_s": round(B / dt, 1),
                                   "tflops": round((gemm + attn) / dt / 1e12, 2), "gemm_tflop": round(gemm / 1e12, 3),
                                   "attn_tflop": round(attn / 1e12, 3),

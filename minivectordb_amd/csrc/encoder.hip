@@ -764,6 +764,173 @@ __global__ __launch_bounds__(256) void gemm_bf16_mfma_kernel(const float* __rest
 }
 
 // =================================================================================================
+// compute = 2: split-precision GEMM on the bf16 matrix cores, fp32-equivalent to ~2^-16
+//   a = ah + al + ra,  w = wh + wl + rw   (bf16 by RNE, |r| <= 2^-16 |.|)
+//   a.w ~ al.wh + ah.wl + ah.wh          three v_mfma_f32_32x32x16_bf16 per 16-k block, fp32 accumulate
+// The fp32 matrix cores (157 TFLOP/s) bound the exact GEMM at T = 8192; the bf16 cores are 16x faster, so three
+// products cost 3/16 of the fp32 MFMA time and the operand error (<= 4.6e-5 |a| |w| worst case, ~1e-6 of the output
+// in practice) stays 20x inside the parity tolerance of the embeddings (2e-5 absolute on unit vectors).  Activations
+// stay fp32 in HBM and are split in registers while they are staged into LDS; weights are split once into two bf16
+// planes (ensure_x3_weights).  Block tile BM x 128 x 32, four waves 2 x 2, register-staged double buffering, rows of
+// 64 B + 16 B pad in LDS (conflict-free b128 fragment reads).
+// =================================================================================================
+__global__ void f32_split_bf16_kernel(const float* __restrict__ in, __bf16* __restrict__ hi, __bf16* __restrict__ lo,
+                                      int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const float v = in[i];
+        const __bf16 h = (__bf16)v;
+        hi[i] = h;
+        lo[i] = (__bf16)(v - (float)h);
+    }
+}
+
+typedef float x3_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t x3_pack(float a, float b) {  // (lo 16 bits: bf16(a), hi 16 bits: bf16(b)), RNE
+    union { bf16x2 v; uint32_t u; } c;
+    c.v = __builtin_convertvector(x3_f2{a, b}, bf16x2);
+    return c.u;
+}
+
+template <int EPI, int BM>
+__global__ __launch_bounds__(256) void gemm_x3_kernel(const float* __restrict__ A, const __bf16* __restrict__ Wh,
+                                                      const __bf16* __restrict__ Wl, const float* __restrict__ bias,
+                                                      const float* __restrict__ R, float* __restrict__ C,
+                                                      const int* __restrict__ Tptr, int N, int K) {
+    constexpr int BN = 128, TM = BM / 64;
+    constexpr int TPR = 256 / BM;        // threads per A row
+    constexpr int KPT = HBK / TPR;       // k per thread and stage: 16 (BM = 128) or 8 (BM = 64)
+    constexpr int kBuf = (2 * BM + 2 * BN) * HROW;  // A_hi | A_lo | W_hi | W_lo
+    extern __shared__ __attribute__((aligned(16))) unsigned char xsm[];
+    const int T = *Tptr;
+    int bx, by;
+    if (!xcd_tile(T, BM, bx, by)) return;
+    const int m0 = by * BM, n0 = bx * BN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int ar = tid / TPR, ap = tid % TPR;  // A: row, part
+    const int wr = tid >> 1, wp = tid & 1;     // W planes: row, half (16 k)
+    const bool a_ok = m0 + ar < T, w_ok = n0 + wr < N;
+    const float* a_ptr = A + (int64_t)(a_ok ? m0 + ar : 0) * K + ap * KPT;
+    const int64_t w_off = (int64_t)(w_ok ? n0 + wr : 0) * K + wp * 16;
+    f32x4 ra[KPT / 4];
+    uint4 rwh[2], rwl[2];
+    auto stage_load = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < KPT / 4; ++i)
+            ra[i] = a_ok ? *reinterpret_cast<const f32x4*>(a_ptr + k0 + 4 * i) : f32x4{0, 0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            rwh[i] = w_ok ? *reinterpret_cast<const uint4*>(Wh + w_off + k0 + 8 * i) : uint4{0, 0, 0, 0};
+            rwl[i] = w_ok ? *reinterpret_cast<const uint4*>(Wl + w_off + k0 + 8 * i) : uint4{0, 0, 0, 0};
+        }
+    };
+    auto stage_write = [&](int buf) {
+        unsigned char* Ah = xsm + buf * kBuf;
+        unsigned char* Al = Ah + BM * HROW;
+        unsigned char* Bh = Al + BM * HROW;
+        unsigned char* Bl = Bh + BN * HROW;
+#pragma unroll
+        for (int i = 0; i < KPT / 8; ++i) {  // 8 elements -> one b128 of hi, one of lo
+            uint4 h, l;
+            uint32_t* hp = reinterpret_cast<uint32_t*>(&h);
+            uint32_t* lp = reinterpret_cast<uint32_t*>(&l);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float x0 = ra[2 * i + (e >> 1)][(e & 1) * 2], x1 = ra[2 * i + (e >> 1)][(e & 1) * 2 + 1];
+                const uint32_t hh = x3_pack(x0, x1);
+                hp[e] = hh;
+                lp[e] = x3_pack(x0 - __uint_as_float(hh << 16), x1 - __uint_as_float(hh & 0xFFFF0000u));
+            }
+            *reinterpret_cast<uint4*>(Ah + ar * HROW + ap * KPT * 2 + i * 16) = h;
+            *reinterpret_cast<uint4*>(Al + ar * HROW + ap * KPT * 2 + i * 16) = l;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            *reinterpret_cast<uint4*>(Bh + wr * HROW + wp * 32 + i * 16) = rwh[i];
+            *reinterpret_cast<uint4*>(Bl + wr * HROW + wp * 32 + i * 16) = rwl[i];
+        }
+    };
+
+    f32x16 acc[TM][2];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = K / HBK;
+    stage_load(0);
+    stage_write(0);
+    __syncthreads();
+    const int fr = lane & 31, fh = lane >> 5;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) stage_load((kt + 1) * HBK);  // in flight during the MFMAs below
+        const unsigned char* Ah = xsm + buf * kBuf;
+        const unsigned char* Al = Ah + BM * HROW;
+        const unsigned char* Bh = Al + BM * HROW;
+        const unsigned char* Bl = Bh + BN * HROW;
+#pragma unroll
+        for (int ks = 0; ks < HBK / 16; ++ks) {
+            // lane l: row l & 31, k = 8 (l >> 5) .. + 7 of this 16-deep step
+            const int off = ks * 32 + fh * 16;
+            bf16x8 ah[TM], al[TM], bh[2], bl[2];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int row = wm * (BM / 2) + i * 32 + fr;
+                ah[i] = *reinterpret_cast<const bf16x8*>(Ah + row * HROW + off);
+                al[i] = *reinterpret_cast<const bf16x8*>(Al + row * HROW + off);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int row = wn * 64 + j * 32 + fr;
+                bh[j] = *reinterpret_cast<const bf16x8*>(Bh + row * HROW + off);
+                bl[j] = *reinterpret_cast<const bf16x8*>(Bl + row * HROW + off);
+            }
+            // small cross terms first, the leading product last
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nk) {
+            stage_write(buf ^ 1);  // the other buffer: last read one iteration ago, behind the barrier below
+            __syncthreads();
+        }
+    }
+    // epilogue.  C/D map of 32x32: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wn * 64 + j * 32 + fr;
+            if (col >= N) continue;
+            const float bv = bias[col];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                if (row < T) {
+                    float v = acc[i][j][r] + bv;
+                    if (EPI == EPI_BIAS_GELU) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+                    if (EPI == EPI_BIAS_RESIDUAL) v += R[(int64_t)row * N + col];
+                    C[(int64_t)row * N + col] = v;
+                }
+            }
+        }
+}
+
+// =================================================================================================
 // attention: one thread per query row, K/V tiles broadcast from LDS, chunked online softmax (fp32)
 // =================================================================================================
 constexpr int ATT_Q = 128;  // queries per block
@@ -997,6 +1164,7 @@ struct LayerW {
     const float *wqkv, *bqkv;  // fused (library owned)
     const float *wo, *bo, *ln1g, *ln1b, *w1, *b1, *w2, *b2, *ln2g, *ln2b;
     __bf16 *wqkv_h = nullptr, *wo_h = nullptr, *w1_h = nullptr, *w2_h = nullptr;  // lazily made bf16 copies
+    __bf16 *wqkv_l = nullptr, *wo_l = nullptr, *w1_l = nullptr, *w2_l = nullptr;  // low planes of the split (compute = 2)
 };
 
 }  // namespace
@@ -1021,7 +1189,7 @@ struct mvdb_encoder {
     std::vector<LayerW> layers;
     std::vector<float*> owned;  // fused qkv weights / biases
     std::vector<void*> owned_h; // bf16 weight copies (compute = 1)
-    bool have_bf16 = false;
+    bool have_bf16 = false, have_x3 = false;
     // workspace (grown on demand), guarded by mu: one forward at a time per encoder
     std::mutex mu;
     int64_t cap_tokens = 0, cap_b = 0;
@@ -1207,6 +1375,69 @@ int ensure_bf16_weights(mvdb_encoder* e, hipStream_t s) {
     return 0;
 }
 
+// compute = 2: BM = 128 when the 128 x 128 grid fills the chip's one-block-per-CU slots at least three times, else 64
+template <int EPI, int BM>
+int launch_gemm_x3_inst(const float* A, const __bf16* Wh, const __bf16* Wl, const float* bias, const float* R, float* C,
+                        const int* Tptr, int64_t Tmax, int N, int K, int device, hipStream_t s) {
+    auto kern = gemm_x3_kernel<EPI, BM>;
+    constexpr int lds = 2 * (2 * BM + 256) * HROW;
+    {
+        static std::mutex mu;
+        static std::map<int, bool> done;
+        std::lock_guard<std::mutex> lk(mu);
+        if (!done[device]) {
+            MVDB_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            done[device] = true;
+        }
+    }
+    dim3 grid((N + 127) / 128, (unsigned)((Tmax + BM - 1) / BM));
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, A, Wh, Wl, bias, R, C, Tptr, N, K);
+    return 0;
+}
+
+template <int EPI>
+int launch_gemm_x3(const float* A, const __bf16* Wh, const __bf16* Wl, const float* bias, const float* R, float* C,
+                   const int* Tptr, int64_t Tmax, int N, int K, int cus, int device, hipStream_t s) {
+    static const int force = []() { const char* v = getenv("MVDB_GEMM_X3_BM"); return v ? atoi(v) : 0; }();
+    const int64_t big = (int64_t)((N + 127) / 128) * ((Tmax + 127) / 128);
+    const bool bm128 = force ? force == 128 : big >= (int64_t)3 * cus;
+    if (bm128) return launch_gemm_x3_inst<EPI, 128>(A, Wh, Wl, bias, R, C, Tptr, Tmax, N, K, device, s);
+    return launch_gemm_x3_inst<EPI, 64>(A, Wh, Wl, bias, R, C, Tptr, Tmax, N, K, device, s);
+}
+
+int make_planes(mvdb_encoder* e, const float* src, int64_t n, __bf16** hi, __bf16** lo, hipStream_t s) {
+    __bf16 *h = nullptr, *l = nullptr;
+    MVDB_HIP(hipMalloc((void**)&h, (size_t)n * sizeof(__bf16)));
+    e->owned_h.push_back(h);
+    MVDB_HIP(hipMalloc((void**)&l, (size_t)n * sizeof(__bf16)));
+    e->owned_h.push_back(l);
+    hipLaunchKernelGGL(f32_split_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, h, l, n);
+    *hi = h;
+    *lo = l;
+    return 0;
+}
+
+int ensure_x3_weights(mvdb_encoder* e, hipStream_t s) {
+    if (e->have_x3) return 0;
+    const int64_t H = e->cfg.hidden, F = e->cfg.intermediate;
+    for (LayerW& L : e->layers) {
+        // the high planes are the bf16 copies of compute = 1: made here when that mode has not run yet
+        __bf16* h = nullptr;
+        MVDB_TRY(make_planes(e, L.wqkv, 3 * H * H, &h, &L.wqkv_l, s));
+        if (!L.wqkv_h) L.wqkv_h = h;
+        MVDB_TRY(make_planes(e, L.wo, H * H, &h, &L.wo_l, s));
+        if (!L.wo_h) L.wo_h = h;
+        MVDB_TRY(make_planes(e, L.w1, F * H, &h, &L.w1_l, s));
+        if (!L.w1_h) L.w1_h = h;
+        MVDB_TRY(make_planes(e, L.w2, H * F, &h, &L.w2_l, s));
+        if (!L.w2_h) L.w2_h = h;
+    }
+    MVDB_HIP(hipGetLastError());
+    e->have_x3 = true;
+    e->have_bf16 = true;
+    return 0;
+}
+
 template <int VPT>
 void launch_ln(const float* y, const int* seq_start, int B, const float* g, const float* b, float eps,
                int H, float* x, int64_t Tmax, hipStream_t s) {
@@ -1253,7 +1484,9 @@ int enqueue_lane(mvdb_encoder* e, mvdb_encoder::Lane& w, const int32_t* ids, con
     }();
     const dim3 agrid((S + ATT_Q - 1) / ATT_Q, c.heads, B);
     for (const LayerW& L : e->layers) {
-        if (compute == 1)
+        if (compute == 2)
+            MVDB_TRY(launch_gemm_x3<EPI_BIAS>(w.x, L.wqkv_h, L.wqkv_l, L.bqkv, nullptr, w.qkv, Tptr, Tmax, 3 * H, H, cus, e->device, s));
+        else if (compute == 1)
             launch_gemm_h<EPI_BIAS>(w.x, L.wqkv_h, L.bqkv, nullptr, w.qkv, Tptr, Tmax, 3 * H, H, s);
         else
             launch_gemm<EPI_BIAS>(w.x, L.wqkv, L.bqkv, nullptr, w.qkv, Tptr, Tmax, 3 * H, H, cus, s);
@@ -1271,14 +1504,19 @@ int enqueue_lane(mvdb_encoder* e, mvdb_encoder::Lane& w, const int32_t* ids, con
             hipLaunchKernelGGL(attention_mfma_kernel<64>, agrid, dim3(256), 0, s, w.qkv, w.seq_start, H, scale,
                                w.ctx);
         }
-        if (compute == 1)
+        if (compute == 2)
+            MVDB_TRY(launch_gemm_x3<EPI_BIAS_RESIDUAL>(w.ctx, L.wo_h, L.wo_l, L.bo, w.x, w.y, Tptr, Tmax, H, H, cus, e->device, s));
+        else if (compute == 1)
             launch_gemm_h<EPI_BIAS_RESIDUAL>(w.ctx, L.wo_h, L.bo, w.x, w.y, Tptr, Tmax, H, H, s);
         else
             launch_gemm<EPI_BIAS_RESIDUAL>(w.ctx, L.wo, L.bo, w.x, w.y, Tptr, Tmax, H, H, cus, s);
 #define LN1_CALL(V) launch_ln<V>(w.y, w.seq_start, B, L.ln1g, L.ln1b, c.ln_eps, H, w.x, Tmax, s)
         MVDB_VPT_SWITCH(LN1_CALL)
 #undef LN1_CALL
-        if (compute == 1) {
+        if (compute == 2) {
+            MVDB_TRY(launch_gemm_x3<EPI_BIAS_GELU>(w.x, L.w1_h, L.w1_l, L.b1, nullptr, w.ffn, Tptr, Tmax, F, H, cus, e->device, s));
+            MVDB_TRY(launch_gemm_x3<EPI_BIAS_RESIDUAL>(w.ffn, L.w2_h, L.w2_l, L.b2, w.x, w.y, Tptr, Tmax, H, F, cus, e->device, s));
+        } else if (compute == 1) {
             launch_gemm_h<EPI_BIAS_GELU>(w.x, L.w1_h, L.b1, nullptr, w.ffn, Tptr, Tmax, F, H, s);
             launch_gemm_h<EPI_BIAS_RESIDUAL>(w.ffn, L.w2_h, L.b2, w.x, w.y, Tptr, Tmax, H, F, s);
         } else {
@@ -1324,16 +1562,19 @@ int enqueue_forward(mvdb_encoder* e, const int32_t* ids, const int32_t* mask, in
 
 int forward_core(mvdb_encoder* e, const int32_t* ids, const int32_t* mask, int B, int S, int compute,
                  float* out, float* hidden, hipStream_t s) {
-    if (compute != 0 && compute != 1)
-        return fail(MVDB_ERR_ARG, "unknown compute mode %d (0 = exact-fp32 MFMA, 1 = bf16 MFMA operands)", compute);
+    if (compute < 0 || compute > 2)
+        return fail(MVDB_ERR_ARG, "unknown compute mode %d (0 = exact-fp32 MFMA, 1 = bf16 MFMA operands, 2 = split-precision bf16 x 3)", compute);
     const mvdb_encoder_cfg& c = e->cfg;
     if (B <= 0 || S <= 0) return fail(MVDB_ERR_ARG, "B and S must be positive");
     if (S + (c.position_offset > 0 ? c.position_offset : 0) > c.max_positions)
         return fail(MVDB_ERR_ARG, "sequence length %d exceeds max_positions %d", S, c.max_positions);
-    if (compute == 1) {
+    if (compute != 0) {
         if (c.hidden % HBK || c.intermediate % HBK)
-            return fail(MVDB_ERR_ARG, "bf16 mode needs hidden and intermediate to be multiples of %d", HBK);
-        MVDB_TRY(ensure_bf16_weights(e, s));
+            return fail(MVDB_ERR_ARG, "bf16 modes need hidden and intermediate to be multiples of %d", HBK);
+        if (compute == 1)
+            MVDB_TRY(ensure_bf16_weights(e, s));
+        else
+            MVDB_TRY(ensure_x3_weights(e, s));
     }
     const int64_t cap_before = e->cap_tokens;
     MVDB_TRY(ensure_ws(e, B, S));

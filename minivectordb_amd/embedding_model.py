@@ -23,6 +23,7 @@ Extras for offline / batched use: ``model_path`` (local HF directory), or ``stat
 ``config`` (+ ``tokenizer``) to inject weights; ``extract_embeddings_batch`` and ``encode_ids``.
 """
 import ctypes
+import os
 from enum import Enum
 
 import numpy as np
@@ -81,6 +82,10 @@ class GpuEncoder:
         self._h = ctypes.c_void_p()
         _native.check(lib.mvdb_encoder_create(ctypes.byref(self.cfg), table, device, ctypes.byref(self._h)))
         self.hidden = self.cfg.hidden
+        # arithmetic of the GEMMs when a call does not say: 2 = split-precision bf16 x 3 on the bf16 matrix cores
+        # (fp32-equivalent to ~2^-16: embeddings within 7e-6 of transformers' fp32 output, tests/test_encoder_gpu.py),
+        # 0 = exact fp32 matrix cores, 1 = single bf16 product (opt-in speed mode, ~1e-3)
+        self.default_compute = int(os.environ.get("MVDB_ENCODER_COMPUTE", "2"))
 
     def close(self):
         if getattr(self, "_h", None):
@@ -93,8 +98,9 @@ class GpuEncoder:
         except Exception:
             pass
 
-    def forward(self, ids, mask, compute=0):
+    def forward(self, ids, mask, compute=None):
         """ids, mask: int arrays [B,S] (host).  Returns pooled + normalised float32 [B,H]."""
+        compute = self.default_compute if compute is None else compute
         ids = np.ascontiguousarray(ids, dtype=np.int32)
         mask = np.ascontiguousarray(mask, dtype=np.int32)
         if ids.ndim != 2 or ids.shape != mask.shape:
@@ -106,10 +112,11 @@ class GpuEncoder:
             ctypes.c_void_p(out.ctypes.data)))
         return out
 
-    def forward_device(self, ids, mask, compute=0, want_hidden=False):
+    def forward_device(self, ids, mask, compute=None, want_hidden=False):
         """ids, mask: int32 torch tensors [B,S] on this device.  Returns (pooled [B,H], hidden [B,S,H] or
         None) as torch tensors; enqueued on torch's current stream."""
         import torch
+        compute = self.default_compute if compute is None else compute
         B, S = ids.shape
         out = torch.empty((B, self.hidden), dtype=torch.float32, device=self.device)
         hidden = torch.empty((B, S, self.hidden), dtype=torch.float32, device=self.device) if want_hidden else None
@@ -192,7 +199,7 @@ class EmbeddingModel:
                                return_tensors='np')
         return np.asarray(batch['input_ids'], dtype=np.int32), np.asarray(batch['attention_mask'], dtype=np.int32)
 
-    def encode_ids(self, input_ids, attention_mask, compute=0):
+    def encode_ids(self, input_ids, attention_mask, compute=None):
         """Token ids / mask [B,S] -> float32 [B,H] pooled, normalised embeddings (GPU)."""
         return self.model.forward(input_ids, attention_mask, compute=compute)
 
