@@ -785,6 +785,18 @@ __global__ void f32_split_bf16_kernel(const float* __restrict__ in, __bf16* __re
     }
 }
 
+// [N][K] fp32 -> [N][K / 32][hi 32 | lo 32] bf16: the W operand of gemm_x3_dma_kernel
+__global__ void f32_split_interleave_kernel(const float* __restrict__ in, __bf16* __restrict__ out, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const float v = in[i];
+        const __bf16 h = (__bf16)v;
+        const int64_t o = (i >> 5) * 64 + (i & 31);  // K % 32 == 0: 32-k blocks never straddle rows
+        out[o] = h;
+        out[o + 32] = (__bf16)(v - (float)h);
+    }
+}
+
 typedef float x3_f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t x3_pack(float a, float b) {  // (lo 16 bits: bf16(a), hi 16 bits: bf16(b)), RNE
     union { bf16x2 v; uint32_t u; } c;
@@ -909,6 +921,175 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(const float* __restrict__ 
             __syncthreads();
         }
     }
+    // epilogue.  C/D map of 32x32: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wn * 64 + j * 32 + fr;
+            if (col >= N) continue;
+            const float bv = bias[col];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                if (row < T) {
+                    float v = acc[i][j][r] + bv;
+                    if (EPI == EPI_BIAS_GELU) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+                    if (EPI == EPI_BIAS_RESIDUAL) v += R[(int64_t)row * N + col];
+                    C[(int64_t)row * N + col] = v;
+                }
+            }
+        }
+}
+
+// The same split-precision GEMM with LDS-DMA staging (default): the register-staged kernel above prefetches ONE
+// K-step, whose global loads (1-2 us) are consumed a few hundred cycles of MFMA later — at T = 8192 it runs at the
+// speed of that latency.  Here fp32 A rows and the two bf16 planes of W go global -> LDS by global_load_lds into a
+// three-stage ring (two K-steps in flight, ONE bare s_barrier per K-step, as gemm_f32_dma_kernel); A fragments are
+// split into (hi, lo) in registers on their way from LDS to the MFMA (6 VALU per pair, in the MFMAs' shadow).
+//   stage = [A: BM rows x 128 B (32 fp32 k)] [W: 128 rows x 128 B (32 k of the hi plane | 32 k of the lo plane)]
+//   W comes from an INTERLEAVED copy of the two planes ([row][K / 32][hi 32 | lo 32], f32_split_interleave_kernel): one
+//   full 128-byte line per row and K-step — with separate planes every request used half a line and the L2 moved
+//   twice the W bytes (PMC: 4.9M line requests per QKV GEMM at T = 8192, 88 % L2 hits, waves parked 49 % of the time)
+//   bank swizzle on the DMA source: slot p of row r holds the row's logical slot p ^ ((r >> 1) & 7)
+template <int EPI, int BM, int NST>
+__global__ __launch_bounds__(256) void gemm_x3_dma_kernel(const float* __restrict__ A, const __bf16* __restrict__ Wp,
+                                                          const float* __restrict__ bias,
+                                                          const float* __restrict__ R, float* __restrict__ C,
+                                                          const int* __restrict__ Tptr, int N, int K) {
+    constexpr int BN = 128, TM = BM / 64;
+    constexpr int kA = BM * 128, kStage = kA + 2 * BN * 64;
+    constexpr int NA = BM / 8;             // DMA instructions of the A tile (8 rows each)
+    constexpr int NI = (NA + 16) / 4;      // per wave and stage (W planes: 8 instructions of 16 rows each)
+    extern __shared__ __attribute__((aligned(16))) unsigned char xsm[];
+    const int T = *Tptr;
+    int bx, by;
+    if (!xcd_tile(T, BM, bx, by)) return;
+    const int m0 = by * BM, n0 = bx * BN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int fr = lane & 31, fh = lane >> 5;
+
+    // DMA roles: instruction q of a stage; wave w issues q = w NI .. w NI + NI - 1 (the kind of q is wave-uniform)
+    uint32_t voff[NI];
+    const char* sbase[NI];
+    int kstep[NI], dsto[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int q = wave * NI + i;
+        if (q < NA) {
+            const int row = 8 * q + (lane >> 3);
+            const int slot = (lane & 7) ^ ((row >> 1) & 7);
+            int g = m0 + row;
+            g = g < T ? g : T - 1;  // rows past the edge: clamped (masked in the epilogue)
+            sbase[i] = reinterpret_cast<const char*>(A);
+            voff[i] = (uint32_t)(((int64_t)g * K * 4) + 16 * slot);
+            kstep[i] = 128;
+            dsto[i] = q * 1024;
+        } else {
+            const int qq = q - NA;  // 8 rows of [hi 64 B | lo 64 B] = one 128-byte line per row and K-step
+            const int row = 8 * qq + (lane >> 3);
+            const int slot = (lane & 7) ^ ((row >> 1) & 7);
+            int g = n0 + row;
+            g = g < N ? g : N - 1;
+            sbase[i] = reinterpret_cast<const char*>(Wp);
+            voff[i] = (uint32_t)(((int64_t)g * K * 4) + 16 * slot);
+            kstep[i] = 128;
+            dsto[i] = kA + qq * 1024;
+        }
+    }
+    auto issue = [&](int kt, int stage) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const char* src = sbase[i] + (int64_t)kt * kstep[i];
+            __builtin_amdgcn_global_load_lds((enc_gbl_ptr)(src + voff[i]), (enc_lds_ptr)(xsm + stage * kStage + dsto[i]), 16, 0, 0);
+        }
+    };
+    // fragment byte offsets inside a stage
+    int a_off[TM][2][2], b_off[2][2][2];
+    const int ga = (fr >> 1) & 7;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+                a_off[i][ks][h] = (wm * (BM / 2) + i * 32 + fr) * 128 + (((4 * ks + 2 * fh + h) ^ ga) << 4);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl)
+                b_off[j][ks][pl] = kA + (wn * 64 + j * 32 + fr) * 128 + (((4 * pl + 2 * ks + fh) ^ ga) << 4);
+
+    f32x16 acc[TM][2];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = K / 32;
+    // ring: NST - 1 stages in flight.  Stages past the end are issued too (clamped to the last K-step, into buffers
+    // nobody reads) so that every counted wait sees a full ring.
+#pragma unroll
+    for (int u = 0; u < NST - 1; ++u) issue(u < nk ? u : nk - 1, u);
+    int st = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * NI) : "memory");  // this wave's part of stage kt has landed
+        __builtin_amdgcn_s_barrier();  // every wave's part has; and every wave is done reading stage kt - 1
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            const int ahead = kt + NST - 1;
+            issue(ahead < nk ? ahead : nk - 1, st == 0 ? NST - 1 : st - 1);  // into the buffer of stage kt - 1
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned char* sb = xsm + st * kStage;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            union Op {
+                bf16x8 v;
+                uint32_t w[4];
+            } ah[TM], al[TM];
+            bf16x8 bh[2], bl[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                bh[j] = *reinterpret_cast<const bf16x8*>(sb + b_off[j][ks][0]);
+                bl[j] = *reinterpret_cast<const bf16x8*>(sb + b_off[j][ks][1]);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const f32x4 x0 = *reinterpret_cast<const f32x4*>(sb + a_off[i][ks][0]);
+                const f32x4 x1 = *reinterpret_cast<const f32x4*>(sb + a_off[i][ks][1]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float p0 = e < 2 ? x0[2 * e] : x1[2 * (e - 2)], p1 = e < 2 ? x0[2 * e + 1] : x1[2 * (e - 2) + 1];
+                    const uint32_t hh = x3_pack(p0, p1);
+                    ah[i].w[e] = hh;
+                    al[i].w[e] = x3_pack(p0 - __uint_as_float(hh << 16), p1 - __uint_as_float(hh & 0xFFFF0000u));
+                }
+            }
+            // small cross terms first, the leading product last
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i].v, bh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i].v, bl[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i].v, bh[j], acc[i][j], 0, 0, 0);
+        }
+        st = st == NST - 1 ? 0 : st + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the clamped look-ahead DMAs must land before the LDS is released
     // epilogue.  C/D map of 32x32: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -1165,6 +1346,7 @@ struct LayerW {
     const float *wo, *bo, *ln1g, *ln1b, *w1, *b1, *w2, *b2, *ln2g, *ln2b;
     __bf16 *wqkv_h = nullptr, *wo_h = nullptr, *w1_h = nullptr, *w2_h = nullptr;  // lazily made bf16 copies
     __bf16 *wqkv_l = nullptr, *wo_l = nullptr, *w1_l = nullptr, *w2_l = nullptr;  // low planes of the split (compute = 2)
+    __bf16 *wqkv_p = nullptr, *wo_p = nullptr, *w1_p = nullptr, *w2_p = nullptr;  // (hi | lo) interleaved per 32-k block
 };
 
 }  // namespace
@@ -1376,33 +1558,53 @@ int ensure_bf16_weights(mvdb_encoder* e, hipStream_t s) {
 }
 
 // compute = 2: BM = 128 when the 128 x 128 grid fills the chip's one-block-per-CU slots at least three times, else 64
-template <int EPI, int BM>
-int launch_gemm_x3_inst(const float* A, const __bf16* Wh, const __bf16* Wl, const float* bias, const float* R, float* C,
-                        const int* Tptr, int64_t Tmax, int N, int K, int device, hipStream_t s) {
-    auto kern = gemm_x3_kernel<EPI, BM>;
-    constexpr int lds = 2 * (2 * BM + 256) * HROW;
-    {
-        static std::mutex mu;
-        static std::map<int, bool> done;
-        std::lock_guard<std::mutex> lk(mu);
-        if (!done[device]) {
-            MVDB_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-            done[device] = true;
-        }
+template <typename Kern>
+int x3_lds_attr(Kern kern, int lds, int device) {
+    static std::mutex mu;
+    static std::map<int, bool> done;  // one instance of this function (and of `done`) per kernel type
+    std::lock_guard<std::mutex> lk(mu);
+    if (!done[device]) {
+        MVDB_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        done[device] = true;
     }
+    return 0;
+}
+
+struct X3W {
+    const __bf16 *hi, *lo, *il;  // separate planes (register-staged kernel), interleaved copy (LDS-DMA kernel)
+};
+
+template <int EPI, int BM, bool DMA, int NST = 3>
+int launch_gemm_x3_inst(const float* A, X3W W, const float* bias, const float* R, float* C,
+                        const int* Tptr, int64_t Tmax, int N, int K, int device, hipStream_t s) {
     dim3 grid((N + 127) / 128, (unsigned)((Tmax + BM - 1) / BM));
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, A, Wh, Wl, bias, R, C, Tptr, N, K);
+    if constexpr (DMA) {
+        auto kern = gemm_x3_dma_kernel<EPI, BM, NST>;
+        constexpr int lds = NST * (BM * 128 + 128 * 128);
+        MVDB_TRY(x3_lds_attr(kern, lds, device));
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, A, W.il, bias, R, C, Tptr, N, K);
+    } else {
+        auto kern = gemm_x3_kernel<EPI, BM>;
+        constexpr int lds = 2 * (2 * BM + 256) * HROW;
+        MVDB_TRY(x3_lds_attr(kern, lds, device));
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, A, W.hi, W.lo, bias, R, C, Tptr, N, K);
+    }
     return 0;
 }
 
 template <int EPI>
-int launch_gemm_x3(const float* A, const __bf16* Wh, const __bf16* Wl, const float* bias, const float* R, float* C,
+int launch_gemm_x3(const float* A, X3W Wh, const float* bias, const float* R, float* C,
                    const int* Tptr, int64_t Tmax, int N, int K, int cus, int device, hipStream_t s) {
     static const int force = []() { const char* v = getenv("MVDB_GEMM_X3_BM"); return v ? atoi(v) : 0; }();
+    static const bool dma = []() { const char* v = getenv("MVDB_GEMM_X3_DMA"); return !(v && *v == '0'); }();
     const int64_t big = (int64_t)((N + 127) / 128) * ((Tmax + 127) / 128);
     const bool bm128 = force ? force == 128 : big >= (int64_t)3 * cus;
-    if (bm128) return launch_gemm_x3_inst<EPI, 128>(A, Wh, Wl, bias, R, C, Tptr, Tmax, N, K, device, s);
-    return launch_gemm_x3_inst<EPI, 64>(A, Wh, Wl, bias, R, C, Tptr, Tmax, N, K, device, s);
+    // LDS-DMA kernel, 64 x 128 tiles, three stages, two workgroups per CU: measured best at every shape (B = 256: S = 32
+    // 2.68 ms vs 3.04 with 128-row tiles for the wide GEMMs, 3.15 register-staged; S = 512 43.8 ms vs 55.7 / 45.3;
+    // rings of 2, 4 or 6 stages, i.e. 3 or 1 workgroups per CU: within 1 %)
+    if (dma) return launch_gemm_x3_inst<EPI, 64, true, 3>(A, Wh, bias, R, C, Tptr, Tmax, N, K, device, s);
+    if (bm128) return launch_gemm_x3_inst<EPI, 128, false>(A, Wh, bias, R, C, Tptr, Tmax, N, K, device, s);
+    return launch_gemm_x3_inst<EPI, 64, false>(A, Wh, bias, R, C, Tptr, Tmax, N, K, device, s);
 }
 
 int make_planes(mvdb_encoder* e, const float* src, int64_t n, __bf16** hi, __bf16** lo, hipStream_t s) {
@@ -1417,10 +1619,23 @@ int make_planes(mvdb_encoder* e, const float* src, int64_t n, __bf16** hi, __bf1
     return 0;
 }
 
+int make_interleaved(mvdb_encoder* e, const float* src, int64_t n, __bf16** out, hipStream_t s) {
+    __bf16* p = nullptr;
+    MVDB_HIP(hipMalloc((void**)&p, (size_t)n * 2 * sizeof(__bf16)));
+    e->owned_h.push_back(p);
+    hipLaunchKernelGGL(f32_split_interleave_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, p, n);
+    *out = p;
+    return 0;
+}
+
 int ensure_x3_weights(mvdb_encoder* e, hipStream_t s) {
     if (e->have_x3) return 0;
     const int64_t H = e->cfg.hidden, F = e->cfg.intermediate;
     for (LayerW& L : e->layers) {
+        MVDB_TRY(make_interleaved(e, L.wqkv, 3 * H * H, &L.wqkv_p, s));
+        MVDB_TRY(make_interleaved(e, L.wo, H * H, &L.wo_p, s));
+        MVDB_TRY(make_interleaved(e, L.w1, F * H, &L.w1_p, s));
+        MVDB_TRY(make_interleaved(e, L.w2, H * F, &L.w2_p, s));
         // the high planes are the bf16 copies of compute = 1: made here when that mode has not run yet
         __bf16* h = nullptr;
         MVDB_TRY(make_planes(e, L.wqkv, 3 * H * H, &h, &L.wqkv_l, s));
@@ -1485,7 +1700,7 @@ int enqueue_lane(mvdb_encoder* e, mvdb_encoder::Lane& w, const int32_t* ids, con
     const dim3 agrid((S + ATT_Q - 1) / ATT_Q, c.heads, B);
     for (const LayerW& L : e->layers) {
         if (compute == 2)
-            MVDB_TRY(launch_gemm_x3<EPI_BIAS>(w.x, L.wqkv_h, L.wqkv_l, L.bqkv, nullptr, w.qkv, Tptr, Tmax, 3 * H, H, cus, e->device, s));
+            MVDB_TRY(launch_gemm_x3<EPI_BIAS>(w.x, X3W{L.wqkv_h, L.wqkv_l, L.wqkv_p}, L.bqkv, nullptr, w.qkv, Tptr, Tmax, 3 * H, H, cus, e->device, s));
         else if (compute == 1)
             launch_gemm_h<EPI_BIAS>(w.x, L.wqkv_h, L.bqkv, nullptr, w.qkv, Tptr, Tmax, 3 * H, H, s);
         else
@@ -1505,7 +1720,7 @@ int enqueue_lane(mvdb_encoder* e, mvdb_encoder::Lane& w, const int32_t* ids, con
                                w.ctx);
         }
         if (compute == 2)
-            MVDB_TRY(launch_gemm_x3<EPI_BIAS_RESIDUAL>(w.ctx, L.wo_h, L.wo_l, L.bo, w.x, w.y, Tptr, Tmax, H, H, cus, e->device, s));
+            MVDB_TRY(launch_gemm_x3<EPI_BIAS_RESIDUAL>(w.ctx, X3W{L.wo_h, L.wo_l, L.wo_p}, L.bo, w.x, w.y, Tptr, Tmax, H, H, cus, e->device, s));
         else if (compute == 1)
             launch_gemm_h<EPI_BIAS_RESIDUAL>(w.ctx, L.wo_h, L.bo, w.x, w.y, Tptr, Tmax, H, H, s);
         else
@@ -1514,8 +1729,8 @@ int enqueue_lane(mvdb_encoder* e, mvdb_encoder::Lane& w, const int32_t* ids, con
         MVDB_VPT_SWITCH(LN1_CALL)
 #undef LN1_CALL
         if (compute == 2) {
-            MVDB_TRY(launch_gemm_x3<EPI_BIAS_GELU>(w.x, L.w1_h, L.w1_l, L.b1, nullptr, w.ffn, Tptr, Tmax, F, H, cus, e->device, s));
-            MVDB_TRY(launch_gemm_x3<EPI_BIAS_RESIDUAL>(w.ffn, L.w2_h, L.w2_l, L.b2, w.x, w.y, Tptr, Tmax, H, F, cus, e->device, s));
+            MVDB_TRY(launch_gemm_x3<EPI_BIAS_GELU>(w.x, X3W{L.w1_h, L.w1_l, L.w1_p}, L.b1, nullptr, w.ffn, Tptr, Tmax, F, H, cus, e->device, s));
+            MVDB_TRY(launch_gemm_x3<EPI_BIAS_RESIDUAL>(w.ffn, X3W{L.w2_h, L.w2_l, L.w2_p}, L.b2, w.x, w.y, Tptr, Tmax, H, F, cus, e->device, s));
         } else if (compute == 1) {
             launch_gemm_h<EPI_BIAS_GELU>(w.x, L.w1_h, L.b1, nullptr, w.ffn, Tptr, Tmax, F, H, s);
             launch_gemm_h<EPI_BIAS_RESIDUAL>(w.ffn, L.w2_h, L.b2, w.x, w.y, Tptr, Tmax, H, F, s);
