@@ -1,5 +1,6 @@
 #!/bin/bash
 # A/B runs of the fp16 nomination pass (half_scan.hip) on one MI355X: writes gpurun_out/half_probe.jsonl
+cd ${GRAFT_REPO_ROOT:-.}
 out=gpurun_out/half_probe.jsonl
 : > $out
 run() { # label, env..., -- bench args
@@ -18,6 +19,8 @@ run "d384 nq128" X=1 -- --nq 128 --dim 384 --steps 20 --warmup 3
 run "d384 nq256" X=1 -- --nq 256 --dim 384 --steps 20 --warmup 3
 run "d384 nq256 old" MVDB_DISABLE_HALF_SCAN=1 -- --nq 256 --dim 384 --steps 20 --warmup 3
 run "d256 nq256" X=1 -- --nq 256 --dim 256 --steps 20 --warmup 3
+run "d1024 nq128" X=1 -- --nq 128 --dim 1024 --rows 5000000 --steps 20 --warmup 3
+run "d1024 nq128 old" MVDB_DISABLE_HALF_SCAN=1 -- --nq 128 --dim 1024 --rows 5000000 --steps 20 --warmup 3
 run "d768 nq128" X=1 -- --nq 128 --dim 768 --rows 5000000 --steps 20 --warmup 3
 run "d768 nq128 old" MVDB_DISABLE_HALF_SCAN=1 -- --nq 128 --dim 768 --rows 5000000 --steps 20 --warmup 3
 python - <<'PY'

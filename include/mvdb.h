@@ -100,9 +100,11 @@ int mvdb_index_remove_rows(mvdb_index* idx, const int64_t* rows_host, int64_t m)
 /* k nearest rows for nq queries.  q_host[nq,d], D_host[nq,k], I_host[nq,k].
  * normalize_q != 0 L2-normalises each query on the device first.
  * Every path returns exact-fp32 scores of the exact top-k: batches of >= 14 queries (k <= 12) are
- * NOMINATED on the bf16 matrix cores from a split-precision product, then re-scored in fp32 and
- * certified per query against the nomination's error bound; a chunk that cannot be certified is
- * re-run on the exact fp32 kernels (mvdb_split_rerun_count counts those).
+ * NOMINATED on the low-precision matrix cores (14..32 queries: bf16 (hi, lo) split-precision product,
+ * 16 nominees; 33+ queries at d = 256 / 384 / 512 / 768: one fp16 product, 64 nominees, 128 or 256
+ * queries per corpus pass), then re-scored in fp32 and certified per query against the nomination's
+ * worst-case error bound; a chunk that cannot be certified is re-run on the exact fp32 kernels
+ * (mvdb_split_rerun_count counts those).
  * Replaces faiss.normalize_L2(embedding) + index.search(embedding, search_k)
  *                                                minivectordb/vector_database.py:475, :497
  *                                                minivectordb/sharded_vector_database.py:604, :626 */

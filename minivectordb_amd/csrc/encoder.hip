@@ -1602,6 +1602,7 @@ int launch_gemm_x3(const float* A, X3W Wh, const float* bias, const float* R, fl
     // LDS-DMA kernel, 64 x 128 tiles, three stages, two workgroups per CU: measured best at every shape (B = 256: S = 32
     // 2.68 ms vs 3.04 with 128-row tiles for the wide GEMMs, 3.15 register-staged; S = 512 43.8 ms vs 55.7 / 45.3;
     // rings of 2, 4 or 6 stages, i.e. 3 or 1 workgroups per CU: within 1 %)
+    if (dma && force == 128) return launch_gemm_x3_inst<EPI, 128, true, 2>(A, Wh, bias, R, C, Tptr, Tmax, N, K, device, s);  // A/B: 64 KiB, two per CU
     if (dma) return launch_gemm_x3_inst<EPI, 64, true, 3>(A, Wh, bias, R, C, Tptr, Tmax, N, K, device, s);
     if (bm128) return launch_gemm_x3_inst<EPI, 128, false>(A, Wh, bias, R, C, Tptr, Tmax, N, K, device, s);
     return launch_gemm_x3_inst<EPI, 64, false>(A, Wh, bias, R, C, Tptr, Tmax, N, K, device, s);

@@ -132,6 +132,13 @@ struct HsStage {
 template <int KQ, int SKB, int NG, int NST, bool SEED>
 __global__ __launch_bounds__(256) void flat_scan_half_kernel(HalfScanArgs a) {
     constexpr int NW = 4;
+    // the next tile's stages are prefetched under the MFMAs of round 0 (F double-buffered) where the registers allow:
+    // at d = 1024 (256 query registers + 2 x 64 of F) the prefetching form spills, the tile is loaded up front instead
+    constexpr bool PREFETCH = !SEED && KQ <= 12;
+    // (With 256 registers of query fragments — 256 queries at d = 512, 128 at d = 1024 — hipcc parks the fragments in
+    //  AGPRs and copies each back before its MFMA, 3.5 v_accvgpr_read per MFMA.  Hand-written MFMAs that read the B
+    //  operand straight from the AGPR remove all of them and change nothing measurable: 52.6k q/s either way at
+    //  256 x 10M x 512.  The pass is bound by the exchange, 384 KiB of LDS traffic per tile at 256 queries, not by issue.)
     static_assert(NG % NW == 0 && (SKB == 2 || SKB == 4) && KQ % SKB == 0 && NST >= 2, "shape");
     using St = HsStage<SKB>;
     static_assert((NST - 1) * St::kDma <= 63, "vmcnt is a 6-bit counter");
@@ -349,7 +356,7 @@ __global__ __launch_bounds__(256) void flat_scan_half_kernel(HalfScanArgs a) {
         gate(rc, sc, m0);
     };
 
-    hs_h8 F[2][KQ];  // the wave's slice of the current / the next tile as fp16 A fragments
+    hs_h8 F[PREFETCH ? 2 : 1][KQ];  // the wave's slice of the current (/ the next) tile as fp16 A fragments
     if (tile < ntiles) {
 #pragma unroll
         for (int g = 0; g < NST; ++g) {
@@ -372,7 +379,7 @@ __global__ __launch_bounds__(256) void flat_scan_half_kernel(HalfScanArgs a) {
     //  MFMAs of the round after it, with F overwritten in place — at 256 queries the query fragments then no longer
     //  fit beside two accumulator sets: 40 spilled registers at d = 512.)
     auto tile_body = [&](auto pc) {
-        constexpr int P = decltype(pc)::value;
+        constexpr int P = PREFETCH ? decltype(pc)::value : 0;
         const int64_t m0 = (a.tile0 + tile) * 32;
         const int64_t next = tile + step;
 #pragma unroll
@@ -386,7 +393,7 @@ __global__ __launch_bounds__(256) void flat_scan_half_kernel(HalfScanArgs a) {
 #pragma unroll
                 for (int j = 0; j < NW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F[P][kb], Q[kb][r][j], acc[j], 0, 0, 0);
             };
-            if (r == 0 && !SEED) {
+            if (r == 0 && PREFETCH) {
 #pragma unroll
                 for (int ks = 0; ks < NS; ++ks) {
                     Raw x;
@@ -397,7 +404,7 @@ __global__ __launch_bounds__(256) void flat_scan_half_kernel(HalfScanArgs a) {
                     refill(next, ks);
 #pragma unroll
                     for (int b = HB; b < SKB; ++b) mfma_kb(ks * SKB + b);
-                    convert(x, F[P ^ 1], ks);
+                    convert(x, F[PREFETCH ? (P ^ 1) : 0], ks);
                 }
             } else {
 #pragma unroll
@@ -407,6 +414,16 @@ __global__ __launch_bounds__(256) void flat_scan_half_kernel(HalfScanArgs a) {
                 finish_round(std::integral_constant<int, 0>{}, acc, m0);
             else
                 finish_round(std::integral_constant<int, (NR > 1 ? 1 : 0)>{}, acc, m0);
+        }
+        if (!PREFETCH && !SEED) {  // the next tile's fragments, nothing overlapped
+#pragma unroll
+            for (int ks = 0; ks < NS; ++ks) {
+                Raw x;
+                wait_stage();
+                read_stage(x);
+                refill(next, ks);
+                convert(x, F[0], ks);
+            }
         }
         tile = next;
     };
@@ -555,7 +572,7 @@ float half_xscale(float row_norm_bound) {
 // 256 queries per pass (two exchange rounds per tile, 32 KiB of lists): 4-KiB stages x 5.
 static int half_kq(int d) {
     switch (d) {
-        case 256: case 384: case 512: case 768: return d / 64;
+        case 256: case 384: case 512: case 768: case 1024: return d / 64;
         default: return 0;
     }
 }
@@ -628,6 +645,7 @@ int launch_half_scan(int d, int nqpad, bool seed, const HalfScanArgs& a, int dev
         case 6: return launch_half_kq<6, 0>(nqpad, seed, a, device, stream, nblocks_out);
         case 8: return launch_half_kq<8, 1>(nqpad, seed, a, device, stream, nblocks_out);
         case 12: return launch_half_kq<12, 1>(nqpad, seed, a, device, stream, nblocks_out);
+        case 16: return launch_half_kq<16, 0>(nqpad, seed, a, device, stream, nblocks_out);
         default: return fail(MVDB_ERR_ARG, "no fp16 nomination kernel for d = %d", d);
     }
 }

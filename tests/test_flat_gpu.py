@@ -513,7 +513,8 @@ def _split_launches(native):
     (127, 512, 10, 70), (15, 512, 10, 30), (16, 128, 10, 24), (17, 96, 12, 33), (6000, 1024, 10, 130),
     (30000, 384, 10, 256),
     (300000, 64, 10, 64), (270001, 128, 5, 130), (300000, 64, 10, 24), (70000, 128, 12, 100), (70001, 128, 12, 24), (40003, 256, 3, 129),  # seed + main launch
-    (70001, 512, 10, 128), (40003, 512, 12, 50), (150003, 512, 5, 100), (33000, 512, 10, 33),  # seed + the K-split d = 512 kernel (split128.hip): ragged last tile, one and two phases
+    (70001, 512, 10, 128), (40003, 512, 12, 50), (150003, 512, 5, 100), (33000, 512, 10, 33),  # seed + the K-split d = 512 kernels: ragged last tile, one and two phases
+    (9000, 768, 10, 100), (70001, 1024, 10, 128), (150003, 384, 10, 256), (40003, 512, 10, 200), (100000, 256, 10, 255),  # fp16 pass: every dimension it serves, 128- and 256-query passes
 ])
 def test_split_precision_batch_pass_matches_oracle(native, monkeypatch, n, d, k, nq):
     """nq >= 33 (24 here), k <= 12: the bf16 split-precision pass nominates 16 rows per query, exact fp32 re-scores
