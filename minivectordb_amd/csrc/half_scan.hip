@@ -530,7 +530,10 @@ __global__ __launch_bounds__(1024) void half_certify_kernel(HalfCertifyArgs a) {
                 const float t = key_score(exact[hl]);
                 ok = t > u + a.eps * a.qnorm[qi];
             }
-            if (!ok) atomicAdd(a.uncertified, 1);
+            if (!ok) {
+                atomicAdd(a.uncertified, 1);
+                a.failed[qi] = 1;
+            }
         }
     }
 }

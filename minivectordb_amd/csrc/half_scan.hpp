@@ -39,7 +39,8 @@ struct HalfCertifyArgs {
     int64_t label_offset;
     float* D;
     int64_t* I;
-    int* uncertified;
+    int* uncertified;      // incremented once per query that fails the certificate
+    int* failed;           // [nq] set to 1 for a query that fails it
 };
 
 // queries per corpus pass of the widest instantiation for dimension d (0: no kernel for this d)

@@ -131,6 +131,9 @@ struct Workspace {
     DevBuf<__bf16> qsplit;  // bf16 (hi | lo) images of one 128-query chunk (split-precision pass)
     DevBuf<float> qnorm;
     DevBuf<int> flags;      // per-chunk count of uncertified queries
+    DevBuf<int> qfail;      // per query: 1 = failed certification; behind them the compact list of those queries
+    DevBuf<float> requery;  // the failed queries, gathered, and their exact results [D | I]
+    DevBuf<int64_t> relabel;
     PinnedBuf pin_flags;
     SelectState* st = nullptr;
     PinnedBuf pin;
@@ -160,6 +163,9 @@ struct Workspace {
         qsplit.release();
         qnorm.release();
         flags.release();
+        qfail.release();
+        requery.release();
+        relabel.release();
         pin_flags.release();
         pin.release();
         if (st) (void)hipFree(st);
@@ -600,7 +606,7 @@ int launch_split32(int KB, const Split32Args& b, int device, hipStream_t s, int*
 }
 
 int launch_split_scan(const mvdb_index* idx, Workspace* ws, const float* q, int nq, int k, int64_t n,
-                      int64_t label_offset, float* D, int64_t* I, int* flag) {
+                      int64_t label_offset, float* D, int64_t* I, int* flag, int* failed) {
     hipStream_t stream = ws->stream;
     __bf16* qh = ws->qsplit.p;
     __bf16* ql = qh + (size_t)128 * idx->d;
@@ -731,6 +737,7 @@ int launch_split_scan(const mvdb_index* idx, Workspace* ws, const float* q, int 
     c.D = D;
     c.I = I;
     c.uncertified = flag;
+    c.failed = failed;
     hipLaunchKernelGGL(split_certify_kernel, dim3(nq), dim3(1024), 0, stream, c);
     MVDB_HIP(hipGetLastError());
     if (a.stats) {
@@ -754,7 +761,7 @@ bool half_path_ok(const mvdb_index* idx) {
 }
 
 int launch_half_pass(const mvdb_index* idx, Workspace* ws, const float* q, int nq, int nqpad, int k, int64_t n,
-                     int64_t label_offset, float* D, int64_t* I, int* flag) {
+                     int64_t label_offset, float* D, int64_t* I, int* flag, int* failed) {
     hipStream_t stream = ws->stream;
     _Float16* qf = reinterpret_cast<_Float16*>(ws->qsplit.p);
     float* qnorm = ws->qnorm.p;
@@ -832,6 +839,7 @@ int launch_half_pass(const mvdb_index* idx, Workspace* ws, const float* q, int n
     c.D = D;
     c.I = I;
     c.uncertified = flag;
+    c.failed = failed;
     MVDB_TRY(launch_half_certify(c, nq, stream));
     if (a.stats) {
         unsigned int st[2] = {0, 0};
@@ -909,27 +917,65 @@ int search_core(const mvdb_index* idx, Workspace* ws, const float* q_dev, int nq
             MVDB_TRY(ws->qsplit.reserve((size_t)std::max(2 * 128, chunk) * idx->d));
             MVDB_TRY(ws->qnorm.reserve((size_t)std::max(256, 3 * chunk)));  // |q|, admission floors (, fp16 pass: 1 / scale)
             MVDB_TRY(ws->flags.reserve((size_t)std::max(nchunks, 64) + 32));  // + diagnostics counters at [64]
-            MVDB_TRY(ws->pin_flags.reserve((size_t)nchunks * sizeof(int)));
+            // pinned: [nchunks] chunk counts | [q0] per-query flags | [q0] int64 list of the failed queries
+            const size_t pin_list = ((size_t)(nchunks + q0) * sizeof(int) + 7) & ~(size_t)7;
+            MVDB_TRY(ws->pin_flags.reserve(pin_list + (size_t)q0 * sizeof(int64_t)));
             MVDB_TRY(ws->cand.reserve((size_t)std::max(128, chunk) * (scan_grid_upper_bound(idx->device) + 1) * kSplitKeep));
+            MVDB_TRY(ws->qfail.reserve((size_t)q0));
             MVDB_HIP(hipMemsetAsync(ws->flags.p, 0, (size_t)nchunks * sizeof(int), s));
+            MVDB_HIP(hipMemsetAsync(ws->qfail.p, 0, (size_t)q0 * sizeof(int), s));
             for (int c = 0; c < nchunks; ++c) {
                 const int c0 = plan[c].first, take = plan[c].second;
                 if (use_half && take >= min_nq)
                     MVDB_TRY(launch_half_pass(idx, ws, qsrc + (int64_t)c0 * idx->ld, take, half_chunk_queries(idx->d, take), k, n, label_offset,
-                                              D_dev + (int64_t)c0 * k, I_dev + (int64_t)c0 * k, ws->flags.p + c));
+                                              D_dev + (int64_t)c0 * k, I_dev + (int64_t)c0 * k, ws->flags.p + c, ws->qfail.p + c0));
                 else
                     MVDB_TRY(launch_split_scan(idx, ws, qsrc + (int64_t)c0 * idx->ld, take, k, n, label_offset,
-                                               D_dev + (int64_t)c0 * k, I_dev + (int64_t)c0 * k, ws->flags.p + c));
+                                               D_dev + (int64_t)c0 * k, I_dev + (int64_t)c0 * k, ws->flags.p + c, ws->qfail.p + c0));
             }
             int* hflags = static_cast<int*>(ws->pin_flags.p);
+            int* hfail = hflags + nchunks;
             MVDB_HIP(hipMemcpyAsync(hflags, ws->flags.p, (size_t)nchunks * sizeof(int), hipMemcpyDeviceToHost, s));
+            MVDB_HIP(hipMemcpyAsync(hfail, ws->qfail.p, (size_t)q0 * sizeof(int), hipMemcpyDeviceToHost, s));
             MVDB_HIP(hipStreamSynchronize(s));
-            for (int c = 0; c < nchunks; ++c) {
-                if (!hflags[c]) continue;
-                const int c0 = plan[c].first, take = plan[c].second;
-                g_split_reruns.fetch_add(1, std::memory_order_relaxed);
-                MVDB_TRY(search_core(idx, ws, qsrc + (int64_t)c0 * idx->ld, take, k, 0, rows_dev, m, label_offset,
-                                     D_dev + (int64_t)c0 * k, I_dev + (int64_t)c0 * k, false));
+            int bad_chunks = 0;
+            for (int c = 0; c < nchunks; ++c) bad_chunks += hflags[c] != 0;
+            if (bad_chunks) {
+                g_split_reruns.fetch_add(bad_chunks, std::memory_order_relaxed);
+                int64_t* hlist = reinterpret_cast<int64_t*>(static_cast<char*>(ws->pin_flags.p) + pin_list);
+                int64_t nb = 0;
+                for (int i = 0; i < q0; ++i)
+                    if (hfail[i]) hlist[nb++] = i;
+                // Few uncertified queries (a handful of duplicate-heavy neighbourhoods in a batch): only THOSE go through
+                // the exact kernels, gathered into one compact batch — a 32-query exact pass costs about one corpus
+                // pass, a whole 128-query chunk on the fp32 matrix cores four.  Many: chunk by chunk as before.
+                const int64_t limit = std::max(1, env_int("MVDB_SPLIT_REQUERY_MAX", 64));
+                if (nb <= limit && nb < q0) {
+                    MVDB_TRY(ws->relabel.reserve((size_t)nb * (1 + k)));
+                    MVDB_TRY(ws->requery.reserve((size_t)nb * (idx->ld + k)));
+                    int64_t* map = ws->relabel.p;
+                    int64_t* It = map + nb;
+                    float* qc = ws->requery.p;
+                    float* Dt = qc + nb * idx->ld;
+                    MVDB_HIP(hipMemcpyAsync(map, hlist, (size_t)nb * sizeof(int64_t), hipMemcpyHostToDevice, s));
+                    const int64_t gtotal = nb * (idx->ld / 4);
+                    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((gtotal + 255) / 256)), dim3(256), 0, s, qc, qsrc,
+                                       (const int64_t*)map, nb, idx->ld);
+                    MVDB_HIP(hipGetLastError());
+                    MVDB_TRY(search_core(idx, ws, qc, (int)nb, k, 0, rows_dev, m, label_offset, Dt, It, false));
+                    hipLaunchKernelGGL(scatter_results_kernel, dim3((unsigned)((nb * k + 255) / 256)), dim3(256), 0, s, Dt, It,
+                                       (const int64_t*)map, nb, k, D_dev, I_dev);
+                    MVDB_HIP(hipGetLastError());
+                    // the pinned list must outlive the upload; the compact buffers the scatter: both are this workspace's
+                    MVDB_HIP(hipStreamSynchronize(s));
+                } else {
+                    for (int c = 0; c < nchunks; ++c) {
+                        if (!hflags[c]) continue;
+                        const int c0 = plan[c].first, take = plan[c].second;
+                        MVDB_TRY(search_core(idx, ws, qsrc + (int64_t)c0 * idx->ld, take, k, 0, rows_dev, m, label_offset,
+                                             D_dev + (int64_t)c0 * k, I_dev + (int64_t)c0 * k, false));
+                    }
+                }
             }
         }
         if (q0 == nq) return 0;
@@ -968,9 +1014,9 @@ int search_core(const mvdb_index* idx, Workspace* ws, const float* q_dev, int nq
             q0 += take;
         }
         if (q0 == nq) return 0;
-        // remainder: already-normalised queries through the paths below
+        // remainder: already-normalised queries through the paths below (a re-run of uncertified queries stays exact)
         return search_core(idx, ws, qsrc + (int64_t)q0 * idx->ld, nq - q0, k, 0, rows_dev, m, label_offset,
-                           D_dev + (int64_t)q0 * k, I_dev + (int64_t)q0 * k);
+                           D_dev + (int64_t)q0 * k, I_dev + (int64_t)q0 * k, allow_split);
     }
 
     if (mfma_path_ok(idx, nq, k, rows_dev)) {

@@ -652,6 +652,7 @@ struct SplitCertifyArgs {
     float* D;
     int64_t* I;
     int* uncertified;      // incremented once per query that fails the test
+    int* failed;           // [nq] set to 1 for a query that fails it (the host re-runs exactly those)
 };
 
 __global__ __launch_bounds__(1024) void split_certify_kernel(SplitCertifyArgs a) {
@@ -718,7 +719,10 @@ __global__ __launch_bounds__(1024) void split_certify_kernel(SplitCertifyArgs a)
                 const float t = key_score(exact[hl]);
                 ok = t > key_score(last) + a.eps * a.qnorm[qi];
             }
-            if (!ok) atomicAdd(a.uncertified, 1);
+            if (!ok) {
+                atomicAdd(a.uncertified, 1);
+                a.failed[qi] = 1;
+            }
         }
     }
 }

@@ -118,6 +118,17 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(float* __restrict__ ds
     }
 }
 
+// results of a compact re-run back into the rows of the queries they belong to: D[map[r], :] = Dt[r, :] (same for I)
+__global__ __launch_bounds__(256) void scatter_results_kernel(const float* __restrict__ Dt, const int64_t* __restrict__ It,
+                                                              const int64_t* __restrict__ map, int64_t nb, int k,
+                                                              float* __restrict__ D, int64_t* __restrict__ I) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nb * k) return;
+    const int64_t r = i / k, c = i - r * k;
+    D[map[r] * k + c] = Dt[i];
+    I[map[r] * k + c] = It[i];
+}
+
 // new row r keeps old row r + (number of deleted rows <= that old row); del[] ascending, unique.
 __global__ __launch_bounds__(256) void build_keep_map_kernel(const int64_t* __restrict__ del,
                                                              int64_t m, int64_t n_new,

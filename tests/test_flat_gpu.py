@@ -628,6 +628,32 @@ def test_split_certificate_at_the_margin(native, d, frac, must_rerun):
     idx.close()
 
 
+@pytest.mark.parametrize("requery_max", [64, 1])
+def test_uncertified_queries_are_rerun_one_by_one(native, monkeypatch, requery_max):
+    """200 queries, three of them with 40 exact copies of their best row in the corpus: those three fail the certificate
+    and ONLY they are re-run on the exact kernels, gathered into one compact batch (requery_max = 64); with the limit at
+    1 the old route — whole chunks on the exact kernels — is taken.  Either way every query's result is exact."""
+    monkeypatch.setenv("MVDB_SPLIT_REQUERY_MAX", str(requery_max))
+    n, d, k, nq = 30000, 512, 10, 200
+    x = _corpus(n, d)
+    q = _corpus(nq, d, seed=77)
+    for qi, base in ((3, 1000), (130, 9000), (199, 20000)):
+        x[base:base + 40] = q[qi]
+    idx = native.FlatIndex(d)
+    idx.add(x)
+    before = native.split_rerun_count()
+    D, I = idx.search(q, k)
+    assert native.split_rerun_count() == before + 1     # one 256-wide pass held all 200 queries
+    for qi, base in ((3, 1000), (130, 9000), (199, 20000)):
+        assert I[qi].tolist() == list(range(base, base + 10))   # ties resolve to the lowest row numbers
+    _check(native, x, q, k, D, I)
+    for i in (0, 3, 64, 130, 131, 199):
+        D1, I1 = idx.search(q[i], k)
+        assert np.array_equal(I1[0], I[i])
+        np.testing.assert_allclose(D1[0], D[i], atol=2e-6, rtol=0)
+    idx.close()
+
+
 def test_split_precision_pass_falls_back_when_it_cannot_certify(native, monkeypatch):
     """40 copies of each query's best row: more than 16 - k rows tie with the k-th score, the certificate fails
     and the chunk is re-run on the exact kernels; ties still resolve to the lowest row numbers."""
