@@ -450,6 +450,237 @@ __global__ __launch_bounds__(256) void flat_scan_half_kernel(HalfScanArgs a) {
         }
 }
 
+// ---- 256 queries per pass, QUERY split: no exchange -----------------------------------------------------------------
+// The K-split kernel above pays for its register-resident queries with the exchange: three of every four partial
+// scores cross LDS, 384 KiB per 32-row tile at 256 queries — at that width the LDS port, not HBM, sets the pace (0.55 of
+// the HBM roofline).  Here every wave owns 64 QUERIES over the FULL K (64 x d fp16 = d / 2 VGPRs: 256 at d = 512) and
+// all four waves share the corpus tile instead: the block converts each K-half of a tile to fp16 ONCE, into LDS, and
+// every wave reads the fragments it needs from there.
+//   per K-half stage (32 rows x d / 2 columns):
+//     wave w DMAs rows 8w .. 8w + 7 of the raw fp32 stage into a three-stage ring (global_load_lds, nt) and is also the
+//     only reader of those rows: it converts them (v_pk_mul_f32 + v_cvt_pk_f16_f32) and writes them to one of two
+//     fp16 stage images (row pitch padded or XOR-swizzled so that the MFMA fragment reads are conflict-free) — no
+//     barrier is needed for the raw data, only the wave's own vmcnt;
+//     all waves then read the 32 x 16 fragments of that image and run 2 x d / 32 MFMAs each (64 queries).
+//   The conversion of stage g + 1 rides under the MFMAs of stage g (two fp16 images): ONE s_barrier per stage, two
+//   per tile, nothing else is shared.  At the end of a tile every wave gates its own 32 x 64 finished scores.
+//   LDS traffic per corpus byte: 1 (DMA) + 1 (raw read) + 0.5 (fp16 write) + 4 x 0.5 (fragment reads) = 4.5 B against the
+//   8 B of the K-split kernel at 256 queries; no partial sums, no exchange additions.
+// The seed launch of a pass is the K-split kernel's (<KQ, 2, 8, 5, true>): it only has to produce floors.
+template <int KT, bool PAD>
+__global__ __launch_bounds__(256) void flat_scan_hq_kernel(HalfScanArgs a) {
+    constexpr int KH = KT / 2;               // 16-k blocks per stage (one K-half)
+    constexpr int RAWP = KH * 64;            // raw row pitch in bytes (KH x 16 floats)
+    constexpr int kRaw = 32 * RAWP;          // raw stage: 32 KiB at d = 512
+    constexpr int kRawW = 8 * RAWP;          // a wave's 8 rows of it
+    constexpr int DPW = kRawW / 1024;        // DMA instructions per wave and stage
+    constexpr int SPR = RAWP / 16;           // 16-byte slots per raw row
+    constexpr int HSL = KH * 2;              // 16-byte slots (8 fp16) per fp16 row
+    constexpr int HP = (PAD ? HSL + 1 : HSL) * 16;  // fp16 row pitch: odd slot count, or XOR swizzle at powers of two
+    constexpr int kH = 32 * HP;
+    constexpr int K = KT * 16;
+    static_assert(kRawW % 1024 == 0 && KT % 2 == 0, "shape");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // 3 raw stages | 2 fp16 images
+    __shared__ uint64_t lists[256 * kHalfKeep];                             // [wave][2 groups][32 queries][16] keys
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int fr = lane & 31, fk = lane >> 5;
+    unsigned char* hbuf = smem + 3 * kRaw;
+    uint64_t* mylists = lists + (size_t)wave * 64 * kHalfKeep;
+    for (int e = lane; e < 64 * kHalfKeep; e += 64) mylists[e] = 0ull;
+
+    // ---- this wave's 64 queries over the whole K: B[k = 16 kb + 8 fk + j][query 32 g + fr]
+    hs_h8 Q[KT][2];
+#pragma unroll
+    for (int kb = 0; kb < KT; ++kb)
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+            Q[kb][g] = *reinterpret_cast<const hs_h8*>(a.qf + (int64_t)((wave * 2 + g) * 32 + fr) * K + kb * 16 + fk * 8);
+    float floor0[2], thr[2], inv[2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const int myq = (wave * 2 + g) * 32 + fr;
+        floor0[g] = myq < a.nq ? (a.thr0 ? a.thr0[myq] : -INFINITY) : INFINITY;
+        thr[g] = floor0[g];
+        inv[g] = a.qinv[myq];
+    }
+    // consume every global load here (see flat_scan_half_kernel)
+#pragma unroll
+    for (int kb = 0; kb < KT; ++kb)
+#pragma unroll
+        for (int g = 0; g < 2; ++g) asm volatile("" : "+v"(Q[kb][g]));
+#pragma unroll
+    for (int g = 0; g < 2; ++g) asm volatile("" : "+v"(floor0[g]), "+v"(thr[g]), "+v"(inv[g]));
+
+    const int64_t ntiles = a.tile1 - a.tile0;
+    const int64_t last = a.n - 1;
+    // ---- roles: DMA instruction i of a stage moves the 16-byte slots 64 i .. 64 i + 63 of the wave's 8 rows (row-major,
+    // lane-linear in LDS); the same (i, lane) reads that slot back for the conversion
+    uint32_t voff[DPW];
+    int hdst[DPW];
+#pragma unroll
+    for (int i = 0; i < DPW; ++i) {
+        const int j = i * 64 + lane;
+        const int row = 8 * wave + j / SPR, cs = j % SPR;  // tile row, 16-byte slot (4 floats) of the K-half
+        voff[i] = (uint32_t)(((int64_t)row * a.ld + 4 * cs) * 4);
+        const int hs = cs >> 1;  // fp16 slot (8 elements): two raw slots each
+        hdst[i] = row * HP + ((PAD ? hs : (hs ^ (row & 15))) << 4) + (cs & 1) * 8;
+    }
+    auto issue_stage = [&](int64_t tile, int half, int buf) {
+        const int64_t row0 = (a.tile0 + tile) * 32;
+        const char* sbase = reinterpret_cast<const char*>(a.X + row0 * a.ld + half * KH * 16);
+        unsigned char* dst = smem + buf * kRaw + wave * kRawW;
+#pragma unroll
+        for (int i = 0; i < DPW; ++i)
+            __builtin_amdgcn_global_load_lds((hs_gbl_ptr)(sbase + voff[i]), (hs_lds_ptr)(dst + i * 1024), 16, 0, 2 /* nt */);
+    };
+    const int frow = fr * HP;
+    const int fsw = PAD ? 0 : (fr & 15);
+    const hs_f2 xs = {a.xscale, a.xscale};
+    const int64_t step = gridDim.x;
+    int64_t tile = blockIdx.x;
+    unsigned n_ins = 0, n_slow = 0;
+    int rb = 0;  // raw buffer of the stage converted next
+    // stage c of the block's flat sequence = (tile + (c / 2) step, half c & 1); stages past the last tile are clamped
+    auto stage_tile = [&](int64_t base, int c) {
+        const int64_t t = base + (int64_t)(c >> 1) * step;
+        return t < ntiles ? t : (base < ntiles ? base : tile);
+    };
+    // converts this wave's rows of the raw stage in buffer rb into fp16 image `hb`, then refills the buffer with the
+    // stage three ahead (`base`, `c`: that stage)
+    struct Raw {
+        hs_f4 v[DPW];
+    };
+    auto read_raw = [&](Raw& x) {
+        const unsigned char* src = smem + rb * kRaw + wave * kRawW + lane * 16;
+#pragma unroll
+        for (int i = 0; i < DPW; ++i) x.v[i] = *reinterpret_cast<const hs_f4*>(src + i * 1024);
+    };
+    auto write_half = [&](const Raw& x, int hb) {
+        unsigned char* dst = hbuf + hb * kH;
+#pragma unroll
+        for (int i = 0; i < DPW; ++i) {
+            union {
+                hs_h2 p[2];
+                hs_f2 f;
+            } u;
+            const hs_f2 lo = {x.v[i][0], x.v[i][1]}, hi = {x.v[i][2], x.v[i][3]};
+            u.p[0] = __builtin_convertvector(lo * xs, hs_h2);  // RNE
+            u.p[1] = __builtin_convertvector(hi * xs, hs_h2);
+            *reinterpret_cast<hs_f2*>(dst + hdst[i]) = u.f;
+        }
+    };
+    auto wait_raw = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * DPW) : "memory");  // the oldest of three stages has landed
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto refill = [&](int64_t base, int c) {
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the raw rows are in registers (and the image is written)
+        __builtin_amdgcn_sched_barrier(0);
+        issue_stage(stage_tile(base, c), c & 1, rb);
+        rb = rb == 2 ? 0 : rb + 1;
+    };
+    hs_f16 acc[2];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[g][e] = 0.f;
+    };
+    // MFMAs of K-half `half` from fp16 image hb
+    auto mfma_half = [&](int half, int hb) {
+        const unsigned char* src = hbuf + hb * kH + frow;
+#pragma unroll
+        for (int kb = 0; kb < KH; ++kb) {
+            const hs_h8 f = *reinterpret_cast<const hs_h8*>(src + (((2 * kb + fk) ^ fsw) << 4));
+#pragma unroll
+            for (int g = 0; g < 2; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f, Q[half * KH + kb][g], acc[g], 0, 0, 0);
+        }
+    };
+    auto gate = [&](int64_t m0) {
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            float sc[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) sc[e] = acc[g][e] * inv[g];  // exact: 1 / (s_q s_x) is a power of two
+            float mx = sc[0];
+#pragma unroll
+            for (int e = 1; e < 16; ++e) mx = fmaxf(mx, sc[e]);
+            if (__ballot(mx >= thr[g]) != 0ull) {
+                ++n_slow;
+                uint64_t* gl = mylists + (size_t)g * 32 * kHalfKeep;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int rl = (e & 3) + 8 * (e >> 2);
+                    const float s = sc[e];
+                    uint64_t mask = __ballot(m0 + rl + 4 * fk <= last && s >= thr[g]);
+                    while (mask) {
+                        const int srcl = __ffsll((long long)mask) - 1;
+                        mask &= mask - 1;
+                        ++n_ins;
+                        const int sq = srcl & 31;
+                        const float sv = __uint_as_float(__builtin_amdgcn_readlane((int)__float_as_uint(s), srcl));
+                        const uint32_t rv = (uint32_t)(m0 + rl + 4 * (srcl >> 5));
+                        const uint64_t kth = lds_list_insert(gl + (size_t)sq * kHalfKeep, kHalfKeep, make_key(sv, rv), lane);
+                        if (fr == sq) thr[g] = kth ? fmaxf(key_score(kth), floor0[g]) : floor0[g];  // both lane halves
+                    }
+                }
+            }
+        }
+    };
+
+    if (tile < ntiles) {
+        // three raw stages in flight; the first is converted with nothing to overlap
+        issue_stage(tile, 0, 0);
+        issue_stage(tile, 1, 1);
+        issue_stage(stage_tile(tile, 2), 0, 2);
+        Raw x;
+        wait_raw();
+        read_raw(x);
+        refill(tile, 3);
+        write_half(x, 0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();  // image 0 = (tile, half 0) is complete
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    while (tile < ntiles) {
+        const int64_t m0 = (a.tile0 + tile) * 32;
+        zero_acc();
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            // MFMAs of (tile, half) from image `half`; beside them the conversion of the NEXT stage — (tile, 1) or
+            // (tile + step, 0) — into the other image, whose readers all passed the barrier that ended the last stage
+            Raw x;
+            wait_raw();
+            read_raw(x);
+            mfma_half(half, half);
+            refill(tile, half + 4);  // the stage three past the one just read: flat index (half + 1) + 3
+            write_half(x, half ^ 1);
+            if (half == 1) gate(m0);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();  // the other image is complete; every wave is done reading this one
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        tile += step;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the clamped look-ahead DMAs must land before the LDS is released
+    if (a.stats && lane == 0) {
+        atomicAdd(a.stats, n_ins);
+        atomicAdd(a.stats + 1, n_slow);
+    }
+#pragma unroll 1
+    for (int q = 0; q < 64; ++q) {
+        const int qq = wave * 64 + q;
+        if (qq >= a.nq) break;
+        if (lane < kHalfKeep)
+            a.cand[((int64_t)qq * gridDim.x + blockIdx.x) * kHalfKeep + lane] = mylists[(size_t)q * kHalfKeep + lane];
+    }
+}
+
 // ---- certification ------------------------------------------------------------------------------------------------
 // One block per query.  U = max(last floor, 16th score of every full block list); R = the 64 best candidates by
 // approximate score; U is raised to a(64th) when R is full; fp32 re-score of R (one wave per nominee, the arithmetic
@@ -624,6 +855,31 @@ static int launch_half_inst(const HalfScanArgs& a, int device, hipStream_t strea
     return 0;
 }
 
+template <int KT, bool PAD>
+static int launch_hq_inst(const HalfScanArgs& a, int device, hipStream_t stream, int* nblocks_out) {
+    auto kern = flat_scan_hq_kernel<KT, PAD>;
+    constexpr int KH = KT / 2;
+    constexpr size_t lds = (size_t)3 * 32 * KH * 64 + (size_t)2 * 32 * (PAD ? 2 * KH + 1 : 2 * KH) * 16;
+    static_assert(lds + 256 * kHalfKeep * 8 <= 160 * 1024, "LDS budget of a CU");
+    {
+        static std::mutex mu;
+        static std::map<int, bool> done;
+        std::lock_guard<std::mutex> lk(mu);
+        if (!done[device]) {
+            MVDB_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            done[device] = true;
+        }
+    }
+    const int64_t ntiles = a.tile1 - a.tile0;
+    const int nblocks = (int)std::max<int64_t>(1, std::min<int64_t>(ntiles, (int64_t)device_cus(device)));
+    *nblocks_out = nblocks;
+    int slot = prof_begin("ip_scan_half", stream);
+    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(256), lds, stream, a);
+    prof_end(slot, stream);
+    MVDB_HIP(hipGetLastError());
+    return 0;
+}
+
 template <int KQ, int SKB4>
 static int launch_half_kq(int nqpad, bool seed, const HalfScanArgs& a, int device, hipStream_t stream, int* nb) {
     // SKB4: 8-KiB stages for the 128-query main launch where KQ % 4 == 0 (d = 512: same speed as 4-KiB stages, 0.81 of
@@ -636,7 +892,8 @@ static int launch_half_kq(int nqpad, bool seed, const HalfScanArgs& a, int devic
     if constexpr (KQ <= 8) {
         if (nqpad == 256) {
             if (seed) return launch_half_inst<KQ, 2, 8, 5, true>(a, device, stream, nb);
-            return launch_half_inst<KQ, 2, 8, 5, false>(a, device, stream, nb);
+            if (getenv("MVDB_HALF_KSPLIT256")) return launch_half_inst<KQ, 2, 8, 5, false>(a, device, stream, nb);  // A/B: the K-split form
+            return launch_hq_inst<KQ * 4, (KQ & (KQ - 1)) != 0>(a, device, stream, nb);
         }
     }
     return fail(MVDB_ERR_ARG, "no fp16 nomination kernel for %d queries per pass at d = %d", nqpad, KQ * 64);
