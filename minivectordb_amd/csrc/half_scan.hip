@@ -450,24 +450,28 @@ __global__ __launch_bounds__(256) void flat_scan_half_kernel(HalfScanArgs a) {
         }
 }
 
-// ---- 256 queries per pass, QUERY split: no exchange -----------------------------------------------------------------
+// ---- d <= 512, 128 or 256 queries per pass, QUERY split: no exchange ------------------------------------------------
 // The K-split kernel above pays for its register-resident queries with the exchange: three of every four partial
 // scores cross LDS, 384 KiB per 32-row tile at 256 queries — at that width the LDS port, not HBM, sets the pace (0.55 of
-// the HBM roofline).  Here every wave owns 64 QUERIES over the FULL K (64 x d fp16 = d / 2 VGPRs: 256 at d = 512) and
-// all four waves share the corpus tile instead: the block converts each K-half of a tile to fp16 ONCE, into LDS, and
+// the HBM roofline).  Here every wave owns 32 G QUERIES (G = 1: 128 per pass, G = 2: 256) over the FULL K (G d / 4 VGPRs:
+// 256 at d = 512, G = 2) and all four waves share the corpus tile instead: the block converts each K-half of a tile to fp16 ONCE, into LDS, and
 // every wave reads the fragments it needs from there.
 //   per K-half stage (32 rows x d / 2 columns):
 //     wave w DMAs rows 8w .. 8w + 7 of the raw fp32 stage into a three-stage ring (global_load_lds, nt) and is also the
 //     only reader of those rows: it converts them (v_pk_mul_f32 + v_cvt_pk_f16_f32) and writes them to one of two
 //     fp16 stage images (row pitch padded or XOR-swizzled so that the MFMA fragment reads are conflict-free) — no
 //     barrier is needed for the raw data, only the wave's own vmcnt;
-//     all waves then read the 32 x 16 fragments of that image and run 2 x d / 32 MFMAs each (64 queries).
+//     all waves then read the 32 x 16 fragments of that image and run G x d / 32 MFMAs each.
 //   The conversion of stage g + 1 rides under the MFMAs of stage g (two fp16 images): ONE s_barrier per stage, two
 //   per tile, nothing else is shared.  At the end of a tile every wave gates its own 32 x 64 finished scores.
 //   LDS traffic per corpus byte: 1 (DMA) + 1 (raw read) + 0.5 (fp16 write) + 4 x 0.5 (fragment reads) = 4.5 B against the
 //   8 B of the K-split kernel at 256 queries; no partial sums, no exchange additions.
-// The seed launch of a pass is the K-split kernel's (<KQ, 2, 8, 5, true>): it only has to produce floors.
-template <int KT, bool PAD>
+// The seed launch of a pass is the K-split kernel's (<KQ, 2, NG, ., true>): it only has to produce floors.
+// Measured (10M rows, k = 10): 40.8k / 60.3k q/s at 128 / 256 queries per pass at d = 512 (K split: 39.4k / 53.1k), 51.9k /
+// 79.3k at d = 384 (48.9k / 63.1k), 73.6k / 106.5k at d = 256 (66.1k / 80.9k).  PMC at 256 queries, d = 512: shader clock
+// 1.76 GHz (the chip's power limit: matrix cores 35 % busy beside 6 TB/s of HBM traffic), 5,640 cycles per tile, waves
+// active 43 %, parked on barriers / vmcnt 27 %, issue-stalled 29 %, no LDS bank conflicts.
+template <int KT, bool PAD, int G>
 __global__ __launch_bounds__(256) void flat_scan_hq_kernel(HalfScanArgs a) {
     constexpr int KH = KT / 2;               // 16-k blocks per stage (one K-half)
     constexpr int RAWP = KH * 64;            // raw row pitch in bytes (KH x 16 floats)
@@ -481,25 +485,25 @@ __global__ __launch_bounds__(256) void flat_scan_hq_kernel(HalfScanArgs a) {
     constexpr int K = KT * 16;
     static_assert(kRawW % 1024 == 0 && KT % 2 == 0, "shape");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // 3 raw stages | 2 fp16 images
-    __shared__ uint64_t lists[256 * kHalfKeep];                             // [wave][2 groups][32 queries][16] keys
+    __shared__ uint64_t lists[4 * G * 32 * kHalfKeep];                      // [wave][G groups][32 queries][16] keys
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int fr = lane & 31, fk = lane >> 5;
     unsigned char* hbuf = smem + 3 * kRaw;
-    uint64_t* mylists = lists + (size_t)wave * 64 * kHalfKeep;
-    for (int e = lane; e < 64 * kHalfKeep; e += 64) mylists[e] = 0ull;
+    uint64_t* mylists = lists + (size_t)wave * G * 32 * kHalfKeep;
+    for (int e = lane; e < G * 32 * kHalfKeep; e += 64) mylists[e] = 0ull;
 
     // ---- this wave's 64 queries over the whole K: B[k = 16 kb + 8 fk + j][query 32 g + fr]
-    hs_h8 Q[KT][2];
+    hs_h8 Q[KT][G];
 #pragma unroll
     for (int kb = 0; kb < KT; ++kb)
 #pragma unroll
-        for (int g = 0; g < 2; ++g)
-            Q[kb][g] = *reinterpret_cast<const hs_h8*>(a.qf + (int64_t)((wave * 2 + g) * 32 + fr) * K + kb * 16 + fk * 8);
-    float floor0[2], thr[2], inv[2];
+        for (int g = 0; g < G; ++g)
+            Q[kb][g] = *reinterpret_cast<const hs_h8*>(a.qf + (int64_t)((wave * G + g) * 32 + fr) * K + kb * 16 + fk * 8);
+    float floor0[G], thr[G], inv[G];
 #pragma unroll
-    for (int g = 0; g < 2; ++g) {
-        const int myq = (wave * 2 + g) * 32 + fr;
+    for (int g = 0; g < G; ++g) {
+        const int myq = (wave * G + g) * 32 + fr;
         floor0[g] = myq < a.nq ? (a.thr0 ? a.thr0[myq] : -INFINITY) : INFINITY;
         thr[g] = floor0[g];
         inv[g] = a.qinv[myq];
@@ -508,9 +512,9 @@ __global__ __launch_bounds__(256) void flat_scan_hq_kernel(HalfScanArgs a) {
 #pragma unroll
     for (int kb = 0; kb < KT; ++kb)
 #pragma unroll
-        for (int g = 0; g < 2; ++g) asm volatile("" : "+v"(Q[kb][g]));
+        for (int g = 0; g < G; ++g) asm volatile("" : "+v"(Q[kb][g]));
 #pragma unroll
-    for (int g = 0; g < 2; ++g) asm volatile("" : "+v"(floor0[g]), "+v"(thr[g]), "+v"(inv[g]));
+    for (int g = 0; g < G; ++g) asm volatile("" : "+v"(floor0[g]), "+v"(thr[g]), "+v"(inv[g]));
 
     const int64_t ntiles = a.tile1 - a.tile0;
     const int64_t last = a.n - 1;
@@ -582,26 +586,43 @@ __global__ __launch_bounds__(256) void flat_scan_hq_kernel(HalfScanArgs a) {
         issue_stage(stage_tile(base, c), c & 1, rb);
         rb = rb == 2 ? 0 : rb + 1;
     };
-    hs_f16 acc[2];
+    hs_f16 acc[G];
     auto zero_acc = [&]() {
 #pragma unroll
-        for (int g = 0; g < 2; ++g)
+        for (int g = 0; g < G; ++g)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[g][e] = 0.f;
     };
     // MFMAs of K-half `half` from fp16 image hb
     auto mfma_half = [&](int half, int hb) {
         const unsigned char* src = hbuf + hb * kH + frow;
+        auto frag = [&](int kb) { return *reinterpret_cast<const hs_h8*>(src + (((2 * kb + fk) ^ fsw) << 4)); };
+        // fragments three 16-k blocks ahead of the MFMAs that use them (hipcc otherwise reuses ONE register quad and
+        // waits for every read: ds_read, lgkmcnt(0), two MFMAs, ds_read ... with the LDS latency exposed each time)
+        constexpr int AHEAD = (KH < 8 ? KH : 8);
+        hs_h8 f[AHEAD + 1];
+#pragma unroll
+        for (int u = 0; u < AHEAD; ++u) f[u] = frag(u);
 #pragma unroll
         for (int kb = 0; kb < KH; ++kb) {
-            const hs_h8 f = *reinterpret_cast<const hs_h8*>(src + (((2 * kb + fk) ^ fsw) << 4));
+            if (kb + AHEAD < KH) f[(kb + AHEAD) % (AHEAD + 1)] = frag(kb + AHEAD);
 #pragma unroll
-            for (int g = 0; g < 2; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f, Q[half * KH + kb][g], acc[g], 0, 0, 0);
+            for (int g = 0; g < G; ++g)
+                acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[kb % (AHEAD + 1)], Q[half * KH + kb][g], acc[g], 0, 0, 0);
+        }
+        // the order the scheduler must keep: the raw reads of the conversion and the first fragments up front, then one
+        // fragment read per pair of MFMAs (the AGPR -> VGPR copies of the query fragments ride in between)
+        __builtin_amdgcn_sched_group_barrier(0x100, AHEAD, 0);
+#pragma unroll
+        for (int kb = 0; kb < KH; ++kb) {
+            if (kb + AHEAD < KH) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 4 * G, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, G, 0);
         }
     };
     auto gate = [&](int64_t m0) {
 #pragma unroll
-        for (int g = 0; g < 2; ++g) {
+        for (int g = 0; g < G; ++g) {
             float sc[16];
 #pragma unroll
             for (int e = 0; e < 16; ++e) sc[e] = acc[g][e] * inv[g];  // exact: 1 / (s_q s_x) is a power of two
@@ -656,6 +677,7 @@ __global__ __launch_bounds__(256) void flat_scan_hq_kernel(HalfScanArgs a) {
             Raw x;
             wait_raw();
             read_raw(x);
+            __builtin_amdgcn_sched_barrier(0);  // the raw reads go first: their latency and the conversion hide under the MFMAs
             mfma_half(half, half);
             refill(tile, half + 4);  // the stage three past the one just read: flat index (half + 1) + 3
             write_half(x, half ^ 1);
@@ -673,8 +695,8 @@ __global__ __launch_bounds__(256) void flat_scan_hq_kernel(HalfScanArgs a) {
         atomicAdd(a.stats + 1, n_slow);
     }
 #pragma unroll 1
-    for (int q = 0; q < 64; ++q) {
-        const int qq = wave * 64 + q;
+    for (int q = 0; q < G * 32; ++q) {
+        const int qq = wave * G * 32 + q;
         if (qq >= a.nq) break;
         if (lane < kHalfKeep)
             a.cand[((int64_t)qq * gridDim.x + blockIdx.x) * kHalfKeep + lane] = mylists[(size_t)q * kHalfKeep + lane];
@@ -855,12 +877,12 @@ static int launch_half_inst(const HalfScanArgs& a, int device, hipStream_t strea
     return 0;
 }
 
-template <int KT, bool PAD>
+template <int KT, bool PAD, int G>
 static int launch_hq_inst(const HalfScanArgs& a, int device, hipStream_t stream, int* nblocks_out) {
-    auto kern = flat_scan_hq_kernel<KT, PAD>;
+    auto kern = flat_scan_hq_kernel<KT, PAD, G>;
     constexpr int KH = KT / 2;
     constexpr size_t lds = (size_t)3 * 32 * KH * 64 + (size_t)2 * 32 * (PAD ? 2 * KH + 1 : 2 * KH) * 16;
-    static_assert(lds + 256 * kHalfKeep * 8 <= 160 * 1024, "LDS budget of a CU");
+    static_assert(lds + 128 * G * kHalfKeep * 8 <= 160 * 1024, "LDS budget of a CU");
     {
         static std::mutex mu;
         static std::map<int, bool> done;
@@ -886,14 +908,19 @@ static int launch_half_kq(int nqpad, bool seed, const HalfScanArgs& a, int devic
     // the HBM peak; d = 768: 0.84)
     if (nqpad == 128) {
         if (seed) return launch_half_inst<KQ, 2, 4, 6, true>(a, device, stream, nb);
+        // d <= 512: the query-split kernel (no exchange) — 40.8k vs 39.4k q/s at d = 512, 51.9k vs 48.9k at 384, 73.6k vs
+        // 66.1k at 256 (10M rows); MVDB_HALF_KSPLIT=1 keeps the K-split form for A/B runs.  d = 768 / 1024: K split (a
+        // three-stage ring of raw K-halves no longer fits beside the fp16 images)
+        if constexpr (KQ <= 8)
+            if (!getenv("MVDB_HALF_KSPLIT")) return launch_hq_inst<KQ * 4, (KQ & (KQ - 1)) != 0, 1>(a, device, stream, nb);
         if (SKB4 && !getenv("MVDB_HALF_SMALL_STAGES")) return launch_half_inst<KQ, (SKB4 ? 4 : 2), 4, (SKB4 ? 3 : 6), false>(a, device, stream, nb);
         return launch_half_inst<KQ, 2, 4, 6, false>(a, device, stream, nb);
     }
     if constexpr (KQ <= 8) {
         if (nqpad == 256) {
             if (seed) return launch_half_inst<KQ, 2, 8, 5, true>(a, device, stream, nb);
-            if (getenv("MVDB_HALF_KSPLIT256")) return launch_half_inst<KQ, 2, 8, 5, false>(a, device, stream, nb);  // A/B: the K-split form
-            return launch_hq_inst<KQ * 4, (KQ & (KQ - 1)) != 0>(a, device, stream, nb);
+            if (getenv("MVDB_HALF_KSPLIT")) return launch_half_inst<KQ, 2, 8, 5, false>(a, device, stream, nb);  // A/B: the K-split form
+            return launch_hq_inst<KQ * 4, (KQ & (KQ - 1)) != 0, 2>(a, device, stream, nb);
         }
     }
     return fail(MVDB_ERR_ARG, "no fp16 nomination kernel for %d queries per pass at d = %d", nqpad, KQ * 64);
