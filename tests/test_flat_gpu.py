@@ -654,6 +654,33 @@ def test_uncertified_queries_are_rerun_one_by_one(native, monkeypatch, requery_m
     idx.close()
 
 
+def test_fp16_pass_queries_outside_its_range_go_to_the_exact_kernels(native):
+    """A zero query (every score ties: nothing can be certified), a query scaled by 1e30 and one scaled by 1e-30 (outside
+    the 2^-40 .. 2^40 window the fp16 images are scaled from) ride in a 150-query batch: they are re-run on the exact
+    kernels, every other query is served by the fp16 pass, and all results are exact."""
+    n, d, k, nq = 30000, 512, 10, 150
+    x = _corpus(n, d)
+    q = _corpus(nq, d, seed=99)
+    q[5] = 0.0
+    q[7] *= np.float32(1e30)
+    q[9] *= np.float32(1e-30)
+    idx = native.FlatIndex(d)
+    idx.add(x)
+    before = native.split_rerun_count()
+    D, I = idx.search(q, k)
+    assert native.split_rerun_count() == before + 1
+    assert I[5].tolist() == list(range(k)) and not D[5].any()          # all ties: lowest row numbers, score 0
+    x64 = x.astype(np.float64)
+    for i in range(nq):
+        if i == 5:
+            continue
+        t = x64 @ q[i].astype(np.float64)
+        want = np.argsort(-t, kind="stable")[:k]
+        assert I[i].tolist() == want.tolist(), i
+        np.testing.assert_allclose(D[i], t[I[i]], rtol=1e-5, atol=1e-4 * float(np.linalg.norm(q[i].astype(np.float64))))
+    idx.close()
+
+
 def test_split_precision_pass_falls_back_when_it_cannot_certify(native, monkeypatch):
     """40 copies of each query's best row: more than 16 - k rows tie with the k-th score, the certificate fails
     and the chunk is re-run on the exact kernels; ties still resolve to the lowest row numbers."""
