@@ -53,7 +53,8 @@ def pmc_traffic(n, d, nq=1, scan_name=None):
     best = None
     kern = {"ip_scan": "flat_scan_kernel", "ip_scan_mfma": "flat_scan_mfma", "ip_scan_gemm": "flat_scan_gemm",
             "ip_scan_split": "flat_scan_split128_kernel" if d == 512 else "flat_scan_split_kernel",
-            "ip_scan_split32": "flat_scan_split32", "ip_scan_half": "flat_scan_half_kernel"}.get(
+            "ip_scan_split32": "flat_scan_split32",
+            "ip_scan_half": "flat_scan_hq_kernel" if d <= 512 else "flat_scan_half_kernel"}.get(
                 scan_name, "flat_scan_kernel" if nq == 1 else "flat_scan_mfma")
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")))
     files.sort(key=lambda f: f"nq{nq}_" in os.path.basename(f))  # the pass profiled at this nq wins
@@ -64,7 +65,7 @@ def pmc_traffic(n, d, nq=1, scan_name=None):
                     t = rec["hbm_traffic_bytes_per_launch_avg"]
                     # a corpus pass of the split-precision kernels is up to four main launches (phases): the profile
                     # holds the average over those launches, like `algorithmic_bytes_per_launch`
-                    for per_pass in ((1, 2, 3, 4) if ("split" in kern or "half" in kern) else (1,)):
+                    for per_pass in ((1, 2, 3, 4) if ("split" in kern or "half" in kern or "hq" in kern) else (1,)):
                         if abs(t * per_pass / (n * d * 4.0) - 1.0) < 0.25:  # same workload size
                             best = {"bytes": int(t), "source": os.path.basename(f)}
         except Exception:
@@ -307,7 +308,8 @@ def main():
                 "traffic_source": (pmc_traffic(n, d, nq, scan_name) or {}).get("source"),
                 "kernel": {"ip_scan": "flat_scan_kernel", "ip_scan_mfma": "flat_scan_mfma2_kernel",
                            "ip_scan_split": "flat_scan_split128_kernel" if d == 512 else "flat_scan_split_kernel",
-                           "ip_scan_split32": "flat_scan_split32_kernel", "ip_scan_half": "flat_scan_half_kernel"}[scan_name],
+                           "ip_scan_split32": "flat_scan_split32_kernel",
+                           "ip_scan_half": "flat_scan_hq_kernel" if d <= 512 else "flat_scan_half_kernel"}[scan_name],
                 "launches": launches,
                 "avg_launch_ms": round(avg_ms, 4),
                 "algorithmic_bytes_per_launch": int(bytes_per_launch),
