@@ -68,7 +68,7 @@ def main():
                 dt = (time.perf_counter() - t0) / n
                 gemm = T * 12 * (4 * 2 * H * H + 2 * 2 * H * F)
                 attn = float(sum(12 * 4 * int(l) * int(l) * H for l in lens))
-                print(json.dumps({"B": B, "S": S, "ragged": ragged, "compute": {0: "fp32", 1: "bf16", 2: "bf16x3"}[compute],
+                print(json.dumps({"B": B, "S": S, "ragged": ragged, "compute": {0: "fp32", 1: "bf16", 2: "fp16x3"}[compute],
                                   "tokens": T, "ms": round(dt * 1e3, 3), "sentences_per_s": round(B / dt, 1),
                                   "tflops": round((gemm + attn) / dt / 1e12, 2), "gemm_tflop": round(gemm / 1e12, 3),
                                   "attn_tflop": round(attn / 1e12, 3),

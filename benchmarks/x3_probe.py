@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Parity of the encoder's compute modes against transformers' golden outputs (tests/golden/encoder_golden.npz):
-max |embedding error| and max |hidden error| per case for compute = 0 (exact fp32 MFMA) and 2 (bf16 x 3 split)."""
+max |embedding error| and max |hidden error| per case for compute = 0 (exact fp32 MFMA) and 2 (fp16 x 3 split)."""
 import json
 import os
 import sys

@@ -236,9 +236,10 @@ int mvdb_encoder_create(const mvdb_encoder_cfg* cfg, const void* const* weight_p
 int mvdb_encoder_free(mvdb_encoder* enc);
 
 /* ids[B,S], mask[B,S] (int32, host) -> out[B,H] pooled (cfg.pooling) + L2-normalised (host).
- * compute: 0 = exact-fp32 MFMA; 2 = split-precision GEMMs on the bf16 matrix cores (a.w ~ al.wh + ah.wl + ah.wh with
- * (h, l) the bf16 RNE split of an fp32 value, fp32 accumulate: operand error <= 4.6e-5 |a| |w| worst case; embeddings
- * within 7e-6 of the exact mode's, attention / LayerNorm / pooling stay fp32) — what the Python drop-in uses by default;
+ * compute: 0 = exact-fp32 MFMA; 2 = split-precision GEMMs on the fp16 matrix cores (a.w ~ al.wh + ah.wl + ah.wh with
+ * (h, l) the fp16 RNE split of an fp32 value — 22 significant bits —, weights scaled per tensor by a power of two,
+ * fp32 accumulate; needs |activation| <= 65504; embeddings within 6e-7 of transformers' fp32 output like the exact
+ * mode's, attention / LayerNorm / pooling stay fp32) — what the Python drop-in uses by default;
  * 1 = single bf16 product with fp32 accumulate (opt-in speed mode, ~1e-3). */
 int mvdb_encoder_forward(mvdb_encoder* enc, const int32_t* ids_host, const int32_t* mask_host,
                          int B, int S, int compute, float* out_host);

@@ -764,197 +764,68 @@ __global__ __launch_bounds__(256) void gemm_bf16_mfma_kernel(const float* __rest
 }
 
 // =================================================================================================
-// compute = 2: split-precision GEMM on the bf16 matrix cores, fp32-equivalent to ~2^-16
-//   a = ah + al + ra,  w = wh + wl + rw   (bf16 by RNE, |r| <= 2^-16 |.|)
-//   a.w ~ al.wh + ah.wl + ah.wh          three v_mfma_f32_32x32x16_bf16 per 16-k block, fp32 accumulate
-// The fp32 matrix cores (157 TFLOP/s) bound the exact GEMM at T = 8192; the bf16 cores are 16x faster, so three
-// products cost 3/16 of the fp32 MFMA time and the operand error (<= 4.6e-5 |a| |w| worst case, ~1e-6 of the output
-// in practice) stays 20x inside the parity tolerance of the embeddings (2e-5 absolute on unit vectors).  Activations
-// stay fp32 in HBM and are split in registers while they are staged into LDS; weights are split once into two bf16
-// planes (ensure_x3_weights).  Block tile BM x 128 x 32, four waves 2 x 2, register-staged double buffering, rows of
-// 64 B + 16 B pad in LDS (conflict-free b128 fragment reads).
+// compute = 2: split-precision GEMM on the fp16 matrix cores, fp32-equivalent to ~2^-21
+//   a = ah + al + ra,  w = wh + wl + rw   (fp16 by RNE: |r| <= 2^-22 |.|, or 2^-25 absolute once the low part is a
+//                                          subnormal — gfx950's matrix cores read fp16 subnormals exactly,
+//                                          benchmarks/micro/mfma_f16_subnormal.hip)
+//   a.w ~ al.wh + ah.wl + ah.wh          three v_mfma_f32_32x32x16_f16 per 16-k block, fp32 accumulate
+// The fp32 matrix cores (157 TFLOP/s) bound the exact GEMM at T = 8192; the 16-bit cores are 16x faster, so three
+// products cost 3/16 of the fp32 MFMA time.  With bf16 pieces (8 significant bits each) the same scheme left 2^-16 per
+// operand: hidden states within 7.5e-5 of transformers' fp32 output, uncomfortably close to the 1e-4 tolerance; fp16
+// pieces (11 bits each) leave 2^-22 at the same cost.  fp16's range is what has to be watched: weights are scaled per
+// tensor by a power of two that puts max|w| in [2^13, 2^14) (their low parts stay normal numbers; the scale is divided
+// out exactly in the epilogue), activations go in unscaled (|a| <= 65504: LayerNorm outputs, attention contexts and
+// GELU outputs of a BERT-sized encoder are orders of magnitude below).  Activations stay fp32 in HBM and are split in
+// registers on their way from LDS to the MFMA; weights are split once (ensure_x3_weights).
 // =================================================================================================
-__global__ void f32_split_bf16_kernel(const float* __restrict__ in, __bf16* __restrict__ hi, __bf16* __restrict__ lo,
-                                      int64_t n) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) {
-        const float v = in[i];
-        const __bf16 h = (__bf16)v;
-        hi[i] = h;
-        lo[i] = (__bf16)(v - (float)h);
-    }
+typedef _Float16 x3_h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 x3_h2 __attribute__((ext_vector_type(2)));
+typedef float x3_f2 __attribute__((ext_vector_type(2)));
+
+// max |in[i]| as the bits of a non-negative float (atomicMax on the integer image is order-preserving)
+__global__ void absmax_kernel(const float* __restrict__ in, int64_t n, unsigned int* __restrict__ out) {
+    float m = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        m = fmaxf(m, fabsf(in[i]));
+    for (int off = 32; off; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
 }
 
-// [N][K] fp32 -> [N][K / 32][hi 32 | lo 32] bf16: the W operand of gemm_x3_dma_kernel
-__global__ void f32_split_interleave_kernel(const float* __restrict__ in, __bf16* __restrict__ out, int64_t n) {
+// [N][K] fp32 -> [N][K / 32][hi 32 | lo 32] fp16 of scale * w: the W operand of gemm_x3_dma_kernel
+__global__ void f32_split_interleave_kernel(const float* __restrict__ in, _Float16* __restrict__ out, int64_t n,
+                                            float scale) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
-        const float v = in[i];
-        const __bf16 h = (__bf16)v;
+        const float v = in[i] * scale;  // exact: power of two
+        const _Float16 h = (_Float16)v;
         const int64_t o = (i >> 5) * 64 + (i & 31);  // K % 32 == 0: 32-k blocks never straddle rows
         out[o] = h;
-        out[o + 32] = (__bf16)(v - (float)h);
+        out[o + 32] = (_Float16)(v - (float)h);
     }
 }
 
-typedef float x3_f2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ uint32_t x3_pack(float a, float b) {  // (lo 16 bits: bf16(a), hi 16 bits: bf16(b)), RNE
-    union { bf16x2 v; uint32_t u; } c;
-    c.v = __builtin_convertvector(x3_f2{a, b}, bf16x2);
-    return c.u;
+// (hi, lo) fp16 pairs of two fp32 values: 6 VALU (cvt_pk, 2 cvt back, 2 sub, cvt_pk)
+__device__ __forceinline__ void x3_split2(float a, float b, uint32_t& hi, uint32_t& lo) {
+    union { x3_h2 v; uint32_t u; } h, l;
+    h.v = __builtin_convertvector(x3_f2{a, b}, x3_h2);
+    const x3_f2 back = __builtin_convertvector(h.v, x3_f2);
+    l.v = __builtin_convertvector(x3_f2{a - back[0], b - back[1]}, x3_h2);
+    hi = h.u;
+    lo = l.u;
 }
 
-template <int EPI, int BM>
-__global__ __launch_bounds__(256) void gemm_x3_kernel(const float* __restrict__ A, const __bf16* __restrict__ Wh,
-                                                      const __bf16* __restrict__ Wl, const float* __restrict__ bias,
-                                                      const float* __restrict__ R, float* __restrict__ C,
-                                                      const int* __restrict__ Tptr, int N, int K) {
-    constexpr int BN = 128, TM = BM / 64;
-    constexpr int TPR = 256 / BM;        // threads per A row
-    constexpr int KPT = HBK / TPR;       // k per thread and stage: 16 (BM = 128) or 8 (BM = 64)
-    constexpr int kBuf = (2 * BM + 2 * BN) * HROW;  // A_hi | A_lo | W_hi | W_lo
-    extern __shared__ __attribute__((aligned(16))) unsigned char xsm[];
-    const int T = *Tptr;
-    int bx, by;
-    if (!xcd_tile(T, BM, bx, by)) return;
-    const int m0 = by * BM, n0 = bx * BN;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-
-    const int ar = tid / TPR, ap = tid % TPR;  // A: row, part
-    const int wr = tid >> 1, wp = tid & 1;     // W planes: row, half (16 k)
-    const bool a_ok = m0 + ar < T, w_ok = n0 + wr < N;
-    const float* a_ptr = A + (int64_t)(a_ok ? m0 + ar : 0) * K + ap * KPT;
-    const int64_t w_off = (int64_t)(w_ok ? n0 + wr : 0) * K + wp * 16;
-    f32x4 ra[KPT / 4];
-    uint4 rwh[2], rwl[2];
-    auto stage_load = [&](int k0) {
-#pragma unroll
-        for (int i = 0; i < KPT / 4; ++i)
-            ra[i] = a_ok ? *reinterpret_cast<const f32x4*>(a_ptr + k0 + 4 * i) : f32x4{0, 0, 0, 0};
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            rwh[i] = w_ok ? *reinterpret_cast<const uint4*>(Wh + w_off + k0 + 8 * i) : uint4{0, 0, 0, 0};
-            rwl[i] = w_ok ? *reinterpret_cast<const uint4*>(Wl + w_off + k0 + 8 * i) : uint4{0, 0, 0, 0};
-        }
-    };
-    auto stage_write = [&](int buf) {
-        unsigned char* Ah = xsm + buf * kBuf;
-        unsigned char* Al = Ah + BM * HROW;
-        unsigned char* Bh = Al + BM * HROW;
-        unsigned char* Bl = Bh + BN * HROW;
-#pragma unroll
-        for (int i = 0; i < KPT / 8; ++i) {  // 8 elements -> one b128 of hi, one of lo
-            uint4 h, l;
-            uint32_t* hp = reinterpret_cast<uint32_t*>(&h);
-            uint32_t* lp = reinterpret_cast<uint32_t*>(&l);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float x0 = ra[2 * i + (e >> 1)][(e & 1) * 2], x1 = ra[2 * i + (e >> 1)][(e & 1) * 2 + 1];
-                const uint32_t hh = x3_pack(x0, x1);
-                hp[e] = hh;
-                lp[e] = x3_pack(x0 - __uint_as_float(hh << 16), x1 - __uint_as_float(hh & 0xFFFF0000u));
-            }
-            *reinterpret_cast<uint4*>(Ah + ar * HROW + ap * KPT * 2 + i * 16) = h;
-            *reinterpret_cast<uint4*>(Al + ar * HROW + ap * KPT * 2 + i * 16) = l;
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            *reinterpret_cast<uint4*>(Bh + wr * HROW + wp * 32 + i * 16) = rwh[i];
-            *reinterpret_cast<uint4*>(Bl + wr * HROW + wp * 32 + i * 16) = rwl[i];
-        }
-    };
-
-    f32x16 acc[TM][2];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    const int nk = K / HBK;
-    stage_load(0);
-    stage_write(0);
-    __syncthreads();
-    const int fr = lane & 31, fh = lane >> 5;
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) stage_load((kt + 1) * HBK);  // in flight during the MFMAs below
-        const unsigned char* Ah = xsm + buf * kBuf;
-        const unsigned char* Al = Ah + BM * HROW;
-        const unsigned char* Bh = Al + BM * HROW;
-        const unsigned char* Bl = Bh + BN * HROW;
-#pragma unroll
-        for (int ks = 0; ks < HBK / 16; ++ks) {
-            // lane l: row l & 31, k = 8 (l >> 5) .. + 7 of this 16-deep step
-            const int off = ks * 32 + fh * 16;
-            bf16x8 ah[TM], al[TM], bh[2], bl[2];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int row = wm * (BM / 2) + i * 32 + fr;
-                ah[i] = *reinterpret_cast<const bf16x8*>(Ah + row * HROW + off);
-                al[i] = *reinterpret_cast<const bf16x8*>(Al + row * HROW + off);
-            }
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int row = wn * 64 + j * 32 + fr;
-                bh[j] = *reinterpret_cast<const bf16x8*>(Bh + row * HROW + off);
-                bl[j] = *reinterpret_cast<const bf16x8*>(Bl + row * HROW + off);
-            }
-            // small cross terms first, the leading product last
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-        }
-        if (kt + 1 < nk) {
-            stage_write(buf ^ 1);  // the other buffer: last read one iteration ago, behind the barrier below
-            __syncthreads();
-        }
-    }
-    // epilogue.  C/D map of 32x32: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = n0 + wn * 64 + j * 32 + fr;
-            if (col >= N) continue;
-            const float bv = bias[col];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-                if (row < T) {
-                    float v = acc[i][j][r] + bv;
-                    if (EPI == EPI_BIAS_GELU) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
-                    if (EPI == EPI_BIAS_RESIDUAL) v += R[(int64_t)row * N + col];
-                    C[(int64_t)row * N + col] = v;
-                }
-            }
-        }
-}
-
-// The same split-precision GEMM with LDS-DMA staging (default): the register-staged kernel above prefetches ONE
-// K-step, whose global loads (1-2 us) are consumed a few hundred cycles of MFMA later — at T = 8192 it runs at the
-// speed of that latency.  Here fp32 A rows and the two bf16 planes of W go global -> LDS by global_load_lds into a
-// three-stage ring (two K-steps in flight, ONE bare s_barrier per K-step, as gemm_f32_dma_kernel); A fragments are
-// split into (hi, lo) in registers on their way from LDS to the MFMA (6 VALU per pair, in the MFMAs' shadow).
+// Block tile 64 x 128 x 32, four waves 2 x 2.  fp32 A rows and the (hi | lo) lines of W go global -> LDS by
+// global_load_lds into a three-stage ring (two K-steps in flight, ONE bare s_barrier per K-step, as
+// gemm_f32_dma_kernel); A fragments are split into (hi, lo) in registers on their way from LDS to the MFMA (6 VALU per
+// pair, in the MFMAs' shadow).  (A register-staged form with one K-step of prefetch ran 15 % slower and was removed.)
 //   stage = [A: BM rows x 128 B (32 fp32 k)] [W: 128 rows x 128 B (32 k of the hi plane | 32 k of the lo plane)]
 //   W comes from an INTERLEAVED copy of the two planes ([row][K / 32][hi 32 | lo 32], f32_split_interleave_kernel): one
 //   full 128-byte line per row and K-step — with separate planes every request used half a line and the L2 moved
 //   twice the W bytes (PMC: 4.9M line requests per QKV GEMM at T = 8192, 88 % L2 hits, waves parked 49 % of the time)
 //   bank swizzle on the DMA source: slot p of row r holds the row's logical slot p ^ ((r >> 1) & 7)
 template <int EPI, int BM, int NST>
-__global__ __launch_bounds__(256) void gemm_x3_dma_kernel(const float* __restrict__ A, const __bf16* __restrict__ Wp,
-                                                          const float* __restrict__ bias,
+__global__ __launch_bounds__(256) void gemm_x3_dma_kernel(const float* __restrict__ A, const _Float16* __restrict__ Wp,
+                                                          float inv_wscale, const float* __restrict__ bias,
                                                           const float* __restrict__ R, float* __restrict__ C,
                                                           const int* __restrict__ Tptr, int N, int K) {
     constexpr int BN = 128, TM = BM / 64;
@@ -1052,14 +923,14 @@ __global__ __launch_bounds__(256) void gemm_x3_dma_kernel(const float* __restric
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             union Op {
-                bf16x8 v;
+                x3_h8 v;
                 uint32_t w[4];
             } ah[TM], al[TM];
-            bf16x8 bh[2], bl[2];
+            x3_h8 bh[2], bl[2];
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                bh[j] = *reinterpret_cast<const bf16x8*>(sb + b_off[j][ks][0]);
-                bl[j] = *reinterpret_cast<const bf16x8*>(sb + b_off[j][ks][1]);
+                bh[j] = *reinterpret_cast<const x3_h8*>(sb + b_off[j][ks][0]);
+                bl[j] = *reinterpret_cast<const x3_h8*>(sb + b_off[j][ks][1]);
             }
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
@@ -1068,24 +939,22 @@ __global__ __launch_bounds__(256) void gemm_x3_dma_kernel(const float* __restric
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float p0 = e < 2 ? x0[2 * e] : x1[2 * (e - 2)], p1 = e < 2 ? x0[2 * e + 1] : x1[2 * (e - 2) + 1];
-                    const uint32_t hh = x3_pack(p0, p1);
-                    ah[i].w[e] = hh;
-                    al[i].w[e] = x3_pack(p0 - __uint_as_float(hh << 16), p1 - __uint_as_float(hh & 0xFFFF0000u));
+                    x3_split2(p0, p1, ah[i].w[e], al[i].w[e]);
                 }
             }
             // small cross terms first, the leading product last
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i].v, bh[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i].v, bh[j], acc[i][j], 0, 0, 0);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i].v, bl[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i].v, bl[j], acc[i][j], 0, 0, 0);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i].v, bh[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i].v, bh[j], acc[i][j], 0, 0, 0);
         }
         st = st == NST - 1 ? 0 : st + 1;
     }
@@ -1102,7 +971,7 @@ __global__ __launch_bounds__(256) void gemm_x3_dma_kernel(const float* __restric
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
                 if (row < T) {
-                    float v = acc[i][j][r] + bv;
+                    float v = acc[i][j][r] * inv_wscale + bv;  // exact: the weight scale is a power of two
                     if (EPI == EPI_BIAS_GELU) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
                     if (EPI == EPI_BIAS_RESIDUAL) v += R[(int64_t)row * N + col];
                     C[(int64_t)row * N + col] = v;
@@ -1345,8 +1214,9 @@ struct LayerW {
     const float *wqkv, *bqkv;  // fused (library owned)
     const float *wo, *bo, *ln1g, *ln1b, *w1, *b1, *w2, *b2, *ln2g, *ln2b;
     __bf16 *wqkv_h = nullptr, *wo_h = nullptr, *w1_h = nullptr, *w2_h = nullptr;  // lazily made bf16 copies
-    __bf16 *wqkv_l = nullptr, *wo_l = nullptr, *w1_l = nullptr, *w2_l = nullptr;  // low planes of the split (compute = 2)
-    __bf16 *wqkv_p = nullptr, *wo_p = nullptr, *w1_p = nullptr, *w2_p = nullptr;  // (hi | lo) interleaved per 32-k block
+    // compute = 2: (hi | lo) fp16 pieces of scale * w, interleaved per 32-k block, and 1 / scale
+    _Float16 *wqkv_p = nullptr, *wo_p = nullptr, *w1_p = nullptr, *w2_p = nullptr;
+    float wqkv_is = 1.f, wo_is = 1.f, w1_is = 1.f, w2_is = 1.f;
 };
 
 }  // namespace
@@ -1557,74 +1427,49 @@ int ensure_bf16_weights(mvdb_encoder* e, hipStream_t s) {
     return 0;
 }
 
-// compute = 2: BM = 128 when the 128 x 128 grid fills the chip's one-block-per-CU slots at least three times, else 64
-template <typename Kern>
-int x3_lds_attr(Kern kern, int lds, int device) {
-    static std::mutex mu;
-    static std::map<int, bool> done;  // one instance of this function (and of `done`) per kernel type
-    std::lock_guard<std::mutex> lk(mu);
-    if (!done[device]) {
-        MVDB_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        done[device] = true;
-    }
-    return 0;
-}
-
-struct X3W {
-    const __bf16 *hi, *lo, *il;  // separate planes (register-staged kernel), interleaved copy (LDS-DMA kernel)
-};
-
-template <int EPI, int BM, bool DMA, int NST = 3>
-int launch_gemm_x3_inst(const float* A, X3W W, const float* bias, const float* R, float* C,
-                        const int* Tptr, int64_t Tmax, int N, int K, int device, hipStream_t s) {
-    dim3 grid((N + 127) / 128, (unsigned)((Tmax + BM - 1) / BM));
-    if constexpr (DMA) {
-        auto kern = gemm_x3_dma_kernel<EPI, BM, NST>;
-        constexpr int lds = NST * (BM * 128 + 128 * 128);
-        MVDB_TRY(x3_lds_attr(kern, lds, device));
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, A, W.il, bias, R, C, Tptr, N, K);
-    } else {
-        auto kern = gemm_x3_kernel<EPI, BM>;
-        constexpr int lds = 2 * (2 * BM + 256) * HROW;
-        MVDB_TRY(x3_lds_attr(kern, lds, device));
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, A, W.hi, W.lo, bias, R, C, Tptr, N, K);
-    }
-    return 0;
-}
-
+// compute = 2: LDS-DMA kernel, 64 x 128 tiles, three stages, two workgroups per CU — measured best at every shape
+// (B = 256: S = 32 2.68 ms vs 3.04 with 128-row tiles for the wide GEMMs, 3.15 register-staged; S = 512 43.8 ms vs
+// 55.7 / 45.3; rings of 2, 4 or 6 stages, i.e. 3 or 1 workgroups per CU: within 1 %)
 template <int EPI>
-int launch_gemm_x3(const float* A, X3W Wh, const float* bias, const float* R, float* C,
-                   const int* Tptr, int64_t Tmax, int N, int K, int cus, int device, hipStream_t s) {
-    static const int force = []() { const char* v = getenv("MVDB_GEMM_X3_BM"); return v ? atoi(v) : 0; }();
-    static const bool dma = []() { const char* v = getenv("MVDB_GEMM_X3_DMA"); return !(v && *v == '0'); }();
-    const int64_t big = (int64_t)((N + 127) / 128) * ((Tmax + 127) / 128);
-    const bool bm128 = force ? force == 128 : big >= (int64_t)3 * cus;
-    // LDS-DMA kernel, 64 x 128 tiles, three stages, two workgroups per CU: measured best at every shape (B = 256: S = 32
-    // 2.68 ms vs 3.04 with 128-row tiles for the wide GEMMs, 3.15 register-staged; S = 512 43.8 ms vs 55.7 / 45.3;
-    // rings of 2, 4 or 6 stages, i.e. 3 or 1 workgroups per CU: within 1 %)
-    if (dma && force == 128) return launch_gemm_x3_inst<EPI, 128, true, 2>(A, Wh, bias, R, C, Tptr, Tmax, N, K, device, s);  // A/B: 64 KiB, two per CU
-    if (dma) return launch_gemm_x3_inst<EPI, 64, true, 3>(A, Wh, bias, R, C, Tptr, Tmax, N, K, device, s);
-    if (bm128) return launch_gemm_x3_inst<EPI, 128, false>(A, Wh, bias, R, C, Tptr, Tmax, N, K, device, s);
-    return launch_gemm_x3_inst<EPI, 64, false>(A, Wh, bias, R, C, Tptr, Tmax, N, K, device, s);
-}
-
-int make_planes(mvdb_encoder* e, const float* src, int64_t n, __bf16** hi, __bf16** lo, hipStream_t s) {
-    __bf16 *h = nullptr, *l = nullptr;
-    MVDB_HIP(hipMalloc((void**)&h, (size_t)n * sizeof(__bf16)));
-    e->owned_h.push_back(h);
-    MVDB_HIP(hipMalloc((void**)&l, (size_t)n * sizeof(__bf16)));
-    e->owned_h.push_back(l);
-    hipLaunchKernelGGL(f32_split_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, h, l, n);
-    *hi = h;
-    *lo = l;
+int launch_gemm_x3(const float* A, const _Float16* Wp, float inv_wscale, const float* bias, const float* R, float* C,
+                   const int* Tptr, int64_t Tmax, int N, int K, int device, hipStream_t s) {
+    auto kern = gemm_x3_dma_kernel<EPI, 64, 3>;
+    constexpr int lds = 3 * (64 * 128 + 128 * 128);
+    {
+        static std::mutex mu;
+        static std::map<int, bool> done;
+        std::lock_guard<std::mutex> lk(mu);
+        if (!done[device]) {
+            MVDB_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            done[device] = true;
+        }
+    }
+    dim3 grid((N + 127) / 128, (unsigned)((Tmax + 63) / 64));
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, A, Wp, inv_wscale, bias, R, C, Tptr, N, K);
     return 0;
 }
 
-int make_interleaved(mvdb_encoder* e, const float* src, int64_t n, __bf16** out, hipStream_t s) {
-    __bf16* p = nullptr;
-    MVDB_HIP(hipMalloc((void**)&p, (size_t)n * 2 * sizeof(__bf16)));
+// one tensor: max|w| -> power-of-two scale with max|w| * scale in [2^13, 2^14) -> interleaved (hi | lo) fp16 pieces
+int make_interleaved(mvdb_encoder* e, const float* src, int64_t n, _Float16** out, float* inv_scale, unsigned int* scratch,
+                     hipStream_t s) {
+    MVDB_HIP(hipMemsetAsync(scratch, 0, sizeof(unsigned int), s));
+    hipLaunchKernelGGL(absmax_kernel, dim3(256), dim3(256), 0, s, src, n, scratch);
+    unsigned int bits = 0;
+    MVDB_HIP(hipMemcpyAsync(&bits, scratch, sizeof(bits), hipMemcpyDeviceToHost, s));
+    MVDB_HIP(hipStreamSynchronize(s));
+    float mx;
+    memcpy(&mx, &bits, sizeof(mx));
+    if (!(mx < 3.0e38f)) return fail(MVDB_ERR_ARG, "encoder weights hold a non-finite value");
+    int ex = 0;
+    if (mx > 0.f) (void)std::frexp(mx, &ex);          // mx = m 2^ex, m in [0.5, 1)
+    int sexp = mx > 0.f ? 14 - ex : 0;
+    sexp = std::max(-100, std::min(100, sexp));
+    const float scale = std::ldexp(1.f, sexp);
+    *inv_scale = std::ldexp(1.f, -sexp);
+    _Float16* p = nullptr;
+    MVDB_HIP(hipMalloc((void**)&p, (size_t)n * 2 * sizeof(_Float16)));
     e->owned_h.push_back(p);
-    hipLaunchKernelGGL(f32_split_interleave_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, p, n);
+    hipLaunchKernelGGL(f32_split_interleave_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, p, n, scale);
     *out = p;
     return 0;
 }
@@ -1632,25 +1477,19 @@ int make_interleaved(mvdb_encoder* e, const float* src, int64_t n, __bf16** out,
 int ensure_x3_weights(mvdb_encoder* e, hipStream_t s) {
     if (e->have_x3) return 0;
     const int64_t H = e->cfg.hidden, F = e->cfg.intermediate;
+    unsigned int* scratch = nullptr;
+    MVDB_HIP(hipMalloc((void**)&scratch, sizeof(unsigned int)));
+    int rc = 0;
     for (LayerW& L : e->layers) {
-        MVDB_TRY(make_interleaved(e, L.wqkv, 3 * H * H, &L.wqkv_p, s));
-        MVDB_TRY(make_interleaved(e, L.wo, H * H, &L.wo_p, s));
-        MVDB_TRY(make_interleaved(e, L.w1, F * H, &L.w1_p, s));
-        MVDB_TRY(make_interleaved(e, L.w2, H * F, &L.w2_p, s));
-        // the high planes are the bf16 copies of compute = 1: made here when that mode has not run yet
-        __bf16* h = nullptr;
-        MVDB_TRY(make_planes(e, L.wqkv, 3 * H * H, &h, &L.wqkv_l, s));
-        if (!L.wqkv_h) L.wqkv_h = h;
-        MVDB_TRY(make_planes(e, L.wo, H * H, &h, &L.wo_l, s));
-        if (!L.wo_h) L.wo_h = h;
-        MVDB_TRY(make_planes(e, L.w1, F * H, &h, &L.w1_l, s));
-        if (!L.w1_h) L.w1_h = h;
-        MVDB_TRY(make_planes(e, L.w2, H * F, &h, &L.w2_l, s));
-        if (!L.w2_h) L.w2_h = h;
+        if (!rc) rc = make_interleaved(e, L.wqkv, 3 * H * H, &L.wqkv_p, &L.wqkv_is, scratch, s);
+        if (!rc) rc = make_interleaved(e, L.wo, H * H, &L.wo_p, &L.wo_is, scratch, s);
+        if (!rc) rc = make_interleaved(e, L.w1, F * H, &L.w1_p, &L.w1_is, scratch, s);
+        if (!rc) rc = make_interleaved(e, L.w2, H * F, &L.w2_p, &L.w2_is, scratch, s);
     }
+    (void)hipFree(scratch);
+    if (rc) return rc;
     MVDB_HIP(hipGetLastError());
     e->have_x3 = true;
-    e->have_bf16 = true;
     return 0;
 }
 
@@ -1701,7 +1540,7 @@ int enqueue_lane(mvdb_encoder* e, mvdb_encoder::Lane& w, const int32_t* ids, con
     const dim3 agrid((S + ATT_Q - 1) / ATT_Q, c.heads, B);
     for (const LayerW& L : e->layers) {
         if (compute == 2)
-            MVDB_TRY(launch_gemm_x3<EPI_BIAS>(w.x, X3W{L.wqkv_h, L.wqkv_l, L.wqkv_p}, L.bqkv, nullptr, w.qkv, Tptr, Tmax, 3 * H, H, cus, e->device, s));
+            MVDB_TRY(launch_gemm_x3<EPI_BIAS>(w.x, L.wqkv_p, L.wqkv_is, L.bqkv, nullptr, w.qkv, Tptr, Tmax, 3 * H, H, e->device, s));
         else if (compute == 1)
             launch_gemm_h<EPI_BIAS>(w.x, L.wqkv_h, L.bqkv, nullptr, w.qkv, Tptr, Tmax, 3 * H, H, s);
         else
@@ -1721,7 +1560,7 @@ int enqueue_lane(mvdb_encoder* e, mvdb_encoder::Lane& w, const int32_t* ids, con
                                w.ctx);
         }
         if (compute == 2)
-            MVDB_TRY(launch_gemm_x3<EPI_BIAS_RESIDUAL>(w.ctx, X3W{L.wo_h, L.wo_l, L.wo_p}, L.bo, w.x, w.y, Tptr, Tmax, H, H, cus, e->device, s));
+            MVDB_TRY(launch_gemm_x3<EPI_BIAS_RESIDUAL>(w.ctx, L.wo_p, L.wo_is, L.bo, w.x, w.y, Tptr, Tmax, H, H, e->device, s));
         else if (compute == 1)
             launch_gemm_h<EPI_BIAS_RESIDUAL>(w.ctx, L.wo_h, L.bo, w.x, w.y, Tptr, Tmax, H, H, s);
         else
@@ -1730,8 +1569,8 @@ int enqueue_lane(mvdb_encoder* e, mvdb_encoder::Lane& w, const int32_t* ids, con
         MVDB_VPT_SWITCH(LN1_CALL)
 #undef LN1_CALL
         if (compute == 2) {
-            MVDB_TRY(launch_gemm_x3<EPI_BIAS_GELU>(w.x, X3W{L.w1_h, L.w1_l, L.w1_p}, L.b1, nullptr, w.ffn, Tptr, Tmax, F, H, cus, e->device, s));
-            MVDB_TRY(launch_gemm_x3<EPI_BIAS_RESIDUAL>(w.ffn, X3W{L.w2_h, L.w2_l, L.w2_p}, L.b2, w.x, w.y, Tptr, Tmax, H, F, cus, e->device, s));
+            MVDB_TRY(launch_gemm_x3<EPI_BIAS_GELU>(w.x, L.w1_p, L.w1_is, L.b1, nullptr, w.ffn, Tptr, Tmax, F, H, e->device, s));
+            MVDB_TRY(launch_gemm_x3<EPI_BIAS_RESIDUAL>(w.ffn, L.w2_p, L.w2_is, L.b2, w.x, w.y, Tptr, Tmax, H, F, e->device, s));
         } else if (compute == 1) {
             launch_gemm_h<EPI_BIAS_GELU>(w.x, L.w1_h, L.b1, nullptr, w.ffn, Tptr, Tmax, F, H, s);
             launch_gemm_h<EPI_BIAS_RESIDUAL>(w.ffn, L.w2_h, L.b2, w.x, w.y, Tptr, Tmax, H, F, s);

@@ -82,8 +82,9 @@ class GpuEncoder:
         self._h = ctypes.c_void_p()
         _native.check(lib.mvdb_encoder_create(ctypes.byref(self.cfg), table, device, ctypes.byref(self._h)))
         self.hidden = self.cfg.hidden
-        # arithmetic of the GEMMs when a call does not say: 2 = split-precision bf16 x 3 on the bf16 matrix cores
-        # (fp32-equivalent to ~2^-16: embeddings within 7e-6 of transformers' fp32 output, tests/test_encoder_gpu.py),
+        # arithmetic of the GEMMs when a call does not say: 2 = split-precision fp16 x 3 on the 16-bit matrix cores
+        # (fp32-equivalent to ~2^-21: embeddings within 6e-7 of transformers' fp32 output, as close as the exact mode,
+        # tests/test_encoder_gpu.py),
         # 0 = exact fp32 matrix cores, 1 = single bf16 product (opt-in speed mode, ~1e-3)
         self.default_compute = int(os.environ.get("MVDB_ENCODER_COMPUTE", "2"))
 

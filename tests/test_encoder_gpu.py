@@ -18,12 +18,12 @@ def _model(cfg, weights):
     return GpuEncoder(cfg, sd, device=0)
 
 
-@pytest.mark.parametrize("compute", [0, 2], ids=["fp32", "bf16x3"])
+@pytest.mark.parametrize("compute", [0, 2], ids=["fp32", "fp16x3"])
 @pytest.mark.parametrize("i", range(len(CASES)))
 def test_encoder_matches_transformers_golden(i, compute, gpu):
     """Both parity modes against transformers' own outputs, same tolerances: the exact fp32 matrix cores (compute = 0)
-    and the split-precision bf16 x 3 GEMMs the drop-in uses by default (compute = 2: measured 7e-6 on the embeddings,
-    7.5e-5 on hidden states of magnitude ~6)."""
+    and the split-precision fp16 x 3 GEMMs the drop-in uses by default (compute = 2: measured 6e-7 on the embeddings,
+    8e-6 on hidden states of magnitude ~6 — the same as the exact mode)."""
     import torch
     c = CASES[i]
     cfg = E.make_config(c["name"])
@@ -152,7 +152,7 @@ def test_bf16_mode_is_close_but_opt_in(gpu):
     assert np.abs(e16 - e64).max() < 5e-3
     assert (e16 * e32).sum(1).min() > 0.9995
     assert np.abs(e16 - e32).max() > 1e-6  # it really is a different arithmetic
-    assert 0 < np.abs(ex3 - e32).max() < 1.5e-5  # the split mode: a different arithmetic too, 100x closer
+    assert 0 < np.abs(ex3 - e32).max() < 2e-6  # the split mode: a different arithmetic too, 1000x closer
     with pytest.raises(ValueError):
         enc.forward(ids, mask, compute=3)
     enc.close()
