@@ -645,7 +645,7 @@ int launch_split_scan(const mvdb_index* idx, Workspace* ws, const float* q, int 
     uint64_t* cand = ws->cand.p + (size_t)128 * kSplitKeep;          // [nq][gx][16]
     a.cand = cand;
     a.thr0 = nullptr;
-    a.stats = env_int("MVDB_SPLIT_STATS", 0) ? reinterpret_cast<unsigned int*>(ws->flags.p) + 64 : nullptr;
+    a.stats = env_int("MVDB_SPLIT_STATS", 0) ? reinterpret_cast<unsigned int*>(ws->flags.p) + (ws->flags.cap - 32) : nullptr;
     if (a.stats) MVDB_HIP(hipMemsetAsync(a.stats, 0, 8 + 12 * 8, stream));
     const int64_t seed_tiles = std::min<int64_t>(ntiles, cus);
     {
@@ -777,7 +777,7 @@ int launch_half_pass(const mvdb_index* idx, Workspace* ws, const float* q, int n
     a.qinv = qinv;
     a.xscale = xscale;
     a.nq = nq;
-    a.stats = env_int("MVDB_SPLIT_STATS", 0) ? reinterpret_cast<unsigned int*>(ws->flags.p) + 64 : nullptr;
+    a.stats = env_int("MVDB_SPLIT_STATS", 0) ? reinterpret_cast<unsigned int*>(ws->flags.p) + (ws->flags.cap - 32) : nullptr;
     if (a.stats) MVDB_HIP(hipMemsetAsync(a.stats, 0, 8, stream));
     const int64_t ntiles = (n + 31) / 32;
     const int cus = device_cus(idx->device);
@@ -916,7 +916,7 @@ int search_core(const mvdb_index* idx, Workspace* ws, const float* q_dev, int nq
         if (nchunks > 0) {
             MVDB_TRY(ws->qsplit.reserve((size_t)std::max(2 * 128, chunk) * idx->d));
             MVDB_TRY(ws->qnorm.reserve((size_t)std::max(256, 3 * chunk)));  // |q|, admission floors (, fp16 pass: 1 / scale)
-            MVDB_TRY(ws->flags.reserve((size_t)std::max(nchunks, 64) + 32));  // + diagnostics counters at [64]
+            MVDB_TRY(ws->flags.reserve((size_t)std::max(nchunks, 64) + 32));  // + diagnostics counters in the last 32 slots
             // pinned: [nchunks] chunk counts | [q0] per-query flags | [q0] int64 list of the failed queries
             const size_t pin_list = ((size_t)(nchunks + q0) * sizeof(int) + 7) & ~(size_t)7;
             MVDB_TRY(ws->pin_flags.reserve(pin_list + (size_t)q0 * sizeof(int64_t)));

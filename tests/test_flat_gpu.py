@@ -654,6 +654,29 @@ def test_uncertified_queries_are_rerun_one_by_one(native, monkeypatch, requery_m
     idx.close()
 
 
+def test_large_batch_is_cut_into_passes(native):
+    """700 queries in one call at d = 384: two 256-query passes, one 128-query pass (60 real queries... 188 left ->
+    256-wide), every result equal to the single-query search and to the oracle."""
+    n, d, k, nq = 20000, 384, 10, 700
+    x = _corpus(n, d)
+    q = _corpus(nq, d, seed=5)
+    idx = native.FlatIndex(d)
+    idx.add(x)
+    native.prof_enable(True)
+    try:
+        _split_launches(native)
+        D, I = idx.search(q, k)
+        assert _split_launches(native) == 3          # 256 + 256 + 188 queries
+    finally:
+        native.prof_enable(False)
+    _check(native, x, q, k, D, I)
+    for i in (0, 255, 256, 511, 512, 699):
+        D1, I1 = idx.search(q[i], k)
+        assert np.array_equal(I1[0], I[i])
+        np.testing.assert_allclose(D1[0], D[i], atol=2e-6, rtol=0)
+    idx.close()
+
+
 def test_fp16_pass_queries_outside_its_range_go_to_the_exact_kernels(native):
     """A zero query (every score ties: nothing can be certified), a query scaled by 1e30 and one scaled by 1e-30 (outside
     the 2^-40 .. 2^40 window the fp16 images are scaled from) ride in a 150-query batch: they are re-run on the exact
