@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""Encoder forward at the B = 256, S = 512 shape only (for rocprofv3 kernel traces)."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+from minivectordb_amd.embedding_model import GpuEncoder  # noqa: E402
+from oracle.encoder import make_weights  # noqa: E402
+
+cfg = {"model_type": "bert", "vocab_size": 30000, "hidden_size": 384, "num_hidden_layers": 12,
+       "num_attention_heads": 12, "intermediate_size": 1536, "max_position_embeddings": 512,
+       "type_vocab_size": 2, "layer_norm_eps": 1e-12, "hidden_act": "gelu", "pad_token_id": 0}
+dev = torch.device("cuda", 0)
+enc = GpuEncoder(cfg, {k: torch.from_numpy(v) for k, v in make_weights(cfg, 1).items()}, device=0)
+B, S = 256, 512
+rs = np.random.RandomState(0)
+ids = torch.from_numpy(rs.randint(5, 30000, size=(B, S)).astype(np.int32)).to(dev)
+mask = torch.ones((B, S), dtype=torch.int32, device=dev)
+os.environ["MVDB_ENCODER_GRAPH"] = "0"
+for _ in range(int(sys.argv[1]) if len(sys.argv) > 1 else 5):
+    enc.forward_device(ids, mask)
+torch.cuda.synchronize()

@@ -1201,6 +1201,183 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const float* __rest
 }
 
 // concat Wq,Wk,Wv ([H,H] each) and their biases into one [3H,H] / [3H]
+// =================================================================================================
+// compute = 2 attention: the same two products as attention_mfma_kernel on the fp16 matrix cores, split-precision
+// (x = xh + xl in fp16, three v_mfma_f32_32x32x16_f16 per 16-deep step, fp32 accumulate: 2^-22 per operand).  With the
+// GEMMs on the 16-bit cores the exact-fp32 attention had become the largest kernel of the S = 512 forward (28 %).
+//   * K and V tiles are split ONCE per workgroup while they are staged: K as [key][d] (hi, lo) fp16 planes (rows padded
+//     to 2 HD + 16 bytes: conflict-free b128 fragment reads), V TRANSPOSED as [d][key] planes (rows of 136 bytes);
+//   * S^T = K Q^T: A = a K fragment (key on the lane row, 8 consecutive d), B = the Q fragment kept in registers (split
+//     once, pre-scaled by log2(e) / sqrt(hd));
+//   * softmax on the lane as before (the query is the lane's column);
+//   * O^T += V^T P^T: the B operand of k-block kb is registers 8 kb .. 8 kb + 7 of the S^T accumulator AS THEY STAND,
+//     split in place — register j of lane half fh holds key (j & 3) + 8 (j >> 2) + 4 fh of the 16-key block, and the V^T
+//     fragment is gathered in that same key order (two 8-byte reads of four consecutive keys each), so no shuffle and no
+//     P tile through LDS.
+// =================================================================================================
+constexpr int AX_KT = 64;  // keys per LDS tile
+
+template <int HD>
+__global__ __launch_bounds__(256) void attention_x3_kernel(const float* __restrict__ qkv,
+                                                           const int* __restrict__ seq_start, int H, float scale,
+                                                           float* __restrict__ ctx) {
+    constexpr int DT = HD / 32, KB = HD / 16;
+    constexpr int KP = HD * 2 + 16;     // K plane row pitch (bytes)
+    constexpr int VP = AX_KT * 2 + 8;   // V^T plane row pitch (bytes)
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int s0 = seq_start[b], len = seq_start[b + 1] - s0;
+    const int q0 = blockIdx.x * 128;
+    if (q0 >= len) return;
+    __shared__ __attribute__((aligned(16))) unsigned char Kh[AX_KT * KP];
+    __shared__ __attribute__((aligned(16))) unsigned char Kl[AX_KT * KP];
+    __shared__ __attribute__((aligned(16))) unsigned char Vh[HD * VP];
+    __shared__ __attribute__((aligned(16))) unsigned char Vl[HD * VP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 31, fh = lane >> 5;
+    const int64_t ld = 3 * (int64_t)H;
+
+    // Q fragments (B operand): query q0 + 32 wave + fr, k = 16 kb + 8 fh .. + 7, pre-scaled, split once
+    const int qrow = q0 + wave * 32 + fr;
+    const bool qvalid = qrow < len;
+    union Op {
+        x3_h8 v;
+        uint32_t w[4];
+    };
+    Op qh[KB], ql[KB];
+    {
+        const float* qp = qkv + (int64_t)(s0 + (qvalid ? qrow : 0)) * ld + h * HD;
+        const float sc = scale * kLog2e;
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(qp + 16 * kb + 8 * fh);
+            const f32x4 a1 = *reinterpret_cast<const f32x4*>(qp + 16 * kb + 8 * fh + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float p0 = (e < 2 ? a0[2 * e] : a1[2 * (e - 2)]) * sc, p1 = (e < 2 ? a0[2 * e + 1] : a1[2 * (e - 2) + 1]) * sc;
+                x3_split2(qvalid ? p0 : 0.f, qvalid ? p1 : 0.f, qh[kb].w[e], ql[kb].w[e]);
+            }
+        }
+    }
+    f32x16 o[DT];
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
+    float m = -INFINITY, l = 0.f;
+    const bool wave_active = q0 + wave * 32 < len;  // wave-uniform
+
+    for (int kt = 0; kt < len; kt += AX_KT) {
+        const int nk = min(AX_KT, len - kt);
+        __syncthreads();
+        // cooperative tile load + split: thread -> (key, 4 consecutive d)
+        for (int e = tid; e < AX_KT * (HD / 4); e += 256) {
+            const int key = e / (HD / 4), c = (e % (HD / 4)) * 4;
+            f32x4 kv = {0, 0, 0, 0}, vv = {0, 0, 0, 0};
+            if (key < nk) {
+                const float* base = qkv + (int64_t)(s0 + kt + key) * ld + h * HD + c;
+                kv = *reinterpret_cast<const f32x4*>(base + H);
+                vv = *reinterpret_cast<const f32x4*>(base + 2 * H);
+            }
+            uint32_t h0, l0, h1, l1;
+            x3_split2(kv[0], kv[1], h0, l0);
+            x3_split2(kv[2], kv[3], h1, l1);
+            *reinterpret_cast<uint2*>(Kh + key * KP + c * 2) = uint2{h0, h1};
+            *reinterpret_cast<uint2*>(Kl + key * KP + c * 2) = uint2{l0, l1};
+            x3_split2(vv[0], vv[1], h0, l0);
+            x3_split2(vv[2], vv[3], h1, l1);
+            *reinterpret_cast<uint16_t*>(Vh + (c + 0) * VP + key * 2) = (uint16_t)h0;
+            *reinterpret_cast<uint16_t*>(Vh + (c + 1) * VP + key * 2) = (uint16_t)(h0 >> 16);
+            *reinterpret_cast<uint16_t*>(Vh + (c + 2) * VP + key * 2) = (uint16_t)h1;
+            *reinterpret_cast<uint16_t*>(Vh + (c + 3) * VP + key * 2) = (uint16_t)(h1 >> 16);
+            *reinterpret_cast<uint16_t*>(Vl + (c + 0) * VP + key * 2) = (uint16_t)l0;
+            *reinterpret_cast<uint16_t*>(Vl + (c + 1) * VP + key * 2) = (uint16_t)(l0 >> 16);
+            *reinterpret_cast<uint16_t*>(Vl + (c + 2) * VP + key * 2) = (uint16_t)l1;
+            *reinterpret_cast<uint16_t*>(Vl + (c + 3) * VP + key * 2) = (uint16_t)(l1 >> 16);
+        }
+        __syncthreads();
+        if (!wave_active) continue;
+#pragma unroll
+        for (int kb32 = 0; kb32 < AX_KT / 32; ++kb32) {
+            if (kb32 * 32 >= nk) break;
+            // ---- S^T block: 32 keys x 32 queries ----------------------------------------------------
+            f32x16 st;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[r] = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) {
+                const int off = (kb32 * 32 + fr) * KP + (16 * kb + 8 * fh) * 2;
+                const x3_h8 kh = *reinterpret_cast<const x3_h8*>(Kh + off);
+                const x3_h8 kl = *reinterpret_cast<const x3_h8*>(Kl + off);
+                st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[kb].v, st, 0, 0, 0);
+                st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[kb].v, st, 0, 0, 0);
+                st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[kb].v, st, 0, 0, 0);
+            }
+            // ---- online softmax, query on the lane --------------------------------------------------
+            float cmax = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kb32 * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                st[r] = key < nk ? st[r] : -INFINITY;
+                cmax = fmaxf(cmax, st[r]);
+            }
+            cmax = fmaxf(cmax, __shfl_xor(cmax, 32));
+            const float mn = fmaxf(m, cmax);
+            const float alpha = __builtin_amdgcn_exp2f(m - mn);
+            float psum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                st[r] = __builtin_amdgcn_exp2f(st[r] - mn);  // masked keys: 2^(-inf) = 0
+                psum += st[r];
+            }
+            psum += __shfl_xor(psum, 32);
+            l = l * alpha + psum;
+            m = mn;
+#pragma unroll
+            for (int t = 0; t < DT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+            // ---- O^T += V^T · P^T: k-block kb16 = accumulator registers 8 kb16 .. + 7, i.e. keys
+            //      16 kb16 + {4 fh .. 4 fh + 3} and 16 kb16 + 8 + {4 fh .. 4 fh + 3} of this 32-key block
+#pragma unroll
+            for (int kb16 = 0; kb16 < 2; ++kb16) {
+                Op ph, pl;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) x3_split2(st[8 * kb16 + 2 * e], st[8 * kb16 + 2 * e + 1], ph.w[e], pl.w[e]);
+                const int kbase = (kb32 * 32 + 16 * kb16 + 4 * fh) * 2;
+#pragma unroll
+                for (int t = 0; t < DT; ++t) {
+                    const int row = (t * 32 + fr) * VP + kbase;
+                    union {
+                        x3_h8 v;
+                        uint2 u[2];
+                    } vh, vl;
+                    vh.u[0] = *reinterpret_cast<const uint2*>(Vh + row);
+                    vh.u[1] = *reinterpret_cast<const uint2*>(Vh + row + 16);
+                    vl.u[0] = *reinterpret_cast<const uint2*>(Vl + row);
+                    vl.u[1] = *reinterpret_cast<const uint2*>(Vl + row + 16);
+                    o[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl.v, ph.v, o[t], 0, 0, 0);
+                    o[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh.v, pl.v, o[t], 0, 0, 0);
+                    o[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh.v, ph.v, o[t], 0, 0, 0);
+                }
+            }
+        }
+    }
+    if (!wave_active) return;
+    // O^T tile t: col = query fr (lane), row d = t*32 + (r&3) + 8(r>>2) + 4fh
+    if (qvalid) {
+        const float inv = 1.0f / l;
+        float* op = ctx + (int64_t)(s0 + qrow) * H + h * HD;
+#pragma unroll
+        for (int t = 0; t < DT; ++t)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                f32x4 v = {o[t][4 * r4] * inv, o[t][4 * r4 + 1] * inv, o[t][4 * r4 + 2] * inv,
+                           o[t][4 * r4 + 3] * inv};
+                *reinterpret_cast<f32x4*>(op + t * 32 + 8 * r4 + 4 * fh) = v;  // d = 8*r4 + 4fh + 0..3
+            }
+    }
+}
+
 __global__ void concat3_kernel(const float* a, const float* b, const float* c, int64_t n, float* out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
@@ -1537,6 +1714,10 @@ int enqueue_lane(mvdb_encoder* e, mvdb_encoder::Lane& w, const int32_t* ids, con
         const char* v = getenv("MVDB_ENCODER_ATTENTION");
         return v && v[0] == 'v';
     }();
+    static const bool x3_attention = []() {
+        const char* v = getenv("MVDB_ATTENTION_X3");
+        return !(v && *v == '0');
+    }();
     const dim3 agrid((S + ATT_Q - 1) / ATT_Q, c.heads, B);
     for (const LayerW& L : e->layers) {
         if (compute == 2)
@@ -1552,6 +1733,11 @@ int enqueue_lane(mvdb_encoder* e, mvdb_encoder::Lane& w, const int32_t* ids, con
             else
                 hipLaunchKernelGGL(attention_kernel<64>, agrid, dim3(ATT_Q), 0, s, w.qkv, w.seq_start, H, scale,
                                    w.ctx);
+        } else if (compute == 2 && x3_attention) {
+            if (hd == 32)
+                hipLaunchKernelGGL(attention_x3_kernel<32>, agrid, dim3(256), 0, s, w.qkv, w.seq_start, H, scale, w.ctx);
+            else
+                hipLaunchKernelGGL(attention_x3_kernel<64>, agrid, dim3(256), 0, s, w.qkv, w.seq_start, H, scale, w.ctx);
         } else if (hd == 32) {
             hipLaunchKernelGGL(attention_mfma_kernel<32>, agrid, dim3(256), 0, s, w.qkv, w.seq_start, H, scale,
                                w.ctx);
