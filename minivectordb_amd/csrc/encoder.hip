@@ -804,6 +804,22 @@ __global__ void f32_split_interleave_kernel(const float* __restrict__ in, _Float
     }
 }
 
+// erf to 1.5e-7 absolute (Abramowitz & Stegun 7.1.26: 1 - (a1 t + .. + a5 t^5) exp(-x^2), t = 1 / (1 + p |x|)) in ~14
+// instructions; libm's erff is ~50 with branches and was a fifth of the FFN1 GEMM once its MFMAs ran on the 16-bit
+// cores.  GELU error <= 0.5 |x| 1.5e-7: below the fp32 rounding noise of the GEMM that feeds it.  Used by the
+// split-precision mode only; the exact mode keeps erff.
+__device__ __forceinline__ float x3_erf(float x) {
+    const float ax = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+    float p = fmaf(t, 1.061405429f, -1.453152027f);
+    p = fmaf(t, p, 1.421413741f);
+    p = fmaf(t, p, -0.284496736f);
+    p = fmaf(t, p, 0.254829592f);
+    const float e = __builtin_amdgcn_exp2f(-ax * ax * 1.4426950408889634f);
+    const float r = fmaf(-p * t, e, 1.0f);
+    return copysignf(r, x);
+}
+
 // (hi, lo) fp16 pairs of two fp32 values: 6 VALU (cvt_pk, 2 cvt back, 2 sub, cvt_pk)
 __device__ __forceinline__ void x3_split2(float a, float b, uint32_t& hi, uint32_t& lo) {
     union { x3_h2 v; uint32_t u; } h, l;
@@ -972,7 +988,7 @@ __global__ __launch_bounds__(256) void gemm_x3_dma_kernel(const float* __restric
                 const int row = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
                 if (row < T) {
                     float v = acc[i][j][r] * inv_wscale + bv;  // exact: the weight scale is a power of two
-                    if (EPI == EPI_BIAS_GELU) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+                    if (EPI == EPI_BIAS_GELU) v = 0.5f * v * (1.0f + x3_erf(v * 0.70710678118654752440f));
                     if (EPI == EPI_BIAS_RESIDUAL) v += R[(int64_t)row * N + col];
                     C[(int64_t)row * N + col] = v;
                 }
