@@ -111,6 +111,12 @@ class GpuEncoder:
         self._native.check(self._native.lib().mvdb_encoder_forward(
             self._h, ctypes.c_void_p(ids.ctypes.data), ctypes.c_void_p(mask.ctypes.data), B, S, compute,
             ctypes.c_void_p(out.ctypes.data)))
+        if compute == 2 and not np.isfinite(out).all():
+            # the split-precision GEMMs take activations as fp16 pieces: an activation beyond 65504 (no BERT-sized
+            # encoder gets near it) overflows to inf.  Same kernels' exact-fp32 mode instead of a NaN embedding.
+            self._native.check(self._native.lib().mvdb_encoder_forward(
+                self._h, ctypes.c_void_p(ids.ctypes.data), ctypes.c_void_p(mask.ctypes.data), B, S, 0,
+                ctypes.c_void_p(out.ctypes.data)))
         return out
 
     def forward_device(self, ids, mask, compute=None, want_hidden=False):
