@@ -136,6 +136,25 @@ def test_embedding_model_api(gpu):
     assert m2.alternative_model == AlternativeModel.small
 
 
+def test_split_mode_recomputes_exactly_when_an_activation_leaves_fp16_range(gpu):
+    """Activations enter the split-precision GEMMs as fp16 pieces.  With an FFN weight blown up by 1e6 the GELU outputs
+    pass 65504, the split-precision forward turns non-finite, and the host path returns the exact-fp32 mode's result."""
+    cfg = E.make_config("tiny")
+    w = E.make_weights(cfg, 3)
+    w = {k: v.copy() for k, v in w.items()}
+    w["encoder.layer.0.intermediate.dense.weight"] *= np.float32(1e6)
+    ids, mask = E.make_inputs(cfg, 3, 9, 4)
+    enc = _model(cfg, w)
+    import torch
+    dev = torch.device("cuda", 0)
+    raw, _ = enc.forward_device(torch.from_numpy(ids).to(dev), torch.from_numpy(mask).to(dev), compute=2)
+    assert not torch.isfinite(raw).all()                    # the device path reports what the kernels produced
+    e2 = enc.forward(ids, mask, compute=2)
+    e0 = enc.forward(ids, mask, compute=0)
+    assert np.isfinite(e0).all() and np.array_equal(e2, e0)
+    enc.close()
+
+
 def test_bf16_mode_is_close_but_opt_in(gpu):
     """compute = 1 (bf16 MFMA operands, fp32 accumulate) is an opt-in speed mode, not the parity
     path: embeddings stay within 5e-3 of the float64 restatement (cosine to the fp32 result > 0.9995)."""
