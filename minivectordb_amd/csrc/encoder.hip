@@ -839,7 +839,9 @@ __device__ __forceinline__ void x3_split2(float a, float b, uint32_t& hi, uint32
 //   full 128-byte line per row and K-step — with separate planes every request used half a line and the L2 moved
 //   twice the W bytes (PMC: 4.9M line requests per QKV GEMM at T = 8192, 88 % L2 hits, waves parked 49 % of the time)
 //   bank swizzle on the DMA source: slot p of row r holds the row's logical slot p ^ ((r >> 1) & 7)
-template <int EPI, int BM, int NST>
+// DBG != 0: timing ablations (MVDB_GEMM_X3_DBG; results invalid): 1 = no fragment reads / splits / MFMAs (the DMA ring,
+// barriers and epilogue alone), 2 = no DMA (compute on whatever the LDS holds)
+template <int EPI, int BM, int NST, int DBG = 0>
 __global__ __launch_bounds__(256) void gemm_x3_dma_kernel(const float* __restrict__ A, const _Float16* __restrict__ Wp,
                                                           float inv_wscale, const float* __restrict__ bias,
                                                           const float* __restrict__ R, float* __restrict__ C,
@@ -887,6 +889,7 @@ __global__ __launch_bounds__(256) void gemm_x3_dma_kernel(const float* __restric
         }
     }
     auto issue = [&](int kt, int stage) {
+        if (DBG == 2) return;
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const char* src = sbase[i] + (int64_t)kt * kstep[i];
@@ -936,6 +939,11 @@ __global__ __launch_bounds__(256) void gemm_x3_dma_kernel(const float* __restric
         }
         __builtin_amdgcn_sched_barrier(0);
         const unsigned char* sb = xsm + st * kStage;
+        if (DBG == 1) {
+            acc[0][0][0] += (float)kt;
+            st = st == NST - 1 ? 0 : st + 1;
+            continue;
+        }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             union Op {
@@ -1626,14 +1634,17 @@ int ensure_bf16_weights(mvdb_encoder* e, hipStream_t s) {
 template <int EPI>
 int launch_gemm_x3(const float* A, const _Float16* Wp, float inv_wscale, const float* bias, const float* R, float* C,
                    const int* Tptr, int64_t Tmax, int N, int K, int device, hipStream_t s) {
-    auto kern = gemm_x3_dma_kernel<EPI, 64, 3>;
+    static const int dbg = []() { const char* v = getenv("MVDB_GEMM_X3_DBG"); return v ? atoi(v) : 0; }();
+    auto kern = dbg == 1 ? gemm_x3_dma_kernel<EPI, 64, 3, 1> : dbg == 2 ? gemm_x3_dma_kernel<EPI, 64, 3, 2> : gemm_x3_dma_kernel<EPI, 64, 3>;
     constexpr int lds = 3 * (64 * 128 + 128 * 128);
     {
         static std::mutex mu;
         static std::map<int, bool> done;
         std::lock_guard<std::mutex> lk(mu);
         if (!done[device]) {
-            MVDB_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            MVDB_HIP(hipFuncSetAttribute((const void*)gemm_x3_dma_kernel<EPI, 64, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            MVDB_HIP(hipFuncSetAttribute((const void*)gemm_x3_dma_kernel<EPI, 64, 3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            MVDB_HIP(hipFuncSetAttribute((const void*)gemm_x3_dma_kernel<EPI, 64, 3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
             done[device] = true;
         }
     }
