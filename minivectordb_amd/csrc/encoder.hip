@@ -983,7 +983,34 @@ __global__ __launch_bounds__(256) void gemm_x3_dma_kernel(const float* __restric
         st = st == NST - 1 ? 0 : st + 1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the clamped look-ahead DMAs must land before the LDS is released
-    // epilogue.  C/D map of 32x32: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    // epilogue.  C/D map of 32x32: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+    // Tiles that lie wholly inside the matrix (all but the last row band of a ragged batch) take a branch-free path: with
+    // a bounds test per element hipcc put every store in its own basic block behind an s_waitcnt vmcnt(0) — 32 serialised
+    // store round trips per tile.
+    const bool inside = m0 + BM <= T && n0 + BN <= N;  // workgroup-uniform
+    if (inside) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int col = n0 + wn * 64 + j * 32 + fr;
+                const float bv = bias[col];
+                const int row0 = m0 + wm * (BM / 2) + i * 32 + 4 * fh;
+                float res[16];
+                if (EPI == EPI_BIAS_RESIDUAL) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) res[r] = R[(int64_t)(row0 + (r & 3) + 8 * (r >> 2)) * N + col];
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = acc[i][j][r] * inv_wscale + bv;  // exact: the weight scale is a power of two
+                    if (EPI == EPI_BIAS_GELU) v = 0.5f * v * (1.0f + x3_erf(v * 0.70710678118654752440f));
+                    if (EPI == EPI_BIAS_RESIDUAL) v += res[r];
+                    C[(int64_t)(row0 + (r & 3) + 8 * (r >> 2)) * N + col] = v;
+                }
+            }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
