@@ -343,7 +343,31 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(const float* __restr
         }
     }
 
-    // epilogue.  C/D map of 32x32: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    // epilogue.  C/D map of 32x32: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).  Tiles wholly inside the
+    // matrix take a branch-free path (see gemm_x3_dma_kernel: per-element bounds tests serialise the stores).
+    if (m0 + BM <= T && n0 + BN <= N) {
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int j = 0; j < TI; ++j) {
+                const int col = n0 + wn * 32 * TI + j * 32 + fr;
+                const float bvv = bias[col];
+                const int row0 = m0 + wm * 32 * TI + i * 32 + 4 * fk;
+                float res[16];
+                if (EPI == EPI_BIAS_RESIDUAL) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) res[r] = R[(int64_t)(row0 + (r & 3) + 8 * (r >> 2)) * N + col];
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = acc[i][j][r] + bvv;
+                    if (EPI == EPI_BIAS_GELU) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+                    if (EPI == EPI_BIAS_RESIDUAL) v += res[r];
+                    C[(int64_t)(row0 + (r & 3) + 8 * (r >> 2)) * N + col] = v;
+                }
+            }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < TI; ++i)
 #pragma unroll
@@ -489,7 +513,31 @@ __global__ __launch_bounds__(256) void gemm_f32_dma_kernel(const float* __restri
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[0][0][r] += acc2[r];
 
-    // epilogue.  C/D map of 32x32: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    // epilogue.  C/D map of 32x32: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).  Tiles wholly inside the
+    // matrix take a branch-free path (see gemm_x3_dma_kernel: per-element bounds tests serialise the stores).
+    if (m0 + BM <= T && n0 + BN <= N) {
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int j = 0; j < TI; ++j) {
+                const int col = n0 + wn * 32 * TI + j * 32 + fr;
+                const float bvv = bias[col];
+                const int row0 = m0 + wm * 32 * TI + i * 32 + 4 * fk;
+                float res[16];
+                if (EPI == EPI_BIAS_RESIDUAL) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) res[r] = R[(int64_t)(row0 + (r & 3) + 8 * (r >> 2)) * N + col];
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = acc[i][j][r] + bvv;
+                    if (EPI == EPI_BIAS_GELU) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+                    if (EPI == EPI_BIAS_RESIDUAL) v += res[r];
+                    C[(int64_t)(row0 + (r & 3) + 8 * (r >> 2)) * N + col] = v;
+                }
+            }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < TI; ++i)
 #pragma unroll
