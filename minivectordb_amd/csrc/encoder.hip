@@ -111,29 +111,46 @@ __global__ __launch_bounds__(256) void pack_fill_kernel(const int32_t* __restric
 // =================================================================================================
 // row kernels: one wave per token row, VPT = ceil(H/64) values per lane in registers
 // =================================================================================================
-template <int VPT>
+template <int VPT, bool FULL = false>
 __device__ __forceinline__ void wave_layernorm(float (&v)[VPT], int H, int lane, float eps,
                                                const float* __restrict__ gamma,
                                                const float* __restrict__ beta, float* __restrict__ out) {
+    // gamma / beta are fetched BEFORE the reductions (their latency hides under the shuffles) and, when the row fills
+    // every lane slot (H = 64 VPT: 384, 1024), the tail is branch-free: with a bounds test per element hipcc emitted a
+    // loop of load, s_waitcnt vmcnt(0), store — six serialised round trips per row
+    constexpr bool full = FULL;  // the row fills every lane slot: H == 64 VPT
+    float g[VPT], bt[VPT];
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+        const int c = lane + i * 64;
+        const int cc = full || c < H ? c : 0;
+        g[i] = gamma[cc];
+        bt[i] = beta[cc];
+    }
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < VPT; ++i) s += (lane + i * 64 < H) ? v[i] : 0.f;
+    for (int i = 0; i < VPT; ++i) s += (full || lane + i * 64 < H) ? v[i] : 0.f;
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
     const float mean = s / (float)H;
     float q = 0.f;
 #pragma unroll
     for (int i = 0; i < VPT; ++i) {
-        const float dlt = (lane + i * 64 < H) ? v[i] - mean : 0.f;
+        const float dlt = (full || lane + i * 64 < H) ? v[i] - mean : 0.f;
         q += dlt * dlt;
     }
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) q += __shfl_xor(q, m);
     const float rstd = 1.0f / sqrtf(q / (float)H + eps);  // biased variance, eps inside the sqrt
+    if (full) {
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) out[lane + i * 64] = (v[i] - mean) * rstd * g[i] + bt[i];
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < VPT; ++i) {
         const int c = lane + i * 64;
-        if (c < H) out[c] = (v[i] - mean) * rstd * gamma[c] + beta[c];
+        if (c < H) out[c] = (v[i] - mean) * rstd * g[i] + bt[i];
     }
 }
 
@@ -164,7 +181,7 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const int* __restrict__ t
 }
 
 // x[p,:] = LN(y[p,:])   (y already holds dense(...) + bias + residual from the GEMM epilogue)
-template <int VPT>
+template <int VPT, bool FULL>
 __global__ __launch_bounds__(256) void ln_kernel(const float* __restrict__ y,
                                                  const int* __restrict__ seq_start, int B,
                                                  const float* __restrict__ gamma,
@@ -178,9 +195,12 @@ __global__ __launch_bounds__(256) void ln_kernel(const float* __restrict__ y,
 #pragma unroll
     for (int i = 0; i < VPT; ++i) {
         const int c = lane + i * 64;
-        v[i] = c < H ? y[(int64_t)p * H + c] : 0.f;
+        if (FULL)
+            v[i] = y[(int64_t)p * H + c];
+        else
+            v[i] = c < H ? y[(int64_t)p * H + c] : 0.f;
     }
-    wave_layernorm<VPT>(v, H, lane, eps, gamma, beta, x + (int64_t)p * H);
+    wave_layernorm<VPT, FULL>(v, H, lane, eps, gamma, beta, x + (int64_t)p * H);
 }
 
 // out[b,:] = normalize(mean over the sequence's tokens)   — average_pool + F.normalize(eps=1e-12)
@@ -1775,8 +1795,12 @@ int ensure_x3_weights(mvdb_encoder* e, hipStream_t s) {
 template <int VPT>
 void launch_ln(const float* y, const int* seq_start, int B, const float* g, const float* b, float eps,
                int H, float* x, int64_t Tmax, hipStream_t s) {
-    hipLaunchKernelGGL(ln_kernel<VPT>, dim3((unsigned)((Tmax + 3) / 4)), dim3(256), 0, s, y, seq_start, B,
-                       g, b, eps, H, x);
+    if (H == VPT * 64)  // branch-free rows (384, 1024, ...)
+        hipLaunchKernelGGL((ln_kernel<VPT, true>), dim3((unsigned)((Tmax + 3) / 4)), dim3(256), 0, s, y, seq_start, B,
+                           g, b, eps, H, x);
+    else
+        hipLaunchKernelGGL((ln_kernel<VPT, false>), dim3((unsigned)((Tmax + 3) / 4)), dim3(256), 0, s, y, seq_start, B,
+                           g, b, eps, H, x);
 }
 
 // Enqueue every kernel of one forward on `s` (no allocation, no host sync: capturable in a hipGraph).
