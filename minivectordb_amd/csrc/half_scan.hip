@@ -30,18 +30,16 @@
 //     the margin it needs (1.04e-3) is 4.5x the bf16 passes', the margin it has is ~4x theirs.  Queries that fail
 //     (duplicate-heavy neighbourhoods) flag their chunk for a re-run on the exact fp32 kernels (mvdb.hip).
 //
-// Kernel shape (flat_scan_half_kernel<NW, NG, NST, SEED>), d = 128 NW:
-//   K is split over the NW waves of a block (one wave per SIMD): wave w owns columns [128 w, 128 w + 128) of every
-//   row and ALL 32 NG queries of the pass, whose fp16 fragments stay in registers for the whole launch (32 NG VGPRs).
-//   It streams its 512-byte slice of a 32-row tile through a PRIVATE LDS-DMA ring (NST stages of 32 rows x 256 B,
-//   global_load_lds, non-temporal, bank swizzle on the source address), converts the slice to fp16 fragments
-//   (v_pk_mul_f32 + v_cvt_pk_f16_f32: 1 VALU op per element), and accumulates 32 x 32 partial score tiles, NW query
-//   groups per ROUND.  A round ends with the exchange: wave w keeps the group it owns and hands the NW - 1 others
-//   to their owners through LDS (two bare s_barriers per round), sums the NW partials of its own group and gates
-//   the 32 x 32 finished scores (query on the lane, one threshold register per owned group).
-//   No barrier inside the streaming part; NG / NW rounds per tile.
-//   SEED = one tile per block, every score dumped (no lists, no floors): the first launch of a pass.
-//
+// Two kernels compute a(x) and keep the per-block lists; both leave the queries' fp16 fragments in registers for the whole
+// launch and stream the corpus through LDS-DMA rings (global_load_lds, non-temporal):
+//   flat_scan_hq_kernel<KT, PAD, G>   d <= 512 (the default there), 128 G queries per pass.  QUERY split: every wave owns
+//       32 G queries over the full K; the block converts each K-half of a 32-row tile to fp16 once, into LDS, and every
+//       wave reads its fragments from there.  One s_barrier per stage, no exchange.  (Description at the kernel.)
+//   flat_scan_half_kernel<KQ, SKB, NG, NST, SEED>   d = 64 KQ up to 1024, 32 NG queries per pass.  K split: wave w of
+//       four owns 16 KQ columns of every row and ALL queries, streams its slice through a private ring, and after each
+//       round of four 32 x 32 partial score tiles hands three of them to their owners through LDS (two s_barriers per
+//       round).  Serves d = 768 / 1024, and — SEED = one tile per block, every score dumped, no lists — the first launch
+//       of every pass at every d.
 // Algorithmic bytes per launch = rows scanned x ld x 4 (the corpus once for all queries of the pass).
 #include <cmath>
 #include <cstdlib>
