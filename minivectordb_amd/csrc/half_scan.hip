@@ -28,7 +28,7 @@
 //     Every row outside R has a <= U, hence a true score below the k-th result's.  On exchangeable data the last
 //     phase's floor leaves ~100 candidates, so the test compares the k-th score with the ~64th instead of the 16th:
 //     the margin it needs (1.04e-3) is 4.5x the bf16 passes', the margin it has is ~4x theirs.  Queries that fail
-//     (duplicate-heavy neighbourhoods) flag their chunk for a re-run on the exact fp32 kernels (mvdb.hip).
+//     (duplicate-heavy neighbourhoods) are flagged one by one and re-run on the exact fp32 kernels (mvdb.hip).
 //
 // Two kernels compute a(x) and keep the per-block lists; both leave the queries' fp16 fragments in registers for the whole
 // launch and stream the corpus through LDS-DMA rings (global_load_lds, non-temporal):
