@@ -909,15 +909,15 @@ __device__ __forceinline__ void x3_split2(float a, float b, uint32_t& hi, uint32
 //   bank swizzle on the DMA source: slot p of row r holds the row's logical slot p ^ ((r >> 1) & 7)
 // DBG != 0: timing ablations (MVDB_GEMM_X3_DBG; results invalid): 1 = no fragment reads / splits / MFMAs (the DMA ring,
 // barriers and epilogue alone), 2 = no DMA (compute on whatever the LDS holds)
-template <int EPI, int BM, int NST, int DBG = 0>
-__global__ __launch_bounds__(256) void gemm_x3_dma_kernel(const float* __restrict__ A, const _Float16* __restrict__ Wp,
+template <int EPI, int BM, int NST, int DBG = 0, int WAVES = 4>
+__global__ __launch_bounds__(WAVES * 64) void gemm_x3_dma_kernel(const float* __restrict__ A, const _Float16* __restrict__ Wp,
                                                           float inv_wscale, const float* __restrict__ bias,
                                                           const float* __restrict__ R, float* __restrict__ C,
                                                           const int* __restrict__ Tptr, int N, int K) {
-    constexpr int BN = 128, TM = BM / 64;
+    constexpr int BN = 128, WM = WAVES / 2, TM = BM / (32 * WM);  // WAVES / 2 x 2 waves, wave tile 32 TM x 64
     constexpr int kA = BM * 128, kStage = kA + 2 * BN * 64;
     constexpr int NA = BM / 8;             // DMA instructions of the A tile (8 rows each)
-    constexpr int NI = (NA + 16) / 4;      // per wave and stage (W planes: 8 instructions of 16 rows each)
+    constexpr int NI = (NA + 16) / WAVES;  // per wave and stage (W: 16 instructions of 8 rows each)
     extern __shared__ __attribute__((aligned(16))) unsigned char xsm[];
     const int T = *Tptr;
     int bx, by;
@@ -973,7 +973,7 @@ __global__ __launch_bounds__(256) void gemm_x3_dma_kernel(const float* __restric
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int h = 0; h < 2; ++h)
-                a_off[i][ks][h] = (wm * (BM / 2) + i * 32 + fr) * 128 + (((4 * ks + 2 * fh + h) ^ ga) << 4);
+                a_off[i][ks][h] = (wm * (BM / WM) + i * 32 + fr) * 128 + (((4 * ks + 2 * fh + h) ^ ga) << 4);
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -1063,7 +1063,7 @@ __global__ __launch_bounds__(256) void gemm_x3_dma_kernel(const float* __restric
             for (int j = 0; j < 2; ++j) {
                 const int col = n0 + wn * 64 + j * 32 + fr;
                 const float bv = bias[col];
-                const int row0 = m0 + wm * (BM / 2) + i * 32 + 4 * fh;
+                const int row0 = m0 + wm * (BM / WM) + i * 32 + 4 * fh;
                 float res[16];
                 if (EPI == EPI_BIAS_RESIDUAL) {
 #pragma unroll
@@ -1088,7 +1088,7 @@ __global__ __launch_bounds__(256) void gemm_x3_dma_kernel(const float* __restric
             const float bv = bias[col];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                const int row = m0 + wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
                 if (row < T) {
                     float v = acc[i][j][r] * inv_wscale + bv;  // exact: the weight scale is a power of two
                     if (EPI == EPI_BIAS_GELU) v = 0.5f * v * (1.0f + x3_erf(v * 0.70710678118654752440f));
@@ -1744,6 +1744,27 @@ int launch_gemm_x3(const float* A, const _Float16* Wp, float inv_wscale, const f
         }
     }
     dim3 grid((N + 127) / 128, (unsigned)((Tmax + 63) / 64));
+    // Many row bands (S = 512: T = 131072): 128 x 128 tiles on EIGHT waves (wave tile 32 x 64 as in the default, one
+    // workgroup per CU) read W a third less often: 32.2 vs 33.1 ms per forward; at T = 8192 (2.25 rounds of tiles) the
+    // 64-row tiles win, 2.09 vs 2.15 ms and 1.74 vs 1.96 ragged.  MVDB_GEMM_X3_W8 = 0 / 1 forces either.
+    static const int w8env = []() { const char* v = getenv("MVDB_GEMM_X3_W8"); return v ? atoi(v) : -1; }();
+    const bool w8 = w8env >= 0 ? w8env == 1 : (int64_t)((N + 127) / 128) * ((Tmax + 127) / 128) >= (int64_t)8 * device_cus(device);
+    if (w8 && dbg == 0) {
+        auto kern8 = gemm_x3_dma_kernel<EPI, 128, 3, 0, 8>;
+        constexpr int lds8 = 3 * (128 * 128 + 128 * 128);
+        static std::mutex mu8;
+        static std::map<int, bool> done8;
+        {
+            std::lock_guard<std::mutex> lk(mu8);
+            if (!done8[device]) {
+                MVDB_HIP(hipFuncSetAttribute((const void*)kern8, hipFuncAttributeMaxDynamicSharedMemorySize, lds8));
+                done8[device] = true;
+            }
+        }
+        dim3 grid8((N + 127) / 128, (unsigned)((Tmax + 127) / 128));
+        hipLaunchKernelGGL(kern8, grid8, dim3(512), lds8, s, A, Wp, inv_wscale, bias, R, C, Tptr, N, K);
+        return 0;
+    }
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, A, Wp, inv_wscale, bias, R, C, Tptr, N, K);
     return 0;
 }
