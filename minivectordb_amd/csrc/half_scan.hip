@@ -465,16 +465,19 @@ __global__ __launch_bounds__(256) void flat_scan_half_kernel(HalfScanArgs a) {
 //   LDS traffic per corpus byte: 1 (DMA) + 1 (raw read) + 0.5 (fp16 write) + 4 x 0.5 (fragment reads) = 4.5 B against the
 //   8 B of the K-split kernel at 256 queries; no partial sums, no exchange additions.
 // The seed launch of a pass is the K-split kernel's (<KQ, 2, NG, ., true>): it only has to produce floors.
-// Measured (10M rows, k = 10): 40.8k / 60.3k q/s at 128 / 256 queries per pass at d = 512 (K split: 39.4k / 53.1k), 51.9k /
-// 79.3k at d = 384 (48.9k / 63.1k), 73.6k / 106.5k at d = 256 (66.1k / 80.9k).  PMC at 256 queries, d = 512: shader clock
+// Measured (10M rows, k = 10): 40.7k / 66.0k q/s at 128 / 256 queries per pass at d = 512 (K split: 39.4k / 53.1k), 52.4k /
+// 84.7k at d = 384 (48.9k / 63.1k), 73.6k / 107.9k at d = 256 (66.1k / 80.9k); 256 queries = eight waves of 32 queries.  PMC at 256 queries, d = 512: shader clock
 // 1.76 GHz (the chip's power limit: matrix cores 35 % busy beside 6 TB/s of HBM traffic), 5,640 cycles per tile, waves
 // active 43 %, parked on barriers / vmcnt 27 %, issue-stalled 29 %, no LDS bank conflicts.
-template <int KT, bool PAD, int G>
-__global__ __launch_bounds__(256) void flat_scan_hq_kernel(HalfScanArgs a) {
+// WV = waves per workgroup: 4 (one per SIMD), or 8 (two per SIMD, half the rows and half the queries each: the second
+// wave issues MFMAs while the first sits at the stage barrier; 8 x 16 fragment reads per stage instead of 4 x 16)
+template <int KT, bool PAD, int G, int WV = 4>
+__global__ __launch_bounds__(WV * 64) void flat_scan_hq_kernel(HalfScanArgs a) {
     constexpr int KH = KT / 2;               // 16-k blocks per stage (one K-half)
     constexpr int RAWP = KH * 64;            // raw row pitch in bytes (KH x 16 floats)
     constexpr int kRaw = 32 * RAWP;          // raw stage: 32 KiB at d = 512
-    constexpr int kRawW = 8 * RAWP;          // a wave's 8 rows of it
+    constexpr int RW = 32 / WV;              // rows a wave DMAs and converts
+    constexpr int kRawW = RW * RAWP;         // a wave's rows of the stage
     constexpr int DPW = kRawW / 1024;        // DMA instructions per wave and stage
     constexpr int SPR = RAWP / 16;           // 16-byte slots per raw row
     constexpr int HSL = KH * 2;              // 16-byte slots (8 fp16) per fp16 row
@@ -483,7 +486,7 @@ __global__ __launch_bounds__(256) void flat_scan_hq_kernel(HalfScanArgs a) {
     constexpr int K = KT * 16;
     static_assert(kRawW % 1024 == 0 && KT % 2 == 0, "shape");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // 3 raw stages | 2 fp16 images
-    __shared__ uint64_t lists[4 * G * 32 * kHalfKeep];                      // [wave][G groups][32 queries][16] keys
+    __shared__ uint64_t lists[WV * G * 32 * kHalfKeep];                     // [wave][G groups][32 queries][16] keys
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int fr = lane & 31, fk = lane >> 5;
@@ -523,7 +526,7 @@ __global__ __launch_bounds__(256) void flat_scan_hq_kernel(HalfScanArgs a) {
 #pragma unroll
     for (int i = 0; i < DPW; ++i) {
         const int j = i * 64 + lane;
-        const int row = 8 * wave + j / SPR, cs = j % SPR;  // tile row, 16-byte slot (4 floats) of the K-half
+        const int row = RW * wave + j / SPR, cs = j % SPR;  // tile row, 16-byte slot (4 floats) of the K-half
         voff[i] = (uint32_t)(((int64_t)row * a.ld + 4 * cs) * 4);
         const int hs = cs >> 1;  // fp16 slot (8 elements): two raw slots each
         hdst[i] = row * HP + ((PAD ? hs : (hs ^ (row & 15))) << 4) + (cs & 1) * 8;
@@ -875,12 +878,12 @@ static int launch_half_inst(const HalfScanArgs& a, int device, hipStream_t strea
     return 0;
 }
 
-template <int KT, bool PAD, int G>
+template <int KT, bool PAD, int G, int WV = 4>
 static int launch_hq_inst(const HalfScanArgs& a, int device, hipStream_t stream, int* nblocks_out) {
-    auto kern = flat_scan_hq_kernel<KT, PAD, G>;
+    auto kern = flat_scan_hq_kernel<KT, PAD, G, WV>;
     constexpr int KH = KT / 2;
     constexpr size_t lds = (size_t)3 * 32 * KH * 64 + (size_t)2 * 32 * (PAD ? 2 * KH + 1 : 2 * KH) * 16;
-    static_assert(lds + 128 * G * kHalfKeep * 8 <= 160 * 1024, "LDS budget of a CU");
+    static_assert(lds + 32 * WV * G * kHalfKeep * 8 <= 160 * 1024, "LDS budget of a CU");
     {
         static std::mutex mu;
         static std::map<int, bool> done;
@@ -894,7 +897,7 @@ static int launch_hq_inst(const HalfScanArgs& a, int device, hipStream_t stream,
     const int nblocks = (int)std::max<int64_t>(1, std::min<int64_t>(ntiles, (int64_t)device_cus(device)));
     *nblocks_out = nblocks;
     int slot = prof_begin("ip_scan_half", stream);
-    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(256), lds, stream, a);
+    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(WV * 64), lds, stream, a);
     prof_end(slot, stream);
     MVDB_HIP(hipGetLastError());
     return 0;
@@ -918,7 +921,10 @@ static int launch_half_kq(int nqpad, bool seed, const HalfScanArgs& a, int devic
         if (nqpad == 256) {
             if (seed) return launch_half_inst<KQ, 2, 8, 5, true>(a, device, stream, nb);
             if (getenv("MVDB_HALF_KSPLIT")) return launch_half_inst<KQ, 2, 8, 5, false>(a, device, stream, nb);  // A/B: the K-split form
-            return launch_hq_inst<KQ * 4, (KQ & (KQ - 1)) != 0, 2>(a, device, stream, nb);
+            // eight waves of 32 queries (two per SIMD) rather than four of 64: 66.0k vs 61.5k q/s at d = 512, 84.7k vs 79.3k
+            // at 384, 107.9k vs 103.7k at 256; MVDB_HQ_W4=1 keeps the four-wave form for A/B runs
+            if (getenv("MVDB_HQ_W4")) return launch_hq_inst<KQ * 4, (KQ & (KQ - 1)) != 0, 2>(a, device, stream, nb);
+            return launch_hq_inst<KQ * 4, (KQ & (KQ - 1)) != 0, 1, 8>(a, device, stream, nb);
         }
     }
     return fail(MVDB_ERR_ARG, "no fp16 nomination kernel for %d queries per pass at d = %d", nqpad, KQ * 64);
