@@ -1744,12 +1744,31 @@ int launch_gemm_x3(const float* A, const _Float16* Wp, float inv_wscale, const f
         }
     }
     dim3 grid((N + 127) / 128, (unsigned)((Tmax + 63) / 64));
-    // Many row bands (S = 512: T = 131072): 128 x 128 tiles on EIGHT waves (wave tile 32 x 64 as in the default, one
-    // workgroup per CU) read W a third less often: 32.2 vs 33.1 ms per forward; at T = 8192 (2.25 rounds of tiles) the
-    // 64-row tiles win, 2.09 vs 2.15 ms and 1.74 vs 1.96 ragged.  MVDB_GEMM_X3_W8 = 0 / 1 forces either.
-    static const int w8env = []() { const char* v = getenv("MVDB_GEMM_X3_W8"); return v ? atoi(v) : -1; }();
-    const bool w8 = w8env >= 0 ? w8env == 1 : (int64_t)((N + 127) / 128) * ((Tmax + 127) / 128) >= (int64_t)8 * device_cus(device);
-    if (w8 && dbg == 0) {
+    // Many row bands (S = 512: T = 131072, >= 8 rounds of 128 x 128 tiles): 128 x 128 tiles on FOUR waves — wave tile 64 x 64,
+    // 8 fragment reads per 12 MFMAs where the 32 x 64 wave tile of the default needs 12 (its LDS port and its matrix cores
+    // are co-limited) —, two stages (64 KiB), two workgroups per CU: 29.3 ms per forward vs 33.1 with the default tiles and
+    // 32.2 with 128 x 128 tiles on eight waves of 32 x 64 (MVDB_GEMM_X3_W8=1).  At T = 8192 the 576 / 768 / 192 tiles of a GEMM
+    // are 1.1 / 1.5 / 0.4 rounds: 2.07 vs 2.02 ms on a full batch, 2.23 vs 1.70 on a ragged one — the 64-row tiles stay.
+    static const int big4env = []() { const char* v = getenv("MVDB_GEMM_X3_BM128W4"); return v ? atoi(v) : -1; }();
+    static const bool w8 = []() { const char* v = getenv("MVDB_GEMM_X3_W8"); return v && *v == '1'; }();
+    const bool many = (int64_t)((N + 127) / 128) * ((Tmax + 127) / 128) >= (int64_t)8 * device_cus(device);
+    if (dbg == 0 && !w8 && (big4env >= 0 ? big4env == 1 : many)) {
+        auto kern4 = gemm_x3_dma_kernel<EPI, 128, 2, 0, 4>;
+        constexpr int lds4 = 2 * (128 * 128 + 128 * 128);
+        static std::mutex mu4;
+        static std::map<int, bool> done4;
+        {
+            std::lock_guard<std::mutex> lk(mu4);
+            if (!done4[device]) {
+                MVDB_HIP(hipFuncSetAttribute((const void*)kern4, hipFuncAttributeMaxDynamicSharedMemorySize, lds4));
+                done4[device] = true;
+            }
+        }
+        dim3 grid4((N + 127) / 128, (unsigned)((Tmax + 127) / 128));
+        hipLaunchKernelGGL(kern4, grid4, dim3(256), lds4, s, A, Wp, inv_wscale, bias, R, C, Tptr, N, K);
+        return 0;
+    }
+    if (dbg == 0 && w8) {
         auto kern8 = gemm_x3_dma_kernel<EPI, 128, 3, 0, 8>;
         constexpr int lds8 = 3 * (128 * 128 + 128 * 128);
         static std::mutex mu8;
