@@ -103,8 +103,8 @@ int mvdb_index_remove_rows(mvdb_index* idx, const int64_t* rows_host, int64_t m)
  * NOMINATED on the low-precision matrix cores (14..32 queries: bf16 (hi, lo) split-precision product,
  * 16 nominees; 33+ queries at d = 256 / 384 / 512 / 768: one fp16 product, 64 nominees, 128 or 256
  * queries per corpus pass), then re-scored in fp32 and certified per query against the nomination's
- * worst-case error bound; a chunk that cannot be certified is re-run on the exact fp32 kernels
- * (mvdb_split_rerun_count counts those).
+ * worst-case error bound; queries that cannot be certified are re-run on the exact fp32 kernels
+ * (mvdb_split_rerun_count counts the chunks that held one).
  * Replaces faiss.normalize_L2(embedding) + index.search(embedding, search_k)
  *                                                minivectordb/vector_database.py:475, :497
  *                                                minivectordb/sharded_vector_database.py:604, :626 */
@@ -191,9 +191,9 @@ int mvdb_synth_fill_device(float* out_dev, int64_t n, int d, uint64_t seed, int6
 int mvdb_prof_enable(int on);
 int mvdb_prof_read(const char* name, int64_t* launches, double* total_ms);
 
-/* Number of 128-query chunks of the split-precision batch pass (bf16 matrix cores, results certified
- * against exact fp32 re-scores) that failed certification and were re-run on the exact fp32 kernels
- * since the library was loaded.  Diagnostic only. */
+/* Number of chunks (up to 256 queries) of the certified batch passes that held a query which failed certification — those
+ * queries, or past MVDB_SPLIT_REQUERY_MAX of them the whole chunks, were re-run on the exact fp32 kernels — since the
+ * library was loaded.  Diagnostic only. */
 int64_t mvdb_split_rerun_count(void);
 
 /* The certificate's error bound per unit |q| * max|x| at dimension d: operand truncation of the bf16 split,
