@@ -1336,19 +1336,22 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const float* __rest
 // =================================================================================================
 constexpr int AX_KT = 64;  // keys per LDS tile
 
-template <int HD>
-__global__ __launch_bounds__(256) void attention_x3_kernel(const float* __restrict__ qkv,
+// WV = waves per workgroup (32 queries each): 4, or 1 for short sequences (S <= 32: one workgroup per (sentence, head) with
+// no idle waves and a 32-key tile, twice as many resident)
+template <int HD, int WV = 4>
+__global__ __launch_bounds__(WV * 64) void attention_x3_kernel(const float* __restrict__ qkv,
                                                            const int* __restrict__ seq_start, int H, float scale,
                                                            float* __restrict__ ctx) {
     constexpr int DT = HD / 32, KB = HD / 16;
     constexpr int KP = HD * 2 + 16;     // K plane row pitch (bytes)
-    constexpr int VP = AX_KT * 2 + 8;   // V^T plane row pitch (bytes)
+    constexpr int VP = (WV == 1 ? 32 : AX_KT) * 2 + 8;   // V^T plane row pitch (bytes)
     const int b = blockIdx.z, h = blockIdx.y;
     const int s0 = seq_start[b], len = seq_start[b + 1] - s0;
-    const int q0 = blockIdx.x * 128;
+    constexpr int KT = WV == 1 ? 32 : AX_KT;  // keys per LDS tile
+    const int q0 = blockIdx.x * (32 * WV);
     if (q0 >= len) return;
-    __shared__ __attribute__((aligned(16))) unsigned char Kh[AX_KT * KP];
-    __shared__ __attribute__((aligned(16))) unsigned char Kl[AX_KT * KP];
+    __shared__ __attribute__((aligned(16))) unsigned char Kh[(WV == 1 ? 32 : AX_KT) * KP];
+    __shared__ __attribute__((aligned(16))) unsigned char Kl[(WV == 1 ? 32 : AX_KT) * KP];
     __shared__ __attribute__((aligned(16))) unsigned char Vh[HD * VP];
     __shared__ __attribute__((aligned(16))) unsigned char Vl[HD * VP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1385,11 +1388,11 @@ __global__ __launch_bounds__(256) void attention_x3_kernel(const float* __restri
     float m = -INFINITY, l = 0.f;
     const bool wave_active = q0 + wave * 32 < len;  // wave-uniform
 
-    for (int kt = 0; kt < len; kt += AX_KT) {
-        const int nk = min(AX_KT, len - kt);
+    for (int kt = 0; kt < len; kt += KT) {
+        const int nk = min(KT, len - kt);
         __syncthreads();
         // cooperative tile load + split: thread -> (key, 4 consecutive d)
-        for (int e = tid; e < AX_KT * (HD / 4); e += 256) {
+        for (int e = tid; e < KT * (HD / 4); e += WV * 64) {
             const int key = e / (HD / 4), c = (e % (HD / 4)) * 4;
             f32x4 kv = {0, 0, 0, 0}, vv = {0, 0, 0, 0};
             if (key < nk) {
@@ -1416,7 +1419,7 @@ __global__ __launch_bounds__(256) void attention_x3_kernel(const float* __restri
         __syncthreads();
         if (!wave_active) continue;
 #pragma unroll
-        for (int kb32 = 0; kb32 < AX_KT / 32; ++kb32) {
+        for (int kb32 = 0; kb32 < KT / 32; ++kb32) {
             if (kb32 * 32 >= nk) break;
             // ---- S^T block: 32 keys x 32 queries ----------------------------------------------------
             f32x16 st;
@@ -1884,6 +1887,10 @@ int enqueue_lane(mvdb_encoder* e, mvdb_encoder::Lane& w, const int32_t* ids, con
         const char* v = getenv("MVDB_ATTENTION_X3");
         return !(v && *v == '0');
     }();
+    static const bool x3_short = []() {
+        const char* v = getenv("MVDB_ATTENTION_X3_SHORT");
+        return !(v && *v == '0');
+    }();
     const dim3 agrid((S + ATT_Q - 1) / ATT_Q, c.heads, B);
     for (const LayerW& L : e->layers) {
         if (compute == 2)
@@ -1900,7 +1907,13 @@ int enqueue_lane(mvdb_encoder* e, mvdb_encoder::Lane& w, const int32_t* ids, con
                 hipLaunchKernelGGL(attention_kernel<64>, agrid, dim3(ATT_Q), 0, s, w.qkv, w.seq_start, H, scale,
                                    w.ctx);
         } else if (compute == 2 && x3_attention) {
-            if (hd == 32)
+            if (S <= 32 && x3_short) {  // one wave per (sentence, head)
+                const dim3 sgrid(1, c.heads, B);
+                if (hd == 32)
+                    hipLaunchKernelGGL((attention_x3_kernel<32, 1>), sgrid, dim3(64), 0, s, w.qkv, w.seq_start, H, scale, w.ctx);
+                else
+                    hipLaunchKernelGGL((attention_x3_kernel<64, 1>), sgrid, dim3(64), 0, s, w.qkv, w.seq_start, H, scale, w.ctx);
+            } else if (hd == 32)
                 hipLaunchKernelGGL(attention_x3_kernel<32>, agrid, dim3(256), 0, s, w.qkv, w.seq_start, H, scale, w.ctx);
             else
                 hipLaunchKernelGGL(attention_x3_kernel<64>, agrid, dim3(256), 0, s, w.qkv, w.seq_start, H, scale, w.ctx);
