@@ -215,7 +215,17 @@ __global__ __launch_bounds__(256) void pool_norm_kernel(const float* __restrict_
     float sq = 0.f;
     for (int c = threadIdx.x; c < H; c += blockDim.x) {
         float s = 0.f;
-        for (int t = 0; t < span; ++t) s += x[(int64_t)(s0 + t) * H + c];
+        int t = 0;
+        // eight loads in flight, added in token order (the same sum as a plain loop, which hipcc compiles to one
+        // dependent load -> add per token: 32 serialised round trips at S = 32)
+        for (; t + 8 <= span; t += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = x[(int64_t)(s0 + t + u) * H + c];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; t < span; ++t) s += x[(int64_t)(s0 + t) * H + c];
         const float e = s / (float)span;  // empty sequence -> NaN, as the reference's 0/0
         out[(int64_t)b * H + c] = e;
         sq += e * e;
