@@ -240,3 +240,15 @@ def test_half_eps_covers_emulated_nomination(d, mode, flush):
         assert np.all(e_nom + e_re <= eps), (name, mode, flush, float((e_nom + e_re).max()), eps)
         worst = max(worst, float((e_nom + e_re).max()))
     assert 0 < worst < eps
+
+
+def test_half_pass_widths_by_dimension():
+    """Host-only query of the pass table: 256 queries per corpus pass where the query-split kernel
+    exists, 128 where only the K-split kernel does, 0 where the bf16-split kernels still serve."""
+    from minivectordb_amd import _native
+    for d in (256, 384, 512):
+        assert _native.half_max_queries(d) == 256
+    for d in (768, 1024):
+        assert _native.half_max_queries(d) == 128
+    for d in (32, 64, 100, 128, 640, 2048):
+        assert _native.half_max_queries(d) == 0
