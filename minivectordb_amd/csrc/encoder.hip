@@ -108,13 +108,32 @@ __global__ __launch_bounds__(256) void pack_fill_kernel(const int32_t* __restric
     }
 }
 
+// One element per lane of a 32-column group -> the group's (hi | lo) line: `line` = the 128 bytes that hold columns
+// c0 .. c0 + 31 of a row in the [row][K / 32][hi 32 | lo 32] image (as a float pointer: the fp32 position of (row, c0) —
+// the image has the bytes of the fp32 matrix), c = the lane's column in the group.  Lanes c and c ^ 1 trade halves so that
+// every lane stores ONE dword: even lanes the hi pieces of columns (c, c + 1), odd lanes the lo pieces of (c - 1, c).
+// Both lanes of a pair must call it (`ok` = store or not, the same for both).
+__device__ __forceinline__ void x3_pair_store(float* line, int c, float v, bool ok) {
+    const _Float16 h = (_Float16)v;
+    const _Float16 l = (_Float16)(v - (float)h);
+    union { _Float16 f[2]; uint32_t u; } mine;
+    mine.f[0] = h;
+    mine.f[1] = l;
+    const uint32_t other = (uint32_t)__builtin_amdgcn_mov_dpp((int)mine.u, 0xB1, 0xF, 0xF, true);  // quad_perm [1, 0, 3, 2]
+    const bool odd = c & 1;
+    const uint32_t word = odd ? (other >> 16) | (mine.u & 0xffff0000u) : (mine.u & 0xffffu) | (other << 16);
+    if (ok) reinterpret_cast<uint32_t*>(line)[odd ? 16 + (c >> 1) : (c >> 1)] = word;
+}
+
 // =================================================================================================
 // row kernels: one wave per token row, VPT = ceil(H/64) values per lane in registers
 // =================================================================================================
 template <int VPT, bool FULL = false>
 __device__ __forceinline__ void wave_layernorm(float (&v)[VPT], int H, int lane, float eps,
                                                const float* __restrict__ gamma,
-                                               const float* __restrict__ beta, float* __restrict__ out) {
+                                               const float* __restrict__ beta, float* __restrict__ out,
+                                               float* __restrict__ outp) {
+    // outp: NULL, or the row in the (hi | lo) fp16 image that feeds the split-precision GEMMs (needs H % 32 == 0)
     // gamma / beta are fetched BEFORE the reductions (their latency hides under the shuffles) and, when the row fills
     // every lane slot (H = 64 VPT: 384, 1024), the tail is branch-free: with a bounds test per element hipcc emitted a
     // loop of load, s_waitcnt vmcnt(0), store — six serialised round trips per row
@@ -144,13 +163,19 @@ __device__ __forceinline__ void wave_layernorm(float (&v)[VPT], int H, int lane,
     const float rstd = 1.0f / sqrtf(q / (float)H + eps);  // biased variance, eps inside the sqrt
     if (full) {
 #pragma unroll
-        for (int i = 0; i < VPT; ++i) out[lane + i * 64] = (v[i] - mean) * rstd * g[i] + bt[i];
+        for (int i = 0; i < VPT; ++i) {
+            const float r = (v[i] - mean) * rstd * g[i] + bt[i];
+            out[lane + i * 64] = r;
+            if (outp) x3_pair_store(outp + i * 64 + (lane & 32), lane & 31, r, true);
+        }
         return;
     }
 #pragma unroll
     for (int i = 0; i < VPT; ++i) {
         const int c = lane + i * 64;
-        if (c < H) out[c] = (v[i] - mean) * rstd * g[i] + bt[i];
+        const float r = (v[i] - mean) * rstd * g[i] + bt[i];
+        if (c < H) out[c] = r;
+        if (outp) x3_pair_store(outp + (c < H ? (c & ~31) : 0), lane & 31, r, c < H);
     }
 }
 
@@ -164,7 +189,7 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const int* __restrict__ t
                                                        const float* __restrict__ type,
                                                        const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, float eps, int H,
-                                                       float* __restrict__ x) {
+                                                       float* __restrict__ x, float* __restrict__ xp) {
     const int T = seq_start[B];
     const int lane = threadIdx.x & 63;
     const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -177,7 +202,7 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const int* __restrict__ t
         const int c = lane + i * 64;
         v[i] = c < H ? (w[c] + type[c]) + ps[c] : 0.f;  // HF: inputs_embeds + token_type, then + position
     }
-    wave_layernorm<VPT>(v, H, lane, eps, gamma, beta, x + (int64_t)p * H);
+    wave_layernorm<VPT>(v, H, lane, eps, gamma, beta, x + (int64_t)p * H, xp ? xp + (int64_t)p * H : nullptr);
 }
 
 // x[p,:] = LN(y[p,:])   (y already holds dense(...) + bias + residual from the GEMM epilogue)
@@ -186,7 +211,7 @@ __global__ __launch_bounds__(256) void ln_kernel(const float* __restrict__ y,
                                                  const int* __restrict__ seq_start, int B,
                                                  const float* __restrict__ gamma,
                                                  const float* __restrict__ beta, float eps, int H,
-                                                 float* __restrict__ x) {
+                                                 float* __restrict__ x, float* __restrict__ xp) {
     const int T = seq_start[B];
     const int lane = threadIdx.x & 63;
     const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -200,7 +225,7 @@ __global__ __launch_bounds__(256) void ln_kernel(const float* __restrict__ y,
         else
             v[i] = c < H ? y[(int64_t)p * H + c] : 0.f;
     }
-    wave_layernorm<VPT, FULL>(v, H, lane, eps, gamma, beta, x + (int64_t)p * H);
+    wave_layernorm<VPT, FULL>(v, H, lane, eps, gamma, beta, x + (int64_t)p * H, xp ? xp + (int64_t)p * H : nullptr);
 }
 
 // out[b,:] = normalize(mean over the sequence's tokens)   — average_pool + F.normalize(eps=1e-12)
@@ -908,19 +933,21 @@ __device__ __forceinline__ void x3_split2(float a, float b, uint32_t& hi, uint32
     lo = l.u;
 }
 
-// Block tile 64 x 128 x 32, four waves 2 x 2.  fp32 A rows and the (hi | lo) lines of W go global -> LDS by
-// global_load_lds into a three-stage ring (two K-steps in flight, ONE bare s_barrier per K-step, as
-// gemm_f32_dma_kernel); A fragments are split into (hi, lo) in registers on their way from LDS to the MFMA (6 VALU per
-// pair, in the MFMAs' shadow).  (A register-staged form with one K-step of prefetch ran 15 % slower and was removed.)
-//   stage = [A: BM rows x 128 B (32 fp32 k)] [W: 128 rows x 128 B (32 k of the hi plane | 32 k of the lo plane)]
-//   W comes from an INTERLEAVED copy of the two planes ([row][K / 32][hi 32 | lo 32], f32_split_interleave_kernel): one
-//   full 128-byte line per row and K-step — with separate planes every request used half a line and the L2 moved
-//   twice the W bytes (PMC: 4.9M line requests per QKV GEMM at T = 8192, 88 % L2 hits, waves parked 49 % of the time)
+// Block tile 64 x 128 x 32, four waves 2 x 2.  BOTH operands arrive as (hi | lo) fp16 lines — A from the kernel that
+// produced the activations (LayerNorm, attention, the GELU epilogue below: x3_pair_store), W from the one-time split of
+// the weights — and go global -> LDS by global_load_lds into a three-stage ring (two K-steps in flight, ONE bare
+// s_barrier per K-step, as gemm_f32_dma_kernel); the MFMA fragments are read from LDS as they stand: no VALU work in
+// the K loop.  (First version: fp32 A rows, split in registers between LDS and the MFMA by every one of the N / 128
+// workgroups that read them — 45 VALU per 12 MFMAs, 3 x the MFMA time in the compute-only ablation.)
+//   stage = [A: BM rows x 128 B] [W: 128 rows x 128 B], a row's 128 bytes = 32 k of the hi plane | 32 k of the lo plane
+//   ([row][K / 32][hi 32 | lo 32]: one full 128-byte line per row and K-step — with separate planes every request used
+//   half a line and the L2 moved twice the W bytes: 4.9M line requests per QKV GEMM at T = 8192)
 //   bank swizzle on the DMA source: slot p of row r holds the row's logical slot p ^ ((r >> 1) & 7)
-// DBG != 0: timing ablations (MVDB_GEMM_X3_DBG; results invalid): 1 = no fragment reads / splits / MFMAs (the DMA ring,
+// EPI_BIAS_GELU writes its output as (hi | lo) lines too (it only feeds the next GEMM); the other epilogues write fp32.
+// DBG != 0: timing ablations (MVDB_GEMM_X3_DBG; results invalid): 1 = no fragment reads / MFMAs (the DMA ring,
 // barriers and epilogue alone), 2 = no DMA (compute on whatever the LDS holds)
 template <int EPI, int BM, int NST, int DBG = 0, int WAVES = 4>
-__global__ __launch_bounds__(WAVES * 64) void gemm_x3_dma_kernel(const float* __restrict__ A, const _Float16* __restrict__ Wp,
+__global__ __launch_bounds__(WAVES * 64) void gemm_x3_dma_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ Wp,
                                                           float inv_wscale, const float* __restrict__ bias,
                                                           const float* __restrict__ R, float* __restrict__ C,
                                                           const int* __restrict__ Tptr, int N, int K) {
@@ -982,8 +1009,8 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_x3_dma_kernel(const float* __
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-            for (int h = 0; h < 2; ++h)
-                a_off[i][ks][h] = (wm * (BM / WM) + i * 32 + fr) * 128 + (((4 * ks + 2 * fh + h) ^ ga) << 4);
+            for (int pl = 0; pl < 2; ++pl)
+                a_off[i][ks][pl] = (wm * (BM / WM) + i * 32 + fr) * 128 + (((4 * pl + 2 * ks + fh) ^ ga) << 4);
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -1024,11 +1051,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_x3_dma_kernel(const float* __
         }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            union Op {
-                x3_h8 v;
-                uint32_t w[4];
-            } ah[TM], al[TM];
-            x3_h8 bh[2], bl[2];
+            x3_h8 ah[TM], al[TM], bh[2], bl[2];
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 bh[j] = *reinterpret_cast<const x3_h8*>(sb + b_off[j][ks][0]);
@@ -1036,27 +1059,22 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_x3_dma_kernel(const float* __
             }
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                const f32x4 x0 = *reinterpret_cast<const f32x4*>(sb + a_off[i][ks][0]);
-                const f32x4 x1 = *reinterpret_cast<const f32x4*>(sb + a_off[i][ks][1]);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float p0 = e < 2 ? x0[2 * e] : x1[2 * (e - 2)], p1 = e < 2 ? x0[2 * e + 1] : x1[2 * (e - 2) + 1];
-                    x3_split2(p0, p1, ah[i].w[e], al[i].w[e]);
-                }
+                ah[i] = *reinterpret_cast<const x3_h8*>(sb + a_off[i][ks][0]);
+                al[i] = *reinterpret_cast<const x3_h8*>(sb + a_off[i][ks][1]);
             }
             // small cross terms first, the leading product last
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i].v, bh[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i].v, bl[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i].v, bh[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
         }
         st = st == NST - 1 ? 0 : st + 1;
     }
@@ -1084,7 +1102,10 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_x3_dma_kernel(const float* __
                     float v = acc[i][j][r] * inv_wscale + bv;  // exact: the weight scale is a power of two
                     if (EPI == EPI_BIAS_GELU) v = 0.5f * v * (1.0f + x3_erf(v * 0.70710678118654752440f));
                     if (EPI == EPI_BIAS_RESIDUAL) v += res[r];
-                    C[(int64_t)(row0 + (r & 3) + 8 * (r >> 2)) * N + col] = v;
+                    if (EPI == EPI_BIAS_GELU)
+                        x3_pair_store(C + (int64_t)(row0 + (r & 3) + 8 * (r >> 2)) * N + (col & ~31), fr, v, true);
+                    else
+                        C[(int64_t)(row0 + (r & 3) + 8 * (r >> 2)) * N + col] = v;
                 }
             }
         return;
@@ -1094,14 +1115,16 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_x3_dma_kernel(const float* __
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int col = n0 + wn * 64 + j * 32 + fr;
-            if (col >= N) continue;
+            if (col >= N) continue;  // N % 32 == 0: whole 32-column groups (lane pairs stay together)
             const float bv = bias[col];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-                if (row < T) {
-                    float v = acc[i][j][r] * inv_wscale + bv;  // exact: the weight scale is a power of two
-                    if (EPI == EPI_BIAS_GELU) v = 0.5f * v * (1.0f + x3_erf(v * 0.70710678118654752440f));
+                float v = acc[i][j][r] * inv_wscale + bv;  // exact: the weight scale is a power of two
+                if (EPI == EPI_BIAS_GELU) {
+                    v = 0.5f * v * (1.0f + x3_erf(v * 0.70710678118654752440f));
+                    x3_pair_store(C + (int64_t)(row < T ? row : 0) * N + (col & ~31), fr, v, row < T);  // row: uniform per lane half
+                } else if (row < T) {
                     if (EPI == EPI_BIAS_RESIDUAL) v += R[(int64_t)row * N + col];
                     C[(int64_t)row * N + col] = v;
                 }
@@ -1498,14 +1521,22 @@ __global__ __launch_bounds__(WV * 64) void attention_x3_kernel(const float* __re
     // O^T tile t: col = query fr (lane), row d = t*32 + (r&3) + 8(r>>2) + 4fh
     if (qvalid) {
         const float inv = 1.0f / l;
-        float* op = ctx + (int64_t)(s0 + qrow) * H + h * HD;
+        // the context only feeds the output projection: written as the (hi | lo) fp16 lines gemm_x3_dma_kernel reads
+        // (h HD + 32 t is a multiple of 32: 32-column group t of the head = one 128-byte line of the image)
+        unsigned char* op = reinterpret_cast<unsigned char*>(ctx + (int64_t)(s0 + qrow) * H + h * HD);
 #pragma unroll
         for (int t = 0; t < DT; ++t)
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4) {
-                f32x4 v = {o[t][4 * r4] * inv, o[t][4 * r4 + 1] * inv, o[t][4 * r4 + 2] * inv,
-                           o[t][4 * r4 + 3] * inv};
-                *reinterpret_cast<f32x4*>(op + t * 32 + 8 * r4 + 4 * fh) = v;  // d = 8*r4 + 4fh + 0..3
+                uint32_t h0, l0, h1, l1;  // d = 8 r4 + 4 fh + 0 .. 3
+                x3_split2(o[t][4 * r4] * inv, o[t][4 * r4 + 1] * inv, h0, l0);
+                x3_split2(o[t][4 * r4 + 2] * inv, o[t][4 * r4 + 3] * inv, h1, l1);
+                // the two lane halves trade pieces: fh = 0 stores the hi pieces of d = 8 r4 .. 8 r4 + 7, fh = 1 the lo
+                // pieces — one 16-byte store per lane (two 8-byte stores each cost 2.4 us per layer at T = 8192)
+                const uint32_t g0 = (uint32_t)__shfl_xor((int)(fh ? h0 : l0), 32);
+                const uint32_t g1 = (uint32_t)__shfl_xor((int)(fh ? h1 : l1), 32);
+                const uint4 w = fh ? uint4{g0, g1, l0, l1} : uint4{h0, h1, g0, g1};
+                *reinterpret_cast<uint4*>(op + t * 128 + fh * 64 + 16 * r4) = w;
             }
     }
 }
@@ -1560,12 +1591,13 @@ struct mvdb_encoder {
         int *rank = nullptr, *count = nullptr, *seq_start = nullptr, *tok_id = nullptr, *tok_pos = nullptr,
             *tok_src = nullptr;
         float *x = nullptr, *y = nullptr, *qkv = nullptr, *ctx = nullptr, *ffn = nullptr;
+        float* xp = nullptr;  // compute = 2: the (hi | lo) fp16 image of x (same bytes as x)
         void release() {
-            void* ptrs[] = {rank, count, seq_start, tok_id, tok_pos, tok_src, x, y, qkv, ctx, ffn};
+            void* ptrs[] = {rank, count, seq_start, tok_id, tok_pos, tok_src, x, y, qkv, ctx, ffn, xp};
             for (void* p : ptrs)
                 if (p) (void)hipFree(p);
             rank = count = seq_start = tok_id = tok_pos = tok_src = nullptr;
-            x = y = qkv = ctx = ffn = nullptr;
+            x = y = qkv = ctx = ffn = xp = nullptr;
         }
     } lane[2];
     hipStream_t stream2 = nullptr;             // second half of a split batch
@@ -1629,7 +1661,8 @@ int alloc_lane(mvdb_encoder* e, mvdb_encoder::Lane& w, int64_t B, int64_t tokens
     MVDB_TRY(dev_alloc(&w.y, tokens * H));
     MVDB_TRY(dev_alloc(&w.qkv, tokens * 3 * H));
     MVDB_TRY(dev_alloc(&w.ctx, tokens * H));
-    MVDB_TRY(dev_alloc(&w.ffn, tokens * F));
+    MVDB_TRY(dev_alloc(&w.ffn, tokens * std::max(F, H)));
+    MVDB_TRY(dev_alloc(&w.xp, tokens * H));
     return 0;
 }
 
@@ -1740,8 +1773,9 @@ int ensure_bf16_weights(mvdb_encoder* e, hipStream_t s) {
 // (B = 256: S = 32 2.68 ms vs 3.04 with 128-row tiles for the wide GEMMs, 3.15 register-staged; S = 512 43.8 ms vs
 // 55.7 / 45.3; rings of 2, 4 or 6 stages, i.e. 3 or 1 workgroups per CU: within 1 %)
 template <int EPI>
-int launch_gemm_x3(const float* A, const _Float16* Wp, float inv_wscale, const float* bias, const float* R, float* C,
+int launch_gemm_x3(const float* Aimg, const _Float16* Wp, float inv_wscale, const float* bias, const float* R, float* C,
                    const int* Tptr, int64_t Tmax, int N, int K, int device, hipStream_t s) {
+    const _Float16* A = reinterpret_cast<const _Float16*>(Aimg);  // [T][K / 32][hi 32 | lo 32]: the bytes of a [T][K] fp32 matrix
     static const int dbg = []() { const char* v = getenv("MVDB_GEMM_X3_DBG"); return v ? atoi(v) : 0; }();
     auto kern = dbg == 1 ? gemm_x3_dma_kernel<EPI, 64, 3, 1> : dbg == 2 ? gemm_x3_dma_kernel<EPI, 64, 3, 2> : gemm_x3_dma_kernel<EPI, 64, 3>;
     constexpr int lds = 3 * (64 * 128 + 128 * 128);
@@ -1847,13 +1881,13 @@ int ensure_x3_weights(mvdb_encoder* e, hipStream_t s) {
 
 template <int VPT>
 void launch_ln(const float* y, const int* seq_start, int B, const float* g, const float* b, float eps,
-               int H, float* x, int64_t Tmax, hipStream_t s) {
+               int H, float* x, float* xp, int64_t Tmax, hipStream_t s) {
     if (H == VPT * 64)  // branch-free rows (384, 1024, ...)
         hipLaunchKernelGGL((ln_kernel<VPT, true>), dim3((unsigned)((Tmax + 3) / 4)), dim3(256), 0, s, y, seq_start, B,
-                           g, b, eps, H, x);
+                           g, b, eps, H, x, xp);
     else
         hipLaunchKernelGGL((ln_kernel<VPT, false>), dim3((unsigned)((Tmax + 3) / 4)), dim3(256), 0, s, y, seq_start, B,
-                           g, b, eps, H, x);
+                           g, b, eps, H, x, xp);
 }
 
 // Enqueue every kernel of one forward on `s` (no allocation, no host sync: capturable in a hipGraph).
@@ -1870,6 +1904,9 @@ int enqueue_lane(mvdb_encoder* e, mvdb_encoder::Lane& w, const int32_t* ids, con
     hipLaunchKernelGGL(pack_fill_kernel, dim3(B), dim3(256), 0, s, ids, w.rank, w.seq_start, S,
                        c.position_offset, c.vocab_size, w.tok_id, w.tok_pos, w.tok_src);
     const dim3 rowgrid((unsigned)((Tmax + 3) / 4));
+    // compute = 2: every GEMM input is a (hi | lo) fp16 image written by its producer — x by the LayerNorms (beside the
+    // fp32 x the residuals and the pooling read), the context by the attention kernel, the GELU output by FFN1's epilogue
+    float* xp = compute == 2 ? w.xp : nullptr;
 #define MVDB_VPT_SWITCH(CALL)                                      \
     switch (vpt) {                                                 \
         case 1: CALL(1); break;  case 2: CALL(2); break;           \
@@ -1883,7 +1920,7 @@ int enqueue_lane(mvdb_encoder* e, mvdb_encoder::Lane& w, const int32_t* ids, con
     }
 #define EMBED_CALL(V)                                                                                  \
     hipLaunchKernelGGL(embed_ln_kernel<V>, rowgrid, dim3(256), 0, s, w.tok_id, w.tok_pos, w.seq_start, \
-                       B, e->word, e->pos, e->type, e->embg, e->embb, c.ln_eps, H, w.x)
+                       B, e->word, e->pos, e->type, e->embg, e->embb, c.ln_eps, H, w.x, xp)
     MVDB_VPT_SWITCH(EMBED_CALL)
 #undef EMBED_CALL
 
@@ -1902,9 +1939,10 @@ int enqueue_lane(mvdb_encoder* e, mvdb_encoder::Lane& w, const int32_t* ids, con
         return !(v && *v == '0');
     }();
     const dim3 agrid((S + ATT_Q - 1) / ATT_Q, c.heads, B);
+    const bool ctx_is_image = compute == 2 && x3_attention && !attn_valu;
     for (const LayerW& L : e->layers) {
         if (compute == 2)
-            MVDB_TRY(launch_gemm_x3<EPI_BIAS>(w.x, L.wqkv_p, L.wqkv_is, L.bqkv, nullptr, w.qkv, Tptr, Tmax, 3 * H, H, e->device, s));
+            MVDB_TRY(launch_gemm_x3<EPI_BIAS>(xp, L.wqkv_p, L.wqkv_is, L.bqkv, nullptr, w.qkv, Tptr, Tmax, 3 * H, H, e->device, s));
         else if (compute == 1)
             launch_gemm_h<EPI_BIAS>(w.x, L.wqkv_h, L.bqkv, nullptr, w.qkv, Tptr, Tmax, 3 * H, H, s);
         else
@@ -1934,17 +1972,25 @@ int enqueue_lane(mvdb_encoder* e, mvdb_encoder::Lane& w, const int32_t* ids, con
             hipLaunchKernelGGL(attention_mfma_kernel<64>, agrid, dim3(256), 0, s, w.qkv, w.seq_start, H, scale,
                                w.ctx);
         }
-        if (compute == 2)
-            MVDB_TRY(launch_gemm_x3<EPI_BIAS_RESIDUAL>(w.ctx, L.wo_p, L.wo_is, L.bo, w.x, w.y, Tptr, Tmax, H, H, e->device, s));
+        if (compute == 2) {
+            const float* ctx_img = w.ctx;
+            if (!ctx_is_image) {  // an fp32 attention kernel ran (A/B switches): split its output into the image form
+                const int64_t n = Tmax * H;
+                hipLaunchKernelGGL(f32_split_interleave_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w.ctx,
+                                   reinterpret_cast<_Float16*>(w.ffn), n, 1.0f);
+                ctx_img = w.ffn;
+            }
+            MVDB_TRY(launch_gemm_x3<EPI_BIAS_RESIDUAL>(ctx_img, L.wo_p, L.wo_is, L.bo, w.x, w.y, Tptr, Tmax, H, H, e->device, s));
+        }
         else if (compute == 1)
             launch_gemm_h<EPI_BIAS_RESIDUAL>(w.ctx, L.wo_h, L.bo, w.x, w.y, Tptr, Tmax, H, H, s);
         else
             launch_gemm<EPI_BIAS_RESIDUAL>(w.ctx, L.wo, L.bo, w.x, w.y, Tptr, Tmax, H, H, cus, s);
-#define LN1_CALL(V) launch_ln<V>(w.y, w.seq_start, B, L.ln1g, L.ln1b, c.ln_eps, H, w.x, Tmax, s)
+#define LN1_CALL(V) launch_ln<V>(w.y, w.seq_start, B, L.ln1g, L.ln1b, c.ln_eps, H, w.x, xp, Tmax, s)
         MVDB_VPT_SWITCH(LN1_CALL)
 #undef LN1_CALL
         if (compute == 2) {
-            MVDB_TRY(launch_gemm_x3<EPI_BIAS_GELU>(w.x, L.w1_p, L.w1_is, L.b1, nullptr, w.ffn, Tptr, Tmax, F, H, e->device, s));
+            MVDB_TRY(launch_gemm_x3<EPI_BIAS_GELU>(xp, L.w1_p, L.w1_is, L.b1, nullptr, w.ffn, Tptr, Tmax, F, H, e->device, s));
             MVDB_TRY(launch_gemm_x3<EPI_BIAS_RESIDUAL>(w.ffn, L.w2_p, L.w2_is, L.b2, w.x, w.y, Tptr, Tmax, H, F, e->device, s));
         } else if (compute == 1) {
             launch_gemm_h<EPI_BIAS_GELU>(w.x, L.w1_h, L.b1, nullptr, w.ffn, Tptr, Tmax, F, H, s);
@@ -1953,7 +1999,7 @@ int enqueue_lane(mvdb_encoder* e, mvdb_encoder::Lane& w, const int32_t* ids, con
             launch_gemm<EPI_BIAS_GELU>(w.x, L.w1, L.b1, nullptr, w.ffn, Tptr, Tmax, F, H, cus, s);
             launch_gemm<EPI_BIAS_RESIDUAL>(w.ffn, L.w2, L.b2, w.x, w.y, Tptr, Tmax, H, F, cus, s);
         }
-#define LN2_CALL(V) launch_ln<V>(w.y, w.seq_start, B, L.ln2g, L.ln2b, c.ln_eps, H, w.x, Tmax, s)
+#define LN2_CALL(V) launch_ln<V>(w.y, w.seq_start, B, L.ln2g, L.ln2b, c.ln_eps, H, w.x, xp, Tmax, s)
         MVDB_VPT_SWITCH(LN2_CALL)
 #undef LN2_CALL
     }
@@ -1993,7 +2039,7 @@ int enqueue_forward(mvdb_encoder* e, const int32_t* ids, const int32_t* mask, in
 int forward_core(mvdb_encoder* e, const int32_t* ids, const int32_t* mask, int B, int S, int compute,
                  float* out, float* hidden, hipStream_t s) {
     if (compute < 0 || compute > 2)
-        return fail(MVDB_ERR_ARG, "unknown compute mode %d (0 = exact-fp32 MFMA, 1 = bf16 MFMA operands, 2 = split-precision bf16 x 3)", compute);
+        return fail(MVDB_ERR_ARG, "unknown compute mode %d (0 = exact-fp32 MFMA, 1 = bf16 MFMA operands, 2 = split-precision fp16 x 3)", compute);
     const mvdb_encoder_cfg& c = e->cfg;
     if (B <= 0 || S <= 0) return fail(MVDB_ERR_ARG, "B and S must be positive");
     if (S + (c.position_offset > 0 ? c.position_offset : 0) > c.max_positions)
