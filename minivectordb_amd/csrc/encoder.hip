@@ -884,6 +884,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_mfma_kernel(const float* __rest
 typedef _Float16 x3_h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 x3_h2 __attribute__((ext_vector_type(2)));
 typedef float x3_f2 __attribute__((ext_vector_type(2)));
+typedef unsigned int x3_u2 __attribute__((ext_vector_type(2)));
 
 // max |in[i]| as the bits of a non-negative float (atomicMax on the integer image is order-preserving)
 __global__ void absmax_kernel(const float* __restrict__ in, int64_t n, unsigned int* __restrict__ out) {
@@ -1522,21 +1523,32 @@ __global__ __launch_bounds__(WV * 64) void attention_x3_kernel(const float* __re
     if (qvalid) {
         const float inv = 1.0f / l;
         // the context only feeds the output projection: written as the (hi | lo) fp16 lines gemm_x3_dma_kernel reads
-        // (h HD + 32 t is a multiple of 32: 32-column group t of the head = one 128-byte line of the image)
+        // (h HD + 32 t is a multiple of 32: 32-column group t of the head = one 128-byte line of the image).  A lane holds
+        // d = 8 r4 + 4 fh + 0 .. 3; the two lane halves trade their r4 = 2p + 1 / 2p pieces (v_permlane32_swap) so that
+        // fh = 0 ends up with d = 16 p .. 16 p + 7 and fh = 1 with 16 p + 8 .. 16 p + 15: every store instruction then
+        // writes whole 32-byte sectors (16 bytes per lane, the two halves adjacent), as the fp32 form did — stores of
+        // half sectors cost 2.4 us per layer at T = 8192.
         unsigned char* op = reinterpret_cast<unsigned char*>(ctx + (int64_t)(s0 + qrow) * H + h * HD);
 #pragma unroll
         for (int t = 0; t < DT; ++t)
 #pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) {
-                uint32_t h0, l0, h1, l1;  // d = 8 r4 + 4 fh + 0 .. 3
-                x3_split2(o[t][4 * r4] * inv, o[t][4 * r4 + 1] * inv, h0, l0);
-                x3_split2(o[t][4 * r4 + 2] * inv, o[t][4 * r4 + 3] * inv, h1, l1);
-                // the two lane halves trade pieces: fh = 0 stores the hi pieces of d = 8 r4 .. 8 r4 + 7, fh = 1 the lo
-                // pieces — one 16-byte store per lane (two 8-byte stores each cost 2.4 us per layer at T = 8192)
-                const uint32_t g0 = (uint32_t)__shfl_xor((int)(fh ? h0 : l0), 32);
-                const uint32_t g1 = (uint32_t)__shfl_xor((int)(fh ? h1 : l1), 32);
-                const uint4 w = fh ? uint4{g0, g1, l0, l1} : uint4{h0, h1, g0, g1};
-                *reinterpret_cast<uint4*>(op + t * 128 + fh * 64 + 16 * r4) = w;
+            for (int p2 = 0; p2 < 2; ++p2) {
+                uint32_t ha[2], la[2], hb[2], lb[2];  // a: r4 = 2 p2, b: r4 = 2 p2 + 1
+                x3_split2(o[t][8 * p2] * inv, o[t][8 * p2 + 1] * inv, ha[0], la[0]);
+                x3_split2(o[t][8 * p2 + 2] * inv, o[t][8 * p2 + 3] * inv, ha[1], la[1]);
+                x3_split2(o[t][8 * p2 + 4] * inv, o[t][8 * p2 + 5] * inv, hb[0], lb[0]);
+                x3_split2(o[t][8 * p2 + 6] * inv, o[t][8 * p2 + 7] * inv, hb[1], lb[1]);
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {  // a.hi lanes <-> b.lo lanes: fh = 0 keeps (own a, partner's a), fh = 1 (partner's b, own b)
+                    const x3_u2 sh = __builtin_amdgcn_permlane32_swap(ha[e], hb[e], false, false);
+                    const x3_u2 sl = __builtin_amdgcn_permlane32_swap(la[e], lb[e], false, false);
+                    ha[e] = sh[0];
+                    hb[e] = sh[1];
+                    la[e] = sl[0];
+                    lb[e] = sl[1];
+                }
+                *reinterpret_cast<uint4*>(op + t * 128 + 32 * p2 + 16 * fh) = uint4{ha[0], ha[1], hb[0], hb[1]};
+                *reinterpret_cast<uint4*>(op + t * 128 + 64 + 32 * p2 + 16 * fh) = uint4{la[0], la[1], lb[0], lb[1]};
             }
     }
 }
