@@ -22,6 +22,9 @@ CONFIGS = {
     "xlmr-tiny": ("xlm-roberta", 150, 128, 2, 4, 256, 80),
     # multilingual-e5-large / bge-m3 widths (XLM-R large: H 1024, 16 heads of 64, FFN 4096), 2 layers
     "xlmr-large-dims": ("xlm-roberta", 300, 1024, 2, 16, 4096, 600),
+    # widths that are multiples of 32 but not of 64 (three heads of 32, FFN 160): rows that do not fill every lane slot
+    # of the row kernels, GEMM column tiles that end inside a 128-column block
+    "h96": ("bert", 90, 96, 2, 3, 160, 64),
 }
 
 

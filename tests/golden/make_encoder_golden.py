@@ -24,6 +24,8 @@ CASES = [  # (config, weight seed, B, S, input seed)
     ("e5-small-dims", 10, 2, 512, 13),  # the reference's truncation cap (max_length = 512)
     ("e5-small-dims", 10, 256, 32, 31),  # BASELINE config 5's batch: 256 ragged sentences (embeddings only)
     ("xlmr-large-dims", 12, 4, 33, 41),  # bge-m3: CLS state of XLMRobertaModel, right-padded batch
+    ("h96", 14, 5, 23, 51),   # H = 96, FFN 160: multiples of 32 but not of 64 (partial lane slots, partial column tiles)
+    ("h96", 14, 70, 13, 52),  # the same widths over several 64-row bands
 ]
 EMB_ONLY = {8}  # cases whose hidden states are not stored (size)
 
