@@ -22,17 +22,22 @@ def main():
     cfg = {"model_type": "bert", "vocab_size": 250037, "hidden_size": 384, "num_hidden_layers": 12,
            "num_attention_heads": 12, "intermediate_size": 1536, "max_position_embeddings": 512,
            "type_vocab_size": 2, "layer_norm_eps": 1e-12, "hidden_act": "gelu", "pad_token_id": 0}
+    model = os.environ.get("MVDB_BENCH_MODEL", "e5-small")
+    if model == "e5-large":  # multilingual-e5-large / bge-m3 (XLM-R large): the reference's AlternativeModel.large / .bgem3
+        cfg.update({"model_type": "xlm-roberta", "vocab_size": 250002, "hidden_size": 1024, "num_hidden_layers": 24,
+                    "num_attention_heads": 16, "intermediate_size": 4096, "max_position_embeddings": 514,
+                    "type_vocab_size": 1, "layer_norm_eps": 1e-5, "pad_token_id": 1})
     from oracle.encoder import weight_names
     g = torch.Generator(device="cpu").manual_seed(0)
-    H, F = 384, 1536
+    H, F, L = cfg["hidden_size"], cfg["intermediate_size"], cfg["num_hidden_layers"]
     sd = {}
     for name in weight_names(cfg):
         if name == "embeddings.word_embeddings.weight":
             shape = (cfg["vocab_size"], H)
         elif name == "embeddings.position_embeddings.weight":
-            shape = (512, H)
+            shape = (cfg["max_position_embeddings"], H)
         elif name == "embeddings.token_type_embeddings.weight":
-            shape = (2, H)
+            shape = (cfg["type_vocab_size"], H)
         elif name.endswith("intermediate.dense.weight"):
             shape = (F, H)
         elif name.endswith("intermediate.dense.bias"):
@@ -56,7 +61,7 @@ def main():
             lens = rs.randint(S // 4, S + 1, size=B) if ragged else np.full(B, S)
             mask = torch.from_numpy((np.arange(S)[None, :] < lens[:, None]).astype(np.int32)).to(dev)
             T = int(lens.sum())
-            for compute in (0, 2, 1):
+            for compute in ((0, 2, 1) if model == "e5-small" else (0, 2)):
                 for _ in range(3):
                     enc.forward_device(ids, mask, compute=compute)
                 torch.cuda.synchronize()
@@ -66,9 +71,9 @@ def main():
                     enc.forward_device(ids, mask, compute=compute)
                 torch.cuda.synchronize()
                 dt = (time.perf_counter() - t0) / n
-                gemm = T * 12 * (4 * 2 * H * H + 2 * 2 * H * F)
-                attn = float(sum(12 * 4 * int(l) * int(l) * H for l in lens))
-                print(json.dumps({"B": B, "S": S, "ragged": ragged, "compute": {0: "fp32", 1: "bf16", 2: "fp16x3"}[compute],
+                gemm = T * L * (4 * 2 * H * H + 2 * 2 * H * F)
+                attn = float(sum(L * 4 * int(l) * int(l) * H for l in lens))
+                print(json.dumps({"model": model, "B": B, "S": S, "ragged": ragged, "compute": {0: "fp32", 1: "bf16", 2: "fp16x3"}[compute],
                                   "tokens": T, "ms": round(dt * 1e3, 3), "sentences_per_s": round(B / dt, 1),
                                   "tflops": round((gemm + attn) / dt / 1e12, 2), "gemm_tflop": round(gemm / 1e12, 3),
                                   "attn_tflop": round(attn / 1e12, 3),

@@ -1803,14 +1803,19 @@ int launch_gemm_x3(const float* Aimg, const _Float16* Wp, float inv_wscale, cons
         }
     }
     dim3 grid((N + 127) / 128, (unsigned)((Tmax + 63) / 64));
-    // Many row bands (S = 512: T = 131072, >= 8 rounds of 128 x 128 tiles): 128 x 128 tiles on FOUR waves — wave tile 64 x 64,
-    // 8 fragment reads per 12 MFMAs where the 32 x 64 wave tile of the default needs 12 (its LDS port and its matrix cores
-    // are co-limited) —, two stages (64 KiB), two workgroups per CU: 29.3 ms per forward vs 33.1 with the default tiles and
-    // 32.2 with 128 x 128 tiles on eight waves of 32 x 64 (MVDB_GEMM_X3_W8=1).  At T = 8192 the 576 / 768 / 192 tiles of a GEMM
-    // are 1.1 / 1.5 / 0.4 rounds: 2.07 vs 2.02 ms on a full batch, 2.23 vs 1.70 on a ragged one — the 64-row tiles stay.
+    // Enough 128 x 128 tiles to fill every resident slot (two workgroups per CU) at least once: 128 x 128 tiles on FOUR
+    // waves — wave tile 64 x 64, 8 fragment reads per 12 MFMAs where the 32 x 64 wave tile of the default needs 12, and a
+    // third less L2 -> LDS traffic per output —, two stages (64 KiB), two workgroups per CU.  e5-small, S = 512: 29.3 ms
+    // per forward vs 33.1 with the default tiles and 32.2 with 128 x 128 tiles on eight waves of 32 x 64
+    // (MVDB_GEMM_X3_W8=1).  The threshold (MVDB_GEMM_X3_MANY, in units of the CU count, counted on the padded batch):
+    // at 2 an e5-large-shaped forward (H = 1024, 24 layers) of 256 x 32 tokens takes 16.7 ms against 18.3 at 8, 17.4 at 3
+    // (ragged: 12.9 / 12.9 / 12.5); e5-small at T = 8192 — QKV and FFN1 qualify, 1.1 / 1.5 rounds — is within the
+    // run-to-run spread either way (1.97 vs 1.99 ms, ragged 1.64 vs 1.62).  Forcing them onto the N = 384 GEMMs as well
+    // (192 tiles) costs a ragged batch 30 %.
     static const int big4env = []() { const char* v = getenv("MVDB_GEMM_X3_BM128W4"); return v ? atoi(v) : -1; }();
     static const bool w8 = []() { const char* v = getenv("MVDB_GEMM_X3_W8"); return v && *v == '1'; }();
-    const bool many = (int64_t)((N + 127) / 128) * ((Tmax + 127) / 128) >= (int64_t)8 * device_cus(device);
+    static const int many_x = []() { const char* v = getenv("MVDB_GEMM_X3_MANY"); return v && *v ? atoi(v) : 2; }();
+    const bool many = (int64_t)((N + 127) / 128) * ((Tmax + 127) / 128) >= (int64_t)many_x * device_cus(device);
     if (dbg == 0 && !w8 && (big4env >= 0 ? big4env == 1 : many)) {
         auto kern4 = gemm_x3_dma_kernel<EPI, 128, 2, 0, 4>;
         constexpr int lds4 = 2 * (128 * 128 + 128 * 128);

@@ -175,3 +175,32 @@ def test_bf16_mode_is_close_but_opt_in(gpu):
     with pytest.raises(ValueError):
         enc.forward(ids, mask, compute=3)
     enc.close()
+
+
+@pytest.mark.parametrize("tiles", ["0", "1"], ids=["64-row", "128-row"])
+def test_split_precision_gemm_tile_forms_match_golden(tiles, gpu):
+    """Both tile forms of the split-precision GEMM (64 x 128 on 32 x 64 wave tiles; 128 x 128 on 64 x 64 wave tiles, which
+    the launcher picks once a GEMM has >= 2 CUs' worth of 128 x 128 tiles) on every golden case, each forced through
+    MVDB_GEMM_X3_BM128W4 in its own process (the switch is read once per process)."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import sys, numpy as np, torch\n"
+        "sys.path.insert(0, 'tests')\n"
+        "from encoder_cases import load_cases\n"
+        "from oracle import encoder as E\n"
+        "from minivectordb_amd.embedding_model import GpuEncoder\n"
+        "worst = 0.0\n"
+        "for c in load_cases():\n"
+        "    cfg = E.make_config(c['name']); w = E.make_weights(cfg, c['wseed'])\n"
+        "    enc = GpuEncoder(cfg, {k: torch.from_numpy(v) for k, v in w.items()}, device=0)\n"
+        "    emb = enc.forward(c['ids'], c['mask'], compute=2)\n"
+        "    worst = max(worst, float(np.abs(emb - c['emb']).max()))\n"
+        "    enc.close()\n"
+        "print('worst', worst)\n"
+        "sys.exit(0 if worst <= 2e-5 else 1)\n")
+    env = dict(os.environ, MVDB_GEMM_X3_BM128W4=tiles)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
