@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Encoder forward at the B = 256, S = 32 shape only (for rocprofv3 kernel traces)."""
+"""Encoder forward at the B = 256, S = 32 shape only (for rocprofv3 kernel traces).
+MVDB_S32_MODEL=e5-large: the XLM-R-large shape (H 1024, 24 layers, FFN 4096); MVDB_S32_S: another sequence length."""
 import os
 import sys
 
@@ -16,10 +17,12 @@ from oracle.encoder import make_weights  # noqa: E402
 cfg = {"model_type": "bert", "vocab_size": 30000, "hidden_size": 384, "num_hidden_layers": 12,
        "num_attention_heads": 12, "intermediate_size": 1536, "max_position_embeddings": 512,
        "type_vocab_size": 2, "layer_norm_eps": 1e-12, "hidden_act": "gelu", "pad_token_id": 0}
+if os.environ.get("MVDB_S32_MODEL") == "e5-large":
+    cfg.update({"hidden_size": 1024, "num_hidden_layers": 24, "num_attention_heads": 16, "intermediate_size": 4096})
 dev = torch.device("cuda", 0)
 w = make_weights(cfg, 1)
 enc = GpuEncoder(cfg, {k: torch.from_numpy(v) for k, v in w.items()}, device=0)
-B, S = 256, 32
+B, S = 256, int(os.environ.get("MVDB_S32_S", "32"))
 rs = np.random.RandomState(0)
 ids = torch.from_numpy(rs.randint(5, 30000, size=(B, S)).astype(np.int32)).to(dev)
 mask = torch.ones((B, S), dtype=torch.int32, device=dev)

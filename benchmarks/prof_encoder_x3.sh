@@ -9,7 +9,7 @@ IFS=';' read -ra ARR <<< "$SETS"
 : > $OUT/pmc_summary.txt
 for set in "${ARR[@]}"; do
   tag=$(echo $set | cut -d' ' -f1)
-  timeout 300 rocprofv3 --pmc $set --output-format csv -d /tmp/epmc_${tag} -- python3 $R/benchmarks/bench_encoder_s32.py 6 > /tmp/epmc_${tag}.log 2>&1
+  timeout 300 rocprofv3 --pmc $set --output-format csv -d /tmp/epmc_${tag} -- python3 $R/benchmarks/bench_encoder_s32.py ${MVDB_PROF_ITERS:-6} > /tmp/epmc_${tag}.log 2>&1
   python3 - <<PY >> $OUT/pmc_summary.txt
 import csv, glob, collections
 f = glob.glob("/tmp/epmc_${tag}/**/*_counter_collection.csv", recursive=True)

@@ -947,15 +947,16 @@ __device__ __forceinline__ void x3_split2(float a, float b, uint32_t& hi, uint32
 // EPI_BIAS_GELU writes its output as (hi | lo) lines too (it only feeds the next GEMM); the other epilogues write fp32.
 // DBG != 0: timing ablations (MVDB_GEMM_X3_DBG; results invalid): 1 = no fragment reads / MFMAs (the DMA ring,
 // barriers and epilogue alone), 2 = no DMA (compute on whatever the LDS holds)
-template <int EPI, int BM, int NST, int DBG = 0, int WAVES = 4>
+template <int EPI, int BM, int NST, int DBG = 0, int WAVES = 4, int BN = 128>
 __global__ __launch_bounds__(WAVES * 64) void gemm_x3_dma_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ Wp,
                                                           float inv_wscale, const float* __restrict__ bias,
                                                           const float* __restrict__ R, float* __restrict__ C,
                                                           const int* __restrict__ Tptr, int N, int K) {
-    constexpr int BN = 128, WM = WAVES / 2, TM = BM / (32 * WM);  // WAVES / 2 x 2 waves, wave tile 32 TM x 64
-    constexpr int kA = BM * 128, kStage = kA + 2 * BN * 64;
-    constexpr int NA = BM / 8;             // DMA instructions of the A tile (8 rows each)
-    constexpr int NI = (NA + 16) / WAVES;  // per wave and stage (W: 16 instructions of 8 rows each)
+    constexpr int WM = WAVES / 2, TM = BM / (32 * WM), TN = BN / 64;  // WAVES / 2 x 2 waves, wave tile 32 TM x 32 TN
+    constexpr int kA = BM * 128, kStage = kA + BN * 128;
+    constexpr int NA = BM / 8;                  // DMA instructions of the A tile (8 rows each)
+    constexpr int NI = (NA + BN / 8) / WAVES;   // per wave and stage (W: BN / 8 instructions of 8 rows each)
+    static_assert((NA + BN / 8) % WAVES == 0, "whole DMA instructions per wave");
     extern __shared__ __attribute__((aligned(16))) unsigned char xsm[];
     const int T = *Tptr;
     int bx, by;
@@ -967,7 +968,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_x3_dma_kernel(const _Float16*
     const int fr = lane & 31, fh = lane >> 5;
 
     // DMA roles: instruction q of a stage; wave w issues q = w NI .. w NI + NI - 1 (the kind of q is wave-uniform)
-    uint32_t voff[NI];
+    int64_t voff[NI];  // T K 4 bytes pass 4 GiB at 512 x 512 tokens of a 4096-wide FFN
     const char* sbase[NI];
     int kstep[NI], dsto[NI];
 #pragma unroll
@@ -979,7 +980,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_x3_dma_kernel(const _Float16*
             int g = m0 + row;
             g = g < T ? g : T - 1;  // rows past the edge: clamped (masked in the epilogue)
             sbase[i] = reinterpret_cast<const char*>(A);
-            voff[i] = (uint32_t)(((int64_t)g * K * 4) + 16 * slot);
+            voff[i] = (int64_t)g * K * 4 + 16 * slot;
             kstep[i] = 128;
             dsto[i] = q * 1024;
         } else {
@@ -989,7 +990,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_x3_dma_kernel(const _Float16*
             int g = n0 + row;
             g = g < N ? g : N - 1;
             sbase[i] = reinterpret_cast<const char*>(Wp);
-            voff[i] = (uint32_t)(((int64_t)g * K * 4) + 16 * slot);
+            voff[i] = (int64_t)g * K * 4 + 16 * slot;
             kstep[i] = 128;
             dsto[i] = kA + qq * 1024;
         }
@@ -1003,7 +1004,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_x3_dma_kernel(const _Float16*
         }
     };
     // fragment byte offsets inside a stage
-    int a_off[TM][2][2], b_off[2][2][2];
+    int a_off[TM][2][2], b_off[TN][2][2];
     const int ga = (fr >> 1) & 7;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -1013,18 +1014,18 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_x3_dma_kernel(const _Float16*
             for (int pl = 0; pl < 2; ++pl)
                 a_off[i][ks][pl] = (wm * (BM / WM) + i * 32 + fr) * 128 + (((4 * pl + 2 * ks + fh) ^ ga) << 4);
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int pl = 0; pl < 2; ++pl)
-                b_off[j][ks][pl] = kA + (wn * 64 + j * 32 + fr) * 128 + (((4 * pl + 2 * ks + fh) ^ ga) << 4);
+                b_off[j][ks][pl] = kA + (wn * (BN / 2) + j * 32 + fr) * 128 + (((4 * pl + 2 * ks + fh) ^ ga) << 4);
 
-    f32x16 acc[TM][2];
+    f32x16 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -1052,9 +1053,9 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_x3_dma_kernel(const _Float16*
         }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            x3_h8 ah[TM], al[TM], bh[2], bl[2];
+            x3_h8 ah[TM], al[TM], bh[TN], bl[TN];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
+            for (int j = 0; j < TN; ++j) {
                 bh[j] = *reinterpret_cast<const x3_h8*>(sb + b_off[j][ks][0]);
                 bl[j] = *reinterpret_cast<const x3_h8*>(sb + b_off[j][ks][1]);
             }
@@ -1067,15 +1068,15 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_x3_dma_kernel(const _Float16*
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
         }
         st = st == NST - 1 ? 0 : st + 1;
     }
@@ -1089,8 +1090,8 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_x3_dma_kernel(const _Float16*
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int col = n0 + wn * 64 + j * 32 + fr;
+            for (int j = 0; j < TN; ++j) {
+                const int col = n0 + wn * (BN / 2) + j * 32 + fr;
                 const float bv = bias[col];
                 const int row0 = m0 + wm * (BM / WM) + i * 32 + 4 * fh;
                 float res[16];
@@ -1114,8 +1115,8 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_x3_dma_kernel(const _Float16*
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = n0 + wn * 64 + j * 32 + fr;
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + wn * (BN / 2) + j * 32 + fr;
             if (col >= N) continue;  // N % 32 == 0: whole 32-column groups (lane pairs stay together)
             const float bv = bias[col];
 #pragma unroll
@@ -1816,6 +1817,37 @@ int launch_gemm_x3(const float* Aimg, const _Float16* Wp, float inv_wscale, cons
     static const bool w8 = []() { const char* v = getenv("MVDB_GEMM_X3_W8"); return v && *v == '1'; }();
     static const int many_x = []() { const char* v = getenv("MVDB_GEMM_X3_MANY"); return v && *v ? atoi(v) : 2; }();
     const bool many = (int64_t)((N + 127) / 128) * ((Tmax + 127) / 128) >= (int64_t)many_x * device_cus(device);
+    // N a multiple of 256 and whole rounds of 256 x 256 tiles: ONE workgroup of eight waves per CU on a 256 x 256 tile (wave
+    // tile 64 x 128: 24 fragment reads per 48 MFMAs; two 64-KiB stages) — half the L2 -> LDS bytes per output of two
+    // 128 x 128 workgroups.  PMC on the e5-large shape at 256 x 512 tokens: matrix cores 61 % busy in the QKV GEMM, 60 %
+    // in the N = 1024 ones, 53 % in FFN1 (GELU epilogue).  Forward of that shape (24 layers): 294.9 -> 265.2 ms (ragged
+    // 189.4 -> 177.9), S = 256 137.0 -> 122.9, S = 128 66.8 -> 60.2 (ragged 45.0 -> 46.4), S = 64 33.7 -> 29.8; at S = 32 its
+    // 384 / 128 tiles per GEMM are 1.5 / 0.5 rounds of the 256 CUs and it loses (16.6 -> 17.9 ms, ragged 12.9 -> 16.8) — hence
+    // the rule: at least one round, and either >= 4 rounds or a last round that is >= 85 % full (counted on the padded
+    // batch).  MVDB_GEMM_X3_BIG: 1 forces it wherever N % 256 == 0, 0 disables it.
+    static const int big8env = []() { const char* v = getenv("MVDB_GEMM_X3_BIG"); return v ? atoi(v) : -1; }();
+    bool big8 = N % 256 == 0;
+    if (big8 && big8env != 1) {
+        const int64_t cus = device_cus(device), t256 = (int64_t)(N / 256) * ((Tmax + 255) / 256);
+        const int64_t rounds = (t256 + cus - 1) / cus;
+        big8 = big8env != 0 && t256 >= cus && (t256 >= 4 * cus || t256 * 100 >= rounds * cus * 85);
+    }
+    if (dbg == 0 && !w8 && big4env < 0 && big8) {
+        auto kernb = gemm_x3_dma_kernel<EPI, 256, 2, 0, 8, 256>;
+        constexpr int ldsb = 2 * (256 * 128 + 256 * 128);
+        static std::mutex mub;
+        static std::map<int, bool> doneb;
+        {
+            std::lock_guard<std::mutex> lk(mub);
+            if (!doneb[device]) {
+                MVDB_HIP(hipFuncSetAttribute((const void*)kernb, hipFuncAttributeMaxDynamicSharedMemorySize, ldsb));
+                doneb[device] = true;
+            }
+        }
+        dim3 gridb(N / 256, (unsigned)((Tmax + 255) / 256));
+        hipLaunchKernelGGL(kernb, gridb, dim3(512), ldsb, s, A, Wp, inv_wscale, bias, R, C, Tptr, N, K);
+        return 0;
+    }
     if (dbg == 0 && !w8 && (big4env >= 0 ? big4env == 1 : many)) {
         auto kern4 = gemm_x3_dma_kernel<EPI, 128, 2, 0, 4>;
         constexpr int lds4 = 2 * (128 * 128 + 128 * 128);

@@ -177,11 +177,12 @@ def test_bf16_mode_is_close_but_opt_in(gpu):
     enc.close()
 
 
-@pytest.mark.parametrize("tiles", ["0", "1"], ids=["64-row", "128-row"])
+@pytest.mark.parametrize("tiles", ["BM128W4=0", "BM128W4=1", "BIG=1"], ids=["64-row", "128-row", "256x256"])
 def test_split_precision_gemm_tile_forms_match_golden(tiles, gpu):
-    """Both tile forms of the split-precision GEMM (64 x 128 on 32 x 64 wave tiles; 128 x 128 on 64 x 64 wave tiles, which
-    the launcher picks once a GEMM has >= 2 CUs' worth of 128 x 128 tiles) on every golden case, each forced through
-    MVDB_GEMM_X3_BM128W4 in its own process (the switch is read once per process)."""
+    """Every tile form of the split-precision GEMM (64 x 128 on 32 x 64 wave tiles; 128 x 128 on 64 x 64 wave tiles, which
+    the launcher picks once a GEMM has >= 2 CUs' worth of 128 x 128 tiles; 256 x 256 on eight 64 x 128 wave tiles where
+    N % 256 == 0) on every golden case, each forced through its MVDB_GEMM_X3_* switch in its own process (the switches
+    are read once per process)."""
     import os
     import subprocess
     import sys
@@ -200,7 +201,8 @@ def test_split_precision_gemm_tile_forms_match_golden(tiles, gpu):
         "    enc.close()\n"
         "print('worst', worst)\n"
         "sys.exit(0 if worst <= 2e-5 else 1)\n")
-    env = dict(os.environ, MVDB_GEMM_X3_BM128W4=tiles)
+    name, value = tiles.split("=")
+    env = dict(os.environ, **{"MVDB_GEMM_X3_" + name: value})
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
