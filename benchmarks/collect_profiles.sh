@@ -28,6 +28,7 @@ for nq in 128 256; do
 done
 python3 $R/benchmarks/bench_config5.py > $OUT/${TAG}_config5_end_to_end.jsonl 2>> $OUT/bench.err
 python3 $R/benchmarks/bench_encoder.py > $OUT/${TAG}_encoder_bench.jsonl 2>> $OUT/bench.err
+MVDB_BENCH_MODEL=e5-large python3 $R/benchmarks/bench_encoder.py > $OUT/${TAG}_encoder_large_bench.jsonl 2>> $OUT/bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/enc_s32 -- python3 $R/benchmarks/bench_encoder_s32.py 30 > /dev/null 2>&1
 cp $(find /tmp/enc_s32 -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_encoder_s32_kernel_stats.csv
 bash $R/benchmarks/prof_encoder_x3.sh $TAG/enc_pmc > /dev/null 2>&1

@@ -477,7 +477,7 @@ __global__ __launch_bounds__(256) void gemm_f32_dma_kernel(const float* __restri
 
     // DMA roles: instruction q (0 .. 4 NI - 1) of a stage moves tile rows 8 q .. 8 q + 7 (A rows first, then W rows);
     // wave w issues q = w NI .. w NI + NI - 1.  Per-lane source offsets never change: bases are scalars.
-    uint32_t voff[NI];
+    int64_t voff[NI];  // T K 4 bytes can pass 4 GiB
     const float* sbase[NI];
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
@@ -489,7 +489,7 @@ __global__ __launch_bounds__(256) void gemm_f32_dma_kernel(const float* __restri
         const int lim = isA ? T : N;
         g = g < lim ? g : lim - 1;                  // rows past the edge: clamped (masked in the epilogue)
         sbase[i] = isA ? A : W;
-        voff[i] = (uint32_t)(((int64_t)g * K + 4 * slot) * 4);
+        voff[i] = ((int64_t)g * K + 4 * slot) * 4;
     }
     auto issue = [&](int kt, int stage) {
 #pragma unroll
@@ -652,7 +652,7 @@ __global__ __launch_bounds__(256) void gemm_f32_dma_persistent_kernel(const floa
     const bool isA = wave < 2;  // waves 0, 1 move the 64 A rows, waves 2, 3 the 64 W rows
     const float* sbase = isA ? A : W;
     const int lim = isA ? T : N;
-    uint32_t voff[NI];
+    int64_t voff[NI];  // T K 4 bytes can pass 4 GiB
     auto set_tile = [&](unsigned lin) {
         const int m0 = (int)(lin / gx) * BM, n0 = (int)(lin % gx) * BN;
 #pragma unroll
@@ -661,7 +661,7 @@ __global__ __launch_bounds__(256) void gemm_f32_dma_persistent_kernel(const floa
             const int slot = (lane & 7) ^ (row & 7);
             int g = isA ? m0 + row : n0 + (row - BM);
             g = g < lim ? g : lim - 1;
-            voff[i] = (uint32_t)(((int64_t)g * K + 4 * slot) * 4);
+            voff[i] = ((int64_t)g * K + 4 * slot) * 4;
         }
     };
     unsigned iu = 0;  // issue cursor: tile ordinal, K-step, ring stage
