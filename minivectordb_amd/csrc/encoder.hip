@@ -1471,12 +1471,15 @@ __global__ __launch_bounds__(WV * 64) void attention_x3_kernel(const float* __re
             }
             // ---- online softmax, query on the lane --------------------------------------------------
             float cmax = -INFINITY;
+            if (kb32 * 32 + 32 > nk) {  // only the last block of a sequence has keys to mask (workgroup-uniform)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = kb32 * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-                st[r] = key < nk ? st[r] : -INFINITY;
-                cmax = fmaxf(cmax, st[r]);
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kb32 * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                    st[r] = key < nk ? st[r] : -INFINITY;
+                }
             }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) cmax = fmaxf(cmax, st[r]);
             cmax = fmaxf(cmax, __shfl_xor(cmax, 32));
             const float mn = fmaxf(m, cmax);
             const float alpha = __builtin_amdgcn_exp2f(m - mn);
@@ -1489,10 +1492,12 @@ __global__ __launch_bounds__(WV * 64) void attention_x3_kernel(const float* __re
             psum += __shfl_xor(psum, 32);
             l = l * alpha + psum;
             m = mn;
+            if (__ballot(alpha != 1.0f) != 0ull) {  // once the running maxima have settled no lane rescales
 #pragma unroll
-            for (int t = 0; t < DT; ++t)
+                for (int t = 0; t < DT; ++t)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+                    for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+            }
             // ---- O^T += V^T · P^T: k-block kb16 = accumulator registers 8 kb16 .. + 7, i.e. keys
             //      16 kb16 + {4 fh .. 4 fh + 3} and 16 kb16 + 8 + {4 fh .. 4 fh + 3} of this 32-key block
 #pragma unroll
