@@ -947,11 +947,23 @@ __device__ __forceinline__ void x3_split2(float a, float b, uint32_t& hi, uint32
 // EPI_BIAS_GELU writes its output as (hi | lo) lines too (it only feeds the next GEMM); the other epilogues write fp32.
 // DBG != 0: timing ablations (MVDB_GEMM_X3_DBG; results invalid): 1 = no fragment reads / MFMAs (the DMA ring,
 // barriers and epilogue alone), 2 = no DMA (compute on whatever the LDS holds)
+// The 256-row tile form pays off when its tiles make whole rounds of the CUs: at least one round, and either >= 4 rounds
+// or a last round >= 85 % full.  Evaluated on the host with the padded token count (can the form apply at all?) and on the
+// device with the packed one (does it?): a ragged batch of 256 x 128 token slots holds ~20k tokens, not 32k.
+__host__ __device__ inline bool x3_big_form(int64_t T, int N, int bn, int cus) {
+    const int64_t tiles = (int64_t)(N / bn) * ((T + 255) / 256);
+    const int64_t rounds = (tiles + cus - 1) / cus;
+    return tiles >= cus && (tiles >= 4 * (int64_t)cus || tiles * 100 >= rounds * cus * 85);
+}
+
 template <int EPI, int BM, int NST, int DBG = 0, int WAVES = 4, int BN = 128>
 __global__ __launch_bounds__(WAVES * 64) void gemm_x3_dma_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ Wp,
                                                           float inv_wscale, const float* __restrict__ bias,
                                                           const float* __restrict__ R, float* __restrict__ C,
-                                                          const int* __restrict__ Tptr, int N, int K) {
+                                                          const int* __restrict__ Tptr, int N, int K, int sel_bn, int sel_cus) {
+    // sel_bn != 0: this launch is one of a PAIR — the 256-row form (sel_bn > 0) and its fallback (sel_bn < 0) — and the
+    // number of packed tokens, known only on the device, decides which of the two does the work (x3_big_form)
+    if (sel_bn != 0 && x3_big_form(*Tptr, N, sel_bn > 0 ? sel_bn : -sel_bn, sel_cus) != (sel_bn > 0)) return;
     constexpr int WM = WAVES / 2, TM = BM / (32 * WM), TN = BN / 64;  // WAVES / 2 x 2 waves, wave tile 32 TM x 32 TN
     constexpr int kA = BM * 128, kStage = kA + BN * 128;
     constexpr int NA = BM / 8;                  // DMA instructions of the A tile (8 rows each)
@@ -1829,29 +1841,46 @@ int launch_gemm_x3(const float* Aimg, const _Float16* Wp, float inv_wscale, cons
     // 189.4 -> 177.9), S = 256 137.0 -> 122.9, S = 128 66.8 -> 60.2 (ragged 45.0 -> 46.4), S = 64 33.7 -> 29.8; at S = 32 its
     // 384 / 128 tiles per GEMM are 1.5 / 0.5 rounds of the 256 CUs and it loses (16.6 -> 17.9 ms, ragged 12.9 -> 16.8) — hence
     // the rule: at least one round, and either >= 4 rounds or a last round that is >= 85 % full (counted on the padded
-    // batch).  MVDB_GEMM_X3_BIG: 1 forces it wherever N % 256 == 0, 0 disables it.
+    // batch).  MVDB_GEMM_X3_BIG: 1 forces it wherever N % 256 == 0 or N % 192 == 0, 0 disables it.
     static const int big8env = []() { const char* v = getenv("MVDB_GEMM_X3_BIG"); return v ? atoi(v) : -1; }();
-    bool big8 = N % 256 == 0;
-    if (big8 && big8env != 1) {
-        const int64_t cus = device_cus(device), t256 = (int64_t)(N / 256) * ((Tmax + 255) / 256);
-        const int64_t rounds = (t256 + cus - 1) / cus;
-        big8 = big8env != 0 && t256 >= cus && (t256 >= 4 * cus || t256 * 100 >= rounds * cus * 85);
-    }
-    if (dbg == 0 && !w8 && big4env < 0 && big8) {
-        auto kernb = gemm_x3_dma_kernel<EPI, 256, 2, 0, 8, 256>;
-        constexpr int ldsb = 2 * (256 * 128 + 256 * 128);
-        static std::mutex mub;
-        static std::map<int, bool> doneb;
-        {
-            std::lock_guard<std::mutex> lk(mub);
-            if (!doneb[device]) {
-                MVDB_HIP(hipFuncSetAttribute((const void*)kernb, hipFuncAttributeMaxDynamicSharedMemorySize, ldsb));
-                doneb[device] = true;
+    // N % 256 != 0 but N % 192 == 0 (every GEMM of a 384-wide model): the same form on 256 x 192 tiles (wave tile 64 x 96)
+    const int bign = N % 256 == 0 ? 256 : N % 192 == 0 ? 192 : 0;
+    const int cus = device_cus(device);
+    // forced (1): unconditional; default: launched as a pair with the fallback below when the padded batch could qualify
+    const bool big_pair = bign != 0 && big8env < 0 && x3_big_form(Tmax, N, bign, cus);
+    int sel_bn = 0;  // the fallback's selector
+    if (dbg == 0 && !w8 && big4env < 0 && bign != 0 && (big8env == 1 || big_pair)) {
+        const dim3 gridb(N / bign, (unsigned)((Tmax + 255) / 256));
+        const int sel_big = big8env == 1 ? 0 : bign;
+        if (bign == 256) {
+            auto kernb = gemm_x3_dma_kernel<EPI, 256, 2, 0, 8, 256>;
+            constexpr int ldsb = 2 * (256 * 128 + 256 * 128);
+            static std::mutex mub;
+            static std::map<int, bool> doneb;
+            {
+                std::lock_guard<std::mutex> lk(mub);
+                if (!doneb[device]) {
+                    MVDB_HIP(hipFuncSetAttribute((const void*)kernb, hipFuncAttributeMaxDynamicSharedMemorySize, ldsb));
+                    doneb[device] = true;
+                }
             }
+            hipLaunchKernelGGL(kernb, gridb, dim3(512), ldsb, s, A, Wp, inv_wscale, bias, R, C, Tptr, N, K, sel_big, cus);
+        } else {
+            auto kernc = gemm_x3_dma_kernel<EPI, 256, 2, 0, 8, 192>;
+            constexpr int ldsc = 2 * (256 * 128 + 192 * 128);
+            static std::mutex muc;
+            static std::map<int, bool> donec;
+            {
+                std::lock_guard<std::mutex> lk(muc);
+                if (!donec[device]) {
+                    MVDB_HIP(hipFuncSetAttribute((const void*)kernc, hipFuncAttributeMaxDynamicSharedMemorySize, ldsc));
+                    donec[device] = true;
+                }
+            }
+            hipLaunchKernelGGL(kernc, gridb, dim3(512), ldsc, s, A, Wp, inv_wscale, bias, R, C, Tptr, N, K, sel_big, cus);
         }
-        dim3 gridb(N / 256, (unsigned)((Tmax + 255) / 256));
-        hipLaunchKernelGGL(kernb, gridb, dim3(512), ldsb, s, A, Wp, inv_wscale, bias, R, C, Tptr, N, K);
-        return 0;
+        if (big8env == 1) return 0;
+        sel_bn = -bign;  // the fallback runs only where the packed token count rules the 256-row form out
     }
     if (dbg == 0 && !w8 && (big4env >= 0 ? big4env == 1 : many)) {
         auto kern4 = gemm_x3_dma_kernel<EPI, 128, 2, 0, 4>;
@@ -1866,7 +1895,7 @@ int launch_gemm_x3(const float* Aimg, const _Float16* Wp, float inv_wscale, cons
             }
         }
         dim3 grid4((N + 127) / 128, (unsigned)((Tmax + 127) / 128));
-        hipLaunchKernelGGL(kern4, grid4, dim3(256), lds4, s, A, Wp, inv_wscale, bias, R, C, Tptr, N, K);
+        hipLaunchKernelGGL(kern4, grid4, dim3(256), lds4, s, A, Wp, inv_wscale, bias, R, C, Tptr, N, K, sel_bn, cus);
         return 0;
     }
     if (dbg == 0 && w8) {
@@ -1882,10 +1911,10 @@ int launch_gemm_x3(const float* Aimg, const _Float16* Wp, float inv_wscale, cons
             }
         }
         dim3 grid8((N + 127) / 128, (unsigned)((Tmax + 127) / 128));
-        hipLaunchKernelGGL(kern8, grid8, dim3(512), lds8, s, A, Wp, inv_wscale, bias, R, C, Tptr, N, K);
+        hipLaunchKernelGGL(kern8, grid8, dim3(512), lds8, s, A, Wp, inv_wscale, bias, R, C, Tptr, N, K, sel_bn, cus);
         return 0;
     }
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, A, Wp, inv_wscale, bias, R, C, Tptr, N, K);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, A, Wp, inv_wscale, bias, R, C, Tptr, N, K, sel_bn, cus);
     return 0;
 }
 
