@@ -2018,7 +2018,8 @@ int enqueue_lane(mvdb_encoder* e, mvdb_encoder::Lane& w, const int32_t* ids, con
         return !(v && *v == '0');
     }();
     // sequences longer than this run 256-query workgroups (eight waves): each K / V tile is loaded and split for twice as
-    // many queries — e5-small, B = 256: S = 512 28.9 -> 27.7 ms per forward (ragged 19.4 -> 18.6), S = 256 13.4 -> 13.0
+    // many queries — e5-small, B = 256: S = 512 28.9 -> 27.7 ms per forward (ragged 19.4 -> 18.6), S = 256 13.4 -> 13.0; sixteen
+    // waves (one workgroup per (sentence, head) at S = 512) add nothing: 27.4 vs 27.3, ragged 18.6 vs 18.3
     static const int x3_wide_from = []() {
         const char* v = getenv("MVDB_ATTENTION_X3_WIDE_FROM");
         return v && *v ? atoi(v) : 128;
