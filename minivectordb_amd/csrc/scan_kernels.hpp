@@ -98,16 +98,18 @@ __global__ __launch_bounds__(kScanThreads) void flat_scan_kernel(ScanArgs a) {
     const int64_t nbatches = (a.n + RB - 1) / RB;
     const int64_t last = a.n - 1;
 
-    // issue the U*C loads of batch b (nothing waits here)
-    auto load_batch = [&](int64_t b, f32x4 (&x)[U][C]) {
+    // physical rows of batch b (SUBSET: one 8-byte load per row through rows[])
+    auto batch_rows = [&](int64_t b, int64_t (&pr)[U]) {
         const int64_t row0 = b * RB + g;
-        int64_t pr[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             int64_t r = row0 + (int64_t)u * RPI;
             r = r < last ? r : last;  // clamp: tail lanes re-read the last row, result discarded
             pr[u] = SUBSET ? a.rows[r] : r;
         }
+    };
+    // issue the U*C loads of a batch (nothing waits here)
+    auto load_batch = [&](const int64_t (&pr)[U], f32x4 (&x)[U][C]) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const float* p = a.X + pr[u] * a.ld + t * 4;
@@ -176,10 +178,29 @@ __global__ __launch_bounds__(kScanThreads) void flat_scan_kernel(ScanArgs a) {
         }
     };
 
-    for (int64_t b = gw; b < nbatches; b += nwaves_total) {
-        f32x4 x[U][C];
-        load_batch(b, x);
-        consume_batch(b, x);
+    if (SUBSET) {
+        // the row ids of the NEXT batch are fetched behind this batch's row loads, so that a batch never waits for
+        // its own indirection (id load -> vmcnt(0) -> row loads serialised two round trips per batch: 2.0-2.3 TB/s of
+        // rows touched at 10M x 512)
+        int64_t pr[U], pn[U];
+        if (gw < nbatches) batch_rows(gw, pr);
+        for (int64_t b = gw; b < nbatches; b += nwaves_total) {
+            f32x4 x[U][C];
+            load_batch(pr, x);
+            const int64_t bn = b + nwaves_total;
+            batch_rows(bn < nbatches ? bn : b, pn);
+            consume_batch(b, x);
+#pragma unroll
+            for (int u = 0; u < U; ++u) pr[u] = pn[u];
+        }
+    } else {
+        for (int64_t b = gw; b < nbatches; b += nwaves_total) {
+            f32x4 x[U][C];
+            int64_t pr[U];
+            batch_rows(b, pr);
+            load_batch(pr, x);
+            consume_batch(b, x);
+        }
     }
 
     if (MODE == kModeTopK) {
