@@ -47,6 +47,16 @@ def main():
         # includes the H2D copy of the row list (8 B per row) — what find_most_similar's filtered branch pays
         print(json.dumps({"what": f"subset search, {frac:g} of the rows (sorted ids), k=10", "rows": m,
                           "ms": round(dt * 1e3, 3), "GBps_rows_touched": round(m * row_bytes / dt / 1e9, 1)}), flush=True)
+    import os
+    for frac in (0.99, 0.9, 0.5):  # dense subsets (exclude-filters): the opt-in full score pass + pick, and the default gather path
+        m = int(n * frac)
+        rows = np.sort(rs.choice(n, m, replace=False)).astype(np.int64)
+        out = {"what": f"dense subset, {frac:g} of the rows, k=10", "rows": m}
+        for label, pct in (("full_pass_ms", "50"), ("gather_ms", "101")):
+            os.environ["MVDB_SUBSET_DENSE_PERCENT"] = pct
+            out[label] = round(timeit(lambda: idx.search_subset(q[0], 10, rows), 10) * 1e3, 3)
+        os.environ.pop("MVDB_SUBSET_DENSE_PERCENT", None)
+        print(json.dumps(out), flush=True)
     rows = rs.permutation(n)[:n // 10].astype(np.int64)
     dt = timeit(lambda: idx.search_subset(q[0], 10, rows), 10)
     print(json.dumps({"what": "subset search, 0.1 of the rows (random order), k=10", "rows": len(rows),

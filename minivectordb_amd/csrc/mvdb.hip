@@ -859,6 +859,29 @@ bool mfma_path_ok(const mvdb_index* idx, int nq, int k, const int64_t* rows_dev)
 }
 
 // Core: queries already on the device (padded to ld), outputs on the device.  Enqueues on ws.stream.
+// sub[qi, p] = full[qi, rows[p]]: the scores of a dense subset picked out of a full-corpus score pass
+__global__ void gather_scores_kernel(const float* __restrict__ full, int64_t n, const int64_t* __restrict__ rows,
+                                     int64_t m, float* __restrict__ sub) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int qi = blockIdx.y;
+    if (p < m) sub[(int64_t)qi * m + p] = full[(int64_t)qi * n + rows[p]];
+}
+
+// OPT-IN (MVDB_SUBSET_DENSE_PERCENT = 50 ...; default off): a subset that keeps most of the corpus scored by a pass over
+// EVERY row at the full scan's rate, the subset's scores picked out afterwards — scores pass over all rows ->
+// gather_scores_kernel -> the radix select of the large-k path over the m subset scores (labels = positions in the list,
+// as the gather path returns them).  Same results (test_dense_subset_takes_the_full_score_pass), but measured SLOWER than
+// the pipelined gather at 10M x 512: 7.4 vs 7.0 ms at 99 % of the rows, 5.4 vs 3.5 at 50 % (1.6 / 0.8 ms of either are the
+// upload of the id list) — the eight histogram passes of the select over 10M scores cost more than the gather loses.
+// Kept as the A/B reference for the open work: a fused masked scan (row -> position map), and an entry point that takes
+// the EXCLUDED rows so that the id list of an exclude-filter is not ~n entries long.
+bool dense_subset_ok(const mvdb_index* idx, int nq, const int64_t* rows_dev, int64_t m) {
+    if (!rows_dev || nq > 4) return false;
+    const int pct = env_int("MVDB_SUBSET_DENSE_PERCENT", 101);
+    if (pct > 100 || idx->n < env_int("MVDB_SUBSET_DENSE_MIN_ROWS", 200000)) return false;
+    return m * 100 >= idx->n * (int64_t)pct;
+}
+
 int search_core(const mvdb_index* idx, Workspace* ws, const float* q_dev, int nq, int k,
                 int normalize_q, const int64_t* rows_dev, int64_t m, int64_t label_offset,
                 float* D_dev, int64_t* I_dev, bool allow_split = true) {
@@ -1071,7 +1094,8 @@ int search_core(const mvdb_index* idx, Workspace* ws, const float* q_dev, int nq
         return 0;
     }
 
-    if (k <= kMaxFusedK) {
+    const bool dense = dense_subset_ok(idx, nq, rows_dev, m);
+    if (k <= kMaxFusedK && !dense) {
         MVDB_TRY(ws->cand.reserve((size_t)nq * scan_grid_upper_bound(idx->device) * k));
         a.cand = ws->cand.p;
         int nblocks = 0;
@@ -1089,18 +1113,35 @@ int search_core(const mvdb_index* idx, Workspace* ws, const float* q_dev, int nq
         return 0;
     }
 
-    // ---- large k: scores -> radix select -> sort -------------------------------------------------
-    MVDB_TRY(ws->scores.reserve((size_t)nq * n));
-    a.scores = ws->scores.p;
+    // ---- large k, or a dense subset: scores -> radix select -> sort -------------------------------
+    const float* sc_base = nullptr;
     int nblocks = 0;
-    MVDB_TRY(launch_scan(idx->metric, kModeScores, a, nq, idx->device, s, &nblocks));
+    if (dense) {
+        // every row is scored once, in corpus order; the subset's scores are then picked out in list order
+        const int64_t nall = idx->n;
+        MVDB_TRY(ws->scores.reserve((size_t)nq * nall + (size_t)nq * n));
+        a.n = nall;
+        a.rows = nullptr;
+        a.scores = ws->scores.p;
+        MVDB_TRY(launch_scan(idx->metric, kModeScores, a, nq, idx->device, s, &nblocks));
+        float* sub = ws->scores.p + (size_t)nq * nall;
+        hipLaunchKernelGGL(gather_scores_kernel, dim3((unsigned)((n + 255) / 256), nq), dim3(256), 0, s, ws->scores.p, nall,
+                           rows_dev, n, sub);
+        MVDB_HIP(hipGetLastError());
+        sc_base = sub;
+    } else {
+        MVDB_TRY(ws->scores.reserve((size_t)nq * n));
+        a.scores = ws->scores.p;
+        MVDB_TRY(launch_scan(idx->metric, kModeScores, a, nq, idx->device, s, &nblocks));
+        sc_base = ws->scores.p;
+    }
     const int64_t k_eff = std::min<int64_t>(k, n);
     const int64_t P = pow2ceil(std::max<int64_t>(k, 2));
     MVDB_TRY(ws->selkeys.reserve((size_t)P));
     const int cus = device_cus(idx->device);
     const int sel_grid = (int)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, cus * 8));
     for (int qi = 0; qi < nq; ++qi) {
-        const float* sc = ws->scores.p + (int64_t)qi * n;
+        const float* sc = sc_base + (int64_t)qi * n;
         hipLaunchKernelGGL(select_init_kernel, dim3(1), dim3(256), 0, s, ws->st, (uint64_t)k_eff);
         for (int shift = 56; shift >= 0; shift -= 8) {
             hipLaunchKernelGGL(radix_hist_kernel, dim3(sel_grid), dim3(256), 0, s, sc, n, shift,
