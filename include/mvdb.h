@@ -239,13 +239,21 @@ int mvdb_encoder_free(mvdb_encoder* enc);
  * compute: 0 = exact-fp32 MFMA; 2 = split-precision GEMMs on the fp16 matrix cores (a.w ~ al.wh + ah.wl + ah.wh with
  * (h, l) the fp16 RNE split of an fp32 value — 22 significant bits —, weights scaled per tensor by a power of two,
  * fp32 accumulate; needs |activation| <= 65504; embeddings within 6e-7 of transformers' fp32 output like the exact
- * mode's, attention / LayerNorm / pooling stay fp32) — what the Python drop-in uses by default;
+ * mode's; the two attention products run the same split, softmax / LayerNorm / pooling stay fp32) — what the Python
+ * drop-in uses by default;
  * 1 = single bf16 product with fp32 accumulate (opt-in speed mode, ~1e-3). */
 int mvdb_encoder_forward(mvdb_encoder* enc, const int32_t* ids_host, const int32_t* mask_host,
                          int B, int S, int compute, float* out_host);
 int mvdb_encoder_forward_device(mvdb_encoder* enc, const int32_t* ids_dev, const int32_t* mask_dev,
                                 int B, int S, int compute, float* out_dev, float* hidden_dev,
                                 void* stream);
+
+/* Which tile form of the split-precision GEMM a batch of `tokens` packed tokens selects for an N-wide product on a
+ * device with `compute_units` CUs: 256 or 192 = the 256-row form on 256 x 256 / 256 x 192 tiles (one eight-wave workgroup
+ * per CU; N % 256 == 0 resp. N % 192 == 0 and the tiles make whole rounds of the CUs: >= 1 round, and >= 4 rounds or a
+ * last round >= 85 % full), 0 = the 64- / 128-row forms.  The same predicate runs on the device, on the packed token
+ * count, inside the paired launches of a forward; exported so that the rule is testable without a GPU. */
+int mvdb_encoder_gemm_tile_form(int64_t tokens, int n, int compute_units);
 
 #ifdef __cplusplus
 }

@@ -98,6 +98,7 @@ PROTOTYPES = {
     "mvdb_encoder_create": (ctypes.c_int, [ctypes.POINTER(EncoderCfg), ctypes.POINTER(c_vp), ctypes.c_int,
                                            ctypes.POINTER(c_vp)]),
     "mvdb_encoder_free": (ctypes.c_int, [c_vp]),
+    "mvdb_encoder_gemm_tile_form": (ctypes.c_int, [ctypes.c_int64, ctypes.c_int, ctypes.c_int]),
     "mvdb_encoder_forward": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_vp]),
     "mvdb_encoder_forward_device": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                    c_vp, c_vp, c_vp]),
@@ -309,6 +310,11 @@ def half_eps(d):
 
 def half_max_queries(d):
     return int(lib().mvdb_half_max_queries(int(d)))
+
+
+def encoder_gemm_tile_form(tokens, n, compute_units=256):
+    """256 / 192: the 256-row tile form of the split-precision GEMM applies to `tokens` packed tokens; 0: it does not."""
+    return int(lib().mvdb_encoder_gemm_tile_form(int(tokens), int(n), int(compute_units)))
 
 
 def prof_read(name):

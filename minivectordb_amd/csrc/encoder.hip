@@ -2276,6 +2276,12 @@ int mvdb_encoder_create(const mvdb_encoder_cfg* cfg, const void* const* w, int d
     return 0;
 }
 
+int mvdb_encoder_gemm_tile_form(int64_t tokens, int n, int compute_units) {
+    if (tokens <= 0 || n <= 0 || compute_units <= 0) return 0;
+    const int bn = n % 256 == 0 ? 256 : n % 192 == 0 ? 192 : 0;
+    return bn != 0 && x3_big_form(tokens, n, bn, compute_units) ? bn : 0;
+}
+
 int mvdb_encoder_free(mvdb_encoder* e) {
     if (!e) return 0;
     {
