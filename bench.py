@@ -185,6 +185,11 @@ def main():
     torch.cuda.synchronize()
 
     searcher = ShardedSearcher(idx, k, rank=rank, world=world, rows_per_rank=n, device=dev)
+    if world > 1 and backend == "nccl" and not share_gpu and os.environ.get("MVDB_COLLECTIVE") != "torch":
+        # a scaling run must measure the in-library RCCL route, not a silent fallback to torch's all-gather
+        assert searcher.collective.startswith("ncclAllGather"), (
+            f"rank {rank}: the exchange fell back to {searcher.collective!r}; set MVDB_COLLECTIVE=torch to bench that "
+            "route on purpose")
 
     def barrier():
         if world > 1:

@@ -5,6 +5,12 @@ Public surface mirrors the reference package (minivectordb/): ``VectorDatabase``
 hand-written HIP kernels behind the C-ABI in include/mvdb.h; there is no CPU fallback.
 """
 
+import os as _os
+
+# RCCL / cross-process device tensors need dmabuf IPC on this host driver; it has to be in the environment before the
+# first HIP call of the process (harmless for single-GPU use)
+_os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 __all__ = ["VectorDatabase", "ShardedVectorDatabase", "DistributedShardedVectorDatabase", "EmbeddingModel",
            "AlternativeModel"]
 

@@ -81,12 +81,15 @@ class _RowStore:
 
     def flush(self, index):
         """Upload the pending rows (normalised on the device, vector_database.py:45-46) and forget the host copies."""
-        for block in self.pending:
+        # a block leaves `pending` the moment it is on the device: if a later add raises (hipMalloc while growing),
+        # the rows already uploaded are not uploaded again by the next build
+        while self.pending:
+            block = self.pending[0]
             index.add(block, normalize=True)
+            self.pending.pop(0)
+            self.npending -= block.shape[0]
             self.synced += block.shape[0]
-        if self.pending:
             self._cache = None
-        self.pending, self.npending = [], 0
 
     def delete(self, rows, index):
         """Remove the given stacked row numbers (np.delete semantics: later rows move up)."""

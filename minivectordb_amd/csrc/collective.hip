@@ -53,7 +53,8 @@ Rccl* rccl() {
             for (const char* n : names)
                 if ((r.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
         if (!r.handle) {
-            r.why = std::string("librccl.so not loadable: ") + (dlerror() ? dlerror() : "unknown");
+            const char* de = dlerror();  // ONE call: dlerror() clears the error state
+            r.why = std::string("librccl.so not loadable: ") + (de ? de : "unknown");
             return;
         }
         r.GetUniqueId = (fn_GetUniqueId)dlsym(r.handle, "ncclGetUniqueId");

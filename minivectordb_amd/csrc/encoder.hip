@@ -1614,7 +1614,10 @@ struct mvdb_encoder {
     bool have_bf16 = false, have_x3 = false;
     // workspace (grown on demand), guarded by mu: one forward at a time per encoder
     std::mutex mu;
-    int64_t cap_tokens = 0, cap_b = 0;
+    uint64_t ws_gen = 0;                  // bumped whenever the workspace is reallocated
+    int64_t cap_tokens = 0, cap_b = 0;    // lane 0 (a whole batch)
+    int64_t cap1_tokens = 0, cap1_b = 0;  // lane 1 (the larger half of a split batch): its own capacity — ceil(B / 2) * S of
+                                          // a later call can exceed half of what lane 0 was sized for (odd B, longer S)
     // Two lanes: lane 0 holds a whole batch; when a batch is split in two halves that run concurrently on two streams
     // (enqueue_split), lane 1 holds the second half.
     struct Lane {
@@ -1640,7 +1643,7 @@ struct mvdb_encoder {
     void free_ws() {
         lane[0].release();
         lane[1].release();
-        cap_tokens = cap_b = 0;
+        cap_tokens = cap_b = cap1_tokens = cap1_b = 0;
     }
 };
 
@@ -1698,13 +1701,19 @@ int alloc_lane(mvdb_encoder* e, mvdb_encoder::Lane& w, int64_t B, int64_t tokens
 
 int ensure_ws(mvdb_encoder* e, int B, int S) {
     const int64_t tokens = (int64_t)B * S;
-    if (tokens <= e->cap_tokens && B <= e->cap_b) return 0;
+    const int64_t b1 = B - B / 2;  // the larger half of a split batch
+    if (tokens <= e->cap_tokens && B <= e->cap_b && b1 * S <= e->cap1_tokens && b1 <= e->cap1_b) return 0;
+    // grow, never shrink: each lane gets the larger of what it had and what this call needs
+    const int64_t t0 = std::max(tokens, e->cap_tokens), c0 = std::max<int64_t>(B, e->cap_b);
+    const int64_t t1 = std::max(b1 * S, e->cap1_tokens), c1 = std::max(b1, e->cap1_b);
     e->free_ws();
-    MVDB_TRY(alloc_lane(e, e->lane[0], B, tokens));
-    const int64_t b1 = B - B / 2;  // the larger half
-    MVDB_TRY(alloc_lane(e, e->lane[1], b1, b1 * S));
-    e->cap_tokens = tokens;
-    e->cap_b = B;
+    ++e->ws_gen;
+    MVDB_TRY(alloc_lane(e, e->lane[0], c0, t0));
+    MVDB_TRY(alloc_lane(e, e->lane[1], c1, t1));
+    e->cap_tokens = t0;
+    e->cap_b = c0;
+    e->cap1_tokens = t1;
+    e->cap1_b = c1;
     return 0;
 }
 
@@ -2148,9 +2157,9 @@ int forward_core(mvdb_encoder* e, const int32_t* ids, const int32_t* mask, int B
         else
             MVDB_TRY(ensure_x3_weights(e, s));
     }
-    const int64_t cap_before = e->cap_tokens;
+    const uint64_t gen_before = e->ws_gen;
     MVDB_TRY(ensure_ws(e, B, S));
-    if (e->cap_tokens != cap_before) e->drop_graphs();  // workspace moved: captured pointers are stale
+    if (e->ws_gen != gen_before) e->drop_graphs();  // workspace moved: captured pointers are stale
 
     // ~90 short launches per forward: replay them as ONE hipGraph per (shape, buffers) instead of paying
     // the host launch path per kernel (the S = 32 forward is launch-bound otherwise)

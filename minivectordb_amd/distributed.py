@@ -68,6 +68,106 @@ def shard_ranges(total_rows, world):
     return out
 
 
+class Collective:
+    """The exchange route of one process group, decided ONCE and shared by every searcher that uses the group:
+    RCCL's ``ncclAllGather`` issued from inside libmvdb.so (``native``: one communicator per ``Collective``), or the
+    process group's own ``all_gather_into_tensor`` (``torch``).
+
+    want = None (or ``MVDB_COLLECTIVE`` unset): native on an RCCL group with GPU tensors, torch otherwise; a native
+    route that cannot be brought up falls back to torch, loudly, on EVERY rank together.
+    want = "native" asked for EXPLICITLY (argument or ``MVDB_COLLECTIVE=native``): failure raises on every rank — a
+    broken native route must not be masked by the fallback (the bench line's `collective` field would be the only tell).
+    """
+
+    TORCH = "torch.distributed.all_gather_into_tensor"
+    NATIVE = "ncclAllGather (mvdb_allgather_topk, libmvdb.so)"
+
+    def __init__(self, rank, world, device, group=None, want=None):
+        self.rank, self.world, self.device, self.group = int(rank), int(world), device, group
+        self.comm = None
+        self.name = "none"
+        if self.world > 1:
+            self.name = self._pick(want)
+
+    def _agree(self, ok):
+        """MIN over the ranks of a local 0/1 — every rank must reach this call whatever happened to it before."""
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=self.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
+        return int(t.item()) == 1
+
+    def _pick(self, want):
+        want = want or os.environ.get("MVDB_COLLECTIVE")
+        explicit = want == "native"
+        on_gpu = self.device.type == "cuda"
+        backend = dist.get_backend(self.group) if dist.is_initialized() else None
+        if want is None:
+            want = "native" if (on_gpu and backend == "nccl") else "torch"
+        if want == "torch":
+            return self.TORCH
+        if want != "native":
+            raise ValueError(f"MVDB_COLLECTIVE must be 'native' or 'torch' (got {want!r})")
+        from . import _native
+
+        def give_up(why):
+            if self.comm is not None:
+                self.comm.close()
+                self.comm = None
+            if explicit:
+                raise RuntimeError(f"MVDB_COLLECTIVE=native was requested but the RCCL route of libmvdb.so is "
+                                   f"unavailable on rank {self.rank}: {why}")
+            print(f"[mvdb] rank {self.rank}: native RCCL communicator unavailable ({why}); using {self.TORCH}",
+                  file=sys.stderr, flush=True)
+            return self.TORCH
+
+        # Agree FIRST: ncclCommInitRank blocks until every rank has joined, so a rank that cannot bind librccl must be
+        # known to all before anybody enters it.
+        bound = on_gpu and _native.lib().mvdb_comm_available() == 0
+        if not self._agree(bound):
+            return give_up("librccl could not be bound on every rank" + ("" if bound else f" ({_native.last_error()})"))
+        # From here on a rank that fails still takes part in every collective below: the outcome is decided by ONE
+        # MIN all-reduce that all ranks reach, so no rank can end up on a different route than its peers.
+        err = None
+        box = [None]
+        try:
+            # rank 0 draws the RCCL unique id; the launcher's process group is only the side channel for it
+            if self.rank == 0:
+                box[0] = _native.Comm.unique_id()
+        except Exception as e:
+            err = e
+        dist.broadcast_object_list(box, src=dist.get_global_rank(self.group, 0) if self.group else 0, group=self.group)
+        if not self._agree(box[0] is not None):
+            return give_up(f"no unique id ({err})")
+        good = False
+        try:
+            self.comm = _native.Comm(box[0], self.rank, self.world, device=self.device.index or 0)
+            # one probe gather: every rank must see every rank's block in rank order
+            mine = torch.full((16,), self.rank, dtype=torch.uint8, device=self.device)
+            allb = torch.full((16 * self.world,), 255, dtype=torch.uint8, device=self.device)
+            self.comm.allgather(mine.data_ptr(), allb.data_ptr(), 16, stream=torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            want_t = torch.arange(self.world, dtype=torch.uint8, device=self.device).repeat_interleave(16)
+            good = bool(torch.equal(allb, want_t))
+            if not good:
+                err = "probe all-gather returned the wrong blocks"
+        except Exception as e:
+            err = e
+        if not self._agree(good):
+            return give_up(err if err is not None else "another rank failed to bring the communicator up")
+        return self.NATIVE
+
+    def all_gather(self, gathered, local):
+        if self.comm is not None:
+            self.comm.allgather(local.buf.data_ptr(), gathered.buf.data_ptr(), local.nbytes,
+                                stream=torch.cuda.current_stream().cuda_stream)
+        else:
+            dist.all_gather_into_tensor(gathered.buf, local.buf, group=self.group)
+
+    def close(self):
+        if self.comm is not None:
+            self.comm.close()
+            self.comm = None
+
+
 class ShardedSearcher:
     """Search this rank's shard, all-gather the per-shard top-k, merge.
 
@@ -77,6 +177,8 @@ class ShardedSearcher:
     local_search   callable(q, D_view, I_view, label_offset, rows=None, normalize_q=False): fills the views
                    (device tensors); `rows` = int64 device tensor of LOCAL row numbers to restrict the scan to
     merge          callable(gathered: PackedTopK, D_out, I_out): merges `world` lists
+    collective     None / "native" / "torch" (a route to bring up for this searcher), or a `Collective` that several
+                   searchers share (it is then NOT closed by this searcher)
     """
 
     def __init__(self, index, k, rank=0, world=1, rows_per_rank=None, label_offset=None, device=None, group=None,
@@ -91,61 +193,13 @@ class ShardedSearcher:
         self._local_search = local_search or self._hip_local_search
         self._merge = merge or self._hip_merge
         self._bufs = {}
-        self._comm = None
-        self.collective = "none"
-        if self.world > 1:
-            self.collective = self._pick_collective(collective)
-
-    # ---- the exchange: ncclAllGather inside libmvdb.so, or the process group's all-gather -------
-    def _pick_collective(self, want):
-        want = want or os.environ.get("MVDB_COLLECTIVE")
-        on_gpu = self.device.type == "cuda"
-        backend = dist.get_backend(self.group) if dist.is_initialized() else None
-        if want is None:
-            want = "native" if (on_gpu and backend == "nccl") else "torch"
-        if want == "torch":
-            return "torch.distributed.all_gather_into_tensor"
-        if want != "native":
-            raise ValueError(f"MVDB_COLLECTIVE must be 'native' or 'torch' (got {want!r})")
-        from . import _native
-        # Agree FIRST: ncclCommInitRank blocks until every rank has joined, so a rank that cannot bind librccl must be
-        # known to all before anybody enters it.
-        ok = torch.tensor([1 if _native.lib().mvdb_comm_available() == 0 else 0], dtype=torch.int32, device=self.device)
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.group)
-        if int(ok.item()) == 0:
-            print(f"[mvdb] rank {self.rank}: librccl could not be bound on every rank ({_native.last_error()}); "
-                  "using torch.distributed.all_gather_into_tensor", file=sys.stderr, flush=True)
-            return "torch.distributed.all_gather_into_tensor"
-        try:
-            # rank 0 draws the RCCL unique id; the launcher's process group is only the side channel for it
-            box = [_native.Comm.unique_id() if self.rank == 0 else None]
-            dist.broadcast_object_list(box, src=dist.get_global_rank(self.group, 0) if self.group else 0,
-                                       group=self.group)
-            self._comm = _native.Comm(box[0], self.rank, self.world, device=self.device.index or 0)
-            # one probe gather: every rank must see every rank's block in rank order
-            mine = torch.full((16,), self.rank, dtype=torch.uint8, device=self.device)
-            allb = torch.full((16 * self.world,), 255, dtype=torch.uint8, device=self.device)
-            stream = torch.cuda.current_stream().cuda_stream
-            self._comm.allgather(mine.data_ptr(), allb.data_ptr(), 16, stream=stream)
-            torch.cuda.synchronize()
-            want_t = torch.arange(self.world, dtype=torch.uint8, device=self.device).repeat_interleave(16)
-            good = torch.tensor([1 if torch.equal(allb, want_t) else 0], dtype=torch.int32, device=self.device)
-            dist.all_reduce(good, op=dist.ReduceOp.MIN, group=self.group)
-            if int(good.item()) == 0:
-                raise RuntimeError("probe all-gather returned the wrong blocks on some rank")
-            return "ncclAllGather (mvdb_allgather_topk, libmvdb.so)"
-        except Exception as e:  # both routes are RCCL over xGMI; say loudly which one is in use
-            print(f"[mvdb] rank {self.rank}: native RCCL communicator unavailable ({e}); "
-                  "using torch.distributed.all_gather_into_tensor", file=sys.stderr, flush=True)
-            self._comm = None
-            return "torch.distributed.all_gather_into_tensor"
+        self._owns_collective = not isinstance(collective, Collective)
+        self._collective = collective if isinstance(collective, Collective) else Collective(
+            self.rank, self.world, self.device, group=group, want=collective)
+        self.collective = self._collective.name
 
     def _all_gather(self, gathered, local):
-        if self._comm is not None:
-            self._comm.allgather(local.buf.data_ptr(), gathered.buf.data_ptr(), local.nbytes,
-                                 stream=torch.cuda.current_stream().cuda_stream)
-        else:
-            dist.all_gather_into_tensor(gathered.buf, local.buf, group=self.group)
+        self._collective.all_gather(gathered, local)
 
     # ---- defaults: HIP kernels through the C-ABI ------------------------------------------------
     def _hip_local_search(self, q, D, I, label_offset, rows=None, normalize_q=False):
@@ -198,9 +252,9 @@ class ShardedSearcher:
         return D_out, I_out
 
     def close(self):
-        if self._comm is not None:
-            self._comm.close()
-            self._comm = None
+        if self._owns_collective:
+            self._collective.close()
+        self._bufs = {}
 
 
 class DistributedShardedVectorDatabase:
@@ -208,15 +262,18 @@ class DistributedShardedVectorDatabase:
     ``find_most_similar`` of ``ShardedVectorDatabase`` with the stacked matrix row-partitioned over the
     ranks of a ``torch.distributed`` job (one process per GPU).
 
-    Every rank loads the bookkeeping of ALL shard files (ids, metadata, inverted index — global row
-    numbers are the reference's stacking order, sharded_vector_database.py:45-71) but keeps only the
-    embeddings of its own contiguous run of shard files (``shard_files_for_rank``) resident in HBM.
+    Every rank unpickles ONLY its own contiguous run of shard files (``shard_files_for_rank``; `files_opened` lists
+    them) — their embeddings go to its HBM, their bookkeeping (ids, metadata, inverted index) is exchanged with one
+    ``all_gather_object`` so that every rank ends up with the bookkeeping of ALL shards (global row numbers are the
+    reference's stacking order, sharded_vector_database.py:45-71) without any rank reading another rank's
+    embeddings from disk (at BASELINE config 4 that would be 164 GB read eight times).
     ``find_most_similar`` is SPMD: every rank calls it with the same arguments and gets the same,
     global answer — local scan (full, or restricted to the filtered rows this rank owns) written straight
     into the packed exchange block on the device, ONE all-gather of the per-shard top-k, k-way merge on
     every rank, one copy of the k results to the host.  Exact score ties resolve to the lower global row
     number.  Writes are not supported in this mode (build the directory with ``ShardedVectorDatabase``);
-    world * k <= 16384 (one block sorts the gathered lists in LDS).
+    world * k <= 16384 (one block sorts the gathered lists in LDS).  The exchange route (RCCL communicator) is
+    brought up once per database and shared by the per-k searchers; `close()` releases it.
 
     `index_factory` / `local_search` / `merge` exist for the world_size-2 ``gloo`` test on CPU.
     """
@@ -241,33 +298,38 @@ class DistributedShardedVectorDatabase:
         self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
         self.storage_dir = storage_dir
 
-        files = [f for f in os.listdir(storage_dir) if f.endswith('.pkl')]
-        files.sort(key=lambda x: int(x.split('_')[1].split('.')[0]))
-        mine = set(shard_files_for_rank(storage_dir, self.rank, self.world))
-        self.metadata, self.unique_ids = [], []
-        self.inverted_index = defaultdict(set)
-        pieces, self.first_row, self.local_rows = [], None, 0
-        for fname in files:
+        mine = shard_files_for_rank(storage_dir, self.rank, self.world)
+        self.files_opened = []
+        book, pieces = [], []   # book: this rank's files in order, (unique_ids, metadata, inverted_index)
+        for fname in mine:
             with open(os.path.join(storage_dir, fname), 'rb') as f:
                 data = pickle.load(f)
-            if fname in mine:
-                if self.first_row is None:
-                    self.first_row = len(self.unique_ids)
-                pieces.append(np.asarray(data['embeddings'], dtype=np.float32))
-                self.local_rows += len(data['unique_ids'])
-            self.metadata.extend(data['metadata'])
-            self.unique_ids.extend(data['unique_ids'])
-            for key, value in data['inverted_index'].items():
-                self.inverted_index[key].update(value)
+            self.files_opened.append(fname)
+            pieces.append(np.asarray(data['embeddings'], dtype=np.float32))
+            book.append((data['unique_ids'], data['metadata'], dict(data['inverted_index'])))
             del data
-        if self.first_row is None:
-            self.first_row = len(self.unique_ids)
+        self.local_rows = sum(len(b[0]) for b in book)
+        dim = pieces[0].shape[1] if pieces else None
+        if self.world > 1:
+            # ranks own contiguous runs of files in rank order, so rank order IS the reference's stacking order
+            everyone = [None] * self.world
+            dist.all_gather_object(everyone, (book, dim), group=group)
+        else:
+            everyone = [(book, dim)]
+        self.metadata, self.unique_ids = [], []
+        self.inverted_index = defaultdict(set)
+        self.first_row = 0
+        for r, (rbook, _) in enumerate(everyone):
+            if r == self.rank:
+                self.first_row = len(self.unique_ids)
+            for uids, metas, inv in rbook:
+                self.metadata.extend(metas)
+                self.unique_ids.extend(uids)
+                for key, value in inv.items():
+                    self.inverted_index[key].update(value)
         self.inverse_id_map = {uid: i for i, uid in enumerate(self.unique_ids)}
-        self.embedding_size = pieces[0].shape[1] if pieces else None
-        if self.world > 1:  # ranks without rows still need the dimension
-            dims = [None] * self.world
-            dist.all_gather_object(dims, self.embedding_size, group=group)
-            self.embedding_size = next((x for x in dims if x), None)
+        self.embedding_size = next((d for _, d in everyone if d), None)  # ranks without rows still need the dimension
+        del everyone, book
 
         # the reference's filter engine, bound to this object's bookkeeping
         class _Filters(FilterAndRerankMixin):
@@ -289,6 +351,9 @@ class DistributedShardedVectorDatabase:
         self._local_search = local_search
         self._merge = merge
         self._searchers = {}
+        # ONE exchange route for the whole database (search_k = min(k, hits) changes with every filter: a communicator per
+        # distinct k would put ncclCommInitRank on the query path and never free it)
+        self._collective = Collective(self.rank, self.world, self.device, group=group)
 
     def autocut_scores(self, score_list):
         return self._filters.autocut_scores(score_list)
@@ -296,11 +361,20 @@ class DistributedShardedVectorDatabase:
     def _searcher(self, k):
         s = self._searchers.get(k)
         if s is None:
+            if len(self._searchers) >= 64:   # per-k exchange buffers only: cheap to drop and rebuild
+                self._searchers.clear()
             s = ShardedSearcher(self.index, k, rank=self.rank, world=self.world, label_offset=self.first_row,
                                 device=self.device, group=self.group, local_search=self._local_search,
-                                merge=self._merge)
+                                merge=self._merge, collective=self._collective)
             self._searchers[k] = s
         return s
+
+    def close(self):
+        """Release the exchange route (RCCL communicator) and the per-k buffers; the device index stays usable."""
+        for s in self._searchers.values():
+            s.close()
+        self._searchers = {}
+        self._collective.close()
 
     def find_most_similar(self, embedding, metadata_filter=None, exclude_filter=None, or_filters=None, k=5,
                           autocut=False):

@@ -7,12 +7,12 @@ Same public methods, arguments, return types and error behaviour as the referenc
 autocut, pickle format) is Python as in the reference.  What changed underneath:
 
 * ``faiss.IndexFlatIP`` + ``faiss.normalize_L2``  ->  one device-resident matrix (``FlatIndex``);
-  rows are normalised on the device and the normalised rows are copied back into the host matrix,
-  reproducing the reference's in-place side effect (vector_database.py:45) that ``get_vector`` and
-  ``persist_to_disk`` expose.
+  rows are normalised on the device, which is then their ONLY home (``_dbcore._RowStore``: no host
+  mirror).  ``get_vector`` / ``embeddings`` / ``persist_to_disk`` read the device rows back, so the
+  reference's in-place normalisation side effect (vector_database.py:45) stays visible.
 * A write no longer forces an O(N*d) rebuild at the next query (vector_database.py:477-479,
-  :42-47): appended rows are uploaded incrementally, deleted rows are compacted on the device.
-* The host matrix grows geometrically instead of ``np.vstack`` per insert (:72, :107).
+  :42-47): rows stored since the last build wait in host blocks and are uploaded incrementally,
+  deleted rows are compacted on the device (no ``np.vstack`` per insert, :72, :107).
 * With no filter the reference materialises ``set(inverse_id_map.values())`` per query (:356);
   here "all rows" is represented symbolically.
 * The filtered branch searches the listed rows of the resident corpus in place

@@ -170,6 +170,18 @@ def _dist_worker(rank, world, port, path, out_dir):
     holder["db"] = db
     assert db._searcher(5).collective == "torch.distributed.all_gather_into_tensor"
     assert db.world == world and db.local_rows > 0
+    # a rank unpickles ONLY its own shard files; the bookkeeping of the others arrives by all_gather_object
+    from minivectordb_amd.sharded_vector_database import shard_files_for_rank
+    assert db.files_opened == shard_files_for_rank(path, rank, world) and len(db.files_opened) == 5
+    assert len(db.unique_ids) == 95 and len(db.metadata) == 95
+    # every per-k searcher shares the database's ONE exchange route
+    assert db._searcher(7)._collective is db._searcher(5)._collective is db._collective
+    # an EXPLICIT request for the native RCCL route must raise where it cannot be brought up (gloo group, CPU
+    # tensors) instead of silently measuring the torch route — on every rank together, no rank left in a collective
+    from minivectordb_amd.distributed import Collective
+    with pytest.raises(RuntimeError, match="MVDB_COLLECTIVE=native"):
+        Collective(rank, world, torch.device("cpu"), want="native")
+    assert Collective(rank, world, torch.device("cpu")).name == Collective.TORCH
     q = flat.synth(len(QUERIES), 48, 654)
     res = []
     for i, kw in enumerate(QUERIES):
@@ -177,6 +189,7 @@ def _dist_worker(rank, world, port, path, out_dir):
         res.append((list(ids), [float(v) for v in dists], list(metas)))
     with open(os.path.join(out_dir, f"res{rank}.pkl"), "wb") as f:
         pickle.dump((res, db.first_row, db.local_rows), f)
+    db.close()
     dist.barrier()
     dist.destroy_process_group()
 
