@@ -17,6 +17,14 @@ Inputs are resident in HBM when the timed region starts (corpus and all W+K quer
 on the device beforehand); results stay on the device.  The PCIe-inclusive host API rate is
 reported separately as `host_api_qps` and is never `value`.
 
+Beside the headline, at N = 1 the same JSON line carries two more blocks, measured OUTSIDE the headline's timed region
+(BASELINE config 5; --no-encoder skips them):
+  "encoder": the e5-small-shaped encoder forward (256 sentences, S = 32 and 512) in the drop-in's default arithmetic
+             (split-precision fp16 x 3 on the 16-bit matrix cores) and in the exact fp32-MFMA mode, each with its MFMA
+             roofline, next to `cpu_baseline` = transformers' own BertModel (what the reference runs,
+             minivectordb/embedding_model.py:62-71) + average_pool + F.normalize on this box's host cores;
+  "config5": encoder forward -> 256 queries -> kNN over a resident 10M x 384 corpus, end to end on the device.
+
 Launch: python bench.py [--gpus 1]       or, for N > 1 (the driver does this):
         python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
                --master-port P bench.py --gpus N --steps K --warmup W
@@ -124,6 +132,154 @@ def cpu_baseline(native, idx, d, k, queries_host, full_rows, budget_s=20.0):
     }
 
 
+MFMA_PEAK_TF = {"fp16x3": 2500.0, "fp32": 157.3}   # dense peaks, /opt/skills/guides/MI355X_MICROARCH.md
+E5_SMALL = {"model_type": "bert", "vocab_size": 250037, "hidden_size": 384, "num_hidden_layers": 12,
+            "num_attention_heads": 12, "intermediate_size": 1536, "max_position_embeddings": 512, "type_vocab_size": 2,
+            "layer_norm_eps": 1e-12, "hidden_act": "gelu", "pad_token_id": 0}
+
+
+def encoder_flops(lens, cfg):
+    """Algorithmic FLOPs of one forward: the four GEMMs per layer + the two attention products."""
+    H, F, L = cfg["hidden_size"], cfg["intermediate_size"], cfg["num_hidden_layers"]
+    gemm = float(sum(lens)) * L * (4 * 2 * H * H + 2 * 2 * H * F)
+    attn = float(sum(L * 4 * int(n) * int(n) * H for n in lens))
+    return gemm + attn
+
+
+def encoder_and_config5(native, dev, k, no_cpu):
+    """BASELINE config 5 where the driver sees it: encoder forward (256 sentences) alone, its CPU baseline, and encoder ->
+    256-query kNN over 10M x 384 end to end.  Weights are seeded random tensors of the e5-small architecture (no
+    checkpoint offline); the SAME weights run on the CPU through transformers' BertModel."""
+    import numpy as np
+    import torch
+    from transformers import BertConfig, BertModel
+    from minivectordb_amd.embedding_model import GpuEncoder
+
+    torch.manual_seed(0)
+    hf = BertModel(BertConfig(**{kk: v for kk, v in E5_SMALL.items() if kk != "model_type"}), add_pooling_layer=False).eval()
+    with torch.no_grad():  # HF's init: 0.02-sigma weights, zero biases, unit LayerNorm — make every term count
+        for name, p in hf.named_parameters():
+            if name.endswith("bias"):
+                p.add_(0.1 * torch.randn_like(p))
+            elif "LayerNorm.weight" in name:
+                p.add_(0.2 * torch.randn_like(p))
+            elif "dense.weight" in name or "self." in name:
+                p.mul_(2.5)
+    enc = GpuEncoder(hf.config, hf.state_dict(), device=dev.index or 0)
+    B, H = 256, E5_SMALL["hidden_size"]
+    torch.cuda.set_stream(torch.cuda.Stream(dev))  # a real stream: the encoder replays its captured hipGraph on it
+    stream = torch.cuda.current_stream().cuda_stream
+    out = {"model": "multilingual-e5-small architecture (BERT, H 384, 12 layers, 12 heads, FFN 1536), seeded weights",
+           "sentences": B, "shapes": []}
+    inputs = {}
+    for S in (32, 512):
+        rs = np.random.RandomState(S)
+        ids = rs.randint(5, 250000, size=(B, S)).astype(np.int32)
+        for ragged in (False, True):
+            lens = rs.randint(max(1, S // 4), S + 1, size=B) if ragged else np.full(B, S)
+            mask = (np.arange(S)[None, :] < lens[:, None]).astype(np.int32)
+            ids_d, mask_d = torch.from_numpy(ids).to(dev), torch.from_numpy(mask).to(dev)
+            inputs[(S, ragged)] = (ids, mask, ids_d, mask_d, lens)
+            flops = encoder_flops(lens, E5_SMALL)
+            rec = {"S": S, "ragged": bool(ragged), "tokens": int(lens.sum())}
+            for mode, compute, products in (("fp16x3", 2, 3), ("fp32", 0, 1)):
+                for _ in range(3):
+                    enc.forward_device(ids_d, mask_d, compute=compute)
+                torch.cuda.synchronize()
+                reps = 20 if S == 32 else 5
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    enc.forward_device(ids_d, mask_d, compute=compute)
+                torch.cuda.synchronize()
+                dt = (time.perf_counter() - t0) / reps
+                tf = products * flops / dt / 1e12   # matrix-core products actually issued
+                rec[mode] = {"ms": round(dt * 1e3, 3), "sentences_per_s": round(B / dt, 1),
+                             "roofline": {"bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_PEAK_TF[mode],
+                                          "unit": "TFLOP/s", "frac": round(tf / MFMA_PEAK_TF[mode], 4),
+                                          "mfma_products_per_algorithmic_product": products,
+                                          "algorithmic_tflop_per_forward": round(flops / 1e12, 4)}}
+            out["shapes"].append(rec)
+    out["default_mode"] = "fp16x3 (split-precision: a.w ~ al.wh + ah.wl + ah.wh in fp16 pieces, fp32 accumulate)"
+
+    # ---- CPU baseline: the reference's own forward (transformers BertModel + average_pool + F.normalize) ------------
+    if not no_cpu:
+        import torch.nn.functional as F
+        threads = torch.get_num_threads()
+
+        def cpu_forward(ids, mask):
+            with torch.no_grad():
+                bi, bm = torch.from_numpy(ids.astype(np.int64)), torch.from_numpy(mask.astype(np.int64))
+                o = hf(input_ids=bi, attention_mask=bm).last_hidden_state
+                o = o.masked_fill(~bm[..., None].bool(), 0.0)
+                return F.normalize(o.sum(dim=1) / bm.sum(dim=1)[..., None], p=2, dim=1).numpy()
+
+        cpu = {"kind": "reference", "cores": threads, "unit": "sentences/s",
+               "what": "transformers BertModel (the library the reference calls) + average_pool + F.normalize, torch CPU"}
+        ids, mask, ids_d, mask_d, lens = inputs[(32, True)]
+        cpu_forward(ids[:32], mask[:32])  # warm the thread pool
+        t0 = time.perf_counter()
+        ref = cpu_forward(ids, mask)
+        t32 = time.perf_counter() - t0
+        got, _ = enc.forward_device(ids_d, mask_d)
+        torch.cuda.synchronize()
+        cpu["S32_ragged"] = {"ms_per_256_sentences": round(t32 * 1e3, 1), "value": round(B / t32, 1),
+                             "sample": "the whole 256-sentence batch, once"}
+        cpu["max_abs_diff_gpu_vs_cpu_embedding"] = float(np.abs(got.cpu().numpy() - ref).max())
+        ids, mask, _, _, lens = inputs[(512, True)]
+        nb = 16  # bounded sample: 16 of the 256 sentences
+        t0 = time.perf_counter()
+        cpu_forward(ids[:nb], mask[:nb])
+        t512 = time.perf_counter() - t0
+        frac = float(lens[:nb].sum()) / float(lens.sum())
+        cpu["S512_ragged"] = {"ms_per_256_sentences": round(t512 / frac * 1e3, 1), "value": round(B * frac / t512, 1),
+                              "sample": f"first {nb} of 256 sentences ({frac:.3f} of the tokens), time scaled by tokens"}
+        cpu["value"] = cpu["S32_ragged"]["value"]
+        out["cpu_baseline"] = cpu
+    else:
+        out["cpu_baseline"] = None
+
+    # ---- config 5 end to end: encoder -> 256 queries -> kNN over 10M x 384, nothing leaves the device -----------------
+    n5 = 10_000_000
+    idx5 = native.FlatIndex(H, device=dev.index or 0)
+    idx5.reserve(n5)
+    idx5.add_synthetic(n5, 1234, normalize=True)
+    D = torch.empty((B, k), dtype=torch.float32, device=dev)
+    I = torch.empty((B, k), dtype=torch.int64, device=dev)
+    c5 = {"workload": f"256 sentences -> e5-small-shaped encoder -> 256 x {H} queries -> IP kNN, k = {k}, over {n5} x {H} fp32",
+          "shapes": []}
+    for S in (32, 512):
+        _, _, ids_d, mask_d, lens = inputs[(S, True)]
+
+        def step():
+            emb, _ = enc.forward_device(ids_d, mask_d)
+            idx5.search_device(emb.data_ptr(), B, k, D.data_ptr(), I.data_ptr(), stream=stream)
+
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        reps = 5
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            enc.forward_device(ids_d, mask_d)
+        torch.cuda.synchronize()
+        t_enc = (time.perf_counter() - t0) / reps
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            step()
+        torch.cuda.synchronize()
+        t_all = (time.perf_counter() - t0) / reps
+        passes = -(-B // max(native.half_max_queries(H), 128))
+        knn_gbs = passes * n5 * H * 4 / max(t_all - t_enc, 1e-9) / 1e9
+        c5["shapes"].append({"S": S, "ragged": True, "tokens": int(lens.sum()), "encoder_ms": round(t_enc * 1e3, 3),
+                             "knn_ms": round((t_all - t_enc) * 1e3, 3), "end_to_end_ms": round(t_all * 1e3, 3),
+                             "sentences_per_s": round(B / t_all, 1), "knn_corpus_passes": passes,
+                             "knn_roofline": {"bound": "hbm", "achieved": round(knn_gbs, 1), "peak": HBM_PEAK_GBS,
+                                              "unit": "GB/s", "frac": round(knn_gbs / HBM_PEAK_GBS, 4)}})
+    idx5.close()
+    enc.close()
+    return out, c5
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -135,6 +291,7 @@ def main():
     ap.add_argument("--nq", type=int, default=1, help="queries per step (1 = the reference API shape; >1 = one "
                     "multi-query MFMA pass per step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-encoder", action="store_true", help="skip the encoder / config-5 blocks")
     ap.add_argument("--dump", default=None, help="rank 0 writes the merged (D, I) of the first 16 timed steps to this "
                     ".npz (tests/test_config4_gpu.py compares them with a single-index search)")
     args = ap.parse_args()
@@ -339,6 +496,14 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(native, idx, d, k, qh, n)
             else:
                 out["cpu_baseline"] = None
+            if not args.no_encoder and nq == 1:
+                searcher.close()
+                idx.close()   # the headline corpus (20 GB) is no longer needed
+                try:
+                    out["encoder"], out["config5"] = encoder_and_config5(native, dev, k, args.no_cpu_baseline)
+                except Exception as e:  # the headline line must survive a failure of the secondary blocks
+                    out["encoder"] = {"error": f"{type(e).__name__}: {e}"}
+                    out["config5"] = None
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)

@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """BASELINE config 5, encoder half: multilingual-e5-small-shaped encoder forward (random-init
-weights, synthetic token ids), batch 256, S in {32, 512}.  Reports sentences/s and TFLOP/s of the
-exact-fp32 MFMA path against the 157.3 TFLOP/s fp32 matrix peak."""
+weights, synthetic token ids), batch 256, S in {32, 512}.  Reports sentences/s and, per arithmetic mode, the
+matrix-core rate against THAT mode's peak (/opt/skills/guides/MI355X_MICROARCH.md): the exact mode issues fp32 MFMAs
+(157.3 TFLOP/s); the split-precision mode issues THREE fp16 products per fp32 product on the 16-bit cores (2,500 TFLOP/s
+dense) — its fraction is 3 x the algorithmic FLOPs / time / 2.5e15, never a fraction of the fp32 peak.
+MVDB_BENCH_S="32,512", MVDB_BENCH_COMPUTE="0,2,1", MVDB_BENCH_REPS=10, MVDB_BENCH_MODEL=e5-small|e5-large."""
 import json
 import os
 import sys
@@ -61,11 +64,13 @@ def main():
             lens = rs.randint(S // 4, S + 1, size=B) if ragged else np.full(B, S)
             mask = torch.from_numpy((np.arange(S)[None, :] < lens[:, None]).astype(np.int32)).to(dev)
             T = int(lens.sum())
-            for compute in ((0, 2, 1) if model == "e5-small" else (0, 2)):
+            modes = os.environ.get("MVDB_BENCH_COMPUTE")
+            modes = [int(v) for v in modes.split(",")] if modes else ([0, 2, 1] if model == "e5-small" else [0, 2])
+            for compute in modes:
                 for _ in range(3):
                     enc.forward_device(ids, mask, compute=compute)
                 torch.cuda.synchronize()
-                n = 10
+                n = int(os.environ.get("MVDB_BENCH_REPS", "10"))
                 t0 = time.perf_counter()
                 for _ in range(n):
                     enc.forward_device(ids, mask, compute=compute)
@@ -77,7 +82,11 @@ def main():
                                   "tokens": T, "ms": round(dt * 1e3, 3), "sentences_per_s": round(B / dt, 1),
                                   "tflops": round((gemm + attn) / dt / 1e12, 2), "gemm_tflop": round(gemm / 1e12, 3),
                                   "attn_tflop": round(attn / 1e12, 3),
-                                  "frac_of_fp32_mfma_peak": round((gemm + attn) / dt / 157.3e12, 4)}), flush=True)
+                                  # matrix-core products issued per algorithmic product, and the peak they run against
+                                  "mfma_products_per_flop": {0: 1, 1: 1, 2: 3}[compute],
+                                  "mfma_peak_tflops": {0: 157.3, 1: 2500.0, 2: 2500.0}[compute],
+                                  "frac_of_mfma_peak": round({0: 1, 1: 1, 2: 3}[compute] * (gemm + attn) / dt /
+                                                             ({0: 157.3e12, 1: 2.5e15, 2: 2.5e15}[compute]), 4)}), flush=True)
     enc.close()
 
 

@@ -114,6 +114,11 @@ __global__ __launch_bounds__(256) void pack_fill_kernel(const int32_t* __restric
 // every lane stores ONE dword: even lanes the hi pieces of columns (c, c + 1), odd lanes the lo pieces of (c - 1, c).
 // Both lanes of a pair must call it (`ok` = store or not, the same for both).
 __device__ __forceinline__ void x3_pair_store(float* line, int c, float v, bool ok) {
+    // v is made opaque first: otherwise hipcc may contract the producer's multiply-add INTO the conversion
+    // (v_fma_mixlo_f16: one rounding of the exact fma to fp16) at some call sites and not at others, so that the same
+    // row got different (hi, lo) bits on the branch-free and on the edge path of an epilogue — the result of a sentence
+    // then depended, in the last bit, on where it sat in the batch
+    asm volatile("" : "+v"(v));
     const _Float16 h = (_Float16)v;
     const _Float16 l = (_Float16)(v - (float)h);
     union { _Float16 f[2]; uint32_t u; } mine;
@@ -280,7 +285,9 @@ __global__ __launch_bounds__(256) void unpack_hidden_kernel(const float* __restr
 // =================================================================================================
 // GEMM  C[T,N] = A[T,K] · W[N,K]^T + bias (+ epilogue), exact fp32 on v_mfma_f32_32x32x2_f32
 // =================================================================================================
-enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_RESIDUAL = 2 };
+// EPI_BIAS_QKV (split-precision GEMM only): bias, the first `qcols` columns (the queries) scaled by `qscale`
+// (log2(e) / sqrt(head_dim): the attention kernel's score scale), output written as (hi | lo) fp16 lines
+enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_RESIDUAL = 2, EPI_BIAS_QKV = 3 };
 
 constexpr int GBM = 128, GBN = 128, GBK = 16;  // GBM/GBN: the bf16 kernel's tile; fp32 tiles are 64*TI
 
@@ -926,12 +933,51 @@ __device__ __forceinline__ float x3_erf(float x) {
 
 // (hi, lo) fp16 pairs of two fp32 values: 6 VALU (cvt_pk, 2 cvt back, 2 sub, cvt_pk)
 __device__ __forceinline__ void x3_split2(float a, float b, uint32_t& hi, uint32_t& lo) {
+    asm volatile("" : "+v"(a), "+v"(b));  // opaque: no contraction of the producer's multiply-add into the conversion
     union { x3_h2 v; uint32_t u; } h, l;
     h.v = __builtin_convertvector(x3_f2{a, b}, x3_h2);
     const x3_f2 back = __builtin_convertvector(h.v, x3_f2);
     l.v = __builtin_convertvector(x3_f2{a - back[0], b - back[1]}, x3_h2);
     hi = h.u;
     lo = l.u;
+}
+
+// ---- epilogues on TRANSPOSED accumulator tiles ------------------------------------------------------------------------
+// The split-precision GEMMs issue their MFMAs with the WEIGHT fragment as the first operand: D = W_tile A_tile^T, so a
+// lane's column of D is a TOKEN ROW of the output (m = lane & 31) and its 16 registers are 16 of the tile's 32 output
+// columns: register r = column (r & 3) + 8 (r >> 2) + 4 fh — four groups of four consecutive columns, the other lane
+// half (fh ^ 1) holding the groups in between.  What that buys over the natural orientation (one column, 16 rows per lane):
+//   * fp32 outputs / residuals move as 16-byte pieces (4 per tile and lane instead of 16 dwords), the two lane halves
+//     of one instruction writing adjacent pieces: whole 32-byte sectors;
+//   * the (hi | lo) fp16 image of a row is written as 16-byte pieces as well (x3t_store_image: the lane halves trade
+//     four-column groups by v_permlane32_swap so that each ends up with eight consecutive columns): 4 stores per tile and
+//     lane instead of 16, no DPP pairing;
+//   * a row's LayerNorm statistics are sums over the lane's OWN registers plus one exchange with the other half.
+// The stores of a big tile were issue-bound: 128 dword stores per lane on a 256 x 256 tile, as long as its K loop at K = 384.
+__device__ __forceinline__ void x3t_store_image(unsigned char* line, int fh, const float (&v)[16], bool ok) {
+    // line: the 128 bytes [hi 32 | lo 32] of (this lane's row, this tile's 32 columns).  Every lane must take part in the
+    // swaps (EXEC all ones); only the stores are predicated.
+#pragma unroll
+    for (int p2 = 0; p2 < 2; ++p2) {
+        uint32_t ha[2], la[2], hb[2], lb[2];  // a: columns 16 p2 + 4 fh + 0..3, b: columns 16 p2 + 8 + 4 fh + 0..3
+        x3_split2(v[8 * p2], v[8 * p2 + 1], ha[0], la[0]);
+        x3_split2(v[8 * p2 + 2], v[8 * p2 + 3], ha[1], la[1]);
+        x3_split2(v[8 * p2 + 4], v[8 * p2 + 5], hb[0], lb[0]);
+        x3_split2(v[8 * p2 + 6], v[8 * p2 + 7], hb[1], lb[1]);
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {  // fh = 0 keeps (own a, partner's a) = columns 16 p2 .. + 7, fh = 1 (partner's b, own b) = 16 p2 + 8 .. + 15
+            const x3_u2 sh = __builtin_amdgcn_permlane32_swap(ha[e], hb[e], false, false);
+            const x3_u2 sl = __builtin_amdgcn_permlane32_swap(la[e], lb[e], false, false);
+            ha[e] = sh[0];
+            hb[e] = sh[1];
+            la[e] = sl[0];
+            lb[e] = sl[1];
+        }
+        if (ok) {
+            *reinterpret_cast<uint4*>(line + 32 * p2 + 16 * fh) = uint4{ha[0], ha[1], hb[0], hb[1]};
+            *reinterpret_cast<uint4*>(line + 64 + 32 * p2 + 16 * fh) = uint4{la[0], la[1], lb[0], lb[1]};
+        }
+    }
 }
 
 // Block tile 64 x 128 x 32, four waves 2 x 2.  BOTH operands arrive as (hi | lo) fp16 lines — A from the kernel that
@@ -945,7 +991,7 @@ __device__ __forceinline__ void x3_split2(float a, float b, uint32_t& hi, uint32
 //   half a line and the L2 moved twice the W bytes: 4.9M line requests per QKV GEMM at T = 8192)
 //   bank swizzle on the DMA source: slot p of row r holds the row's logical slot p ^ ((r >> 1) & 7)
 // EPI_BIAS_GELU writes its output as (hi | lo) lines too (it only feeds the next GEMM); the other epilogues write fp32.
-// DBG != 0: timing ablations (MVDB_GEMM_X3_DBG; results invalid): 1 = no fragment reads / MFMAs (the DMA ring,
+// dbg != 0: timing ablations (MVDB_GEMM_X3_DBG; results invalid): 1 = no fragment reads / MFMAs (the DMA ring,
 // barriers and epilogue alone), 2 = no DMA (compute on whatever the LDS holds)
 // The 256-row tile form pays off when its tiles make whole rounds of the CUs: at least one round, and either >= 4 rounds
 // or a last round >= 85 % full.  Evaluated on the host with the padded token count (can the form apply at all?) and on the
@@ -956,11 +1002,15 @@ __host__ __device__ inline bool x3_big_form(int64_t T, int N, int bn, int cus) {
     return tiles >= cus && (tiles >= 4 * (int64_t)cus || tiles * 100 >= rounds * cus * 85);
 }
 
-template <int EPI, int BM, int NST, int DBG = 0, int WAVES = 4, int BN = 128>
+template <int EPI, int BM, int NST, int WAVES = 4, int BN = 128, int DBG = 0>
 __global__ __launch_bounds__(WAVES * 64) void gemm_x3_dma_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ Wp,
                                                           float inv_wscale, const float* __restrict__ bias,
                                                           const float* __restrict__ R, float* __restrict__ C,
-                                                          const int* __restrict__ Tptr, int N, int K, int sel_bn, int sel_cus) {
+                                                          const int* __restrict__ Tptr, int N, int K, int sel_bn, int sel_cus,
+                                                          int qcols, float qscale) {
+    // DBG != 0 (builds with -DMVDB_X3_ABLATE + MVDB_GEMM_X3_DBG): timing ablations, results INVALID — 1: no fragment
+    // reads / MFMAs, 2: no DMA, 3: no epilogue, 4: no K loop (epilogue only).  Compile-time: the same switches as a
+    // kernel ARGUMENT cost the default path dearly (S = 512 FFN1 GEMM 553 -> 2,190 us: hipcc spilled around the branches)
     // sel_bn != 0: this launch is one of a PAIR — the 256-row form (sel_bn > 0) and its fallback (sel_bn < 0) — and the
     // number of packed tokens, known only on the device, decides which of the two does the work (x3_big_form)
     if (sel_bn != 0 && x3_big_form(*Tptr, N, sel_bn > 0 ? sel_bn : -sel_bn, sel_cus) != (sel_bn > 0)) return;
@@ -1041,11 +1091,13 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_x3_dma_kernel(const _Float16*
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int nk = K / 32;
+    const int nk = DBG == 4 ? 0 : K / 32;
     // ring: NST - 1 stages in flight.  Stages past the end are issued too (clamped to the last K-step, into buffers
     // nobody reads) so that every counted wait sees a full ring.
+    if (nk > 0) {
 #pragma unroll
-    for (int u = 0; u < NST - 1; ++u) issue(u < nk ? u : nk - 1, u);
+        for (int u = 0; u < NST - 1; ++u) issue(u < nk ? u : nk - 1, u);
+    }
     int st = 0;
     for (int kt = 0; kt < nk; ++kt) {
         __builtin_amdgcn_sched_barrier(0);
@@ -1076,74 +1128,299 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_x3_dma_kernel(const _Float16*
                 ah[i] = *reinterpret_cast<const x3_h8*>(sb + a_off[i][ks][0]);
                 al[i] = *reinterpret_cast<const x3_h8*>(sb + a_off[i][ks][1]);
             }
-            // small cross terms first, the leading product last
+            // small cross terms first, the leading product last; the WEIGHT fragment is the first operand: acc[i][j] is the
+            // transposed tile (lane = token row, registers = output columns, see x3t_store_image)
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], al[i], acc[i][j], 0, 0, 0);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[j], ah[i], acc[i][j], 0, 0, 0);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], ah[i], acc[i][j], 0, 0, 0);
         }
         st = st == NST - 1 ? 0 : st + 1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the clamped look-ahead DMAs must land before the LDS is released
-    // epilogue.  C/D map of 32x32: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
-    // Tiles that lie wholly inside the matrix (all but the last row band of a ragged batch) take a branch-free path: with
-    // a bounds test per element hipcc put every store in its own basic block behind an s_waitcnt vmcnt(0) — 32 serialised
-    // store round trips per tile.
-    const bool inside = m0 + BM <= T && n0 + BN <= N;  // workgroup-uniform
-    if (inside) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int col = n0 + wn * (BN / 2) + j * 32 + fr;
-                const float bv = bias[col];
-                const int row0 = m0 + wm * (BM / WM) + i * 32 + 4 * fh;
-                float res[16];
-                if (EPI == EPI_BIAS_RESIDUAL) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) res[r] = R[(int64_t)(row0 + (r & 3) + 8 * (r >> 2)) * N + col];
-                }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float v = acc[i][j][r] * inv_wscale + bv;  // exact: the weight scale is a power of two
-                    if (EPI == EPI_BIAS_GELU) v = 0.5f * v * (1.0f + x3_erf(v * 0.70710678118654752440f));
-                    if (EPI == EPI_BIAS_RESIDUAL) v += res[r];
-                    if (EPI == EPI_BIAS_GELU)
-                        x3_pair_store(C + (int64_t)(row0 + (r & 3) + 8 * (r >> 2)) * N + (col & ~31), fr, v, true);
-                    else
-                        C[(int64_t)(row0 + (r & 3) + 8 * (r >> 2)) * N + col] = v;
-                }
-            }
+    if (DBG == 3) {  // ablation: K loop only (the accumulators stay live through this never-taken store)
+        if (acc[0][0][0] == 1.2345e-30f) C[0] = 0.f;
         return;
     }
+    // epilogue on the transposed tiles: lane = token row, register r = column (r & 3) + 8 (r >> 2) + 4 fh of the tile.
+    // Rows past T (last row band of a ragged batch) and column tiles past N (N % 32 == 0: whole tiles) only predicate the
+    // stores: one exec mask per tile, no branch per element.
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int row = m0 + wm * (BM / WM) + i * 32 + fr;
+        const bool rok = row < T;
+        const int64_t rbase = (int64_t)(rok ? row : T - 1) * N;  // clamped: loads stay in bounds
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int cb = n0 + wn * (BN / 2) + j * 32;  // first column of the tile
+            const bool ok = rok && cb < N;
+            const int cbc = cb < N ? cb : 0;
+            float v[16];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias + cbc + 8 * g + 4 * fh);
+                f32x4 r4 = {0.f, 0.f, 0.f, 0.f};
+                if (EPI == EPI_BIAS_RESIDUAL) r4 = *reinterpret_cast<const f32x4*>(R + rbase + cbc + 8 * g + 4 * fh);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float x = acc[i][j][4 * g + e] * inv_wscale + b4[e];  // exact: the weight scale is a power of two
+                    if (EPI == EPI_BIAS_GELU) x = 0.5f * x * (1.0f + x3_erf(x * 0.70710678118654752440f));
+                    if (EPI == EPI_BIAS_RESIDUAL) x += r4[e];
+                    if (EPI == EPI_BIAS_QKV) x = cb < qcols ? x * qscale : x;  // uniform per tile (qcols % 32 == 0)
+                    v[4 * g + e] = x;
+                }
+            }
+            if (EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_QKV) {
+                x3t_store_image(reinterpret_cast<unsigned char*>(C + rbase + cbc), fh, v, ok);
+            } else if (ok) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<f32x4*>(C + rbase + cbc + 8 * g + 4 * fh) = f32x4{v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};
+            }
+        }
+    }
+}
+
+// =================================================================================================
+// compute = 2, N == H GEMMs (attention output projection, FFN2): the split-precision GEMM with bias + residual +
+// LayerNorm fused into the epilogue.  A workgroup owns WHOLE ROWS — tile BM x H, waves WM x 4, wave tile 32 TM x 32 TN,
+// H = 128 TN — so the row statistics never leave the CU: the LayerNorm kernel that followed each of these GEMMs (two
+// launches, an fp32 y written and read back, 11 % of the S = 32 forward) is gone.
+//   v  = acc / wscale + bias + x        (x: the residual stream, read by the rows' owner only)
+//   x' = (v - mean) * rstd * gamma + beta, two-pass statistics as ln_kernel / torch (mean first, then the squared
+//        deviations).  The tiles are TRANSPOSED (x3t_store_image): a lane is a token row, so a row's sums are over the
+//        lane's own TN x 16 registers, one v_permlane32_swap with the other lane half (the columns in between; the same
+//        bits on both halves) and the four column waves through LDS (summed in wave order: deterministic)
+//   x' is written IN PLACE over x (fp32, for the next residual and the pooling) and as the (hi | lo) fp16 image the next
+//   GEMM's A operand is DMA'd from.
+// K loop: gemm_x3_dma_kernel's (LDS-DMA ring, one bare s_barrier per K-step, fragments read as they stand).  The W tile
+// is all H rows of the weight: BM = 32 keeps a T = 8192 batch on every CU (256 workgroups, ring of three stages =
+// 156 KiB); BM = 64 / 128 (eight waves) serve longer batches with less W traffic per row.
+// =================================================================================================
+template <int BM, int WM, int TN, int NST, int DBG = 0>
+__global__ __launch_bounds__(WM * 256) void gemm_x3_ln_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ Wp,
+                                                             float inv_wscale, const float* __restrict__ bias,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             float eps, float* X, float* Xp, const int* __restrict__ Tptr, int K) {
+    constexpr int WN = 4, WAVES = WM * WN, TM = BM / (32 * WM), BN = WN * TN * 32;
+    constexpr int kA = BM * 128, kStage = kA + BN * 128;
+    constexpr int NA = BM / 8;                  // DMA instructions of the A tile (8 rows each)
+    constexpr int NI = (NA + BN / 8) / WAVES;   // per wave and stage
+    static_assert((NA + BN / 8) % WAVES == 0, "whole DMA instructions per wave");
+    static_assert(2 * BM * 4 * 4 <= NST * kStage, "row statistics reuse the ring");
+    extern __shared__ __attribute__((aligned(16))) unsigned char xsm[];
+    const int T = *Tptr;
+    const int m0 = blockIdx.x * BM;
+    if (m0 >= T) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int fr = lane & 31, fh = lane >> 5;
+
+    int64_t voff[NI];
+    const char* sbase[NI];
+    int dsto[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int q = wave * NI + i;
+        if (q < NA) {
+            const int row = 8 * q + (lane >> 3);
+            const int slot = (lane & 7) ^ ((row >> 1) & 7);
+            int g = m0 + row;
+            g = g < T ? g : T - 1;  // rows past the edge: clamped (never stored)
+            sbase[i] = reinterpret_cast<const char*>(A);
+            voff[i] = (int64_t)g * K * 4 + 16 * slot;
+            dsto[i] = q * 1024;
+        } else {
+            const int qq = q - NA;
+            const int row = 8 * qq + (lane >> 3);  // < BN = N: every row exists
+            const int slot = (lane & 7) ^ ((row >> 1) & 7);
+            sbase[i] = reinterpret_cast<const char*>(Wp);
+            voff[i] = (int64_t)row * K * 4 + 16 * slot;
+            dsto[i] = kA + qq * 1024;
+        }
+    }
+    auto issue = [&](int kt, int stage) {
+        if (DBG == 2) return;  // ablations as in gemm_x3_dma_kernel (results invalid)
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+            __builtin_amdgcn_global_load_lds((enc_gbl_ptr)(sbase[i] + (int64_t)kt * 128 + voff[i]),
+                                             (enc_lds_ptr)(xsm + stage * kStage + dsto[i]), 16, 0, 0);
+    };
+    int a_off[TM][2][2], b_off[TN][2][2];
+    const int ga = (fr >> 1) & 7;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int col = n0 + wn * (BN / 2) + j * 32 + fr;
-            if (col >= N) continue;  // N % 32 == 0: whole 32-column groups (lane pairs stay together)
-            const float bv = bias[col];
+        for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-                float v = acc[i][j][r] * inv_wscale + bv;  // exact: the weight scale is a power of two
-                if (EPI == EPI_BIAS_GELU) {
-                    v = 0.5f * v * (1.0f + x3_erf(v * 0.70710678118654752440f));
-                    x3_pair_store(C + (int64_t)(row < T ? row : 0) * N + (col & ~31), fr, v, row < T);  // row: uniform per lane half
-                } else if (row < T) {
-                    if (EPI == EPI_BIAS_RESIDUAL) v += R[(int64_t)row * N + col];
-                    C[(int64_t)row * N + col] = v;
-                }
+            for (int pl = 0; pl < 2; ++pl)
+                a_off[i][ks][pl] = (wm * (TM * 32) + i * 32 + fr) * 128 + (((4 * pl + 2 * ks + fh) ^ ga) << 4);
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl)
+                b_off[j][ks][pl] = kA + (wn * (TN * 32) + j * 32 + fr) * 128 + (((4 * pl + 2 * ks + fh) ^ ga) << 4);
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = DBG == 4 ? 0 : K / 32;
+    if (nk > 0) {
+#pragma unroll
+        for (int u = 0; u < NST - 1; ++u) issue(u < nk ? u : nk - 1, u);
+    }
+    int st = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * NI) : "memory");  // this wave's part of stage kt has landed
+        __builtin_amdgcn_s_barrier();  // every wave's part has; and every wave is done reading stage kt - 1
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            const int ahead = kt + NST - 1;
+            issue(ahead < nk ? ahead : nk - 1, st == 0 ? NST - 1 : st - 1);  // into the buffer of stage kt - 1
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned char* sb = xsm + st * kStage;
+        if (DBG == 1) {
+            acc[0][0][0] += (float)kt;
+            st = st == NST - 1 ? 0 : st + 1;
+            continue;
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            x3_h8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                bh[j] = *reinterpret_cast<const x3_h8*>(sb + b_off[j][ks][0]);
+                bl[j] = *reinterpret_cast<const x3_h8*>(sb + b_off[j][ks][1]);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                ah[i] = *reinterpret_cast<const x3_h8*>(sb + a_off[i][ks][0]);
+                al[i] = *reinterpret_cast<const x3_h8*>(sb + a_off[i][ks][1]);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], al[i], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[j], ah[i], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], ah[i], acc[i][j], 0, 0, 0);
+        }
+        st = st == NST - 1 ? 0 : st + 1;
+    }
+    // ---- epilogue: v = acc / wscale + bias + residual, LayerNorm over the row, in place ------------------------------
+    // transposed tiles (x3t_store_image): lane = token row, so a row's statistics are sums over the lane's own TN x 16
+    // registers, one exchange with the other lane half (its columns in between) and the four column waves through LDS
+    if (DBG == 3) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (acc[0][0][0] == 1.2345e-30f) X[0] = 0.f;
+        return;
+    }
+    int64_t rbase[TM];
+    bool rok[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int row = m0 + wm * (TM * 32) + i * 32 + fr;
+        rok[i] = row < T;
+        rbase[i] = (int64_t)(rok[i] ? row : T - 1) * BN;  // clamped: loads stay in bounds, stores are predicated
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int c4 = wn * (TN * 32) + j * 32 + 8 * g + 4 * fh;
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias + c4);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const f32x4 r4 = *reinterpret_cast<const f32x4*>(X + rbase[i] + c4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    acc[i][j][4 * g + e] = (acc[i][j][4 * g + e] * inv_wscale + b4[e]) + r4[e];  // exact scale: power of two
             }
         }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the clamped look-ahead DMAs have landed (and the residual loads)
+    __builtin_amdgcn_s_barrier();                     // every wave is done with the ring: its first bytes become scratch
+    float* red = reinterpret_cast<float*>(xsm);       // [2 passes][WN column waves][BM rows]
+    float rstd[TM];
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {  // 0: mean (then acc -= mean), 1: variance of the centred values
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            float p = 0.f;
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) p += pass == 0 ? acc[i][j][r] : acc[i][j][r] * acc[i][j][r];
+            // + the other lane half's columns: (lower, lower) + (upper, upper) on both halves, the same bits on both
+            const x3_u2 sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(p), __float_as_uint(p), false, false);
+            p = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+            if (fh == 0) red[(pass * WN + wn) * BM + wm * (TM * 32) + i * 32 + fr] = p;
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the partial sums are in LDS
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            float tot = 0.f;
+#pragma unroll
+            for (int w = 0; w < WN; ++w) tot += red[(pass * WN + w) * BM + wm * (TM * 32) + i * 32 + fr];  // wave order: deterministic
+            if (pass == 0) {
+                const float mean = tot / (float)BN;
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] -= mean;
+            } else {
+                rstd[i] = 1.0f / sqrtf(tot / (float)BN + eps);  // biased variance, eps inside the sqrt
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        f32x4 g4[4], t4[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int c4 = wn * (TN * 32) + j * 32 + 8 * g + 4 * fh;
+            g4[g] = *reinterpret_cast<const f32x4*>(gamma + c4);
+            t4[g] = *reinterpret_cast<const f32x4*>(beta + c4);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            float v[16];
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[4 * g + e] = acc[i][j][4 * g + e] * rstd[i] * g4[g][e] + t4[g][e];
+            const int cb = wn * (TN * 32) + j * 32;
+            if (rok[i]) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<f32x4*>(X + rbase[i] + cb + 8 * g + 4 * fh) = f32x4{v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};
+            }
+            x3t_store_image(reinterpret_cast<unsigned char*>(Xp + rbase[i] + cb), fh, v, rok[i]);
+        }
+    }
 }
 
 // =================================================================================================
@@ -1571,6 +1848,245 @@ __global__ __launch_bounds__(WV * 64) void attention_x3_kernel(const float* __re
     }
 }
 
+// =================================================================================================
+// compute = 2 attention on (hi | lo) IMAGES of Q, K, V (the QKV GEMM's EPI_BIAS_QKV epilogue writes them, Q already
+// scaled by log2(e) / sqrt(hd)): same products, same softmax, same output as attention_x3_kernel, but no operand is split
+// or transposed by this kernel —
+//   * a head's 32 dimensions of one token are exactly one 128-byte line [hi 32 | lo 32] of the image (two lines at
+//     hd = 64), so K and V tiles go global -> LDS by LDS-DMA as they stand (two stages: the next tile is in flight under
+//     the current tile's MFMAs; ONE bare s_barrier per tile) and the Q fragments are plain 16-byte loads;
+//   * the K fragment of S^T = K Q^T is a b128 read of a line (bank swizzle on the DMA source: 16-byte slot p of key r
+//     holds the line's slot p ^ ((r >> 1) & 7); hd = 64: p ^ (r & 15) over the two lines);
+//   * the V^T fragment of O^T += V^T P^T is read from the ROW-major V tile with ds_read_b64_tr_b16 (four keys x sixteen
+//     dimensions per sixteen lanes, delivered transposed): keys 4 fh .. + 3 and 8 + 4 fh .. + 3 of the 16-key block, the
+//     order in which the S^T accumulator holds P.  V lines are stored with their 64-byte halves exchanged on keys with
+//     (key >> 1) & 1 (hd = 64: the four 64-byte quarters rotated by key & 3): the four keys of a read then sit on four
+//     different bank groups.
+// What is left on the VALU: the softmax and the (hi, lo) split of P.
+// =================================================================================================
+typedef short x3_s4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) x3_s4 x3_lds_s4;
+
+template <int HD, int WV>
+__global__ __launch_bounds__(WV * 64) void attention_x3i_kernel(const float* __restrict__ qkv, const int* __restrict__ seq_start,
+                                                               int H, float* __restrict__ ctx) {
+    constexpr int DT = HD / 32, KB = HD / 16, LPK = HD / 32;  // lines per key
+    constexpr int KT = WV == 1 ? 32 : 64;                     // keys per tile
+    constexpr int kTile = KT * LPK * 128;                     // bytes of a K (or V) tile
+    constexpr int NQ = 2 * KT * LPK / 8;                      // DMA instructions per tile (8 lines each): K then V
+    constexpr int NI = NQ / WV;
+    static_assert(NQ % WV == 0, "whole DMA instructions per wave");
+    constexpr int SLOTS = 8 * LPK;                            // 16-byte slots per key
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int s0 = seq_start[b], len = seq_start[b + 1] - s0;
+    const int q0 = blockIdx.x * (32 * WV);
+    if (q0 >= len) return;
+    __shared__ __attribute__((aligned(16))) unsigned char kv[2 * 2 * kTile];  // [stage][K | V][key][line][128 B]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 31, fh = lane >> 5;
+    const int64_t pitch = 3 * (int64_t)H * 4;  // bytes per token row of the image
+    const char* base = reinterpret_cast<const char*>(qkv) + (int64_t)s0 * pitch;
+
+    // Q fragments (B operand): query q0 + 32 wave + fr, d = 16 kb + 8 fh .. + 7: hi at byte 2 d of its line, lo 64 further
+    const int qrow = q0 + wave * 32 + fr;
+    const bool qvalid = qrow < len;
+    x3_h8 qh[KB], ql[KB];
+    {
+        const char* qp = base + (int64_t)(qvalid ? qrow : 0) * pitch + (int64_t)h * HD * 4;
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+            const int off = (kb >> 1) * 128 + (2 * (kb & 1) + fh) * 16;
+            qh[kb] = *reinterpret_cast<const x3_h8*>(qp + off);
+            ql[kb] = *reinterpret_cast<const x3_h8*>(qp + off + 64);
+            if (!qvalid) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) qh[kb][e] = ql[kb][e] = (_Float16)0.f;
+            }
+        }
+    }
+    // DMA roles: instruction q of a tile moves lines 8 q' .. 8 q' + 7 of K (q < NQ / 2) or V; a lane's source is
+    // (key row, line of the head, logical slot) for the physical slot it fills
+    int dkey[NI], dsrc[NI], ddst[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int q = wave * NI + i;
+        const bool isv = q >= NQ / 2;
+        const int L = 8 * (isv ? q - NQ / 2 : q) + (lane >> 3);  // line of the tile
+        const int key = L / LPK, sub = L % LPK;
+        const int phys = sub * 8 + (lane & 7);                    // slot inside the key's SLOTS
+        const int sw = isv ? (LPK == 1 ? ((key >> 1) & 1) << 2 : (key & 3) << 2) : (LPK == 1 ? (key >> 1) & 7 : key & 15);
+        const int logical = phys ^ sw;
+        dkey[i] = key;
+        dsrc[i] = (isv ? 2 * H * 4 : H * 4) + h * HD * 4 + logical * 16;
+        ddst[i] = (isv ? kTile : 0) + (isv ? q - NQ / 2 : q) * 1024;
+    }
+    auto issue = [&](int kt, int stage) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            int key = kt + dkey[i];
+            key = key < len ? key : len - 1;  // past the sequence: any valid row (its scores are masked)
+            __builtin_amdgcn_global_load_lds((enc_gbl_ptr)(base + (int64_t)key * pitch + dsrc[i]),
+                                             (enc_lds_ptr)(kv + stage * 2 * kTile + ddst[i]), 16, 0, 0);
+        }
+    };
+    // fragment addresses inside a stage.  K (A operand of S^T): key = 32 kb32 + fr, d = 16 kb + 8 fh
+    int k_off[KB][2];
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+            const int logical = (kb >> 1) * 8 + 4 * pl + 2 * (kb & 1) + fh;
+            const int sw = LPK == 1 ? (fr >> 1) & 7 : fr & 15;  // key = 32 kb32 + fr: same low bits
+            k_off[kb][pl] = fr * (LPK * 128) + ((logical ^ sw) << 4);
+        }
+    // V^T (A operand of O^T += V^T P^T) by transposed reads: the 16 lanes (g = lane >> 4) of a group point at keys
+    // kbase + 4 (g >> 1) + q (q = (lane >> 2) & 3), dimensions 32 t + 16 (g & 1) + 4 p (p = lane & 3); lane li of the group
+    // receives dimension 32 t + 16 (g & 1) + li = 32 t + fr of those four keys
+    int v_off[DT][2][2];  // [t][plane][first / second key quad], for the key block at kbase = 0
+    {
+        const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+#pragma unroll
+        for (int t = 0; t < DT; ++t)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+                for (int hq = 0; hq < 2; ++hq) {
+                    const int key = 8 * hq + 4 * (g >> 1) + q;  // + 16 kb16 + 32 kb32: multiples of 16 leave the swizzle alone
+                    const int logical = t * 8 + 4 * pl + 2 * (g & 1) + (pp >> 1);
+                    const int sw = LPK == 1 ? ((key >> 1) & 1) << 2 : (key & 3) << 2;
+                    v_off[t][pl][hq] = kTile + key * (LPK * 128) + ((logical ^ sw) << 4) + 8 * (pp & 1);
+                }
+    }
+
+    f32x16 o[DT];
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
+    float m = -INFINITY, l = 0.f;
+    const bool wave_active = q0 + wave * 32 < len;  // wave-uniform
+
+    issue(0, 0);
+    int stg = 0;
+    for (int kt = 0; kt < len; kt += KT) {
+        const int nk = min(KT, len - kt);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's lines of tile kt have landed
+        __builtin_amdgcn_s_barrier();                     // everybody's have; everybody is done with tile kt - KT
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + KT < len) issue(kt + KT, stg ^ 1);       // under this tile's MFMAs
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned char* sb = kv + stg * 2 * kTile;
+        stg ^= 1;
+        if (!wave_active) continue;
+#pragma unroll
+        for (int kb32 = 0; kb32 < KT / 32; ++kb32) {
+            if (kb32 * 32 >= nk) break;
+            const unsigned char* kbp = sb + kb32 * 32 * (LPK * 128);
+            // ---- S^T block: 32 keys x 32 queries ----------------------------------------------------
+            f32x16 st;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[r] = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) {
+                const x3_h8 kh = *reinterpret_cast<const x3_h8*>(kbp + k_off[kb][0]);
+                const x3_h8 kl = *reinterpret_cast<const x3_h8*>(kbp + k_off[kb][1]);
+                st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[kb], st, 0, 0, 0);
+                st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[kb], st, 0, 0, 0);
+                st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[kb], st, 0, 0, 0);
+            }
+            // the V^T fragments of this key block do not depend on P: their reads fly under the softmax
+            union VF {
+                x3_h8 v;
+                x3_s4 q[2];
+            };
+            VF vh[2][DT], vl[2][DT];
+#pragma unroll
+            for (int kb16 = 0; kb16 < 2; ++kb16)
+#pragma unroll
+                for (int t = 0; t < DT; ++t)
+#pragma unroll
+                    for (int hq = 0; hq < 2; ++hq) {
+                        const unsigned char* vp = kbp + kb16 * 16 * (LPK * 128);
+                        vh[kb16][t].q[hq] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((x3_lds_s4*)(vp + v_off[t][0][hq]));
+                        vl[kb16][t].q[hq] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((x3_lds_s4*)(vp + v_off[t][1][hq]));
+                    }
+            // ---- online softmax, query on the lane --------------------------------------------------
+            float cmax = -INFINITY;
+            if (kb32 * 32 + 32 > nk) {  // only the last block of a sequence has keys to mask (workgroup-uniform)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kb32 * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                    st[r] = key < nk ? st[r] : -INFINITY;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) cmax = fmaxf(cmax, st[r]);
+            cmax = fmaxf(cmax, __shfl_xor(cmax, 32));
+            const float mn = fmaxf(m, cmax);
+            const float alpha = __builtin_amdgcn_exp2f(m - mn);
+            float psum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                st[r] = __builtin_amdgcn_exp2f(st[r] - mn);  // masked keys: 2^(-inf) = 0
+                psum += st[r];
+            }
+            psum += __shfl_xor(psum, 32);
+            l = l * alpha + psum;
+            m = mn;
+            if (__ballot(alpha != 1.0f) != 0ull) {  // once the running maxima have settled no lane rescales
+#pragma unroll
+                for (int t = 0; t < DT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+            }
+            // ---- O^T += V^T . P^T: k-block kb16 = accumulator registers 8 kb16 .. + 7 ------------------
+#pragma unroll
+            for (int kb16 = 0; kb16 < 2; ++kb16) {
+                union {
+                    x3_h8 v;
+                    uint32_t w[4];
+                } ph, pl;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) x3_split2(st[8 * kb16 + 2 * e], st[8 * kb16 + 2 * e + 1], ph.w[e], pl.w[e]);
+#pragma unroll
+                for (int t = 0; t < DT; ++t) {
+                    o[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl[kb16][t].v, ph.v, o[t], 0, 0, 0);
+                    o[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[kb16][t].v, pl.v, o[t], 0, 0, 0);
+                    o[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[kb16][t].v, ph.v, o[t], 0, 0, 0);
+                }
+            }
+        }
+    }
+    if (!wave_active || !qvalid) return;
+    // O^T tile t: col = query fr (lane), row d = t*32 + (r&3) + 8(r>>2) + 4fh -> the (hi | lo) lines of the context image
+    // (see attention_x3_kernel: lane halves trade pieces so that every store writes whole 32-byte sectors)
+    const float inv = 1.0f / l;
+    unsigned char* op = reinterpret_cast<unsigned char*>(ctx + (int64_t)(s0 + qrow) * H + h * HD);
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+        for (int p2 = 0; p2 < 2; ++p2) {
+            uint32_t ha[2], la[2], hb[2], lb[2];  // a: r4 = 2 p2, b: r4 = 2 p2 + 1
+            x3_split2(o[t][8 * p2] * inv, o[t][8 * p2 + 1] * inv, ha[0], la[0]);
+            x3_split2(o[t][8 * p2 + 2] * inv, o[t][8 * p2 + 3] * inv, ha[1], la[1]);
+            x3_split2(o[t][8 * p2 + 4] * inv, o[t][8 * p2 + 5] * inv, hb[0], lb[0]);
+            x3_split2(o[t][8 * p2 + 6] * inv, o[t][8 * p2 + 7] * inv, hb[1], lb[1]);
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const x3_u2 sh = __builtin_amdgcn_permlane32_swap(ha[e], hb[e], false, false);
+                const x3_u2 sl = __builtin_amdgcn_permlane32_swap(la[e], lb[e], false, false);
+                ha[e] = sh[0];
+                hb[e] = sh[1];
+                la[e] = sl[0];
+                lb[e] = sl[1];
+            }
+            *reinterpret_cast<uint4*>(op + t * 128 + 32 * p2 + 16 * fh) = uint4{ha[0], ha[1], hb[0], hb[1]};
+            *reinterpret_cast<uint4*>(op + t * 128 + 64 + 32 * p2 + 16 * fh) = uint4{la[0], la[1], lb[0], lb[1]};
+        }
+}
+
 __global__ void concat3_kernel(const float* a, const float* b, const float* c, int64_t n, float* out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
@@ -1607,6 +2123,10 @@ struct mvdb_encoder {
         graphs.clear();
     }
     int device = 0;
+    // A/B switches, read from the environment when the encoder is created (so that one process can hold encoders of both
+    // kinds): MVDB_GEMM_LN_FUSED (0 never, 1 by batch size, 2 always), MVDB_ATTENTION_IMG (0: fp32 qkv + per-tile split)
+    int opt_ln_fused = 1;
+    bool opt_img_attn = true;
     const float *word = nullptr, *pos = nullptr, *type = nullptr, *embg = nullptr, *embb = nullptr;
     std::vector<LayerW> layers;
     std::vector<float*> owned;  // fused qkv weights / biases
@@ -1811,24 +2331,43 @@ int ensure_bf16_weights(mvdb_encoder* e, hipStream_t s) {
 // compute = 2: LDS-DMA kernel, 64 x 128 tiles, three stages, two workgroups per CU — measured best at every shape
 // (B = 256: S = 32 2.68 ms vs 3.04 with 128-row tiles for the wide GEMMs, 3.15 register-staged; S = 512 43.8 ms vs
 // 55.7 / 45.3; rings of 2, 4 or 6 stages, i.e. 3 or 1 workgroups per CU: within 1 %)
+// Raises a kernel's dynamic-LDS limit once per (kernel, device).
+int x3_set_lds(const void* kern, int lds, int device) {
+    static std::mutex mu;
+    static std::map<std::pair<const void*, int>, int> done;
+    std::lock_guard<std::mutex> lk(mu);
+    int& have = done[{kern, device}];
+    if (lds > have) {
+        MVDB_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        have = lds;
+    }
+    return 0;
+}
+
+// Timing ablations of the split-precision GEMMs (DBG template parameter: 1 no fragment reads / MFMAs, 2 no DMA, 3 no
+// epilogue, 4 no K loop; results invalid) exist only in builds with -DMVDB_X3_ABLATE (make ABLATE=1), selected at run time
+// by MVDB_GEMM_X3_DBG; the normal build instantiates the real kernels only.
+#ifdef MVDB_X3_ABLATE
+#define X3_KERN(...)                                                                                                  \
+    (dbg == 1 ? gemm_x3_dma_kernel<__VA_ARGS__, 1> : dbg == 2 ? gemm_x3_dma_kernel<__VA_ARGS__, 2> :                 \
+     dbg == 3 ? gemm_x3_dma_kernel<__VA_ARGS__, 3> : dbg == 4 ? gemm_x3_dma_kernel<__VA_ARGS__, 4> : gemm_x3_dma_kernel<__VA_ARGS__, 0>)
+#define X3_LN_KERN(...)                                                                                               \
+    (dbg == 1 ? gemm_x3_ln_kernel<__VA_ARGS__, 1> : dbg == 2 ? gemm_x3_ln_kernel<__VA_ARGS__, 2> :                   \
+     dbg == 3 ? gemm_x3_ln_kernel<__VA_ARGS__, 3> : dbg == 4 ? gemm_x3_ln_kernel<__VA_ARGS__, 4> : gemm_x3_ln_kernel<__VA_ARGS__, 0>)
+#else
+#define X3_KERN(...) gemm_x3_dma_kernel<__VA_ARGS__, 0>
+#define X3_LN_KERN(...) gemm_x3_ln_kernel<__VA_ARGS__, 0>
+#endif
+
 template <int EPI>
 int launch_gemm_x3(const float* Aimg, const _Float16* Wp, float inv_wscale, const float* bias, const float* R, float* C,
-                   const int* Tptr, int64_t Tmax, int N, int K, int device, hipStream_t s) {
+                   const int* Tptr, int64_t Tmax, int N, int K, int device, hipStream_t s, int qcols = 0, float qscale = 1.f) {
     const _Float16* A = reinterpret_cast<const _Float16*>(Aimg);  // [T][K / 32][hi 32 | lo 32]: the bytes of a [T][K] fp32 matrix
     static const int dbg = []() { const char* v = getenv("MVDB_GEMM_X3_DBG"); return v ? atoi(v) : 0; }();
-    auto kern = dbg == 1 ? gemm_x3_dma_kernel<EPI, 64, 3, 1> : dbg == 2 ? gemm_x3_dma_kernel<EPI, 64, 3, 2> : gemm_x3_dma_kernel<EPI, 64, 3>;
+    (void)dbg;
+    auto kern = X3_KERN(EPI, 64, 3, 4, 128);
     constexpr int lds = 3 * (64 * 128 + 128 * 128);
-    {
-        static std::mutex mu;
-        static std::map<int, bool> done;
-        std::lock_guard<std::mutex> lk(mu);
-        if (!done[device]) {
-            MVDB_HIP(hipFuncSetAttribute((const void*)gemm_x3_dma_kernel<EPI, 64, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-            MVDB_HIP(hipFuncSetAttribute((const void*)gemm_x3_dma_kernel<EPI, 64, 3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-            MVDB_HIP(hipFuncSetAttribute((const void*)gemm_x3_dma_kernel<EPI, 64, 3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-            done[device] = true;
-        }
-    }
+    MVDB_TRY(x3_set_lds((const void*)kern, lds, device));
     dim3 grid((N + 127) / 128, (unsigned)((Tmax + 63) / 64));
     // Enough 128 x 128 tiles to fill every resident slot (two workgroups per CU) at least once: 128 x 128 tiles on FOUR
     // waves — wave tile 64 x 64, 8 fragment reads per 12 MFMAs where the 32 x 64 wave tile of the default needs 12, and a
@@ -1858,73 +2397,94 @@ int launch_gemm_x3(const float* Aimg, const _Float16* Wp, float inv_wscale, cons
     // forced (1): unconditional; default: launched as a pair with the fallback below when the padded batch could qualify
     const bool big_pair = bign != 0 && big8env < 0 && x3_big_form(Tmax, N, bign, cus);
     int sel_bn = 0;  // the fallback's selector
-    if (dbg == 0 && !w8 && big4env < 0 && bign != 0 && (big8env == 1 || big_pair)) {
+    if (!w8 && big4env < 0 && bign != 0 && (big8env == 1 || big_pair)) {
         const dim3 gridb(N / bign, (unsigned)((Tmax + 255) / 256));
         const int sel_big = big8env == 1 ? 0 : bign;
         if (bign == 256) {
-            auto kernb = gemm_x3_dma_kernel<EPI, 256, 2, 0, 8, 256>;
+            auto kernb = X3_KERN(EPI, 256, 2, 8, 256);
             constexpr int ldsb = 2 * (256 * 128 + 256 * 128);
-            static std::mutex mub;
-            static std::map<int, bool> doneb;
-            {
-                std::lock_guard<std::mutex> lk(mub);
-                if (!doneb[device]) {
-                    MVDB_HIP(hipFuncSetAttribute((const void*)kernb, hipFuncAttributeMaxDynamicSharedMemorySize, ldsb));
-                    doneb[device] = true;
-                }
-            }
-            hipLaunchKernelGGL(kernb, gridb, dim3(512), ldsb, s, A, Wp, inv_wscale, bias, R, C, Tptr, N, K, sel_big, cus);
+            MVDB_TRY(x3_set_lds((const void*)kernb, ldsb, device));
+            hipLaunchKernelGGL(kernb, gridb, dim3(512), ldsb, s, A, Wp, inv_wscale, bias, R, C, Tptr, N, K, sel_big, cus, qcols, qscale);
         } else {
-            auto kernc = gemm_x3_dma_kernel<EPI, 256, 2, 0, 8, 192>;
+            auto kernc = X3_KERN(EPI, 256, 2, 8, 192);
             constexpr int ldsc = 2 * (256 * 128 + 192 * 128);
-            static std::mutex muc;
-            static std::map<int, bool> donec;
-            {
-                std::lock_guard<std::mutex> lk(muc);
-                if (!donec[device]) {
-                    MVDB_HIP(hipFuncSetAttribute((const void*)kernc, hipFuncAttributeMaxDynamicSharedMemorySize, ldsc));
-                    donec[device] = true;
-                }
-            }
-            hipLaunchKernelGGL(kernc, gridb, dim3(512), ldsc, s, A, Wp, inv_wscale, bias, R, C, Tptr, N, K, sel_big, cus);
+            MVDB_TRY(x3_set_lds((const void*)kernc, ldsc, device));
+            hipLaunchKernelGGL(kernc, gridb, dim3(512), ldsc, s, A, Wp, inv_wscale, bias, R, C, Tptr, N, K, sel_big, cus, qcols, qscale);
         }
         if (big8env == 1) return 0;
         sel_bn = -bign;  // the fallback runs only where the packed token count rules the 256-row form out
     }
-    if (dbg == 0 && !w8 && (big4env >= 0 ? big4env == 1 : many)) {
-        auto kern4 = gemm_x3_dma_kernel<EPI, 128, 2, 0, 4>;
+    // (Tried in round 3 and dropped: 128 x 192 tiles on four waves, two 40-KiB stages, TWO workgroups per CU so that one
+    // workgroup's stores run under the other's K loop — S = 512 forward 26.7 ms vs 25.9 with the 256-row forms, S = 32 2.01
+    // vs 1.96: the epilogue is not what the 256-row forms wait for.)
+    if (!w8 && (big4env >= 0 ? big4env == 1 : many)) {
+        auto kern4 = X3_KERN(EPI, 128, 2, 4, 128);
         constexpr int lds4 = 2 * (128 * 128 + 128 * 128);
-        static std::mutex mu4;
-        static std::map<int, bool> done4;
-        {
-            std::lock_guard<std::mutex> lk(mu4);
-            if (!done4[device]) {
-                MVDB_HIP(hipFuncSetAttribute((const void*)kern4, hipFuncAttributeMaxDynamicSharedMemorySize, lds4));
-                done4[device] = true;
-            }
-        }
+        MVDB_TRY(x3_set_lds((const void*)kern4, lds4, device));
         dim3 grid4((N + 127) / 128, (unsigned)((Tmax + 127) / 128));
-        hipLaunchKernelGGL(kern4, grid4, dim3(256), lds4, s, A, Wp, inv_wscale, bias, R, C, Tptr, N, K, sel_bn, cus);
+        hipLaunchKernelGGL(kern4, grid4, dim3(256), lds4, s, A, Wp, inv_wscale, bias, R, C, Tptr, N, K, sel_bn, cus, qcols, qscale);
         return 0;
     }
-    if (dbg == 0 && w8) {
-        auto kern8 = gemm_x3_dma_kernel<EPI, 128, 3, 0, 8>;
+    if (w8) {
+        auto kern8 = X3_KERN(EPI, 128, 3, 8, 128);
         constexpr int lds8 = 3 * (128 * 128 + 128 * 128);
-        static std::mutex mu8;
-        static std::map<int, bool> done8;
-        {
-            std::lock_guard<std::mutex> lk(mu8);
-            if (!done8[device]) {
-                MVDB_HIP(hipFuncSetAttribute((const void*)kern8, hipFuncAttributeMaxDynamicSharedMemorySize, lds8));
-                done8[device] = true;
-            }
-        }
+        MVDB_TRY(x3_set_lds((const void*)kern8, lds8, device));
         dim3 grid8((N + 127) / 128, (unsigned)((Tmax + 127) / 128));
-        hipLaunchKernelGGL(kern8, grid8, dim3(512), lds8, s, A, Wp, inv_wscale, bias, R, C, Tptr, N, K, sel_bn, cus);
+        hipLaunchKernelGGL(kern8, grid8, dim3(512), lds8, s, A, Wp, inv_wscale, bias, R, C, Tptr, N, K, sel_bn, cus, qcols, qscale);
         return 0;
     }
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, A, Wp, inv_wscale, bias, R, C, Tptr, N, K, sel_bn, cus);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, A, Wp, inv_wscale, bias, R, C, Tptr, N, K, sel_bn, cus, qcols, qscale);
     return 0;
+}
+
+// ---- N == H GEMM with bias + residual + LayerNorm in the epilogue (gemm_x3_ln_kernel) --------------------------------
+bool x3_ln_fusable(int H) { return H % 128 == 0 && H <= 512; }
+
+template <int BM, int WM, int TN>
+int launch_gemm_x3_ln_inst(const _Float16* A, const _Float16* Wp, float inv_wscale, const float* bias, const float* gamma,
+                           const float* beta, float eps, float* X, float* Xp, const int* Tptr, int64_t Tmax, int K, int device,
+                           hipStream_t s) {
+    constexpr int kStage = (BM + 128 * TN) * 128;
+    constexpr int NST = 3 * kStage <= 160 * 1024 ? 3 : 2;
+    static_assert(2 * kStage <= 160 * 1024, "two stages must fit the CU's LDS");
+    static const int dbg = []() { const char* v = getenv("MVDB_GEMM_X3_DBG"); return v ? atoi(v) : 0; }();
+    (void)dbg;
+    auto kern = X3_LN_KERN(BM, WM, TN, NST);
+    constexpr int lds = NST * kStage;
+    MVDB_TRY(x3_set_lds((const void*)kern, lds, device));
+    hipLaunchKernelGGL(kern, dim3((unsigned)((Tmax + BM - 1) / BM)), dim3(WM * 256), lds, s, A, Wp, inv_wscale, bias, gamma, beta,
+                       eps, X, Xp, Tptr, K);
+    return 0;
+}
+
+template <int TN>
+int launch_gemm_x3_ln_tn(int bm, const _Float16* A, const _Float16* Wp, float inv_wscale, const float* bias, const float* gamma,
+                         const float* beta, float eps, float* X, float* Xp, const int* Tptr, int64_t Tmax, int K, int device,
+                         hipStream_t s) {
+    if (bm == 128) return launch_gemm_x3_ln_inst<128, 2, TN>(A, Wp, inv_wscale, bias, gamma, beta, eps, X, Xp, Tptr, Tmax, K, device, s);
+    if (bm == 64) return launch_gemm_x3_ln_inst<64, 2, TN>(A, Wp, inv_wscale, bias, gamma, beta, eps, X, Xp, Tptr, Tmax, K, device, s);
+    return launch_gemm_x3_ln_inst<32, 1, TN>(A, Wp, inv_wscale, bias, gamma, beta, eps, X, Xp, Tptr, Tmax, K, device, s);
+}
+
+// X (in: the residual rows; out: LayerNorm(A W^T + bias + X), fp32) and Xp (out: its (hi | lo) image); N = H = 128 TN.
+// Rows per workgroup: the largest of 128 / 64 / 32 that still gives every CU a workgroup (counted on the padded batch) —
+// a workgroup streams ALL of W whatever its height, so taller tiles mean less L2 -> LDS traffic per output row, but at
+// T = 8192 only 32-row tiles reach all 256 CUs.  MVDB_GEMM_LN_BM overrides.
+int launch_gemm_x3_ln(const float* Aimg, const _Float16* Wp, float inv_wscale, const float* bias, const float* gamma,
+                      const float* beta, float eps, float* X, float* Xp, const int* Tptr, int64_t Tmax, int H, int K, int device,
+                      hipStream_t s) {
+    const _Float16* A = reinterpret_cast<const _Float16*>(Aimg);
+    static const int bm_env = []() { const char* v = getenv("MVDB_GEMM_LN_BM"); return v && *v ? atoi(v) : 0; }();
+    const int cus = device_cus(device);
+    int bm = (Tmax + 127) / 128 >= cus ? 128 : (Tmax + 63) / 64 >= cus ? 64 : 32;
+    if (bm_env == 32 || bm_env == 64 || bm_env == 128) bm = bm_env;
+    switch (H / 128) {
+        case 1: return launch_gemm_x3_ln_tn<1>(bm, A, Wp, inv_wscale, bias, gamma, beta, eps, X, Xp, Tptr, Tmax, K, device, s);
+        case 2: return launch_gemm_x3_ln_tn<2>(bm, A, Wp, inv_wscale, bias, gamma, beta, eps, X, Xp, Tptr, Tmax, K, device, s);
+        case 3: return launch_gemm_x3_ln_tn<3>(bm, A, Wp, inv_wscale, bias, gamma, beta, eps, X, Xp, Tptr, Tmax, K, device, s);
+        case 4: return launch_gemm_x3_ln_tn<4>(bm, A, Wp, inv_wscale, bias, gamma, beta, eps, X, Xp, Tptr, Tmax, K, device, s);
+        default: return fail(MVDB_ERR_ARG, "no LayerNorm-fused GEMM for H = %d", H);
+    }
 }
 
 // one tensor: max|w| -> power-of-two scale with max|w| * scale in [2^13, 2^14) -> interleaved (hi | lo) fp16 pieces
@@ -2039,8 +2599,23 @@ int enqueue_lane(mvdb_encoder* e, mvdb_encoder::Lane& w, const int32_t* ids, con
     }();
     const dim3 agrid((S + ATT_Q - 1) / ATT_Q, c.heads, B);
     const bool ctx_is_image = compute == 2 && x3_attention && !attn_valu;
+    // Q / K / V as (hi | lo) images straight from the QKV GEMM's epilogue (Q pre-scaled), attention_x3i_kernel on them:
+    // MVDB_ATTENTION_IMG=0 keeps the fp32 qkv + attention_x3_kernel (splits K / V per workgroup) as the A/B reference
+    const bool img_attn = ctx_is_image && e->opt_img_attn;  // MVDB_ATTENTION_IMG as read when the encoder was created
+    // bias + residual + LayerNorm in the epilogue of the N = H GEMMs (MVDB_GEMM_LN_FUSED=0: separate ln_kernel launches;
+    // =2: at every batch size).  A row-owning workgroup streams ALL of W and there is one workgroup per CU, so the fused
+    // kernel needs rows: measured on e5-small, B = 256 (full / ragged batch, ms per forward, fused vs GEMM + ln_kernel):
+    // S = 32 1.97 / 1.54 vs 1.98 / 1.34, S = 64 3.24 / 2.43 vs 3.36 / 2.20, S = 128 5.71 / 4.23 vs 6.11 / 4.08,
+    // S = 256 11.85 / 8.50 vs 12.73 / 8.30, S = 512 25.6 / 17.0 vs 27.1 / 18.1 — ahead on full batches from S = 64, on
+    // ragged ones (64 % of the token slots filled; the row count per workgroup is chosen from the PADDED count, the only
+    // one the host knows) only at S = 512.  Default: from 128 token slots per CU.
+    const int ln_env = e->opt_ln_fused;  // MVDB_GEMM_LN_FUSED as read when the encoder was created
+    const bool ln_fused = compute == 2 && x3_ln_fusable(H) && ln_env != 0 && (ln_env == 2 || Tmax >= 128 * (int64_t)cus);
     for (const LayerW& L : e->layers) {
-        if (compute == 2)
+        if (compute == 2 && img_attn)
+            MVDB_TRY(launch_gemm_x3<EPI_BIAS_QKV>(xp, L.wqkv_p, L.wqkv_is, L.bqkv, nullptr, w.qkv, Tptr, Tmax, 3 * H, H, e->device, s,
+                                                  H, scale * kLog2e));
+        else if (compute == 2)
             MVDB_TRY(launch_gemm_x3<EPI_BIAS>(xp, L.wqkv_p, L.wqkv_is, L.bqkv, nullptr, w.qkv, Tptr, Tmax, 3 * H, H, e->device, s));
         else if (compute == 1)
             launch_gemm_h<EPI_BIAS>(w.x, L.wqkv_h, L.bqkv, nullptr, w.qkv, Tptr, Tmax, 3 * H, H, s);
@@ -2053,6 +2628,23 @@ int enqueue_lane(mvdb_encoder* e, mvdb_encoder::Lane& w, const int32_t* ids, con
             else
                 hipLaunchKernelGGL(attention_kernel<64>, agrid, dim3(ATT_Q), 0, s, w.qkv, w.seq_start, H, scale,
                                    w.ctx);
+        } else if (img_attn) {
+            if (S <= 32 && x3_short) {  // one wave per (sentence, head)
+                const dim3 sgrid(1, c.heads, B);
+                if (hd == 32)
+                    hipLaunchKernelGGL((attention_x3i_kernel<32, 1>), sgrid, dim3(64), 0, s, w.qkv, w.seq_start, H, w.ctx);
+                else
+                    hipLaunchKernelGGL((attention_x3i_kernel<64, 1>), sgrid, dim3(64), 0, s, w.qkv, w.seq_start, H, w.ctx);
+            } else if (S > x3_wide_from) {  // eight waves = 256 queries per workgroup share each K / V tile
+                const dim3 wgrid((S + 255) / 256, c.heads, B);
+                if (hd == 32)
+                    hipLaunchKernelGGL((attention_x3i_kernel<32, 8>), wgrid, dim3(512), 0, s, w.qkv, w.seq_start, H, w.ctx);
+                else
+                    hipLaunchKernelGGL((attention_x3i_kernel<64, 8>), wgrid, dim3(512), 0, s, w.qkv, w.seq_start, H, w.ctx);
+            } else if (hd == 32)
+                hipLaunchKernelGGL((attention_x3i_kernel<32, 4>), agrid, dim3(256), 0, s, w.qkv, w.seq_start, H, w.ctx);
+            else
+                hipLaunchKernelGGL((attention_x3i_kernel<64, 4>), agrid, dim3(256), 0, s, w.qkv, w.seq_start, H, w.ctx);
         } else if (compute == 2 && x3_attention) {
             if (S <= 32 && x3_short) {  // one wave per (sentence, head)
                 const dim3 sgrid(1, c.heads, B);
@@ -2085,18 +2677,24 @@ int enqueue_lane(mvdb_encoder* e, mvdb_encoder::Lane& w, const int32_t* ids, con
                                    reinterpret_cast<_Float16*>(w.ffn), n, 1.0f);
                 ctx_img = w.ffn;
             }
-            MVDB_TRY(launch_gemm_x3<EPI_BIAS_RESIDUAL>(ctx_img, L.wo_p, L.wo_is, L.bo, w.x, w.y, Tptr, Tmax, H, H, e->device, s));
+            if (ln_fused)
+                MVDB_TRY(launch_gemm_x3_ln(ctx_img, L.wo_p, L.wo_is, L.bo, L.ln1g, L.ln1b, c.ln_eps, w.x, xp, Tptr, Tmax, H, H, e->device, s));
+            else
+                MVDB_TRY(launch_gemm_x3<EPI_BIAS_RESIDUAL>(ctx_img, L.wo_p, L.wo_is, L.bo, w.x, w.y, Tptr, Tmax, H, H, e->device, s));
         }
         else if (compute == 1)
             launch_gemm_h<EPI_BIAS_RESIDUAL>(w.ctx, L.wo_h, L.bo, w.x, w.y, Tptr, Tmax, H, H, s);
         else
             launch_gemm<EPI_BIAS_RESIDUAL>(w.ctx, L.wo, L.bo, w.x, w.y, Tptr, Tmax, H, H, cus, s);
 #define LN1_CALL(V) launch_ln<V>(w.y, w.seq_start, B, L.ln1g, L.ln1b, c.ln_eps, H, w.x, xp, Tmax, s)
-        MVDB_VPT_SWITCH(LN1_CALL)
+        if (!ln_fused) { MVDB_VPT_SWITCH(LN1_CALL) }
 #undef LN1_CALL
         if (compute == 2) {
             MVDB_TRY(launch_gemm_x3<EPI_BIAS_GELU>(xp, L.w1_p, L.w1_is, L.b1, nullptr, w.ffn, Tptr, Tmax, F, H, e->device, s));
-            MVDB_TRY(launch_gemm_x3<EPI_BIAS_RESIDUAL>(w.ffn, L.w2_p, L.w2_is, L.b2, w.x, w.y, Tptr, Tmax, H, F, e->device, s));
+            if (ln_fused)
+                MVDB_TRY(launch_gemm_x3_ln(w.ffn, L.w2_p, L.w2_is, L.b2, L.ln2g, L.ln2b, c.ln_eps, w.x, xp, Tptr, Tmax, H, F, e->device, s));
+            else
+                MVDB_TRY(launch_gemm_x3<EPI_BIAS_RESIDUAL>(w.ffn, L.w2_p, L.w2_is, L.b2, w.x, w.y, Tptr, Tmax, H, F, e->device, s));
         } else if (compute == 1) {
             launch_gemm_h<EPI_BIAS_GELU>(w.x, L.w1_h, L.b1, nullptr, w.ffn, Tptr, Tmax, F, H, s);
             launch_gemm_h<EPI_BIAS_RESIDUAL>(w.ffn, L.w2_h, L.b2, w.x, w.y, Tptr, Tmax, H, F, s);
@@ -2105,7 +2703,7 @@ int enqueue_lane(mvdb_encoder* e, mvdb_encoder::Lane& w, const int32_t* ids, con
             launch_gemm<EPI_BIAS_RESIDUAL>(w.ffn, L.w2, L.b2, w.x, w.y, Tptr, Tmax, H, F, cus, s);
         }
 #define LN2_CALL(V) launch_ln<V>(w.y, w.seq_start, B, L.ln2g, L.ln2b, c.ln_eps, H, w.x, xp, Tmax, s)
-        MVDB_VPT_SWITCH(LN2_CALL)
+        if (!ln_fused) { MVDB_VPT_SWITCH(LN2_CALL) }
 #undef LN2_CALL
     }
 #undef MVDB_VPT_SWITCH
@@ -2167,9 +2765,12 @@ int forward_core(mvdb_encoder* e, const int32_t* ids, const int32_t* mask, int B
         const char* v = getenv("MVDB_ENCODER_GRAPH");
         return !(v && *v == '0');
     }();
-    int pslot = prof_begin("encoder", s);
+    // the caller is capturing `s` into a graph of its own (e.g. encoder -> search as ONE graph): plain launches join it
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    const bool outer_capture = s && hipStreamIsCapturing(s, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
+    int pslot = outer_capture ? -1 : prof_begin("encoder", s);
     int rc = 0;
-    if (use_graph && !hidden && s) {
+    if (use_graph && !hidden && s && !outer_capture) {
         const GraphKey key{B, S, compute, ids, mask, out};
         auto it = e->graphs.find(key);
         if (it == e->graphs.end()) {
@@ -2233,6 +2834,12 @@ int mvdb_encoder_create(const mvdb_encoder_cfg* cfg, const void* const* w, int d
     mvdb_encoder* e = new mvdb_encoder();
     e->cfg = *cfg;
     e->device = device;
+    {
+        const char* v = getenv("MVDB_GEMM_LN_FUSED");
+        e->opt_ln_fused = v && *v ? atoi(v) : 1;
+        v = getenv("MVDB_ATTENTION_IMG");
+        e->opt_img_attn = !(v && *v == '0');
+    }
     e->word = (const float*)w[0];
     e->pos = (const float*)w[1];
     e->type = (const float*)w[2];

@@ -134,7 +134,7 @@ struct Workspace {
     DevBuf<int> qfail;      // per query: 1 = failed certification; behind them the compact list of those queries
     DevBuf<float> requery;  // the failed queries, gathered, and their exact results [D | I]
     DevBuf<int64_t> relabel;
-    PinnedBuf pin_flags;
+    DevBuf<int> nfail;      // number of uncertified queries of the call (device-side gate of the exact re-run)
     SelectState* st = nullptr;
     PinnedBuf pin;
     std::mutex use_mu;  // stream workspaces are shared by every host thread that names the stream: one search at a time
@@ -166,7 +166,7 @@ struct Workspace {
         qfail.release();
         requery.release();
         relabel.release();
-        pin_flags.release();
+        nfail.release();
         pin.release();
         if (st) (void)hipFree(st);
         if (own_stream && stream) (void)hipStreamDestroy(stream);
@@ -441,6 +441,24 @@ int launch_mfma_inst(const MfmaScanArgs& a, int device, hipStream_t stream, int*
 }
 
 template <int KB, int NG, int SKB>
+int launch_mfma2_gated_inst(const MfmaScanArgs& a, int device, hipStream_t stream, int* nblocks_out, const int* gate, int gate_lo) {
+    auto kern = flat_scan_mfma2_gated_kernel<KB, NG, SKB>;
+    const size_t lds = (size_t)kScanWaves * mfma2_wave_lds_bytes(SKB) + (size_t)kScanWaves * NG * 16 * a.k * 8;
+    MVDB_TRY(ensure_dynamic_lds((const void*)kern, lds, device));
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, kScanThreads, lds) != hipSuccess || nb <= 0)
+        nb = 1;
+    nb = std::min(nb, std::max(1, env_int("MVDB_MFMA_BLOCKS_PER_CU", 2)));
+    const int64_t ntiles = (a.n + 15) / 16;
+    const int64_t want = (ntiles + kScanWaves - 1) / kScanWaves;
+    const int nblocks = (int)std::max<int64_t>(1, std::min<int64_t>(want, (int64_t)device_cus(device) * nb));
+    *nblocks_out = nblocks;
+    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(kScanThreads), lds, stream, a, gate, gate_lo);
+    MVDB_HIP(hipGetLastError());
+    return 0;
+}
+
+template <int KB, int NG, int SKB>
 int launch_mfma2_inst(const MfmaScanArgs& a, int device, hipStream_t stream, int* nblocks_out) {
     auto kern = flat_scan_mfma2_kernel<KB, NG, SKB>;
     const size_t lds = (size_t)kScanWaves * mfma2_wave_lds_bytes(SKB) + (size_t)kScanWaves * NG * 16 * a.k * 8;
@@ -486,6 +504,26 @@ int launch_mfma2(int KB, const MfmaScanArgs& a, int device, hipStream_t s, int* 
     return fail(MVDB_ERR_ARG, "no staged multi-query kernel for d = %d with %d query group(s)", KB * 16, NG);
 }
 
+// The exact re-run of uncertified queries (search_core): the same pass, enabled on the device by `*gate > gate_lo`.
+// Returns the queries one launch takes (32 at d <= 512, 16 at d = 768 / 1024), 0 when there is no kernel for d.
+int mfma_gated_queries(const mvdb_index* idx) {
+    const int KB = idx->d / 16;
+    if (idx->d % 128 != 0) return 0;  // the staged kernel only
+    return KB <= 32 ? 32 : (KB == 48 || KB == 64) ? 16 : 0;
+}
+int launch_mfma2_gated(int KB, const MfmaScanArgs& a, int device, hipStream_t s, int* nb, const int* gate, int gate_lo) {
+    switch (KB) {
+        case 8: return launch_mfma2_gated_inst<8, 2, 8>(a, device, s, nb, gate, gate_lo);
+        case 16: return launch_mfma2_gated_inst<16, 2, 8>(a, device, s, nb, gate, gate_lo);
+        case 24: return launch_mfma2_gated_inst<24, 2, 8>(a, device, s, nb, gate, gate_lo);
+        case 32: return launch_mfma2_gated_inst<32, 2, 8>(a, device, s, nb, gate, gate_lo);
+        case 48: return launch_mfma2_gated_inst<48, 1, 8>(a, device, s, nb, gate, gate_lo);
+        case 64: return launch_mfma2_gated_inst<64, 1, 8>(a, device, s, nb, gate, gate_lo);
+        default: break;
+    }
+    return fail(MVDB_ERR_ARG, "no gated multi-query kernel for d = %d", KB * 16);
+}
+
 template <int NG>
 int launch_mfma_ng(int KB, const MfmaScanArgs& a, int device, hipStream_t s, int* nb) {
     switch (KB) {
@@ -507,7 +545,7 @@ bool gemm_path_ok(const mvdb_index* idx, int nq, int k, const int64_t* rows_dev)
 }
 
 int launch_gemm_scan(const mvdb_index* idx, const float* q, int nq, int k, int64_t n, uint64_t* cand,
-                     hipStream_t stream, int* nblocks_out) {
+                     hipStream_t stream, int* nblocks_out, const int* gate = nullptr, int gate_lo = 0) {
     GemmScanArgs a;
     a.X = idx->X;
     a.n = n;
@@ -527,6 +565,12 @@ int launch_gemm_scan(const mvdb_index* idx, const float* q, int nq, int k, int64
     const int64_t ntiles = (n + 127) / 128;
     const int gx = (int)std::max<int64_t>(1, std::min<int64_t>(ntiles, (int64_t)device_cus(idx->device) * nb / qtiles));
     *nblocks_out = gx;
+    if (gate) {
+        MVDB_TRY(ensure_dynamic_lds((const void*)flat_scan_gemm_gated_kernel, lds, idx->device));
+        hipLaunchKernelGGL(flat_scan_gemm_gated_kernel, dim3(gx, qtiles), dim3(256), lds, stream, a, gate, gate_lo);
+        MVDB_HIP(hipGetLastError());
+        return 0;
+    }
     int slot = prof_begin("ip_scan_gemm", stream);
     hipLaunchKernelGGL(flat_scan_gemm_kernel, dim3(gx, qtiles), dim3(256), lds, stream, a);
     prof_end(slot, stream);
@@ -535,7 +579,19 @@ int launch_gemm_scan(const mvdb_index* idx, const float* q, int nq, int k, int64
 }
 
 // nq >= 33, k <= 12, rows of known norm: split-precision bf16 pass + exact certification (scan_split_kernels.hpp)
-std::atomic<long> g_split_reruns{0};
+// Chunks that held an uncertified query, counted ON THE DEVICE (split_plan_kernel): the host never reads a certification
+// flag on the search path.  One counter per device, read (with a device synchronise) by mvdb_split_rerun_count().
+std::mutex g_rerun_mu;
+std::map<int, unsigned long long*> g_rerun_ctr;
+unsigned long long* rerun_counter(int device) {
+    std::lock_guard<std::mutex> lk(g_rerun_mu);
+    auto it = g_rerun_ctr.find(device);
+    if (it != g_rerun_ctr.end()) return it->second;
+    unsigned long long* p = nullptr;
+    if (hipMalloc((void**)&p, sizeof(*p)) != hipSuccess || hipMemset(p, 0, sizeof(*p)) != hipSuccess) return nullptr;
+    g_rerun_ctr[device] = p;
+    return p;
+}
 
 // Worst-case bound, per unit |q| * max|x|, on everything that separates the quantities the certificate compares
 // from the real-number scores t(x) = q.x (derivation: DESIGN.md section 4.3b; checked in tests/test_split_bound.py):
@@ -940,9 +996,6 @@ int search_core(const mvdb_index* idx, Workspace* ws, const float* q_dev, int nq
             MVDB_TRY(ws->qsplit.reserve((size_t)std::max(2 * 128, chunk) * idx->d));
             MVDB_TRY(ws->qnorm.reserve((size_t)std::max(256, 3 * chunk)));  // |q|, admission floors (, fp16 pass: 1 / scale)
             MVDB_TRY(ws->flags.reserve((size_t)std::max(nchunks, 64) + 32));  // + diagnostics counters in the last 32 slots
-            // pinned: [nchunks] chunk counts | [q0] per-query flags | [q0] int64 list of the failed queries
-            const size_t pin_list = ((size_t)(nchunks + q0) * sizeof(int) + 7) & ~(size_t)7;
-            MVDB_TRY(ws->pin_flags.reserve(pin_list + (size_t)q0 * sizeof(int64_t)));
             MVDB_TRY(ws->cand.reserve((size_t)std::max(128, chunk) * (scan_grid_upper_bound(idx->device) + 1) * kSplitKeep));
             MVDB_TRY(ws->qfail.reserve((size_t)q0));
             MVDB_HIP(hipMemsetAsync(ws->flags.p, 0, (size_t)nchunks * sizeof(int), s));
@@ -956,50 +1009,88 @@ int search_core(const mvdb_index* idx, Workspace* ws, const float* q_dev, int nq
                     MVDB_TRY(launch_split_scan(idx, ws, qsrc + (int64_t)c0 * idx->ld, take, k, n, label_offset,
                                                D_dev + (int64_t)c0 * k, I_dev + (int64_t)c0 * k, ws->flags.p + c, ws->qfail.p + c0));
             }
-            int* hflags = static_cast<int*>(ws->pin_flags.p);
-            int* hfail = hflags + nchunks;
-            MVDB_HIP(hipMemcpyAsync(hflags, ws->flags.p, (size_t)nchunks * sizeof(int), hipMemcpyDeviceToHost, s));
-            MVDB_HIP(hipMemcpyAsync(hfail, ws->qfail.p, (size_t)q0 * sizeof(int), hipMemcpyDeviceToHost, s));
-            MVDB_HIP(hipStreamSynchronize(s));
-            int bad_chunks = 0;
-            for (int c = 0; c < nchunks; ++c) bad_chunks += hflags[c] != 0;
-            if (bad_chunks) {
-                g_split_reruns.fetch_add(bad_chunks, std::memory_order_relaxed);
-                int64_t* hlist = reinterpret_cast<int64_t*>(static_cast<char*>(ws->pin_flags.p) + pin_list);
-                int64_t nb = 0;
-                for (int i = 0; i < q0; ++i)
-                    if (hfail[i]) hlist[nb++] = i;
-                // Few uncertified queries (a handful of duplicate-heavy neighbourhoods in a batch): only THOSE go through
-                // the exact kernels, gathered into one compact batch — a 32-query exact pass costs about one corpus
-                // pass, a whole 128-query chunk on the fp32 matrix cores four.  Many: chunk by chunk as before.
-                const int64_t limit = std::max(1, env_int("MVDB_SPLIT_REQUERY_MAX", 64));
-                if (nb <= limit && nb < q0) {
-                    MVDB_TRY(ws->relabel.reserve((size_t)nb * (1 + k)));
-                    MVDB_TRY(ws->requery.reserve((size_t)nb * (idx->ld + k)));
-                    int64_t* map = ws->relabel.p;
-                    int64_t* It = map + nb;
-                    float* qc = ws->requery.p;
-                    float* Dt = qc + nb * idx->ld;
-                    MVDB_HIP(hipMemcpyAsync(map, hlist, (size_t)nb * sizeof(int64_t), hipMemcpyHostToDevice, s));
-                    const int64_t gtotal = nb * (idx->ld / 4);
-                    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((gtotal + 255) / 256)), dim3(256), 0, s, qc, qsrc,
-                                       (const int64_t*)map, nb, idx->ld);
+            // ---- uncertified queries: re-run on the exact kernels WITHOUT the host ever learning which they were ----------
+            // split_plan_kernel compacts the failed queries (ascending) and publishes their number nb; the exact passes below
+            // are launched unconditionally over the compact batch and enabled on the device: a launch whose query range
+            // starts at or beyond nb returns at once (a few microseconds each when every query certified — the usual case).
+            //   compact queries [0, 64): two 32-query fp32-MFMA passes (one corpus pass each: a handful of duplicate-heavy
+            //                            neighbourhoods in a batch cost about one pass);
+            //   the rest, in 128s:       the GEMM-tiled exact scan (a whole chunk failing: duplicate-heavy data).
+            // No stream synchronise, no device-to-host copy: the call can be captured into a hipGraph (after one eager call
+            // has sized the workspace) and an encoder -> search chain stays one enqueue.
+            unsigned long long* ctr = rerun_counter(idx->device);
+            if (!ctr) return fail(MVDB_ERR_OOM, "device allocation for the re-run counter failed");
+            const int R = q0;  // most queries that can fail
+            MVDB_TRY(ws->nfail.reserve(1));
+            MVDB_TRY(ws->relabel.reserve((size_t)R * (1 + k)));
+            MVDB_TRY(ws->requery.reserve((size_t)(R + 128) * idx->ld + (size_t)R * k));  // + one query tile of slack for the scans
+            int64_t* map = ws->relabel.p;
+            int64_t* It = map + R;
+            float* qc = ws->requery.p;
+            float* Dt = qc + (size_t)(R + 128) * idx->ld;
+            hipLaunchKernelGGL(split_plan_kernel, dim3(1), dim3(64), 0, s, (const int*)ws->flags.p, nchunks, (const int*)ws->qfail.p, q0,
+                               map, ws->nfail.p, ctr);
+            {
+                const int64_t rows = R + 128, gtotal = rows * (idx->ld / 4);
+                const int ggrid = (int)std::min<int64_t>((gtotal + 255) / 256, (int64_t)device_cus(idx->device) * 8);
+                hipLaunchKernelGGL(gather_failed_kernel, dim3(ggrid), dim3(256), 0, s, qc, qsrc, (const int64_t*)map,
+                                   (const int*)ws->nfail.p, rows, idx->ld);
+            }
+            MVDB_HIP(hipGetLastError());
+            const int per_pass = mfma_gated_queries(idx);
+            const int KB = idx->d / 16;
+            int off = 0;
+            if (per_pass > 0 && !env_int("MVDB_DISABLE_MFMA_SCAN", 0)) {
+                MVDB_TRY(ws->cand.reserve((size_t)32 * scan_grid_upper_bound(idx->device) * k));
+                for (int pass = 0; pass < 2 && off < R; ++pass) {
+                    const int take = std::min(per_pass, R - off);
+                    MfmaScanArgs ma;
+                    ma.X = idx->X;
+                    ma.n = n;
+                    ma.ld = idx->ld;
+                    ma.q = qc + (int64_t)off * idx->ld;
+                    ma.nq = take;
+                    ma.k = k;
+                    ma.cand = ws->cand.p;
+                    int nblocks = 0;
+                    MVDB_TRY(launch_mfma2_gated(KB, ma, idx->device, s, &nblocks, ws->nfail.p, off));
+                    MergeArgs mg;
+                    mg.keys = ws->cand.p;
+                    mg.nlists = nblocks;
+                    mg.k = k;
+                    mg.metric = idx->metric;
+                    mg.label_offset = label_offset;
+                    mg.D = Dt + (int64_t)off * k;
+                    mg.I = It + (int64_t)off * k;
+                    mg.gate = ws->nfail.p;
+                    mg.gate_lo = off;
+                    hipLaunchKernelGGL(merge_keys_kernel, dim3(take), dim3(kMergeThreads), 0, s, mg);
                     MVDB_HIP(hipGetLastError());
-                    MVDB_TRY(search_core(idx, ws, qc, (int)nb, k, 0, rows_dev, m, label_offset, Dt, It, false));
-                    hipLaunchKernelGGL(scatter_results_kernel, dim3((unsigned)((nb * k + 255) / 256)), dim3(256), 0, s, Dt, It,
-                                       (const int64_t*)map, nb, k, D_dev, I_dev);
-                    MVDB_HIP(hipGetLastError());
-                    // the pinned list must outlive the upload; the compact buffers the scatter: both are this workspace's
-                    MVDB_HIP(hipStreamSynchronize(s));
-                } else {
-                    for (int c = 0; c < nchunks; ++c) {
-                        if (!hflags[c]) continue;
-                        const int c0 = plan[c].first, take = plan[c].second;
-                        MVDB_TRY(search_core(idx, ws, qsrc + (int64_t)c0 * idx->ld, take, k, 0, rows_dev, m, label_offset,
-                                             D_dev + (int64_t)c0 * k, I_dev + (int64_t)c0 * k, false));
-                    }
+                    off += take;
                 }
             }
+            if (off < R) MVDB_TRY(ws->cand.reserve((size_t)128 * scan_grid_upper_bound(idx->device) * k));
+            while (off < R) {
+                const int take = std::min(128, R - off);
+                int nblocks = 0;
+                MVDB_TRY(launch_gemm_scan(idx, qc + (int64_t)off * idx->ld, take, k, n, ws->cand.p, s, &nblocks, ws->nfail.p, off));
+                MergeArgs mg;
+                mg.keys = ws->cand.p;
+                mg.nlists = nblocks;
+                mg.k = k;
+                mg.metric = idx->metric;
+                mg.label_offset = label_offset;
+                mg.D = Dt + (int64_t)off * k;
+                mg.I = It + (int64_t)off * k;
+                mg.gate = ws->nfail.p;
+                mg.gate_lo = off;
+                hipLaunchKernelGGL(merge_keys_kernel, dim3(take), dim3(kMergeThreads), 0, s, mg);
+                MVDB_HIP(hipGetLastError());
+                off += take;
+            }
+            hipLaunchKernelGGL(scatter_failed_kernel, dim3((unsigned)(((int64_t)R * k + 255) / 256)), dim3(256), 0, s, (const float*)Dt,
+                               (const int64_t*)It, (const int64_t*)map, (const int*)ws->nfail.p, (int64_t)R, k, D_dev, I_dev);
+            MVDB_HIP(hipGetLastError());
         }
         if (q0 == nq) return 0;
         return search_core(idx, ws, qsrc + (int64_t)q0 * idx->ld, nq - q0, k, 0, rows_dev, m, label_offset,
@@ -1615,12 +1706,10 @@ int mvdb_index_search_device(const mvdb_index* idx, const float* q_dev, int nq, 
         MVDB_HIP(hipGetLastError());
         q = ws->q.p;
     }
-    // The split-precision batch pass reads its certification flags on the host (one stream synchronise per call) and
-    // may re-launch: not legal while `stream` is being captured into a graph — the exact kernels are used there.
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    const bool capturing = stream && hipStreamIsCapturing((hipStream_t)stream, &cap) == hipSuccess &&
-                           cap != hipStreamCaptureStatusNone;
-    return search_core(idx, ws, q, nq, k, normalize_q, nullptr, 0, label_offset, D_dev, I_dev, !capturing);
+    // Nothing below synchronises the stream or reads from the device (certification failures of the batch passes are
+    // re-run by device-gated launches): the call may be captured into a hipGraph once an eager call of the same shape
+    // has sized the stream's workspace (allocation is not capturable).
+    return search_core(idx, ws, q, nq, k, normalize_q, nullptr, 0, label_offset, D_dev, I_dev);
 }
 
 __global__ void map_subset_labels_kernel(int64_t* I, int64_t total, const int64_t* __restrict__ rows,
@@ -1720,7 +1809,19 @@ double mvdb_split_eps(int d) { return d > 0 ? split_eps(d) : 0.0; }
 double mvdb_half_eps(int d) { return d > 0 ? half_eps(d) : 0.0; }
 int mvdb_half_max_queries(int d) { return d > 0 ? half_max_queries(d) : 0; }
 
-int64_t mvdb_split_rerun_count(void) { return (int64_t)g_split_reruns.load(std::memory_order_relaxed); }
+int64_t mvdb_split_rerun_count(void) {
+    // diagnostic: the counters live on the devices (the search path never reports to the host); finished work only —
+    // synchronise the streams you searched on first (the host API does)
+    std::lock_guard<std::mutex> lk(g_rerun_mu);
+    int64_t total = 0;
+    for (auto& kv : g_rerun_ctr) {
+        DeviceGuard dg(kv.first);
+        unsigned long long v = 0;
+        if (hipDeviceSynchronize() == hipSuccess && hipMemcpy(&v, kv.second, sizeof(v), hipMemcpyDeviceToHost) == hipSuccess)
+            total += (int64_t)v;
+    }
+    return total;
+}
 
 int mvdb_prof_enable(int on) {
     std::lock_guard<std::mutex> lk(g_prof_mu);

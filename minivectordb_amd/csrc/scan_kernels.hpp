@@ -222,6 +222,8 @@ struct MergeArgs {
     int64_t label_offset;
     float* D;    // [nq, k]
     int64_t* I;  // [nq, k]
+    const int* gate = nullptr;  // optional device-side enable: query blockIdx.x is merged iff *gate > gate_lo + blockIdx.x
+    int gate_lo = 0;
 };
 
 constexpr int kMergeThreads = 1024;
@@ -229,6 +231,7 @@ constexpr int kMergeWaves = kMergeThreads / kWave;
 constexpr int kMergeUnroll = 8;
 
 __global__ __launch_bounds__(kMergeThreads) void merge_keys_kernel(MergeArgs a) {
+    if (a.gate && *a.gate <= a.gate_lo + (int)blockIdx.x) return;
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x >> 6;
     const int qi = blockIdx.x;

@@ -83,7 +83,7 @@ __device__ __forceinline__ void mfma_block_merge(const uint64_t* lists, int nq, 
 }
 
 template <int KB, int NG>
-__global__ __launch_bounds__(kScanThreads) void flat_scan_mfma_kernel(MfmaScanArgs a) {
+__device__ __forceinline__ void flat_scan_mfma_body(const MfmaScanArgs& a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* Qf = reinterpret_cast<float*>(smem);                                   // [NG][KB*4][64]
     uint64_t* lists = reinterpret_cast<uint64_t*>(smem + (size_t)NG * KB * 4 * 64 * 4);  // [4][NG*16][k]
@@ -143,6 +143,17 @@ __global__ __launch_bounds__(kScanThreads) void flat_scan_mfma_kernel(MfmaScanAr
     mfma_block_merge<NG>(lists, a.nq, k, a.cand, lane, wave);
 }
 
+template <int KB, int NG>
+__global__ __launch_bounds__(kScanThreads) void flat_scan_mfma_kernel(MfmaScanArgs a) {
+    flat_scan_mfma_body<KB, NG>(a);
+}
+// enabled by a device-side count (the whole pass runs iff *gate > gate_lo): see flat_scan_gated_kernel
+template <int KB, int NG>
+__global__ __launch_bounds__(kScanThreads) void flat_scan_mfma_gated_kernel(MfmaScanArgs a, const int* __restrict__ gate, int gate_lo) {
+    if (*gate <= gate_lo) return;
+    flat_scan_mfma_body<KB, NG>(a);
+}
+
 }  // namespace mvdb
 
 // =================================================================================================
@@ -168,7 +179,7 @@ constexpr int mfma2_stage_bytes(int skb) { return 16 * skb * 64; }
 constexpr int mfma2_wave_lds_bytes(int skb) { return 2 * mfma2_stage_bytes(skb); }
 
 template <int KB, int NG, int SKB>
-__global__ __launch_bounds__(kScanThreads) void flat_scan_mfma2_kernel(MfmaScanArgs a) {
+__device__ __forceinline__ void flat_scan_mfma2_body(const MfmaScanArgs& a) {
     static_assert(KB % SKB == 0 && (SKB == 8 || SKB == 16), "d must be a multiple of the stage depth");
     constexpr int NS = KB / SKB;  // stages per tile
     constexpr int kStageFloats = SKB * 16, kStageBytes = mfma2_stage_bytes(SKB), kWaveLdsBytes = mfma2_wave_lds_bytes(SKB);
@@ -286,6 +297,17 @@ __global__ __launch_bounds__(kScanThreads) void flat_scan_mfma2_kernel(MfmaScanA
     mfma_block_merge<NG>(lists, a.nq, k, a.cand, lane, wave);
 }
 
+template <int KB, int NG, int SKB>
+__global__ __launch_bounds__(kScanThreads) void flat_scan_mfma2_kernel(MfmaScanArgs a) {
+    flat_scan_mfma2_body<KB, NG, SKB>(a);
+}
+// enabled by a device-side count (the whole pass runs iff *gate > gate_lo): see flat_scan_gated_kernel
+template <int KB, int NG, int SKB>
+__global__ __launch_bounds__(kScanThreads) void flat_scan_mfma2_gated_kernel(MfmaScanArgs a, const int* __restrict__ gate, int gate_lo) {
+    if (*gate <= gate_lo) return;
+    flat_scan_mfma2_body<KB, NG, SKB>(a);
+}
+
 }  // namespace mvdb
 
 // =================================================================================================
@@ -315,7 +337,7 @@ struct GemmScanArgs {
     uint64_t* cand;  // [nq, gridDim.x, k]
 };
 
-__global__ __launch_bounds__(256) void flat_scan_gemm_kernel(GemmScanArgs a) {
+__device__ __forceinline__ void flat_scan_gemm_body(const GemmScanArgs& a) {
     constexpr int BM = 128, BN = 128, BK = 16, LD = BM + 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* tiles = reinterpret_cast<float*>(smem);                                   // [2][A|B][BK][LD]
@@ -454,6 +476,13 @@ __global__ __launch_bounds__(256) void flat_scan_gemm_kernel(GemmScanArgs a) {
         }
         if (lane < k) a.cand[((int64_t)qq * gridDim.x + blockIdx.x) * k + lane] = tk.key;
     }
+}
+
+__global__ __launch_bounds__(256) void flat_scan_gemm_kernel(GemmScanArgs a) { flat_scan_gemm_body(a); }
+// enabled by a device-side count (the whole launch runs iff *gate > gate_lo): see flat_scan_gated_kernel
+__global__ __launch_bounds__(256) void flat_scan_gemm_gated_kernel(GemmScanArgs a, const int* __restrict__ gate, int gate_lo) {
+    if (*gate <= gate_lo) return;
+    flat_scan_gemm_body(a);
 }
 
 }  // namespace mvdb

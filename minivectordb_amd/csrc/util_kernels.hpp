@@ -129,6 +129,58 @@ __global__ __launch_bounds__(256) void scatter_results_kernel(const float* __res
     I[map[r] * k + c] = It[i];
 }
 
+// ---- device-side bookkeeping of a certified batch pass (mvdb.hip: search_core) -----------------------------------------
+// The host never reads the certification flags: one wave turns the per-query flags into the compact, ascending list of the
+// queries that failed (map[0 .. nb)), publishes nb and adds the number of chunks that held one to the re-run counter.
+__global__ __launch_bounds__(64) void split_plan_kernel(const int* __restrict__ chunk_flags, int nchunks,
+                                                        const int* __restrict__ qfail, int nq, int64_t* __restrict__ map,
+                                                        int* __restrict__ nb_out, unsigned long long* __restrict__ rerun_ctr) {
+    const int lane = threadIdx.x;
+    int bad = 0;
+    for (int c = lane; c < nchunks; c += 64) bad += chunk_flags[c] != 0;
+    for (int m = 32; m >= 1; m >>= 1) bad += __shfl_xor(bad, m);
+    int run = 0;
+    for (int base = 0; base < nq; base += 64) {
+        const int i = base + lane;
+        const bool f = i < nq && qfail[i] != 0;
+        const unsigned long long mask = __ballot(f);
+        if (f) map[run + __popcll(mask & ((1ull << lane) - 1ull))] = i;
+        run += __popcll(mask);
+    }
+    if (lane == 0) {
+        *nb_out = run;
+        if (bad) atomicAdd(rerun_ctr, (unsigned long long)bad);
+    }
+}
+
+// dst[r, :] = src[map[r], :] for r < *nb, zeros for the other rows of [0, rows) (the gated exact kernels read whole
+// query tiles)
+__global__ __launch_bounds__(256) void gather_failed_kernel(float* __restrict__ dst, const float* __restrict__ src,
+                                                            const int64_t* __restrict__ map, const int* __restrict__ nb,
+                                                            int64_t rows, int64_t ld) {
+    const int64_t d4 = ld / 4;
+    const int64_t total = rows * d4;
+    const int64_t live = *nb;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / d4, c = i - r * d4;
+        f32x4u v = {0.f, 0.f, 0.f, 0.f};
+        if (r < live) v = *reinterpret_cast<const f32x4u*>(src + map[r] * ld + c * 4);
+        *reinterpret_cast<f32x4u*>(dst + r * ld + c * 4) = v;
+    }
+}
+
+// D[map[r], :] = Dt[r, :] (same for I) for r < *nb
+__global__ __launch_bounds__(256) void scatter_failed_kernel(const float* __restrict__ Dt, const int64_t* __restrict__ It,
+                                                             const int64_t* __restrict__ map, const int* __restrict__ nb, int64_t rows,
+                                                             int k, float* __restrict__ D, int64_t* __restrict__ I) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * k) return;
+    const int64_t r = i / k, c = i - r * k;
+    if (r >= *nb) return;
+    D[map[r] * k + c] = Dt[i];
+    I[map[r] * k + c] = It[i];
+}
+
 // new row r keeps old row r + (number of deleted rows <= that old row); del[] ascending, unique.
 __global__ __launch_bounds__(256) void build_keep_map_kernel(const int64_t* __restrict__ del,
                                                              int64_t m, int64_t n_new,

@@ -76,6 +76,8 @@ class GpuEncoder:
             name = lib.mvdb_encoder_weight_name(ctypes.byref(self.cfg), i).decode()
             t = state_dict[prefix + name]
             t = t.detach().to(device=self.device, dtype=torch.float32).contiguous()
+            if t.data_ptr() % 16:  # the kernels read weights and biases in 16-byte pieces (a view into a larger tensor)
+                t = t.clone()
             self._weights.append(t)
             table[i] = t.data_ptr()
         torch.cuda.synchronize(self.device)

@@ -51,3 +51,22 @@ class SpmXlmrTokenizer:
             ids[i, :len(r)] = r
             mask[i, :len(r)] = 1
         return {"input_ids": ids, "attention_mask": mask}
+
+
+def hf_fast_tokenizer(vocab_size=200):
+    """A REAL HF tokenizer object that `save_pretrained` / `AutoTokenizer.from_pretrained` round-trip offline: a
+    `tokenizers` Unigram model trained on CORPUS with XLM-R's special-token layout (<s> = 0, <pad> = 1, </s> = 2,
+    <unk> = 3) and its `<s> A </s>` template, wrapped as PreTrainedTokenizerFast.  Used by the production-load-path
+    test (tests/test_load_path_gpu.py); the released e5 / bge-m3 tokenizer files are not available offline."""
+    from tokenizers import Tokenizer, decoders, models, pre_tokenizers, processors, trainers
+    from transformers import PreTrainedTokenizerFast
+    tok = Tokenizer(models.Unigram())
+    tok.pre_tokenizer = pre_tokenizers.Metaspace()
+    tok.decoder = decoders.Metaspace()
+    trainer = trainers.UnigramTrainer(vocab_size=vocab_size, special_tokens=["<s>", "<pad>", "</s>", "<unk>"],
+                                      unk_token="<unk>", show_progress=False)
+    tok.train_from_iterator(CORPUS * 20, trainer)
+    tok.post_processor = processors.TemplateProcessing(single="<s> $A </s>", pair="<s> $A </s> </s> $B </s>",
+                                                       special_tokens=[("<s>", 0), ("</s>", 2)])
+    return PreTrainedTokenizerFast(tokenizer_object=tok, bos_token="<s>", eos_token="</s>", pad_token="<pad>",
+                                   unk_token="<unk>", cls_token="<s>", sep_token="</s>")

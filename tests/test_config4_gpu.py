@@ -68,9 +68,23 @@ def test_config4_two_rank_bench_path_on_a_shared_gpu(gpu, tmp_path):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", str(steps),
            "--warmup", str(warmup), "--rows", str(rows), "--dim", str(d), "--k", str(k), "--dump", dump]
-    p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
-    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
-    line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
+    # own session + faulthandler: if the two ranks ever hang, SIGABRT makes every Python process of the job print where
+    import signal
+    env["PYTHONFAULTHANDLER"] = "1"
+    proc = subprocess.Popen(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                            start_new_session=True)
+    try:
+        so, se = proc.communicate(timeout=int(os.environ.get("MVDB_TEST_SUBPROCESS_TIMEOUT", "600")))
+    except subprocess.TimeoutExpired:
+        os.killpg(proc.pid, signal.SIGABRT)
+        try:
+            so, se = proc.communicate(timeout=20)
+        except subprocess.TimeoutExpired:
+            os.killpg(proc.pid, signal.SIGKILL)
+            so, se = proc.communicate()
+        pytest.fail("two-rank bench.py hung; tracebacks of its processes:\n" + so[-1500:] + se[-6000:])
+    assert proc.returncode == 0, so[-2000:] + se[-4000:]
+    line = [l for l in so.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["corpus_rows"] == 2 * rows
     # headline = queries/s over the WHOLE corpus (not shard passes summed over ranks)

@@ -53,6 +53,71 @@ def test_encoder_matches_transformers_golden(i, compute, gpu):
         encc.close()
 
 
+@pytest.mark.parametrize("switches", [{"MVDB_GEMM_LN_FUSED": "2"}, {"MVDB_GEMM_LN_FUSED": "0"},
+                                      {"MVDB_ATTENTION_IMG": "0", "MVDB_GEMM_LN_FUSED": "0"}],
+                         ids=["ln-fused-always", "ln-kernel", "fp32-qkv-attention"])
+@pytest.mark.parametrize("i", range(len(CASES)))
+def test_split_precision_kernel_variants_match_golden(i, switches, gpu, monkeypatch):
+    """The default picks by batch size between (a) the N = H GEMMs with bias + residual + LayerNorm fused into their epilogue
+    (gemm_x3_ln_kernel: row-owning workgroups, 32 / 64 / 128 rows by batch size) and (b) the 2D-tiled GEMM + ln_kernel; and
+    attention runs on the (hi | lo) Q / K / V images of the QKV epilogue (attention_x3i_kernel: LDS-DMA'd tiles, transposed
+    LDS reads) with the fp32-qkv kernel as the A/B reference.  Every variant, forced on every golden case (widths the
+    fused kernel has no instantiation for — H = 64, 96, 1024 — fall back to (b) by themselves)."""
+    import torch
+    for k, v in switches.items():
+        monkeypatch.setenv(k, v)  # read when the encoder is created
+    c = CASES[i]
+    cfg = E.make_config(c["name"])
+    enc = _model(cfg, E.make_weights(cfg, c["wseed"]))
+    emb = enc.forward(c["ids"], c["mask"], compute=2)
+    np.testing.assert_allclose(emb, c["emb"], atol=2e-5, rtol=0)
+    if c["hidden_valid"] is not None:
+        dev = torch.device("cuda", 0)
+        _, hidden = enc.forward_device(torch.from_numpy(c["ids"]).to(dev), torch.from_numpy(c["mask"]).to(dev), compute=2,
+                                       want_hidden=True)
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(hidden.cpu().numpy()[c["mask"].astype(bool)], c["hidden_valid"], atol=1e-4, rtol=0)
+    enc.close()
+
+
+def test_batch_composition_does_not_change_a_row(gpu, monkeypatch):
+    """A sentence's embedding is bit-for-bit the same whatever else is in the batch and wherever its rows fall in a tile
+    (the reference semantics are B = 1).  Round 3 found hipcc contracting `a * b + c` INTO the fp16 conversion of the
+    (hi | lo) split (v_fma_mixlo_f16) on one epilogue path and not on another: the inputs of the split are opaque now."""
+    for fused in ("2", "0"):
+        monkeypatch.setenv("MVDB_GEMM_LN_FUSED", fused)
+        cfg = E.make_config("e5-small-dims")
+        enc = _model(cfg, E.make_weights(cfg, 21))
+        ids, mask = E.make_inputs(cfg, 8, 40, 22)
+        ref = enc.forward(ids, mask)
+        for nb in (1, 2, 3, 5, 7):
+            assert np.array_equal(enc.forward(ids[:nb], mask[:nb]), ref[:nb]), (fused, nb)
+        enc.close()
+
+
+def test_exact_mode_second_lane_workspace_grows(gpu):
+    """The exact mode runs big batches as two halves on two streams; the second half's workspace has its own capacity
+    (round-2 advisor finding: after forward(256, 256) a forward(129, 508) fits the first lane's 65536-token capacity but
+    its second half needs 65 * 508 = 33020 token slots > the 32768 the second lane was sized for)."""
+    cfg = E.make_config("tiny")
+    w = E.make_weights(cfg, 3)
+    cfg = dict(cfg, max_position_embeddings=512)
+    w["embeddings.position_embeddings.weight"] = np.random.RandomState(5).standard_normal((512, cfg["hidden_size"])).astype(np.float32) * 0.5
+    enc = _model(cfg, w)
+    ids1, mask1 = E.make_inputs(cfg, 256, 256, 1)
+    enc.forward(ids1, mask1, compute=0)
+    ids2, mask2 = E.make_inputs(cfg, 129, 508, 2)
+    got = enc.forward(ids2, mask2, compute=0)       # split: lanes of 64 and 65 sentences
+    enc2 = _model(cfg, w)                            # fresh workspace, sized for this call
+    want = enc2.forward(ids2, mask2, compute=0)
+    assert np.array_equal(got, want)
+    for b in (0, 64, 128):                           # and a row equals its own single-sentence forward
+        n = int(mask2[b].sum())
+        np.testing.assert_allclose(got[b], enc.forward(ids2[b:b + 1, :n], mask2[b:b + 1, :n], compute=0)[0], atol=2e-6, rtol=0)
+    enc.close()
+    enc2.close()
+
+
 def test_encoder_matches_float64_and_live_transformers(gpu):
     cfg = E.make_config("e5-small-dims")
     w = E.make_weights(cfg, 21)

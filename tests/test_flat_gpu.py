@@ -774,3 +774,50 @@ def test_split_precision_pass_falls_back_when_it_cannot_certify(native, monkeypa
         native.prof_enable(False)
     idx2.close()
     idx.close()
+
+
+def test_batch_search_never_syncs_and_is_capturable(native):
+    """mvdb_index_search_device reads nothing back from the device: queries a certified batch pass cannot certify are
+    compacted, re-run on the exact kernels and scattered by launches that are enabled on the device.  So a 256-query
+    search — one of its queries planted on 40 exact duplicates, which MUST be re-run — can be captured into a hipGraph
+    (after one eager call has sized the stream's workspace) and replays to the eager call's ids and scores; with other
+    queries in the same buffers the replay re-decides on the device which of them to re-run."""
+    import torch
+    n, d, k, nq = 30000, 512, 10, 256
+    x = _corpus(n, d)
+    q = _corpus(nq, d, seed=77)
+    x[1000:1040] = q[3]            # query 3 cannot be certified
+    q2 = _corpus(nq, d, seed=78)
+    x[9000:9040] = q2[130]         # in the second query set it is query 130 (and query 3 certifies)
+    idx = native.FlatIndex(d)
+    idx.add(x)
+    dev = torch.device("cuda", 0)
+    qt = torch.from_numpy(q).to(dev)
+    D = torch.empty((nq, k), dtype=torch.float32, device=dev)
+    I = torch.empty((nq, k), dtype=torch.int64, device=dev)
+    stream = torch.cuda.Stream(dev)
+    with torch.cuda.stream(stream):
+        before = native.split_rerun_count()
+        idx.search_device(qt.data_ptr(), nq, k, D.data_ptr(), I.data_ptr(), stream=stream.cuda_stream)   # eager: sizes the workspace
+        stream.synchronize()
+        assert native.split_rerun_count() == before + 1
+        D0, I0 = D.cpu().numpy().copy(), I.cpu().numpy().copy()
+        assert I0[3].tolist() == list(range(1000, 1010))
+        _check(native, x, q, k, D0, I0)
+        g = torch.cuda.CUDAGraph()
+        D.zero_()
+        I.zero_()
+        with torch.cuda.graph(g, stream=stream, capture_error_mode="thread_local"):
+            idx.search_device(qt.data_ptr(), nq, k, D.data_ptr(), I.data_ptr(), stream=stream.cuda_stream)
+        g.replay()
+        stream.synchronize()
+        torch.cuda.synchronize()
+        assert np.array_equal(I.cpu().numpy(), I0) and np.array_equal(D.cpu().numpy(), D0)
+        # other queries through the SAME graph: which of them is re-run is decided on the device at replay time
+        qt.copy_(torch.from_numpy(q2).to(dev))
+        g.replay()
+        torch.cuda.synchronize()
+        D1, I1 = D.cpu().numpy(), I.cpu().numpy()
+        assert I1[130].tolist() == list(range(9000, 9010))
+        _check(native, x, q2, k, D1, I1)
+    idx.close()
