@@ -115,11 +115,11 @@ int mvdb_index_search(const mvdb_index* idx, const float* q_host, int nq, int k,
  * NULL for the legacy default stream).  label_offset is added to every label (global row number of
  * this shard's first row).  This is the entry point the one-process-per-GPU sharded search uses
  * ahead of its RCCL all-gather.
- * Synchronisation: calls with fewer than 14 queries, k > 12, or a corpus of unknown row norms return
- * without synchronising.  Batches served by the split-precision pass (>= 14 queries, k <= 12)
- * synchronise `stream` ONCE per call, after the last pass, to read the per-chunk certification flags
- * (a chunk that failed is re-run on the exact kernels before the call returns); while `stream` is
- * being captured into a hipGraph that pass is not used, so the call stays capturable.
+ * Synchronisation: NONE, whatever the batch size.  The host never reads a certification flag: the queries a
+ * certified batch pass could not certify are compacted, re-run on the exact kernels and scattered back by launches
+ * that are enabled ON THE DEVICE (they return at once when every query certified).  The call can therefore be captured
+ * into a hipGraph — after one eager call of the same shape on that stream has sized its workspace (allocation is not
+ * capturable) — e.g. encoder forward -> search as ONE graph.
  * One search at a time per (index, stream): concurrent calls naming the same stream are serialised. */
 int mvdb_index_search_device(const mvdb_index* idx, const float* q_dev, int nq, int k,
                              int normalize_q, int64_t label_offset, float* D_dev, int64_t* I_dev,
@@ -143,6 +143,42 @@ int mvdb_index_search_subset(const mvdb_index* idx, const float* q_host, int nq,
 int mvdb_index_search_subset_device(const mvdb_index* idx, const float* q_dev, int nq, int k, int normalize_q,
                                     const int64_t* rows_dev, int64_t m, int map_labels, int64_t label_offset,
                                     float* D_dev, int64_t* I_dev, void* stream);
+
+/* Search restricted to the rows whose bit is set in a BITMAP over the resident corpus: mask[(ntotal + 63) / 64] 64-bit
+ * words, bit (r & 63) of word r >> 6 = row r; bits at or beyond ntotal are ignored.  Every row is scored in ONE pass at
+ * the full scan's rate and rows with a clear bit are never offered to the top-k — the form for filters that keep MOST
+ * rows (the reference's exclude-filters: a row list of ~ntotal entries gathered row by row is slower than the scan it
+ * avoids, and its 8 bytes per row are the upload).  labels == 0: positions in the ascending list of the set rows — exactly
+ * what mvdb_index_search_subset returns for that list; labels == 1: row numbers.  Exact score ties resolve to the lower
+ * row number in both.  Fewer than k rows selected: the tail is -1 / -FLT_MAX (IP) as everywhere.
+ * Replaces the same per-query sub-index as mvdb_index_search_subset
+ *                                                minivectordb/vector_database.py:508-523 (exclude filters :354-386)
+ *                                                minivectordb/sharded_vector_database.py:634-649 */
+int mvdb_index_search_masked(const mvdb_index* idx, const float* q_host, int nq, int k, int normalize_q,
+                             const uint64_t* mask_host, int labels, float* D_host, int64_t* I_host);
+
+/* Device-resident variant (mask_dev, queries and outputs in device memory, enqueued on `stream`, no synchronisation);
+ * labels == 1: row number + label_offset. */
+int mvdb_index_search_masked_device(const mvdb_index* idx, const float* q_dev, int nq, int k, int normalize_q,
+                                    const uint64_t* mask_dev, int labels, int64_t label_offset, float* D_dev,
+                                    int64_t* I_dev, void* stream);
+
+/* A filter's rows kept RESIDENT on the device, so that consecutive searches under the same filter (the reference
+ * re-evaluates its filter and re-gathers the rows for every query, vector_database.py:477-523) pay neither the host pass
+ * over the list nor its upload again.  excluded == 0: the m listed rows (labels order ties by list position, as
+ * mvdb_index_search_subset); excluded != 0: every row BUT the listed ones (an exclude-filter: m is small, the set is
+ * ~ntotal rows).  The library picks the representation: a bitmap (n / 8 bytes; one full-rate pass per search) for excluded
+ * sets and for sorted lists that keep >= 1/3 of the rows, a device row list otherwise.  A set belongs to the index state it
+ * was built against: rows appended later are not part of it; after a removal (rows renumbered) searching it fails with
+ * MVDB_ERR_ARG. */
+typedef struct mvdb_rowset mvdb_rowset;
+int mvdb_rowset_create(const mvdb_index* idx, const int64_t* rows_host, int64_t m, int excluded, mvdb_rowset** out);
+int64_t mvdb_rowset_size(const mvdb_rowset* rs);      /* rows selected */
+int mvdb_rowset_is_bitmap(const mvdb_rowset* rs);
+int mvdb_rowset_free(mvdb_rowset* rs);
+/* labels are ROW NUMBERS of the index (not positions).  Replaces the same call sites as mvdb_index_search_subset. */
+int mvdb_index_search_rowset(const mvdb_index* idx, const float* q_host, int nq, int k, int normalize_q,
+                             const mvdb_rowset* rs, float* D_host, int64_t* I_host);
 
 /* Merge `nlists` sorted top-k lists per query into one [nq,k] result on the device.  List l lives
  * at D_dev + l*list_stride_D (floats, [nq,k]) and I_dev + l*list_stride_I (int64, [nq,k]) — the

@@ -33,6 +33,25 @@ class _AllRows:
         return set(range(self.n))
 
 
+class _AllRowsExcept:
+    """Symbolic 'every stored row but these' — what an exclude-filter leaves of `_AllRows` (the reference subtracts from an
+    O(N) Python set per query, vector_database.py:354-386).  Searched as a resident bitmap (`mvdb_rowset_create(...,
+    excluded=1)`): n / 8 bytes up the wire, one full-rate pass over the corpus."""
+
+    def __init__(self, n, removed):
+        self.n = n
+        self.removed = {r for r in removed if 0 <= r < n}
+
+    def __len__(self):
+        return self.n - len(self.removed)
+
+    def __bool__(self):
+        return len(self) > 0
+
+    def materialize(self):
+        return set(range(self.n)) - self.removed
+
+
 class _RowStore:
     """The stacked embedding matrix of a database, WITHOUT a host mirror of what the device already holds.
 
@@ -280,9 +299,47 @@ class FilterAndRerankMixin:
         if len(wanted) == n_rows:
             scores, rows = index.search(query, take, normalize_q=True)
             return [(int(r), s) for r, s in zip(rows[0], scores[0]) if r != -1]
-        subset = self._subset_order(wanted)
-        scores, positions = index.search_subset(query, take, subset, normalize_q=True)
-        return [(int(subset[p]), s) for p, s in zip(positions[0], scores[0]) if p != -1]
+        for attempt in range(3):
+            rowset = self._resident_rowset(index, wanted, (metadata_filter, exclude_filter, or_filters))
+            try:
+                scores, rows = index.search_rowset(query, take, rowset, normalize_q=True)
+                break
+            except ValueError:
+                # another thread deleted rows between the filter and the search (the reference would still be searching
+                # its old index object): evaluate the filter again on the current rows
+                if attempt == 2:
+                    raise
+                with self.lock:
+                    self._invalidate_filter_cache()
+                    wanted = self._get_filtered_indices(metadata_filter, exclude_filter, or_filters)
+                    index = self.index
+                if not wanted or index is None:
+                    return []
+                take = min(k, len(wanted))
+        return [(int(r), s) for r, s in zip(rows[0], scores[0]) if r != -1]
+
+    def _resident_rowset(self, index, wanted, filters):
+        """The filtered rows as a device-resident row set (`mvdb_rowset`), kept until the next write: the reference
+        gathers the filtered rows into a throw-away index for EVERY query (vector_database.py:508-523); here consecutive
+        queries under one filter upload nothing.  An exclude-filter over everything travels as the few excluded rows and
+        lives as a bitmap; a row list keeps the reference's enumeration order (`_subset_order`: ties resolve as there)."""
+        cache = self.__dict__.setdefault("_rowsets", {})
+        try:
+            key = repr(filters)
+        except Exception:
+            key = None
+        hit = cache.get(key) if key is not None else None
+        if hit is not None and hit[0] is index:
+            return hit[1]
+        if isinstance(wanted, _AllRowsExcept):
+            rowset = index.rowset(np.fromiter(wanted.removed, dtype=np.int64, count=len(wanted.removed)), excluded=True)
+        else:
+            rowset = index.rowset(self._subset_order(wanted))
+        if key is not None:
+            if len(cache) >= 16:  # a handful of filters in rotation; each holds device memory until its last user drops it
+                cache.clear()
+            cache[key] = (index, rowset)
+        return rowset
 
     def _package(self, hits, autocut):
         """[(id, score, metadata)] -> (ids, distances, metadatas): tuples, three empty lists when there
@@ -366,6 +423,9 @@ class FilterAndRerankMixin:
 
     def _invalidate_filter_cache(self):
         self.__dict__["_value_index"] = {}
+        # built against the previous rows: dropped, not closed — a search running outside the lock may still hold one
+        # (its device memory goes when the last reference does)
+        self.__dict__["_rowsets"] = {}
 
     def _apply_or_filter(self, or_filters):
         result_indices = set()
@@ -421,7 +481,7 @@ class FilterAndRerankMixin:
                 # only pay the O(N) set when something is actually excluded
                 probe = self._apply_exclude_filter(exclude_filter, _ExclusionProbe())
                 if probe.removed:
-                    filtered_indices = filtered_indices.materialize() - probe.removed
+                    filtered_indices = _AllRowsExcept(filtered_indices.n, probe.removed)
             else:
                 filtered_indices = self._apply_exclude_filter(exclude_filter, filtered_indices)
 

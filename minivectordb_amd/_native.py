@@ -73,6 +73,15 @@ PROTOTYPES = {
                                                 ctypes.c_int64, c_vp, c_vp]),
     "mvdb_index_search_subset_device": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_vp,
                                                        ctypes.c_int64, ctypes.c_int, ctypes.c_int64, c_vp, c_vp, c_vp]),
+    "mvdb_index_search_masked": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_vp, ctypes.c_int,
+                                                c_vp, c_vp]),
+    "mvdb_index_search_masked_device": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_vp,
+                                                       ctypes.c_int, ctypes.c_int64, c_vp, c_vp, c_vp]),
+    "mvdb_rowset_create": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int64, ctypes.c_int, ctypes.POINTER(c_vp)]),
+    "mvdb_rowset_size": (ctypes.c_int64, [c_vp]),
+    "mvdb_rowset_is_bitmap": (ctypes.c_int, [c_vp]),
+    "mvdb_rowset_free": (ctypes.c_int, [c_vp]),
+    "mvdb_index_search_rowset": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_vp, c_vp, c_vp]),
     "mvdb_comm_available": (ctypes.c_int, []),
     "mvdb_comm_unique_id": (ctypes.c_int, [c_vp]),
     "mvdb_comm_create": (ctypes.c_int, [c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(c_vp)]),
@@ -236,6 +245,48 @@ class FlatIndex:
                                              rows.shape[0], _ptr(D), _ptr(I)))
         return D, I
 
+    def rowset(self, rows, excluded=False):
+        """The listed rows (or, excluded=True, every row BUT them) made resident on the device for repeated searches under
+        one filter: see RowSet."""
+        return RowSet(self, rows, excluded)
+
+    def search_rowset(self, q, k, rowset, normalize_q=False):
+        """Search a resident RowSet; labels are ROW NUMBERS of the index."""
+        q = np.ascontiguousarray(np.atleast_2d(np.asarray(q, dtype=np.float32)))
+        if q.shape[1] != self.d:
+            raise ValueError(f"query dimension {q.shape[1]} != index dimension {self.d}")
+        nq = q.shape[0]
+        D = np.empty((nq, k), dtype=np.float32)
+        I = np.empty((nq, k), dtype=np.int64)
+        check(lib().mvdb_index_search_rowset(self._h, _ptr(q), nq, int(k), int(bool(normalize_q)), rowset._h, _ptr(D),
+                                             _ptr(I)))
+        return D, I
+
+    def search_masked(self, q, k, mask_words, normalize_q=False, labels="rows"):
+        """Search the rows whose bit is set in `mask_words` (uint64[(ntotal + 63) // 64], bit r & 63 of word r >> 6 = row r;
+        `pack_row_mask` builds it).  labels="rows": row numbers; "positions": positions in the ascending list of the
+        selected rows (what search_subset returns for that list)."""
+        q = np.ascontiguousarray(np.atleast_2d(np.asarray(q, dtype=np.float32)))
+        if q.shape[1] != self.d:
+            raise ValueError(f"query dimension {q.shape[1]} != index dimension {self.d}")
+        mask_words = np.ascontiguousarray(mask_words, dtype=np.uint64)
+        if mask_words.shape[0] < (self.ntotal + 63) // 64:
+            raise ValueError("the mask has fewer than (ntotal + 63) // 64 words")
+        nq = q.shape[0]
+        D = np.empty((nq, k), dtype=np.float32)
+        I = np.empty((nq, k), dtype=np.int64)
+        check(lib().mvdb_index_search_masked(self._h, _ptr(q), nq, int(k), int(bool(normalize_q)), _ptr(mask_words),
+                                             {"positions": 0, "rows": 1}[labels], _ptr(D), _ptr(I)))
+        return D, I
+
+    def search_masked_device(self, q_ptr, nq, k, mask_ptr, D_ptr, I_ptr, stream=0, normalize_q=False, labels="rows",
+                             label_offset=0):
+        """Device-pointer variant of search_masked."""
+        check(lib().mvdb_index_search_masked_device(
+            self._h, ctypes.c_void_p(q_ptr), int(nq), int(k), int(bool(normalize_q)), ctypes.c_void_p(mask_ptr),
+            {"positions": 0, "rows": 1}[labels], int(label_offset), ctypes.c_void_p(D_ptr), ctypes.c_void_p(I_ptr),
+            ctypes.c_void_p(stream)))
+
     def search_device(self, q_ptr, nq, k, D_ptr, I_ptr, stream=0, normalize_q=False, label_offset=0):
         """All buffers are device pointers (ints); enqueues on `stream` and returns."""
         check(lib().mvdb_index_search_device(self._h, ctypes.c_void_p(q_ptr), int(nq), int(k),
@@ -250,6 +301,34 @@ class FlatIndex:
             self._h, ctypes.c_void_p(q_ptr), int(nq), int(k), int(bool(normalize_q)), ctypes.c_void_p(rows_ptr), int(m),
             int(bool(map_labels)), int(label_offset), ctypes.c_void_p(D_ptr), ctypes.c_void_p(I_ptr),
             ctypes.c_void_p(stream)))
+
+
+class RowSet:
+    """mvdb_rowset*: a filter's rows resident on the device (a bitmap for dense / excluded sets, a row list otherwise).
+    Valid until the index it was built on gains or loses a row."""
+
+    def __init__(self, index, rows, excluded=False):
+        rows = np.ascontiguousarray(rows, dtype=np.int64)
+        self._h = ctypes.c_void_p()
+        check(lib().mvdb_rowset_create(index._h, _ptr(rows), rows.shape[0], int(bool(excluded)), ctypes.byref(self._h)))
+
+    def __len__(self):
+        return int(lib().mvdb_rowset_size(self._h))
+
+    @property
+    def is_bitmap(self):
+        return bool(lib().mvdb_rowset_is_bitmap(self._h))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            lib().mvdb_rowset_free(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class Comm:
@@ -294,6 +373,19 @@ def normalize_l2(x, device=0):
 
 def prof_enable(on=True):
     check(lib().mvdb_prof_enable(int(bool(on))))
+
+
+def pack_row_mask(n, rows=None, excluded=None):
+    """uint64 words of the row bitmap search_masked takes: the listed `rows` set, or every row but `excluded`."""
+    bits = np.zeros((n + 63) // 64 * 64, dtype=np.uint8)
+    if rows is not None:
+        bits[np.fromiter(rows, dtype=np.int64, count=len(rows)) if not isinstance(rows, np.ndarray) else rows] = 1
+    else:
+        bits[:n] = 1
+        if excluded:
+            bits[np.fromiter(excluded, dtype=np.int64, count=len(excluded)) if not isinstance(excluded, np.ndarray)
+                 else excluded] = 0
+    return np.packbits(bits, bitorder="little").view(np.uint64)
 
 
 def split_rerun_count():

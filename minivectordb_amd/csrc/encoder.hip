@@ -19,7 +19,7 @@
 //     register-staged global->LDS double buffering (T14 split).  Results are bit-for-bit an fp32
 //     fmaf chain in k order (parity with the reference's fp32).
 //   * attention on the same MFMA ("swapped" K·Q^T, softmax in registers, P^T taken from the
-//     accumulator as the next product's operand); an opt-in bf16-operand GEMM mode (compute = 1).
+//     accumulator as the next product's operand); default arithmetic: split-precision fp16 x 3 (compute = 2, below).
 //   * the whole forward is captured once per shape and replayed as one hipGraph.
 //   * Q/K/V projections fused into one [3H,H] GEMM (weights concatenated once at create time).
 //   * bias / erf-GELU / residual fused into the GEMM epilogue; LayerNorm and pooling are
@@ -289,7 +289,7 @@ __global__ __launch_bounds__(256) void unpack_hidden_kernel(const float* __restr
 // (log2(e) / sqrt(head_dim): the attention kernel's score scale), output written as (hi | lo) fp16 lines
 enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_RESIDUAL = 2, EPI_BIAS_QKV = 3 };
 
-constexpr int GBM = 128, GBN = 128, GBK = 16;  // GBM/GBN: the bf16 kernel's tile; fp32 tiles are 64*TI
+constexpr int GBK = 16;  // k granularity of the exact fp32 GEMM tiles (hidden / intermediate must be multiples)
 
 // TI = 32x32 MFMA tiles per wave and dimension: TI = 2 -> 128x128 block tile (best reuse), TI = 1 ->
 // 64x64 (4x the blocks: used when the 128x128 grid would leave CUs idle, e.g. N = 384 at T = 8192).
@@ -620,259 +620,11 @@ __global__ __launch_bounds__(256) void gemm_f32_dma_kernel(const float* __restri
         }
 }
 
-// Persistent form of the kernel above (64x64 tiles), used when there are at least two tiles per resident workgroup
-// (N = 1152 / 1536 at T = 8192): gridDim.x = 3 per CU workgroups, each walking a strided share of its XCD's contiguous
-// band of the ACTIVE tiles (XCD k serves the k-th eighth of the tile list: its L2 holds 1/8 of A's rows plus W) with
-// ONE DMA ring that runs across tile boundaries — the first two K-steps of the next tile are in flight while the
-// current tile finishes and writes its epilogue, so the pipeline fill (2 us of a 25 us tile at K = 384) is paid once
-// per workgroup instead of once per tile.  The split is static.  (Tried: tiles drawn from per-XCD ticket counters —
-// 288 returning atomics on one address per XCD and launch cost more than they balance: 5.1 vs 3.9 ms per forward.
-// Not used where tiles < 2 x workgroups: a ragged batch then leaves workgroups without a tile and the busy ones
-// end up unevenly spread over the CUs, 76 vs 43 us per N = 384 GEMM.)
-template <int EPI>
-__global__ __launch_bounds__(256) void gemm_f32_dma_persistent_kernel(const float* __restrict__ A, const float* __restrict__ W,
-                                                                      const float* __restrict__ bias,
-                                                                      const float* __restrict__ R, float* __restrict__ C,
-                                                                      const int* __restrict__ Tptr, int N, int K) {
-    constexpr int BM = 64, BN = 64, NST = 3, kStage = (BM + BN) * 128, NI = 4;
-    extern __shared__ __attribute__((aligned(16))) unsigned char gsm[];
-    const int T = *Tptr;
-    const unsigned gx = (unsigned)((N + BN - 1) / BN);
-    const unsigned active = gx * (unsigned)((T + BM - 1) / BM);
-    const unsigned G = gridDim.x, b = blockIdx.x;  // G is a multiple of 8
-    const unsigned xcd = b & 7u, chunk = active >> 3, nb = G >> 3;
-    const unsigned first = xcd * chunk + (b >> 3), band_end = (xcd + 1u) * chunk;
-    const unsigned my_tiles = first < band_end ? (band_end - first + nb - 1) / nb : 0;
-    const unsigned tail0 = chunk << 3;
-    const bool tail_tile = tail0 + b < active;  // the < 8 leftover tiles go to the first workgroups
-    const unsigned ntl = my_tiles + (tail_tile ? 1u : 0u);
-    if (ntl == 0) return;
-    auto tile_lin = [&](unsigned u) { return u < my_tiles ? first + u * nb : tail0 + b; };
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    const int fr = lane & 31, fk = lane >> 5;
-    const int nk = K / 32;
-
-    // DMA roles as above; offsets are recomputed when the issue cursor enters a new tile
-    const bool isA = wave < 2;  // waves 0, 1 move the 64 A rows, waves 2, 3 the 64 W rows
-    const float* sbase = isA ? A : W;
-    const int lim = isA ? T : N;
-    int64_t voff[NI];  // T K 4 bytes can pass 4 GiB
-    auto set_tile = [&](unsigned lin) {
-        const int m0 = (int)(lin / gx) * BM, n0 = (int)(lin % gx) * BN;
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const int row = 8 * (wave * NI + i) + (lane >> 3);
-            const int slot = (lane & 7) ^ (row & 7);
-            int g = isA ? m0 + row : n0 + (row - BM);
-            g = g < lim ? g : lim - 1;
-            voff[i] = ((int64_t)g * K + 4 * slot) * 4;
-        }
-    };
-    unsigned iu = 0;  // issue cursor: tile ordinal, K-step, ring stage
-    int ikt = 0, ist = 0;
-    auto issue_next = [&]() {
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const char* src = reinterpret_cast<const char*>(sbase) + (int64_t)ikt * 128;
-            __builtin_amdgcn_global_load_lds((enc_gbl_ptr)(src + voff[i]),
-                                             (enc_lds_ptr)(gsm + ist * kStage + (wave * NI + i) * 1024), 16, 0, 0);
-        }
-        ist = ist == NST - 1 ? 0 : ist + 1;
-        if (++ikt == nk) {
-            ikt = 0;
-            ++iu;
-            if (iu < ntl) set_tile(tile_lin(iu));
-        }
-    };
-    const int a_off = (wm * 32 + fr) * 128, b_off = (BM + wn * 32 + fr) * 128;
-    const int sw = fr & 7;
-
-    set_tile(tile_lin(0));
-    issue_next();
-    if (iu < ntl) issue_next();
-    int st = 0;
-    for (unsigned u = 0; u < ntl; ++u) {
-        const unsigned lin = tile_lin(u);
-        const int m0 = (int)(lin / gx) * BM, n0 = (int)(lin % gx) * BN;
-        f32x16 acc, acc2;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = acc2[r] = 0.f;
-        for (int kt = 0; kt < nk; ++kt) {
-            const bool last_step = u + 1 == ntl && kt + 1 == nk;
-            __builtin_amdgcn_sched_barrier(0);
-            if (!last_step)
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI) : "memory");  // this wave's part of the current stage landed
-            else
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();  // every wave's part has; every wave is done with the stage before it
-            __builtin_amdgcn_sched_barrier(0);
-            if (iu < ntl) issue_next();    // two stages ahead, into the buffer just released
-            __builtin_amdgcn_sched_barrier(0);
-            const unsigned char* sb = gsm + st * kStage;
-            f32x4 av[2], bv[2];
-            av[0] = *reinterpret_cast<const f32x4*>(sb + a_off + ((fk ^ sw) << 4));
-            bv[0] = *reinterpret_cast<const f32x4*>(sb + b_off + ((fk ^ sw) << 4));
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                if (c + 1 < 4) {  // fragments of chunk c + 1 are read under the MFMAs of chunk c
-                    const int so = ((2 * (c + 1) + fk) ^ sw) << 4;
-                    av[(c + 1) & 1] = *reinterpret_cast<const f32x4*>(sb + a_off + so);
-                    bv[(c + 1) & 1] = *reinterpret_cast<const f32x4*>(sb + b_off + so);
-                }
-#pragma unroll
-                for (int j4 = 0; j4 < 4; ++j4) {  // two accumulation chains, summed in the epilogue
-                    if (j4 & 1)
-                        acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c & 1][j4], bv[c & 1][j4], acc2, 0, 0, 0);
-                    else
-                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c & 1][j4], bv[c & 1][j4], acc, 0, 0, 0);
-                }
-            }
-            st = st == NST - 1 ? 0 : st + 1;
-        }
-        // epilogue of this tile; the next tile's first stages are already in flight
-        const int col = n0 + wn * 32 + fr;
-        if (col < N) {
-            const float bvv = bias[col];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
-                if (row < T) {
-                    float v = (acc[r] + acc2[r]) + bvv;
-                    if (EPI == EPI_BIAS_GELU) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
-                    if (EPI == EPI_BIAS_RESIDUAL) v += R[(int64_t)row * N + col];
-                    C[(int64_t)row * N + col] = v;
-                }
-            }
-        }
-        // The epilogue's loads and stores went through the vector-memory counter the ring is paced by: drain them, so
-        // that the counted wait of the next K-step sees ring traffic only.
-        __builtin_amdgcn_sched_barrier(0);
-        if (u + 1 < ntl) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
-
-// =================================================================================================
-// opt-in bf16 GEMM (compute = 1): operands rounded to bf16 (RNE), fp32 accumulate on
-// v_mfma_f32_32x32x16_bf16 (16x the fp32 MFMA rate).  NOT parity-exact: the reference computes in
-// fp32; embeddings move by ~1e-3.  Activations stay fp32 in memory (converted while staging into
-// LDS); weights are converted once (library-owned bf16 copies).
-// =================================================================================================
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-
-constexpr int HBK = 32;       // k per LDS tile
-constexpr int HROW = 80;      // LDS row stride in bytes: 64 B of bf16 + 16 B pad => conflict-free b128 reads
-
-__global__ void f32_to_bf16_kernel(const float* __restrict__ in, __bf16* __restrict__ out, int64_t n) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = (__bf16)in[i];
-}
-
-template <int EPI>
-__global__ __launch_bounds__(256) void gemm_bf16_mfma_kernel(const float* __restrict__ A,
-                                                             const __bf16* __restrict__ W,
-                                                             const float* __restrict__ bias,
-                                                             const float* __restrict__ R,
-                                                             float* __restrict__ C,
-                                                             const int* __restrict__ Tptr, int N, int K) {
-    const int T = *Tptr;
-    const int m0 = blockIdx.y * GBM;
-    if (m0 >= T) return;
-    const int n0 = blockIdx.x * GBN;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 2 * GBM * HROW];  // [buf][A|B][row][80 B]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-
-    // staging roles: thread -> (row = tid/2, half = tid%2): 16 consecutive k of that row
-    const int lr = tid >> 1, lh = tid & 1;
-    const bool a_ok = m0 + lr < T, w_ok = n0 + lr < N;
-    const float* a_ptr = A + (int64_t)(a_ok ? m0 + lr : 0) * K + lh * 16;
-    const __bf16* w_ptr = W + (int64_t)(w_ok ? n0 + lr : 0) * K + lh * 16;
-    f32x4 ra[4];
-    uint4 rw[2];
-    auto stage_load = [&](int k0) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            ra[i] = a_ok ? *reinterpret_cast<const f32x4*>(a_ptr + k0 + 4 * i) : f32x4{0, 0, 0, 0};
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-            rw[i] = w_ok ? *reinterpret_cast<const uint4*>(w_ptr + k0 + 8 * i) : uint4{0, 0, 0, 0};
-    };
-    auto stage_write = [&](int buf) {
-        unsigned char* As = lds + buf * (2 * GBM * HROW);
-        unsigned char* Bs = As + GBM * HROW;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            bf16x8 v;
-            v[0] = (__bf16)ra[2 * i][0]; v[1] = (__bf16)ra[2 * i][1];
-            v[2] = (__bf16)ra[2 * i][2]; v[3] = (__bf16)ra[2 * i][3];
-            v[4] = (__bf16)ra[2 * i + 1][0]; v[5] = (__bf16)ra[2 * i + 1][1];
-            v[6] = (__bf16)ra[2 * i + 1][2]; v[7] = (__bf16)ra[2 * i + 1][3];
-            *reinterpret_cast<bf16x8*>(As + lr * HROW + lh * 32 + i * 16) = v;
-            *reinterpret_cast<uint4*>(Bs + lr * HROW + lh * 32 + i * 16) = rw[i];
-        }
-    };
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    const int nk = K / HBK;
-    stage_load(0);
-    stage_write(0);
-    __syncthreads();
-    const int fr = lane & 31, fh = lane >> 5;
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) stage_load((kt + 1) * HBK);
-        const unsigned char* As = lds + buf * (2 * GBM * HROW);
-        const unsigned char* Bs = As + GBM * HROW;
-#pragma unroll
-        for (int ks = 0; ks < HBK / 16; ++ks) {
-            // lane l: A[row = l&31][k = 8*(l>>5) .. +7] of this 16-deep step
-            const int off = ks * 32 + fh * 16;
-            const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(As + (wm * 64 + fr) * HROW + off);
-            const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(As + (wm * 64 + 32 + fr) * HROW + off);
-            const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(Bs + (wn * 64 + fr) * HROW + off);
-            const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(Bs + (wn * 64 + 32 + fr) * HROW + off);
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
-        }
-        if (kt + 1 < nk) {
-            stage_write(buf ^ 1);
-            __syncthreads();
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = n0 + wn * 64 + j * 32 + fr;
-            if (col >= N) continue;
-            const float bv = bias[col];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-                if (row < T) {
-                    float v = acc[i][j][r] + bv;
-                    if (EPI == EPI_BIAS_GELU) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
-                    if (EPI == EPI_BIAS_RESIDUAL) v += R[(int64_t)row * N + col];
-                    C[(int64_t)row * N + col] = v;
-                }
-            }
-        }
-}
-
+// (A persistent form of this kernel — one DMA ring running across tile boundaries, static tile split per XCD — was built in
+// round 2 and removed in round 3: +4 % on a full B = 256, S = 32 batch, -30 % on a ragged one; ticket counters -25 %.)
+// (compute = 1 — GEMM operands rounded to ONE bf16 product, ~1e-3 on the embeddings — was removed in round 3: the
+// split-precision mode below is both faster (2.0 vs 2.7 ms at B = 256, S = 32) and fp32-equivalent.)
+constexpr int HBK = 32;       // k granularity of the split-precision images
 // =================================================================================================
 // compute = 2: split-precision GEMM on the fp16 matrix cores, fp32-equivalent to ~2^-21
 //   a = ah + al + ra,  w = wh + wl + rw   (fp16 by RNE: |r| <= 2^-22 |.|, or 2^-25 absolute once the low part is a
@@ -1876,7 +1628,6 @@ __global__ __launch_bounds__(WV * 64) void attention_x3i_kernel(const float* __r
     constexpr int NQ = 2 * KT * LPK / 8;                      // DMA instructions per tile (8 lines each): K then V
     constexpr int NI = NQ / WV;
     static_assert(NQ % WV == 0, "whole DMA instructions per wave");
-    constexpr int SLOTS = 8 * LPK;                            // 16-byte slots per key
     const int b = blockIdx.z, h = blockIdx.y;
     const int s0 = seq_start[b], len = seq_start[b + 1] - s0;
     const int q0 = blockIdx.x * (32 * WV);
@@ -2099,7 +1850,6 @@ __global__ void concat3_kernel(const float* a, const float* b, const float* c, i
 struct LayerW {
     const float *wqkv, *bqkv;  // fused (library owned)
     const float *wo, *bo, *ln1g, *ln1b, *w1, *b1, *w2, *b2, *ln2g, *ln2b;
-    __bf16 *wqkv_h = nullptr, *wo_h = nullptr, *w1_h = nullptr, *w2_h = nullptr;  // lazily made bf16 copies
     // compute = 2: (hi | lo) fp16 pieces of scale * w, interleaved per 32-k block, and 1 / scale
     _Float16 *wqkv_p = nullptr, *wo_p = nullptr, *w1_p = nullptr, *w2_p = nullptr;
     float wqkv_is = 1.f, wo_is = 1.f, w1_is = 1.f, w2_is = 1.f;
@@ -2130,8 +1880,8 @@ struct mvdb_encoder {
     const float *word = nullptr, *pos = nullptr, *type = nullptr, *embg = nullptr, *embb = nullptr;
     std::vector<LayerW> layers;
     std::vector<float*> owned;  // fused qkv weights / biases
-    std::vector<void*> owned_h; // bf16 weight copies (compute = 1)
-    bool have_bf16 = false, have_x3 = false;
+    std::vector<void*> owned_h; // (hi | lo) fp16 weight images (compute = 2)
+    bool have_x3 = false;
     // workspace (grown on demand), guarded by mu: one forward at a time per encoder
     std::mutex mu;
     uint64_t ws_gen = 0;                  // bumped whenever the workspace is reallocated
@@ -2266,18 +2016,6 @@ void launch_gemm(const float* A, const float* W, const float* bias, const float*
         // at N = 1152).  Measured 4.12 vs 4.26 ms per forward at B = 256, S = 32.  With 128x128 tiles (96 KiB of LDS,
         // one block per CU) it loses to the register-staged kernel (81 vs 67 ms at S = 512): not used there.
         constexpr int lds = 3 * 128 * 128;
-        // opt-in (MVDB_GEMM_PERSISTENT = 1: every small-tile GEMM, 2: only those with >= 2 tiles per workgroup): the
-        // persistent form gains 4 % on a FULL batch (3.90 vs 4.05 ms at B = 256, S = 32) and loses 30 % on a ragged one
-        // (3.78 vs 2.91 ms) when applied to the N = 384 GEMMs; restricted to the wide GEMMs it is within 1-3 % either way
-        static const int persistent = []() { const char* v = getenv("MVDB_GEMM_PERSISTENT"); return v ? atoi(v) : 0; }();
-        if (persistent) {
-            const int64_t tiles = (int64_t)((N + 63) / 64) * ((Tmax + 63) / 64);
-            const unsigned g = (unsigned)std::min<int64_t>(tiles, (int64_t)3 * cus) & ~7u;
-            if (g >= 8 && (persistent == 1 || tiles >= 2 * (int64_t)g)) {
-                hipLaunchKernelGGL((gemm_f32_dma_persistent_kernel<EPI>), dim3(g), dim3(256), lds, s, A, W, bias, R, C, Tptr, N, K);
-                return;
-            }
-        }
         dim3 grid((N + 63) / 64, (unsigned)((Tmax + 63) / 64));
         hipLaunchKernelGGL((gemm_f32_dma_kernel<EPI, 1>), grid, dim3(256), lds, s, A, W, bias, R, C, Tptr, N, K);
         return;
@@ -2296,36 +2034,6 @@ void launch_gemm(const float* A, const float* W, const float* bias, const float*
         else
             hipLaunchKernelGGL((gemm_f32_mfma_kernel<EPI, 1, 16>), grid, dim3(256), 0, s, A, W, bias, R, C, Tptr, N, K);
     }
-}
-
-template <int EPI>
-void launch_gemm_h(const float* A, const __bf16* W, const float* bias, const float* R, float* C,
-                   const int* Tptr, int64_t Tmax, int N, int K, hipStream_t s) {
-    dim3 grid((N + GBN - 1) / GBN, (unsigned)((Tmax + GBM - 1) / GBM));
-    hipLaunchKernelGGL(gemm_bf16_mfma_kernel<EPI>, grid, dim3(256), 0, s, A, W, bias, R, C, Tptr, N, K);
-}
-
-int make_bf16(mvdb_encoder* e, const float* src, int64_t n, __bf16** out, hipStream_t s) {
-    __bf16* p = nullptr;
-    MVDB_HIP(hipMalloc((void**)&p, (size_t)n * sizeof(__bf16)));
-    e->owned_h.push_back(p);
-    hipLaunchKernelGGL(f32_to_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, p, n);
-    *out = p;
-    return 0;
-}
-
-int ensure_bf16_weights(mvdb_encoder* e, hipStream_t s) {
-    if (e->have_bf16) return 0;
-    const int64_t H = e->cfg.hidden, F = e->cfg.intermediate;
-    for (LayerW& L : e->layers) {
-        MVDB_TRY(make_bf16(e, L.wqkv, 3 * H * H, &L.wqkv_h, s));
-        MVDB_TRY(make_bf16(e, L.wo, H * H, &L.wo_h, s));
-        MVDB_TRY(make_bf16(e, L.w1, F * H, &L.w1_h, s));
-        MVDB_TRY(make_bf16(e, L.w2, H * F, &L.w2_h, s));
-    }
-    MVDB_HIP(hipGetLastError());
-    e->have_bf16 = true;
-    return 0;
 }
 
 // compute = 2: LDS-DMA kernel, 64 x 128 tiles, three stages, two workgroups per CU — measured best at every shape
@@ -2617,8 +2325,6 @@ int enqueue_lane(mvdb_encoder* e, mvdb_encoder::Lane& w, const int32_t* ids, con
                                                   H, scale * kLog2e));
         else if (compute == 2)
             MVDB_TRY(launch_gemm_x3<EPI_BIAS>(xp, L.wqkv_p, L.wqkv_is, L.bqkv, nullptr, w.qkv, Tptr, Tmax, 3 * H, H, e->device, s));
-        else if (compute == 1)
-            launch_gemm_h<EPI_BIAS>(w.x, L.wqkv_h, L.bqkv, nullptr, w.qkv, Tptr, Tmax, 3 * H, H, s);
         else
             launch_gemm<EPI_BIAS>(w.x, L.wqkv, L.bqkv, nullptr, w.qkv, Tptr, Tmax, 3 * H, H, cus, s);
         if (attn_valu) {  // MVDB_ENCODER_ATTENTION=valu: the thread-per-query VALU kernel (A/B reference)
@@ -2682,8 +2388,6 @@ int enqueue_lane(mvdb_encoder* e, mvdb_encoder::Lane& w, const int32_t* ids, con
             else
                 MVDB_TRY(launch_gemm_x3<EPI_BIAS_RESIDUAL>(ctx_img, L.wo_p, L.wo_is, L.bo, w.x, w.y, Tptr, Tmax, H, H, e->device, s));
         }
-        else if (compute == 1)
-            launch_gemm_h<EPI_BIAS_RESIDUAL>(w.ctx, L.wo_h, L.bo, w.x, w.y, Tptr, Tmax, H, H, s);
         else
             launch_gemm<EPI_BIAS_RESIDUAL>(w.ctx, L.wo, L.bo, w.x, w.y, Tptr, Tmax, H, H, cus, s);
 #define LN1_CALL(V) launch_ln<V>(w.y, w.seq_start, B, L.ln1g, L.ln1b, c.ln_eps, H, w.x, xp, Tmax, s)
@@ -2695,9 +2399,6 @@ int enqueue_lane(mvdb_encoder* e, mvdb_encoder::Lane& w, const int32_t* ids, con
                 MVDB_TRY(launch_gemm_x3_ln(w.ffn, L.w2_p, L.w2_is, L.b2, L.ln2g, L.ln2b, c.ln_eps, w.x, xp, Tptr, Tmax, H, F, e->device, s));
             else
                 MVDB_TRY(launch_gemm_x3<EPI_BIAS_RESIDUAL>(w.ffn, L.w2_p, L.w2_is, L.b2, w.x, w.y, Tptr, Tmax, H, F, e->device, s));
-        } else if (compute == 1) {
-            launch_gemm_h<EPI_BIAS_GELU>(w.x, L.w1_h, L.b1, nullptr, w.ffn, Tptr, Tmax, F, H, s);
-            launch_gemm_h<EPI_BIAS_RESIDUAL>(w.ffn, L.w2_h, L.b2, w.x, w.y, Tptr, Tmax, H, F, s);
         } else {
             launch_gemm<EPI_BIAS_GELU>(w.x, L.w1, L.b1, nullptr, w.ffn, Tptr, Tmax, F, H, cus, s);
             launch_gemm<EPI_BIAS_RESIDUAL>(w.ffn, L.w2, L.b2, w.x, w.y, Tptr, Tmax, H, F, cus, s);
@@ -2741,19 +2442,17 @@ int enqueue_forward(mvdb_encoder* e, const int32_t* ids, const int32_t* mask, in
 
 int forward_core(mvdb_encoder* e, const int32_t* ids, const int32_t* mask, int B, int S, int compute,
                  float* out, float* hidden, hipStream_t s) {
-    if (compute < 0 || compute > 2)
-        return fail(MVDB_ERR_ARG, "unknown compute mode %d (0 = exact-fp32 MFMA, 1 = bf16 MFMA operands, 2 = split-precision fp16 x 3)", compute);
+    if (compute != 0 && compute != 2)
+        return fail(MVDB_ERR_ARG, "unknown compute mode %d (0 = exact-fp32 MFMA, 2 = split-precision fp16 x 3; 1, the single-bf16-product "
+                                  "mode of earlier builds, was removed: slower and less exact than 2)", compute);
     const mvdb_encoder_cfg& c = e->cfg;
     if (B <= 0 || S <= 0) return fail(MVDB_ERR_ARG, "B and S must be positive");
     if (S + (c.position_offset > 0 ? c.position_offset : 0) > c.max_positions)
         return fail(MVDB_ERR_ARG, "sequence length %d exceeds max_positions %d", S, c.max_positions);
-    if (compute != 0) {
+    if (compute == 2) {
         if (c.hidden % HBK || c.intermediate % HBK)
-            return fail(MVDB_ERR_ARG, "bf16 modes need hidden and intermediate to be multiples of %d", HBK);
-        if (compute == 1)
-            MVDB_TRY(ensure_bf16_weights(e, s));
-        else
-            MVDB_TRY(ensure_x3_weights(e, s));
+            return fail(MVDB_ERR_ARG, "the split-precision mode needs hidden and intermediate to be multiples of %d", HBK);
+        MVDB_TRY(ensure_x3_weights(e, s));
     }
     const uint64_t gen_before = e->ws_gen;
     MVDB_TRY(ensure_ws(e, B, S));

@@ -17,7 +17,6 @@
 #include "scan_mfma_kernels.hpp"
 #include "scan_split_kernels.hpp"
 #include "select_kernels.hpp"
-#include "split128.hpp"
 #include "half_scan.hpp"
 #include "util_kernels.hpp"
 
@@ -181,6 +180,8 @@ struct mvdb_index {
     float* X = nullptr;
     int64_t n = 0, cap = 0;
     float row_norm_bound = 0.f;  // upper bound of |row| over the stored rows (INFINITY: unknown, raw adds)
+    uint64_t renumbered = 0;     // bumped whenever stored rows change their numbers (remove_rows, reset): resident row sets
+                                 // built before are stale
     mutable std::shared_mutex mu;  // search: shared; add/reset/remove/free: exclusive
     mutable std::mutex ws_mu;
     mutable std::vector<Workspace*> free_ws;           // synchronous searches
@@ -261,9 +262,9 @@ int env_int(const char* name, int dflt) {
     return v && *v ? atoi(v) : dflt;
 }
 
-template <int G, int C, int U, int METRIC, int MODE, bool NT, bool SUBSET, bool MASKED>
+template <int G, int C, int U, int METRIC, int MODE, bool NT, int SEL, bool MASKED>
 int launch_scan_kern(const ScanArgs& a, int nq, int device, hipStream_t stream, int* nblocks_out) {
-    auto kern = flat_scan_kernel<G, C, U, METRIC, MODE, NT, SUBSET, MASKED>;
+    auto kern = flat_scan_kernel<G, C, U, METRIC, MODE, NT, SEL, MASKED>;
     static int occ = 0;  // blocks per CU this instantiation sustains
     static int occ_hw = 0;
     if (occ == 0) {
@@ -299,12 +300,16 @@ int launch_scan_kern(const ScanArgs& a, int nq, int device, hipStream_t stream, 
 template <int G, int C, int U, int METRIC, int MODE, bool NT = true>
 int launch_scan_inst(const ScanArgs& a, int nq, int device, hipStream_t s, int* nb) {
     const bool masked = a.d4 != G * C;
-    if (a.rows) {
-        if (masked) return launch_scan_kern<G, C, U, METRIC, MODE, NT, true, true>(a, nq, device, s, nb);
-        return launch_scan_kern<G, C, U, METRIC, MODE, NT, true, false>(a, nq, device, s, nb);
+    if (a.mask) {  // bitmap-selected rows (mvdb_index_search_masked)
+        if (masked) return launch_scan_kern<G, C, U, METRIC, MODE, NT, 2, true>(a, nq, device, s, nb);
+        return launch_scan_kern<G, C, U, METRIC, MODE, NT, 2, false>(a, nq, device, s, nb);
     }
-    if (masked) return launch_scan_kern<G, C, U, METRIC, MODE, NT, false, true>(a, nq, device, s, nb);
-    return launch_scan_kern<G, C, U, METRIC, MODE, NT, false, false>(a, nq, device, s, nb);
+    if (a.rows) {
+        if (masked) return launch_scan_kern<G, C, U, METRIC, MODE, NT, 1, true>(a, nq, device, s, nb);
+        return launch_scan_kern<G, C, U, METRIC, MODE, NT, 1, false>(a, nq, device, s, nb);
+    }
+    if (masked) return launch_scan_kern<G, C, U, METRIC, MODE, NT, 0, true>(a, nq, device, s, nb);
+    return launch_scan_kern<G, C, U, METRIC, MODE, NT, 0, false>(a, nq, device, s, nb);
 }
 
 template <int G, int C, int U>
@@ -364,6 +369,11 @@ int launch_scan(int metric, int mode, const ScanArgs& a, int nq, int device, hip
         MVDB_SCAN_U_CASE(16, 1)
 #undef MVDB_SCAN_U_CASE
     }
+    // Row-list (gather) scans of two- and three-chunk rows keep FOUR rows in flight per wave (the streaming scan: two): a
+    // gathered row is a fresh DRAM page, so more rows must be outstanding to cover its latency — 10M x 512 rows resident,
+    // ids on the device: 10 % of the rows 5.74 -> 6.23 TB/s of rows touched, 50 % 6.37 -> 6.78, 99 % 6.54 -> 6.95.
+    if (a.rows && sh.G == 64 && sh.C == 2) return launch_scan_gcu<64, 2, 4>(metric, mode, a, nq, device, s, nblocks);
+    if (a.rows && sh.G == 64 && sh.C == 3) return launch_scan_gcu<64, 3, 4>(metric, mode, a, nq, device, s, nblocks);
 #define MVDB_SCAN_CASE(G_, C_, U_) \
     if (sh.G == G_ && sh.C == C_) return launch_scan_gcu<G_, C_, U_>(metric, mode, a, nq, device, s, nblocks);
     MVDB_SCAN_CASE(1, 1, 4)
@@ -616,9 +626,20 @@ double split_eps(int d) {
     return (e_op + e_acc + e_re) * (1.0 + 4e-6) + 4.0 * u24;
 }
 
+// k the certified passes serve: 12 with the 16-nominee bf16 passes; 32 where the fp16 pass exists — it re-scores 64 nominees,
+// so its certificate compares the k-th exact score with the ~64th approximate one: at k = 32 the gap is still ~6 eps on
+// exchangeable data (10M x 512 random rows: 32nd to 64th score 6.1e-3, eps 1.04e-3; 1.6e-2 at k = 10)
+constexpr int kHalfMaxK = 32;
+bool half_path_ok(const mvdb_index* idx);
+int mfma_gated_queries(const mvdb_index* idx);
+
 bool split_path_ok(const mvdb_index* idx, int nq, int k, const int64_t* rows_dev) {
     if (env_int("MVDB_DISABLE_SPLIT_SCAN", 0)) return false;
-    if (nq < 2 || k > kSplitMaxK || rows_dev || idx->metric != MVDB_METRIC_IP) return false;
+    if (nq < 2 || rows_dev || idx->metric != MVDB_METRIC_IP) return false;
+    // (k > 16 also needs the gated fp32-MFMA pass for the exact re-runs: the GEMM-tiled scan keeps 16 results per query)
+    if (k > kSplitMaxK && !(k <= kHalfMaxK && nq >= env_int("MVDB_SPLIT_SCAN_MIN_NQ", 33) && half_path_ok(idx) &&
+                            (k <= kGemmScanMaxK || mfma_gated_queries(idx) > 0)))
+        return false;
     // rows of known, sane norm only: the bound scales with max|x|, and bf16 keeps fp32's exponent range only up
     // to 3.39e38 (a split of larger elements would overflow to infinity)
     if (!(idx->row_norm_bound > 0.f) || !(idx->row_norm_bound < 1.0e30f)) return false;
@@ -745,21 +766,6 @@ int launch_split_scan(const mvdb_index* idx, Workspace* ws, const float* q, int 
             b.tile1 = (rows_upto + 31) / 32;
             b.thr0 = a.thr0;
             MVDB_TRY(launch_split32(idx->d / 16, b, idx->device, stream, &gx));
-        } else if (split128_supported(idx->d) && !env_int("MVDB_DISABLE_SPLIT128", 0)) {
-            // 33..128 queries: K split over the four waves of a block, query fragments in registers (split128.hip)
-            Split128Args b;
-            b.X = idx->X;
-            b.n = rows_upto;
-            b.ld = idx->ld;
-            b.qh = qh;
-            b.ql = ql;
-            b.nq = nq;
-            b.cand = cand;
-            b.tile0 = a.tile0 * 4;
-            b.tile1 = (rows_upto + 31) / 32;
-            b.thr0 = a.thr0;
-            b.stats = a.stats;
-            MVDB_TRY(launch_split128(idx->d, b, idx->device, stream, &gx));
         } else {
             SplitScanArgs c = a;
             c.n = rows_upto;
@@ -801,11 +807,6 @@ int launch_split_scan(const mvdb_index* idx, Workspace* ws, const float* q, int 
         MVDB_HIP(hipMemcpyAsync(st, a.stats, sizeof(st), hipMemcpyDeviceToHost, stream));
         MVDB_HIP(hipStreamSynchronize(stream));
         fprintf(stderr, "[mvdb split] list inserts %u, slow-path wave-tiles %u (seed + main launch)\n", st[0], st[1]);
-        const unsigned long long* t = reinterpret_cast<const unsigned long long*>(st + 2);
-        if (t[2])  // MVDB_SPLIT128_DBG=2048: s_memtime sums of block 7, per wave
-            for (int w = 0; w < 4; ++w)
-                fprintf(stderr, "[mvdb split128 timers] wave %d: vmcnt wait %llu, DMA issue %llu, stages %llu cycles\n", w,
-                        t[3 * w], t[3 * w + 1], t[3 * w + 2]);
     }
     return 0;
 }
@@ -938,11 +939,37 @@ bool dense_subset_ok(const mvdb_index* idx, int nq, const int64_t* rows_dev, int
     return m * 100 >= idx->n * (int64_t)pct;
 }
 
+// label of result = position p with rows = the ascending list of the mask's set bits: p = number of set bits below the row
+__global__ __launch_bounds__(256) void mask_rank_kernel(int64_t* __restrict__ I, const uint64_t* __restrict__ mask) {
+    __shared__ int part[256];
+    const int64_t row = I[blockIdx.x];
+    if (row < 0) return;  // block-uniform
+    const int64_t words = row >> 6;
+    int c = 0;
+    for (int64_t w = threadIdx.x; w < words; w += 256) c += __popcll(mask[w]);
+    if (threadIdx.x == 0 && (row & 63)) c += __popcll(mask[words] & ((1ull << (row & 63)) - 1ull));
+    part[threadIdx.x] = c;
+    __syncthreads();
+    for (int m = 128; m >= 1; m >>= 1) {
+        if ((int)threadIdx.x < m) part[threadIdx.x] += part[threadIdx.x + m];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) I[blockIdx.x] = part[0];
+}
+
 int search_core(const mvdb_index* idx, Workspace* ws, const float* q_dev, int nq, int k,
                 int normalize_q, const int64_t* rows_dev, int64_t m, int64_t label_offset,
-                float* D_dev, int64_t* I_dev, bool allow_split = true) {
+                float* D_dev, int64_t* I_dev, bool allow_split = true, const uint64_t* mask_dev = nullptr) {
     hipStream_t s = ws->stream;
-    const int64_t n = rows_dev ? m : idx->n;
+    // row list: its m entries; bitmap: the first m rows when the caller says how many rows the bitmap covers (a resident
+    // row set built before later appends), else every row
+    const int64_t n = rows_dev ? m : (mask_dev && m > 0 ? std::min<int64_t>(m, idx->n) : idx->n);
+    if (mask_dev) {  // bitmap-selected rows: the exact single-pass kernels only (as row lists)
+        allow_split = false;
+        rows_dev = nullptr;
+    }
+    // the multi-query passes take neither a row list nor a bitmap
+    const int64_t* restricted = mask_dev ? reinterpret_cast<const int64_t*>(mask_dev) : rows_dev;
     if (n == 0) {
         const int64_t total = (int64_t)nq * k;
         hipLaunchKernelGGL(fill_missing_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
@@ -959,6 +986,7 @@ int search_core(const mvdb_index* idx, Workspace* ws, const float* q_dev, int nq
     a.normalize_q = normalize_q;
     a.k = k;
     a.rows = rows_dev;
+    a.mask = mask_dev;
     a.cand = nullptr;
     a.scores = nullptr;
 
@@ -983,11 +1011,11 @@ int search_core(const mvdb_index* idx, Workspace* ws, const float* q_dev, int nq
         const int chunk = use_half ? half_max_queries(idx->d) : 128;
         std::vector<std::pair<int, int>> plan;  // (first query, count)
         int q0 = 0;
-        while (nq - q0 >= min_nq) {
+        while (nq - q0 >= min_nq && (use_half || k <= kSplitMaxK)) {
             plan.emplace_back(q0, std::min(nq - q0, chunk));
             q0 += plan.back().second;
         }
-        if (nq - q0 >= env_int("MVDB_SPLIT32_MIN_NQ", 14) && nq - q0 <= 32 && split32_ok(idx)) {
+        if (k <= kSplitMaxK && nq - q0 >= env_int("MVDB_SPLIT32_MIN_NQ", 14) && nq - q0 <= 32 && split32_ok(idx)) {
             plan.emplace_back(q0, nq - q0);
             q0 = nq;
         }
@@ -1042,7 +1070,8 @@ int search_core(const mvdb_index* idx, Workspace* ws, const float* q_dev, int nq
             int off = 0;
             if (per_pass > 0 && !env_int("MVDB_DISABLE_MFMA_SCAN", 0)) {
                 MVDB_TRY(ws->cand.reserve((size_t)32 * scan_grid_upper_bound(idx->device) * k));
-                for (int pass = 0; pass < 2 && off < R; ++pass) {
+                const int max_passes = k > kGemmScanMaxK ? (R + per_pass - 1) / per_pass : 2;  // the GEMM scan keeps k <= 16
+                for (int pass = 0; pass < max_passes && off < R; ++pass) {
                     const int take = std::min(per_pass, R - off);
                     MfmaScanArgs ma;
                     ma.X = idx->X;
@@ -1099,7 +1128,7 @@ int search_core(const mvdb_index* idx, Workspace* ws, const float* q_dev, int nq
 
     // Large batches are cut into chunks: >= 104 queries left -> one 128-query GEMM-tiled launch (compute-
     // bound, 13.7 ms at 10M x 512), fewer -> 32-query MFMA passes (4.0 ms each); measured crossover ~100.
-    if (gemm_path_ok(idx, nq, k, rows_dev)) {
+    if (gemm_path_ok(idx, nq, k, restricted)) {
         const float* qsrc = q_dev;
         if (normalize_q) {
             MVDB_TRY(ws->qn.reserve((size_t)nq * idx->ld));
@@ -1133,7 +1162,7 @@ int search_core(const mvdb_index* idx, Workspace* ws, const float* q_dev, int nq
                            D_dev + (int64_t)q0 * k, I_dev + (int64_t)q0 * k, allow_split);
     }
 
-    if (mfma_path_ok(idx, nq, k, rows_dev)) {
+    if (mfma_path_ok(idx, nq, k, restricted)) {
         // ---- several queries per corpus pass on the fp32 matrix cores ---------------------------
         const float* qsrc = q_dev;
         if (normalize_q) {
@@ -1255,7 +1284,7 @@ int search_core(const mvdb_index* idx, Workspace* ws, const float* q_dev, int nq
         }
         hipLaunchKernelGGL(emit_sorted_kernel, dim3((k + 255) / 256), dim3(256), 0, s,
                            ws->selkeys.p, k, idx->metric, label_offset, D_dev + (int64_t)qi * k,
-                           I_dev + (int64_t)qi * k);
+                           I_dev + (int64_t)qi * k, mask_dev ? 1 : 0);
         MVDB_HIP(hipGetLastError());
     }
     return 0;
@@ -1409,6 +1438,7 @@ int mvdb_index_reset(mvdb_index* idx) {
     MVDB_TRY(quiesce());
     idx->n = 0;
     idx->row_norm_bound = 0.f;
+    ++idx->renumbered;
     return 0;
 }
 
@@ -1579,6 +1609,7 @@ int mvdb_index_remove_rows(mvdb_index* idx, const int64_t* rows_host, int64_t m)
     }
     DeviceGuard dg(idx->device);
     MVDB_TRY(quiesce());
+    ++idx->renumbered;
     const int64_t n_new = idx->n - m;
     if (n_new == 0) {
         idx->n = 0;
@@ -1750,6 +1781,204 @@ int mvdb_index_search_subset_device(const mvdb_index* idx, const float* q_dev, i
         MVDB_HIP(hipGetLastError());
     }
     return 0;
+}
+
+static int finish_mask_labels(const mvdb_index* idx, Workspace* ws, int nq, int k, const uint64_t* mask_dev, int labels,
+                              int64_t* I_dev) {
+    if (labels == 0) {  // positions in the ascending list of the set rows (what mvdb_index_search_subset returns for that list)
+        hipLaunchKernelGGL(mask_rank_kernel, dim3((unsigned)((int64_t)nq * k)), dim3(256), 0, ws->stream, I_dev, mask_dev);
+        MVDB_HIP(hipGetLastError());
+    }
+    return 0;
+}
+
+int mvdb_index_search_masked_device(const mvdb_index* idx, const float* q_dev, int nq, int k, int normalize_q,
+                                    const uint64_t* mask_dev, int labels, int64_t label_offset, float* D_dev,
+                                    int64_t* I_dev, void* stream) {
+    MVDB_TRY(check_search_args(idx, q_dev, nq, k, D_dev, I_dev));
+    if (!mask_dev) return fail(MVDB_ERR_ARG, "mask is NULL");
+    if (labels != 0 && labels != 1) return fail(MVDB_ERR_ARG, "labels must be 0 (positions) or 1 (row numbers)");
+    std::shared_lock<std::shared_mutex> lk(idx->mu);
+    DeviceGuard dg(idx->device);
+    Workspace* ws = idx->for_stream((hipStream_t)stream);
+    if (!ws) return fail(MVDB_ERR_HIP, "workspace allocation failed");
+    std::lock_guard<std::mutex> use(ws->use_mu);
+    const float* q = q_dev;
+    if (idx->ld != idx->d) {
+        MVDB_TRY(ws->q.reserve((size_t)nq * idx->ld));
+        hipLaunchKernelGGL(pad_rows_kernel, dim3((unsigned)(((int64_t)nq * idx->ld + 255) / 256)),
+                           dim3(256), 0, ws->stream, ws->q.p, q_dev, (int64_t)nq, idx->d, idx->ld);
+        MVDB_HIP(hipGetLastError());
+        q = ws->q.p;
+    }
+    MVDB_TRY(search_core(idx, ws, q, nq, k, normalize_q, nullptr, 0, labels == 1 ? label_offset : 0, D_dev, I_dev, false, mask_dev));
+    return finish_mask_labels(idx, ws, nq, k, mask_dev, labels, I_dev);
+}
+
+int mvdb_index_search_masked(const mvdb_index* idx, const float* q_host, int nq, int k, int normalize_q,
+                             const uint64_t* mask_host, int labels, float* D_host, int64_t* I_host) {
+    MVDB_TRY(check_search_args(idx, q_host, nq, k, D_host, I_host));
+    if (!mask_host) return fail(MVDB_ERR_ARG, "mask is NULL");
+    if (labels != 0 && labels != 1) return fail(MVDB_ERR_ARG, "labels must be 0 (positions) or 1 (row numbers)");
+    std::shared_lock<std::shared_mutex> lk(idx->mu);
+    DeviceGuard dg(idx->device);
+    Workspace* ws = idx->acquire();
+    if (!ws) return MVDB_ERR_HIP;
+    int rc = 0;
+    do {
+        if ((rc = stage_queries(idx, ws, q_host, nq))) break;
+        const size_t total = (size_t)nq * k;
+        if ((rc = ws->out.reserve(total + (total + 1) / 2))) break;
+        float* D_dev = reinterpret_cast<float*>(ws->out.p + total);
+        const size_t words = (size_t)((idx->n + 63) / 64);
+        if ((rc = ws->rows.reserve(std::max<size_t>(words, 1)))) break;  // 8-byte words: the row-list buffer serves
+        uint64_t* mask_dev = reinterpret_cast<uint64_t*>(ws->rows.p);
+        if (words) {
+            hipError_t e = hipMemcpyAsync(mask_dev, mask_host, words * sizeof(uint64_t), hipMemcpyHostToDevice, ws->stream);
+            if (e != hipSuccess) {
+                rc = fail(MVDB_ERR_HIP, "mask upload failed: %s", hipGetErrorString(e));
+                break;
+            }
+        }
+        if ((rc = search_core(idx, ws, ws->q.p, nq, k, normalize_q, nullptr, 0, 0, D_dev, ws->out.p, false, mask_dev))) break;
+        if ((rc = finish_mask_labels(idx, ws, nq, k, mask_dev, labels, ws->out.p))) break;
+        rc = fetch_results(ws, total, D_host, I_host);
+    } while (0);
+    idx->release(ws);
+    return rc;
+}
+
+// ---- resident row sets: a filter's rows uploaded ONCE, searched many times ---------------------------------------------
+// Built on the host in one pass over the list (range check, sortedness, duplicates are the caller's business as in
+// mvdb_index_search_subset): a SORTED list that keeps at least a third of the rows, and every "all rows but these" set,
+// becomes a bitmap (n / 8 bytes up the wire instead of 8 per row, one full-rate pass per search); anything else stays a
+// row list on the device.  Results carry ROW NUMBERS.
+}  // extern "C"
+
+struct mvdb_rowset {
+    int device = 0;
+    int64_t n_at_create = 0;  // the index's row count the set was built against
+    uint64_t renumbered = 0;  // ... and its renumbering generation
+    int64_t count = 0;        // rows selected
+    int64_t* rows = nullptr;  // list form (device), in the caller's order
+    uint64_t* mask = nullptr; // bitmap form (device)
+};
+
+extern "C" {
+
+int mvdb_rowset_create(const mvdb_index* idx, const int64_t* rows_host, int64_t m, int excluded, mvdb_rowset** out) {
+    if (!out) return fail(MVDB_ERR_ARG, "out is NULL");
+    *out = nullptr;
+    if (!idx) return fail(MVDB_ERR_ARG, "index is NULL");
+    if (m < 0) return fail(MVDB_ERR_ARG, "negative row count");
+    if (m > 0 && !rows_host) return fail(MVDB_ERR_ARG, "rows is NULL");
+    std::shared_lock<std::shared_mutex> lk(idx->mu);
+    const int64_t n = idx->n;
+    bool sorted = true;
+    {
+        int64_t lo = 0, hi = -1, prev = -1;
+        for (int64_t i = 0; i < m; ++i) {
+            const int64_t r = rows_host[i];
+            lo = (i == 0 || r < lo) ? r : lo;
+            hi = (i == 0 || r > hi) ? r : hi;
+            sorted &= r > prev;
+            prev = r;
+        }
+        if (m > 0 && (lo < 0 || hi >= n))
+            return fail(MVDB_ERR_ARG, "row %lld out of range [0,%lld)", (long long)(lo < 0 ? lo : hi), (long long)n);
+    }
+    DeviceGuard dg(idx->device);
+    mvdb_rowset* rs = new mvdb_rowset();
+    rs->device = idx->device;
+    rs->n_at_create = n;
+    rs->renumbered = idx->renumbered;
+    const bool as_mask = excluded || (sorted && m * 3 >= n && n >= 4096);
+    hipError_t e = hipSuccess;
+    if (as_mask) {
+        const size_t words = (size_t)((n + 63) / 64);
+        std::vector<uint64_t> w(std::max<size_t>(words, 1), excluded ? ~0ull : 0ull);
+        if (excluded) {
+            if (n & 63) w[words - 1] = (1ull << (n & 63)) - 1ull;  // bits at or beyond n stay clear
+            int64_t removed = 0;
+            for (int64_t i = 0; i < m; ++i) {
+                uint64_t& word = w[rows_host[i] >> 6];
+                const uint64_t bit = 1ull << (rows_host[i] & 63);
+                removed += (word & bit) != 0;  // a row listed twice is removed once
+                word &= ~bit;
+            }
+            rs->count = n - removed;
+        } else {
+            for (int64_t i = 0; i < m; ++i) w[rows_host[i] >> 6] |= 1ull << (rows_host[i] & 63);
+            rs->count = m;  // sorted strictly ascending: no duplicates
+        }
+        e = hipMalloc((void**)&rs->mask, w.size() * sizeof(uint64_t));
+        if (e == hipSuccess) e = hipMemcpy(rs->mask, w.data(), w.size() * sizeof(uint64_t), hipMemcpyHostToDevice);
+    } else {
+        rs->count = m;
+        e = hipMalloc((void**)&rs->rows, (size_t)std::max<int64_t>(m, 1) * sizeof(int64_t));
+        if (e == hipSuccess && m > 0) e = hipMemcpy(rs->rows, rows_host, (size_t)m * sizeof(int64_t), hipMemcpyHostToDevice);
+    }
+    if (e != hipSuccess) {
+        if (rs->mask) (void)hipFree(rs->mask);
+        if (rs->rows) (void)hipFree(rs->rows);
+        delete rs;
+        return fail(MVDB_ERR_HIP, "row set upload failed: %s", hipGetErrorString(e));
+    }
+    *out = rs;
+    return 0;
+}
+
+int64_t mvdb_rowset_size(const mvdb_rowset* rs) { return rs ? rs->count : -1; }
+int mvdb_rowset_is_bitmap(const mvdb_rowset* rs) { return rs && rs->mask ? 1 : 0; }
+
+int mvdb_rowset_free(mvdb_rowset* rs) {
+    if (!rs) return 0;
+    {
+        DeviceGuard dg(rs->device);
+        if (rs->mask) (void)hipFree(rs->mask);
+        if (rs->rows) (void)hipFree(rs->rows);
+    }
+    delete rs;
+    return 0;
+}
+
+int mvdb_index_search_rowset(const mvdb_index* idx, const float* q_host, int nq, int k, int normalize_q,
+                             const mvdb_rowset* rs, float* D_host, int64_t* I_host) {
+    MVDB_TRY(check_search_args(idx, q_host, nq, k, D_host, I_host));
+    if (!rs) return fail(MVDB_ERR_ARG, "row set is NULL");
+    std::shared_lock<std::shared_mutex> lk(idx->mu);
+    // rows appended since the set was built are simply not part of it (the filter was evaluated before they arrived);
+    // a SHRUNK index has renumbered its rows: the set is stale
+    if (rs->device != idx->device || rs->n_at_create > idx->n || rs->renumbered != idx->renumbered)
+        return fail(MVDB_ERR_ARG, "the row set was built for another state of the index (%lld rows then, %lld now)",
+                    (long long)rs->n_at_create, (long long)idx->n);
+    DeviceGuard dg(idx->device);
+    Workspace* ws = idx->acquire();
+    if (!ws) return MVDB_ERR_HIP;
+    int rc = 0;
+    do {
+        if ((rc = stage_queries(idx, ws, q_host, nq))) break;
+        const size_t total = (size_t)nq * k;
+        if ((rc = ws->out.reserve(total + (total + 1) / 2))) break;
+        float* D_dev = reinterpret_cast<float*>(ws->out.p + total);
+        if (rs->mask) {
+            if ((rc = search_core(idx, ws, ws->q.p, nq, k, normalize_q, nullptr, rs->n_at_create, 0, D_dev, ws->out.p, false, rs->mask))) break;
+        } else {
+            // count == 0: search_core's empty-corpus branch needs a non-NULL list to take the subset meaning
+            if ((rc = search_core(idx, ws, ws->q.p, nq, k, normalize_q, rs->rows, rs->count, 0, D_dev, ws->out.p))) break;
+            if (rs->count > 0) {
+                hipLaunchKernelGGL(map_subset_labels_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ws->stream,
+                                   ws->out.p, (int64_t)total, (const int64_t*)rs->rows, (int64_t)0);
+                if (hipGetLastError() != hipSuccess) {
+                    rc = fail(MVDB_ERR_HIP, "label mapping failed");
+                    break;
+                }
+            }
+        }
+        rc = fetch_results(ws, total, D_host, I_host);
+    } while (0);
+    idx->release(ws);
+    return rc;
 }
 
 int mvdb_merge_topk_device(int metric, int nlists, int nq, int k, const float* D_dev,

@@ -38,6 +38,8 @@ struct ScanArgs {
     int normalize_q;      // L2-normalise the query in the prologue
     int k;                // <= kMaxFusedK in kModeTopK
     const int64_t* rows;  // optional subset: physical row of logical row r (NULL = identity)
+    const uint64_t* mask; // optional subset as a BITMAP over the physical rows (bit r & 63 of word r >> 6): every row is
+                          // scored at the full scan's rate, rows whose bit is clear are never offered; labels = row numbers
     uint64_t* cand;       // kModeTopK : [nq, gridDim.x, k] sorted block lists
     float* scores;        // kModeScores: [nq, n]
 };
@@ -50,14 +52,18 @@ __device__ __forceinline__ float group_reduce_add(float v) {
 }
 
 // METRIC 0: inner product (score = q.x).  METRIC 1: squared L2 (score = -|q-x|^2).
-// SUBSET : rows[] indirection (compile-time, so the identity path carries no branch and — crucially —
-//          no `s_waitcnt vmcnt(0)` between the row loads of a batch).
+// SEL    : 0 every row; 1 rows[] indirection (compile-time, so the identity path carries no branch and — crucially —
+//          no `s_waitcnt vmcnt(0)` between the row loads of a batch); 2 bitmap (a.mask): rows in corpus order, the bit of
+//          each row of the NEXT batch fetched behind the current batch's row loads; a clear bit only keeps the row out of
+//          the top-k gate (and writes -inf in score mode) — dense filters (exclude-filters keep most rows) then cost one
+//          full scan instead of a gather that is slower than the scan it avoids.
 // MASKED : the row has fewer than G*C chunks (lanes with chunk >= d4 load nothing).  When the row
 //          fills every lane the loads are unconditional: no exec-mask branches in the loop.
 // (Explicit register double-buffering of batches was measured and dropped: 3-5 % slower than relying
 //  on the other resident waves, profiles/r01_sweep_scan_variants.txt lineage.)
-template <int G, int C, int U, int METRIC, int MODE, bool NT = true, bool SUBSET = false, bool MASKED = true>
+template <int G, int C, int U, int METRIC, int MODE, bool NT = true, int SEL = 0, bool MASKED = true>
 __global__ __launch_bounds__(kScanThreads) void flat_scan_kernel(ScanArgs a) {
+    constexpr bool SUBSET = SEL == 1;
     constexpr int RPI = kWave / G;  // rows per wave-instruction
     constexpr int RB = RPI * U;     // rows per wave batch
     const int lane = threadIdx.x & (kWave - 1);
@@ -124,8 +130,18 @@ __global__ __launch_bounds__(kScanThreads) void flat_scan_kernel(ScanArgs a) {
         }
     };
 
+    // SEL == 2: is row r selected?  (one 8-byte load per row; the lanes of a row read the same word)
+    auto batch_bits = [&](int64_t b, bool (&sel)[U]) {
+        const int64_t row0 = b * RB + g;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            int64_t r = row0 + (int64_t)u * RPI;
+            r = r < last ? r : last;
+            sel[u] = (a.mask[r >> 6] >> (r & 63)) & 1ull;
+        }
+    };
     // reduce batch b and offer its rows to the top-k list / write its scores
-    auto consume_batch = [&](int64_t b, f32x4 (&x)[U][C]) {
+    auto consume_batch = [&](int64_t b, f32x4 (&x)[U][C], const bool (&sel)[U]) {
         const int64_t row0 = b * RB + g;
         float s[U];
 #pragma unroll
@@ -164,7 +180,7 @@ __global__ __launch_bounds__(kScanThreads) void flat_scan_kernel(ScanArgs a) {
                 const int64_t r = row0 + (int64_t)u * RPI;
                 if (t == 0 && r < a.n) {
                     const float v = s[u];
-                    a.scores[(int64_t)qi * a.n + r] = (v == v) ? v : -INFINITY;
+                    a.scores[(int64_t)qi * a.n + r] = (v == v && (SEL != 2 || sel[u])) ? v : -INFINITY;
                 }
             }
         } else {
@@ -172,13 +188,30 @@ __global__ __launch_bounds__(kScanThreads) void flat_scan_kernel(ScanArgs a) {
             for (int u = 0; u < U; ++u) {
                 const int64_t r = row0 + (int64_t)u * RPI;
                 // gate on the score alone (NaN fails); exact 64-bit order decided inside offer()
-                const bool pass = (t == 0) && (r < a.n) && (s[u] >= tk.thr_score);
+                const bool pass = (t == 0) && (r < a.n) && (SEL != 2 || sel[u]) && (s[u] >= tk.thr_score);
                 if (__ballot(pass)) tk.offer(pass ? make_key(s[u], (uint32_t)r) : 0ull);
             }
         }
     };
 
-    if (SUBSET) {
+    bool all_rows[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) all_rows[u] = true;
+    if (SEL == 2) {
+        bool sel[U], seln[U];
+        if (gw < nbatches) batch_bits(gw, sel);
+        for (int64_t b = gw; b < nbatches; b += nwaves_total) {
+            f32x4 x[U][C];
+            int64_t pr[U];
+            batch_rows(b, pr);
+            load_batch(pr, x);
+            const int64_t bn = b + nwaves_total;
+            batch_bits(bn < nbatches ? bn : b, seln);  // behind the row loads: never waited for by its own batch
+            consume_batch(b, x, sel);
+#pragma unroll
+            for (int u = 0; u < U; ++u) sel[u] = seln[u];
+        }
+    } else if (SUBSET) {
         // the row ids of the NEXT batch are fetched behind this batch's row loads, so that a batch never waits for
         // its own indirection (id load -> vmcnt(0) -> row loads serialised two round trips per batch: 2.0-2.3 TB/s of
         // rows touched at 10M x 512)
@@ -189,7 +222,7 @@ __global__ __launch_bounds__(kScanThreads) void flat_scan_kernel(ScanArgs a) {
             load_batch(pr, x);
             const int64_t bn = b + nwaves_total;
             batch_rows(bn < nbatches ? bn : b, pn);
-            consume_batch(b, x);
+            consume_batch(b, x, all_rows);
 #pragma unroll
             for (int u = 0; u < U; ++u) pr[u] = pn[u];
         }
@@ -199,7 +232,7 @@ __global__ __launch_bounds__(kScanThreads) void flat_scan_kernel(ScanArgs a) {
             int64_t pr[U];
             batch_rows(b, pr);
             load_batch(pr, x);
-            consume_batch(b, x);
+            consume_batch(b, x, all_rows);
         }
     }
 

@@ -128,13 +128,14 @@ __global__ void zero_tail_kernel(uint64_t* keys, int64_t from, int64_t to) {
     if (i < to) keys[i] = 0;
 }
 
+// drop_unselected: bitmap-selected search — rows outside the mask were written with score -inf and are not results
 __global__ void emit_sorted_kernel(const uint64_t* __restrict__ keys, int k, int metric,
                                    int64_t label_offset, float* __restrict__ D,
-                                   int64_t* __restrict__ I) {
+                                   int64_t* __restrict__ I, int drop_unselected) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= k) return;
     const uint64_t key = keys[i];
-    if (key) {
+    if (key && !(drop_unselected && key_score(key) == -INFINITY)) {
         const float s = key_score(key);
         D[i] = metric == 0 ? s : -s;
         I[i] = label_offset + (int64_t)key_row(key);

@@ -394,7 +394,12 @@ class DistributedShardedVectorDatabase:
         if len(filtered) != n_total:
             # the filtered rows this rank owns, as LOCAL row numbers, ascending (ties -> lower global row)
             lo, hi = self.first_row, self.first_row + self.local_rows
-            mine = np.array(sorted(r for r in filtered if lo <= r < hi), dtype=np.int64) - lo
+            removed = getattr(filtered, "removed", None)
+            if removed is not None:  # _AllRowsExcept (an exclude-filter over everything): this rank's rows but the excluded
+                gone = np.array(sorted(r - lo for r in removed if lo <= r < hi), dtype=np.int64)
+                mine = np.setdiff1d(np.arange(self.local_rows, dtype=np.int64), gone, assume_unique=True)
+            else:
+                mine = np.array(sorted(r for r in filtered if lo <= r < hi), dtype=np.int64) - lo
             rows = torch.from_numpy(mine).to(self.device)
         Dg, Ig = self._searcher(search_k).search_device(q_dev, rows=rows, normalize_q=True)
         Dg, Ig = Dg.cpu().numpy()[0], Ig.cpu().numpy()[0]

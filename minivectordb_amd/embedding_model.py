@@ -87,7 +87,7 @@ class GpuEncoder:
         # arithmetic of the GEMMs when a call does not say: 2 = split-precision fp16 x 3 on the 16-bit matrix cores
         # (fp32-equivalent to ~2^-21: embeddings within 6e-7 of transformers' fp32 output, as close as the exact mode,
         # tests/test_encoder_gpu.py),
-        # 0 = exact fp32 matrix cores, 1 = single bf16 product (opt-in speed mode, ~1e-3)
+        # 0 = exact fp32 matrix cores
         self.default_compute = int(os.environ.get("MVDB_ENCODER_COMPUTE", "2"))
 
     def close(self):

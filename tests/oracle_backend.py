@@ -9,6 +9,17 @@ import numpy as np
 from oracle import flat
 
 
+class _OracleRowSet:
+    def __init__(self, rows, n, gen):
+        self.rows, self.n, self.gen = rows, n, gen
+
+    def __len__(self):
+        return len(self.rows)
+
+    def close(self):
+        pass
+
+
 class OracleIndex:
     def __init__(self, d, metric=0, device=0):
         self.d, self.metric, self.device = int(d), metric, device
@@ -47,6 +58,7 @@ class OracleIndex:
         rows = np.asarray(rows, dtype=np.int64)
         assert len(set(rows.tolist())) == len(rows)
         self.x = np.ascontiguousarray(np.delete(self.x, rows, 0))
+        self.renumbered = getattr(self, "renumbered", 0) + 1
         self.calls.append(("remove", len(rows)))
 
     def search(self, q, k, normalize_q=False):
@@ -57,6 +69,22 @@ class OracleIndex:
             return (np.full((q.shape[0], k), -3.4028234663852886e38, np.float32),
                     np.full((q.shape[0], k), -1, np.int64))
         return flat.flat_search(x, q, k, metric=self.metric, normalize_q=normalize_q)
+
+    def rowset(self, rows, excluded=False):
+        """Stand-in of _native.RowSet: the rows in search order (an excluded set: every other row, ascending)."""
+        rows = np.asarray(rows, dtype=np.int64)
+        if excluded:
+            keep = np.ones(self.x.shape[0], dtype=bool)
+            keep[rows] = False
+            rows = np.flatnonzero(keep).astype(np.int64)
+        self.calls.append(("rowset", len(rows)))
+        return _OracleRowSet(rows, self.x.shape[0], getattr(self, "renumbered", 0))
+
+    def search_rowset(self, q, k, rowset, normalize_q=False):
+        if rowset.n > self.x.shape[0] or rowset.gen != getattr(self, "renumbered", 0):
+            raise ValueError("the row set was built for another state of the index")  # what mvdb_index_search_rowset reports
+        D, P = self.search_subset(q, k, rowset.rows, normalize_q=normalize_q)
+        return D, np.where(P >= 0, rowset.rows[np.maximum(P, 0)], -1)
 
     def search_subset(self, q, k, rows, normalize_q=False):
         self.calls.append(("subset", k, len(rows)))

@@ -553,6 +553,8 @@ def _split_launches(native):
     (300000, 64, 10, 64), (270001, 128, 5, 130), (300000, 64, 10, 24), (70000, 128, 12, 100), (70001, 128, 12, 24), (40003, 256, 3, 129),  # seed + main launch
     (70001, 512, 10, 128), (40003, 512, 12, 50), (150003, 512, 5, 100), (33000, 512, 10, 33),  # seed + the K-split d = 512 kernels: ragged last tile, one and two phases
     (9000, 768, 10, 100), (70001, 1024, 10, 128), (150003, 384, 10, 256), (40003, 512, 10, 200), (100000, 256, 10, 255),  # fp16 pass: every dimension it serves, 128- and 256-query passes
+    (60000, 128, 10, 256), (50001, 640, 10, 128), (30000, 896, 10, 70),  # round 3: d = 640, 896 on the fp16 pass too (128: bf16 split)
+    (80000, 512, 16, 128), (150003, 512, 32, 256), (60000, 384, 20, 130), (50001, 640, 16, 100), (40000, 1024, 32, 64),  # k up to 32 (64 nominees)
 ])
 def test_split_precision_batch_pass_matches_oracle(native, monkeypatch, n, d, k, nq):
     """nq >= 33 (24 here), k <= 12: the bf16 split-precision pass nominates 16 rows per query, exact fp32 re-scores
@@ -660,6 +662,42 @@ def test_split_certificate_at_the_margin(native, d, frac, must_rerun):
         if spacing >= 1e-5 or qi not in (0, 17, 39):
             assert I[qi].tolist() == want.tolist(), (qi, I[qi], want)
         else:   # finer steps: fp32 re-scores (1e-7) still order them; float64 adjudicates anything closer
+            ok, msg = flat.adjudicate(x, q[qi], k, D[qi], I[qi], tol=TOL)
+            assert ok, msg
+        np.testing.assert_allclose(D[qi], t[I[qi]], atol=TOL, rtol=0)
+    idx.close()
+
+
+@pytest.mark.parametrize("frac,must_rerun", [(1 / 48, True), (0.9, False)])
+def test_fp16_certificate_at_the_margin_k32(native, frac, must_rerun):
+    """k = 32 on the fp16 pass (64 nominees re-scored): 80 rows graded `frac * eps` apart, SCATTERED over the corpus (every
+    block list holds at most a few).  Steps of eps / 48: the 64th nominee is only 0.67 eps below the 32nd result — the
+    certificate must refuse and the exact re-run must return the right ids; steps of 0.9 eps: 29 eps of room — it must
+    certify on its own.  Either way the ids are exact."""
+    n, d, k, nq = 40000, 512, 32, 40
+    assert native.half_max_queries(d) >= nq
+    eps = native.half_eps(d)
+    spacing = frac * eps
+    rs = np.random.RandomState(int(frac * 1e4) + 32)
+    x = _corpus(n, d)
+    q = _corpus(nq, d, seed=4242)
+    cos = 0.9 - spacing * np.arange(80)
+    for qi, base in ((0, 100), (17, 133), (39, 171)):
+        rows = _graded_rows(q[qi], cos, rs)
+        x[base + 490 * rs.permutation(80)] = rows          # one planted row every 490 rows, in random score order
+    idx = native.FlatIndex(d)
+    idx.add(x)
+    before = native.split_rerun_count()
+    D, I = idx.search(q, k)
+    reran = native.split_rerun_count() - before
+    assert (reran >= 1) == must_rerun, (reran, eps)
+    x64 = x.astype(np.float64)
+    for qi in range(nq):
+        t = x64 @ q[qi].astype(np.float64)
+        want = np.argsort(-t, kind="stable")[:k]
+        if spacing >= 1e-5 or qi not in (0, 17, 39):
+            assert I[qi].tolist() == want.tolist(), (qi, I[qi], want)
+        else:
             ok, msg = flat.adjudicate(x, q[qi], k, D[qi], I[qi], tol=TOL)
             assert ok, msg
         np.testing.assert_allclose(D[qi], t[I[qi]], atol=TOL, rtol=0)
@@ -821,3 +859,150 @@ def test_batch_search_never_syncs_and_is_capturable(native):
         assert I1[130].tolist() == list(range(9000, 9010))
         _check(native, x, q2, k, D1, I1)
     idx.close()
+
+
+# ---- bitmap-selected search and resident row sets (reference: the per-query sub-index, vector_database.py:508-523) --------
+@pytest.mark.parametrize("d,metric", [(512, flat.METRIC_IP), (100, flat.METRIC_IP), (384, flat.METRIC_L2)])
+@pytest.mark.parametrize("frac", [0.01, 0.5, 0.99])
+def test_masked_search_equals_the_subset_search_of_the_ascending_list(native, d, metric, frac):
+    """mvdb_index_search_masked == mvdb_index_search_subset on the ascending list of the mask's set rows: same scores, and
+    with labels = positions the same labels (the oracle's flat_search(rows=...)); labels = rows gives rows[position].  Exact
+    ties (planted duplicates) resolve to the lower row in both."""
+    n, k, nq = 50_000, 10, 3
+    x = _corpus(n, d, normalize=metric == flat.METRIC_IP)
+    q = _corpus(nq, d, seed=9, normalize=metric == flat.METRIC_IP)
+    x[40_001] = x[300]       # exact duplicates: equal scores for every query
+    x[777] = x[300]
+    rs = np.random.RandomState(int(frac * 100) + d)
+    rows = np.sort(rs.choice(n, int(n * frac), replace=False)).astype(np.int64)
+    rows = np.unique(np.concatenate([rows, [300, 777, 40_001]]))
+    q[0] = x[300]            # query 0's best rows ARE the three duplicates
+    idx = native.FlatIndex(d, metric=metric)
+    idx.add(x)
+    mask = native.pack_row_mask(n, rows=rows)
+    Dp, Ip = idx.search_masked(q, k, mask, labels="positions")
+    Do, Io = flat.flat_search(x, q, k, metric=metric, rows=rows)
+    Ds, Is = idx.search_subset(q, k, rows)
+    assert np.array_equal(Ip, Is)
+    np.testing.assert_allclose(Dp, Ds, atol=0, rtol=0)       # the same kernel arithmetic, row for row
+    _check(native, x, q, k, Dp, Ip, metric=metric, rows=rows)
+    Dr, Ir = idx.search_masked(q, k, mask, labels="rows")
+    assert np.array_equal(Ir, rows[Ip]) and np.array_equal(Dr, Dp)
+    assert Ir[0, :3].tolist() == [300, 777, 40_001]           # ties: ascending row
+    idx.close()
+
+
+def test_masked_search_edge_cases(native):
+    """k larger than the number of selected rows (tail -1), k > 64 (scores + radix select path), an empty mask, a mask with
+    bits set beyond ntotal, several queries."""
+    n, d = 20_000, 256
+    x = _corpus(n, d)
+    q = _corpus(2, d, seed=4)
+    idx = native.FlatIndex(d)
+    idx.add(x)
+    rows = np.array([5, 17, 19_999], dtype=np.int64)
+    mask = native.pack_row_mask(n, rows=rows)
+    mask[-1] |= np.uint64(0xFFFF) << np.uint64(48)            # garbage beyond row n - 1 must be ignored
+    D, I = idx.search_masked(q, 8, mask)
+    t = x[rows].astype(np.float64) @ q.astype(np.float64).T
+    for i in range(2):
+        want = rows[np.argsort(-t[:, i], kind="stable")]
+        assert I[i, :3].tolist() == want.tolist() and (I[i, 3:] == -1).all()
+        assert (D[i, 3:] == np.float32(-3.4028234663852886e38)).all()
+    D0, I0 = idx.search_masked(q, 5, np.zeros_like(mask))
+    assert (I0 == -1).all()
+    rs = np.random.RandomState(1)
+    many = np.sort(rs.choice(n, 9000, replace=False)).astype(np.int64)
+    mk = native.pack_row_mask(n, rows=many)
+    for k in (100, 1000):                                      # the scores + select path, restricted by the bitmap
+        Dk, Ik = idx.search_masked(q, k, mk)
+        Do, Io = flat.flat_search(x, q, k, rows=many)
+        assert np.array_equal(Ik, many[Io])
+        np.testing.assert_allclose(Dk, Do, atol=2e-6, rtol=0)
+    Dm, Im = idx.search_masked(q, 9500, mk)                    # more than the mask selects
+    assert (Im[:, :9000] >= 0).all() and (Im[:, 9000:] == -1).all()
+    idx.close()
+
+
+def test_resident_row_sets(native):
+    """mvdb_rowset: a filter's rows made resident once.  An unsorted list stays a list (ties by list position, as the
+    reference's sub-index); a sorted list that keeps a third of the rows, and every 'all but these' set, become bitmaps;
+    results are ROW NUMBERS and equal the subset search; appends keep a set valid (new rows are not part of it), a removal
+    makes it stale (ValueError)."""
+    n, d, k = 30_000, 512, 10
+    x = _corpus(n, d)
+    q = _corpus(2, d, seed=2)
+    x[123] = x[29_000]                                          # a tie between rows 123 and 29,000
+    q[0] = x[123]
+    idx = native.FlatIndex(d)
+    idx.add(x)
+    rs = np.random.RandomState(3)
+    perm = rs.permutation(n)[:5000].astype(np.int64)
+    perm = np.concatenate([[29_000, 123], perm[(perm != 123) & (perm != 29_000)]])   # 29,000 is listed BEFORE 123
+    s1 = idx.rowset(perm)
+    assert not s1.is_bitmap and len(s1) == len(perm)
+    D1, I1 = idx.search_rowset(q, k, s1)
+    Ds, Is = idx.search_subset(q, k, perm)
+    assert np.array_equal(I1, perm[Is]) and np.array_equal(D1, Ds)
+    assert I1[0, :2].tolist() == [29_000, 123]                   # list order decides the tie
+    dense = np.sort(rs.choice(n, 20_000, replace=False)).astype(np.int64)
+    dense = np.unique(np.concatenate([dense, [123, 29_000]]))
+    s2 = idx.rowset(dense)
+    assert s2.is_bitmap and len(s2) == len(dense)
+    D2, I2 = idx.search_rowset(q, k, s2)
+    Dd, Id = idx.search_subset(q, k, dense)
+    assert np.array_equal(I2, dense[Id]) and np.array_equal(D2, Dd)
+    assert I2[0, :2].tolist() == [123, 29_000]                   # ascending rows
+    excl = np.array([123, 7, 7, 15_000], dtype=np.int64)          # a row listed twice is removed once
+    s3 = idx.rowset(excl, excluded=True)
+    assert s3.is_bitmap and len(s3) == n - 3
+    D3, I3 = idx.search_rowset(q, k, s3)
+    keep = np.setdiff1d(np.arange(n), excl)
+    De, Ie = idx.search_subset(q, k, keep)
+    assert np.array_equal(I3, keep[Ie]) and np.array_equal(D3, De)
+    assert 123 not in I3[0] and I3[0, 0] == 29_000
+    idx.add(_corpus(10, d, seed=8))                               # appended rows: the sets still answer, without them
+    D3b, I3b = idx.search_rowset(q, k, s3)
+    assert np.array_equal(I3b, I3) and np.array_equal(D3b, D3)
+    assert np.array_equal(idx.search_rowset(q, k, s1)[1], I1)
+    idx.remove_rows(np.array([5], dtype=np.int64))                # rows renumbered: stale
+    for s in (s1, s2, s3):
+        with pytest.raises(ValueError, match="another state"):
+            idx.search_rowset(q, k, s)
+        s.close()
+    with pytest.raises(ValueError, match="out of range"):
+        idx.rowset(np.array([idx.ntotal], dtype=np.int64))
+    idx.close()
+
+
+def test_drop_in_exclude_filter_runs_as_a_resident_bitmap(native):
+    """VectorDatabase.find_most_similar with an exclude-filter over everything: the reference subtracts from an O(N) set and
+    gathers ~N rows into a throw-away index per query (vector_database.py:354-386, :508-523); here the excluded rows go
+    up once, the search is one full-rate pass under a bitmap, and the next query under the same filter uploads nothing."""
+    from minivectordb_amd import VectorDatabase
+    from minivectordb_amd import _dbcore
+    n, d = 6000, 64
+    x = _corpus(n, d)
+    db = VectorDatabase(storage_file="/tmp/mvdb_test_excl.pkl")
+    db.store_embeddings_batch(list(range(n)), list(x), [{"tag": "odd" if i % 7 == 3 else "even", "i": i} for i in range(n)])
+    made = []
+    orig = native.FlatIndex.rowset
+
+    def spy(self, rows, excluded=False):
+        made.append((len(rows), excluded))
+        return orig(self, rows, excluded)
+
+    native.FlatIndex.rowset = spy
+    try:
+        ids, dist, meta = db.find_most_similar(x[3], exclude_filter={"tag": "odd"}, k=5)
+        ids2, _, _ = db.find_most_similar(x[11], exclude_filter={"tag": "odd"}, k=5)
+    finally:
+        native.FlatIndex.rowset = orig
+    assert made == [(len(range(3, n, 7)), True)]                  # one resident set, built from the EXCLUDED rows, reused
+    assert all(m["tag"] == "even" for m in meta) and 3 not in ids and ids2[0] == 11
+    kept = np.array([i for i in range(n) if i % 7 != 3])
+    Do, Io = flat.flat_search(db.embeddings, x[3:4] / np.linalg.norm(x[3]), 5, rows=kept)
+    assert list(ids) == kept[Io[0]].tolist()
+    db.store_embedding("new", x[3], {"tag": "even"})              # a write drops the resident sets
+    ids3, _, _ = db.find_most_similar(x[3], exclude_filter={"tag": "odd"}, k=2)
+    assert "new" in ids3

@@ -248,7 +248,7 @@ def test_half_pass_widths_by_dimension():
     from minivectordb_amd import _native
     for d in (256, 384, 512):
         assert _native.half_max_queries(d) == 256
-    for d in (768, 1024):
+    for d in (640, 768, 896, 1024):   # round 3: every even multiple of 64 from 256 to 1024
         assert _native.half_max_queries(d) == 128
-    for d in (32, 64, 100, 128, 640, 2048):
+    for d in (32, 64, 100, 128, 192, 320, 576, 2048):   # d = 128: tried and dropped (half_scan.hip: half_kq)
         assert _native.half_max_queries(d) == 0
