@@ -47,15 +47,30 @@ def main():
         # includes the H2D copy of the row list (8 B per row) — what find_most_similar's filtered branch pays
         print(json.dumps({"what": f"subset search, {frac:g} of the rows (sorted ids), k=10", "rows": m,
                           "ms": round(dt * 1e3, 3), "GBps_rows_touched": round(m * row_bytes / dt / 1e9, 1)}), flush=True)
-    import os
-    for frac in (0.99, 0.9, 0.5):  # dense subsets (exclude-filters): the opt-in full score pass + pick, and the default gather path
+    # a filter's rows four ways, host API: the row list per query (what round 2 had), the bitmap per query, and the
+    # RESIDENT row set (uploaded once: list, bitmap, or "every row but these") — what the drop-in keeps per filter
+    for frac in (0.99, 0.9, 0.5, 0.1):
         m = int(n * frac)
         rows = np.sort(rs.choice(n, m, replace=False)).astype(np.int64)
-        out = {"what": f"dense subset, {frac:g} of the rows, k=10", "rows": m}
-        for label, pct in (("full_pass_ms", "50"), ("gather_ms", "101")):
-            os.environ["MVDB_SUBSET_DENSE_PERCENT"] = pct
-            out[label] = round(timeit(lambda: idx.search_subset(q[0], 10, rows), 10) * 1e3, 3)
-        os.environ.pop("MVDB_SUBSET_DENSE_PERCENT", None)
+        out = {"what": f"filter keeping {frac:g} of the rows, k=10 (host API incl. PCIe)", "rows": m}
+        out["row_list_per_query_ms"] = round(timeit(lambda: idx.search_subset(q[0], 10, rows), 10) * 1e3, 3)
+        t0 = time.perf_counter()
+        mask = native.pack_row_mask(n, rows=rows)
+        out["pack_bitmap_on_host_ms"] = round((time.perf_counter() - t0) * 1e3, 2)
+        out["bitmap_per_query_ms"] = round(timeit(lambda: idx.search_masked(q[0], 10, mask), 10) * 1e3, 3)
+        t0 = time.perf_counter()
+        rsid = idx.rowset(rows)
+        out["rowset_create_ms"] = round((time.perf_counter() - t0) * 1e3, 2)
+        out["rowset_is_bitmap"] = rsid.is_bitmap
+        out["resident_rowset_ms"] = round(timeit(lambda: idx.search_rowset(q[0], 10, rsid), 20) * 1e3, 3)
+        rsid.close()
+        if frac >= 0.9:
+            excl = np.setdiff1d(np.arange(n, dtype=np.int64), rows)
+            t0 = time.perf_counter()
+            rse = idx.rowset(excl, excluded=True)
+            out["excluded_rowset_create_ms"] = round((time.perf_counter() - t0) * 1e3, 2)
+            out["excluded_rowset_ms"] = round(timeit(lambda: idx.search_rowset(q[0], 10, rse), 20) * 1e3, 3)
+            rse.close()
         print(json.dumps(out), flush=True)
     rows = rs.permutation(n)[:n // 10].astype(np.int64)
     dt = timeit(lambda: idx.search_subset(q[0], 10, rows), 10)

@@ -4,10 +4,12 @@ The library is the ONLY compute back end of this package: there is no CPU fallba
 fails loudly when the in-tree shared object is missing, and every compute entry point raises
 ``RuntimeError`` when no HIP device is usable.
 
-torch is imported first on purpose: PyTorch-ROCm bundles its own HIP runtime under the SONAME
-``libamdhip64.so.7``; loading it first makes libmvdb.so bind to the same runtime instance, so
-device pointers and streams can be exchanged with torch tensors (torch is used only for device
-memory, streams and torch.distributed — never for the search arithmetic).
+PyTorch-ROCm bundles its own HIP runtime under the SONAME ``libamdhip64.so.7``; libmvdb.so must bind to
+THAT instance, so that device pointers and streams can be exchanged with torch tensors (torch is used
+only for device memory, streams and torch.distributed — never for the search arithmetic) and so that a
+later ``import torch`` does not bring a second HIP runtime into the process.  If torch is already
+imported its runtime is loaded; otherwise torch's ``lib/libamdhip64.so`` is pre-loaded by path WITHOUT
+importing torch (a VectorDatabase-only user pays no 1-2 s ``import torch`` on the first query).
 """
 import ctypes
 import os
@@ -16,6 +18,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libmvdb.so")
+LIB_PATH = os.environ.get("MVDB_LIBMVDB", LIB_PATH)  # diagnostics only: e.g. the ablation build (make ABLATE=1)
 
 METRIC_IP = 0
 METRIC_L2 = 1
@@ -114,6 +117,30 @@ PROTOTYPES = {
 }
 
 
+def _bind_torch_hip_runtime():
+    """One HIP runtime per process (module docstring): torch's own, loaded before libmvdb.so resolves its
+    ``libamdhip64.so.7`` dependency."""
+    import sys
+    if "torch" in sys.modules or os.environ.get("MVDB_IMPORT_TORCH_FIRST") == "1":
+        import torch  # noqa: F401
+        return
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return  # no torch in this environment: the system ROCm runtime serves
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+            return
+        except OSError:
+            pass
+    import torch  # noqa: F401  (layout not recognised: the slow, certain way)
+
+
 def lib():
     """Load libmvdb.so (once).  Raises if the in-tree build is missing — never falls back."""
     global _lib
@@ -124,7 +151,7 @@ def lib():
             f"{LIB_PATH} is missing: build the HIP library first "
             "(python -c 'import __graft_entry__ as g; g.build()' or make -C minivectordb_amd/csrc). "
             "minivectordb_amd has no CPU fallback.")
-    import torch  # noqa: F401  (see module docstring: binds both to one HIP runtime)
+    _bind_torch_hip_runtime()
     L = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(L, name)

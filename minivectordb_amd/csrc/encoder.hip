@@ -706,6 +706,11 @@ __device__ __forceinline__ void x3_split2(float a, float b, uint32_t& hi, uint32
 //     lane instead of 16, no DPP pairing;
 //   * a row's LayerNorm statistics are sums over the lane's OWN registers plus one exchange with the other half.
 // The stores of a big tile were issue-bound: 128 dword stores per lane on a 256 x 256 tile, as long as its K loop at K = 384.
+// What the epilogue is bound by NOW is the bytes it writes (ablation build, make ABLATE=1, MVDB_GEMM_X3_DBG=4 = no K loop):
+// at T = 131072 the QKV / FFN1 / N = H kernels write 604 / 805 / 403 (+ 201 read) MB in 109 / 175 / 130 us = 5.6 / 4.6 /
+// 4.6 TB/s, at T = 8192 37.7 / 50 / 25 MB in 12.4 / 14.9 / 10.7 us (launch ramp included) — a third of each GEMM, serial
+// with its K loop.  Tried on top and dropped (same time to 1 %): staging the outputs through LDS so that every store
+// instruction writes whole 128-byte lines instead of 32 bytes of 32 different rows.
 __device__ __forceinline__ void x3t_store_image(unsigned char* line, int fh, const float (&v)[16], bool ok) {
     // line: the 128 bytes [hi 32 | lo 32] of (this lane's row, this tile's 32 columns).  Every lane must take part in the
     // swaps (EXEC all ones); only the stores are predicated.

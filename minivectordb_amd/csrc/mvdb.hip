@@ -916,29 +916,8 @@ bool mfma_path_ok(const mvdb_index* idx, int nq, int k, const int64_t* rows_dev)
 }
 
 // Core: queries already on the device (padded to ld), outputs on the device.  Enqueues on ws.stream.
-// sub[qi, p] = full[qi, rows[p]]: the scores of a dense subset picked out of a full-corpus score pass
-__global__ void gather_scores_kernel(const float* __restrict__ full, int64_t n, const int64_t* __restrict__ rows,
-                                     int64_t m, float* __restrict__ sub) {
-    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int qi = blockIdx.y;
-    if (p < m) sub[(int64_t)qi * m + p] = full[(int64_t)qi * n + rows[p]];
-}
-
-// OPT-IN (MVDB_SUBSET_DENSE_PERCENT = 50 ...; default off): a subset that keeps most of the corpus scored by a pass over
-// EVERY row at the full scan's rate, the subset's scores picked out afterwards — scores pass over all rows ->
-// gather_scores_kernel -> the radix select of the large-k path over the m subset scores (labels = positions in the list,
-// as the gather path returns them).  Same results (test_dense_subset_takes_the_full_score_pass), but measured SLOWER than
-// the pipelined gather at 10M x 512: 7.4 vs 7.0 ms at 99 % of the rows, 5.4 vs 3.5 at 50 % (1.6 / 0.8 ms of either are the
-// upload of the id list) — the eight histogram passes of the select over 10M scores cost more than the gather loses.
-// Kept as the A/B reference for the open work: a fused masked scan (row -> position map), and an entry point that takes
-// the EXCLUDED rows so that the id list of an exclude-filter is not ~n entries long.
-bool dense_subset_ok(const mvdb_index* idx, int nq, const int64_t* rows_dev, int64_t m) {
-    if (!rows_dev || nq > 4) return false;
-    const int pct = env_int("MVDB_SUBSET_DENSE_PERCENT", 101);
-    if (pct > 100 || idx->n < env_int("MVDB_SUBSET_DENSE_MIN_ROWS", 200000)) return false;
-    return m * 100 >= idx->n * (int64_t)pct;
-}
-
+// (Round 2 had an opt-in "dense subset" route here — score every row, pick the subset's scores out, radix-select over
+// them — measured slower than the gather; round 3 replaced it by the bitmap-selected scan, mvdb_index_search_masked.)
 // label of result = position p with rows = the ascending list of the mask's set bits: p = number of set bits below the row
 __global__ __launch_bounds__(256) void mask_rank_kernel(int64_t* __restrict__ I, const uint64_t* __restrict__ mask) {
     __shared__ int part[256];
@@ -1214,8 +1193,7 @@ int search_core(const mvdb_index* idx, Workspace* ws, const float* q_dev, int nq
         return 0;
     }
 
-    const bool dense = dense_subset_ok(idx, nq, rows_dev, m);
-    if (k <= kMaxFusedK && !dense) {
+    if (k <= kMaxFusedK) {
         MVDB_TRY(ws->cand.reserve((size_t)nq * scan_grid_upper_bound(idx->device) * k));
         a.cand = ws->cand.p;
         int nblocks = 0;
@@ -1233,28 +1211,12 @@ int search_core(const mvdb_index* idx, Workspace* ws, const float* q_dev, int nq
         return 0;
     }
 
-    // ---- large k, or a dense subset: scores -> radix select -> sort -------------------------------
-    const float* sc_base = nullptr;
+    // ---- large k: scores -> radix select -> sort ------------------------------------------------------
     int nblocks = 0;
-    if (dense) {
-        // every row is scored once, in corpus order; the subset's scores are then picked out in list order
-        const int64_t nall = idx->n;
-        MVDB_TRY(ws->scores.reserve((size_t)nq * nall + (size_t)nq * n));
-        a.n = nall;
-        a.rows = nullptr;
-        a.scores = ws->scores.p;
-        MVDB_TRY(launch_scan(idx->metric, kModeScores, a, nq, idx->device, s, &nblocks));
-        float* sub = ws->scores.p + (size_t)nq * nall;
-        hipLaunchKernelGGL(gather_scores_kernel, dim3((unsigned)((n + 255) / 256), nq), dim3(256), 0, s, ws->scores.p, nall,
-                           rows_dev, n, sub);
-        MVDB_HIP(hipGetLastError());
-        sc_base = sub;
-    } else {
-        MVDB_TRY(ws->scores.reserve((size_t)nq * n));
-        a.scores = ws->scores.p;
-        MVDB_TRY(launch_scan(idx->metric, kModeScores, a, nq, idx->device, s, &nblocks));
-        sc_base = ws->scores.p;
-    }
+    MVDB_TRY(ws->scores.reserve((size_t)nq * n));
+    a.scores = ws->scores.p;
+    MVDB_TRY(launch_scan(idx->metric, kModeScores, a, nq, idx->device, s, &nblocks));
+    const float* sc_base = ws->scores.p;
     const int64_t k_eff = std::min<int64_t>(k, n);
     const int64_t P = pow2ceil(std::max<int64_t>(k, 2));
     MVDB_TRY(ws->selkeys.reserve((size_t)P));
@@ -1850,7 +1812,7 @@ int mvdb_index_search_masked(const mvdb_index* idx, const float* q_host, int nq,
 
 // ---- resident row sets: a filter's rows uploaded ONCE, searched many times ---------------------------------------------
 // Built on the host in one pass over the list (range check, sortedness, duplicates are the caller's business as in
-// mvdb_index_search_subset): a SORTED list that keeps at least a third of the rows, and every "all rows but these" set,
+// mvdb_index_search_subset): a SORTED list that keeps at least 90 % of the rows, and every "all rows but these" set,
 // becomes a bitmap (n / 8 bytes up the wire instead of 8 per row, one full-rate pass per search); anything else stays a
 // row list on the device.  Results carry ROW NUMBERS.
 }  // extern "C"
@@ -1892,7 +1854,11 @@ int mvdb_rowset_create(const mvdb_index* idx, const int64_t* rows_host, int64_t 
     rs->device = idx->device;
     rs->n_at_create = n;
     rs->renumbered = idx->renumbered;
-    const bool as_mask = excluded || (sorted && m * 3 >= n && n >= 4096);
+    // bitmap: "all rows but these", and sorted lists that keep >= 90 % of the rows.  On the device a resident LIST is
+    // gathered at 6.2-7.0 TB/s of rows touched (10M x 512: half the rows 1.50 ms, 90 % 2.65 ms, 99 % 2.89 ms) against
+    // 2.87 ms for the bitmap's full pass at any density, so the bitmap only wins where the list is ~n long — there it
+    // is 64x smaller in HBM and on the wire
+    const bool as_mask = excluded || (sorted && m * 10 >= n * 9 && n >= 4096);
     hipError_t e = hipSuccess;
     if (as_mask) {
         const size_t words = (size_t)((n + 63) / 64);

@@ -203,44 +203,6 @@ def test_subset_search(native):
     idx.close()
 
 
-def test_dense_subset_takes_the_full_score_pass(native, monkeypatch):
-    """Opt-in path (MVDB_SUBSET_DENSE_PERCENT): a subset that keeps >= half of the rows scored by ONE pass over the whole
-    corpus and picked out of the score vector (mvdb.hip dense_subset_ok); same results, positions and tie order as the
-    gather path."""
-    monkeypatch.setenv("MVDB_SUBSET_DENSE_MIN_ROWS", "0")
-    monkeypatch.setenv("MVDB_SUBSET_DENSE_PERCENT", "50")
-    n, d = 6000, 256
-    x = _corpus(n, d)
-    x[100] = x[4100]  # exact ties across the subset
-    q = _corpus(3, d, seed=91)
-    rng = np.random.RandomState(3)
-    native.prof_enable(True)
-    try:
-        for metric in (native.METRIC_IP, native.METRIC_L2):
-            idx = native.FlatIndex(d, metric=metric)
-            idx.add(x)
-            for m, k in [(3000, 10), (3100, 1), (4500, 64), (6000, 10), (6000, 100), (5999, 12)]:
-                rows = rng.permutation(n)[:m].astype(np.int64)
-                native.prof_read("ip_scan_scores")  # read-and-clear
-                native.prof_read("ip_scan")
-                D, I = idx.search_subset(q, k, rows)
-                assert native.prof_read("ip_scan_scores")[0] == 1, "one full score pass for all three queries"
-                assert native.prof_read("ip_scan")[0] == 0
-                assert (I >= 0).all() and (I < m).all()
-                _check(native, x, q, k, D, I, rows=rows, metric=metric)
-                monkeypatch.setenv("MVDB_SUBSET_DENSE_PERCENT", "101")  # the gather path on the same call
-                D2, I2 = idx.search_subset(q, k, rows)
-                monkeypatch.setenv("MVDB_SUBSET_DENSE_PERCENT", "50")
-                np.testing.assert_array_equal(I, I2)
-                np.testing.assert_array_equal(D, D2)
-            native.prof_read("ip_scan_scores")
-            idx.search_subset(q, 10, rng.permutation(n)[:2000].astype(np.int64))  # a third of the rows: gathered
-            assert native.prof_read("ip_scan_scores")[0] == 0
-            idx.close()
-    finally:
-        native.prof_enable(False)
-
-
 def test_l2_metric_extension(native):
     n, d = 4000, 96
     x = flat.synth(n, d, 11)
@@ -926,7 +888,7 @@ def test_masked_search_edge_cases(native):
 
 def test_resident_row_sets(native):
     """mvdb_rowset: a filter's rows made resident once.  An unsorted list stays a list (ties by list position, as the
-    reference's sub-index); a sorted list that keeps a third of the rows, and every 'all but these' set, become bitmaps;
+    reference's sub-index); a sorted list that keeps 90 % of the rows, and every 'all but these' set, become bitmaps;
     results are ROW NUMBERS and equal the subset search; appends keep a set valid (new rows are not part of it), a removal
     makes it stale (ValueError)."""
     n, d, k = 30_000, 512, 10
@@ -945,7 +907,7 @@ def test_resident_row_sets(native):
     Ds, Is = idx.search_subset(q, k, perm)
     assert np.array_equal(I1, perm[Is]) and np.array_equal(D1, Ds)
     assert I1[0, :2].tolist() == [29_000, 123]                   # list order decides the tie
-    dense = np.sort(rs.choice(n, 20_000, replace=False)).astype(np.int64)
+    dense = np.sort(rs.choice(n, 28_000, replace=False)).astype(np.int64)
     dense = np.unique(np.concatenate([dense, [123, 29_000]]))
     s2 = idx.rowset(dense)
     assert s2.is_bitmap and len(s2) == len(dense)
