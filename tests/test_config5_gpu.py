@@ -74,5 +74,39 @@ def test_config5_encoder_batch256_then_knn_10m_x_384(gpu):
         D1, I1 = idx.search(emb_host[b], k)
         assert np.array_equal(I1[0], Ih[b]), (b, I1[0], Ih[b])
         np.testing.assert_allclose(D1[0], Dh[b], atol=2e-6, rtol=0)
+    # ---- the whole chain as ONE hipGraph: encoder forward -> 256 queries -> certified kNN --------------------------
+    # mvdb_index_search_device never reads the device back and the encoder joins an outer capture with plain launches, so
+    # the two calls record into one graph; the replay must reproduce the eager ids and scores bit for bit
+    cur = torch.cuda.current_stream()
+    g = torch.cuda.CUDAGraph()
+    emb_g = torch.empty_like(emb2)
+    Dg, Ig = torch.empty_like(D), torch.empty_like(I)
+    for _ in range(2):   # eager calls on this stream size the workspaces (allocation is not capturable)
+        e_, _ = enc.forward_device(ids, mask)
+        emb_g.copy_(e_)
+        idx.search_device(emb_g.data_ptr(), B, k, Dg.data_ptr(), Ig.data_ptr(), stream=stream)
+    torch.cuda.synchronize()
+    with torch.cuda.graph(g, stream=cur, capture_error_mode="thread_local"):
+        e_, _ = enc.forward_device(ids, mask)
+        emb_g.copy_(e_)
+        idx.search_device(emb_g.data_ptr(), B, k, Dg.data_ptr(), Ig.data_ptr(), stream=stream)
+    Dg.zero_()
+    Ig.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert np.array_equal(Ig.cpu().numpy(), Ih) and np.array_equal(Dg.cpu().numpy(), Dh)
+    import time
+    t0 = time.perf_counter()
+    for _ in range(10):
+        g.replay()
+    torch.cuda.synchronize()
+    t_graph = (time.perf_counter() - t0) / 10
+    t0 = time.perf_counter()
+    for _ in range(10):
+        e_, _ = enc.forward_device(ids, mask)
+        idx.search_device(e_.data_ptr(), B, k, Dg.data_ptr(), Ig.data_ptr(), stream=stream)
+    torch.cuda.synchronize()
+    t_eager = (time.perf_counter() - t0) / 10
+    print(f"config 5 (S = 32, 10M x 384): one graph {t_graph * 1e3:.3f} ms, two eager calls {t_eager * 1e3:.3f} ms")
     idx.close()
     enc.close()
