@@ -737,6 +737,179 @@ __device__ __forceinline__ void x3t_store_image(unsigned char* line, int fh, con
     }
 }
 
+// One K-step (32 k = two MFMA k-blocks) of a wave tile 32 TM x 32 TN on the stage at sb: fragments read from LDS as they
+// stand, three products per k-block — the small cross terms first, the leading product last; the WEIGHT fragment is the
+// first operand: acc[i][j] is the transposed tile (lane = token row, registers = output columns, see x3t_store_image).
+// The order is laid down by hand: the fragments a product group needs are requested while the group BEFORE it runs, so
+// the only LDS latency a wave sees is that of the first six reads behind the barrier.  (Left to hipcc the loop was
+// [reads, s_waitcnt lgkmcnt(0), 4 - 8 MFMAs] six times per K-step — per-workgroup timeline of the 256 x 256 form at
+// K = 384, benchmarks/x3_timeline.py: 25.9 us per K loop against 15.4 us of matrix-core time.)
+typedef float f32x4s __attribute__((ext_vector_type(4)));
+template <int SHAPE>
+__device__ __forceinline__ void x3_mfma(const x3_h8& a, const x3_h8& b, f32x16& c, int p) {
+    if (SHAPE == 0) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    } else {  // timing stand-in (DBG == 6): two 16x16x32 MFMAs on the same registers, results meaningless
+        const int o = 8 * (p & 1);
+        f32x4s c0 = {c[o], c[o + 1], c[o + 2], c[o + 3]}, c1 = {c[o + 4], c[o + 5], c[o + 6], c[o + 7]};
+        c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c1, 0, 0, 0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            c[o + e] = c0[e];
+            c[o + 4 + e] = c1[e];
+        }
+    }
+}
+
+struct X3NoDma {
+    __device__ __forceinline__ void operator()(int) const {}
+};
+
+// NP > 0: the wave's NP LDS-DMA instructions of the look-ahead stage are issued BETWEEN the MFMAs of the first k-block,
+// one every (3 TM TN) / NP MFMAs, instead of as a burst behind the barrier: a global_load_lds costs its wave 60 - 180
+// cycles of issue (address path), which is matrix-core time when both waves of a SIMD pay it at the same moment.
+template <int TM, int TN, int SHAPE = 0, int NP = 0, class Dma = X3NoDma>
+__device__ __forceinline__ void x3_kstep(const unsigned char* sb, const int (&a_off)[2][2], const int (&b_off)[2][2],
+                                         f32x16 (&acc)[TM][TN], Dma dma = Dma()) {
+    x3_h8 ah[2][TM], al[2][TM], bh[2][TN], bl[2][TN];
+    auto read_first = [&](int ks) {  // what the first product (wh . al) needs
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bh[ks][j] = *reinterpret_cast<const x3_h8*>(sb + b_off[ks][0] + j * 4096);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) al[ks][i] = *reinterpret_cast<const x3_h8*>(sb + a_off[ks][1] + i * 4096);
+    };
+    auto read_rest = [&](int ks) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bl[ks][j] = *reinterpret_cast<const x3_h8*>(sb + b_off[ks][1] + j * 4096);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) ah[ks][i] = *reinterpret_cast<const x3_h8*>(sb + a_off[ks][0] + i * 4096);
+    };
+    constexpr int SP = NP > 0 ? (3 * TM * TN / NP > 0 ? 3 * TM * TN / NP : 1) : 1;
+    auto after = [&](int ks, int m) {  // m: MFMAs of this k-block issued so far
+        if (NP > 0 && ks == 0 && m % SP == 0 && m / SP - 1 < NP) {
+            __builtin_amdgcn_sched_barrier(0);
+            dma(m / SP - 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    read_first(0);
+    read_rest(0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                x3_mfma<SHAPE>(bh[ks][j], al[ks][i], acc[i][j], 0);
+                after(ks, i * TN + j + 1);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                x3_mfma<SHAPE>(bl[ks][j], ah[ks][i], acc[i][j], 1);
+                after(ks, TM * TN + i * TN + j + 1);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+        if (ks == 0) read_first(1);  // under the leading product of k-block 0 ...
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                x3_mfma<SHAPE>(bh[ks][j], ah[ks][i], acc[i][j], 2);
+                after(ks, 2 * TM * TN + i * TN + j + 1);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+        if (ks == 0) read_rest(1);  // ... and under the first product of k-block 1 (at most 2 (TM + TN) fragments live)
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (NP > 0) {  // pieces the spacing did not reach (3 TM TN < NP)
+#pragma unroll
+        for (int p = 3 * TM * TN / SP; p < NP; ++p) dma(p);
+    }
+}
+
+// The K-step as hipcc schedules it (reads and MFMAs of a k-block in source order, the compiler's own waits): what the
+// one-tile-per-workgroup forms run — on their smaller wave tiles the hand-laid order below measured 2 - 3 % slower
+// (e5-small forward, 256 x 32 tokens: 2.04 -> 2.08 ms).
+template <int TM, int TN>
+__device__ __forceinline__ void x3_kstep_plain(const unsigned char* sb, const int (&a_off)[2][2], const int (&b_off)[2][2],
+                                               f32x16 (&acc)[TM][TN]) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        x3_h8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            bh[j] = *reinterpret_cast<const x3_h8*>(sb + b_off[ks][0] + j * 4096);
+            bl[j] = *reinterpret_cast<const x3_h8*>(sb + b_off[ks][1] + j * 4096);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            ah[i] = *reinterpret_cast<const x3_h8*>(sb + a_off[ks][0] + i * 4096);
+            al[i] = *reinterpret_cast<const x3_h8*>(sb + a_off[ks][1] + i * 4096);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], al[i], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[j], ah[i], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], ah[i], acc[i][j], 0, 0, 0);
+    }
+}
+
+// Epilogue of a wave tile 32 TM x 32 TN on the transposed accumulator tiles: lane = token row, register r = column
+// (r & 3) + 8 (r >> 2) + 4 fh of the tile.  Rows past T (last row band of a ragged batch) and column tiles past N
+// (N % 32 == 0: whole tiles) only predicate the stores: one exec mask per tile, no branch per element.
+template <int EPI, int TM, int TN>
+__device__ __forceinline__ void x3_epilogue(const f32x16 (&acc)[TM][TN], int row0, int col0, int fr, int fh, int T, int N,
+                                            float inv_wscale, const float* __restrict__ bias, const float* __restrict__ R,
+                                            float* __restrict__ C, int qcols, float qscale) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int row = row0 + i * 32 + fr;
+        const bool rok = row < T;
+        const int64_t rbase = (int64_t)(rok ? row : T - 1) * N;  // clamped: loads stay in bounds
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int cb = col0 + j * 32;  // first column of the tile
+            const bool ok = rok && cb < N;
+            const int cbc = cb < N ? cb : 0;
+            float v[16];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias + cbc + 8 * g + 4 * fh);
+                f32x4 r4 = {0.f, 0.f, 0.f, 0.f};
+                if (EPI == EPI_BIAS_RESIDUAL) r4 = *reinterpret_cast<const f32x4*>(R + rbase + cbc + 8 * g + 4 * fh);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float x = acc[i][j][4 * g + e] * inv_wscale + b4[e];  // exact: the weight scale is a power of two
+                    if (EPI == EPI_BIAS_GELU) x = 0.5f * x * (1.0f + x3_erf(x * 0.70710678118654752440f));
+                    if (EPI == EPI_BIAS_RESIDUAL) x += r4[e];
+                    if (EPI == EPI_BIAS_QKV) x = cb < qcols ? x * qscale : x;  // uniform per tile (qcols % 32 == 0)
+                    v[4 * g + e] = x;
+                }
+            }
+            if (EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_QKV) {
+                x3t_store_image(reinterpret_cast<unsigned char*>(C + rbase + cbc), fh, v, ok);
+            } else if (ok) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<f32x4*>(C + rbase + cbc + 8 * g + 4 * fh) = f32x4{v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};
+            }
+        }
+    }
+}
+
 // Block tile 64 x 128 x 32, four waves 2 x 2.  BOTH operands arrive as (hi | lo) fp16 lines — A from the kernel that
 // produced the activations (LayerNorm, attention, the GELU epilogue below: x3_pair_store), W from the one-time split of
 // the weights — and go global -> LDS by global_load_lds into a three-stage ring (two K-steps in flight, ONE bare
@@ -759,7 +932,37 @@ __host__ __device__ inline bool x3_big_form(int64_t T, int N, int bn, int cus) {
     return tiles >= cus && (tiles >= 4 * (int64_t)cus || tiles * 100 >= rounds * cus * 85);
 }
 
-template <int EPI, int BM, int NST, int WAVES = 4, int BN = 128, int DBG = 0>
+#ifdef MVDB_X3_ABLATE
+// DBG == 5 (ablation build only): the real kernel plus a per-tile timeline — 16 words per tile:
+// [tile id, HW_ID, XCC_ID, t start, t first stage landed, t K loop done, t stores issued, t stores acknowledged,
+//  shader clock at "first stage landed", shader clock at "K loop done", ...], t = s_memrealtime (100 MHz, one clock for the
+// whole chip), shader clock = s_memtime: (difference of the two) / (difference of t) x 100 MHz is the clock the chip held
+// over the K loop.  Read back with mvdb_debug_x3_trace.  DBG == 6: the same with every v_mfma_f32_32x32x16_f16 of the K
+// loop replaced by two v_mfma_f32_16x16x32_f16 on the same registers (same FLOPs, same LDS bytes, WRONG results): what the
+// other MFMA shape would do to the K loop's time and clock, before anyone rewrites the epilogues for it.
+constexpr int kX3TraceBlocks = 16384;
+constexpr int kX3TraceWords = 16;
+__device__ unsigned long long g_x3_trace[kX3TraceWords * kX3TraceBlocks];
+__device__ __forceinline__ void x3_trace(int slot, bool first = false, int rec = -1) {
+    if ((threadIdx.x & 63) != 0 || threadIdx.x >= 64) return;
+    const unsigned b = rec >= 0 ? (unsigned)rec : blockIdx.y * gridDim.x + blockIdx.x;
+    if (b >= (unsigned)kX3TraceBlocks) return;
+    if (first) {
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        g_x3_trace[kX3TraceWords * b + 0] = b;
+        g_x3_trace[kX3TraceWords * b + 1] = hw;
+        g_x3_trace[kX3TraceWords * b + 2] = xcc;
+    }
+    g_x3_trace[kX3TraceWords * b + slot] = wall_clock64();
+    if (slot == 4 || slot == 5) g_x3_trace[kX3TraceWords * b + slot + 4] = __builtin_readcyclecounter();
+}
+#else
+__device__ __forceinline__ void x3_trace(int, bool = false, int = -1) {}
+#endif
+
+template <int EPI, int BM, int NST, int WAVES = 4, int BN = 128, int SPREAD = 0, int DBG = 0>
 __global__ __launch_bounds__(WAVES * 64) void gemm_x3_dma_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ Wp,
                                                           float inv_wscale, const float* __restrict__ bias,
                                                           const float* __restrict__ R, float* __restrict__ C,
@@ -785,6 +988,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_x3_dma_kernel(const _Float16*
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int fr = lane & 31, fh = lane >> 5;
+    if (DBG == 5) x3_trace(3, true);
 
     // DMA roles: instruction q of a stage; wave w issues q = w NI .. w NI + NI - 1 (the kind of q is wave-uniform)
     int64_t voff[NI];  // T K 4 bytes pass 4 GiB at 512 x 512 tokens of a 4096-wide FFN
@@ -814,31 +1018,26 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_x3_dma_kernel(const _Float16*
             dsto[i] = kA + qq * 1024;
         }
     }
-    auto issue = [&](int kt, int stage) {
+    auto issue_piece = [&](int kt, int stage, int i) {
         if (DBG == 2) return;
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const char* src = sbase[i] + (int64_t)kt * kstep[i];
-            __builtin_amdgcn_global_load_lds((enc_gbl_ptr)(src + voff[i]), (enc_lds_ptr)(xsm + stage * kStage + dsto[i]), 16, 0, 0);
-        }
+        const char* src = sbase[i] + (int64_t)kt * kstep[i];
+        __builtin_amdgcn_global_load_lds((enc_gbl_ptr)(src + voff[i]), (enc_lds_ptr)(xsm + stage * kStage + dsto[i]), 16, 0, 0);
     };
-    // fragment byte offsets inside a stage
-    int a_off[TM][2][2], b_off[TN][2][2];
+    auto issue = [&](int kt, int stage) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) issue_piece(kt, stage, i);
+    };
+    // fragment byte offsets inside a stage, tile (0, 0) of the wave: row tile i / column tile j add 4096 i / 4096 j, folded into
+    // the ds_read's immediate (the swizzle term depends on the row's low bits only)
+    int a_off[2][2], b_off[2][2];
     const int ga = (fr >> 1) & 7;
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int pl = 0; pl < 2; ++pl)
-                a_off[i][ks][pl] = (wm * (BM / WM) + i * 32 + fr) * 128 + (((4 * pl + 2 * ks + fh) ^ ga) << 4);
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int pl = 0; pl < 2; ++pl)
-                b_off[j][ks][pl] = kA + (wn * (BN / 2) + j * 32 + fr) * 128 + (((4 * pl + 2 * ks + fh) ^ ga) << 4);
+        for (int pl = 0; pl < 2; ++pl) {
+            a_off[ks][pl] = (wm * (BM / WM) + fr) * 128 + (((4 * pl + 2 * ks + fh) ^ ga) << 4);
+            b_off[ks][pl] = kA + (wn * (BN / 2) + fr) * 128 + (((4 * pl + 2 * ks + fh) ^ ga) << 4);
+        }
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -861,10 +1060,9 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_x3_dma_kernel(const _Float16*
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * NI) : "memory");  // this wave's part of stage kt has landed
         __builtin_amdgcn_s_barrier();  // every wave's part has; and every wave is done reading stage kt - 1
         __builtin_amdgcn_sched_barrier(0);
-        {
-            const int ahead = kt + NST - 1;
-            issue(ahead < nk ? ahead : nk - 1, st == 0 ? NST - 1 : st - 1);  // into the buffer of stage kt - 1
-        }
+        if (DBG == 5 && kt == 0) x3_trace(4);
+        const int ahead = kt + NST - 1, akt = ahead < nk ? ahead : nk - 1, abuf = st == 0 ? NST - 1 : st - 1;  // into the buffer of stage kt - 1
+        if (!SPREAD || DBG == 1) issue(akt, abuf);
         __builtin_amdgcn_sched_barrier(0);
         const unsigned char* sb = xsm + st * kStage;
         if (DBG == 1) {
@@ -872,78 +1070,170 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_x3_dma_kernel(const _Float16*
             st = st == NST - 1 ? 0 : st + 1;
             continue;
         }
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            x3_h8 ah[TM], al[TM], bh[TN], bl[TN];
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                bh[j] = *reinterpret_cast<const x3_h8*>(sb + b_off[j][ks][0]);
-                bl[j] = *reinterpret_cast<const x3_h8*>(sb + b_off[j][ks][1]);
-            }
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                ah[i] = *reinterpret_cast<const x3_h8*>(sb + a_off[i][ks][0]);
-                al[i] = *reinterpret_cast<const x3_h8*>(sb + a_off[i][ks][1]);
-            }
-            // small cross terms first, the leading product last; the WEIGHT fragment is the first operand: acc[i][j] is the
-            // transposed tile (lane = token row, registers = output columns, see x3t_store_image)
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], al[i], acc[i][j], 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[j], ah[i], acc[i][j], 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], ah[i], acc[i][j], 0, 0, 0);
-        }
+        if (SPREAD)
+            x3_kstep<TM, TN, 0, NI>(sb, a_off, b_off, acc, [&](int i) { issue_piece(akt, abuf, i); });
+        else
+            x3_kstep_plain<TM, TN>(sb, a_off, b_off, acc);
         st = st == NST - 1 ? 0 : st + 1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the clamped look-ahead DMAs must land before the LDS is released
-    if (DBG == 3) {  // ablation: K loop only (the accumulators stay live through this never-taken store)
-        if (acc[0][0][0] == 1.2345e-30f) C[0] = 0.f;
+    if (DBG == 3) {  // ablation: K loop only.  EVERY accumulator stays live through this never-taken store (with one
+        float live = 0.f;  // of them hipcc drops the MFMAs of all the other tiles and the "K loop" costs 1 / (TM TN))
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) live += acc[i][j][r];
+        if (live == 1.2345e-30f) C[0] = 0.f;
         return;
     }
-    // epilogue on the transposed tiles: lane = token row, register r = column (r & 3) + 8 (r >> 2) + 4 fh of the tile.
-    // Rows past T (last row band of a ragged batch) and column tiles past N (N % 32 == 0: whole tiles) only predicate the
-    // stores: one exec mask per tile, no branch per element.
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int row = m0 + wm * (BM / WM) + i * 32 + fr;
-        const bool rok = row < T;
-        const int64_t rbase = (int64_t)(rok ? row : T - 1) * N;  // clamped: loads stay in bounds
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int cb = n0 + wn * (BN / 2) + j * 32;  // first column of the tile
-            const bool ok = rok && cb < N;
-            const int cbc = cb < N ? cb : 0;
-            float v[16];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias + cbc + 8 * g + 4 * fh);
-                f32x4 r4 = {0.f, 0.f, 0.f, 0.f};
-                if (EPI == EPI_BIAS_RESIDUAL) r4 = *reinterpret_cast<const f32x4*>(R + rbase + cbc + 8 * g + 4 * fh);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float x = acc[i][j][4 * g + e] * inv_wscale + b4[e];  // exact: the weight scale is a power of two
-                    if (EPI == EPI_BIAS_GELU) x = 0.5f * x * (1.0f + x3_erf(x * 0.70710678118654752440f));
-                    if (EPI == EPI_BIAS_RESIDUAL) x += r4[e];
-                    if (EPI == EPI_BIAS_QKV) x = cb < qcols ? x * qscale : x;  // uniform per tile (qcols % 32 == 0)
-                    v[4 * g + e] = x;
-                }
-            }
-            if (EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_QKV) {
-                x3t_store_image(reinterpret_cast<unsigned char*>(C + rbase + cbc), fh, v, ok);
-            } else if (ok) {
-#pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    *reinterpret_cast<f32x4*>(C + rbase + cbc + 8 * g + 4 * fh) = f32x4{v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};
-            }
-        }
+    if (DBG == 5) x3_trace(5);
+    x3_epilogue<EPI, TM, TN>(acc, m0 + wm * (BM / WM), n0 + wn * (BN / 2), fr, fh, T, N, inv_wscale, bias, R, C, qcols, qscale);
+    if (DBG == 5) {
+        __builtin_amdgcn_sched_barrier(0);
+        x3_trace(6);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        x3_trace(7);
     }
+}
+
+// =================================================================================================
+// The 256-row tile forms as ONE PERSISTENT workgroup per CU (eight waves 4 x 2, wave tile 64 x 32 TN, BN = 64 TN, two
+// stages): workgroup w walks the tiles w, w + G, w + 2 G, ... of the XCD-aware tile list (xcd_tile's order, on the
+// packed token count), and the K-step pipeline runs THROUGH the tile boundary — the look-ahead DMA of a tile's last
+// K-step fetches the next tile's first stage, which lands under the epilogue.  Per-workgroup timeline of the
+// one-tile-per-workgroup form at T = 131072, FFN1 (benchmarks/x3_timeline.py, 3072 workgroups, 12 per CU):
+// 2.4 us launch -> first stage landed, 26.5 us K loop (88 % matrix-core issue at the ~1.6 GHz the chip holds there),
+// 9.9 us epilogue, 0.3 us store drain, and 4.6 us between a workgroup's end and the start of the next one on its CU:
+// 7 us of every 43.7 were neither K loop nor epilogue.
+// =================================================================================================
+template <int EPI, int BN, int SPREAD = 1, int DBG = 0>
+__global__ __launch_bounds__(512) void gemm_x3_big_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ Wp,
+                                                          float inv_wscale, const float* __restrict__ bias,
+                                                          const float* __restrict__ R, float* __restrict__ C,
+                                                          const int* __restrict__ Tptr, int N, int K, int sel_bn, int sel_cus,
+                                                          int qcols, float qscale) {
+    if (sel_bn != 0 && x3_big_form(*Tptr, N, sel_bn > 0 ? sel_bn : -sel_bn, sel_cus) != (sel_bn > 0)) return;
+    constexpr int BM = 256, WAVES = 8, WM = 4, TM = 2, TN = BN / 64;
+    constexpr int kA = BM * 128, kStage = kA + BN * 128;
+    constexpr int NA = BM / 8, NI = (NA + BN / 8) / WAVES;
+    static_assert((NA + BN / 8) % WAVES == 0, "whole DMA instructions per wave");
+    extern __shared__ __attribute__((aligned(16))) unsigned char xsm[];
+    const int T = *Tptr;
+    const unsigned gx = (unsigned)(N / BN);
+    const unsigned active = gx * (unsigned)((T + BM - 1) / BM), chunk = active >> 3;
+    unsigned v = blockIdx.x;
+    if (v >= active) return;
+    auto tile_of = [&](unsigned vl, int& m0, int& n0) {
+        unsigned lin = vl;
+        if (lin < (chunk << 3)) lin = (lin & 7u) * chunk + (lin >> 3);
+        m0 = (int)(lin / gx) * BM;
+        n0 = (int)(lin % gx) * BN;
+    };
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int fr = lane & 31, fh = lane >> 5;
+    // DMA roles (gemm_x3_dma_kernel's): instruction q = wave NI + i of a stage moves 8 rows of A (q < NA) or of W.  Source =
+    // a wave-uniform base of (tile, K-step) + a 32-bit lane offset inside the tile (the tile's rows are < 2 MiB apart).
+    uint32_t lrow[NI], lslot[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int q = wave * NI + i;
+        const int row = 8 * (q < NA ? q : q - NA) + (lane >> 3);
+        lrow[i] = (uint32_t)row;
+        lslot[i] = (uint32_t)(16 * ((lane & 7) ^ ((row >> 1) & 7)));
+    }
+    auto issue_piece = [&](int m0, int n0, int kt, int stage, int i) {
+        const int q = wave * NI + i;
+        const char* base = q < NA ? reinterpret_cast<const char*>(A) + ((int64_t)m0 * K * 4 + (int64_t)kt * 128)
+                                  : reinterpret_cast<const char*>(Wp) + ((int64_t)n0 * K * 4 + (int64_t)kt * 128);
+        const uint32_t rlim = (uint32_t)(T - 1 - m0);  // rows past the edge: clamped (masked in the epilogue); N % BN == 0
+        const uint32_t r = q < NA ? (lrow[i] < rlim ? lrow[i] : rlim) : lrow[i];
+        const uint32_t off = r * (uint32_t)(K * 4) + lslot[i];
+        __builtin_amdgcn_global_load_lds((enc_gbl_ptr)(base + off),
+                                         (enc_lds_ptr)(xsm + stage * kStage + (q < NA ? q * 1024 : kA + (q - NA) * 1024)), 16, 0, 0);
+    };
+    auto issue = [&](int m0, int n0, int kt, int stage) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) issue_piece(m0, n0, kt, stage, i);
+    };
+    // fragment byte offsets inside a stage, tile (0, 0) of the wave: row tile i / column tile j add 4096 i / 4096 j, folded into
+    // the ds_read's immediate (the swizzle term depends on the row's low bits only)
+    int a_off[2][2], b_off[2][2];
+    const int ga = (fr >> 1) & 7;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+            a_off[ks][pl] = (wm * (BM / WM) + fr) * 128 + (((4 * pl + 2 * ks + fh) ^ ga) << 4);
+            b_off[ks][pl] = kA + (wn * (BN / 2) + fr) * 128 + (((4 * pl + 2 * ks + fh) ^ ga) << 4);
+        }
+
+    const int nk = DBG == 4 ? 0 : K / 32;
+    int m0, n0;
+    tile_of(v, m0, n0);
+    if (nk > 0) issue(m0, n0, 0, 0);
+    int st = 0;
+    for (;;) {
+        if (DBG == 5 || DBG == 6) x3_trace(3, true, (int)v);
+        f32x16 acc[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        const unsigned vn = v + gridDim.x;
+        int m1 = m0, n1 = n0;
+        if (vn < active) tile_of(vn, m1, n1);
+        for (int kt = 0; kt < nk; ++kt) {
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's part of stage kt has landed (and, at kt = 0, its stores of the tile before are acknowledged)
+            __builtin_amdgcn_s_barrier();                       // every wave's part has; and every wave is done reading the other buffer
+            __builtin_amdgcn_sched_barrier(0);
+            if ((DBG == 5 || DBG == 6) && kt == 0) x3_trace(4, false, (int)v);
+            // look-ahead: K-step kt + 1 of this tile, or the next tile's first stage (lands under this tile's epilogue);
+            // issued piece by piece between the MFMAs (x3_kstep)
+            // (the last tile's last K-step re-fetches its own first stage into the buffer nobody reads: no branch per piece)
+            const bool more = kt + 1 < nk;
+            const int lm = more ? m0 : m1, ln = more ? n0 : n1, lk = more ? kt + 1 : 0;
+            auto dma = [&](int i) { issue_piece(lm, ln, lk, st ^ 1, i); };
+            if (SPREAD)
+                x3_kstep<TM, TN, DBG == 6 ? 1 : 0, NI>(xsm + st * kStage, a_off, b_off, acc, dma);
+            else {
+#pragma unroll
+                for (int i = 0; i < NI; ++i) dma(i);
+                __builtin_amdgcn_sched_barrier(0);
+                x3_kstep<TM, TN, DBG == 6 ? 1 : 0>(xsm + st * kStage, a_off, b_off, acc);
+            }
+            st ^= 1;
+        }
+        if (DBG == 5 || DBG == 6) x3_trace(5, false, (int)v);
+        if (DBG == 3) {
+            float live = 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) live += acc[i][j][r];
+            if (live == 1.2345e-30f) C[0] = 0.f;
+        } else {
+            x3_epilogue<EPI, TM, TN>(acc, m0 + wm * (BM / WM), n0 + wn * (BN / 2), fr, fh, T, N, inv_wscale, bias, R, C, qcols, qscale);
+        }
+        if (DBG == 5 || DBG == 6) {
+            __builtin_amdgcn_sched_barrier(0);
+            x3_trace(6, false, (int)v);
+            x3_trace(7, false, (int)v);
+        }
+        if (vn >= active) break;
+        v = vn;
+        m0 = m1;
+        n0 = n1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 // =================================================================================================
@@ -962,7 +1252,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_x3_dma_kernel(const _Float16*
 // is all H rows of the weight: BM = 32 keeps a T = 8192 batch on every CU (256 workgroups, ring of three stages =
 // 156 KiB); BM = 64 / 128 (eight waves) serve longer batches with less W traffic per row.
 // =================================================================================================
-template <int BM, int WM, int TN, int NST, int DBG = 0>
+template <int BM, int WM, int TN, int NST, int SPREAD = 0, int DBG = 0>
 __global__ __launch_bounds__(WM * 256) void gemm_x3_ln_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ Wp,
                                                              float inv_wscale, const float* __restrict__ bias,
                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -1005,29 +1295,26 @@ __global__ __launch_bounds__(WM * 256) void gemm_x3_ln_kernel(const _Float16* __
             dsto[i] = kA + qq * 1024;
         }
     }
-    auto issue = [&](int kt, int stage) {
+    auto issue_piece = [&](int kt, int stage, int i) {
         if (DBG == 2) return;  // ablations as in gemm_x3_dma_kernel (results invalid)
-#pragma unroll
-        for (int i = 0; i < NI; ++i)
-            __builtin_amdgcn_global_load_lds((enc_gbl_ptr)(sbase[i] + (int64_t)kt * 128 + voff[i]),
-                                             (enc_lds_ptr)(xsm + stage * kStage + dsto[i]), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((enc_gbl_ptr)(sbase[i] + (int64_t)kt * 128 + voff[i]),
+                                         (enc_lds_ptr)(xsm + stage * kStage + dsto[i]), 16, 0, 0);
     };
-    int a_off[TM][2][2], b_off[TN][2][2];
+    auto issue = [&](int kt, int stage) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) issue_piece(kt, stage, i);
+    };
+    // fragment byte offsets inside a stage, tile (0, 0) of the wave: row tile i / column tile j add 4096 i / 4096 j, folded into
+    // the ds_read's immediate (the swizzle term depends on the row's low bits only)
+    int a_off[2][2], b_off[2][2];
     const int ga = (fr >> 1) & 7;
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int pl = 0; pl < 2; ++pl)
-                a_off[i][ks][pl] = (wm * (TM * 32) + i * 32 + fr) * 128 + (((4 * pl + 2 * ks + fh) ^ ga) << 4);
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int pl = 0; pl < 2; ++pl)
-                b_off[j][ks][pl] = kA + (wn * (TN * 32) + j * 32 + fr) * 128 + (((4 * pl + 2 * ks + fh) ^ ga) << 4);
+        for (int pl = 0; pl < 2; ++pl) {
+            a_off[ks][pl] = (wm * (TM * 32) + fr) * 128 + (((4 * pl + 2 * ks + fh) ^ ga) << 4);
+            b_off[ks][pl] = kA + (wn * (TN * 32) + fr) * 128 + (((4 * pl + 2 * ks + fh) ^ ga) << 4);
+        }
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -1048,10 +1335,8 @@ __global__ __launch_bounds__(WM * 256) void gemm_x3_ln_kernel(const _Float16* __
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * NI) : "memory");  // this wave's part of stage kt has landed
         __builtin_amdgcn_s_barrier();  // every wave's part has; and every wave is done reading stage kt - 1
         __builtin_amdgcn_sched_barrier(0);
-        {
-            const int ahead = kt + NST - 1;
-            issue(ahead < nk ? ahead : nk - 1, st == 0 ? NST - 1 : st - 1);  // into the buffer of stage kt - 1
-        }
+        const int ahead = kt + NST - 1, akt = ahead < nk ? ahead : nk - 1, abuf = st == 0 ? NST - 1 : st - 1;  // into the buffer of stage kt - 1
+        if (!SPREAD || DBG == 1) issue(akt, abuf);
         __builtin_amdgcn_sched_barrier(0);
         const unsigned char* sb = xsm + st * kStage;
         if (DBG == 1) {
@@ -1059,32 +1344,10 @@ __global__ __launch_bounds__(WM * 256) void gemm_x3_ln_kernel(const _Float16* __
             st = st == NST - 1 ? 0 : st + 1;
             continue;
         }
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            x3_h8 ah[TM], al[TM], bh[TN], bl[TN];
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                bh[j] = *reinterpret_cast<const x3_h8*>(sb + b_off[j][ks][0]);
-                bl[j] = *reinterpret_cast<const x3_h8*>(sb + b_off[j][ks][1]);
-            }
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                ah[i] = *reinterpret_cast<const x3_h8*>(sb + a_off[i][ks][0]);
-                al[i] = *reinterpret_cast<const x3_h8*>(sb + a_off[i][ks][1]);
-            }
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], al[i], acc[i][j], 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[j], ah[i], acc[i][j], 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], ah[i], acc[i][j], 0, 0, 0);
-        }
+        if (SPREAD)
+            x3_kstep<TM, TN, 0, NI>(sb, a_off, b_off, acc, [&](int i) { issue_piece(akt, abuf, i); });
+        else
+            x3_kstep_plain<TM, TN>(sb, a_off, b_off, acc);
         st = st == NST - 1 ? 0 : st + 1;
     }
     // ---- epilogue: v = acc / wscale + bias + residual, LayerNorm over the row, in place ------------------------------
@@ -1092,7 +1355,14 @@ __global__ __launch_bounds__(WM * 256) void gemm_x3_ln_kernel(const _Float16* __
     // registers, one exchange with the other lane half (its columns in between) and the four column waves through LDS
     if (DBG == 3) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (acc[0][0][0] == 1.2345e-30f) X[0] = 0.f;
+        float live = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) live += acc[i][j][r];
+        if (live == 1.2345e-30f) X[0] = 0.f;
         return;
     }
     int64_t rbase[TM];
@@ -2063,12 +2333,17 @@ int x3_set_lds(const void* kern, int lds, int device) {
 #ifdef MVDB_X3_ABLATE
 #define X3_KERN(...)                                                                                                  \
     (dbg == 1 ? gemm_x3_dma_kernel<__VA_ARGS__, 1> : dbg == 2 ? gemm_x3_dma_kernel<__VA_ARGS__, 2> :                 \
-     dbg == 3 ? gemm_x3_dma_kernel<__VA_ARGS__, 3> : dbg == 4 ? gemm_x3_dma_kernel<__VA_ARGS__, 4> : gemm_x3_dma_kernel<__VA_ARGS__, 0>)
+     dbg == 3 ? gemm_x3_dma_kernel<__VA_ARGS__, 3> : dbg == 4 ? gemm_x3_dma_kernel<__VA_ARGS__, 4> :                 \
+     dbg == 5 ? gemm_x3_dma_kernel<__VA_ARGS__, 5> : gemm_x3_dma_kernel<__VA_ARGS__, 0>)
+#define X3_BIG_KERN(...)                                                                                              \
+    (dbg == 3 ? gemm_x3_big_kernel<__VA_ARGS__, 3> : dbg == 4 ? gemm_x3_big_kernel<__VA_ARGS__, 4> :                 \
+     dbg == 5 ? gemm_x3_big_kernel<__VA_ARGS__, 5> : dbg == 6 ? gemm_x3_big_kernel<__VA_ARGS__, 6> : gemm_x3_big_kernel<__VA_ARGS__, 0>)
 #define X3_LN_KERN(...)                                                                                               \
     (dbg == 1 ? gemm_x3_ln_kernel<__VA_ARGS__, 1> : dbg == 2 ? gemm_x3_ln_kernel<__VA_ARGS__, 2> :                   \
      dbg == 3 ? gemm_x3_ln_kernel<__VA_ARGS__, 3> : dbg == 4 ? gemm_x3_ln_kernel<__VA_ARGS__, 4> : gemm_x3_ln_kernel<__VA_ARGS__, 0>)
 #else
 #define X3_KERN(...) gemm_x3_dma_kernel<__VA_ARGS__, 0>
+#define X3_BIG_KERN(...) gemm_x3_big_kernel<__VA_ARGS__, 0>
 #define X3_LN_KERN(...) gemm_x3_ln_kernel<__VA_ARGS__, 0>
 #endif
 
@@ -2078,7 +2353,8 @@ int launch_gemm_x3(const float* Aimg, const _Float16* Wp, float inv_wscale, cons
     const _Float16* A = reinterpret_cast<const _Float16*>(Aimg);  // [T][K / 32][hi 32 | lo 32]: the bytes of a [T][K] fp32 matrix
     static const int dbg = []() { const char* v = getenv("MVDB_GEMM_X3_DBG"); return v ? atoi(v) : 0; }();
     (void)dbg;
-    auto kern = X3_KERN(EPI, 64, 3, 4, 128);
+    static const bool spread_small = []() { const char* v = getenv("MVDB_GEMM_X3_SPREAD_SMALL"); return !(v && *v == '0'); }();
+    auto kern = spread_small ? X3_KERN(EPI, 64, 3, 4, 128, 1) : X3_KERN(EPI, 64, 3, 4, 128, 0);
     constexpr int lds = 3 * (64 * 128 + 128 * 128);
     MVDB_TRY(x3_set_lds((const void*)kern, lds, device));
     dim3 grid((N + 127) / 128, (unsigned)((Tmax + 63) / 64));
@@ -2113,13 +2389,29 @@ int launch_gemm_x3(const float* Aimg, const _Float16* Wp, float inv_wscale, cons
     if (!w8 && big4env < 0 && bign != 0 && (big8env == 1 || big_pair)) {
         const dim3 gridb(N / bign, (unsigned)((Tmax + 255) / 256));
         const int sel_big = big8env == 1 ? 0 : bign;
-        if (bign == 256) {
-            auto kernb = X3_KERN(EPI, 256, 2, 8, 256);
+        // one persistent workgroup per CU walking the tile list (gemm_x3_big_kernel); MVDB_GEMM_X3_PERSIST=0: one workgroup per tile
+        static const bool persist = []() { const char* v = getenv("MVDB_GEMM_X3_PERSIST"); return !(v && *v == '0'); }();
+        if (persist) {
+            const unsigned gp = (unsigned)std::min<int64_t>((int64_t)gridb.x * gridb.y, cus);
+            static const bool spread = []() { const char* v = getenv("MVDB_GEMM_X3_SPREAD"); return !(v && *v == '0'); }();
+            if (bign == 256) {
+                auto kernp = spread ? X3_BIG_KERN(EPI, 256, 1) : X3_BIG_KERN(EPI, 256, 0);
+                constexpr int ldsp = 2 * (256 * 128 + 256 * 128);
+                MVDB_TRY(x3_set_lds((const void*)kernp, ldsp, device));
+                hipLaunchKernelGGL(kernp, dim3(gp), dim3(512), ldsp, s, A, Wp, inv_wscale, bias, R, C, Tptr, N, K, sel_big, cus, qcols, qscale);
+            } else {
+                auto kernp = spread ? X3_BIG_KERN(EPI, 192, 1) : X3_BIG_KERN(EPI, 192, 0);
+                constexpr int ldsp = 2 * (256 * 128 + 192 * 128);
+                MVDB_TRY(x3_set_lds((const void*)kernp, ldsp, device));
+                hipLaunchKernelGGL(kernp, dim3(gp), dim3(512), ldsp, s, A, Wp, inv_wscale, bias, R, C, Tptr, N, K, sel_big, cus, qcols, qscale);
+            }
+        } else if (bign == 256) {
+            auto kernb = X3_KERN(EPI, 256, 2, 8, 256, 0);
             constexpr int ldsb = 2 * (256 * 128 + 256 * 128);
             MVDB_TRY(x3_set_lds((const void*)kernb, ldsb, device));
             hipLaunchKernelGGL(kernb, gridb, dim3(512), ldsb, s, A, Wp, inv_wscale, bias, R, C, Tptr, N, K, sel_big, cus, qcols, qscale);
         } else {
-            auto kernc = X3_KERN(EPI, 256, 2, 8, 192);
+            auto kernc = X3_KERN(EPI, 256, 2, 8, 192, 0);
             constexpr int ldsc = 2 * (256 * 128 + 192 * 128);
             MVDB_TRY(x3_set_lds((const void*)kernc, ldsc, device));
             hipLaunchKernelGGL(kernc, gridb, dim3(512), ldsc, s, A, Wp, inv_wscale, bias, R, C, Tptr, N, K, sel_big, cus, qcols, qscale);
@@ -2131,7 +2423,7 @@ int launch_gemm_x3(const float* Aimg, const _Float16* Wp, float inv_wscale, cons
     // workgroup's stores run under the other's K loop — S = 512 forward 26.7 ms vs 25.9 with the 256-row forms, S = 32 2.01
     // vs 1.96: the epilogue is not what the 256-row forms wait for.)
     if (!w8 && (big4env >= 0 ? big4env == 1 : many)) {
-        auto kern4 = X3_KERN(EPI, 128, 2, 4, 128);
+        auto kern4 = spread_small ? X3_KERN(EPI, 128, 2, 4, 128, 1) : X3_KERN(EPI, 128, 2, 4, 128, 0);
         constexpr int lds4 = 2 * (128 * 128 + 128 * 128);
         MVDB_TRY(x3_set_lds((const void*)kern4, lds4, device));
         dim3 grid4((N + 127) / 128, (unsigned)((Tmax + 127) / 128));
@@ -2139,7 +2431,7 @@ int launch_gemm_x3(const float* Aimg, const _Float16* Wp, float inv_wscale, cons
         return 0;
     }
     if (w8) {
-        auto kern8 = X3_KERN(EPI, 128, 3, 8, 128);
+        auto kern8 = X3_KERN(EPI, 128, 3, 8, 128, 0);
         constexpr int lds8 = 3 * (128 * 128 + 128 * 128);
         MVDB_TRY(x3_set_lds((const void*)kern8, lds8, device));
         dim3 grid8((N + 127) / 128, (unsigned)((Tmax + 127) / 128));
@@ -2162,7 +2454,8 @@ int launch_gemm_x3_ln_inst(const _Float16* A, const _Float16* Wp, float inv_wsca
     static_assert(2 * kStage <= 160 * 1024, "two stages must fit the CU's LDS");
     static const int dbg = []() { const char* v = getenv("MVDB_GEMM_X3_DBG"); return v ? atoi(v) : 0; }();
     (void)dbg;
-    auto kern = X3_LN_KERN(BM, WM, TN, NST);
+    static const bool spread = []() { const char* v = getenv("MVDB_GEMM_LN_SPREAD"); return !(v && *v == '0'); }();
+    auto kern = spread ? X3_LN_KERN(BM, WM, TN, NST, 1) : X3_LN_KERN(BM, WM, TN, NST, 0);
     constexpr int lds = NST * kStage;
     MVDB_TRY(x3_set_lds((const void*)kern, lds, device));
     hipLaunchKernelGGL(kern, dim3((unsigned)((Tmax + BM - 1) / BM)), dim3(WM * 256), lds, s, A, Wp, inv_wscale, bias, gamma, beta,
@@ -2509,6 +2802,20 @@ int forward_core(mvdb_encoder* e, const int32_t* ids, const int32_t* mask, int B
 }  // namespace
 
 extern "C" {
+
+#ifdef MVDB_X3_ABLATE
+// ablation build only: copies the DBG == 5 timeline of the last traced GEMM launch (16 words per tile) and clears it
+int mvdb_debug_x3_trace(unsigned long long* out, int nblocks) {
+    if (!out || nblocks <= 0 || nblocks > kX3TraceBlocks) return fail(MVDB_ERR_ARG, "bad trace request");
+    MVDB_HIP(hipDeviceSynchronize());
+    MVDB_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_x3_trace), (size_t)nblocks * kX3TraceWords * sizeof(unsigned long long)));
+    void* sym = nullptr;
+    MVDB_HIP(hipGetSymbolAddress(&sym, HIP_SYMBOL(g_x3_trace)));
+    MVDB_HIP(hipMemset(sym, 0, sizeof(unsigned long long) * kX3TraceWords * kX3TraceBlocks));
+    return 0;
+}
+#endif
+
 
 int mvdb_encoder_weight_count(const mvdb_encoder_cfg* cfg) {
     if (check_cfg(cfg)) return -1;
