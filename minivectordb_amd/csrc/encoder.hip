@@ -706,11 +706,14 @@ __device__ __forceinline__ void x3_split2(float a, float b, uint32_t& hi, uint32
 //     lane instead of 16, no DPP pairing;
 //   * a row's LayerNorm statistics are sums over the lane's OWN registers plus one exchange with the other half.
 // The stores of a big tile were issue-bound: 128 dword stores per lane on a 256 x 256 tile, as long as its K loop at K = 384.
-// What the epilogue is bound by NOW is the bytes it writes (ablation build, make ABLATE=1, MVDB_GEMM_X3_DBG=4 = no K loop):
-// at T = 131072 the QKV / FFN1 / N = H kernels write 604 / 805 / 403 (+ 201 read) MB in 109 / 175 / 130 us = 5.6 / 4.6 /
-// 4.6 TB/s, at T = 8192 37.7 / 50 / 25 MB in 12.4 / 14.9 / 10.7 us (launch ramp included) — a third of each GEMM, serial
-// with its K loop.  Tried on top and dropped (same time to 1 %): staging the outputs through LDS so that every store
-// instruction writes whole 128-byte lines instead of 32 bytes of 32 different rows.
+// Where a GEMM's time goes NOW (ablation build, make ABLATE=1: MVDB_GEMM_X3_DBG = 3 K loop only / 4 epilogue only; us per launch,
+// full / K loop only / epilogue only): T = 131072  QKV 373 / 274 / 116, FFN1 517 / 349 / 178, N = H + LayerNorm 379 / 233 / 132;
+// T = 8192  35.1 / 27.2 / 11.9, 39.6 / 32.2 / 13.1, 41.0 / 29.7 / 10.7 (launch ramp in both parts).  The per-tile timeline
+// (DBG = 5, benchmarks/x3_timeline.py) of FFN1 at T = 131072: K loop 25.6 us = 47.6k cycles at the 1.87 GHz the chip holds
+// there, against 36.9k cycles of MFMA issue; epilogue 10 us until the FIRST wave has issued its stores and ~4.6 more until
+// the last one has — GELU + the (hi, lo) split are ~25 VALU instructions per element, 128 elements per lane: the FFN1
+// epilogue is bound by VALU issue, not by its 805 MB of stores (staging the outputs through LDS so that every store
+// writes whole 128-byte lines changed nothing).
 __device__ __forceinline__ void x3t_store_image(unsigned char* line, int fh, const float (&v)[16], bool ok) {
     // line: the 128 bytes [hi 32 | lo 32] of (this lane's row, this tile's 32 columns).  Every lane must take part in the
     // swaps (EXEC all ones); only the stores are predicated.
@@ -1103,10 +1106,13 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_x3_dma_kernel(const _Float16*
 // stages): workgroup w walks the tiles w, w + G, w + 2 G, ... of the XCD-aware tile list (xcd_tile's order, on the
 // packed token count), and the K-step pipeline runs THROUGH the tile boundary — the look-ahead DMA of a tile's last
 // K-step fetches the next tile's first stage, which lands under the epilogue.  Per-workgroup timeline of the
-// one-tile-per-workgroup form at T = 131072, FFN1 (benchmarks/x3_timeline.py, 3072 workgroups, 12 per CU):
-// 2.4 us launch -> first stage landed, 26.5 us K loop (88 % matrix-core issue at the ~1.6 GHz the chip holds there),
-// 9.9 us epilogue, 0.3 us store drain, and 4.6 us between a workgroup's end and the start of the next one on its CU:
-// 7 us of every 43.7 were neither K loop nor epilogue.
+// one-tile-per-workgroup form at T = 131072, FFN1 (benchmarks/x3_timeline.py, 3072 workgroups, 12 per CU): 2.4 us launch ->
+// first stage landed, 26.5 us K loop (51.2k cycles at 1.94 GHz for 36.9k cycles of MFMA issue), 9.9 us until wave 0 has
+// issued its stores, and 4.6 us more until the next workgroup starts on the CU (the slowest wave's epilogue + the
+// relaunch).  Persistent: the 2.4 us are gone, the 4.6 become the wait for the slowest wave at the next tile's first
+// barrier; S = 512 forward 26.0 -> 25.7 ms.  With the DMA instructions spread between the MFMAs (x3_kstep): 47.6k cycles
+// per K loop, at 1.87 GHz — the chip gives part of every saved cycle back as clock (25.7 -> 25.4 ms).  A 16x16x32 stand-in
+// for the MFMAs (DBG = 6: same FLOPs, same LDS bytes) ran the K loop in 52.0k cycles at the same clock: not a lever here.
 // =================================================================================================
 template <int EPI, int BN, int SPREAD = 1, int DBG = 0>
 __global__ __launch_bounds__(512) void gemm_x3_big_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ Wp,
@@ -2419,6 +2425,8 @@ int launch_gemm_x3(const float* Aimg, const _Float16* Wp, float inv_wscale, cons
         if (big8env == 1) return 0;
         sel_bn = -bign;  // the fallback runs only where the packed token count rules the 256-row form out
     }
+    // (Tried in round 3 and dropped: the persistent eight-wave kernel on 128 x 192 / 128 x 256 tiles (wave tile 32 x 96 / 32 x 128) for
+    // batches too small for the 256-row forms — S = 32 forward 2.37 ms vs 2.04 with the 128 x 128 four-wave tiles below.)
     // (Tried in round 3 and dropped: 128 x 192 tiles on four waves, two 40-KiB stages, TWO workgroups per CU so that one
     // workgroup's stores run under the other's K loop — S = 512 forward 26.7 ms vs 25.9 with the 256-row forms, S = 32 2.01
     // vs 1.96: the epilogue is not what the 256-row forms wait for.)
