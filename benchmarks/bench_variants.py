@@ -72,6 +72,19 @@ def main():
             out["excluded_rowset_ms"] = round(timeit(lambda: idx.search_rowset(q[0], 10, rse), 20) * 1e3, 3)
             rse.close()
         print(json.dumps(out), flush=True)
+    # BATCHES under a filter (bitmap / resident bitmap row set): the certified fp16 pass and the fp32-MFMA pass take the bitmap
+    qb = flat.synth(256, d, 91)
+    flat.normalize_l2(qb)
+    for frac in (0.5, 0.99):
+        excl = np.sort(rs.choice(n, n - int(n * frac), replace=False)).astype(np.int64)
+        rse = idx.rowset(excl, excluded=True)
+        out = {"what": f"batches under a filter keeping {frac:g} of the rows (resident bitmap), k=10, host API"}
+        for nb in (8, 32, 128, 256):
+            dtb = timeit(lambda: idx.search_rowset(qb[:nb], 10, rse), 5)
+            out[f"nq{nb}_ms"] = round(dtb * 1e3, 3)
+            out[f"nq{nb}_qps"] = round(nb / dtb, 1)
+        rse.close()
+        print(json.dumps(out), flush=True)
     rows = rs.permutation(n)[:n // 10].astype(np.int64)
     dt = timeit(lambda: idx.search_subset(q[0], 10, rows), 10)
     print(json.dumps({"what": "subset search, 0.1 of the rows (random order), k=10", "rows": len(rows),

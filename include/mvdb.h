@@ -151,6 +151,9 @@ int mvdb_index_search_subset_device(const mvdb_index* idx, const float* q_dev, i
  * avoids, and its 8 bytes per row are the upload).  labels == 0: positions in the ascending list of the set rows — exactly
  * what mvdb_index_search_subset returns for that list; labels == 1: row numbers.  Exact score ties resolve to the lower
  * row number in both.  Fewer than k rows selected: the tail is -1 / -FLT_MAX (IP) as everywhere.
+ * nq > 1 (inner product, d % 128 == 0, k <= 64): the batch shares corpus passes like an unfiltered one — 33+ queries on the
+ * certified fp16 pass (the bit is consulted where a row is about to be nominated), fewer on the fp32-MFMA pass, which also
+ * re-runs uncertified queries under the bitmap; other shapes answer the bitmap one query at a time.
  * Replaces the same per-query sub-index as mvdb_index_search_subset
  *                                                minivectordb/vector_database.py:508-523 (exclude filters :354-386)
  *                                                minivectordb/sharded_vector_database.py:634-649 */

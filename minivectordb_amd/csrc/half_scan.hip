@@ -305,10 +305,11 @@ __global__ __launch_bounds__(256) void flat_scan_half_kernel(HalfScanArgs a) {
             const int myq = (r * NW + wave) * 32 + fr;
             if (myq < a.nq) {
                 uint64_t* out = a.cand + ((int64_t)myq * gridDim.x + blockIdx.x) * 32;
+                const uint32_t mw = a.mask ? a.mask[m0 >> 5] : 0xffffffffu;  // the tile's 32 rows = one word of the bitmap
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int rl = (e & 3) + 8 * (e >> 2) + 4 * fk;
-                    out[rl] = m0 + rl <= last ? make_key(sc[e], (uint32_t)(m0 + rl)) : 0ull;
+                    out[rl] = (m0 + rl <= last && ((mw >> rl) & 1u)) ? make_key(sc[e], (uint32_t)(m0 + rl)) : 0ull;
                 }
             }
         } else {
@@ -318,11 +319,12 @@ __global__ __launch_bounds__(256) void flat_scan_half_kernel(HalfScanArgs a) {
             if (__ballot(mx >= thr[r]) != 0ull) {
                 ++n_slow;
                 uint64_t* rl_lists = mylists + (size_t)r * 32 * kHalfKeep;
+                const uint32_t mw = a.mask ? a.mask[m0 >> 5] : 0xffffffffu;  // row selection: looked at on the slow path only
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int rl = (e & 3) + 8 * (e >> 2);
                     const float s = sc[e];
-                    uint64_t mask = __ballot(m0 + rl + 4 * fk <= last && s >= thr[r]);
+                    uint64_t mask = __ballot(m0 + rl + 4 * fk <= last && ((mw >> (rl + 4 * fk)) & 1u) && s >= thr[r]);
                     while (mask) {
                         const int srcl = __ffsll((long long)mask) - 1;
                         mask &= mask - 1;
@@ -633,11 +635,12 @@ __global__ __launch_bounds__(WV * 64) void flat_scan_hq_kernel(HalfScanArgs a) {
             if (__ballot(mx >= thr[g]) != 0ull) {
                 ++n_slow;
                 uint64_t* gl = mylists + (size_t)g * 32 * kHalfKeep;
+                const uint32_t mw = a.mask ? a.mask[m0 >> 5] : 0xffffffffu;  // row selection: looked at on the slow path only
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int rl = (e & 3) + 8 * (e >> 2);
                     const float s = sc[e];
-                    uint64_t mask = __ballot(m0 + rl + 4 * fk <= last && s >= thr[g]);
+                    uint64_t mask = __ballot(m0 + rl + 4 * fk <= last && ((mw >> (rl + 4 * fk)) & 1u) && s >= thr[g]);
                     while (mask) {
                         const int srcl = __ffsll((long long)mask) - 1;
                         mask &= mask - 1;

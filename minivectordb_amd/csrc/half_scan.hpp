@@ -22,6 +22,7 @@ struct HalfScanArgs {
     int64_t tile1;
     const float* thr0;    // [nq] admission floors, or NULL
     unsigned int* stats;  // NULL, or [2]: list inserts, wave-tiles that reached the slow path (diagnostics)
+    const uint32_t* mask = nullptr;  // NULL, or one bit per row (bit r & 31 of word r >> 5): only rows whose bit is set may be nominated
 };
 
 struct HalfCertifyArgs {

@@ -452,7 +452,7 @@ int launch_mfma_inst(const MfmaScanArgs& a, int device, hipStream_t stream, int*
 
 template <int KB, int NG, int SKB>
 int launch_mfma2_gated_inst(const MfmaScanArgs& a, int device, hipStream_t stream, int* nblocks_out, const int* gate, int gate_lo) {
-    auto kern = flat_scan_mfma2_gated_kernel<KB, NG, SKB>;
+    auto kern = a.mask ? flat_scan_mfma2_gated_kernel<KB, NG, SKB, true> : flat_scan_mfma2_gated_kernel<KB, NG, SKB, false>;
     const size_t lds = (size_t)kScanWaves * mfma2_wave_lds_bytes(SKB) + (size_t)kScanWaves * NG * 16 * a.k * 8;
     MVDB_TRY(ensure_dynamic_lds((const void*)kern, lds, device));
     int nb = 0;
@@ -818,7 +818,7 @@ bool half_path_ok(const mvdb_index* idx) {
 }
 
 int launch_half_pass(const mvdb_index* idx, Workspace* ws, const float* q, int nq, int nqpad, int k, int64_t n,
-                     int64_t label_offset, float* D, int64_t* I, int* flag, int* failed) {
+                     int64_t label_offset, float* D, int64_t* I, int* flag, int* failed, const uint32_t* mask = nullptr) {
     hipStream_t stream = ws->stream;
     _Float16* qf = reinterpret_cast<_Float16*>(ws->qsplit.p);
     float* qnorm = ws->qnorm.p;
@@ -834,6 +834,7 @@ int launch_half_pass(const mvdb_index* idx, Workspace* ws, const float* q, int n
     a.qinv = qinv;
     a.xscale = xscale;
     a.nq = nq;
+    a.mask = mask;
     a.stats = env_int("MVDB_SPLIT_STATS", 0) ? reinterpret_cast<unsigned int*>(ws->flags.p) + (ws->flags.cap - 32) : nullptr;
     if (a.stats) MVDB_HIP(hipMemsetAsync(a.stats, 0, 8, stream));
     const int64_t ntiles = (n + 31) / 32;
@@ -943,11 +944,17 @@ int search_core(const mvdb_index* idx, Workspace* ws, const float* q_dev, int nq
     // row list: its m entries; bitmap: the first m rows when the caller says how many rows the bitmap covers (a resident
     // row set built before later appends), else every row
     const int64_t n = rows_dev ? m : (mask_dev && m > 0 ? std::min<int64_t>(m, idx->n) : idx->n);
-    if (mask_dev) {  // bitmap-selected rows: the exact single-pass kernels only (as row lists)
-        allow_split = false;
+    // Bitmap-selected rows, several queries: the passes that take a bitmap are the fp16 nomination pass (33+ queries; the
+    // bit is looked at where a row is about to be nominated) and the staged fp32-MFMA pass (2..32 queries, and the exact
+    // re-runs of uncertified queries); everything else answers a bitmap one query at a time.
+    const uint32_t* mask32 = reinterpret_cast<const uint32_t*>(mask_dev);
+    const bool masked_batch = mask_dev && nq >= 2 && k <= kMaxFusedK && idx->metric == MVDB_METRIC_IP && idx->ld == idx->d &&
+                              mfma_gated_queries(idx) > 0 && !env_int("MVDB_DISABLE_MASKED_BATCH", 0);
+    if (mask_dev) {
         rows_dev = nullptr;
+        if (!masked_batch || !half_path_ok(idx) || nq < env_int("MVDB_SPLIT_SCAN_MIN_NQ", 33)) allow_split = false;
     }
-    // the multi-query passes take neither a row list nor a bitmap
+    // the other multi-query passes take neither a row list nor a bitmap
     const int64_t* restricted = mask_dev ? reinterpret_cast<const int64_t*>(mask_dev) : rows_dev;
     if (n == 0) {
         const int64_t total = (int64_t)nq * k;
@@ -990,11 +997,11 @@ int search_core(const mvdb_index* idx, Workspace* ws, const float* q_dev, int nq
         const int chunk = use_half ? half_max_queries(idx->d) : 128;
         std::vector<std::pair<int, int>> plan;  // (first query, count)
         int q0 = 0;
-        while (nq - q0 >= min_nq && (use_half || k <= kSplitMaxK)) {
+        while (nq - q0 >= min_nq && (use_half || (k <= kSplitMaxK && !mask_dev))) {
             plan.emplace_back(q0, std::min(nq - q0, chunk));
             q0 += plan.back().second;
         }
-        if (k <= kSplitMaxK && nq - q0 >= env_int("MVDB_SPLIT32_MIN_NQ", 14) && nq - q0 <= 32 && split32_ok(idx)) {
+        if (!mask_dev && k <= kSplitMaxK && nq - q0 >= env_int("MVDB_SPLIT32_MIN_NQ", 14) && nq - q0 <= 32 && split32_ok(idx)) {
             plan.emplace_back(q0, nq - q0);
             q0 = nq;
         }
@@ -1011,7 +1018,7 @@ int search_core(const mvdb_index* idx, Workspace* ws, const float* q_dev, int nq
                 const int c0 = plan[c].first, take = plan[c].second;
                 if (use_half && take >= min_nq)
                     MVDB_TRY(launch_half_pass(idx, ws, qsrc + (int64_t)c0 * idx->ld, take, half_chunk_queries(idx->d, take), k, n, label_offset,
-                                              D_dev + (int64_t)c0 * k, I_dev + (int64_t)c0 * k, ws->flags.p + c, ws->qfail.p + c0));
+                                              D_dev + (int64_t)c0 * k, I_dev + (int64_t)c0 * k, ws->flags.p + c, ws->qfail.p + c0, mask32));
                 else
                     MVDB_TRY(launch_split_scan(idx, ws, qsrc + (int64_t)c0 * idx->ld, take, k, n, label_offset,
                                                D_dev + (int64_t)c0 * k, I_dev + (int64_t)c0 * k, ws->flags.p + c, ws->qfail.p + c0));
@@ -1049,7 +1056,8 @@ int search_core(const mvdb_index* idx, Workspace* ws, const float* q_dev, int nq
             int off = 0;
             if (per_pass > 0 && !env_int("MVDB_DISABLE_MFMA_SCAN", 0)) {
                 MVDB_TRY(ws->cand.reserve((size_t)32 * scan_grid_upper_bound(idx->device) * k));
-                const int max_passes = k > kGemmScanMaxK ? (R + per_pass - 1) / per_pass : 2;  // the GEMM scan keeps k <= 16
+                // (the GEMM scan keeps k <= 16 and takes no bitmap: those re-runs are all fp32-MFMA passes)
+                const int max_passes = (k > kGemmScanMaxK || mask_dev) ? (R + per_pass - 1) / per_pass : 2;
                 for (int pass = 0; pass < max_passes && off < R; ++pass) {
                     const int take = std::min(per_pass, R - off);
                     MfmaScanArgs ma;
@@ -1060,6 +1068,7 @@ int search_core(const mvdb_index* idx, Workspace* ws, const float* q_dev, int nq
                     ma.nq = take;
                     ma.k = k;
                     ma.cand = ws->cand.p;
+                    ma.mask = mask32;
                     int nblocks = 0;
                     MVDB_TRY(launch_mfma2_gated(KB, ma, idx->device, s, &nblocks, ws->nfail.p, off));
                     MergeArgs mg;
@@ -1077,6 +1086,7 @@ int search_core(const mvdb_index* idx, Workspace* ws, const float* q_dev, int nq
                     off += take;
                 }
             }
+            if (off < R && mask_dev) return fail(MVDB_ERR_ARG, "internal: bitmap re-run left to the GEMM scan");
             if (off < R) MVDB_TRY(ws->cand.reserve((size_t)128 * scan_grid_upper_bound(idx->device) * k));
             while (off < R) {
                 const int take = std::min(128, R - off);
@@ -1102,7 +1112,47 @@ int search_core(const mvdb_index* idx, Workspace* ws, const float* q_dev, int nq
         }
         if (q0 == nq) return 0;
         return search_core(idx, ws, qsrc + (int64_t)q0 * idx->ld, nq - q0, k, 0, rows_dev, m, label_offset,
-                           D_dev + (int64_t)q0 * k, I_dev + (int64_t)q0 * k, false);
+                           D_dev + (int64_t)q0 * k, I_dev + (int64_t)q0 * k, false, mask_dev);
+    }
+
+    if (masked_batch) {
+        // ---- bitmap-selected rows, 2+ queries: staged fp32-MFMA passes of up to 32 (d <= 512) / 16 queries, exact ----------
+        const float* qsrc = q_dev;
+        if (normalize_q) {
+            MVDB_TRY(ws->qn.reserve((size_t)nq * idx->ld));
+            MVDB_HIP(hipMemcpyAsync(ws->qn.p, q_dev, (size_t)nq * idx->ld * sizeof(float), hipMemcpyDeviceToDevice, s));
+            MVDB_TRY(normalize_range(idx, ws->qn.p, nq, s));
+            qsrc = ws->qn.p;
+        }
+        const int per_pass = mfma_gated_queries(idx);
+        MVDB_TRY(ws->cand.reserve((size_t)32 * scan_grid_upper_bound(idx->device) * k));
+        for (int q0 = 0; q0 < nq; q0 += per_pass) {
+            const int take = std::min(per_pass, nq - q0);
+            MfmaScanArgs ma;
+            ma.X = idx->X;
+            ma.n = n;
+            ma.ld = idx->ld;
+            ma.q = qsrc + (int64_t)q0 * idx->ld;
+            ma.nq = take;
+            ma.k = k;
+            ma.cand = ws->cand.p;
+            ma.mask = mask32;
+            int nblocks = 0;
+            int slot = prof_begin("ip_scan_mfma_masked", s);
+            MVDB_TRY(launch_mfma2_gated(idx->d / 16, ma, idx->device, s, &nblocks, nullptr, 0));
+            prof_end(slot, s);
+            MergeArgs mg;
+            mg.keys = ws->cand.p;
+            mg.nlists = nblocks;
+            mg.k = k;
+            mg.metric = idx->metric;
+            mg.label_offset = label_offset;
+            mg.D = D_dev + (int64_t)q0 * k;
+            mg.I = I_dev + (int64_t)q0 * k;
+            hipLaunchKernelGGL(merge_keys_kernel, dim3(take), dim3(kMergeThreads), 0, s, mg);
+            MVDB_HIP(hipGetLastError());
+        }
+        return 0;
     }
 
     // Large batches are cut into chunks: >= 104 queries left -> one 128-query GEMM-tiled launch (compute-
@@ -1773,7 +1823,7 @@ int mvdb_index_search_masked_device(const mvdb_index* idx, const float* q_dev, i
         MVDB_HIP(hipGetLastError());
         q = ws->q.p;
     }
-    MVDB_TRY(search_core(idx, ws, q, nq, k, normalize_q, nullptr, 0, labels == 1 ? label_offset : 0, D_dev, I_dev, false, mask_dev));
+    MVDB_TRY(search_core(idx, ws, q, nq, k, normalize_q, nullptr, 0, labels == 1 ? label_offset : 0, D_dev, I_dev, true, mask_dev));
     return finish_mask_labels(idx, ws, nq, k, mask_dev, labels, I_dev);
 }
 
@@ -1802,7 +1852,7 @@ int mvdb_index_search_masked(const mvdb_index* idx, const float* q_host, int nq,
                 break;
             }
         }
-        if ((rc = search_core(idx, ws, ws->q.p, nq, k, normalize_q, nullptr, 0, 0, D_dev, ws->out.p, false, mask_dev))) break;
+        if ((rc = search_core(idx, ws, ws->q.p, nq, k, normalize_q, nullptr, 0, 0, D_dev, ws->out.p, true, mask_dev))) break;
         if ((rc = finish_mask_labels(idx, ws, nq, k, mask_dev, labels, ws->out.p))) break;
         rc = fetch_results(ws, total, D_host, I_host);
     } while (0);
@@ -1928,7 +1978,7 @@ int mvdb_index_search_rowset(const mvdb_index* idx, const float* q_host, int nq,
         if ((rc = ws->out.reserve(total + (total + 1) / 2))) break;
         float* D_dev = reinterpret_cast<float*>(ws->out.p + total);
         if (rs->mask) {
-            if ((rc = search_core(idx, ws, ws->q.p, nq, k, normalize_q, nullptr, rs->n_at_create, 0, D_dev, ws->out.p, false, rs->mask))) break;
+            if ((rc = search_core(idx, ws, ws->q.p, nq, k, normalize_q, nullptr, rs->n_at_create, 0, D_dev, ws->out.p, true, rs->mask))) break;
         } else {
             // count == 0: search_core's empty-corpus branch needs a non-NULL list to take the subset meaning
             if ((rc = search_core(idx, ws, ws->q.p, nq, k, normalize_q, rs->rows, rs->count, 0, D_dev, ws->out.p))) break;

@@ -37,6 +37,7 @@ struct MfmaScanArgs {
     int nq;          // <= 16 * NG
     int k;           // <= kMaxFusedK
     uint64_t* cand;  // [nq, gridDim.x, k]
+    const uint32_t* mask = nullptr;  // NULL, or one bit per row: only rows whose bit is set are offered to the lists
 };
 
 // Offer one 16-row tile's scores to the per-wave, per-query LDS lists.  acc[g][r] of lane l is the score
@@ -178,7 +179,7 @@ typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 constexpr int mfma2_stage_bytes(int skb) { return 16 * skb * 64; }
 constexpr int mfma2_wave_lds_bytes(int skb) { return 2 * mfma2_stage_bytes(skb); }
 
-template <int KB, int NG, int SKB>
+template <int KB, int NG, int SKB, bool MASKED = false>
 __device__ __forceinline__ void flat_scan_mfma2_body(const MfmaScanArgs& a) {
     static_assert(KB % SKB == 0 && (SKB == 8 || SKB == 16), "d must be a multiple of the stage depth");
     constexpr int NS = KB / SKB;  // stages per tile
@@ -246,6 +247,8 @@ __device__ __forceinline__ void flat_scan_mfma2_body(const MfmaScanArgs& a) {
     }
     while (tile < ntiles) {
         const int64_t next_tile = tile + nwaves_total;
+        uint32_t mw = 0xffffffffu;  // MASKED: the bitmap word holding this tile's 16 rows, requested before the tile's stages
+        if (MASKED) mw = a.mask[tile >> 1];
         f32x4m acc0[NG], acc1[NG];
 #pragma unroll
         for (int g = 0; g < NG; ++g) acc0[g] = acc1[g] = f32x4m{0, 0, 0, 0};
@@ -289,7 +292,8 @@ __device__ __forceinline__ void flat_scan_mfma2_body(const MfmaScanArgs& a) {
         f32x4m acc[NG];
 #pragma unroll
         for (int g = 0; g < NG; ++g) acc[g] = acc0[g] + acc1[g];
-        mfma_tile_select<NG>(acc, thr, tile * 16 + fr <= last, (uint32_t)(tile * 16 + fr), a.nq, k, mylists, lane);
+        mfma_tile_select<NG>(acc, thr, tile * 16 + fr <= last && ((mw >> ((int)(tile & 1) * 16 + fr)) & 1u), (uint32_t)(tile * 16 + fr), a.nq, k,
+                             mylists, lane);
         tile = next_tile;
     }
 
@@ -301,11 +305,12 @@ template <int KB, int NG, int SKB>
 __global__ __launch_bounds__(kScanThreads) void flat_scan_mfma2_kernel(MfmaScanArgs a) {
     flat_scan_mfma2_body<KB, NG, SKB>(a);
 }
-// enabled by a device-side count (the whole pass runs iff *gate > gate_lo): see flat_scan_gated_kernel
-template <int KB, int NG, int SKB>
+// enabled by a device-side count (the whole pass runs iff *gate > gate_lo; gate == NULL: always): see flat_scan_gated_kernel.
+// MASKED: only rows whose bit is set in a.mask are offered to the lists (bitmap-selected batches and their exact re-runs).
+template <int KB, int NG, int SKB, bool MASKED = false>
 __global__ __launch_bounds__(kScanThreads) void flat_scan_mfma2_gated_kernel(MfmaScanArgs a, const int* __restrict__ gate, int gate_lo) {
-    if (*gate <= gate_lo) return;
-    flat_scan_mfma2_body<KB, NG, SKB>(a);
+    if (gate && *gate <= gate_lo) return;
+    flat_scan_mfma2_body<KB, NG, SKB, MASKED>(a);
 }
 
 }  // namespace mvdb

@@ -846,11 +846,78 @@ def test_masked_search_equals_the_subset_search_of_the_ascending_list(native, d,
     Do, Io = flat.flat_search(x, q, k, metric=metric, rows=rows)
     Ds, Is = idx.search_subset(q, k, rows)
     assert np.array_equal(Ip, Is)
-    np.testing.assert_allclose(Dp, Ds, atol=0, rtol=0)       # the same kernel arithmetic, row for row
+    np.testing.assert_allclose(Dp, Ds, atol=2e-6, rtol=0)    # (several queries + bitmap: the fp32-MFMA pass; the list: the GEMV scan)
+    D1, I1 = idx.search_masked(q[1], k, mask, labels="positions")
+    D2, I2 = idx.search_subset(q[1], k, rows)
+    assert np.array_equal(I1, I2)
+    np.testing.assert_allclose(D1, D2, atol=0, rtol=0)       # one query: the same kernel arithmetic, row for row
     _check(native, x, q, k, Dp, Ip, metric=metric, rows=rows)
     Dr, Ir = idx.search_masked(q, k, mask, labels="rows")
     assert np.array_equal(Ir, rows[Ip]) and np.array_equal(Dr, Dp)
     assert Ir[0, :3].tolist() == [300, 777, 40_001]           # ties: ascending row
+    idx.close()
+
+
+@pytest.mark.parametrize("d,nq,k", [(512, 8, 10), (512, 40, 10), (384, 256, 10), (512, 300, 32), (768, 130, 10), (128, 40, 10),
+                                    (100, 40, 10)])
+@pytest.mark.parametrize("frac", [0.5, 0.97])
+def test_masked_batches_match_oracle(native, d, nq, k, frac):
+    """A bitmap and a BATCH of queries: 33+ queries go through the fp16 nomination pass (the bit is looked at where a row is
+    about to be nominated), fewer — and widths without that pass (d = 128) — through the staged fp32-MFMA pass, d = 100
+    through the one-query scan; the best rows of several queries sit OUTSIDE the selection and must not come back.
+    Ids equal the oracle's on the selected rows."""
+    n = 60_000
+    x = _corpus(n, d)
+    q = _corpus(nq, d, seed=31)
+    rs = np.random.RandomState(d + nq)
+    rows = np.sort(rs.choice(n, int(n * frac), replace=False)).astype(np.int64)
+    sel = np.zeros(n, bool)
+    sel[rows] = True
+    out = np.flatnonzero(~sel)
+    for j, qi in enumerate(range(0, nq, max(1, nq // 7))):      # a perfect match per probed query, outside the selection
+        x[out[11 * j + 3]] = q[qi]
+    idx = native.FlatIndex(d)
+    idx.add(x)
+    mask = native.pack_row_mask(n, rows=rows)
+    D, I = idx.search_masked(q, k, mask, labels="rows")
+    assert sel[I].all()
+    _check(native, x, q, k, D, np.searchsorted(rows, I), rows=rows)
+    Dp, Ip = idx.search_masked(q, k, mask, labels="positions")
+    assert np.array_equal(rows[Ip], I) and np.array_equal(Dp, D)
+    idx.close()
+
+
+def test_masked_batch_reruns_uncertified_queries_under_the_mask(native):
+    """200 queries under a bitmap keeping 70 % of the rows; three of them have 40 exact copies of their best row INSIDE the
+    selection (their certificates must fail: the exact re-run — the gated fp32-MFMA pass, with the bitmap — answers them)
+    and 40 more copies OUTSIDE it (never returned)."""
+    n, d, k, nq = 40_000, 512, 10, 200
+    x = _corpus(n, d)
+    q = _corpus(nq, d, seed=78)
+    sel = np.ones(n, bool)
+    sel[np.random.RandomState(5).choice(n, int(0.3 * n), replace=False)] = False
+    for qi, base in ((3, 1000), (130, 9000), (199, 20000)):
+        sel[base:base + 40] = True
+        x[base:base + 40] = q[qi]
+        sel[base + 5000:base + 5040] = False
+        x[base + 5000:base + 5040] = q[qi]
+    rows = np.flatnonzero(sel).astype(np.int64)
+    idx = native.FlatIndex(d)
+    idx.add(x)
+    mask = native.pack_row_mask(n, rows=rows)
+    before = native.split_rerun_count()
+    D, I = idx.search_masked(q, k, mask, labels="rows")
+    assert native.split_rerun_count() == before + 1
+    assert sel[I].all()
+    for qi, base in ((3, 1000), (130, 9000), (199, 20000)):
+        assert I[qi].tolist() == list(range(base, base + 10))   # ties resolve to the lowest row numbers
+    _check(native, x, q, k, D, np.searchsorted(rows, I), rows=rows)
+    rs_ = idx.rowset(np.flatnonzero(~sel).astype(np.int64), excluded=True)   # the same through a resident (bitmap) row set
+    assert rs_.is_bitmap
+    Dr, Ir = idx.search_rowset(q, k, rs_)
+    assert np.array_equal(Ir, I)
+    np.testing.assert_allclose(Dr, D, atol=2e-6, rtol=0)
+    rs_.close()
     idx.close()
 
 
@@ -913,7 +980,8 @@ def test_resident_row_sets(native):
     assert s2.is_bitmap and len(s2) == len(dense)
     D2, I2 = idx.search_rowset(q, k, s2)
     Dd, Id = idx.search_subset(q, k, dense)
-    assert np.array_equal(I2, dense[Id]) and np.array_equal(D2, Dd)
+    assert np.array_equal(I2, dense[Id])                       # (two queries + bitmap: the fp32-MFMA pass; the list: the GEMV scan)
+    np.testing.assert_allclose(D2, Dd, atol=2e-6, rtol=0)
     assert I2[0, :2].tolist() == [123, 29_000]                   # ascending rows
     excl = np.array([123, 7, 7, 15_000], dtype=np.int64)          # a row listed twice is removed once
     s3 = idx.rowset(excl, excluded=True)
@@ -921,7 +989,8 @@ def test_resident_row_sets(native):
     D3, I3 = idx.search_rowset(q, k, s3)
     keep = np.setdiff1d(np.arange(n), excl)
     De, Ie = idx.search_subset(q, k, keep)
-    assert np.array_equal(I3, keep[Ie]) and np.array_equal(D3, De)
+    assert np.array_equal(I3, keep[Ie])
+    np.testing.assert_allclose(D3, De, atol=2e-6, rtol=0)
     assert 123 not in I3[0] and I3[0, 0] == 29_000
     idx.add(_corpus(10, d, seed=8))                               # appended rows: the sets still answer, without them
     D3b, I3b = idx.search_rowset(q, k, s3)
