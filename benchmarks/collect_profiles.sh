@@ -35,7 +35,7 @@ cp $(find /tmp/enc_s32 -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_encoder_
 MVDB_S32_S=512 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/enc_s512 -- python3 $R/benchmarks/bench_encoder_s32.py 5 > /dev/null 2>&1
 cp $(find /tmp/enc_s512 -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_encoder_s512_kernel_stats.csv
 MVDB_BENCH_COMPUTE=2 MVDB_BENCH_S=32,64,128,256,512 python3 $R/benchmarks/bench_encoder.py > $OUT/${TAG}_encoder_seq_sweep.jsonl 2>> $OUT/bench.err
-MVDB_GEMM_LN_FUSED=0 MVDB_ATTENTION_IMG=0 MVDB_BENCH_COMPUTE=2 MVDB_BENCH_S=32,512 python3 $R/benchmarks/bench_encoder.py > $OUT/${TAG}_encoder_bench_r02_paths.jsonl 2>> $OUT/bench.err
+MVDB_GEMM_LN_FUSED=0 MVDB_ATTENTION_IMG=0 MVDB_GEMM_X3_PERSIST=0 MVDB_GEMM_X3_SPREAD_SMALL=0 MVDB_GEMM_LN_SPREAD=0 MVDB_BENCH_COMPUTE=2 MVDB_BENCH_S=32,512 python3 $R/benchmarks/bench_encoder.py > $OUT/${TAG}_encoder_bench_r02_paths.jsonl 2>> $OUT/bench.err
 bash $R/benchmarks/prof_encoder_x3.sh $TAG/enc_pmc > /dev/null 2>&1
 cp $OUT/enc_pmc/pmc_summary.txt $OUT/${TAG}_encoder_s32_pmc.txt
 python3 $R/benchmarks/scale_check.py > $OUT/${TAG}_scale_check_80M.json 2>> $OUT/bench.err
@@ -46,4 +46,21 @@ rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/subs -- python3 $R/
 cp $(find /tmp/subs -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_subset_kernel_stats.csv
 bash $R/benchmarks/half_probe.sh > $OUT/half_probe.log 2>&1
 cp $R/gpurun_out/half_probe.jsonl $OUT/${TAG}_half_pass_dims.jsonl
+# ablation build (make -C minivectordb_amd/csrc ABLATE=1 before the run): per-tile timelines and the K-loop / epilogue split
+ABL=$R/minivectordb_amd/lib/libmvdb_ablate.so
+if [ -f $ABL ]; then
+  MVDB_LIBMVDB=$ABL MVDB_GEMM_X3_DBG=5 python3 $R/benchmarks/x3_timeline.py 512 > $OUT/${TAG}_x3_timeline_s512.txt 2>&1
+  MVDB_LIBMVDB=$ABL MVDB_GEMM_X3_DBG=5 MVDB_GEMM_X3_SPREAD=0 python3 $R/benchmarks/x3_timeline.py 512 > $OUT/${TAG}_x3_timeline_s512_dma_burst.txt 2>&1
+  MVDB_LIBMVDB=$ABL MVDB_GEMM_X3_DBG=6 python3 $R/benchmarks/x3_timeline.py 512 > $OUT/${TAG}_x3_timeline_s512_mfma16x16x32_standin.txt 2>&1
+  : > $OUT/${TAG}_x3_ablations.txt
+  for d in 0 3 4; do
+    for S in 32 512; do
+      n=30; [ $S = 512 ] && n=5
+      MVDB_LIBMVDB=$ABL MVDB_GEMM_LN_FUSED=2 MVDB_GEMM_X3_DBG=$d MVDB_S32_S=$S rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/abl_${d}_$S -- python3 $R/benchmarks/bench_encoder_s32.py $n > /dev/null 2>&1
+      f=$(find /tmp/abl_${d}_$S -name "*kernel_stats.csv" | head -1)
+      echo "== MVDB_GEMM_X3_DBG=$d (0 full, 3 K loop only, 4 epilogue only), B = 256, S = $S: kernel, calls, average ns" >> $OUT/${TAG}_x3_ablations.txt
+      grep -E "gemm_x3" $f | sed 's/_ZN12_GLOBAL__N_1//; s/EEEvPK[^"]*"//' | cut -d, -f1,2,4 >> $OUT/${TAG}_x3_ablations.txt
+    done
+  done
+fi
 ls -la $OUT

@@ -473,7 +473,11 @@ __global__ __launch_bounds__(256) void flat_scan_half_kernel(HalfScanArgs a) {
 // active 43 %, parked on barriers / vmcnt 27 %, issue-stalled 29 %, no LDS bank conflicts.
 // WV = waves per workgroup: 4 (one per SIMD), or 8 (two per SIMD, half the rows and half the queries each: the second
 // wave issues MFMAs while the first sits at the stage barrier; 8 x 16 fragment reads per stage instead of 4 x 16)
-template <int KT, bool PAD, int G, int WV = 4>
+// PIPE: the refill DMAs of the raw ring and the conversion of the next stage are issued BETWEEN the MFMAs of the current one
+// (one DMA instruction after every second MFMA of the first half of the stage, one converted piece after every second MFMA
+// of the rest) instead of behind them: both waves of a SIMD reach the barrier together, so whatever follows the MFMAs in
+// program order is time the matrix cores idle.  10M x 512, 128 / 256 queries per pass: +1.4 % / +1.3 % q/s; 256 at d = 384: +4 %.
+template <int KT, bool PAD, int G, int WV = 4, bool PIPE = false>
 __global__ __launch_bounds__(WV * 64) void flat_scan_hq_kernel(HalfScanArgs a) {
     constexpr int KH = KT / 2;               // 16-k blocks per stage (one K-half)
     constexpr int RAWP = KH * 64;            // raw row pitch in bytes (KH x 16 floats)
@@ -533,13 +537,15 @@ __global__ __launch_bounds__(WV * 64) void flat_scan_hq_kernel(HalfScanArgs a) {
         const int hs = cs >> 1;  // fp16 slot (8 elements): two raw slots each
         hdst[i] = row * HP + ((PAD ? hs : (hs ^ (row & 15))) << 4) + (cs & 1) * 8;
     }
-    auto issue_stage = [&](int64_t tile, int half, int buf) {
+    auto issue_piece = [&](int64_t tile, int half, int buf, int i) {
         const int64_t row0 = (a.tile0 + tile) * 32;
         const char* sbase = reinterpret_cast<const char*>(a.X + row0 * a.ld + half * KH * 16);
         unsigned char* dst = smem + buf * kRaw + wave * kRawW;
+        __builtin_amdgcn_global_load_lds((hs_gbl_ptr)(sbase + voff[i]), (hs_lds_ptr)(dst + i * 1024), 16, 0, 2 /* nt */);
+    };
+    auto issue_stage = [&](int64_t tile, int half, int buf) {
 #pragma unroll
-        for (int i = 0; i < DPW; ++i)
-            __builtin_amdgcn_global_load_lds((hs_gbl_ptr)(sbase + voff[i]), (hs_lds_ptr)(dst + i * 1024), 16, 0, 2 /* nt */);
+        for (int i = 0; i < DPW; ++i) issue_piece(tile, half, buf, i);
     };
     const int frow = fr * HP;
     const int fsw = PAD ? 0 : (fr & 15);
@@ -563,19 +569,20 @@ __global__ __launch_bounds__(WV * 64) void flat_scan_hq_kernel(HalfScanArgs a) {
 #pragma unroll
         for (int i = 0; i < DPW; ++i) x.v[i] = *reinterpret_cast<const hs_f4*>(src + i * 1024);
     };
-    auto write_half = [&](const Raw& x, int hb) {
+    auto write_piece = [&](const Raw& x, int hb, int i) {
         unsigned char* dst = hbuf + hb * kH;
+        union {
+            hs_h2 p[2];
+            hs_f2 f;
+        } u;
+        const hs_f2 lo = {x.v[i][0], x.v[i][1]}, hi = {x.v[i][2], x.v[i][3]};
+        u.p[0] = __builtin_convertvector(lo * xs, hs_h2);  // RNE
+        u.p[1] = __builtin_convertvector(hi * xs, hs_h2);
+        *reinterpret_cast<hs_f2*>(dst + hdst[i]) = u.f;
+    };
+    auto write_half = [&](const Raw& x, int hb) {
 #pragma unroll
-        for (int i = 0; i < DPW; ++i) {
-            union {
-                hs_h2 p[2];
-                hs_f2 f;
-            } u;
-            const hs_f2 lo = {x.v[i][0], x.v[i][1]}, hi = {x.v[i][2], x.v[i][3]};
-            u.p[0] = __builtin_convertvector(lo * xs, hs_h2);  // RNE
-            u.p[1] = __builtin_convertvector(hi * xs, hs_h2);
-            *reinterpret_cast<hs_f2*>(dst + hdst[i]) = u.f;
-        }
+        for (int i = 0; i < DPW; ++i) write_piece(x, hb, i);
     };
     auto wait_raw = [&]() {
         __builtin_amdgcn_sched_barrier(0);
@@ -622,6 +629,46 @@ __global__ __launch_bounds__(WV * 64) void flat_scan_hq_kernel(HalfScanArgs a) {
             __builtin_amdgcn_sched_group_barrier(0x002, 4 * G, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, G, 0);
         }
+    };
+    // PIPE: MFMAs of (tile, half) from image hb with, between them, the refill of the raw buffer just read (stage `c` of
+    // `base`) and the conversion of x into the other image
+    auto piped_half = [&](int half, int hb, const Raw& x, int64_t base, int c) {
+        const unsigned char* src = hbuf + hb * kH + frow;
+        auto frag = [&](int kb) { return *reinterpret_cast<const hs_h8*>(src + (((2 * kb + fk) ^ fsw) << 4)); };
+        constexpr int AHEAD = (KH < 8 ? KH : 8);
+        constexpr int D0 = 1, DS = (KH / 2 - D0) / DPW > 0 ? (KH / 2 - D0) / DPW : 1;  // DMA piece i after MFMA block D0 + i DS
+        constexpr int C0 = D0 + DPW * DS, CS = (KH - C0) / DPW > 0 ? (KH - C0) / DPW : 1;  // converted piece i after block C0 + i CS
+        hs_h8 f[AHEAD + 1];
+        const int64_t rt = stage_tile(base, c);
+#pragma unroll
+        for (int u = 0; u < AHEAD; ++u) f[u] = frag(u);
+        __builtin_amdgcn_sched_barrier(0);
+        constexpr int ND = (KH - 1 - D0) / DS + 1 < DPW ? (KH - 1 - D0) / DS + 1 : DPW;              // pieces placed inside the loop
+        constexpr int NC = C0 < KH ? ((KH - 1 - C0) / CS + 1 < DPW ? (KH - 1 - C0) / CS + 1 : DPW) : 0;
+#pragma unroll
+        for (int kb = 0; kb < KH; ++kb) {
+            if (kb + AHEAD < KH) f[(kb + AHEAD) % (AHEAD + 1)] = frag(kb + AHEAD);
+#pragma unroll
+            for (int g = 0; g < G; ++g)
+                acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[kb % (AHEAD + 1)], Q[half * KH + kb][g], acc[g], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (kb >= D0 && (kb - D0) % DS == 0 && (kb - D0) / DS < ND) {
+                // the raw rows are older LDS reads than every fragment read: with at most AHEAD + 1 of the newest outstanding
+                // they are in registers
+                if (kb == D0) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(AHEAD + 1) : "memory");
+                issue_piece(rt, c & 1, rb, (kb - D0) / DS);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (kb >= C0 && (kb - C0) % CS == 0 && (kb - C0) / CS < NC) {
+                write_piece(x, hb ^ 1, (kb - C0) / CS);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#pragma unroll
+        for (int i = ND; i < DPW; ++i) issue_piece(rt, c & 1, rb, i);
+#pragma unroll
+        for (int i = NC; i < DPW; ++i) write_piece(x, hb ^ 1, i);
+        rb = rb == 2 ? 0 : rb + 1;
     };
     auto gate = [&](int64_t m0) {
 #pragma unroll
@@ -682,9 +729,13 @@ __global__ __launch_bounds__(WV * 64) void flat_scan_hq_kernel(HalfScanArgs a) {
             wait_raw();
             read_raw(x);
             __builtin_amdgcn_sched_barrier(0);  // the raw reads go first: their latency and the conversion hide under the MFMAs
-            mfma_half(half, half);
-            refill(tile, half + 4);  // the stage three past the one just read: flat index (half + 1) + 3
-            write_half(x, half ^ 1);
+            if (PIPE) {
+                piped_half(half, half, x, tile, half + 4);
+            } else {
+                mfma_half(half, half);
+                refill(tile, half + 4);  // the stage three past the one just read: flat index (half + 1) + 3
+                write_half(x, half ^ 1);
+            }
             if (half == 1) gate(m0);
             __builtin_amdgcn_sched_barrier(0);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -886,7 +937,8 @@ static int launch_half_inst(const HalfScanArgs& a, int device, hipStream_t strea
 
 template <int KT, bool PAD, int G, int WV = 4>
 static int launch_hq_inst(const HalfScanArgs& a, int device, hipStream_t stream, int* nblocks_out) {
-    auto kern = flat_scan_hq_kernel<KT, PAD, G, WV>;
+    static const bool pipe = []() { const char* v = getenv("MVDB_HQ_PIPE"); return !(v && *v == '0'); }();  // 0: DMA refill + conversion behind the MFMAs (A/B)
+    auto kern = pipe ? flat_scan_hq_kernel<KT, PAD, G, WV, true> : flat_scan_hq_kernel<KT, PAD, G, WV, false>;
     constexpr int KH = KT / 2;
     constexpr size_t lds = (size_t)3 * 32 * KH * 64 + (size_t)2 * 32 * (PAD ? 2 * KH + 1 : 2 * KH) * 16;
     static_assert(lds + 32 * WV * G * kHalfKeep * 8 <= 160 * 1024, "LDS budget of a CU");
