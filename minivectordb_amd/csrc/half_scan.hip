@@ -473,6 +473,16 @@ __global__ __launch_bounds__(256) void flat_scan_half_kernel(HalfScanArgs a) {
 // active 43 %, parked on barriers / vmcnt 27 %, issue-stalled 29 %, no LDS bank conflicts.
 // WV = waves per workgroup: 4 (one per SIMD), or 8 (two per SIMD, half the rows and half the queries each: the second
 // wave issues MFMAs while the first sits at the stage barrier; 8 x 16 fragment reads per stage instead of 4 x 16)
+#ifdef MVDB_X3_ABLATE
+// ablation build: shader cycles wave 0 of every block spends per phase of a stage, summed over the launch
+// [0] waiting for the raw stage (vmcnt), [1] raw reads + MFMAs (+ what is interleaved), [2] what follows them before the
+// barrier (refill / conversion when not interleaved, gate), [3] barrier (+ lgkmcnt), [4] stages counted
+__device__ unsigned long long g_hq_phase[8];
+#define HQ_STAMP(v) const unsigned long long v = __builtin_readcyclecounter()
+#else
+#define HQ_STAMP(v) do { } while (0)
+#endif
+
 // PIPE: the refill DMAs of the raw ring and the conversion of the next stage are issued BETWEEN the MFMAs of the current one
 // (one DMA instruction after every second MFMA of the first half of the stage, one converted piece after every second MFMA
 // of the rest) instead of behind them: both waves of a SIMD reach the barrier together, so whatever follows the MFMAs in
@@ -632,6 +642,14 @@ __global__ __launch_bounds__(WV * 64) void flat_scan_hq_kernel(HalfScanArgs a) {
     };
     // PIPE: MFMAs of (tile, half) from image hb with, between them, the refill of the raw buffer just read (stage `c` of
     // `base`) and the conversion of x into the other image
+    // (Measured on top and dropped, 10M x 512, 256 queries per pass, 66.9k q/s with this order: the refill as ONE burst right
+    //  behind the stage's barrier, where nothing of the wave is in flight — 65.1k; the upper half of the block's waves running
+    //  conversion first and DMAs last so that half as many waves queue on the CU's vector-memory path at a time — 40.3k, the
+    //  two code copies spill.  benchmarks/micro/load_issue_cost.hip: a 1-KiB load, LDS-DMA or into VGPRs alike, costs its
+    //  wave ~44 cycles of issue when four waves of a CU issue together and ~97 when eight do — the path takes ~12 cycles per
+    //  KiB CU-wide, and a wave stalled in it issues no MFMA either.  benchmarks/hq_phases.py (ablation build) stamps the
+    //  phases of a stage: at 256 queries wave 0 spends 1,011 cycles on the 16 MFMAs (512 cycles of matrix-core time) with the
+    //  DMAs, the conversion and the fragment reads between them, and 1,042 waiting at the barrier for its SIMD mate to do the same.)
     auto piped_half = [&](int half, int hb, const Raw& x, int64_t base, int c) {
         const unsigned char* src = hbuf + hb * kH + frow;
         auto frag = [&](int kb) { return *reinterpret_cast<const hs_h8*>(src + (((2 * kb + fk) ^ fsw) << 4)); };
@@ -718,6 +736,9 @@ __global__ __launch_bounds__(WV * 64) void flat_scan_hq_kernel(HalfScanArgs a) {
         __builtin_amdgcn_s_barrier();  // image 0 = (tile, half 0) is complete
         __builtin_amdgcn_sched_barrier(0);
     }
+#ifdef MVDB_X3_ABLATE
+    unsigned long long ph[5] = {0, 0, 0, 0, 0};
+#endif
     while (tile < ntiles) {
         const int64_t m0 = (a.tile0 + tile) * 32;
         zero_acc();
@@ -726,25 +747,46 @@ __global__ __launch_bounds__(WV * 64) void flat_scan_hq_kernel(HalfScanArgs a) {
             // MFMAs of (tile, half) from image `half`; beside them the conversion of the NEXT stage — (tile, 1) or
             // (tile + step, 0) — into the other image, whose readers all passed the barrier that ended the last stage
             Raw x;
+            HQ_STAMP(t0);
             wait_raw();
+            HQ_STAMP(t1);
             read_raw(x);
             __builtin_amdgcn_sched_barrier(0);  // the raw reads go first: their latency and the conversion hide under the MFMAs
             if (PIPE) {
                 piped_half(half, half, x, tile, half + 4);
+                __builtin_amdgcn_sched_barrier(0);
             } else {
                 mfma_half(half, half);
+            }
+            HQ_STAMP(t2);
+            if (!PIPE) {
                 refill(tile, half + 4);  // the stage three past the one just read: flat index (half + 1) + 3
                 write_half(x, half ^ 1);
             }
             if (half == 1) gate(m0);
             __builtin_amdgcn_sched_barrier(0);
+            HQ_STAMP(t3);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();  // the other image is complete; every wave is done reading this one
             __builtin_amdgcn_sched_barrier(0);
+#ifdef MVDB_X3_ABLATE
+            {
+                HQ_STAMP(t4);
+                ph[0] += t1 - t0;
+                ph[1] += t2 - t1;
+                ph[2] += t3 - t2;
+                ph[3] += t4 - t3;
+                ph[4] += 1;
+            }
+#endif
         }
         tile += step;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the clamped look-ahead DMAs must land before the LDS is released
+#ifdef MVDB_X3_ABLATE
+    if (threadIdx.x == 0)
+        for (int i = 0; i < 5; ++i) atomicAdd(&g_hq_phase[i], ph[i]);
+#endif
     if (a.stats && lane == 0) {
         atomicAdd(a.stats, n_ins);
         atomicAdd(a.stats + 1, n_slow);
@@ -1008,3 +1050,14 @@ int launch_half_certify(const HalfCertifyArgs& a, int nq, hipStream_t stream) {
 }
 
 }  // namespace mvdb
+
+#ifdef MVDB_X3_ABLATE
+// ablation build only: reads and clears the per-phase cycle sums of the query-split kernel's launches so far
+extern "C" int mvdb_debug_hq_phases(unsigned long long* out) {
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(mvdb::g_hq_phase), 8 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    void* sym = nullptr;
+    if (hipGetSymbolAddress(&sym, HIP_SYMBOL(mvdb::g_hq_phase)) != hipSuccess) return -1;
+    return hipMemset(sym, 0, 8 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#endif
