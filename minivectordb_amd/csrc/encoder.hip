@@ -1268,47 +1268,44 @@ __global__ __launch_bounds__(WM * 256) void gemm_x3_ln_kernel(const _Float16* __
     constexpr int NA = BM / 8;                  // DMA instructions of the A tile (8 rows each)
     constexpr int NI = (NA + BN / 8) / WAVES;   // per wave and stage
     static_assert((NA + BN / 8) % WAVES == 0, "whole DMA instructions per wave");
-    static_assert(2 * BM * 4 * 4 <= NST * kStage, "row statistics reuse the ring");
+    // PERSISTENT (the two-stage forms, BM = 64 / 128): the grid is one workgroup per CU, workgroup w owns the row bands
+    // w, w + G, ... and the K-step pipeline runs through the band boundary as in gemm_x3_big_kernel (the next band's first
+    // stage lands under the LayerNorm epilogue; the row statistics have their own LDS behind the ring).  The three-stage
+    // form (BM = 32: T = 8192) stays one band per workgroup: its counted waits would have to count the epilogue's loads.
+    constexpr bool PERS = NST == 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char xsm[];
+    float* red = reinterpret_cast<float*>(xsm + NST * kStage);  // [2 passes][WN column waves][BM rows]
     const int T = *Tptr;
-    const int m0 = blockIdx.x * BM;
+    int m0 = blockIdx.x * BM;
     if (m0 >= T) return;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const int fr = lane & 31, fh = lane >> 5;
 
-    int64_t voff[NI];
-    const char* sbase[NI];
-    int dsto[NI];
+    // DMA roles: instruction q = wave NI + i of a stage moves 8 rows of A (q < NA) or of W; source = a wave-uniform base of
+    // (band, K-step) + a 32-bit lane offset
+    uint32_t lrow[NI], lslot[NI];
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
         const int q = wave * NI + i;
-        if (q < NA) {
-            const int row = 8 * q + (lane >> 3);
-            const int slot = (lane & 7) ^ ((row >> 1) & 7);
-            int g = m0 + row;
-            g = g < T ? g : T - 1;  // rows past the edge: clamped (never stored)
-            sbase[i] = reinterpret_cast<const char*>(A);
-            voff[i] = (int64_t)g * K * 4 + 16 * slot;
-            dsto[i] = q * 1024;
-        } else {
-            const int qq = q - NA;
-            const int row = 8 * qq + (lane >> 3);  // < BN = N: every row exists
-            const int slot = (lane & 7) ^ ((row >> 1) & 7);
-            sbase[i] = reinterpret_cast<const char*>(Wp);
-            voff[i] = (int64_t)row * K * 4 + 16 * slot;
-            dsto[i] = kA + qq * 1024;
-        }
+        const int row = 8 * (q < NA ? q : q - NA) + (lane >> 3);
+        lrow[i] = (uint32_t)row;
+        lslot[i] = (uint32_t)(16 * ((lane & 7) ^ ((row >> 1) & 7)));
     }
-    auto issue_piece = [&](int kt, int stage, int i) {
+    auto issue_piece = [&](int mb, int kt, int stage, int i) {
         if (DBG == 2) return;  // ablations as in gemm_x3_dma_kernel (results invalid)
-        __builtin_amdgcn_global_load_lds((enc_gbl_ptr)(sbase[i] + (int64_t)kt * 128 + voff[i]),
-                                         (enc_lds_ptr)(xsm + stage * kStage + dsto[i]), 16, 0, 0);
+        const int q = wave * NI + i;
+        const char* base = q < NA ? reinterpret_cast<const char*>(A) + ((int64_t)mb * K * 4 + (int64_t)kt * 128)
+                                  : reinterpret_cast<const char*>(Wp) + (int64_t)kt * 128;
+        const uint32_t rlim = (uint32_t)(T - 1 - mb);  // rows past the edge: clamped (never stored); W: every row exists
+        const uint32_t r = q < NA ? (lrow[i] < rlim ? lrow[i] : rlim) : lrow[i];
+        __builtin_amdgcn_global_load_lds((enc_gbl_ptr)(base + (r * (uint32_t)(K * 4) + lslot[i])),
+                                         (enc_lds_ptr)(xsm + stage * kStage + (q < NA ? q * 1024 : kA + (q - NA) * 1024)), 16, 0, 0);
     };
-    auto issue = [&](int kt, int stage) {
+    auto issue = [&](int mb, int kt, int stage) {
 #pragma unroll
-        for (int i = 0; i < NI; ++i) issue_piece(kt, stage, i);
+        for (int i = 0; i < NI; ++i) issue_piece(mb, kt, stage, i);
     };
     // fragment byte offsets inside a stage, tile (0, 0) of the wave: row tile i / column tile j add 4096 i / 4096 j, folded into
     // the ds_read's immediate (the swizzle term depends on the row's low bits only)
@@ -1322,138 +1319,148 @@ __global__ __launch_bounds__(WM * 256) void gemm_x3_ln_kernel(const _Float16* __
             b_off[ks][pl] = kA + (wn * (TN * 32) + fr) * 128 + (((4 * pl + 2 * ks + fh) ^ ga) << 4);
         }
 
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
     const int nk = DBG == 4 ? 0 : K / 32;
+    const int mstep = PERS ? (int)gridDim.x * BM : 0;
     if (nk > 0) {
 #pragma unroll
-        for (int u = 0; u < NST - 1; ++u) issue(u < nk ? u : nk - 1, u);
+        for (int u = 0; u < NST - 1; ++u) issue(m0, u < nk ? u : nk - 1, u);
     }
     int st = 0;
-    for (int kt = 0; kt < nk; ++kt) {
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * NI) : "memory");  // this wave's part of stage kt has landed
-        __builtin_amdgcn_s_barrier();  // every wave's part has; and every wave is done reading stage kt - 1
-        __builtin_amdgcn_sched_barrier(0);
-        const int ahead = kt + NST - 1, akt = ahead < nk ? ahead : nk - 1, abuf = st == 0 ? NST - 1 : st - 1;  // into the buffer of stage kt - 1
-        if (!SPREAD || DBG == 1) issue(akt, abuf);
-        __builtin_amdgcn_sched_barrier(0);
-        const unsigned char* sb = xsm + st * kStage;
-        if (DBG == 1) {
-            acc[0][0][0] += (float)kt;
-            st = st == NST - 1 ? 0 : st + 1;
-            continue;
-        }
-        if (SPREAD)
-            x3_kstep<TM, TN, 0, NI>(sb, a_off, b_off, acc, [&](int i) { issue_piece(akt, abuf, i); });
-        else
-            x3_kstep_plain<TM, TN>(sb, a_off, b_off, acc);
-        st = st == NST - 1 ? 0 : st + 1;
-    }
-    // ---- epilogue: v = acc / wscale + bias + residual, LayerNorm over the row, in place ------------------------------
-    // transposed tiles (x3t_store_image): lane = token row, so a row's statistics are sums over the lane's own TN x 16
-    // registers, one exchange with the other lane half (its columns in between) and the four column waves through LDS
-    if (DBG == 3) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        float live = 0.f;
+    for (;;) {
+        f32x16 acc[TM][TN];
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) live += acc[i][j][r];
-        if (live == 1.2345e-30f) X[0] = 0.f;
-        return;
-    }
-    int64_t rbase[TM];
-    bool rok[TM];
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int row = m0 + wm * (TM * 32) + i * 32 + fr;
-        rok[i] = row < T;
-        rbase[i] = (int64_t)(rok[i] ? row : T - 1) * BN;  // clamped: loads stay in bounds, stores are predicated
-    }
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int c4 = wn * (TN * 32) + j * 32 + 8 * g + 4 * fh;
-            const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias + c4);
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const f32x4 r4 = *reinterpret_cast<const f32x4*>(X + rbase[i] + c4);
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    acc[i][j][4 * g + e] = (acc[i][j][4 * g + e] * inv_wscale + b4[e]) + r4[e];  // exact scale: power of two
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        const int m1 = m0 + mstep;                 // the next band of this workgroup
+        const bool more_bands = PERS && m1 < T;
+        for (int kt = 0; kt < nk; ++kt) {
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * NI) : "memory");  // this wave's part of stage kt has landed
+            __builtin_amdgcn_s_barrier();  // every wave's part has; and every wave is done reading stage kt - 1
+            __builtin_amdgcn_sched_barrier(0);
+            // look-ahead into the buffer of stage kt - 1: K-step kt + NST - 1 of this band (clamped past the end: every counted
+            // wait sees a full ring) or, persistent, the next band's first stage
+            const int ahead = kt + NST - 1;
+            const bool cross = PERS && ahead >= nk && more_bands;
+            const int amb = cross ? m1 : m0, akt = cross ? 0 : (ahead < nk ? ahead : nk - 1), abuf = st == 0 ? NST - 1 : st - 1;
+            if (!SPREAD || DBG == 1) issue(amb, akt, abuf);
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned char* sb = xsm + st * kStage;
+            if (DBG == 1) {
+                acc[0][0][0] += (float)kt;
+                st = st == NST - 1 ? 0 : st + 1;
+                continue;
             }
+            if (SPREAD)
+                x3_kstep<TM, TN, 0, NI>(sb, a_off, b_off, acc, [&](int i) { issue_piece(amb, akt, abuf, i); });
+            else
+                x3_kstep_plain<TM, TN>(sb, a_off, b_off, acc);
+            st = st == NST - 1 ? 0 : st + 1;
         }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the clamped look-ahead DMAs have landed (and the residual loads)
-    __builtin_amdgcn_s_barrier();                     // every wave is done with the ring: its first bytes become scratch
-    float* red = reinterpret_cast<float*>(xsm);       // [2 passes][WN column waves][BM rows]
-    float rstd[TM];
+        // ---- epilogue: v = acc / wscale + bias + residual, LayerNorm over the row, in place ------------------------------
+        // transposed tiles (x3t_store_image): lane = token row, so a row's statistics are sums over the lane's own TN x 16
+        // registers, one exchange with the other lane half (its columns in between) and the four column waves through LDS
+        if (DBG == 3) {
+            float live = 0.f;
 #pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {  // 0: mean (then acc -= mean), 1: variance of the centred values
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            float p = 0.f;
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) p += pass == 0 ? acc[i][j][r] : acc[i][j][r] * acc[i][j][r];
-            // + the other lane half's columns: (lower, lower) + (upper, upper) on both halves, the same bits on both
-            const x3_u2 sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(p), __float_as_uint(p), false, false);
-            p = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
-            if (fh == 0) red[(pass * WN + wn) * BM + wm * (TM * 32) + i * 32 + fr] = p;
-        }
-        __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the partial sums are in LDS
-        __builtin_amdgcn_s_barrier();
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            float tot = 0.f;
-#pragma unroll
-            for (int w = 0; w < WN; ++w) tot += red[(pass * WN + w) * BM + wm * (TM * 32) + i * 32 + fr];  // wave order: deterministic
-            if (pass == 0) {
-                const float mean = tot / (float)BN;
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[i][j][r] -= mean;
-            } else {
-                rstd[i] = 1.0f / sqrtf(tot / (float)BN + eps);  // biased variance, eps inside the sqrt
-            }
+                    for (int r = 0; r < 16; ++r) live += acc[i][j][r];
+            if (live == 1.2345e-30f) X[0] = 0.f;
+            if (!more_bands) break;
+            m0 = m1;
+            continue;
         }
-    }
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        f32x4 g4[4], t4[4];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int c4 = wn * (TN * 32) + j * 32 + 8 * g + 4 * fh;
-            g4[g] = *reinterpret_cast<const f32x4*>(gamma + c4);
-            t4[g] = *reinterpret_cast<const f32x4*>(beta + c4);
-        }
+        int64_t rbase[TM];
+        bool rok[TM];
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            float v[16];
+            const int row = m0 + wm * (TM * 32) + i * 32 + fr;
+            rok[i] = row < T;
+            rbase[i] = (int64_t)(rok[i] ? row : T - 1) * BN;  // clamped: loads stay in bounds, stores are predicated
+        }
 #pragma unroll
-            for (int g = 0; g < 4; ++g)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[4 * g + e] = acc[i][j][4 * g + e] * rstd[i] * g4[g][e] + t4[g][e];
-            const int cb = wn * (TN * 32) + j * 32;
-            if (rok[i]) {
+            for (int g = 0; g < 4; ++g) {
+                const int c4 = wn * (TN * 32) + j * 32 + 8 * g + 4 * fh;
+                const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias + c4);
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const f32x4 r4 = *reinterpret_cast<const f32x4*>(X + rbase[i] + c4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        acc[i][j][4 * g + e] = (acc[i][j][4 * g + e] * inv_wscale + b4[e]) + r4[e];  // exact scale: power of two
+                }
+            }
+        float rstd[TM];
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {  // 0: mean (then acc -= mean), 1: variance of the centred values
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                float p = 0.f;
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) p += pass == 0 ? acc[i][j][r] : acc[i][j][r] * acc[i][j][r];
+                // + the other lane half's columns: (lower, lower) + (upper, upper) on both halves, the same bits on both
+                const x3_u2 sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(p), __float_as_uint(p), false, false);
+                p = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+                if (fh == 0) red[(pass * WN + wn) * BM + wm * (TM * 32) + i * 32 + fr] = p;
+            }
+            __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the partial sums are in LDS
+            __builtin_amdgcn_s_barrier();
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                float tot = 0.f;
+#pragma unroll
+                for (int w = 0; w < WN; ++w) tot += red[(pass * WN + w) * BM + wm * (TM * 32) + i * 32 + fr];  // wave order: deterministic
+                if (pass == 0) {
+                    const float mean = tot / (float)BN;
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[i][j][r] -= mean;
+                } else {
+                    rstd[i] = 1.0f / sqrtf(tot / (float)BN + eps);  // biased variance, eps inside the sqrt
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            f32x4 g4[4], t4[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c4 = wn * (TN * 32) + j * 32 + 8 * g + 4 * fh;
+                g4[g] = *reinterpret_cast<const f32x4*>(gamma + c4);
+                t4[g] = *reinterpret_cast<const f32x4*>(beta + c4);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                float v[16];
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
-                    *reinterpret_cast<f32x4*>(X + rbase[i] + cb + 8 * g + 4 * fh) = f32x4{v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[4 * g + e] = acc[i][j][4 * g + e] * rstd[i] * g4[g][e] + t4[g][e];
+                const int cb = wn * (TN * 32) + j * 32;
+                if (rok[i]) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        *reinterpret_cast<f32x4*>(X + rbase[i] + cb + 8 * g + 4 * fh) = f32x4{v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};
+                }
+                x3t_store_image(reinterpret_cast<unsigned char*>(Xp + rbase[i] + cb), fh, v, rok[i]);
             }
-            x3t_store_image(reinterpret_cast<unsigned char*>(Xp + rbase[i] + cb), fh, v, rok[i]);
         }
+        if (!more_bands) break;
+        m0 = m1;
+        // (the statistics scratch is reused by the next band only after its K loop: a dozen barriers from here)
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the clamped look-ahead DMAs must land before the LDS is released
 }
 
 // =================================================================================================
@@ -2464,10 +2471,14 @@ int launch_gemm_x3_ln_inst(const _Float16* A, const _Float16* Wp, float inv_wsca
     (void)dbg;
     static const bool spread = []() { const char* v = getenv("MVDB_GEMM_LN_SPREAD"); return !(v && *v == '0'); }();
     auto kern = spread ? X3_LN_KERN(BM, WM, TN, NST, 1) : X3_LN_KERN(BM, WM, TN, NST, 0);
-    constexpr int lds = NST * kStage;
+    constexpr int lds = NST * kStage + 2 * 4 * BM * 4;  // the ring + the row statistics
+    static_assert(lds <= 160 * 1024, "LDS budget of a CU");
     MVDB_TRY(x3_set_lds((const void*)kern, lds, device));
-    hipLaunchKernelGGL(kern, dim3((unsigned)((Tmax + BM - 1) / BM)), dim3(WM * 256), lds, s, A, Wp, inv_wscale, bias, gamma, beta,
-                       eps, X, Xp, Tptr, K);
+    // two-stage forms: persistent, one workgroup per CU (a multiple of the row bands would leave a last round part full anyway)
+    const int64_t bands = (Tmax + BM - 1) / BM;
+    static const bool persist = []() { const char* v = getenv("MVDB_GEMM_LN_PERSIST"); return !(v && *v == '0'); }();  // 0: one band per workgroup (A/B)
+    const unsigned grid = (unsigned)(NST == 2 && persist ? std::min<int64_t>(bands, device_cus(device)) : bands);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(WM * 256), lds, s, A, Wp, inv_wscale, bias, gamma, beta, eps, X, Xp, Tptr, K);
     return 0;
 }
 
@@ -2475,7 +2486,10 @@ template <int TN>
 int launch_gemm_x3_ln_tn(int bm, const _Float16* A, const _Float16* Wp, float inv_wscale, const float* bias, const float* gamma,
                          const float* beta, float eps, float* X, float* Xp, const int* Tptr, int64_t Tmax, int K, int device,
                          hipStream_t s) {
-    if (bm == 128) return launch_gemm_x3_ln_inst<128, 2, TN>(A, Wp, inv_wscale, bias, gamma, beta, eps, X, Xp, Tptr, Tmax, K, device, s);
+    // (H = 512 at 128 rows: two 80-KiB stages are the whole LDS, no room for the row statistics behind them: 64 rows there)
+    if constexpr (TN < 4)
+        if (bm == 128) return launch_gemm_x3_ln_inst<128, 2, TN>(A, Wp, inv_wscale, bias, gamma, beta, eps, X, Xp, Tptr, Tmax, K, device, s);
+    if (bm == 128) bm = 64;
     if (bm == 64) return launch_gemm_x3_ln_inst<64, 2, TN>(A, Wp, inv_wscale, bias, gamma, beta, eps, X, Xp, Tptr, Tmax, K, device, s);
     return launch_gemm_x3_ln_inst<32, 1, TN>(A, Wp, inv_wscale, bias, gamma, beta, eps, X, Xp, Tptr, Tmax, K, device, s);
 }

@@ -80,6 +80,25 @@ def test_split_precision_kernel_variants_match_golden(i, switches, gpu, monkeypa
     enc.close()
 
 
+@pytest.mark.parametrize("env", [{"MVDB_GEMM_X3_BIG": "1"}, {"MVDB_GEMM_X3_BIG": "1", "MVDB_GEMM_X3_PERSIST": "0"},
+                                 {"MVDB_GEMM_X3_SPREAD": "0", "MVDB_GEMM_X3_SPREAD_SMALL": "0", "MVDB_GEMM_LN_SPREAD": "0"}],
+                         ids=["persistent-256-row-tiles-forced", "one-tile-per-workgroup-256-row-tiles-forced", "dma-burst"])
+def test_gemm_tile_forms_match_golden_in_a_fresh_process(env, gpu):
+    """The tile-form switches of the split-precision GEMMs are read once per process: a child pytest runs every split-mode
+    golden case with (a) the persistent 256-row kernel FORCED onto batches it would never be chosen for (fewer tiles than
+    CUs, a last row band of a few rows), (b) its one-tile-per-workgroup predecessor, (c) the LDS-DMA instructions issued as
+    one burst per K-step instead of between the MFMAs."""
+    import os
+    import subprocess
+    import sys
+    child_env = dict(os.environ, **env)
+    r = subprocess.run([sys.executable, "-m", "pytest", __file__, "-q", "-x", "-m", "gpu", "-k",
+                        "test_encoder_matches_transformers_golden and fp16x3"], env=child_env, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-500:]
+
+
 def test_batch_composition_does_not_change_a_row(gpu, monkeypatch):
     """A sentence's embedding is bit-for-bit the same whatever else is in the batch and wherever its rows fall in a tile
     (the reference semantics are B = 1).  Round 3 found hipcc contracting `a * b + c` INTO the fp16 conversion of the
