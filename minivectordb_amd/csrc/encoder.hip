@@ -1272,6 +1272,8 @@ __global__ __launch_bounds__(WM * 256) void gemm_x3_ln_kernel(const _Float16* __
     // w, w + G, ... and the K-step pipeline runs through the band boundary as in gemm_x3_big_kernel (the next band's first
     // stage lands under the LayerNorm epilogue; the row statistics have their own LDS behind the ring).  The three-stage
     // form (BM = 32: T = 8192) stays one band per workgroup: its counted waits would have to count the epilogue's loads.
+    // (Tried on that form and dropped: four more waves that only issue the ring's DMAs, so that the compute waves — one per
+    //  SIMD there — never stall in the vector-memory path: 1.91 ms per S = 32 forward either way.)
     constexpr bool PERS = NST == 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char xsm[];
     float* red = reinterpret_cast<float*>(xsm + NST * kStage);  // [2 passes][WN column waves][BM rows]
