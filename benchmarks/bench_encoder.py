@@ -56,7 +56,7 @@ def main():
             t = t + 1.0
         sd[name] = t
     enc = GpuEncoder(cfg, sd, device=0)
-    B = 256
+    B = int(os.environ.get("MVDB_BENCH_B", "256"))
     for S in [int(v) for v in os.environ.get("MVDB_BENCH_S", "32,512").split(",")]:
         rs = np.random.RandomState(S)
         ids = torch.from_numpy(rs.randint(5, 250000, size=(B, S)).astype(np.int32)).to(dev)
