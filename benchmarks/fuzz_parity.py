@@ -1,7 +1,9 @@
 """Randomised GPU parity fuzz: random (n, d, nq, k, metric, subset, normalisation) cases through the C-ABI,
-each query adjudicated against the float64 oracle.  usage: fuzz_parity.py SEED SECONDS [split] (on a GPU box);
-`split` biases the cases towards the split-precision batch pass (nq >= 40, k <= 12, d % 32 == 0, up to 400k rows so
-that the seed launch runs too) and reports how many chunks fell back to the exact kernels."""
+each query adjudicated against the float64 oracle.  usage: fuzz_parity.py SEED SECONDS [split | masked] (on a GPU box);
+`split` biases the cases towards the certified batch passes (nq >= 40, k <= 32, d % 32 == 0, up to 400k rows so
+that the seed launch runs too) and reports how many chunks fell back to the exact kernels; `masked` is `split` under a
+random BITMAP (density 0.02 .. 0.99, any nq >= 2: the fp16 pass, the fp32-MFMA pass and the one-query scan all take it),
+half of the cases through a resident row set."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -10,7 +12,8 @@ from minivectordb_amd import _native as native
 rs = np.random.RandomState(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 dims = [1,2,3,4,5,7,8,16,31,32,33,48,64,96,100,128,160,192,224,256,300,384,512,640,768,1000,1024,1100,2048,4096]
 t_end = time.time() + float(sys.argv[2]) if len(sys.argv) > 2 else time.time() + 120
-split_mode = len(sys.argv) > 3 and sys.argv[3] == "split"
+masked_mode = len(sys.argv) > 3 and sys.argv[3] == "masked"
+split_mode = masked_mode or (len(sys.argv) > 3 and sys.argv[3] == "split")
 cases = fails = 0
 reruns0 = native.split_rerun_count()
 while time.time() < t_end:
@@ -20,11 +23,12 @@ while time.time() < t_end:
     k = int(rs.choice([1,2,5,10,63,64,65,100,300, rs.randint(1, 200)]))
     metric = int(rs.choice([0,0,0,1]))
     if split_mode:
-        d = int(rs.choice([32, 64, 96, 128, 256, 384, 512, 768, 1024]))
+        d = int(rs.choice([32, 64, 96, 128, 256, 384, 512, 640, 768, 896, 1024]))
         n = int(rs.choice([15, 16, 17, 127, 128, 129, 1000, rs.randint(1, 20000), rs.randint(262144, 400000)]))
         nq = int(rs.choice([40, 41, 64, 127, 128, 129, 200, 256, rs.randint(40, 300)]))
-        k = int(rs.randint(1, 13))
+        k = int(rs.randint(1, 33))
         metric = 0
+        if masked_mode: nq = int(rs.choice([2, 8, 31, 32, 33, nq, nq]))
     if n * d > 30_000_000: n = 30_000_000 // d
     x = flat.synth(n, d, rs.randint(1<<30)); 
     if rs.rand() < 0.7: flat.normalize_l2(x)
@@ -34,7 +38,19 @@ while time.time() < t_end:
     idx = native.FlatIndex(d, metric=metric)
     idx.add(x)
     subset = None
-    if rs.rand() < 0.3 and n > 1:
+    if masked_mode and n > 1:
+        dens = float(rs.choice([0.02, 0.3, 0.5, 0.9, 0.99]))
+        sel = rs.rand(n) < dens
+        sel[rs.randint(n)] = True
+        subset = np.flatnonzero(sel).astype(np.int64)
+        if rs.rand() < 0.5:
+            D, I = idx.search_masked(q, k, native.pack_row_mask(n, rows=subset), normalize_q=normq, labels="positions")
+        else:
+            rset = idx.rowset(np.flatnonzero(~sel).astype(np.int64), excluded=True)
+            D, I = idx.search_rowset(q, k, rset, normalize_q=normq)
+            rset.close()
+            I = np.where(I >= 0, np.searchsorted(subset, np.maximum(I, 0)), -1)   # row numbers -> positions in the selection
+    elif rs.rand() < 0.3 and n > 1:
         m = rs.randint(1, n+1); subset = rs.permutation(n)[:m].astype(np.int64)
         D, I = idx.search_subset(q, k, subset, normalize_q=normq)
     else:
