@@ -3,6 +3,18 @@ import sys
 
 import pytest
 
+# The float64 adjudication of the oracle is thousands of SMALL numpy products; on a 128-core box the default BLAS / OpenMP
+# thread pools make each of them ~0.1 s (measured: 14 fuzz cases in 200 s instead of ~900).  Bound them unless the caller
+# has chosen — before numpy loads where possible, through threadpoolctl otherwise.
+for _v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+    os.environ.setdefault(_v, "8")
+if "numpy" in sys.modules:
+    try:
+        from threadpoolctl import threadpool_limits
+        threadpool_limits(limits=int(os.environ["OMP_NUM_THREADS"]))
+    except Exception:  # pragma: no cover - best effort
+        pass
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
