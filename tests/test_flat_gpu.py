@@ -666,12 +666,10 @@ def test_fp16_certificate_at_the_margin_k32(native, frac, must_rerun):
     idx.close()
 
 
-@pytest.mark.parametrize("requery_max", [64, 1])
-def test_uncertified_queries_are_rerun_one_by_one(native, monkeypatch, requery_max):
+def test_uncertified_queries_are_rerun_one_by_one(native):
     """200 queries, three of them with 40 exact copies of their best row in the corpus: those three fail the certificate
-    and ONLY they are re-run on the exact kernels, gathered into one compact batch (requery_max = 64); with the limit at
-    1 the old route — whole chunks on the exact kernels — is taken.  Either way every query's result is exact."""
-    monkeypatch.setenv("MVDB_SPLIT_REQUERY_MAX", str(requery_max))
+    and ONLY they are re-run on the exact kernels, gathered on the device into one compact batch (the launches of the
+    re-run are gated by the device-side count: the host never learns which queries they were).  Every result is exact."""
     n, d, k, nq = 30000, 512, 10, 200
     x = _corpus(n, d)
     q = _corpus(nq, d, seed=77)
