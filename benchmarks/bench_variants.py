@@ -116,6 +116,12 @@ def main():
     dt = timeit(lambda: idxl.search(q[0], 10), 20)
     print(json.dumps({"what": "L2 metric full search k=10", "ms": round(dt * 1e3, 3), "GBps": round(n * row_bytes / dt / 1e9, 1)}),
           flush=True)
+    ql = flat.synth(32, d, 77)
+    flat.normalize_l2(ql)
+    out = {"what": "L2 metric, several queries per call (fp32-MFMA pass: |q|^2 + |x|^2 - 2 q.x), k=10"}
+    for nb in (8, 32):
+        out[f"nq{nb}_ms"] = round(timeit(lambda: idxl.search(ql[:nb], 10), 5) * 1e3, 3)
+    print(json.dumps(out), flush=True)
     idxl.close()
 
 

@@ -101,10 +101,12 @@ int mvdb_index_remove_rows(mvdb_index* idx, const int64_t* rows_host, int64_t m)
  * normalize_q != 0 L2-normalises each query on the device first.
  * Every path returns exact-fp32 scores of the exact top-k: batches of >= 14 queries (k <= 12) are
  * NOMINATED on the low-precision matrix cores (14..32 queries: bf16 (hi, lo) split-precision product,
- * 16 nominees; 33+ queries at d = 256 / 384 / 512 / 768: one fp16 product, 64 nominees, 128 or 256
- * queries per corpus pass), then re-scored in fp32 and certified per query against the nomination's
+ * 16 nominees; 33+ queries (k <= 32) at d = 256 / 384 / 512 / 640 / 768 / 896 / 1024: one fp16 product, 64 nominees,
+ * 128 or 256 queries per corpus pass), then re-scored in fp32 and certified per query against the nomination's
  * worst-case error bound; queries that cannot be certified are re-run on the exact fp32 kernels
- * (mvdb_split_rerun_count counts the chunks that held one).
+ * (mvdb_split_rerun_count counts the chunks that held one).  MVDB_METRIC_L2 (an extension: the reference builds
+ * IndexFlatIP only): one query sums (q - x)^2 directly; several queries share corpus passes on the fp32 matrix cores
+ * as |q|^2 + |x|^2 - 2 q.x (d % 128 == 0, d <= 768; differences of the two forms are at the rounding level of the norms).
  * Replaces faiss.normalize_L2(embedding) + index.search(embedding, search_k)
  *                                                minivectordb/vector_database.py:475, :497
  *                                                minivectordb/sharded_vector_database.py:604, :626 */

@@ -469,8 +469,8 @@ int launch_mfma2_gated_inst(const MfmaScanArgs& a, int device, hipStream_t strea
 }
 
 template <int KB, int NG, int SKB>
-int launch_mfma2_inst(const MfmaScanArgs& a, int device, hipStream_t stream, int* nblocks_out) {
-    auto kern = flat_scan_mfma2_kernel<KB, NG, SKB>;
+int launch_mfma2_inst(const MfmaScanArgs& a, int device, hipStream_t stream, int* nblocks_out, int metric = MVDB_METRIC_IP) {
+    auto kern = metric == MVDB_METRIC_L2 ? flat_scan_mfma2_kernel<KB, NG, SKB, 1> : flat_scan_mfma2_kernel<KB, NG, SKB, 0>;
     const size_t lds = (size_t)kScanWaves * mfma2_wave_lds_bytes(SKB) + (size_t)kScanWaves * NG * 16 * a.k * 8;
     MVDB_TRY(ensure_dynamic_lds((const void*)kern, lds, device));
     int nb = 0;
@@ -489,25 +489,25 @@ int launch_mfma2_inst(const MfmaScanArgs& a, int device, hipStream_t stream, int
 }
 
 template <int NG>
-int launch_mfma2(int KB, const MfmaScanArgs& a, int device, hipStream_t s, int* nb) {
+int launch_mfma2(int KB, const MfmaScanArgs& a, int device, hipStream_t s, int* nb, int metric = MVDB_METRIC_IP) {
     // 1-KiB-per-row stages (one contiguous KiB per DMA instruction) measured 2-5 % faster than 512-B
     // stages at 10M x 512; they need 32 KiB of LDS per wave, so fall back when the k-lists do not fit
     const size_t lds_deep = (size_t)kScanWaves * mfma2_wave_lds_bytes(16) + (size_t)kScanWaves * NG * 16 * a.k * 8;
     const bool deep = env_int("MVDB_MFMA_STAGE", 16) == 16 && lds_deep <= 160 * 1024;
     switch (KB) {
-        case 8: return launch_mfma2_inst<8, NG, 8>(a, device, s, nb);
-        case 16: return deep ? launch_mfma2_inst<16, NG, 16>(a, device, s, nb)
-                             : launch_mfma2_inst<16, NG, 8>(a, device, s, nb);
-        case 24: return launch_mfma2_inst<24, NG, 8>(a, device, s, nb);
-        case 32: return deep ? launch_mfma2_inst<32, NG, 16>(a, device, s, nb)
-                             : launch_mfma2_inst<32, NG, 8>(a, device, s, nb);
+        case 8: return launch_mfma2_inst<8, NG, 8>(a, device, s, nb, metric);
+        case 16: return deep ? launch_mfma2_inst<16, NG, 16>(a, device, s, nb, metric)
+                             : launch_mfma2_inst<16, NG, 8>(a, device, s, nb, metric);
+        case 24: return launch_mfma2_inst<24, NG, 8>(a, device, s, nb, metric);
+        case 32: return deep ? launch_mfma2_inst<32, NG, 16>(a, device, s, nb, metric)
+                             : launch_mfma2_inst<32, NG, 8>(a, device, s, nb, metric);
         // d = 768 / 1024 (e5-large, bge-m3 widths): one query group only — the 192 / 256 registers of
         // query fragments leave one wave per SIMD, like two groups at d = 512
-        case 48: if (NG == 1) return deep ? launch_mfma2_inst<48, 1, 16>(a, device, s, nb)
-                                          : launch_mfma2_inst<48, 1, 8>(a, device, s, nb);
+        case 48: if (NG == 1) return deep ? launch_mfma2_inst<48, 1, 16>(a, device, s, nb, metric)
+                                          : launch_mfma2_inst<48, 1, 8>(a, device, s, nb, metric);
                  break;
-        case 64: if (NG == 1) return deep ? launch_mfma2_inst<64, 1, 16>(a, device, s, nb)
-                                          : launch_mfma2_inst<64, 1, 8>(a, device, s, nb);
+        case 64: if (NG == 1) return deep ? launch_mfma2_inst<64, 1, 16>(a, device, s, nb, metric)
+                                          : launch_mfma2_inst<64, 1, 8>(a, device, s, nb, metric);
                  break;
         default: break;
     }
@@ -910,8 +910,11 @@ int launch_half_pass(const mvdb_index* idx, Workspace* ws, const float* q, int n
 
 bool mfma_path_ok(const mvdb_index* idx, int nq, int k, const int64_t* rows_dev) {
     if (env_int("MVDB_DISABLE_MFMA_SCAN", 0)) return false;
-    if (nq < 2 || k > kMaxFusedK || rows_dev || idx->metric != MVDB_METRIC_IP) return false;
+    if (nq < 2 || k > kMaxFusedK || rows_dev) return false;
     if (idx->d % 16 || idx->ld != idx->d) return false;
+    // squared L2 as |q|^2 + |x|^2 - 2 q.x: the staged kernel only (it sees whole rows go by)
+    // (d <= 768: at d = 1024 the L2 form of the kernel spills; two 16-query groups only up to d = 384, same reason)
+    if (idx->metric != MVDB_METRIC_IP && !(idx->d % 128 == 0 && idx->d <= 768 && env_int("MVDB_MFMA_V", 2) == 2 && !env_int("MVDB_DISABLE_L2_MFMA", 0))) return false;
     const int KB = idx->d / 16;
     return KB == 4 || KB == 8 || KB == 16 || KB == 24 || KB == 32 || KB == 48 || KB == 64;
 }
@@ -1208,7 +1211,7 @@ int search_core(const mvdb_index* idx, Workspace* ws, const float* q_dev, int nq
             // staged kernel: 32 queries per pass (two query groups share each B fragment); the v1
             // kernel with two groups runs at one wave per SIMD and loses to two 16-query passes
             const bool staged = idx->d % 128 == 0 && env_int("MVDB_MFMA_V", 2) == 2;
-            const bool two_groups = left > 16 && idx->d <= 512 && env_int("MVDB_MFMA_NG2", staged ? 1 : 0);
+            const bool two_groups = left > 16 && idx->d <= (idx->metric == MVDB_METRIC_IP ? 512 : 384) && env_int("MVDB_MFMA_NG2", staged ? 1 : 0);
             const int take = two_groups ? std::min(left, 32) : std::min(left, 16);
             MfmaScanArgs ma;
             ma.X = idx->X;
@@ -1221,11 +1224,11 @@ int search_core(const mvdb_index* idx, Workspace* ws, const float* q_dev, int nq
             int nblocks = 0;
             const int KB = idx->d / 16;
             if (take > 16 && staged)
-                MVDB_TRY(launch_mfma2<2>(KB, ma, idx->device, s, &nblocks));
+                MVDB_TRY(launch_mfma2<2>(KB, ma, idx->device, s, &nblocks, idx->metric));
             else if (take > 16)
                 MVDB_TRY(launch_mfma_ng<2>(KB, ma, idx->device, s, &nblocks));
             else if (staged)
-                MVDB_TRY(launch_mfma2<1>(KB, ma, idx->device, s, &nblocks));  // LDS-DMA staged, coalesced
+                MVDB_TRY(launch_mfma2<1>(KB, ma, idx->device, s, &nblocks, idx->metric));  // LDS-DMA staged, coalesced
             else
                 MVDB_TRY(launch_mfma_ng<1>(KB, ma, idx->device, s, &nblocks));
             MergeArgs mg;

@@ -179,7 +179,7 @@ typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 constexpr int mfma2_stage_bytes(int skb) { return 16 * skb * 64; }
 constexpr int mfma2_wave_lds_bytes(int skb) { return 2 * mfma2_stage_bytes(skb); }
 
-template <int KB, int NG, int SKB, bool MASKED = false>
+template <int KB, int NG, int SKB, bool MASKED = false, int METRIC = 0>
 __device__ __forceinline__ void flat_scan_mfma2_body(const MfmaScanArgs& a) {
     static_assert(KB % SKB == 0 && (SKB == 8 || SKB == 16), "d must be a multiple of the stage depth");
     constexpr int NS = KB / SKB;  // stages per tile
@@ -207,6 +207,23 @@ __device__ __forceinline__ void flat_scan_mfma2_body(const MfmaScanArgs& a) {
     for (int g = 0; g < NG; ++g)
 #pragma unroll
         for (int r = 0; r < 4; ++r) thr[g][r] = (g * 16 + 4 * (lane >> 4) + r) < a.nq ? -INFINITY : INFINITY;
+    // METRIC 1 (squared L2 by |q|^2 + |x|^2 - 2 q.x; the lists keep -distance as everywhere): |q|^2 of the four queries
+    // whose scores this lane's accumulator registers hold — query g 16 + 4 (lane >> 4) + r
+    float qn[NG][4];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        float qs = 0.f;
+        if (METRIC == 1) {
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) qs = fmaf(qa[g][kb][j], qa[g][kb][j], qs);
+            qs += __shfl_xor(qs, 16);
+            qs += __shfl_xor(qs, 32);  // |q|^2 of query g 16 + (lane & 15), on all four k-group lanes
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) qn[g][r] = METRIC == 1 ? __shfl(qs, 4 * (lane >> 4) + r) : 0.f;
+    }
 
     const int64_t ntiles = (a.n + 15) / 16;
     const int64_t nwaves_total = (int64_t)gridDim.x * kScanWaves;
@@ -250,6 +267,7 @@ __device__ __forceinline__ void flat_scan_mfma2_body(const MfmaScanArgs& a) {
         uint32_t mw = 0xffffffffu;  // MASKED: the bitmap word holding this tile's 16 rows, requested before the tile's stages
         if (MASKED) mw = a.mask[tile >> 1];
         f32x4m acc0[NG], acc1[NG];
+        float xs = 0.f;  // METRIC 1: this lane's share of |x|^2 of row tile 16 + (lane & 15)
 #pragma unroll
         for (int g = 0; g < NG; ++g) acc0[g] = acc1[g] = f32x4m{0, 0, 0, 0};
 #pragma unroll
@@ -273,6 +291,12 @@ __device__ __forceinline__ void flat_scan_mfma2_body(const MfmaScanArgs& a) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
             if (t2 < ntiles) issue_stage(t2, (ks + 2) % NS, buf);  // refill the buffer just drained
+            if (METRIC == 1) {
+#pragma unroll
+                for (int kbl = 0; kbl < SKB; ++kbl)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) xs = fmaf(xb[kbl][j], xb[kbl][j], xs);
+            }
 #pragma unroll
             for (int kbl = 0; kbl < SKB; ++kbl) {
                 const int kb = ks * SKB + kbl;
@@ -292,6 +316,14 @@ __device__ __forceinline__ void flat_scan_mfma2_body(const MfmaScanArgs& a) {
         f32x4m acc[NG];
 #pragma unroll
         for (int g = 0; g < NG; ++g) acc[g] = acc0[g] + acc1[g];
+        if (METRIC == 1) {
+            xs += __shfl_xor(xs, 16);
+            xs += __shfl_xor(xs, 32);  // |x|^2 of this lane's row
+#pragma unroll
+            for (int g = 0; g < NG; ++g)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[g][r] = (2.f * acc[g][r] - xs) - qn[g][r];  // -(|q|^2 + |x|^2 - 2 q.x)
+        }
         mfma_tile_select<NG>(acc, thr, tile * 16 + fr <= last && ((mw >> ((int)(tile & 1) * 16 + fr)) & 1u), (uint32_t)(tile * 16 + fr), a.nq, k,
                              mylists, lane);
         tile = next_tile;
@@ -301,9 +333,9 @@ __device__ __forceinline__ void flat_scan_mfma2_body(const MfmaScanArgs& a) {
     mfma_block_merge<NG>(lists, a.nq, k, a.cand, lane, wave);
 }
 
-template <int KB, int NG, int SKB>
+template <int KB, int NG, int SKB, int METRIC = 0>
 __global__ __launch_bounds__(kScanThreads) void flat_scan_mfma2_kernel(MfmaScanArgs a) {
-    flat_scan_mfma2_body<KB, NG, SKB>(a);
+    flat_scan_mfma2_body<KB, NG, SKB, false, METRIC>(a);
 }
 // enabled by a device-side count (the whole pass runs iff *gate > gate_lo; gate == NULL: always): see flat_scan_gated_kernel.
 // MASKED: only rows whose bit is set in a.mask are offered to the lists (bitmap-selected batches and their exact re-runs).

@@ -216,6 +216,40 @@ def test_l2_metric_extension(native):
     idx.close()
 
 
+@pytest.mark.parametrize("d,nq,k", [(128, 2, 10), (512, 8, 10), (384, 32, 5), (512, 40, 64), (768, 20, 10), (1024, 5, 3), (100, 4, 7)])
+@pytest.mark.parametrize("normalized", [True, False])
+def test_l2_batches_share_corpus_passes(native, d, nq, k, normalized):
+    """Squared L2 with several queries per call: the staged fp32-MFMA pass computes |q|^2 + |x|^2 - 2 q.x (whole rows go
+    through its LDS ring, so |x|^2 costs no extra read); one query at a time the scan sums (q - x)^2 directly.  Both must
+    agree with the float64 adjudication (the expansion cancels: tolerance scales with the magnitude of the distances), ties
+    (a planted duplicate row) resolve to the lower row, and a query equal to a stored row finds it at distance ~0."""
+    n = 30_000
+    x = flat.synth(n, d, 21)
+    if normalized:
+        flat.normalize_l2(x)
+    x[17_000] = x[123]
+    q = flat.synth(nq, d, 22)
+    if normalized:
+        flat.normalize_l2(q)
+    q[0] = x[123]
+    idx = native.FlatIndex(d, metric=native.METRIC_L2)
+    idx.add(x)
+    D, I = idx.search(q, k)
+    assert I[0, :2].tolist() == [123, 17_000]
+    mag = float(max(1.0, np.abs(D).max()))
+    assert abs(D[0, 0]) <= 4e-6 * mag
+    assert np.all(np.diff(D, axis=1) >= -4e-6 * mag)
+    Do, Io = flat.flat_search(x, q, k, metric=flat.METRIC_L2)
+    for i in range(nq):
+        ok, msg = flat.adjudicate(x, q[i], k, D[i], I[i], metric=flat.METRIC_L2, tol=1e-4 * mag, tie_eps=4e-6 * mag)
+        assert ok, f"query {i}: {msg}"
+    np.testing.assert_allclose(D, Do, atol=1e-5 * mag, rtol=0)
+    for i in (0, nq - 1):                                       # the same query alone: the direct form
+        D1, I1 = idx.search(q[i], k)
+        np.testing.assert_allclose(D1[0], D[i], atol=1e-5 * mag, rtol=0)
+    idx.close()
+
+
 def test_remove_rows_matches_np_delete(native):
     n, d = 3000, 64
     x = _corpus(n, d)
