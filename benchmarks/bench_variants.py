@@ -17,11 +17,16 @@ from oracle import flat  # noqa: E402
 
 
 def timeit(fn, reps):
-    fn()
-    t0 = time.perf_counter()
-    for _ in range(reps):
+    """Median of `reps` calls after three warm-up calls: the first calls of a kernel variant in a process pay one-off costs
+    (code-object load, LDS attribute, workspace growth — up to ~100 ms, and not always on the very first call)."""
+    for _ in range(3):
         fn()
-    return (time.perf_counter() - t0) / reps
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t0)
+    return float(np.median(ts))
 
 
 def main():
