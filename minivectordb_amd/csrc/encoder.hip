@@ -707,8 +707,8 @@ __device__ __forceinline__ void x3_split2(float a, float b, uint32_t& hi, uint32
 //   * a row's LayerNorm statistics are sums over the lane's OWN registers plus one exchange with the other half.
 // The stores of a big tile were issue-bound: 128 dword stores per lane on a 256 x 256 tile, as long as its K loop at K = 384.
 // Where a GEMM's time goes NOW (ablation build, make ABLATE=1: MVDB_GEMM_X3_DBG = 3 K loop only / 4 epilogue only; us per launch,
-// full / K loop only / epilogue only): T = 131072  QKV 377 / 270 / 113, FFN1 506 / 344 / 181, N = H + LayerNorm 372 / 214 / 131;
-// T = 8192  33.9 / 24.8 / 11.8, 37.8 / 27.9 / 13.1, 36.0 / 23.6 / 10.8 (launch ramp in both parts; profiles/r03_x3_ablations.txt).  The per-tile timeline
+// full / K loop only / epilogue only): T = 131072  QKV 377 / 277 / 126, FFN1 525 / 352 / 182, N = H + LayerNorm 382 / 222 / 136;
+// T = 8192  35.3 / 25.4 / 11.8, 39.4 / 29.1 / 13.1, 33.5 / 22.7 / 10.8 (launch ramp in both parts; profiles/r03_x3_ablations.txt).  The per-tile timeline
 // (DBG = 5, benchmarks/x3_timeline.py) of FFN1 at T = 131072: K loop 25.6 us = 47.6k cycles at the 1.87 GHz the chip holds
 // there, against 36.9k cycles of MFMA issue; epilogue 10 us until the FIRST wave has issued its stores and ~4.6 more until
 // the last one has — GELU + the (hi, lo) split are ~25 VALU instructions per element, 128 elements per lane: the FFN1
