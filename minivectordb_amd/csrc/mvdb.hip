@@ -273,7 +273,7 @@ int launch_scan_kern(const ScanArgs& a, int nq, int device, hipStream_t stream, 
             nb <= 0)
             nb = 4;
         occ_hw = nb;
-        // measured on MI355X (benchmarks/sweep_scan2.py, 10M x 512, gpurun_out/sweep4.log): with ~4
+        // measured on MI355X (round-1 sweep, profiles/r01_sweep_scan_variants.txt, 10M x 512): with ~4
         // independent 16-B loads per lane, 2 resident blocks (8 waves) per CU reach 7.21-7.24 TB/s; more
         // waves or more loads in flight per lane are 2-4 % slower, 1 block per CU is latency-starved
         // (gpurun_out/sweep_dims.log: the one- and three-chunk shapes — d = 64 / 256 / 384 — prefer U = 4 with
@@ -344,31 +344,9 @@ int ensure_dynamic_lds(const void* kern, size_t lds, int device) {
 int launch_scan(int metric, int mode, const ScanArgs& a, int nq, int device, hipStream_t s,
                 int* nblocks) {
     const Shape sh = choose_shape(a.d4);
-    if (sh.G == 64 && sh.C == 2 && metric == MVDB_METRIC_IP && mode == kModeTopK) {
-        // tuning hook for the headline shape (d = 512): MVDB_SCAN_VARIANT = U*100 + NT
-        switch (env_int("MVDB_SCAN_VARIANT", -1)) {
-            case 201: return launch_scan_inst<64, 2, 2, 0, kModeTopK, true>(a, nq, device, s, nblocks);
-            case 400: return launch_scan_inst<64, 2, 4, 0, kModeTopK, false>(a, nq, device, s, nblocks);
-            case 401: return launch_scan_inst<64, 2, 4, 0, kModeTopK, true>(a, nq, device, s, nblocks);
-            case 801: return launch_scan_inst<64, 2, 8, 0, kModeTopK, true>(a, nq, device, s, nblocks);
-            default: break;
-        }
-    }
-    {   // tuning hook for other shapes: MVDB_SCAN_U in {1,2,4,8} overrides the rows in flight per wave
-        const int u = env_int("MVDB_SCAN_U", 0);
-#define MVDB_SCAN_U_CASE(G_, C_)                                                                        \
-    if (u && sh.G == G_ && sh.C == C_) {                                                                \
-        if (u == 1) return launch_scan_gcu<G_, C_, 1>(metric, mode, a, nq, device, s, nblocks);          \
-        if (u == 2) return launch_scan_gcu<G_, C_, 2>(metric, mode, a, nq, device, s, nblocks);          \
-        if (u == 4) return launch_scan_gcu<G_, C_, 4>(metric, mode, a, nq, device, s, nblocks);          \
-        if (u == 8) return launch_scan_gcu<G_, C_, 8>(metric, mode, a, nq, device, s, nblocks);          \
-    }
-        MVDB_SCAN_U_CASE(32, 3)
-        MVDB_SCAN_U_CASE(64, 1)
-        MVDB_SCAN_U_CASE(64, 4)
-        MVDB_SCAN_U_CASE(16, 1)
-#undef MVDB_SCAN_U_CASE
-    }
+    // (Rounds 1 - 2 carried run-time tuning hooks here — MVDB_SCAN_VARIANT, MVDB_SCAN_U: other rows-in-flight counts per shape,
+    //  17 more shapes x 24 kernels each; the sweeps they served are in profiles/r01_sweep_scan_variants.txt.  Removed in round 3:
+    //  they were 40 % of this code object, which a process loads whole before its first search.)
     // Row-list (gather) scans of two- and three-chunk rows keep FOUR rows in flight per wave (the streaming scan: two): a
     // gathered row is a fresh DRAM page, so more rows must be outstanding to cover its latency — 10M x 512 rows resident,
     // ids on the device: 10 % of the rows 5.74 -> 6.23 TB/s of rows touched, 50 % 6.37 -> 6.78, 99 % 6.54 -> 6.95.
