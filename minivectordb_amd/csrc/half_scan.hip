@@ -53,6 +53,12 @@
 
 namespace mvdb {
 
+#ifndef MVDB_HQ_AHEAD_WIDE
+#define MVDB_HQ_AHEAD_WIDE 6
+#endif
+constexpr int kAheadWide = MVDB_HQ_AHEAD_WIDE;  // fragment reads in flight ahead of the MFMAs, 256 queries at d = 512: with 8 (the other
+                                                // forms' value) the kernel spills 28 bytes at 256 registers; 6: none, +1.7 % q/s
+
 typedef _Float16 hs_h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 hs_h2 __attribute__((ext_vector_type(2)));
 typedef float hs_f2 __attribute__((ext_vector_type(2)));
@@ -619,7 +625,7 @@ __global__ __launch_bounds__(WV * 64) void flat_scan_hq_kernel(HalfScanArgs a) {
         auto frag = [&](int kb) { return *reinterpret_cast<const hs_h8*>(src + (((2 * kb + fk) ^ fsw) << 4)); };
         // fragments three 16-k blocks ahead of the MFMAs that use them (hipcc otherwise reuses ONE register quad and
         // waits for every read: ds_read, lgkmcnt(0), two MFMAs, ds_read ... with the LDS latency exposed each time)
-        constexpr int AHEAD = (KH < 8 ? KH : 8);
+        constexpr int AHEAD = (WV == 8 && KT >= 32) ? kAheadWide : (KH < 8 ? KH : 8);
         hs_h8 f[AHEAD + 1];
 #pragma unroll
         for (int u = 0; u < AHEAD; ++u) f[u] = frag(u);
@@ -653,7 +659,7 @@ __global__ __launch_bounds__(WV * 64) void flat_scan_hq_kernel(HalfScanArgs a) {
     auto piped_half = [&](int half, int hb, const Raw& x, int64_t base, int c) {
         const unsigned char* src = hbuf + hb * kH + frow;
         auto frag = [&](int kb) { return *reinterpret_cast<const hs_h8*>(src + (((2 * kb + fk) ^ fsw) << 4)); };
-        constexpr int AHEAD = (KH < 8 ? KH : 8);
+        constexpr int AHEAD = (WV == 8 && KT >= 32) ? kAheadWide : (KH < 8 ? KH : 8);
         constexpr int D0 = 1, DS = (KH / 2 - D0) / DPW > 0 ? (KH / 2 - D0) / DPW : 1;  // DMA piece i after MFMA block D0 + i DS
         constexpr int C0 = D0 + DPW * DS, CS = (KH - C0) / DPW > 0 ? (KH - C0) / DPW : 1;  // converted piece i after block C0 + i CS
         hs_h8 f[AHEAD + 1];
