@@ -448,7 +448,15 @@ int launch_mfma2_gated_inst(const MfmaScanArgs& a, int device, hipStream_t strea
 
 template <int KB, int NG, int SKB>
 int launch_mfma2_inst(const MfmaScanArgs& a, int device, hipStream_t stream, int* nblocks_out, int metric = MVDB_METRIC_IP) {
-    auto kern = metric == MVDB_METRIC_L2 ? flat_scan_mfma2_kernel<KB, NG, SKB, 1> : flat_scan_mfma2_kernel<KB, NG, SKB, 0>;
+    // the L2 form exists where it fits the registers (mfma_path_ok / two_groups route L2 batches accordingly)
+    constexpr bool kL2Form = KB <= 48 && !(KB == 32 && NG == 2);
+    auto kern = flat_scan_mfma2_kernel<KB, NG, SKB, 0>;
+    if (metric == MVDB_METRIC_L2) {
+        if constexpr (kL2Form)
+            kern = flat_scan_mfma2_kernel<KB, NG, SKB, 1>;
+        else
+            return fail(MVDB_ERR_ARG, "no L2 form of the staged multi-query kernel for d = %d with %d query group(s)", KB * 16, NG);
+    }
     const size_t lds = (size_t)kScanWaves * mfma2_wave_lds_bytes(SKB) + (size_t)kScanWaves * NG * 16 * a.k * 8;
     MVDB_TRY(ensure_dynamic_lds((const void*)kern, lds, device));
     int nb = 0;
