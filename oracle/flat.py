@@ -45,6 +45,12 @@ def lib():
         L.oracle_flat_search_f64.argtypes = [f32p, ctypes.c_int64, ctypes.c_int, f32p, ctypes.c_int, ctypes.c_int,
                                              ctypes.c_int, ctypes.c_int, i64p, ctypes.c_int, f64p, i64p]
         L.oracle_flat_search_f64.restype = None
+        u8p = ctypes.POINTER(ctypes.c_uint8)
+        L.oracle_flat_search_block.argtypes = [f32p, ctypes.c_int64, ctypes.c_int, f32p, ctypes.c_int, ctypes.c_int,
+                                               ctypes.c_int, ctypes.c_int64, u8p, ctypes.c_int, f32p, i64p]
+        L.oracle_flat_search_block.restype = None
+        L.oracle_merge_topk.argtypes = [f32p, i64p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, f32p, i64p]
+        L.oracle_merge_topk.restype = None
         L.oracle_scores_f64.argtypes = [f32p, ctypes.c_int, f32p, ctypes.c_int, i64p, ctypes.c_int64, f64p]
         L.oracle_scores_f64.restype = None
         L.oracle_max_threads.restype = ctypes.c_int
@@ -101,6 +107,41 @@ def flat_search(x, q, k, metric=METRIC_IP, normalize_q=False, rows=None, nthread
         D = np.empty((nq, k), dtype=np.float32)
         lib().oracle_flat_search(xp, n, d, qp, nq, k, metric, int(normalize_q), rp, nthreads,
                                  D.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), Ip)
+    return D, I
+
+
+def flat_search_block(x, q, k, id_base=0, metric=METRIC_IP, keep=None, nthreads=None):
+    """All queries against ONE block of rows (labels id_base + row): the arithmetic and (score, id) order of
+    flat_search, looped tile-major so that many queries share each pass over the block.  keep: optional uint8[n], rows
+    with 0 are outside the searched set.  Returns (D [nq,k], I [nq,k])."""
+    x, xp = _f32(x)
+    q, qp = _f32(np.atleast_2d(np.asarray(q, dtype=np.float32)))
+    nq, d = q.shape
+    assert x.ndim == 2 and x.shape[1] == d
+    kp = None
+    if keep is not None:
+        keep = np.ascontiguousarray(keep, dtype=np.uint8)
+        assert keep.shape == (x.shape[0],)
+        kp = keep.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8))
+    D = np.empty((nq, k), dtype=np.float32)
+    I = np.empty((nq, k), dtype=np.int64)
+    lib().oracle_flat_search_block(xp, x.shape[0], d, qp, nq, k, metric, int(id_base), kp,
+                                   int(nthreads or max_threads()), D.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
+                                   I.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)))
+    return D, I
+
+
+def merge_topk(parts, metric=METRIC_IP):
+    """Top-k of the union of per-block results [(D [nq,k], I [nq,k]), ...] by the oracle's total order."""
+    Dp = np.ascontiguousarray(np.stack([p[0] for p in parts]), dtype=np.float32)
+    Ip = np.ascontiguousarray(np.stack([p[1] for p in parts]), dtype=np.int64)
+    _, nq, k = Dp.shape
+    D = np.empty((nq, k), dtype=np.float32)
+    I = np.empty((nq, k), dtype=np.int64)
+    lib().oracle_merge_topk(Dp.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
+                            Ip.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), Dp.shape[0], nq, k, metric,
+                            D.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
+                            I.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)))
     return D, I
 
 

@@ -242,6 +242,85 @@ void oracle_flat_search_f64(const float* x, int64_t n, int d, const float* q, in
     search_impl(x, n, d, q, nq, k, metric, normalize_q, rows, 1, nthreads, NULL, D64, I);
 }
 
+/*
+ * Many queries over ONE block of rows, for the full-size parity tests (tests/bigcheck.py streams a 10M / 80M-row device
+ * corpus through here in 1M-row blocks).  The SAME arithmetic and order as oracle_flat_search — every (query, row) pair is
+ * one dot_f32 / l2sqr_f32, candidates are ordered by (score desc, id asc) — only the loop nest differs: threads own row
+ * ranges, walk them in tiles that stay in their cache and score every query against a tile before moving on (the
+ * per-query scan above re-streams the block from DRAM once per query).  Labels are id_base + row, so per-block results
+ * merge on the host by the same total order (oracle_merge_topk).  Rows with NaN scores never enter, as above.
+ * keep (optional, one byte per row of the block): rows whose byte is 0 are not part of the searched set (a filter).
+ * D[nq,k], I[nq,k]; missing slots -1 / -FLT_MAX (IP) or +FLT_MAX (L2).
+ */
+void oracle_flat_search_block(const float* x, int64_t n, int d, const float* q, int nq, int k, int metric,
+                              int64_t id_base, const uint8_t* keep, int nthreads, float* D, int64_t* I) {
+    if (nthreads < 1) nthreads = 1;
+    const int64_t tile = 128;
+    item_t* heaps = (item_t*)malloc((size_t)nthreads * nq * k * sizeof(item_t));
+    int* cnts = (int*)calloc((size_t)nthreads * nq, sizeof(int));
+#pragma omp parallel for num_threads(nthreads) schedule(static, 1)
+    for (int t = 0; t < nthreads; ++t) {
+        const int64_t r0 = n * t / nthreads, r1 = n * (t + 1) / nthreads;
+        item_t* hp = heaps + (size_t)t * nq * k;
+        int* cp = cnts + (size_t)t * nq;
+        for (int64_t b = r0; b < r1; b += tile) {
+            const int64_t e = b + tile < r1 ? b + tile : r1;
+            for (int qi = 0; qi < nq; ++qi) {
+                const float* qq = q + (size_t)qi * d;
+                for (int64_t i = b; i < e; ++i) {
+                    if (keep && !keep[i]) continue;
+                    const float* row = x + i * (int64_t)d;
+                    item_t it;
+                    it.id = id_base + i;
+                    it.s = metric == ORACLE_METRIC_IP ? (double)dot_f32(qq, row, d) : -(double)l2sqr_f32(qq, row, d);
+                    heap_offer(hp + (size_t)qi * k, &cp[qi], k, it);
+                }
+            }
+        }
+    }
+    for (int qi = 0; qi < nq; ++qi) {
+        item_t* h0 = heaps + (size_t)qi * k;
+        for (int t = 1; t < nthreads; ++t) {
+            const item_t* ht = heaps + ((size_t)t * nq + qi) * k;
+            for (int j = 0; j < cnts[(size_t)t * nq + qi]; ++j) heap_offer(h0, &cnts[qi], k, ht[j]);
+        }
+        qsort(h0, cnts[qi], sizeof(item_t), cmp_desc);
+        for (int j = 0; j < k; ++j) {
+            const int have = j < cnts[qi];
+            D[(size_t)qi * k + j] = have ? (float)(metric == ORACLE_METRIC_IP ? h0[j].s : -h0[j].s)
+                                         : (metric == ORACLE_METRIC_IP ? -3.402823466e+38f : 3.402823466e+38f);
+            I[(size_t)qi * k + j] = have ? h0[j].id : -1;
+        }
+    }
+    free(heaps);
+    free(cnts);
+}
+
+/* Merge `parts` per-block result lists (Dp[parts][nq][k], Ip likewise; -1 = empty slot) into the top-k of their union by
+ * (score desc for IP / distance asc for L2, id asc): exact, because that order is total. */
+void oracle_merge_topk(const float* Dp, const int64_t* Ip, int parts, int nq, int k, int metric, float* D, int64_t* I) {
+    item_t* all = (item_t*)malloc((size_t)parts * k * sizeof(item_t));
+    for (int qi = 0; qi < nq; ++qi) {
+        int m = 0;
+        for (int p = 0; p < parts; ++p)
+            for (int j = 0; j < k; ++j) {
+                const size_t at = ((size_t)p * nq + qi) * k + j;
+                if (Ip[at] < 0) continue;
+                all[m].s = metric == ORACLE_METRIC_IP ? (double)Dp[at] : -(double)Dp[at];
+                all[m].id = Ip[at];
+                ++m;
+            }
+        qsort(all, m, sizeof(item_t), cmp_desc);
+        for (int j = 0; j < k; ++j) {
+            const int have = j < m;
+            D[(size_t)qi * k + j] = have ? (float)(metric == ORACLE_METRIC_IP ? all[j].s : -all[j].s)
+                                         : (metric == ORACLE_METRIC_IP ? -3.402823466e+38f : 3.402823466e+38f);
+            I[(size_t)qi * k + j] = have ? all[j].id : -1;
+        }
+    }
+    free(all);
+}
+
 /* float64 scores of listed rows against ONE (already prepared) query: out[m] */
 void oracle_scores_f64(const float* x, int d, const float* q, int metric, const int64_t* rows,
                        int64_t m, double* out) {

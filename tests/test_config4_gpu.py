@@ -55,6 +55,18 @@ def test_config4_whole_corpus_80m_x_512_on_one_gpu(gpu):
     # rows from every one of the 8 shards show up among the results (the scan really covers 80M rows)
     shards = set((results["batch128"][1][:, 1:] // 10_000_000).ravel().tolist())
     assert shards >= set(range(8)), shards
+    # 100 fresh queries against the CPU oracle over ALL 80M rows ("100 at 80M"), streamed to the host in
+    # 1M-row blocks: the single-query scan and one 100-query call (tests/bigcheck.py)
+    import bigcheck
+    q100 = flat.synth(100, d, 5678, first_row=4096)
+    flat.normalize_l2(q100)
+    (oracle,), cost = bigcheck.oracle_topk_streamed(idx, n + nq, q100, k)
+    single = [idx.search(q100[i], k) for i in range(100)]
+    D1, I1 = np.concatenate([s[0] for s in single]), np.concatenate([s[1] for s in single])
+    bigcheck.report(dict(bigcheck.compare(idx, q100, D1, I1, *oracle, "config4 80M x 512 on one GPU, 1 query per call"),
+                         oracle_cost=cost))
+    Db, Ib = idx.search(q100, k)
+    bigcheck.report(bigcheck.compare(idx, q100, Db, Ib, *oracle, "config4 80M x 512 on one GPU, 100 queries per call"))
     idx.close()
 
 

@@ -1,0 +1,127 @@
+"""Oracle comparison AT the BASELINE sizes (configs 2 and 3; config 4 is in test_config4_gpu.py): every search path the
+library picks for 1 / 32 / 128 / 256 queries per call is held against the CPU oracle on the full corpus — 1,000 queries at
+1M x 512, 256 at 10M x 512 (1,000 queries per config, seeds 1234 / 5678) — id for id, every id difference
+adjudicated in float64 (tests/bigcheck.py).  Reference call site: minivectordb/vector_database.py:497
+(``index.search(embedding, search_k)``), filtered branch :508-523.
+"""
+import numpy as np
+import pytest
+
+from oracle import flat
+
+import bigcheck
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def native(gpu):
+    from minivectordb_amd import _native
+    assert _native.device_count() >= 1
+    return _native
+
+
+def _queries(nq, d, seed=5678):
+    q = flat.synth(nq, d, seed)
+    flat.normalize_l2(q)
+    return q
+
+
+def _in_chunks(search, q, per_call):
+    out = [search(q[a:a + per_call]) for a in range(0, q.shape[0], per_call)]
+    return np.concatenate([o[0] for o in out]), np.concatenate([o[1] for o in out])
+
+
+def _bitmap(keep):
+    bits = np.zeros((keep.shape[0] + 63) // 64 * 64, dtype=np.uint8)
+    bits[:keep.shape[0]] = keep
+    return np.packbits(bits, bitorder="little").view(np.uint64)
+
+
+def test_config2_1M_x_512_1000_queries_vs_oracle(native):
+    """BASELINE config 2 at full size: 1,000 queries, k = 10, through the single-query scan and through calls of 32 / 128 /
+    256 / 1,000 queries (the fp32-MFMA, bf16-split and fp16-nomination passes and their certified re-runs)."""
+    n, d, k, nq = 1_000_000, 512, 10, 1000
+    idx = native.FlatIndex(d)
+    idx.reserve(n)
+    idx.add_synthetic(n, 1234, normalize=True)
+    q = _queries(nq, d)
+    (oracle,), cost = bigcheck.oracle_topk_streamed(idx, n, q, k)
+    Do, Io = oracle
+    for per_call in (1, 32, 128, 256, 1000):
+        D, I = _in_chunks(lambda qs: idx.search(qs, k), q, per_call)
+        rec = bigcheck.compare(idx, q, D, I, Do, Io, f"config2 1M x 512, {per_call} queries per call")
+        bigcheck.report(dict(rec, oracle_cost=cost))
+    # un-normalised queries through the fused prologue (what find_most_similar sends, vector_database.py:475)
+    D, I = _in_chunks(lambda qs: idx.search(qs * np.float32(3.25), k, normalize_q=True), q[:200], 1)
+    bigcheck.report(bigcheck.compare(idx, q[:200], D, I, Do[:200], Io[:200], "config2 1M x 512, fused query normalisation"))
+    idx.close()
+
+
+def test_config2_1M_x_512_l2_and_filters_vs_oracle(native):
+    """The extensions at config 2's size: L2 metric (north_star names it next to IP) and the filtered branch as a row
+    list, a bitmap and a resident row set, 200 queries each, single and batched."""
+    n, d, k, nq = 1_000_000, 512, 10, 200
+    q = _queries(nq, d)
+    idx = native.FlatIndex(d)
+    idx.reserve(n)
+    idx.add_synthetic(n, 1234, normalize=True)
+    rs = np.random.RandomState(11)
+    keep_half = (rs.rand(n) < 0.5).astype(np.uint8)
+    keep_few = (rs.rand(n) < 0.03).astype(np.uint8)
+    (all_rows, half, few), cost = bigcheck.oracle_topk_streamed(idx, n, q, k, keeps=(None, keep_half, keep_few))
+    words = _bitmap(keep_half)
+    for per_call in (1, 32, 128):
+        D, I = _in_chunks(lambda qs: idx.search_masked(qs, k, words), q, per_call)
+        bigcheck.report(bigcheck.compare(idx, q, D, I, *half, f"config2 bitmap keeping 50 %, {per_call} queries per call"))
+    for keep, want, name in ((keep_half, half, "50 %"), (keep_few, few, "3 %")):
+        rows = np.nonzero(keep)[0].astype(np.int64)
+        rowset = idx.rowset(rows)
+        for per_call in (1, 64):
+            D, I = _in_chunks(lambda qs: idx.search_rowset(qs, k, rowset), q, per_call)
+            bigcheck.report(bigcheck.compare(idx, q, D, I, *want,
+                                             f"config2 resident row set keeping {name}, {per_call} queries per call"))
+        D, P = _in_chunks(lambda qs: idx.search_subset(qs, k, rows), q[:50], 1)   # labels = positions in the list
+        bigcheck.report(bigcheck.compare(idx, q[:50], D, rows[P], want[0][:50], want[1][:50],
+                                         f"config2 row list keeping {name}, per query"))
+        rowset.close()
+    idx.close()
+
+    l2 = native.FlatIndex(d, metric=native.METRIC_L2)
+    l2.reserve(n)
+    l2.add_synthetic(n, 1234, normalize=True)
+    (oracle,), cost = bigcheck.oracle_topk_streamed(l2, n, q, k, metric=flat.METRIC_L2)
+    for per_call in (1, 8, 32, 64, 128, 200):
+        D, I = _in_chunks(lambda qs: l2.search(qs, k), q, per_call)
+        bigcheck.report(bigcheck.compare(l2, q, D, I, *oracle, f"config2 L2 metric, {per_call} queries per call",
+                                         metric=flat.METRIC_L2))
+    l2.close()
+
+
+def test_config3_10M_x_512_every_pass_vs_oracle(native):
+    """BASELINE config 3 (the headline) at full size: 256 queries compared with the oracle over all 10M rows through
+    nq = 1 (first 100 queries), 32, 128 and 256 queries per call, and under a bitmap keeping half of the rows."""
+    n, d, k, nq = 10_000_000, 512, 10, 256
+    idx = native.FlatIndex(d)
+    idx.reserve(n)
+    idx.add_synthetic(n, 1234, normalize=True)
+    q = _queries(nq, d)
+    keep = (np.random.RandomState(3).rand(n) < 0.5).astype(np.uint8)
+    (everything, half), cost = bigcheck.oracle_topk_streamed(idx, n, q, k, keeps=(None, keep))
+    Do, Io = everything
+    reruns = native.split_rerun_count()
+    D, I = _in_chunks(lambda qs: idx.search(qs, k), q[:100], 1)
+    bigcheck.report(dict(bigcheck.compare(idx, q[:100], D, I, Do[:100], Io[:100], "config3 10M x 512, 1 query per call"),
+                         oracle_cost=cost))
+    for per_call in (32, 128, 256):
+        D, I = _in_chunks(lambda qs: idx.search(qs, k), q, per_call)
+        bigcheck.report(bigcheck.compare(idx, q, D, I, Do, Io, f"config3 10M x 512, {per_call} queries per call"))
+    words = _bitmap(keep)
+    D, I = _in_chunks(lambda qs: idx.search_masked(qs, k, words), q[:40], 1)
+    bigcheck.report(bigcheck.compare(idx, q[:40], D, I, half[0][:40], half[1][:40], "config3 bitmap keeping 50 %, 1 query per call"))
+    for per_call in (32, 128):
+        D, I = _in_chunks(lambda qs: idx.search_masked(qs, k, words), q, per_call)
+        bigcheck.report(bigcheck.compare(idx, q, D, I, *half, f"config3 bitmap keeping 50 %, {per_call} queries per call"))
+    bigcheck.report({"what": "config3 certified-pass re-runs during the comparison",
+                     "chunks_rerun": native.split_rerun_count() - reruns})
+    idx.close()

@@ -94,3 +94,80 @@ def test_synth_known_answers():
     assert w.tobytes() == want2.tobytes(), w.tolist()
     big = flat.synth(4096, 512, 1234)
     assert abs(float(big.mean())) < 2e-3 and abs(float(big.std()) - 0.2887) < 5e-3  # Irwin-Hall(4)/2 spread
+
+
+def test_block_search_and_merge_equal_the_sequential_scan():
+    """oracle_flat_search_block + oracle_merge_topk (what tests/bigcheck.py streams a 10M-row device corpus through) must
+    return bit for bit what the per-query sequential scan returns: IP and L2, ragged block sizes, duplicate rows (ties
+    by id across blocks), k larger than a block, row selections, any thread count."""
+    n, d, nq = 7000, 96, 37
+    x = flat.synth(n, d, 1234)
+    flat.normalize_l2(x)
+    x[5000:5003] = x[17]        # exact duplicates in another block: ties must resolve to the lower id
+    q = flat.synth(nq, d, 5678)
+    q[3] = x[17]
+    keep = (np.arange(n) % 3 != 1).astype(np.uint8)
+    for metric in (flat.METRIC_IP, flat.METRIC_L2):
+        for k, cuts in ((10, (0, 1000, 1001, 4096, n)), (300, (0, 200, 6000, n))):
+            want = flat.flat_search(x, q, k, metric=metric)
+            parts = [flat.flat_search_block(x[a:b], q, k, id_base=a, metric=metric, nthreads=t + 1)
+                     for t, (a, b) in enumerate(zip(cuts[:-1], cuts[1:]))]
+            got = flat.merge_topk(parts, metric=metric)
+            assert np.array_equal(got[1], want[1]) and got[0].tobytes() == want[0].tobytes()
+        rows = np.nonzero(keep)[0]
+        Dw, Pw = flat.flat_search(x, q, 10, metric=metric, rows=rows)
+        Dg, Ig = flat.flat_search_block(x, q, 10, metric=metric, keep=keep, nthreads=3)
+        assert np.array_equal(rows[Pw], Ig) and Dg.tobytes() == Dw.tobytes()
+    D, I = flat.flat_search_block(x[:4], q[:2], 6)      # fewer rows than k: -1 / -FLT_MAX padding
+    assert (I[:, 4:] == -1).all() and (D[:, 4:] == np.float32(-3.4028234663852886e38)).all()
+
+
+class _HostIndex:
+    """get_rows over a host matrix: lets tests/bigcheck.py's comparison logic run without a GPU."""
+
+    def __init__(self, x):
+        self.x, self.d = x, x.shape[1]
+
+    def get_rows(self, row0, n, out=None):
+        if out is None:
+            return self.x[row0:row0 + n].copy()
+        out[:] = self.x[row0:row0 + n]
+        return out
+
+
+def test_fullsize_comparison_logic_accepts_near_ties_and_rejects_wrong_rows():
+    import pytest
+    import bigcheck
+    n, d, k = 5000, 64, 10
+    x = flat.synth(n, d, 1234)
+    flat.normalize_l2(x)
+    q = flat.synth(6, d, 5678)
+    flat.normalize_l2(q)
+    x[4000] = x[int(flat.flat_search(x, q[:1], k)[1][0, k - 1])]   # a duplicate of query 0's k-th row: an exact tie
+    idx = _HostIndex(x)
+    (oracle,), _ = bigcheck.oracle_topk_streamed(idx, n, q, k, block=1024)
+    Do, Io = oracle
+    assert np.array_equal(Io, flat.flat_search(x, q, k)[1])
+    rec = bigcheck.compare(idx, q, Do.copy(), Io.copy(), Do, Io, "identical")
+    assert rec["queries_with_id_differences"] == 0
+    # the tie resolved the other way round: accepted and counted
+    I2 = Io.copy()
+    assert 4000 not in I2[0]
+    I2[0, k - 1] = 4000
+    rec = bigcheck.compare(idx, q, Do.copy(), I2, Do, Io, "tie")
+    assert rec["queries_with_id_differences"] == 1 and rec["adjudicated_near_ties"] == 1
+    # a row that is simply not among the best
+    worst = int(np.argmin(x @ q[1]))
+    I3 = Io.copy()
+    I3[1, k - 1] = worst
+    with pytest.raises(AssertionError, match="not a near-tie"):
+        bigcheck.compare(idx, q, Do.copy(), I3, Do, Io, "wrong row")
+    # a wrong distance
+    D4 = Do.copy()
+    D4[2, 0] += 3e-4
+    with pytest.raises(AssertionError, match="distances differ"):
+        bigcheck.compare(idx, q, D4, Io.copy(), Do, Io, "wrong distance")
+    # a selection (filtered search): rows outside it never appear
+    keep = (np.arange(n) % 2 == 0).astype(np.uint8)
+    (sel,), _ = bigcheck.oracle_topk_streamed(idx, n, q, k, keeps=(keep,), block=999)
+    assert (sel[1] % 2 == 0).all()
