@@ -59,6 +59,11 @@ int mvdb_device_count(int* count);
 int mvdb_index_create(int d, int metric, int device, mvdb_index** out);
 int mvdb_index_free(mvdb_index* idx);
 
+/* The MVDB_* tuning / A-B hooks of the search path are read from the environment ONCE, by
+ * mvdb_index_create; the search path itself never calls getenv.  This re-reads them for an existing index (A/B runs and tests
+ * that flip a hook inside one process).  No reference counterpart. */
+int mvdb_index_reload_env(mvdb_index* idx);
+
 /* Drop all rows (capacity is kept). */
 int mvdb_index_reset(mvdb_index* idx);
 
@@ -121,8 +126,12 @@ int mvdb_index_search(const mvdb_index* idx, const float* q_host, int nq, int k,
  * certified batch pass could not certify are compacted, re-run on the exact kernels and scattered back by launches
  * that are enabled ON THE DEVICE (they return at once when every query certified).  The call can therefore be captured
  * into a hipGraph — after one eager call of the same shape on that stream has sized its workspace (allocation is not
- * capturable) — e.g. encoder forward -> search as ONE graph.
- * One search at a time per (index, stream): concurrent calls naming the same stream are serialised. */
+ * capturable) — e.g. encoder forward -> search as ONE graph.  A captured graph names the stream's workspace buffers: from
+ * the first capture on, that workspace never frees a buffer it outgrows (a later, LARGER eager call on the same stream
+ * allocates new ones and parks the old until the index goes), so replaying the earlier graph stays valid.
+ * One search at a time per (index, stream): concurrent calls naming the same stream are serialised.
+ * Mutators (add / remove_rows / reset / reserve) wait for the searches enqueued on THIS index — its streams only, no
+ * device-wide synchronise — and do their own work on a private non-blocking stream. */
 int mvdb_index_search_device(const mvdb_index* idx, const float* q_dev, int nq, int k,
                              int normalize_q, int64_t label_offset, float* D_dev, int64_t* I_dev,
                              void* stream);
@@ -184,6 +193,12 @@ int mvdb_rowset_free(mvdb_rowset* rs);
 /* labels are ROW NUMBERS of the index (not positions).  Replaces the same call sites as mvdb_index_search_subset. */
 int mvdb_index_search_rowset(const mvdb_index* idx, const float* q_host, int nq, int k, int normalize_q,
                              const mvdb_rowset* rs, float* D_host, int64_t* I_host);
+/* Device-resident variant (queries and outputs in device memory, enqueued on `stream`, no synchronisation; labels are row
+ * numbers + label_offset): what a rank of the row-partitioned search runs for a filter whose LOCAL rows it keeps resident.
+ * Replaces the per-shard half of             minivectordb/sharded_vector_database.py:634-649 */
+int mvdb_index_search_rowset_device(const mvdb_index* idx, const float* q_dev, int nq, int k, int normalize_q,
+                                    const mvdb_rowset* rs, int64_t label_offset, float* D_dev, int64_t* I_dev,
+                                    void* stream);
 
 /* Merge `nlists` sorted top-k lists per query into one [nq,k] result on the device.  List l lives
  * at D_dev + l*list_stride_D (floats, [nq,k]) and I_dev + l*list_stride_I (int64, [nq,k]) — the

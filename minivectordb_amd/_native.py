@@ -59,6 +59,7 @@ PROTOTYPES = {
     "mvdb_device_count": (ctypes.c_int, [ctypes.POINTER(ctypes.c_int)]),
     "mvdb_index_create": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(c_vp)]),
     "mvdb_index_free": (ctypes.c_int, [c_vp]),
+    "mvdb_index_reload_env": (ctypes.c_int, [c_vp]),
     "mvdb_index_reset": (ctypes.c_int, [c_vp]),
     "mvdb_index_ntotal": (ctypes.c_int64, [c_vp]),
     "mvdb_index_dim": (ctypes.c_int, [c_vp]),
@@ -85,6 +86,8 @@ PROTOTYPES = {
     "mvdb_rowset_is_bitmap": (ctypes.c_int, [c_vp]),
     "mvdb_rowset_free": (ctypes.c_int, [c_vp]),
     "mvdb_index_search_rowset": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_vp, c_vp, c_vp]),
+    "mvdb_index_search_rowset_device": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_vp,
+                                                       ctypes.c_int64, c_vp, c_vp, c_vp]),
     "mvdb_comm_available": (ctypes.c_int, []),
     "mvdb_comm_unique_id": (ctypes.c_int, [c_vp]),
     "mvdb_comm_create": (ctypes.c_int, [c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(c_vp)]),
@@ -223,6 +226,10 @@ class FlatIndex:
     def reserve(self, n):
         check(lib().mvdb_index_reserve(self._h, int(n)))
 
+    def reload_env(self):
+        """Re-read the MVDB_* hooks (the library reads them once, when the index is created)."""
+        check(lib().mvdb_index_reload_env(self._h))
+
     def add(self, x, normalize=False):
         x = np.ascontiguousarray(x, dtype=np.float32)
         if x.ndim != 2 or x.shape[1] != self.d:
@@ -288,6 +295,12 @@ class FlatIndex:
         check(lib().mvdb_index_search_rowset(self._h, _ptr(q), nq, int(k), int(bool(normalize_q)), rowset._h, _ptr(D),
                                              _ptr(I)))
         return D, I
+
+    def search_rowset_device(self, q_ptr, nq, k, rowset, D_ptr, I_ptr, stream=0, normalize_q=False, label_offset=0):
+        """Device-pointer variant of search_rowset (labels: row numbers + label_offset); enqueues on `stream` and returns."""
+        check(lib().mvdb_index_search_rowset_device(
+            self._h, ctypes.c_void_p(q_ptr), int(nq), int(k), int(bool(normalize_q)), rowset._h, int(label_offset),
+            ctypes.c_void_p(D_ptr), ctypes.c_void_p(I_ptr), ctypes.c_void_p(stream)))
 
     def search_masked(self, q, k, mask_words, normalize_q=False, labels="rows"):
         """Search the rows whose bit is set in `mask_words` (uint64[(ntotal + 63) // 64], bit r & 63 of word r >> 6 = row r;
@@ -409,7 +422,7 @@ def pack_row_mask(n, rows=None, excluded=None):
         bits[np.fromiter(rows, dtype=np.int64, count=len(rows)) if not isinstance(rows, np.ndarray) else rows] = 1
     else:
         bits[:n] = 1
-        if excluded:
+        if excluded is not None and len(excluded):
             bits[np.fromiter(excluded, dtype=np.int64, count=len(excluded)) if not isinstance(excluded, np.ndarray)
                  else excluded] = 0
     return np.packbits(bits, bitorder="little").view(np.uint64)

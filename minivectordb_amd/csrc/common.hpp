@@ -54,13 +54,58 @@ bool prof_enabled();
 int prof_begin(const char* name, hipStream_t stream);
 void prof_end(int slot, hipStream_t stream);
 
+// Every MVDB_* tuning / A-B hook of the SEARCH path.  The environment is read ONCE per index — at mvdb_index_create, and
+// again only when the caller asks (mvdb_index_reload_env: A/B runs and tests that flip a hook inside one process) — never on
+// the search path.  Defaults are the measured best.
+struct Knobs {
+    int scan_blocks_per_cu = 0;      // MVDB_SCAN_BLOCKS_PER_CU (0: the measured default per shape)
+    int mfma_blocks_per_cu = 0;      // MVDB_MFMA_BLOCKS_PER_CU (0: 4 for the fragment-load kernel, 2 for the staged ones)
+    int mfma_stage = 16;             // MVDB_MFMA_STAGE (8 | 16)
+    int mfma_v = 2;                  // MVDB_MFMA_V (1 = fragment loads, 2 = LDS-DMA staged)
+    int mfma_ng2 = -1;               // MVDB_MFMA_NG2 (-1: on for the staged kernel, off otherwise)
+    int gemm_scan_min_nq = 104;      // MVDB_GEMM_SCAN_MIN_NQ
+    int gemm_scan_blocks_per_cu = 2; // MVDB_GEMM_SCAN_BLOCKS_PER_CU
+    int split_scan_min_nq = 33;      // MVDB_SPLIT_SCAN_MIN_NQ
+    int split32_min_nq = 14;         // MVDB_SPLIT32_MIN_NQ
+    int split32_blocks_per_cu = 2;   // MVDB_SPLIT32_BLOCKS_PER_CU
+    int split_phase_growth = 8;      // MVDB_SPLIT_PHASE_GROWTH
+    int half_phase_growth = 16;      // MVDB_HALF_PHASE_GROWTH
+    int half_last_growth = 6;        // MVDB_HALF_LAST_GROWTH
+    int split_dbg = 0;               // MVDB_SPLIT_DBG (timing ablation, invalid results)
+    bool split_stats = false;        // MVDB_SPLIT_STATS
+    bool split_one_phase = false;    // MVDB_SPLIT_ONE_PHASE
+    bool disable_mfma_scan = false, disable_l2_mfma = false, disable_gemm_scan = false, disable_split_scan = false,
+         disable_split32 = false, disable_half_scan = false, disable_masked_batch = false;  // MVDB_DISABLE_*
+    bool hq_pipe = true;             // MVDB_HQ_PIPE (0: refill and conversion behind the MFMAs)
+    bool half_ksplit = false;        // MVDB_HALF_KSPLIT
+    bool half_small_stages = false;  // MVDB_HALF_SMALL_STAGES
+    bool hq_w4 = false;              // MVDB_HQ_W4
+};
+Knobs read_knobs();
+
+// hipOccupancyMaxActiveBlocksPerMultiprocessor, asked once per (kernel, dynamic LDS) and remembered
+int cached_occupancy(const void* kern, int threads, size_t lds, int dflt);
+
+// A search captured into a hipGraph bakes its workspace pointers into the graph.  While a retire list is installed
+// (RetireScope: searches on a workspace that has been captured once), a buffer that must grow is NOT freed — it goes on
+// the list and lives as long as the workspace, so replaying the earlier graph still reads and writes valid memory.
+extern thread_local std::vector<void*>* tls_retire;
+struct RetireScope {
+    std::vector<void*>* prev;
+    explicit RetireScope(std::vector<void*>* list) : prev(tls_retire) { tls_retire = list; }
+    ~RetireScope() { tls_retire = prev; }
+};
+
 template <typename T>
 struct DevBuf {
     T* p = nullptr;
     size_t cap = 0;  // elements
     int reserve(size_t n) {
         if (n <= cap) return 0;
-        if (p) (void)hipFree(p);
+        if (p) {
+            if (tls_retire) tls_retire->push_back((void*)p);
+            else (void)hipFree(p);
+        }
         p = nullptr;
         cap = 0;
         size_t want = n + n / 4 + 64;

@@ -984,8 +984,8 @@ static int launch_half_inst(const HalfScanArgs& a, int device, hipStream_t strea
 }
 
 template <int KT, bool PAD, int G, int WV = 4>
-static int launch_hq_inst(const HalfScanArgs& a, int device, hipStream_t stream, int* nblocks_out) {
-    static const bool pipe = []() { const char* v = getenv("MVDB_HQ_PIPE"); return !(v && *v == '0'); }();  // 0: DMA refill + conversion behind the MFMAs (A/B)
+static int launch_hq_inst(const HalfScanArgs& a, bool pipe, int device, hipStream_t stream, int* nblocks_out) {
+    // pipe = false (MVDB_HQ_PIPE=0): DMA refill + conversion behind the MFMAs (A/B)
     auto kern = pipe ? flat_scan_hq_kernel<KT, PAD, G, WV, true> : flat_scan_hq_kernel<KT, PAD, G, WV, false>;
     constexpr int KH = KT / 2;
     constexpr size_t lds = (size_t)3 * 32 * KH * 64 + (size_t)2 * 32 * (PAD ? 2 * KH + 1 : 2 * KH) * 16;
@@ -1010,7 +1010,7 @@ static int launch_hq_inst(const HalfScanArgs& a, int device, hipStream_t stream,
 }
 
 template <int KQ, int SKB4>
-static int launch_half_kq(int nqpad, bool seed, const HalfScanArgs& a, int device, hipStream_t stream, int* nb) {
+static int launch_half_kq(int nqpad, bool seed, const HalfScanArgs& a, const Knobs& kn, int device, hipStream_t stream, int* nb) {
     // SKB4: 8-KiB stages for the 128-query main launch where KQ % 4 == 0 (d = 512: same speed as 4-KiB stages, 0.81 of
     // the HBM peak; d = 768: 0.84)
     if (nqpad == 128) {
@@ -1019,32 +1019,32 @@ static int launch_half_kq(int nqpad, bool seed, const HalfScanArgs& a, int devic
         // 66.1k at 256 (10M rows); MVDB_HALF_KSPLIT=1 keeps the K-split form for A/B runs.  d = 768 / 1024: K split (a
         // three-stage ring of raw K-halves no longer fits beside the fp16 images)
         if constexpr (KQ <= 8)
-            if (!getenv("MVDB_HALF_KSPLIT")) return launch_hq_inst<KQ * 4, (KQ & (KQ - 1)) != 0, 1>(a, device, stream, nb);
-        if (SKB4 && !getenv("MVDB_HALF_SMALL_STAGES")) return launch_half_inst<KQ, (SKB4 ? 4 : 2), 4, (SKB4 ? 3 : 6), false>(a, device, stream, nb);
+            if (!kn.half_ksplit) return launch_hq_inst<KQ * 4, (KQ & (KQ - 1)) != 0, 1>(a, kn.hq_pipe, device, stream, nb);
+        if (SKB4 && !kn.half_small_stages) return launch_half_inst<KQ, (SKB4 ? 4 : 2), 4, (SKB4 ? 3 : 6), false>(a, device, stream, nb);
         return launch_half_inst<KQ, 2, 4, 6, false>(a, device, stream, nb);
     }
     if constexpr (KQ <= 8) {
         if (nqpad == 256) {
             if (seed) return launch_half_inst<KQ, 2, 8, 5, true>(a, device, stream, nb);
-            if (getenv("MVDB_HALF_KSPLIT")) return launch_half_inst<KQ, 2, 8, 5, false>(a, device, stream, nb);  // A/B: the K-split form
+            if (kn.half_ksplit) return launch_half_inst<KQ, 2, 8, 5, false>(a, device, stream, nb);  // A/B: the K-split form
             // eight waves of 32 queries (two per SIMD) rather than four of 64: 66.0k vs 61.5k q/s at d = 512, 84.7k vs 79.3k
             // at 384, 107.9k vs 103.7k at 256; MVDB_HQ_W4=1 keeps the four-wave form for A/B runs
-            if (getenv("MVDB_HQ_W4")) return launch_hq_inst<KQ * 4, (KQ & (KQ - 1)) != 0, 2>(a, device, stream, nb);
-            return launch_hq_inst<KQ * 4, (KQ & (KQ - 1)) != 0, 1, 8>(a, device, stream, nb);
+            if (kn.hq_w4) return launch_hq_inst<KQ * 4, (KQ & (KQ - 1)) != 0, 2>(a, kn.hq_pipe, device, stream, nb);
+            return launch_hq_inst<KQ * 4, (KQ & (KQ - 1)) != 0, 1, 8>(a, kn.hq_pipe, device, stream, nb);
         }
     }
     return fail(MVDB_ERR_ARG, "no fp16 nomination kernel for %d queries per pass at d = %d", nqpad, KQ * 64);
 }
 
-int launch_half_scan(int d, int nqpad, bool seed, const HalfScanArgs& a, int device, hipStream_t stream, int* nblocks_out) {
+int launch_half_scan(int d, int nqpad, bool seed, const HalfScanArgs& a, const Knobs& kn, int device, hipStream_t stream, int* nblocks_out) {
     switch (half_kq(d)) {
-        case 4: return launch_half_kq<4, 0>(nqpad, seed, a, device, stream, nblocks_out);
-        case 6: return launch_half_kq<6, 0>(nqpad, seed, a, device, stream, nblocks_out);
-        case 8: return launch_half_kq<8, 1>(nqpad, seed, a, device, stream, nblocks_out);
-        case 10: return launch_half_kq<10, 0>(nqpad, seed, a, device, stream, nblocks_out);
-        case 12: return launch_half_kq<12, 1>(nqpad, seed, a, device, stream, nblocks_out);
-        case 14: return launch_half_kq<14, 0>(nqpad, seed, a, device, stream, nblocks_out);
-        case 16: return launch_half_kq<16, 0>(nqpad, seed, a, device, stream, nblocks_out);
+        case 4: return launch_half_kq<4, 0>(nqpad, seed, a, kn, device, stream, nblocks_out);
+        case 6: return launch_half_kq<6, 0>(nqpad, seed, a, kn, device, stream, nblocks_out);
+        case 8: return launch_half_kq<8, 1>(nqpad, seed, a, kn, device, stream, nblocks_out);
+        case 10: return launch_half_kq<10, 0>(nqpad, seed, a, kn, device, stream, nblocks_out);
+        case 12: return launch_half_kq<12, 1>(nqpad, seed, a, kn, device, stream, nblocks_out);
+        case 14: return launch_half_kq<14, 0>(nqpad, seed, a, kn, device, stream, nblocks_out);
+        case 16: return launch_half_kq<16, 0>(nqpad, seed, a, kn, device, stream, nblocks_out);
         default: return fail(MVDB_ERR_ARG, "no fp16 nomination kernel for d = %d", d);
     }
 }

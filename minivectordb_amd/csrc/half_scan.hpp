@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "common.hpp"
+
 namespace mvdb {
 
 constexpr int kHalfKeep = 16;      // nominees per (block, query) list and in the running list between phases
@@ -54,7 +56,7 @@ float half_xscale(float row_norm_bound);
 int launch_half_queries(const float* q, int64_t ld, int d, int nq, int nqpad, float xscale, _Float16* qf, float* qnorm,
                         float* qinv, hipStream_t stream);
 // seed: one tile per block over [tile0, tile1), every score dumped ([nq, blocks, 32] keys); *nblocks_out = blocks
-int launch_half_scan(int d, int nqpad, bool seed, const HalfScanArgs& a, int device, hipStream_t stream, int* nblocks_out);
+int launch_half_scan(int d, int nqpad, bool seed, const HalfScanArgs& a, const Knobs& kn, int device, hipStream_t stream, int* nblocks_out);
 int launch_half_certify(const HalfCertifyArgs& a, int nq, hipStream_t stream);
 
 }  // namespace mvdb

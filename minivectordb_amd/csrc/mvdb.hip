@@ -31,6 +31,58 @@ int launch_merge_di_sort(int metric, int nlists, int nq, int k, const float* D, 
                          int64_t strideI, float* Dout, int64_t* Iout, int device, hipStream_t stream);  // collective.hip
 
 static thread_local char g_err[512] = "";
+thread_local std::vector<void*>* tls_retire = nullptr;
+
+static int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v && *v ? atoi(v) : dflt;
+}
+Knobs read_knobs() {
+    Knobs k;
+    k.scan_blocks_per_cu = env_int("MVDB_SCAN_BLOCKS_PER_CU", 0);
+    k.mfma_blocks_per_cu = env_int("MVDB_MFMA_BLOCKS_PER_CU", 0);
+    k.mfma_stage = env_int("MVDB_MFMA_STAGE", 16);
+    k.mfma_v = env_int("MVDB_MFMA_V", 2);
+    k.mfma_ng2 = env_int("MVDB_MFMA_NG2", -1);
+    k.gemm_scan_min_nq = env_int("MVDB_GEMM_SCAN_MIN_NQ", 104);
+    k.gemm_scan_blocks_per_cu = env_int("MVDB_GEMM_SCAN_BLOCKS_PER_CU", 2);
+    k.split_scan_min_nq = env_int("MVDB_SPLIT_SCAN_MIN_NQ", 33);
+    k.split32_min_nq = env_int("MVDB_SPLIT32_MIN_NQ", 14);
+    k.split32_blocks_per_cu = env_int("MVDB_SPLIT32_BLOCKS_PER_CU", 2);
+    k.split_phase_growth = env_int("MVDB_SPLIT_PHASE_GROWTH", 8);
+    k.half_phase_growth = env_int("MVDB_HALF_PHASE_GROWTH", 16);
+    k.half_last_growth = env_int("MVDB_HALF_LAST_GROWTH", 6);
+    k.split_dbg = env_int("MVDB_SPLIT_DBG", 0);
+    k.split_stats = env_int("MVDB_SPLIT_STATS", 0) != 0;
+    k.split_one_phase = env_int("MVDB_SPLIT_ONE_PHASE", 0) != 0;
+    k.disable_mfma_scan = env_int("MVDB_DISABLE_MFMA_SCAN", 0) != 0;
+    k.disable_l2_mfma = env_int("MVDB_DISABLE_L2_MFMA", 0) != 0;
+    k.disable_gemm_scan = env_int("MVDB_DISABLE_GEMM_SCAN", 0) != 0;
+    k.disable_split_scan = env_int("MVDB_DISABLE_SPLIT_SCAN", 0) != 0;
+    k.disable_split32 = env_int("MVDB_DISABLE_SPLIT32", 0) != 0;
+    k.disable_half_scan = env_int("MVDB_DISABLE_HALF_SCAN", 0) != 0;
+    k.disable_masked_batch = env_int("MVDB_DISABLE_MASKED_BATCH", 0) != 0;
+    {
+        const char* v = getenv("MVDB_HQ_PIPE");
+        k.hq_pipe = !(v && *v == '0');
+    }
+    k.half_ksplit = getenv("MVDB_HALF_KSPLIT") != nullptr;
+    k.half_small_stages = getenv("MVDB_HALF_SMALL_STAGES") != nullptr;
+    k.hq_w4 = getenv("MVDB_HQ_W4") != nullptr;
+    return k;
+}
+
+int cached_occupancy(const void* kern, int threads, size_t lds, int dflt) {
+    static std::mutex mu;
+    static std::map<std::pair<const void*, size_t>, int> cache;
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = cache.find({kern, lds});
+    if (it != cache.end()) return it->second;
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, threads, lds) != hipSuccess || nb <= 0) nb = dflt;
+    cache[{kern, lds}] = nb;
+    return nb;
+}
 
 void set_error(const char* fmt, ...) {
     va_list ap;
@@ -137,6 +189,8 @@ struct Workspace {
     SelectState* st = nullptr;
     PinnedBuf pin;
     std::mutex use_mu;  // stream workspaces are shared by every host thread that names the stream: one search at a time
+    bool captured = false;         // a search on this workspace has been captured into a hipGraph: its buffers are never freed
+    std::vector<void*> retired;    // ... outgrown ones wait here until the workspace goes (common.hpp, RetireScope)
 
     int init(int dev, hipStream_t s) {
         device = dev;
@@ -167,6 +221,8 @@ struct Workspace {
         relabel.release();
         nfail.release();
         pin.release();
+        for (void* old : retired) (void)hipFree(old);
+        retired.clear();
         if (st) (void)hipFree(st);
         if (own_stream && stream) (void)hipStreamDestroy(stream);
     }
@@ -182,6 +238,10 @@ struct mvdb_index {
     float row_norm_bound = 0.f;  // upper bound of |row| over the stored rows (INFINITY: unknown, raw adds)
     uint64_t renumbered = 0;     // bumped whenever stored rows change their numbers (remove_rows, reset): resident row sets
                                  // built before are stale
+    Knobs kn;                    // the MVDB_* hooks as read at creation (mvdb_index_reload_env re-reads)
+    hipStream_t mut = nullptr;   // the mutators' own non-blocking stream: add / remove_rows never touch the legacy stream,
+                                 // so work other libraries have in flight on the device (an encoder forward) is not stalled
+    unsigned int* normmax = nullptr;  // 4-byte scratch of note_row_norms (raw adds)
     mutable std::shared_mutex mu;  // search: shared; add/reset/remove/free: exclusive
     mutable std::mutex ws_mu;
     mutable std::vector<Workspace*> free_ws;           // synchronous searches
@@ -241,6 +301,16 @@ struct mvdb_index {
 
 namespace {
 
+// The launchers below read the hooks of the index being searched through a thread-local pointer (search_core installs it).
+const Knobs g_default_knobs;
+thread_local const Knobs* tls_kn = &g_default_knobs;
+struct KnobScope {
+    const Knobs* prev;
+    explicit KnobScope(const Knobs* k) : prev(tls_kn) { tls_kn = k; }
+    ~KnobScope() { tls_kn = prev; }
+};
+inline const Knobs& kn() { return *tls_kn; }
+
 // ---- shape selection: G lanes per row, C chunks per lane, U rows in flight ----------------------
 struct Shape {
     int G, C;
@@ -257,29 +327,20 @@ Shape choose_shape(int d4) {
 }
 constexpr int kMaxC = 16;  // d <= 4096
 
-int env_int(const char* name, int dflt) {
-    const char* v = getenv(name);
-    return v && *v ? atoi(v) : dflt;
-}
-
 template <int G, int C, int U, int METRIC, int MODE, bool NT, int SEL, bool MASKED>
 int launch_scan_kern(const ScanArgs& a, int nq, int device, hipStream_t stream, int* nblocks_out) {
     auto kern = flat_scan_kernel<G, C, U, METRIC, MODE, NT, SEL, MASKED>;
-    static int occ = 0;  // blocks per CU this instantiation sustains
-    static int occ_hw = 0;
-    if (occ == 0) {
-        int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, kScanThreads, 0) != hipSuccess ||
-            nb <= 0)
-            nb = 4;
-        occ_hw = nb;
+    const int occ_hw = cached_occupancy((const void*)kern, kScanThreads, 0, 4);  // blocks per CU this instantiation sustains
+    int occ;
+    {
+        const int nb = occ_hw;
         // measured on MI355X (round-1 sweep, profiles/r01_sweep_scan_variants.txt, 10M x 512): with ~4
         // independent 16-B loads per lane, 2 resident blocks (8 waves) per CU reach 7.21-7.24 TB/s; more
         // waves or more loads in flight per lane are 2-4 % slower, 1 block per CU is latency-starved
         // (gpurun_out/sweep_dims.log: the one- and three-chunk shapes — d = 64 / 256 / 384 — prefer U = 4 with
         //  3 resident blocks: 7.0-7.1 TB/s vs 6.5-6.9 at 2)
         occ = std::min(nb, (C == 1 || C == 3) ? 3 : 2);
-        const int cap_env = env_int("MVDB_SCAN_BLOCKS_PER_CU", 0);  // tuning hook
+        const int cap_env = kn().scan_blocks_per_cu;  // tuning hook
         if (cap_env > 0) occ = std::min(occ_hw, cap_env);
     }
     constexpr int RB = (kWave / G) * U;
@@ -400,11 +461,16 @@ int64_t pow2ceil(int64_t v) {
 
 int normalize_range(const mvdb_index* idx, float* base, int64_t n, hipStream_t s);
 
-// Mutators (add / remove_rows / reset) hold the index exclusively, which only excludes HOST calls: scans enqueued
-// earlier by mvdb_index_search_device on non-blocking streams may still be reading the matrix.  Drain the device
-// before touching it (the mutators then work on the legacy stream and finish with a device sync of their own).
-int quiesce() {
-    MVDB_HIP(hipDeviceSynchronize());
+// Mutators (add / remove_rows / reset / reserve) hold the index exclusively, which only excludes HOST calls: scans enqueued
+// earlier by mvdb_index_search_device on caller streams may still be reading the matrix.  Wait for THIS index's searches —
+// every stream that ever searched it has a workspace here (the synchronous API's own workspaces are idle once a call has
+// returned) — and for nothing else: no hipDeviceSynchronize, so an encoder forward or another index on the same device
+// keeps running.  The mutators then work on the index's own non-blocking stream (idx->mut) and wait for that stream only.
+int quiesce(mvdb_index* idx) {
+    std::lock_guard<std::mutex> lk(idx->ws_mu);
+    for (auto& kv : idx->stream_ws) MVDB_HIP(hipStreamSynchronize((hipStream_t)kv.first));
+    if (idx->default_stream_ws) MVDB_HIP(hipStreamSynchronize(nullptr));
+    if (!idx->mut) MVDB_HIP(hipStreamCreateWithFlags(&idx->mut, hipStreamNonBlocking));
     return 0;
 }
 
@@ -413,10 +479,8 @@ int launch_mfma_inst(const MfmaScanArgs& a, int device, hipStream_t stream, int*
     auto kern = flat_scan_mfma_kernel<KB, NG>;
     const size_t lds = (size_t)NG * KB * 4 * 64 * 4 + (size_t)kScanWaves * NG * 16 * a.k * 8;
     MVDB_TRY(ensure_dynamic_lds((const void*)kern, lds, device));
-    int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, kScanThreads, lds) != hipSuccess || nb <= 0)
-        nb = 1;
-    nb = std::min(nb, std::max(1, env_int("MVDB_MFMA_BLOCKS_PER_CU", 4)));
+    int nb = cached_occupancy((const void*)kern, kScanThreads, lds, 1);
+    nb = std::min(nb, kn().mfma_blocks_per_cu > 0 ? kn().mfma_blocks_per_cu : 4);
     const int64_t ntiles = (a.n + 15) / 16;
     const int64_t want = (ntiles + kScanWaves - 1) / kScanWaves;
     const int nblocks = (int)std::max<int64_t>(1, std::min<int64_t>(want, (int64_t)device_cus(device) * nb));
@@ -433,10 +497,8 @@ int launch_mfma2_gated_inst(const MfmaScanArgs& a, int device, hipStream_t strea
     auto kern = a.mask ? flat_scan_mfma2_gated_kernel<KB, NG, SKB, true> : flat_scan_mfma2_gated_kernel<KB, NG, SKB, false>;
     const size_t lds = (size_t)kScanWaves * mfma2_wave_lds_bytes(SKB) + (size_t)kScanWaves * NG * 16 * a.k * 8;
     MVDB_TRY(ensure_dynamic_lds((const void*)kern, lds, device));
-    int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, kScanThreads, lds) != hipSuccess || nb <= 0)
-        nb = 1;
-    nb = std::min(nb, std::max(1, env_int("MVDB_MFMA_BLOCKS_PER_CU", 2)));
+    int nb = cached_occupancy((const void*)kern, kScanThreads, lds, 1);
+    nb = std::min(nb, kn().mfma_blocks_per_cu > 0 ? kn().mfma_blocks_per_cu : 2);
     const int64_t ntiles = (a.n + 15) / 16;
     const int64_t want = (ntiles + kScanWaves - 1) / kScanWaves;
     const int nblocks = (int)std::max<int64_t>(1, std::min<int64_t>(want, (int64_t)device_cus(device) * nb));
@@ -459,10 +521,8 @@ int launch_mfma2_inst(const MfmaScanArgs& a, int device, hipStream_t stream, int
     }
     const size_t lds = (size_t)kScanWaves * mfma2_wave_lds_bytes(SKB) + (size_t)kScanWaves * NG * 16 * a.k * 8;
     MVDB_TRY(ensure_dynamic_lds((const void*)kern, lds, device));
-    int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, kScanThreads, lds) != hipSuccess || nb <= 0)
-        nb = 1;
-    nb = std::min(nb, std::max(1, env_int("MVDB_MFMA_BLOCKS_PER_CU", 2)));
+    int nb = cached_occupancy((const void*)kern, kScanThreads, lds, 1);
+    nb = std::min(nb, kn().mfma_blocks_per_cu > 0 ? kn().mfma_blocks_per_cu : 2);
     const int64_t ntiles = (a.n + 15) / 16;
     const int64_t want = (ntiles + kScanWaves - 1) / kScanWaves;
     const int nblocks = (int)std::max<int64_t>(1, std::min<int64_t>(want, (int64_t)device_cus(device) * nb));
@@ -479,7 +539,7 @@ int launch_mfma2(int KB, const MfmaScanArgs& a, int device, hipStream_t s, int* 
     // 1-KiB-per-row stages (one contiguous KiB per DMA instruction) measured 2-5 % faster than 512-B
     // stages at 10M x 512; they need 32 KiB of LDS per wave, so fall back when the k-lists do not fit
     const size_t lds_deep = (size_t)kScanWaves * mfma2_wave_lds_bytes(16) + (size_t)kScanWaves * NG * 16 * a.k * 8;
-    const bool deep = env_int("MVDB_MFMA_STAGE", 16) == 16 && lds_deep <= 160 * 1024;
+    const bool deep = kn().mfma_stage == 16 && lds_deep <= 160 * 1024;
     switch (KB) {
         case 8: return launch_mfma2_inst<8, NG, 8>(a, device, s, nb, metric);
         case 16: return deep ? launch_mfma2_inst<16, NG, 16>(a, device, s, nb, metric)
@@ -534,8 +594,8 @@ int launch_mfma_ng(int KB, const MfmaScanArgs& a, int device, hipStream_t s, int
 
 // nq >= 64, k <= 16: compute-bound tiled GEMM + top-k (scan_mfma_kernels.hpp, last section)
 bool gemm_path_ok(const mvdb_index* idx, int nq, int k, const int64_t* rows_dev) {
-    if (env_int("MVDB_DISABLE_GEMM_SCAN", 0)) return false;
-    if (nq < env_int("MVDB_GEMM_SCAN_MIN_NQ", 104) || k > kGemmScanMaxK || rows_dev || idx->metric != MVDB_METRIC_IP)
+    if (idx->kn.disable_gemm_scan) return false;
+    if (nq < idx->kn.gemm_scan_min_nq || k > kGemmScanMaxK || rows_dev || idx->metric != MVDB_METRIC_IP)
         return false;
     return idx->d % 16 == 0 && idx->ld == idx->d;
 }
@@ -553,10 +613,8 @@ int launch_gemm_scan(const mvdb_index* idx, const float* q, int nq, int k, int64
     a.cand = cand;
     const size_t lds = (size_t)2 * 2 * 16 * 132 * 4 + (size_t)4 * 64 * k * 8;
     MVDB_TRY(ensure_dynamic_lds((const void*)flat_scan_gemm_kernel, lds, idx->device));
-    int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, flat_scan_gemm_kernel, 256, lds) != hipSuccess || nb <= 0)
-        nb = 1;
-    nb = std::min(nb, std::max(1, env_int("MVDB_GEMM_SCAN_BLOCKS_PER_CU", 2)));
+    int nb = cached_occupancy((const void*)flat_scan_gemm_kernel, 256, lds, 1);
+    nb = std::min(nb, std::max(1, kn().gemm_scan_blocks_per_cu));
     const int qtiles = (nq + 127) / 128;
     const int64_t ntiles = (n + 127) / 128;
     const int gx = (int)std::max<int64_t>(1, std::min<int64_t>(ntiles, (int64_t)device_cus(idx->device) * nb / qtiles));
@@ -620,10 +678,10 @@ bool half_path_ok(const mvdb_index* idx);
 int mfma_gated_queries(const mvdb_index* idx);
 
 bool split_path_ok(const mvdb_index* idx, int nq, int k, const int64_t* rows_dev) {
-    if (env_int("MVDB_DISABLE_SPLIT_SCAN", 0)) return false;
+    if (idx->kn.disable_split_scan) return false;
     if (nq < 2 || rows_dev || idx->metric != MVDB_METRIC_IP) return false;
     // (k > 16 also needs the gated fp32-MFMA pass for the exact re-runs: the GEMM-tiled scan keeps 16 results per query)
-    if (k > kSplitMaxK && !(k <= kHalfMaxK && nq >= env_int("MVDB_SPLIT_SCAN_MIN_NQ", 33) && half_path_ok(idx) &&
+    if (k > kSplitMaxK && !(k <= kHalfMaxK && nq >= idx->kn.split_scan_min_nq && half_path_ok(idx) &&
                             (k <= kGemmScanMaxK || mfma_gated_queries(idx) > 0)))
         return false;
     // rows of known, sane norm only: the bound scales with max|x|, and bf16 keeps fp32's exponent range only up
@@ -633,7 +691,7 @@ bool split_path_ok(const mvdb_index* idx, int nq, int k, const int64_t* rows_dev
 }
 
 bool split32_ok(const mvdb_index* idx) {
-    if (env_int("MVDB_DISABLE_SPLIT32", 0)) return false;
+    if (idx->kn.disable_split32) return false;
     const int KB = idx->d / 16;
     return idx->d % 64 == 0 && (KB == 4 || KB == 8 || KB == 16 || KB == 24 || KB == 32);
 }
@@ -643,9 +701,8 @@ int launch_split32_inst(const Split32Args& b, int device, hipStream_t stream, in
     auto kern = flat_scan_split32_kernel<KB>;
     const size_t lds = (size_t)kScanWaves * 2 * 8192;
     MVDB_TRY(ensure_dynamic_lds((const void*)kern, lds, device));
-    int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, kScanThreads, lds) != hipSuccess || nb <= 0) nb = 1;
-    nb = std::min(nb, std::max(1, env_int("MVDB_SPLIT32_BLOCKS_PER_CU", 2)));
+    int nb = cached_occupancy((const void*)kern, kScanThreads, lds, 1);
+    nb = std::min(nb, std::max(1, kn().split32_blocks_per_cu));
     const int64_t ntiles = b.tile1 - b.tile0;
     const int64_t want = (ntiles + kScanWaves - 1) / kScanWaves;
     const int nblocks = (int)std::max<int64_t>(1, std::min<int64_t>(want, (int64_t)device_cus(device) * nb));
@@ -685,7 +742,7 @@ int launch_split_scan(const mvdb_index* idx, Workspace* ws, const float* q, int 
     a.ql = ql;
     a.nq = nq;
     void (*kern)(SplitScanArgs) = flat_scan_split_kernel<0>;
-    switch (env_int("MVDB_SPLIT_DBG", 0)) {  // timing ablations (invalid results), benchmarks/split_probe.py
+    switch (idx->kn.split_dbg) {  // timing ablations (invalid results), benchmarks/split_probe.py
         case 2: kern = flat_scan_split_kernel<2>; break;
         case 4: kern = flat_scan_split_kernel<4>; break;
         case 6: kern = flat_scan_split_kernel<6>; break;
@@ -708,7 +765,7 @@ int launch_split_scan(const mvdb_index* idx, Workspace* ws, const float* q, int 
     uint64_t* cand = ws->cand.p + (size_t)128 * kSplitKeep;          // [nq][gx][16]
     a.cand = cand;
     a.thr0 = nullptr;
-    a.stats = env_int("MVDB_SPLIT_STATS", 0) ? reinterpret_cast<unsigned int*>(ws->flags.p) + (ws->flags.cap - 32) : nullptr;
+    a.stats = idx->kn.split_stats ? reinterpret_cast<unsigned int*>(ws->flags.p) + (ws->flags.cap - 32) : nullptr;
     if (a.stats) MVDB_HIP(hipMemsetAsync(a.stats, 0, 8 + 12 * 8, stream));
     const int64_t seed_tiles = std::min<int64_t>(ntiles, cus);
     {
@@ -730,11 +787,11 @@ int launch_split_scan(const mvdb_index* idx, Workspace* ws, const float* q, int 
     // — each one a serial LDS round trip that also stalls the three waves it shares an exchange barrier with (1.4 ms
     // of a 5.2 ms launch); with floors refreshed after 0.26M and 2.1M rows it takes ~35.
     int gx = 0;
-    const int phase_growth = std::max(2, env_int("MVDB_SPLIT_PHASE_GROWTH", 8));
+    const int phase_growth = std::max(2, idx->kn.split_phase_growth);
     int64_t covered = seed_tiles;  // 128-row tiles scanned so far
     while (covered < ntiles) {
         int64_t upto = ntiles;
-        if (!env_int("MVDB_SPLIT_ONE_PHASE", 0) && covered * phase_growth * 2 <= ntiles) upto = covered * phase_growth;
+        if (!idx->kn.split_one_phase && covered * phase_growth * 2 <= ntiles) upto = covered * phase_growth;
         a.tile0 = covered;
         a.tile1 = upto;
         const int64_t rows_upto = std::min<int64_t>(n, upto * 128);
@@ -799,7 +856,7 @@ int launch_split_scan(const mvdb_index* idx, Workspace* ws, const float* q, int 
 
 // ---- fp16 single-product nomination pass (half_scan.hip): 33+ queries per corpus pass where a kernel exists ----------
 bool half_path_ok(const mvdb_index* idx) {
-    if (env_int("MVDB_DISABLE_HALF_SCAN", 0)) return false;
+    if (idx->kn.disable_half_scan) return false;
     return half_max_queries(idx->d) > 0 && idx->ld == idx->d && half_xscale(idx->row_norm_bound) > 0.f;
 }
 
@@ -821,7 +878,7 @@ int launch_half_pass(const mvdb_index* idx, Workspace* ws, const float* q, int n
     a.xscale = xscale;
     a.nq = nq;
     a.mask = mask;
-    a.stats = env_int("MVDB_SPLIT_STATS", 0) ? reinterpret_cast<unsigned int*>(ws->flags.p) + (ws->flags.cap - 32) : nullptr;
+    a.stats = idx->kn.split_stats ? reinterpret_cast<unsigned int*>(ws->flags.p) + (ws->flags.cap - 32) : nullptr;
     if (a.stats) MVDB_HIP(hipMemsetAsync(a.stats, 0, 8, stream));
     const int64_t ntiles = (n + 31) / 32;
     const int cus = device_cus(idx->device);
@@ -835,7 +892,7 @@ int launch_half_pass(const mvdb_index* idx, Workspace* ws, const float* q, int n
     a.tile0 = 0;
     a.tile1 = seed_tiles;
     a.thr0 = nullptr;
-    MVDB_TRY(launch_half_scan(idx->d, nqpad, true, a, idx->device, stream, &gx));
+    MVDB_TRY(launch_half_scan(idx->d, nqpad, true, a, idx->kn, idx->device, stream, &gx));
     hipLaunchKernelGGL(split_seed_kernel, dim3(nq), dim3(1024), 0, stream, cand, 2 * gx, (const uint64_t*)nullptr,
                        seed_keys, floors);
     MVDB_HIP(hipGetLastError());
@@ -845,8 +902,8 @@ int launch_half_pass(const mvdb_index* idx, Workspace* ws, const float* q, int n
     // refreshed floors its lists take hundreds of serial LDS inserts per wave).  Planned backwards: the LAST phase
     // covers at most `last_growth` times the rows before it — that leaves ~16 x last_growth candidates above its
     // floor for the 64-nominee certificate —, the earlier ones up to `growth` times.
-    const int growth = std::max(2, env_int("MVDB_HALF_PHASE_GROWTH", 16));
-    const int last_growth = std::max(2, env_int("MVDB_HALF_LAST_GROWTH", 6));
+    const int growth = std::max(2, idx->kn.half_phase_growth);
+    const int last_growth = std::max(2, idx->kn.half_last_growth);
     std::vector<int64_t> ends;
     for (int64_t b = ntiles, g = last_growth; b > seed_tiles; g = growth) {
         ends.push_back(b);
@@ -858,7 +915,7 @@ int launch_half_pass(const mvdb_index* idx, Workspace* ws, const float* q, int n
     for (size_t p = ends.size(); p-- > 0;) {
         a.tile0 = covered;
         a.tile1 = ends[p];
-        MVDB_TRY(launch_half_scan(idx->d, nqpad, false, a, idx->device, stream, &gx));
+        MVDB_TRY(launch_half_scan(idx->d, nqpad, false, a, idx->kn, idx->device, stream, &gx));
         covered = ends[p];
         if (p > 0) {
             hipLaunchKernelGGL(split_seed_kernel, dim3(nq), dim3(1024), 0, stream, cand, gx, seed_keys, seed_keys, floors);
@@ -895,12 +952,12 @@ int launch_half_pass(const mvdb_index* idx, Workspace* ws, const float* q, int n
 }
 
 bool mfma_path_ok(const mvdb_index* idx, int nq, int k, const int64_t* rows_dev) {
-    if (env_int("MVDB_DISABLE_MFMA_SCAN", 0)) return false;
+    if (idx->kn.disable_mfma_scan) return false;
     if (nq < 2 || k > kMaxFusedK || rows_dev) return false;
     if (idx->d % 16 || idx->ld != idx->d) return false;
     // squared L2 as |q|^2 + |x|^2 - 2 q.x: the staged kernel only (it sees whole rows go by)
     // (d <= 768: at d = 1024 the L2 form of the kernel spills; two 16-query groups only up to d = 384, same reason)
-    if (idx->metric != MVDB_METRIC_IP && !(idx->d % 128 == 0 && idx->d <= 768 && env_int("MVDB_MFMA_V", 2) == 2 && !env_int("MVDB_DISABLE_L2_MFMA", 0))) return false;
+    if (idx->metric != MVDB_METRIC_IP && !(idx->d % 128 == 0 && idx->d <= 768 && idx->kn.mfma_v == 2 && !idx->kn.disable_l2_mfma)) return false;
     const int KB = idx->d / 16;
     return KB == 4 || KB == 8 || KB == 16 || KB == 24 || KB == 32 || KB == 48 || KB == 64;
 }
@@ -929,6 +986,7 @@ __global__ __launch_bounds__(256) void mask_rank_kernel(int64_t* __restrict__ I,
 int search_core(const mvdb_index* idx, Workspace* ws, const float* q_dev, int nq, int k,
                 int normalize_q, const int64_t* rows_dev, int64_t m, int64_t label_offset,
                 float* D_dev, int64_t* I_dev, bool allow_split = true, const uint64_t* mask_dev = nullptr) {
+    KnobScope knobs(&idx->kn);
     hipStream_t s = ws->stream;
     // row list: its m entries; bitmap: the first m rows when the caller says how many rows the bitmap covers (a resident
     // row set built before later appends), else every row
@@ -938,10 +996,10 @@ int search_core(const mvdb_index* idx, Workspace* ws, const float* q_dev, int nq
     // re-runs of uncertified queries); everything else answers a bitmap one query at a time.
     const uint32_t* mask32 = reinterpret_cast<const uint32_t*>(mask_dev);
     const bool masked_batch = mask_dev && nq >= 2 && k <= kMaxFusedK && idx->metric == MVDB_METRIC_IP && idx->ld == idx->d &&
-                              mfma_gated_queries(idx) > 0 && !env_int("MVDB_DISABLE_MASKED_BATCH", 0);
+                              mfma_gated_queries(idx) > 0 && !idx->kn.disable_masked_batch;
     if (mask_dev) {
         rows_dev = nullptr;
-        if (!masked_batch || !half_path_ok(idx) || nq < env_int("MVDB_SPLIT_SCAN_MIN_NQ", 33)) allow_split = false;
+        if (!masked_batch || !half_path_ok(idx) || nq < idx->kn.split_scan_min_nq) allow_split = false;
     }
     // the other multi-query passes take neither a row list nor a bitmap
     const int64_t* restricted = mask_dev ? reinterpret_cast<const int64_t*>(mask_dev) : rows_dev;
@@ -980,7 +1038,7 @@ int search_core(const mvdb_index* idx, Workspace* ws, const float* q_dev, int nq
         // chunk plan: 128 queries per pass while >= 33 remain, then one 14..32-query pass where that kernel exists
         // (below ~14 queries the fp32 pass, whose cost grows with the query count, is faster than the fixed seed +
         // certification overhead: measured crossover 11 queries at 100k rows, 14 at 10M)
-        const int min_nq = env_int("MVDB_SPLIT_SCAN_MIN_NQ", 33);
+        const int min_nq = idx->kn.split_scan_min_nq;
         // where the fp16 single-product pass has a kernel (half_scan.hip) it serves the >= 33-query chunks
         const bool use_half = half_path_ok(idx);
         const int chunk = use_half ? half_max_queries(idx->d) : 128;
@@ -990,7 +1048,7 @@ int search_core(const mvdb_index* idx, Workspace* ws, const float* q_dev, int nq
             plan.emplace_back(q0, std::min(nq - q0, chunk));
             q0 += plan.back().second;
         }
-        if (!mask_dev && k <= kSplitMaxK && nq - q0 >= env_int("MVDB_SPLIT32_MIN_NQ", 14) && nq - q0 <= 32 && split32_ok(idx)) {
+        if (!mask_dev && k <= kSplitMaxK && nq - q0 >= idx->kn.split32_min_nq && nq - q0 <= 32 && split32_ok(idx)) {
             plan.emplace_back(q0, nq - q0);
             q0 = nq;
         }
@@ -1043,7 +1101,7 @@ int search_core(const mvdb_index* idx, Workspace* ws, const float* q_dev, int nq
             const int per_pass = mfma_gated_queries(idx);
             const int KB = idx->d / 16;
             int off = 0;
-            if (per_pass > 0 && !env_int("MVDB_DISABLE_MFMA_SCAN", 0)) {
+            if (per_pass > 0 && !idx->kn.disable_mfma_scan) {
                 MVDB_TRY(ws->cand.reserve((size_t)32 * scan_grid_upper_bound(idx->device) * k));
                 // (the GEMM scan keeps k <= 16 and takes no bitmap: those re-runs are all fp32-MFMA passes)
                 const int max_passes = (k > kGemmScanMaxK || mask_dev) ? (R + per_pass - 1) / per_pass : 2;
@@ -1156,7 +1214,7 @@ int search_core(const mvdb_index* idx, Workspace* ws, const float* q_dev, int nq
             qsrc = ws->qn.p;
         }
         MVDB_TRY(ws->cand.reserve((size_t)128 * scan_grid_upper_bound(idx->device) * k));
-        const int min_nq = env_int("MVDB_GEMM_SCAN_MIN_NQ", 104);
+        const int min_nq = idx->kn.gemm_scan_min_nq;
         int q0 = 0;
         while (nq - q0 >= min_nq) {
             const int take = std::min(nq - q0, 128);
@@ -1196,8 +1254,8 @@ int search_core(const mvdb_index* idx, Workspace* ws, const float* q_dev, int nq
             const int left = nq - q0;
             // staged kernel: 32 queries per pass (two query groups share each B fragment); the v1
             // kernel with two groups runs at one wave per SIMD and loses to two 16-query passes
-            const bool staged = idx->d % 128 == 0 && env_int("MVDB_MFMA_V", 2) == 2;
-            const bool two_groups = left > 16 && idx->d <= (idx->metric == MVDB_METRIC_IP ? 512 : 384) && env_int("MVDB_MFMA_NG2", staged ? 1 : 0);
+            const bool staged = idx->d % 128 == 0 && idx->kn.mfma_v == 2;
+            const bool two_groups = left > 16 && idx->d <= (idx->metric == MVDB_METRIC_IP ? 512 : 384) && (idx->kn.mfma_ng2 >= 0 ? idx->kn.mfma_ng2 != 0 : staged);
             const int take = two_groups ? std::min(left, 32) : std::min(left, 16);
             MfmaScanArgs ma;
             ma.X = idx->X;
@@ -1320,6 +1378,15 @@ int fetch_results(Workspace* ws, size_t total, float* D_host, int64_t* I_host) {
     return 0;
 }
 
+// A search being captured into a hipGraph: from now on this workspace keeps every buffer it outgrows (RetireScope), so a
+// later, larger eager call on the same stream cannot free memory the graph still names.
+void note_capture(Workspace* ws) {
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (ws->stream && !ws->captured && hipStreamIsCapturing(ws->stream, &st) == hipSuccess &&
+        st == hipStreamCaptureStatusActive)
+        ws->captured = true;
+}
+
 int check_search_args(const mvdb_index* idx, const void* q, int nq, int k, const void* D,
                       const void* I) {
     if (!idx) return fail(MVDB_ERR_ARG, "index is NULL");
@@ -1340,8 +1407,9 @@ int grow(mvdb_index* idx, int64_t need) {
     float* nx = nullptr;
     MVDB_HIP(hipMalloc((void**)&nx, (size_t)(cap + kRowSlack) * idx->ld * sizeof(float)));
     if (idx->n > 0) {
-        hipError_t e = hipMemcpy(nx, idx->X, (size_t)idx->n * idx->ld * sizeof(float),
-                                 hipMemcpyDeviceToDevice);
+        hipError_t e = hipMemcpyAsync(nx, idx->X, (size_t)idx->n * idx->ld * sizeof(float),
+                                      hipMemcpyDeviceToDevice, idx->mut);
+        if (e == hipSuccess) e = hipStreamSynchronize(idx->mut);
         if (e != hipSuccess) {
             (void)hipFree(nx);
             return fail(MVDB_ERR_HIP, "device copy while growing index failed: %s",
@@ -1404,7 +1472,15 @@ int mvdb_index_create(int d, int metric, int device, mvdb_index** out) {
     idx->d4 = (int)(idx->ld / 4);
     idx->metric = metric;
     idx->device = device;
+    idx->kn = read_knobs();
     *out = idx;
+    return 0;
+}
+
+int mvdb_index_reload_env(mvdb_index* idx) {
+    if (!idx) return fail(MVDB_ERR_ARG, "index is NULL");
+    std::unique_lock<std::shared_mutex> lk(idx->mu);
+    idx->kn = read_knobs();
     return 0;
 }
 
@@ -1413,7 +1489,9 @@ int mvdb_index_free(mvdb_index* idx) {
     {
         std::unique_lock<std::shared_mutex> lk(idx->mu);
         DeviceGuard dg(idx->device);
-        (void)hipDeviceSynchronize();
+        (void)quiesce(idx);
+        if (idx->mut) (void)hipStreamDestroy(idx->mut);
+        if (idx->normmax) (void)hipFree(idx->normmax);
         for (Workspace* w : idx->free_ws) {
             w->destroy();
             delete w;
@@ -1436,7 +1514,7 @@ int mvdb_index_reset(mvdb_index* idx) {
     if (!idx) return fail(MVDB_ERR_ARG, "index is NULL");
     std::unique_lock<std::shared_mutex> lk(idx->mu);
     DeviceGuard dg(idx->device);
-    MVDB_TRY(quiesce());
+    MVDB_TRY(quiesce(idx));
     idx->n = 0;
     idx->row_norm_bound = 0.f;
     ++idx->renumbered;
@@ -1453,12 +1531,18 @@ int mvdb_index_reserve(mvdb_index* idx, int64_t n) {
     std::unique_lock<std::shared_mutex> lk(idx->mu);
     DeviceGuard dg(idx->device);
     if (n <= idx->cap) return 0;
+    MVDB_TRY(quiesce(idx));
     // exact-size growth (no 1.5x slack): the caller knows the final size
     float* nx = nullptr;
     MVDB_HIP(hipMalloc((void**)&nx, (size_t)(n + kRowSlack) * idx->ld * sizeof(float)));
-    if (idx->n > 0)
-        MVDB_HIP(hipMemcpy(nx, idx->X, (size_t)idx->n * idx->ld * sizeof(float),
-                           hipMemcpyDeviceToDevice));
+    if (idx->n > 0) {
+        hipError_t e = hipMemcpyAsync(nx, idx->X, (size_t)idx->n * idx->ld * sizeof(float), hipMemcpyDeviceToDevice, idx->mut);
+        if (e == hipSuccess) e = hipStreamSynchronize(idx->mut);
+        if (e != hipSuccess) {
+            (void)hipFree(nx);
+            return fail(MVDB_ERR_HIP, "device copy while reserving failed: %s", hipGetErrorString(e));
+        }
+    }
     if (idx->X) (void)hipFree(idx->X);
     idx->X = nx;
     idx->cap = n;
@@ -1474,17 +1558,17 @@ static int note_row_norms(mvdb_index* idx, const float* dst, int64_t n, int norm
         idx->row_norm_bound = std::max(idx->row_norm_bound, 1.000004f);
         return 0;
     }
-    unsigned int* dmax = nullptr;
-    MVDB_HIP(hipMalloc((void**)&dmax, sizeof(unsigned int)));
+    if (!idx->normmax) MVDB_HIP(hipMalloc((void**)&idx->normmax, sizeof(unsigned int)));
+    unsigned int* dmax = idx->normmax;
     unsigned int bits = 0;
-    hipError_t e = hipMemset(dmax, 0, sizeof(unsigned int));
+    hipError_t e = hipMemsetAsync(dmax, 0, sizeof(unsigned int), idx->mut);
     if (e == hipSuccess) {
         const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((n + 3) / 4, (int64_t)device_cus(idx->device) * 16));
-        hipLaunchKernelGGL(max_row_norm2_kernel, dim3(grid), dim3(256), 0, nullptr, dst, n, idx->ld, idx->d4, dmax);
+        hipLaunchKernelGGL(max_row_norm2_kernel, dim3(grid), dim3(256), 0, idx->mut, dst, n, idx->ld, idx->d4, dmax);
         e = hipGetLastError();
     }
-    if (e == hipSuccess) e = hipMemcpy(&bits, dmax, sizeof(bits), hipMemcpyDeviceToHost);
-    (void)hipFree(dmax);
+    if (e == hipSuccess) e = hipMemcpyAsync(&bits, dmax, sizeof(bits), hipMemcpyDeviceToHost, idx->mut);
+    if (e == hipSuccess) e = hipStreamSynchronize(idx->mut);
     MVDB_HIP(e);
     float n2;
     memcpy(&n2, &bits, sizeof(n2));
@@ -1502,20 +1586,19 @@ int mvdb_index_add(mvdb_index* idx, const float* x_host, int64_t n, int normaliz
     DeviceGuard dg(idx->device);
     if (idx->n + n > 0xFFFFFFFFll)
         return fail(MVDB_ERR_ARG, "more than 2^32-1 rows per device index are not supported");
-    MVDB_TRY(quiesce());
+    MVDB_TRY(quiesce(idx));
     MVDB_TRY(grow(idx, idx->n + n));
     float* dst = idx->X + idx->n * idx->ld;
+    // (the rows are not visible to searches until idx->n moves, below; everything runs on the index's own stream)
     if (idx->ld == idx->d) {
-        MVDB_HIP(hipMemcpy(dst, x_host, (size_t)n * idx->d * sizeof(float), hipMemcpyHostToDevice));
+        MVDB_HIP(hipMemcpyAsync(dst, x_host, (size_t)n * idx->d * sizeof(float), hipMemcpyHostToDevice, idx->mut));
     } else {
-        MVDB_HIP(hipMemset(dst, 0, (size_t)n * idx->ld * sizeof(float)));
-        MVDB_HIP(hipMemcpy2D(dst, idx->ld * sizeof(float), x_host, idx->d * sizeof(float),
-                             idx->d * sizeof(float), (size_t)n, hipMemcpyHostToDevice));
+        MVDB_HIP(hipMemsetAsync(dst, 0, (size_t)n * idx->ld * sizeof(float), idx->mut));
+        MVDB_HIP(hipMemcpy2DAsync(dst, idx->ld * sizeof(float), x_host, idx->d * sizeof(float),
+                                  idx->d * sizeof(float), (size_t)n, hipMemcpyHostToDevice, idx->mut));
     }
-    if (normalize) {
-        MVDB_TRY(normalize_range(idx, dst, n, nullptr));
-        MVDB_HIP(hipDeviceSynchronize());
-    }
+    if (normalize) MVDB_TRY(normalize_range(idx, dst, n, idx->mut));
+    MVDB_HIP(hipStreamSynchronize(idx->mut));  // the caller's buffer is free again, the rows are in place
     MVDB_TRY(note_row_norms(idx, dst, n, normalize));
     idx->n += n;
     return 0;
@@ -1530,21 +1613,25 @@ int mvdb_index_add_device(mvdb_index* idx, const float* x_dev, int64_t n, int no
     DeviceGuard dg(idx->device);
     if (idx->n + n > 0xFFFFFFFFll)
         return fail(MVDB_ERR_ARG, "more than 2^32-1 rows per device index are not supported");
-    MVDB_TRY(quiesce());
+    MVDB_TRY(quiesce(idx));
     MVDB_TRY(grow(idx, idx->n + n));
     float* dst = idx->X + idx->n * idx->ld;
+    // x_dev is the caller's: whatever produced it must be complete (or ordered before the legacy stream) — as before, the
+    // copy below waits for the legacy stream only when it is issued there, so it is issued on the mutators' stream after a
+    // legacy-stream join
+    MVDB_HIP(hipStreamSynchronize(nullptr));
     if (idx->ld == idx->d) {
-        MVDB_HIP(hipMemcpy(dst, x_dev, (size_t)n * idx->d * sizeof(float), hipMemcpyDeviceToDevice));
+        MVDB_HIP(hipMemcpyAsync(dst, x_dev, (size_t)n * idx->d * sizeof(float), hipMemcpyDeviceToDevice, idx->mut));
     } else {
         const int cus = device_cus(idx->device);
         const int64_t total = n * idx->ld;
         const int grid = (int)std::min<int64_t>((total + 255) / 256, (int64_t)cus * 16);
-        hipLaunchKernelGGL(pad_rows_kernel, dim3(grid), dim3(256), 0, nullptr, dst, x_dev, n, idx->d,
+        hipLaunchKernelGGL(pad_rows_kernel, dim3(grid), dim3(256), 0, idx->mut, dst, x_dev, n, idx->d,
                            idx->ld);
         MVDB_HIP(hipGetLastError());
     }
-    if (normalize) MVDB_TRY(normalize_range(idx, dst, n, nullptr));
-    MVDB_HIP(hipDeviceSynchronize());
+    if (normalize) MVDB_TRY(normalize_range(idx, dst, n, idx->mut));
+    MVDB_HIP(hipStreamSynchronize(idx->mut));
     MVDB_TRY(note_row_norms(idx, dst, n, normalize));
     idx->n += n;
     return 0;
@@ -1559,17 +1646,17 @@ int mvdb_index_add_synthetic(mvdb_index* idx, int64_t n, uint64_t seed, int64_t 
     DeviceGuard dg(idx->device);
     if (idx->n + n > 0xFFFFFFFFll)
         return fail(MVDB_ERR_ARG, "more than 2^32-1 rows per device index are not supported");
-    MVDB_TRY(quiesce());
+    MVDB_TRY(quiesce(idx));
     MVDB_TRY(grow(idx, idx->n + n));
     float* dst = idx->X + idx->n * idx->ld;
     const int cus = device_cus(idx->device);
     const int64_t total = n * idx->d4;
     const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((total + 255) / 256, (int64_t)cus * 16));
-    hipLaunchKernelGGL(synth_fill_kernel, dim3(grid), dim3(256), 0, nullptr, dst, n, idx->ld, idx->d,
+    hipLaunchKernelGGL(synth_fill_kernel, dim3(grid), dim3(256), 0, idx->mut, dst, n, idx->ld, idx->d,
                        seed, first_row);
     MVDB_HIP(hipGetLastError());
-    if (normalize) MVDB_TRY(normalize_range(idx, dst, n, nullptr));
-    MVDB_HIP(hipDeviceSynchronize());
+    if (normalize) MVDB_TRY(normalize_range(idx, dst, n, idx->mut));
+    MVDB_HIP(hipStreamSynchronize(idx->mut));
     MVDB_TRY(note_row_norms(idx, dst, n, normalize));
     idx->n += n;
     return 0;
@@ -1609,7 +1696,7 @@ int mvdb_index_remove_rows(mvdb_index* idx, const int64_t* rows_host, int64_t m)
             return fail(MVDB_ERR_ARG, "row %lld listed twice", (long long)del[i]);
     }
     DeviceGuard dg(idx->device);
-    MVDB_TRY(quiesce());
+    MVDB_TRY(quiesce(idx));
     ++idx->renumbered;
     const int64_t n_new = idx->n - m;
     if (n_new == 0) {
@@ -1622,34 +1709,36 @@ int mvdb_index_remove_rows(mvdb_index* idx, const int64_t* rows_host, int64_t m)
     if (tail_new > 0) {
         int64_t *del_dev = nullptr, *map_dev = nullptr;
         float* tmp = nullptr;
-        MVDB_HIP(hipMalloc((void**)&del_dev, (size_t)m * sizeof(int64_t)));
-        hipError_t e1 = hipMalloc((void**)&map_dev, (size_t)tail_new * sizeof(int64_t));
-        hipError_t e2 = hipMalloc((void**)&tmp, (size_t)tail_new * idx->ld * sizeof(float));
+        // stream-ordered temporaries: hipFree would synchronise the whole device
+        MVDB_HIP(hipMallocAsync((void**)&del_dev, (size_t)m * sizeof(int64_t), idx->mut));
+        hipError_t e1 = hipMallocAsync((void**)&map_dev, (size_t)tail_new * sizeof(int64_t), idx->mut);
+        hipError_t e2 = hipMallocAsync((void**)&tmp, (size_t)tail_new * idx->ld * sizeof(float), idx->mut);
         int rc = 0;
         if (e1 != hipSuccess || e2 != hipSuccess) {
             rc = fail(MVDB_ERR_OOM, "device allocation for row compaction failed");
         } else {
             for (auto& v : del) v -= first;  // positions relative to the tail
-            hipError_t e = hipMemcpy(del_dev, del.data(), (size_t)m * sizeof(int64_t),
-                                     hipMemcpyHostToDevice);
+            hipError_t e = hipMemcpyAsync(del_dev, del.data(), (size_t)m * sizeof(int64_t),
+                                          hipMemcpyHostToDevice, idx->mut);
             if (e == hipSuccess) {
                 hipLaunchKernelGGL(build_keep_map_kernel, dim3((unsigned)((tail_new + 255) / 256)),
-                                   dim3(256), 0, nullptr, del_dev, m, tail_new, map_dev);
+                                   dim3(256), 0, idx->mut, del_dev, m, tail_new, map_dev);
                 const int64_t total = tail_new * idx->d4;
                 const int grid = (int)std::max<int64_t>(
                     1, std::min<int64_t>((total + 255) / 256, (int64_t)device_cus(idx->device) * 16));
                 float* tail = idx->X + first * idx->ld;
-                hipLaunchKernelGGL(gather_rows_kernel, dim3(grid), dim3(256), 0, nullptr, tmp, tail,
+                hipLaunchKernelGGL(gather_rows_kernel, dim3(grid), dim3(256), 0, idx->mut, tmp, tail,
                                    map_dev, tail_new, idx->ld);
                 e = hipMemcpyAsync(tail, tmp, (size_t)tail_new * idx->ld * sizeof(float),
-                                   hipMemcpyDeviceToDevice, nullptr);
-                if (e == hipSuccess) e = hipDeviceSynchronize();
+                                   hipMemcpyDeviceToDevice, idx->mut);
+                if (e == hipSuccess) e = hipStreamSynchronize(idx->mut);
             }
             if (e != hipSuccess) rc = fail(MVDB_ERR_HIP, "row compaction failed: %s", hipGetErrorString(e));
         }
-        if (del_dev) (void)hipFree(del_dev);
-        if (map_dev) (void)hipFree(map_dev);
-        if (tmp) (void)hipFree(tmp);
+        if (del_dev) (void)hipFreeAsync(del_dev, idx->mut);
+        if (map_dev) (void)hipFreeAsync(map_dev, idx->mut);
+        if (tmp) (void)hipFreeAsync(tmp, idx->mut);
+        (void)hipStreamSynchronize(idx->mut);  // (the pool returns the memory to the device at this point)
         if (rc) return rc;
     }
     idx->n = n_new;
@@ -1730,6 +1819,8 @@ int mvdb_index_search_device(const mvdb_index* idx, const float* q_dev, int nq, 
     Workspace* ws = idx->for_stream((hipStream_t)stream);
     if (!ws) return fail(MVDB_ERR_HIP, "workspace allocation failed");
     std::lock_guard<std::mutex> use(ws->use_mu);
+    note_capture(ws);
+    RetireScope keep(ws->captured ? &ws->retired : nullptr);
     const float* q = q_dev;
     if (idx->ld != idx->d) {  // pad the dense queries to the row stride
         MVDB_TRY(ws->q.reserve((size_t)nq * idx->ld));
@@ -1764,6 +1855,8 @@ int mvdb_index_search_subset_device(const mvdb_index* idx, const float* q_dev, i
     Workspace* ws = idx->for_stream((hipStream_t)stream);
     if (!ws) return fail(MVDB_ERR_HIP, "workspace allocation failed");
     std::lock_guard<std::mutex> use(ws->use_mu);
+    note_capture(ws);
+    RetireScope keep(ws->captured ? &ws->retired : nullptr);
     const float* q = q_dev;
     if (idx->ld != idx->d) {
         MVDB_TRY(ws->q.reserve((size_t)nq * idx->ld));
@@ -1804,6 +1897,8 @@ int mvdb_index_search_masked_device(const mvdb_index* idx, const float* q_dev, i
     Workspace* ws = idx->for_stream((hipStream_t)stream);
     if (!ws) return fail(MVDB_ERR_HIP, "workspace allocation failed");
     std::lock_guard<std::mutex> use(ws->use_mu);
+    note_capture(ws);
+    RetireScope keep(ws->captured ? &ws->retired : nullptr);
     const float* q = q_dev;
     if (idx->ld != idx->d) {
         MVDB_TRY(ws->q.reserve((size_t)nq * idx->ld));
@@ -1903,7 +1998,8 @@ int mvdb_rowset_create(const mvdb_index* idx, const int64_t* rows_host, int64_t 
         const size_t words = (size_t)((n + 63) / 64);
         std::vector<uint64_t> w(std::max<size_t>(words, 1), excluded ? ~0ull : 0ull);
         if (excluded) {
-            if (n & 63) w[words - 1] = (1ull << (n & 63)) - 1ull;  // bits at or beyond n stay clear
+            if (n == 0) w[0] = 0;                                   // an empty index: no row is selected
+            else if (n & 63) w[words - 1] = (1ull << (n & 63)) - 1ull;  // bits at or beyond n stay clear
             int64_t removed = 0;
             for (int64_t i = 0; i < m; ++i) {
                 uint64_t& word = w[rows_host[i] >> 6];
@@ -1947,16 +2043,39 @@ int mvdb_rowset_free(mvdb_rowset* rs) {
     return 0;
 }
 
-int mvdb_index_search_rowset(const mvdb_index* idx, const float* q_host, int nq, int k, int normalize_q,
-                             const mvdb_rowset* rs, float* D_host, int64_t* I_host) {
-    MVDB_TRY(check_search_args(idx, q_host, nq, k, D_host, I_host));
+// the body shared by the host and the device entry points: queries on the device, results to device buffers
+static int rowset_check(const mvdb_index* idx, const mvdb_rowset* rs) {
     if (!rs) return fail(MVDB_ERR_ARG, "row set is NULL");
-    std::shared_lock<std::shared_mutex> lk(idx->mu);
     // rows appended since the set was built are simply not part of it (the filter was evaluated before they arrived);
     // a SHRUNK index has renumbered its rows: the set is stale
     if (rs->device != idx->device || rs->n_at_create > idx->n || rs->renumbered != idx->renumbered)
         return fail(MVDB_ERR_ARG, "the row set was built for another state of the index (%lld rows then, %lld now)",
                     (long long)rs->n_at_create, (long long)idx->n);
+    return 0;
+}
+static int rowset_search_core(const mvdb_index* idx, Workspace* ws, const float* q, int nq, int k, int normalize_q,
+                              const mvdb_rowset* rs, int64_t label_offset, float* D_dev, int64_t* I_dev) {
+    const int64_t total = (int64_t)nq * k;
+    if (rs->count == 0 || (rs->mask && rs->n_at_create == 0)) {  // nothing selected (search_core reads m == 0 as "every row")
+        hipLaunchKernelGGL(fill_missing_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ws->stream, D_dev, I_dev,
+                           total, idx->metric);
+        MVDB_HIP(hipGetLastError());
+        return 0;
+    }
+    if (rs->mask)
+        return search_core(idx, ws, q, nq, k, normalize_q, nullptr, rs->n_at_create, label_offset, D_dev, I_dev, true, rs->mask);
+    MVDB_TRY(search_core(idx, ws, q, nq, k, normalize_q, rs->rows, rs->count, 0, D_dev, I_dev));
+    hipLaunchKernelGGL(map_subset_labels_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ws->stream, I_dev, total,
+                       (const int64_t*)rs->rows, label_offset);
+    MVDB_HIP(hipGetLastError());
+    return 0;
+}
+
+int mvdb_index_search_rowset(const mvdb_index* idx, const float* q_host, int nq, int k, int normalize_q,
+                             const mvdb_rowset* rs, float* D_host, int64_t* I_host) {
+    MVDB_TRY(check_search_args(idx, q_host, nq, k, D_host, I_host));
+    std::shared_lock<std::shared_mutex> lk(idx->mu);
+    MVDB_TRY(rowset_check(idx, rs));
     DeviceGuard dg(idx->device);
     Workspace* ws = idx->acquire();
     if (!ws) return MVDB_ERR_HIP;
@@ -1966,24 +2085,33 @@ int mvdb_index_search_rowset(const mvdb_index* idx, const float* q_host, int nq,
         const size_t total = (size_t)nq * k;
         if ((rc = ws->out.reserve(total + (total + 1) / 2))) break;
         float* D_dev = reinterpret_cast<float*>(ws->out.p + total);
-        if (rs->mask) {
-            if ((rc = search_core(idx, ws, ws->q.p, nq, k, normalize_q, nullptr, rs->n_at_create, 0, D_dev, ws->out.p, true, rs->mask))) break;
-        } else {
-            // count == 0: search_core's empty-corpus branch needs a non-NULL list to take the subset meaning
-            if ((rc = search_core(idx, ws, ws->q.p, nq, k, normalize_q, rs->rows, rs->count, 0, D_dev, ws->out.p))) break;
-            if (rs->count > 0) {
-                hipLaunchKernelGGL(map_subset_labels_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ws->stream,
-                                   ws->out.p, (int64_t)total, (const int64_t*)rs->rows, (int64_t)0);
-                if (hipGetLastError() != hipSuccess) {
-                    rc = fail(MVDB_ERR_HIP, "label mapping failed");
-                    break;
-                }
-            }
-        }
+        if ((rc = rowset_search_core(idx, ws, ws->q.p, nq, k, normalize_q, rs, 0, D_dev, ws->out.p))) break;
         rc = fetch_results(ws, total, D_host, I_host);
     } while (0);
     idx->release(ws);
     return rc;
+}
+
+int mvdb_index_search_rowset_device(const mvdb_index* idx, const float* q_dev, int nq, int k, int normalize_q,
+                                    const mvdb_rowset* rs, int64_t label_offset, float* D_dev, int64_t* I_dev, void* stream) {
+    MVDB_TRY(check_search_args(idx, q_dev, nq, k, D_dev, I_dev));
+    std::shared_lock<std::shared_mutex> lk(idx->mu);
+    MVDB_TRY(rowset_check(idx, rs));
+    DeviceGuard dg(idx->device);
+    Workspace* ws = idx->for_stream((hipStream_t)stream);
+    if (!ws) return fail(MVDB_ERR_HIP, "workspace allocation failed");
+    std::lock_guard<std::mutex> use(ws->use_mu);
+    note_capture(ws);
+    RetireScope keep(ws->captured ? &ws->retired : nullptr);
+    const float* q = q_dev;
+    if (idx->ld != idx->d) {
+        MVDB_TRY(ws->q.reserve((size_t)nq * idx->ld));
+        hipLaunchKernelGGL(pad_rows_kernel, dim3((unsigned)(((int64_t)nq * idx->ld + 255) / 256)),
+                           dim3(256), 0, ws->stream, ws->q.p, q_dev, (int64_t)nq, idx->d, idx->ld);
+        MVDB_HIP(hipGetLastError());
+        q = ws->q.p;
+    }
+    return rowset_search_core(idx, ws, q, nq, k, normalize_q, rs, label_offset, D_dev, I_dev);
 }
 
 int mvdb_merge_topk_device(int metric, int nlists, int nq, int k, const float* D_dev,

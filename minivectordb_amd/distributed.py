@@ -82,11 +82,14 @@ class Collective:
     TORCH = "torch.distributed.all_gather_into_tensor"
     NATIVE = "ncclAllGather (mvdb_allgather_topk, libmvdb.so)"
 
-    def __init__(self, rank, world, device, group=None, want=None):
+    def __init__(self, rank, world, device, group=None, want=None, always=False):
+        """always: bring the route up even at world == 1 (a one-rank process group must exist) — how the one-GPU test
+        box runs ncclCommInitRank, the probe gather and the agreement logic that an N-GPU job runs."""
         self.rank, self.world, self.device, self.group = int(rank), int(world), device, group
         self.comm = None
         self.name = "none"
-        if self.world > 1:
+        self.details = {}
+        if self.world > 1 or always:
             self.name = self._pick(want)
 
     def _agree(self, ok):
@@ -153,6 +156,7 @@ class Collective:
             err = e
         if not self._agree(good):
             return give_up(err if err is not None else "another rank failed to bring the communicator up")
+        self.details = {"unique_id_from": "rank 0 via broadcast_object_list", "probe": "16-byte blocks, rank order verified"}
         return self.NATIVE
 
     def all_gather(self, gathered, local):
@@ -179,11 +183,16 @@ class ShardedSearcher:
     merge          callable(gathered: PackedTopK, D_out, I_out): merges `world` lists
     collective     None / "native" / "torch" (a route to bring up for this searcher), or a `Collective` that several
                    searchers share (it is then NOT closed by this searcher)
+    exchange_always  run the all-gather and the merge even at world == 1 (one-GPU test of the whole exchange path)
+
+    `rows` of search_device / local_search: None, an int64 device tensor of LOCAL row numbers, or a resident row set of
+    the index (`_native.RowSet`: a filter's local rows kept on the device across queries).
     """
 
     def __init__(self, index, k, rank=0, world=1, rows_per_rank=None, label_offset=None, device=None, group=None,
-                 metric=0, local_search=None, merge=None, collective=None):
+                 metric=0, local_search=None, merge=None, collective=None, exchange_always=False):
         self.index, self.k, self.rank, self.world = index, int(k), int(rank), int(world)
+        self._always = bool(exchange_always)
         self.group = group
         self.metric = metric
         self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
@@ -195,7 +204,7 @@ class ShardedSearcher:
         self._bufs = {}
         self._owns_collective = not isinstance(collective, Collective)
         self._collective = collective if isinstance(collective, Collective) else Collective(
-            self.rank, self.world, self.device, group=group, want=collective)
+            self.rank, self.world, self.device, group=group, want=collective, always=self._always)
         self.collective = self._collective.name
 
     def _all_gather(self, gathered, local):
@@ -208,6 +217,9 @@ class ShardedSearcher:
         if rows is None:
             self.index.search_device(q.data_ptr(), q.shape[0], k, D.data_ptr(), I.data_ptr(), stream=stream,
                                      label_offset=label_offset, normalize_q=normalize_q)
+        elif not torch.is_tensor(rows):   # a resident row set: nothing to upload
+            self.index.search_rowset_device(q.data_ptr(), q.shape[0], k, rows, D.data_ptr(), I.data_ptr(), stream=stream,
+                                            normalize_q=normalize_q, label_offset=label_offset)
         else:
             self.index.search_subset_device(q.data_ptr(), q.shape[0], k, rows.data_ptr(), rows.shape[0],
                                             D.data_ptr(), I.data_ptr(), stream=stream, normalize_q=normalize_q,
@@ -226,7 +238,7 @@ class ShardedSearcher:
         b = self._bufs.get(nq)
         if b is None:
             local = PackedTopK(nq, self.k, self.device, 1)
-            gathered = PackedTopK(nq, self.k, self.device, self.world) if self.world > 1 else None
+            gathered = PackedTopK(nq, self.k, self.device, self.world) if (self.world > 1 or self._always) else None
             D_out = torch.empty((nq, self.k), dtype=torch.float32, device=self.device)
             I_out = torch.empty((nq, self.k), dtype=torch.int64, device=self.device)
             b = (local, gathered, D_out, I_out)
@@ -234,8 +246,8 @@ class ShardedSearcher:
         return b
 
     def search_device(self, q, rows=None, normalize_q=False):
-        """q: [nq, d] float32 tensor on this rank's device (identical on every rank); rows: None, or an int64
-        device tensor of this rank's LOCAL row numbers to restrict the scan to (may be empty).
+        """q: [nq, d] float32 tensor on this rank's device (identical on every rank); rows: None, an int64 device
+        tensor of this rank's LOCAL row numbers to restrict the scan to (may be empty), or a resident row set.
         Returns (D [nq,k], I [nq,k]) device tensors holding the GLOBAL top-k (valid until the next
         call with the same nq).  Nothing on this path touches the host."""
         nq = q.shape[0]
@@ -245,7 +257,7 @@ class ShardedSearcher:
             self._local_search(q, D_loc, I_loc, self.label_offset)
         else:
             self._local_search(q, D_loc, I_loc, self.label_offset, rows=rows, normalize_q=normalize_q)
-        if self.world == 1:
+        if self.world == 1 and not self._always:
             return D_loc, I_loc
         self._all_gather(gathered, local)
         self._merge(gathered, D_out, I_out)
@@ -263,33 +275,36 @@ class DistributedShardedVectorDatabase:
     ranks of a ``torch.distributed`` job (one process per GPU).
 
     Every rank unpickles ONLY its own contiguous run of shard files (``shard_files_for_rank``; `files_opened` lists
-    them) — their embeddings go to its HBM, their bookkeeping (ids, metadata, inverted index) is exchanged with one
-    ``all_gather_object`` so that every rank ends up with the bookkeeping of ALL shards (global row numbers are the
-    reference's stacking order, sharded_vector_database.py:45-71) without any rank reading another rank's
-    embeddings from disk (at BASELINE config 4 that would be 164 GB read eight times).
+    them) — their embeddings go to its HBM, their bookkeeping (ids, metadata, inverted index) is exchanged file by
+    file (one bounded ``all_gather_object`` per round of files, over a gloo side group when the job's group is RCCL, so
+    the pickles never stage through HBM) until every rank holds the bookkeeping of ALL shards (global row numbers are the
+    reference's stacking order, sharded_vector_database.py:45-71) without any rank reading another rank's embeddings
+    from disk (at BASELINE config 4 that would be 164 GB read eight times).
     ``find_most_similar`` is SPMD: every rank calls it with the same arguments and gets the same,
     global answer — local scan (full, or restricted to the filtered rows this rank owns) written straight
     into the packed exchange block on the device, ONE all-gather of the per-shard top-k, k-way merge on
-    every rank, one copy of the k results to the host.  Exact score ties resolve to the lower global row
+    every rank, one copy of the k results to the host.  A filter's LOCAL rows stay resident on the device
+    (`mvdb_rowset`, one per filter expression, as `_dbcore` keeps them for the single-GPU classes): a repeated filter
+    evaluates nothing and uploads nothing.  Exact score ties resolve to the lower global row
     number.  Writes are not supported in this mode (build the directory with ``ShardedVectorDatabase``);
     world * k <= 16384 (one block sorts the gathered lists in LDS).  The exchange route (RCCL communicator) is
     brought up once per database and shared by the per-k searchers; `close()` releases it.
 
-    `index_factory` / `local_search` / `merge` exist for the world_size-2 ``gloo`` test on CPU.
+    `index_factory` / `local_search` / `merge` exist for the world_size-2 ``gloo`` test on CPU; `collective`
+    ("native" | "torch") and `exchange_always` for the one-GPU test of the RCCL route at world = 1.
     """
 
     def __init__(self, storage_dir='db_shards', rank=None, world=None, device=None, group=None,
-                 index_factory=None, local_search=None, merge=None):
+                 index_factory=None, local_search=None, merge=None, collective=None, exchange_always=False):
         import pickle
         from collections import defaultdict
 
         import numpy as np
 
-        from ._dbcore import FilterAndRerankMixin, _AllRows
+        from ._dbcore import FilterAndRerankMixin, _IdIndex
         from .sharded_vector_database import shard_files_for_rank
 
         self._np = np
-        self._AllRows = _AllRows
         if world is None:
             world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         if rank is None:
@@ -310,35 +325,30 @@ class DistributedShardedVectorDatabase:
             del data
         self.local_rows = sum(len(b[0]) for b in book)
         dim = pieces[0].shape[1] if pieces else None
-        if self.world > 1:
-            # ranks own contiguous runs of files in rank order, so rank order IS the reference's stacking order
-            everyone = [None] * self.world
-            dist.all_gather_object(everyone, (book, dim), group=group)
-        else:
-            everyone = [(book, dim)]
-        self.metadata, self.unique_ids = [], []
+        per_rank, dims = self._exchange_bookkeeping(book, dim)
+        self.metadata, unique_ids = [], []
         self.inverted_index = defaultdict(set)
         self.first_row = 0
-        for r, (rbook, _) in enumerate(everyone):
+        for r, rbook in enumerate(per_rank):
             if r == self.rank:
-                self.first_row = len(self.unique_ids)
+                self.first_row = len(unique_ids)
             for uids, metas, inv in rbook:
                 self.metadata.extend(metas)
-                self.unique_ids.extend(uids)
+                unique_ids.extend(uids)
                 for key, value in inv.items():
                     self.inverted_index[key].update(value)
-        self.inverse_id_map = {uid: i for i, uid in enumerate(self.unique_ids)}
-        self.embedding_size = next((d for _, d in everyone if d), None)  # ranks without rows still need the dimension
-        del everyone, book
+        self.embedding_size = next((d for d in dims if d), None)  # ranks without rows still need the dimension
+        del per_rank, book
 
-        # the reference's filter engine, bound to this object's bookkeeping
+        # the single-GPU classes' filter engine (value index, symbolic selections), bound to this object's bookkeeping
         class _Filters(FilterAndRerankMixin):
             pass
         self._filters = _Filters()
+        self._filters._ids = _IdIndex(unique_ids)
         self._filters.inverted_index = self.inverted_index
-        self._filters.inverse_id_map = self.inverse_id_map
         self._filters.metadata = self.metadata
         self._filters.hash_vectorizer = None
+        self.unique_ids = self._filters._ids.uids
 
         self.index = None
         if self.embedding_size is not None:
@@ -351,9 +361,53 @@ class DistributedShardedVectorDatabase:
         self._local_search = local_search
         self._merge = merge
         self._searchers = {}
+        self._always = bool(exchange_always)
+        self._local_sets = {}   # filter expression -> (global hit count, this rank's rows: None = all / a resident row set)
+        self.rowsets_built = 0
+        # pinned staging: the query goes up and the k results come down without a pageable bounce
+        self._q_pin = self._q_dev = None
+        if self.device.type == "cuda" and self.embedding_size is not None:
+            self._q_pin = torch.empty((1, self.embedding_size), dtype=torch.float32).pin_memory()
+            self._q_dev = torch.empty((1, self.embedding_size), dtype=torch.float32, device=self.device)
+        self._out_pin = {}
         # ONE exchange route for the whole database (search_k = min(k, hits) changes with every filter: a communicator per
         # distinct k would put ncclCommInitRank on the query path and never free it)
-        self._collective = Collective(self.rank, self.world, self.device, group=group)
+        self._collective = Collective(self.rank, self.world, self.device, group=group, want=collective, always=self._always)
+
+    @property
+    def inverse_id_map(self):
+        return self._filters._ids.inverse_dict()
+
+    def _exchange_bookkeeping(self, book, dim):
+        """Every rank's per-file (ids, metadata, inverted index), in rank order, WITHOUT one giant object gather: round i
+        gathers the i-th file of every rank (a rank that has run out contributes None), so the transient is `world` shard
+        files' worth of pickles per round.  On an RCCL job the rounds run over a gloo side group (host memory; an
+        `all_gather_object` on RCCL stages every pickle through device tensors padded to the largest)."""
+        if self.world == 1:
+            return [book], [dim]
+        side = self.group
+        try:
+            if self.group is None and dist.get_backend() == "nccl":
+                side = dist.new_group(backend="gloo")
+        except Exception as e:   # no gloo in this build: the job's own group serves, chunked all the same
+            print(f"[mvdb] rank {self.rank}: gloo side group unavailable ({e}); bookkeeping goes over the job's group",
+                  file=sys.stderr, flush=True)
+            side = self.group
+        heads = [None] * self.world
+        dist.all_gather_object(heads, (len(book), dim), group=side)
+        per_rank = [[] for _ in range(self.world)]
+        for i in range(max(h[0] for h in heads)):
+            pieces = [None] * self.world
+            dist.all_gather_object(pieces, book[i] if i < len(book) else None, group=side)
+            for r, piece in enumerate(pieces):
+                if piece is not None:
+                    per_rank[r].append(piece)
+        if side is not self.group and side is not None:
+            try:
+                dist.destroy_process_group(side)
+            except Exception:
+                pass
+        return per_rank, [h[1] for h in heads]
 
     def autocut_scores(self, score_list):
         return self._filters.autocut_scores(score_list)
@@ -365,7 +419,7 @@ class DistributedShardedVectorDatabase:
                 self._searchers.clear()
             s = ShardedSearcher(self.index, k, rank=self.rank, world=self.world, label_offset=self.first_row,
                                 device=self.device, group=self.group, local_search=self._local_search,
-                                merge=self._merge, collective=self._collective)
+                                merge=self._merge, collective=self._collective, exchange_always=self._always)
             self._searchers[k] = s
         return s
 
@@ -374,7 +428,48 @@ class DistributedShardedVectorDatabase:
         for s in self._searchers.values():
             s.close()
         self._searchers = {}
+        self._local_sets = {}
         self._collective.close()
+
+    def _local_rows_of(self, metadata_filter, exclude_filter, or_filters):
+        """(global number of rows the filter selects, this rank's share of them) — the share is None (every local row) or
+        a row set resident on this rank's device; evaluated and uploaded ONCE per filter expression (the database is
+        read-only in this mode, so the entry never goes stale)."""
+        try:
+            key = repr((metadata_filter, exclude_filter, or_filters))
+        except Exception:
+            key = None
+        hit = self._local_sets.get(key) if key is not None else None
+        if hit is not None:
+            return hit
+        chosen = self._filters._get_filtered_indices(metadata_filter, exclude_filter, or_filters)
+        rows = None
+        if len(chosen) and not chosen.everything:
+            mine = chosen.local(self.first_row, self.first_row + self.local_rows)
+            if not mine.everything:   # (an exclusion may leave this rank's rows whole)
+                rows = (self.index.rowset(mine.gone, excluded=True) if mine.gone is not None
+                        else self.index.rowset(mine.rows))
+                self.rowsets_built += 1
+        entry = (len(chosen), rows)
+        if key is not None:
+            if len(self._local_sets) >= 16:
+                self._local_sets.clear()
+            self._local_sets[key] = entry
+        return entry
+
+    def _host_results(self, Dg, Ig):
+        """The k merged results of one query on the host: pinned buffers + one stream wait on a GPU."""
+        if self.device.type != "cuda":
+            return Dg.numpy()[0], Ig.numpy()[0]
+        k = Dg.shape[1]
+        pin = self._out_pin.get(k)
+        if pin is None:
+            pin = self._out_pin[k] = (torch.empty((1, k), dtype=torch.float32).pin_memory(),
+                                      torch.empty((1, k), dtype=torch.int64).pin_memory())
+        pin[0].copy_(Dg, non_blocking=True)
+        pin[1].copy_(Ig, non_blocking=True)
+        torch.cuda.current_stream(self.device).synchronize()
+        return pin[0].numpy()[0].copy(), pin[1].numpy()[0].copy()
 
     def find_most_similar(self, embedding, metadata_filter=None, exclude_filter=None, or_filters=None, k=5,
                           autocut=False):
@@ -383,26 +478,23 @@ class DistributedShardedVectorDatabase:
         if n_total == 0 or self.index is None:
             return [], [], []
         q = np.array([np.array(embedding, dtype=np.float32)])  # query prep of sharded_vector_database.py:602-604
-        filtered = self._filters._get_filtered_indices(metadata_filter, exclude_filter, or_filters)
-        if not filtered:
+        if metadata_filter or exclude_filter or or_filters:
+            hits, rows = self._local_rows_of(metadata_filter, exclude_filter, or_filters)
+        else:
+            hits, rows = n_total, None
+        if not hits:
             return [], [], []
-        search_k = min(k, len(filtered))
+        search_k = min(k, hits)
         if self.world * search_k > 16384:
             raise NotImplementedError("DistributedShardedVectorDatabase merges at most 16384 / world results per query")
-        q_dev = torch.from_numpy(q).to(self.device)
-        rows = None
-        if len(filtered) != n_total:
-            # the filtered rows this rank owns, as LOCAL row numbers, ascending (ties -> lower global row)
-            lo, hi = self.first_row, self.first_row + self.local_rows
-            removed = getattr(filtered, "removed", None)
-            if removed is not None:  # _AllRowsExcept (an exclude-filter over everything): this rank's rows but the excluded
-                gone = np.array(sorted(r - lo for r in removed if lo <= r < hi), dtype=np.int64)
-                mine = np.setdiff1d(np.arange(self.local_rows, dtype=np.int64), gone, assume_unique=True)
-            else:
-                mine = np.array(sorted(r for r in filtered if lo <= r < hi), dtype=np.int64) - lo
-            rows = torch.from_numpy(mine).to(self.device)
+        if self._q_pin is not None:
+            self._q_pin.copy_(torch.from_numpy(q))
+            self._q_dev.copy_(self._q_pin, non_blocking=True)
+            q_dev = self._q_dev
+        else:
+            q_dev = torch.from_numpy(q).to(self.device)
         Dg, Ig = self._searcher(search_k).search_device(q_dev, rows=rows, normalize_q=True)
-        Dg, Ig = Dg.cpu().numpy()[0], Ig.cpu().numpy()[0]
+        Dg, Ig = self._host_results(Dg, Ig)
         found = [(self.unique_ids[i], d, self.metadata[i]) for i, d in zip(Ig, Dg) if i >= 0]
         ids, distances, metadatas = zip(*found) if found else ([], [], [])
         if autocut and len(distances) > 1:

@@ -8,6 +8,13 @@ HBM through libmvdb.so.  Spreading the rows over several GPUs (one process per G
 all-gather of per-shard top-k) is ``minivectordb_amd.distributed.ShardedSearcher``; shard files map
 to ranks whole (``shard_files_for_rank``).
 
+Host bookkeeping is this package's own (``_dbcore``): ids live in an ``_IdIndex`` (stable handles, no renumbering loop),
+a delete touches the doomed rows' own metadata keys only, equality filters read an incrementally maintained value index,
+and the first shard with room is found from a cursor instead of a scan over every shard per stored row.  What the
+reference rebuilds over ALL rows on every delete — ``metadata``, ``unique_ids``, ``inverse_id_map`` and a walk over every
+inverted-index key per deleted id (sharded_vector_database.py:225-241) — is not rebuilt; the shard FILE a delete touches
+is still rewritten whole, as there (:180-204): the files are the persistence contract.
+
 Deliberate fix: ``get_vector`` indexes the shard's array with the row's
 position INSIDE that shard; the reference uses the global row number (:91-96), which is only right
 for shard 0.
@@ -19,14 +26,22 @@ from collections import defaultdict
 
 import numpy as np
 
-from ._dbcore import FilterAndRerankMixin, _RowStore
+from ._dbcore import FilterAndRerankMixin, _IdIndex, _RowStore
+
+
+def _shard_number(file_name):
+    return int(os.path.basename(file_name).split('_')[1].split('.')[0])
+
+
+def _shard_file_names(storage_dir):
+    """``shard_<i>.pkl`` files of a directory in shard order (the reference's stacking order, :41-42)."""
+    return sorted((f for f in os.listdir(storage_dir) if f.endswith('.pkl')), key=_shard_number)
 
 
 def shard_files_for_rank(storage_dir, rank, world):
     """Whole shard files owned by `rank` when a stored database is spread over `world` GPUs:
     contiguous runs of shard ids, so global row order == reference stacking order."""
-    files = [f for f in os.listdir(storage_dir) if f.endswith('.pkl')]
-    files.sort(key=lambda x: int(x.split('_')[1].split('.')[0]))
+    files = _shard_file_names(storage_dir)
     base, rem = divmod(len(files), world)
     start = rank * base + min(rank, rem)
     return files[start:start + base + (1 if rank < rem else 0)]
@@ -40,17 +55,19 @@ class ShardedVectorDatabase(FilterAndRerankMixin):
         self.shard_size = shard_size
         self._mat = None
         self.metadata = []
-        self.unique_ids = []
-        self.inverse_id_map = {}
+        self._ids = _IdIndex()
         self.inverted_index = defaultdict(set)
         self.index = None
         self._embeddings_changed = False
         self._device = device
         self.lock = threading.Lock()
-        self.box_item_map = {}
-        self.inverse_box_item_map = {}
+        self.box_item_map = {}          # shard id -> ids stored in that file, file order
+        self.inverse_box_item_map = {}  # id -> shard id
+        self._shard_order = []          # shard ids in box_item_map (= first-fit) order
+        self._first_open = 0            # shards before this position in _shard_order are full
         self._load_database()
 
+    # ---- what the reference exposes as plain attributes ----------------------------------------------------
     @property
     def embeddings(self):
         return None if self._mat is None else self._mat.materialize(self.index)
@@ -62,11 +79,20 @@ class ShardedVectorDatabase(FilterAndRerankMixin):
             self.index.reset()
         self._embeddings_changed = True
 
+    @property
+    def unique_ids(self):
+        """Stacked row -> id (the list itself: row order, kept by the id index)."""
+        return self._ids.uids
+
+    @property
+    def inverse_id_map(self):
+        """id -> stacked row as a plain dict in row order (brought up to date on demand after a delete)."""
+        return self._ids.inverse_dict()
+
     def _convert_from_non_sharded_db(self, non_sharded_db_object):
-        embeddings = non_sharded_db_object.embeddings
-        metadata = non_sharded_db_object.metadata
-        unique_ids = [non_sharded_db_object.id_map[i] for i in range(len(embeddings))]
-        self.store_embeddings_batch(unique_ids, embeddings, metadata)
+        rows = non_sharded_db_object.embeddings
+        ids_by_row = non_sharded_db_object.id_map
+        self.store_embeddings_batch([ids_by_row[r] for r in range(len(rows))], rows, non_sharded_db_object.metadata)
         del non_sharded_db_object
 
     def _convert_ndarray_float32(self, ndarray):
@@ -96,91 +122,92 @@ class ShardedVectorDatabase(FilterAndRerankMixin):
             pickle.dump(out, f)
 
     def _load_database(self):
-        if not os.path.exists(self.storage_dir):
-            os.makedirs(self.storage_dir)
-
-        shard_files = [f for f in os.listdir(self.storage_dir) if f.endswith('.pkl')]
-        shard_files.sort(key=lambda x: int(x.split('_')[1].split('.')[0]))
-
+        """Stack every shard file in shard order (sharded_vector_database.py:37-71): ONE concatenation of the pieces
+        (the reference re-stacks the growing matrix per shard), ids and metadata appended per file, the inverted index
+        merged, the file -> ids maps filled."""
+        os.makedirs(self.storage_dir, exist_ok=True)
         self.inverted_index = defaultdict(set)
-        pieces = []
-        for shard_file in shard_files:
+        pieces, ids = [], []
+        for name in _shard_file_names(self.storage_dir):
             with self.lock:
-                with open(os.path.join(self.storage_dir, shard_file), 'rb') as f:
-                    data = pickle.load(f)
-                pieces.append(np.asarray(data['embeddings'], dtype=np.float32))
-                self.metadata.extend(data['metadata'])
-                self.unique_ids.extend(data['unique_ids'])
-                for key, value in data['inverted_index'].items():
-                    self.inverted_index[key].update(value)
-                self._update_box_item_map(data['unique_ids'], shard_file)
+                with open(os.path.join(self.storage_dir, name), 'rb') as f:
+                    shard = pickle.load(f)
+            pieces.append(np.asarray(shard['embeddings'], dtype=np.float32))
+            self.metadata.extend(shard['metadata'])
+            ids.extend(shard['unique_ids'])
+            for key, holders in shard['inverted_index'].items():
+                self.inverted_index[key].update(holders)
+            self._update_box_item_map(shard['unique_ids'], name)
+        self._ids = _IdIndex(ids)
+        self._first_open = 0
         if pieces:
-            # one concatenation instead of the reference's vstack per shard (O(shards^2) copying)
             self._mat = _RowStore.adopt(np.concatenate(pieces, axis=0))
-
-        self.inverse_id_map = {uid: i for i, uid in enumerate(self.unique_ids)}
-
         if self._mat is not None and self._mat.n > 0:
             self.embedding_size = self._mat.d
             with self.lock:
                 self._build_index()
 
     def _update_box_item_map(self, unique_ids, shard_file):
-        shard_id = int(os.path.basename(shard_file).split('_')[1].split('.')[0])
+        shard_id = _shard_number(shard_file)
+        if shard_id not in self.box_item_map:
+            self._shard_order.append(shard_id)
         self.box_item_map[shard_id] = unique_ids
-        for uid in unique_ids:
-            self.inverse_box_item_map[uid] = shard_id
+        self.inverse_box_item_map.update(dict.fromkeys(unique_ids, shard_id))
 
     def get_vector(self, unique_id):
         with self.lock:
-            if unique_id not in self.inverse_id_map:
+            if unique_id not in self._ids:
                 raise ValueError("Unique ID does not exist.")
-            shard_id = self.inverse_box_item_map[unique_id]
-            with open(self._shard_path(shard_id), 'rb') as f:
-                data = pickle.load(f)
-            return data['embeddings'][data['unique_ids'].index(unique_id)]
+            shard = self._read_shard(self.inverse_box_item_map[unique_id])
+            return shard['embeddings'][shard['unique_ids'].index(unique_id)]
 
     def _get_available_shard_id(self):
-        for shard_id, items in self.box_item_map.items():
-            if len(items) < self.shard_size:
-                return shard_id
-        return len(self.box_item_map)
+        """First shard, in the order the shards entered `box_item_map`, that holds fewer than `shard_size` ids; when all
+        are full, the NUMBER of shards (the reference's rule, sharded_vector_database.py:98-102, which it evaluates by
+        scanning every shard for every stored row).  Shards only fill up between deletes, so a cursor over the order
+        does: everything before it is full."""
+        order, at = self._shard_order, self._first_open
+        while at < len(order) and len(self.box_item_map[order[at]]) >= self.shard_size:
+            at += 1
+        self._first_open = at
+        return order[at] if at < len(order) else len(self.box_item_map)
 
     # ---- ingest (sharded_vector_database.py:104-132, :243-287) -----------------------------------------
     def _assign_to_shards(self, unique_ids, vectors, metadata_dicts):
-        """First non-full shard (dict order) per row, then ONE rewrite per touched shard file
-        (sharded_vector_database.py:98-102, :276-287)."""
-        groups = defaultdict(list)
+        """One shard per row by first fit, then ONE rewrite per touched shard file (:276-287)."""
+        placed = defaultdict(lambda: ([], [], []))
         for uid, vec, meta in zip(unique_ids, vectors, metadata_dicts):
             shard_id = self._get_available_shard_id()
-            groups[shard_id].append((uid, vec, meta))
-            self.box_item_map.setdefault(shard_id, []).append(uid)
+            if shard_id not in self.box_item_map:
+                self.box_item_map[shard_id] = []
+                self._shard_order.append(shard_id)
+            self.box_item_map[shard_id].append(uid)
             self.inverse_box_item_map[uid] = shard_id
-        for shard_id, items in groups.items():
-            uids, vecs, metas = zip(*items)
-            self._persist_to_shard_multiple(shard_id, list(uids), list(vecs), list(metas))
+            for column, item in zip(placed[shard_id], (uid, vec, meta)):
+                column.append(item)
+        for shard_id, (uids, vecs, metas) in placed.items():
+            self._persist_to_shard_multiple(shard_id, uids, vecs, metas)
 
     def store_embedding(self, unique_id, embedding, metadata_dict={}):
         with self.lock:
-            if unique_id in self.inverse_id_map:
+            if unique_id in self._ids:
                 raise ValueError("Unique ID already exists.")
             vector = self._convert_ndarray_float32(embedding)
             self._admit([unique_id], [vector], [metadata_dict])
-            self.unique_ids.append(unique_id)
             self._assign_to_shards([unique_id], [vector], [metadata_dict])
 
     def _persist_to_shard(self, shard_id, unique_id, embedding, metadata_dict):
         self._persist_to_shard_multiple(shard_id, [unique_id], [embedding], [metadata_dict])
 
     def _persist_to_shard_multiple(self, shard_id, unique_ids, embeddings, metadata_dicts):
-        data = self._read_shard(shard_id)
-        data['embeddings'] = np.vstack([data['embeddings']] + [np.atleast_2d(e) for e in embeddings])
-        data['metadata'].extend(metadata_dicts)
-        data['unique_ids'].extend(unique_ids)
-        for metadata_dict, unique_id in zip(metadata_dicts, unique_ids):
-            for key in metadata_dict:
-                data['inverted_index'][key].add(unique_id)
-        self._write_shard(shard_id, data)
+        shard = self._read_shard(shard_id)
+        shard['embeddings'] = np.vstack([shard['embeddings']] + [np.atleast_2d(e) for e in embeddings])
+        shard['metadata'].extend(metadata_dicts)
+        shard['unique_ids'].extend(unique_ids)
+        for uid, meta in zip(unique_ids, metadata_dicts):
+            for key in meta:
+                shard['inverted_index'][key].add(uid)
+        self._write_shard(shard_id, shard)
 
     def store_embeddings_batch(self, unique_ids: list, embeddings, metadata_dicts=[]):
         with self.lock:
@@ -188,37 +215,37 @@ class ShardedVectorDatabase(FilterAndRerankMixin):
                 raise ValueError("Number of unique IDs must match number of embeddings.")
             vectors = self._convert_ndarray_float32_batch(embeddings)
             for uid in unique_ids:
-                if uid in self.inverse_id_map:
+                if uid in self._ids:
                     raise ValueError(f"Unique ID {uid} already exists.")
             missing = len(unique_ids) - len(metadata_dicts)
             if missing > 0:  # pads the CALLER's list in place, like the reference (:260-261)
                 metadata_dicts.extend({} for _ in range(missing))
             self._admit(unique_ids, vectors, metadata_dicts)
-            self.unique_ids.extend(unique_ids)
             self._assign_to_shards(unique_ids, vectors, metadata_dicts)
 
     # ---- delete (sharded_vector_database.py:180-241) ------------------------------------------------------
     def _remove_embeddings_from_shard(self, shard_id, unique_ids):
+        """Rewrite one shard file without the given ids.  The shard's inverted index loses each id under the keys of that
+        id's OWN metadata (the reference tests every key of the shard per id, :195-200)."""
         with open(self._shard_path(shard_id), 'rb') as f:
-            data = pickle.load(f)
-
+            shard = pickle.load(f)
         doomed = set(unique_ids)
-        keep = [i for i, uid in enumerate(data['unique_ids']) if uid not in doomed]
-        data['embeddings'] = data['embeddings'][keep]
-        data['metadata'] = [data['metadata'][i] for i in keep]
-        data['unique_ids'] = [data['unique_ids'][i] for i in keep]
-
-        for uid in doomed:
-            for key, ids in list(data['inverted_index'].items()):
-                if uid in ids:
-                    ids.discard(uid)
-                    if not ids:
-                        del data['inverted_index'][key]
-
+        stays = np.fromiter((uid not in doomed for uid in shard['unique_ids']), dtype=bool, count=len(shard['unique_ids']))
+        for uid, meta, stay in zip(shard['unique_ids'], shard['metadata'], stays):
+            if stay:
+                continue
+            for key in meta:
+                holders = shard['inverted_index'].get(key)
+                if holders is not None:
+                    holders.discard(uid)
+                    if not holders:
+                        del shard['inverted_index'][key]
+        shard['embeddings'] = shard['embeddings'][stays]
+        shard['metadata'] = [m for m, stay in zip(shard['metadata'], stays) if stay]
+        shard['unique_ids'] = [u for u, stay in zip(shard['unique_ids'], stays) if stay]
         with open(self._shard_path(shard_id), 'wb') as f:
-            pickle.dump(data, f)
-
-        self.box_item_map[shard_id] = data['unique_ids']
+            pickle.dump(shard, f)
+        self.box_item_map[shard_id] = shard['unique_ids']
         for uid in doomed:
             del self.inverse_box_item_map[uid]
 
@@ -226,44 +253,26 @@ class ShardedVectorDatabase(FilterAndRerankMixin):
         with self.lock:
             if not isinstance(unique_ids, list):
                 unique_ids = [unique_ids]
-
             if not unique_ids:
                 raise ValueError("No unique IDs provided.")
-
-            if not all(uid in self.inverse_id_map for uid in unique_ids):
+            if any(uid not in self._ids for uid in unique_ids):
                 raise ValueError("One or more unique IDs do not exist.")
-
             unique_ids = [uid for uid in unique_ids if uid is not None]
 
-            shard_groups = defaultdict(list)
-            for unique_id in unique_ids:
-                shard_groups[self.inverse_box_item_map[unique_id]].append(unique_id)
-            for shard_id, shard_unique_ids in shard_groups.items():
-                self._remove_embeddings_from_shard(shard_id, shard_unique_ids)
-
-            doomed = set(unique_ids)
-            rows = sorted({self.inverse_id_map[uid] for uid in doomed})
-            self._mat.delete(rows, self.index)
-            keep = [i for i, uid in enumerate(self.unique_ids) if uid not in doomed]
-            self.metadata = [self.metadata[i] for i in keep]
-            self.unique_ids = [self.unique_ids[i] for i in keep]
-
+            by_shard = defaultdict(list)
             for uid in unique_ids:
-                for key, ids in list(self.inverted_index.items()):
-                    ids.discard(uid)
-                    if not ids:
-                        del self.inverted_index[key]
+                by_shard[self.inverse_box_item_map[uid]].append(uid)
+            for shard_id, shard_ids in by_shard.items():
+                self._remove_embeddings_from_shard(shard_id, shard_ids)
+            self._first_open = 0   # room has appeared in shards the cursor had passed
 
-            self.inverse_id_map = {uid: i for i, uid in enumerate(self.unique_ids)}
-            self._invalidate_filter_cache()
-            self._embeddings_changed = True
+            # stacked rows, ids, metadata, inverted index, device matrix: only what belongs to the doomed ids moves
+            self._expel(unique_ids)
 
     # ---- search (sharded_vector_database.py:598-662) --------------------------------------------------------
-    def _subset_order(self, wanted):
-        return np.array(list(wanted), dtype=np.int32)  # the int32 row list the reference feeds np.take (:636)
-
     def find_most_similar(self, embedding, metadata_filter=None, exclude_filter=None, or_filters=None, k=5,
                           autocut=False):
-        hits = [(self.unique_ids[row], score, self.metadata[row])
+        uids = self._ids.uids
+        hits = [(uids[row], score, self.metadata[row])
                 for row, score in self._nearest_rows(embedding, metadata_filter, exclude_filter, or_filters, k)]
         return self._package(hits, autocut)

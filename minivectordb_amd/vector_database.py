@@ -66,13 +66,6 @@ class VectorDatabase(FilterAndRerankMixin):
         """Maps unique id to embedding row number (a dict brought up to date on demand after a delete)."""
         return self._ids.inverse_dict()
 
-    def _note_ids(self, unique_ids, first_row):
-        for uid in unique_ids:
-            self._ids.append(uid)
-
-    def _row_count(self):
-        return len(self._ids)
-
     def _convert_ndarray_float32(self, ndarray):
         return np.array(ndarray, dtype=np.float32)
 
@@ -92,7 +85,8 @@ class VectorDatabase(FilterAndRerankMixin):
                 id_map = data['id_map']
                 self._ids = _IdIndex(id_map[i] for i in range(len(id_map)))
                 self.inverted_index = data.get('inverted_index', defaultdict(set))
-                self._invalidate_filter_cache()
+                self.__dict__.pop("_values", None)
+                self._note_write()
                 if self.embedding_size is not None:
                     self._build_index()
 
@@ -138,19 +132,10 @@ class VectorDatabase(FilterAndRerankMixin):
             raise ValueError("Unique ID does not exist.")
 
         with self.lock:
-            # rows behind the deleted one move up by one — on the device (tail compaction), in the metadata list
-            # and in the id list (C memmoves); the reference rebuilds both of its dicts row by row (:139-152)
-            row_num = self._ids.pop(unique_id)
-            self._mat.delete([row_num], self.index)
-            metadata_to_delete = self.metadata.pop(row_num)
-
-            for key in metadata_to_delete:
-                self.inverted_index[key].discard(unique_id)
-                if not self.inverted_index[key]:
-                    del self.inverted_index[key]
-
-            self._invalidate_filter_cache()
-            self._embeddings_changed = True
+            # rows behind the deleted one move up by one — on the device (tail compaction), in the metadata list and in
+            # the id list (C memmoves); the reference rebuilds both of its dicts row by row (:139-152).  Only the keys
+            # of the deleted row's own metadata are visited in the inverted index (:128-137).
+            self._expel([unique_id])
 
     # ---- search (vector_database.py:466-536) -----------------------------------------------------------------
     def find_most_similar(self, embedding, metadata_filter=None, exclude_filter=None, or_filters=None, k=5,

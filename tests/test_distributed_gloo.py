@@ -157,8 +157,8 @@ def _dist_worker(rank, world, port, path, out_dir):
             if kk:
                 d_, i_ = index.search(q.numpy(), kk, normalize_q=normalize_q)
                 Dl[:, :kk], Il[:, :kk] = d_, np.where(i_ >= 0, i_ + label_offset, -1)
-        elif rows.numel():
-            r = rows.numpy()
+        elif len(rows):
+            r = rows.numpy() if torch.is_tensor(rows) else rows.rows   # a device row list, or the index's resident row set
             kk = min(k, r.size)
             d_, p_ = index.search_subset(q.numpy(), kk, r, normalize_q=normalize_q)
             Dl[:, :kk], Il[:, :kk] = d_, np.where(p_ >= 0, r[np.maximum(p_, 0)] + label_offset, -1)
@@ -187,6 +187,13 @@ def _dist_worker(rank, world, port, path, out_dir):
     for i, kw in enumerate(QUERIES):
         ids, dists, metas = db.find_most_similar(q[i], **kw)
         res.append((list(ids), [float(v) for v in dists], list(metas)))
+    # a repeated filter evaluates nothing and uploads nothing: its local rows are a resident row set of this rank's index
+    built, uploads = db.rowsets_built, [c for c in db.index.calls if c[0] == "rowset"]
+    assert built == len(uploads) >= 3
+    for i, kw in enumerate(QUERIES):
+        again = db.find_most_similar(q[i], **kw)
+        assert list(again[0]) == res[i][0]
+    assert db.rowsets_built == built and [c for c in db.index.calls if c[0] == "rowset"] == uploads
     with open(os.path.join(out_dir, f"res{rank}.pkl"), "wb") as f:
         pickle.dump((res, db.first_row, db.local_rows), f)
     db.close()

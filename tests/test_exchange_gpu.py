@@ -104,3 +104,50 @@ def test_distributed_database_device_path_equals_single_process(native, tmp_path
         assert list(got[0]) == list(want[0]), (kw, got[0][:5], want[0][:5])
         np.testing.assert_allclose(np.array(got[1], dtype=np.float64), np.array(want[1], dtype=np.float64), atol=2e-6)
         assert list(got[2]) == list(want[2])
+
+
+def test_native_rccl_route_through_the_distributed_database(native, tmp_path):
+    """The WHOLE N-GPU exchange path on the one-GPU box: a one-rank RCCL process group, `Collective(want="native")`
+    brought up the way an 8-rank job brings it up (librccl bound by dlopen, agreement all-reduces, unique id through
+    broadcast_object_list, ncclCommInitRank, probe gather), then every `find_most_similar` of
+    DistributedShardedVectorDatabase runs local scan -> ncclAllGather (mvdb_allgather_topk) -> merge kernel
+    (`exchange_always`).  Results must equal the single-process class; a filter's local rows go up once."""
+    import os
+    import torch
+    import torch.distributed as dist
+    from minivectordb_amd import ShardedVectorDatabase
+    from minivectordb_amd.distributed import Collective, DistributedShardedVectorDatabase
+    path = str(tmp_path / "shards")
+    n, d = 2000, 128
+    ref = ShardedVectorDatabase(storage_dir=path, shard_size=256)
+    x = flat.synth(n, d, 77)
+    ref.store_embeddings_batch([f"id{i}" for i in range(n)], list(x),
+                               [{"bucket": i % 7, "price": i, "tag": "even" if i % 2 == 0 else "odd"} for i in range(n)])
+    port = 24000 + os.getpid() % 3000
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        db = DistributedShardedVectorDatabase(path, device=torch.device("cuda", 0), collective="native",
+                                              exchange_always=True)
+        assert db._collective.name == Collective.NATIVE and db._collective.comm is not None
+        queries = [dict(k=5), dict(k=10, metadata_filter={"bucket": 3}), dict(k=10, exclude_filter={"tag": "odd"}),
+                   dict(k=6, or_filters=[{"bucket": 1}, {"bucket": 2}], exclude_filter={"price": 8}),
+                   dict(k=70), dict(k=300, metadata_filter={"tag": "even"}), dict(k=3, metadata_filter={"nokey": 1}),
+                   dict(k=9, metadata_filter={"price": {"$lt": 100}}, autocut=True)]
+        q = flat.synth(len(queries), d, 654)
+        for rounds in range(2):   # the second round is answered from the resident row sets
+            for i, kw in enumerate(queries):
+                got = db.find_most_similar(q[i], **kw)
+                want = ref.find_most_similar(q[i], **kw)
+                assert list(got[0]) == list(want[0]), (kw, got[0][:5], want[0][:5])
+                np.testing.assert_allclose(np.array(got[1], dtype=np.float64), np.array(want[1], dtype=np.float64),
+                                           atol=2e-6)
+                assert list(got[2]) == list(want[2])
+            if rounds == 0:
+                built = db.rowsets_built
+                assert built >= 5
+        assert db.rowsets_built == built
+        assert db._searcher(5).collective.startswith("ncclAllGather")
+        db.close()
+    finally:
+        dist.destroy_process_group()

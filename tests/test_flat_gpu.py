@@ -510,11 +510,13 @@ def test_large_batch_gemm_scan_matches_oracle(native, n, d, k, nq):
     idx = native.FlatIndex(d)
     idx.add(x)
     os.environ["MVDB_DISABLE_SPLIT_SCAN"] = "1"  # this test pins the exact-fp32 tiled kernel (the fallback of the split pass)
-    os.environ["MVDB_GEMM_SCAN_MIN_NQ"] = "64"  # the library reads it per call: also cover half-filled query tiles
+    os.environ["MVDB_GEMM_SCAN_MIN_NQ"] = "64"  # also cover half-filled query tiles
+    idx.reload_env()  # the library reads its hooks once per index: at creation, and when asked
     try:
         D, I = idx.search(q, k)
         _check(native, x, q, k, D, I)
         del os.environ["MVDB_GEMM_SCAN_MIN_NQ"]
+        idx.reload_env()
         Dd, Id = idx.search(q, k)  # default chunking (GEMM launches of up to 128 + 32-query passes for the rest)
         assert np.array_equal(Id, I)
         np.testing.assert_allclose(Dd, D, atol=2e-6)
@@ -556,7 +558,7 @@ def test_split_precision_batch_pass_matches_oracle(native, monkeypatch, n, d, k,
     """nq >= 33 (24 here), k <= 12: the bf16 split-precision pass nominates 16 rows per query, exact fp32 re-scores
     decide and certify (scan_split_kernels.hpp).  Results must equal the oracle's and every query's own single-query
     search."""
-    monkeypatch.setenv("MVDB_SPLIT_SCAN_MIN_NQ", "24")  # read per call: also cover sparsely filled query tiles
+    monkeypatch.setenv("MVDB_SPLIT_SCAN_MIN_NQ", "24")  # read when the index is created: also cover sparsely filled query tiles
     x = _corpus(n, d)
     q = _corpus(nq, d, seed=777)
     idx = native.FlatIndex(d)
