@@ -36,6 +36,15 @@ import sys
 import time
 
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (RCCL) — before any HIP init
+os.environ.setdefault("NCCL_DEBUG", "WARN")  # RCCL's own warnings reach the log of a failed multi-GPU bring-up
+
+
+def _rccl_version():
+    try:
+        import torch
+        return ".".join(str(v) for v in torch.cuda.nccl.version())
+    except Exception:  # noqa: BLE001
+        return None
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -52,33 +61,42 @@ def baseline_metric():
         return "queries/sec + p50 latency, brute-force IP kNN, 10M\u00d7512 fp32, k=10"
 
 
-def pmc_traffic(n, d, nq=1, scan_name=None):
+def pmc_traffic(n, d, nq=1, scan_name=None, launched=""):
     """HBM bytes per scan launch from the committed rocprofv3 PMC passes (profiles/*_pmc_summary.json,
     separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same command, FETCH_SIZE doubled per the
     guide's gfx950 correction).  Counters cannot be collected from inside the timed process, so this
-    is the figure of the profiled run of the same workload, or None when no matching profile exists."""
+    is the figure of the profiled run of the same workload — accepted only when the profile's kernel is the very
+    instantiation this run launched (`launched`, from mvdb_prof_symbol: template arguments included); the newest such
+    profile wins and is named, with the commit it was taken at, in `source`.  None when no profile matches."""
     import glob
-    best = None
-    kern = {"ip_scan": "flat_scan_kernel", "ip_scan_mfma": "flat_scan_mfma", "ip_scan_gemm": "flat_scan_gemm",
-            "ip_scan_split": "flat_scan_split_kernel",
-            "ip_scan_split32": "flat_scan_split32",
-            "ip_scan_half": "flat_scan_hq_kernel" if d <= 512 else "flat_scan_half_kernel"}.get(
-                scan_name, "flat_scan_kernel" if nq == 1 else "flat_scan_mfma")
+    squeeze = lambda t: t.replace(" ", "")  # noqa: E731
+    if not launched:
+        return {"bytes": None, "source": "refused: the library did not report the launched kernel"}
+    best, refused = None, None
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")))
     files.sort(key=lambda f: f"nq{nq}_" in os.path.basename(f))  # the pass profiled at this nq wins
+    batch = any(t in launched for t in ("split", "half", "hq"))
     for f in files:
         try:
-            for rec in json.load(open(f)):
-                if kern in rec["kernel"] and rec["launches_fetch_pass"] > 0:
-                    t = rec["hbm_traffic_bytes_per_launch_avg"]
-                    # a corpus pass of the split-precision kernels is up to four main launches (phases): the profile
-                    # holds the average over those launches, like `algorithmic_bytes_per_launch`
-                    for per_pass in ((1, 2, 3, 4) if ("split" in kern or "half" in kern or "hq" in kern) else (1,)):
-                        if abs(t * per_pass / (n * d * 4.0) - 1.0) < 0.25:  # same workload size
-                            best = {"bytes": int(t), "source": os.path.basename(f)}
+            recs = json.load(open(f))
         except Exception:
-            pass
-    return best
+            continue
+        for rec in recs:
+            if not isinstance(rec, dict) or "kernel" not in rec or rec.get("launches_fetch_pass", 0) <= 0:
+                continue
+            if launched.split("<")[0] not in rec["kernel"]:
+                continue
+            t = rec["hbm_traffic_bytes_per_launch_avg"]
+            # a corpus pass of the split-precision kernels is up to four main launches (phases): the profile
+            # holds the average over those launches, like `algorithmic_bytes_per_launch`
+            if not any(abs(t * per_pass / (n * d * 4.0) - 1.0) < 0.25 for per_pass in ((1, 2, 3, 4) if batch else (1,))):
+                continue   # another workload size
+            if squeeze(launched) not in squeeze(rec["kernel"]):
+                refused = f"refused: {os.path.basename(f)} profiled {rec['kernel']}, this run launched {launched}"
+                continue
+            best = {"bytes": int(t), "source": {"file": os.path.basename(f), "kernel": rec["kernel"],
+                                                "git_head": rec.get("git_head")}}
+    return best or {"bytes": None, "source": refused or f"no committed PMC profile of {launched} at this size"}
 
 
 def cpu_baseline(native, idx, d, k, queries_host, full_rows, budget_s=20.0):
@@ -346,12 +364,25 @@ def main():
                                                      torch.cuda.current_stream().cuda_stream))
     torch.cuda.synchronize()
 
-    searcher = ShardedSearcher(idx, k, rank=rank, world=world, rows_per_rank=n, device=dev)
-    if world > 1 and backend == "nccl" and not share_gpu and os.environ.get("MVDB_COLLECTIVE") != "torch":
-        # a scaling run must measure the in-library RCCL route, not a silent fallback to torch's all-gather
-        assert searcher.collective.startswith("ncclAllGather"), (
-            f"rank {rank}: the exchange fell back to {searcher.collective!r}; set MVDB_COLLECTIVE=torch to bench that "
-            "route on purpose")
+    # A scaling run must measure the in-library RCCL route, not a silent fallback to torch's all-gather — and when that
+    # route cannot be brought up the run must say so in ONE parseable line, not die on a traceback.
+    want_native = world > 1 and backend == "nccl" and not share_gpu and os.environ.get("MVDB_COLLECTIVE") != "torch"
+    try:
+        searcher = ShardedSearcher(idx, k, rank=rank, world=world, rows_per_rank=n, device=dev,
+                                   collective="native" if want_native else None)
+        if want_native and not searcher.collective.startswith("ncclAllGather"):
+            raise RuntimeError(f"the exchange fell back to {searcher.collective!r}")
+    except Exception as e:  # noqa: BLE001 - every failure of the bring-up ends the same way
+        print(json.dumps({"error": f"{type(e).__name__}: {e}", "collective": "ncclAllGather (mvdb_allgather_topk, libmvdb.so)",
+                          "rank": rank, "n_gpus": world, "rccl": _rccl_version(),
+                          "hint": "MVDB_COLLECTIVE=torch benches torch.distributed's all-gather instead; "
+                                  "NCCL_DEBUG=INFO shows RCCL's own bring-up log"}), flush=True)
+        if world > 1:
+            try:
+                dist.destroy_process_group()
+            except Exception:  # noqa: BLE001
+                pass
+        raise SystemExit(3)
 
     def barrier():
         if world > 1:
@@ -465,14 +496,17 @@ def main():
                                "launches": launches, "avg_launch_ms": round(avg_ms, 4),
                                "algorithmic_flops_per_launch": flops}
         else:
+            launched = native.prof_symbol(scan_name)
+            traffic = pmc_traffic(n, d, nq, scan_name, launched)
             out["roofline"] = {
                 "bound": "hbm",
                 "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS * world,
                 "unit": "GB/s",
                 "frac": round(achieved / (HBM_PEAK_GBS * world), 4),
-                "traffic": (pmc_traffic(n, d, nq, scan_name) or {}).get("bytes"),
-                "traffic_source": (pmc_traffic(n, d, nq, scan_name) or {}).get("source"),
+                "traffic": traffic["bytes"],
+                "traffic_source": traffic["source"],
+                "launched": launched,
                 "kernel": {"ip_scan": "flat_scan_kernel", "ip_scan_mfma": "flat_scan_mfma2_kernel",
                            "ip_scan_split": "flat_scan_split_kernel",
                            "ip_scan_split32": "flat_scan_split32_kernel",

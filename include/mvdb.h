@@ -246,6 +246,10 @@ int mvdb_synth_fill_device(float* out_dev, int64_t n, int d, uint64_t seed, int6
  * "ip_scan_gemm", "ip_scan_split", "encoder") and returns the number of launches and their summed duration. */
 int mvdb_prof_enable(int on);
 int mvdb_prof_read(const char* name, int64_t* launches, double* total_ms);
+/* The kernel instantiation last launched under label `name` while profiling was on, as rocprofv3 prints it
+ * ("flat_scan_kernel<64, 2, 2, 0, 0, true, 0, false>"; "" if none): bench.py refuses a committed PMC profile whose kernel
+ * differs from what the timed run launched. */
+int mvdb_prof_symbol(const char* name, char* out, int len);
 
 /* Number of chunks (up to 256 queries) of the certified batch passes that held a query which failed certification — those
  * queries, or past MVDB_SPLIT_REQUERY_MAX of them the whole chunks, were re-run on the exact fp32 kernels — since the

@@ -107,6 +107,7 @@ PROTOTYPES = {
     "mvdb_prof_enable": (ctypes.c_int, [ctypes.c_int]),
     "mvdb_prof_read": (ctypes.c_int, [ctypes.c_char_p, ctypes.POINTER(ctypes.c_int64),
                                       ctypes.POINTER(ctypes.c_double)]),
+    "mvdb_prof_symbol": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int]),
     # encoder (encoder.hip)
     "mvdb_encoder_weight_count": (ctypes.c_int, [ctypes.POINTER(EncoderCfg)]),
     "mvdb_encoder_weight_name": (ctypes.c_char_p, [ctypes.POINTER(EncoderCfg), ctypes.c_int]),
@@ -447,6 +448,13 @@ def half_max_queries(d):
 def encoder_gemm_tile_form(tokens, n, compute_units=256):
     """256 / 192: the 256-row tile form of the split-precision GEMM applies to `tokens` packed tokens; 0: it does not."""
     return int(lib().mvdb_encoder_gemm_tile_form(int(tokens), int(n), int(compute_units)))
+
+
+def prof_symbol(name):
+    """Kernel instantiation last launched under profiling label `name` ("" if none)."""
+    buf = ctypes.create_string_buffer(256)
+    check(lib().mvdb_prof_symbol(name.encode(), buf, 256))
+    return buf.value.decode()
 
 
 def prof_read(name):

@@ -53,6 +53,9 @@ bool prof_enabled();
 // returns an opaque slot (or -1 when disabled) after recording the start event on `stream`
 int prof_begin(const char* name, hipStream_t stream);
 void prof_end(int slot, hipStream_t stream);
+// while profiling is on: remember which kernel instantiation a label's launches run (mvdb_prof_symbol; bench.py checks
+// the committed PMC profile against it)
+void prof_symbol(const char* label, const char* fmt, ...);
 
 // Every MVDB_* tuning / A-B hook of the SEARCH path.  The environment is read ONCE per index — at mvdb_index_create, and
 // again only when the caller asks (mvdb_index_reload_env: A/B runs and tests that flip a hook inside one process) — never on

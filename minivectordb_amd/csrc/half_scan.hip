@@ -976,6 +976,8 @@ static int launch_half_inst(const HalfScanArgs& a, int device, hipStream_t strea
     const int64_t ntiles = a.tile1 - a.tile0;
     const int nblocks = (int)std::max<int64_t>(1, std::min<int64_t>(ntiles, (int64_t)device_cus(device)));
     *nblocks_out = nblocks;
+    prof_symbol(SEED ? "ip_scan_half_seed" : "ip_scan_half", "flat_scan_half_kernel<%d, %d, %d, %d, %s>", KQ, SKB, NG, NST,
+                SEED ? "true" : "false");
     int slot = prof_begin(SEED ? "ip_scan_half_seed" : "ip_scan_half", stream);
     hipLaunchKernelGGL(kern, dim3(nblocks), dim3(256), lds, stream, a);
     prof_end(slot, stream);
@@ -1002,6 +1004,7 @@ static int launch_hq_inst(const HalfScanArgs& a, bool pipe, int device, hipStrea
     const int64_t ntiles = a.tile1 - a.tile0;
     const int nblocks = (int)std::max<int64_t>(1, std::min<int64_t>(ntiles, (int64_t)device_cus(device)));
     *nblocks_out = nblocks;
+    prof_symbol("ip_scan_half", "flat_scan_hq_kernel<%d, %s, %d, %d, %s>", KT, PAD ? "true" : "false", G, WV, pipe ? "true" : "false");
     int slot = prof_begin("ip_scan_half", stream);
     hipLaunchKernelGGL(kern, dim3(nblocks), dim3(WV * 64), lds, stream, a);
     prof_end(slot, stream);

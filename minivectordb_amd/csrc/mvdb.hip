@@ -133,6 +133,17 @@ static bool g_prof_on = false;
 static int g_prof_next = 0;
 static std::map<int, ProfPair> g_prof;  // keyed by a ticket that stays valid across mvdb_prof_read
 
+static std::map<std::string, std::string> g_prof_sym;  // label -> the kernel instantiation last launched under it
+void prof_symbol(const char* label, const char* fmt, ...) {
+    if (!g_prof_on) return;
+    char buf[256];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_sym[label] = buf;
+}
 bool prof_enabled() { return g_prof_on; }
 int prof_begin(const char* name, hipStream_t stream) {
     if (!g_prof_on) return -1;
@@ -350,6 +361,8 @@ int launch_scan_kern(const ScanArgs& a, int nq, int device, hipStream_t stream, 
     int nblocks = (int)std::max<int64_t>(1, std::min(want, cap));
     if (nblocks_out) *nblocks_out = nblocks;
     const char* pname = MODE == kModeTopK ? "ip_scan" : "ip_scan_scores";
+    prof_symbol(pname, "flat_scan_kernel<%d, %d, %d, %d, %d, %s, %d, %s>", G, C, U, METRIC, MODE, NT ? "true" : "false", SEL,
+                MASKED ? "true" : "false");
     int slot = prof_begin(pname, stream);
     hipLaunchKernelGGL(kern, dim3(nblocks, nq), dim3(kScanThreads), 0, stream, a);
     prof_end(slot, stream);
@@ -527,6 +540,7 @@ int launch_mfma2_inst(const MfmaScanArgs& a, int device, hipStream_t stream, int
     const int64_t want = (ntiles + kScanWaves - 1) / kScanWaves;
     const int nblocks = (int)std::max<int64_t>(1, std::min<int64_t>(want, (int64_t)device_cus(device) * nb));
     *nblocks_out = nblocks;
+    prof_symbol("ip_scan_mfma", "flat_scan_mfma2_kernel<%d, %d, %d, %d>", KB, NG, SKB, metric == MVDB_METRIC_L2 ? 1 : 0);
     int slot = prof_begin("ip_scan_mfma", stream);
     hipLaunchKernelGGL(kern, dim3(nblocks), dim3(kScanThreads), lds, stream, a);
     prof_end(slot, stream);
@@ -707,6 +721,7 @@ int launch_split32_inst(const Split32Args& b, int device, hipStream_t stream, in
     const int64_t want = (ntiles + kScanWaves - 1) / kScanWaves;
     const int nblocks = (int)std::max<int64_t>(1, std::min<int64_t>(want, (int64_t)device_cus(device) * nb));
     *nblocks_out = nblocks;
+    prof_symbol("ip_scan_split32", "flat_scan_split32_kernel<%d>", KB);
     int slot = prof_begin("ip_scan_split32", stream);
     hipLaunchKernelGGL(kern, dim3(nblocks), dim3(kScanThreads), lds, stream, b);
     prof_end(slot, stream);
@@ -2188,6 +2203,14 @@ int64_t mvdb_split_rerun_count(void) {
 int mvdb_prof_enable(int on) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
     g_prof_on = on != 0;
+    return 0;
+}
+
+int mvdb_prof_symbol(const char* name, char* out, int len) {
+    if (!name || !out || len <= 0) return fail(MVDB_ERR_ARG, "NULL argument");
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    auto it = g_prof_sym.find(name);
+    snprintf(out, (size_t)len, "%s", it == g_prof_sym.end() ? "" : it->second.c_str());
     return 0;
 }
 

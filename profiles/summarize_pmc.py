@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Summarise rocprofv3 output directories into the small files committed under profiles/.
 
-usage: summarize_pmc.py <round-tag> <trace_dir> <fetch_dir> <write_dir>
+usage: summarize_pmc.py <round-tag> <trace_dir> <fetch_dir> <write_dir> [git-head]
+  git-head  : commit the profiled build was made from (bench.py quotes it beside `roofline.traffic`)
   trace_dir : rocprofv3 --kernel-trace --stats --output-format csv
   fetch_dir : rocprofv3 --pmc FETCH_SIZE   (its own pass)
   write_dir : rocprofv3 --pmc WRITE_SIZE   (its own pass)
@@ -35,6 +36,7 @@ def counter_avg(d, name):
 
 def main():
     tag, trace, fetch, write = sys.argv[1:5]
+    git_head = sys.argv[5] if len(sys.argv) > 5 else os.environ.get("MVDB_GIT_HEAD")
     here = os.path.dirname(os.path.abspath(__file__))
     ks = find(trace, "_kernel_stats.csv")
     if ks:
@@ -58,6 +60,7 @@ def main():
             "hbm_traffic_bytes_per_launch_avg": favg * 1024 * 2 + wavg * 1024,
             "trace_calls": int(st.get("Calls", 0) or 0),
             "trace_avg_ns": float(st.get("AverageNs", 0) or 0),
+            "git_head": git_head,
         })
     json.dump(out, open(os.path.join(here, f"{tag}_pmc_summary.json"), "w"), indent=1)
     for o in out:

@@ -857,6 +857,89 @@ def test_batch_search_never_syncs_and_is_capturable(native):
     idx.close()
 
 
+def test_captured_search_survives_a_larger_eager_call_on_its_stream(native):
+    """A captured search names its stream's workspace buffers.  A later, LARGER eager call on the same stream must not free
+    them (it allocates new ones and parks the old): replaying the earlier graph still answers correctly."""
+    import torch
+    n, d, k = 40000, 512, 10
+    x = _corpus(n, d)
+    idx = native.FlatIndex(d)
+    idx.add(x)
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.Stream(dev)
+    q_small = _corpus(8, d, seed=5)
+    q_big = _corpus(700, d, seed=6)
+    qt = torch.from_numpy(q_small).to(dev)
+    D = torch.empty((8, k), dtype=torch.float32, device=dev)
+    I = torch.empty((8, k), dtype=torch.int64, device=dev)
+    with torch.cuda.stream(stream):
+        idx.search_device(qt.data_ptr(), 8, k, D.data_ptr(), I.data_ptr(), stream=stream.cuda_stream)
+        stream.synchronize()
+        D0, I0 = D.cpu().numpy().copy(), I.cpu().numpy().copy()
+        _check(native, x, q_small, k, D0, I0)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=stream, capture_error_mode="thread_local"):
+            idx.search_device(qt.data_ptr(), 8, k, D.data_ptr(), I.data_ptr(), stream=stream.cuda_stream)
+        # far larger shapes on the same stream: every workspace buffer of the 8-query call is outgrown
+        qb = torch.from_numpy(q_big).to(dev)
+        Db = torch.empty((700, 64), dtype=torch.float32, device=dev)
+        Ib = torch.empty((700, 64), dtype=torch.int64, device=dev)
+        idx.search_device(qb.data_ptr(), 700, 64, Db.data_ptr(), Ib.data_ptr(), stream=stream.cuda_stream)
+        idx.search_device(qb.data_ptr(), 300, 200, Db.data_ptr(), Ib.data_ptr(), stream=stream.cuda_stream)  # k > 64: the score matrix
+        stream.synchronize()
+        junk = [torch.full((1 << 22,), 7, dtype=torch.int64, device=dev) for _ in range(8)]   # reuse whatever WAS freed
+        for _ in range(3):
+            D.zero_()
+            I.zero_()
+            g.replay()
+            stream.synchronize()
+            assert np.array_equal(I.cpu().numpy(), I0) and np.array_equal(D.cpu().numpy(), D0)
+        del junk
+    idx.close()
+
+
+def test_add_does_not_synchronise_the_device(native):
+    """Mutators wait for the searches of THEIR index only and work on the index's own stream: with ~0.3 s of unrelated work
+    queued on another stream (an encoder forward in production), a store into an index returns — rows searchable — while
+    that stream is still busy; and a search already enqueued on the index being grown is waited for."""
+    import time
+    import torch
+    dev = torch.device("cuda", 0)
+    d = 256
+    idx = native.FlatIndex(d)
+    x = _corpus(20000, d)
+    idx.add(x[:10000], normalize=True)
+    busy = torch.cuda.Stream(dev)
+    a = torch.randn((8192, 8192), device=dev)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    with torch.cuda.stream(busy):
+        for _ in range(40):
+            a = (a @ a).clamp_(-1, 1)
+    t_enq = time.perf_counter() - t0
+    idx.add(x[10000:], normalize=True)          # grows the matrix (realloc + copy) and normalises on idx->mut
+    D, I = idx.search(x[15000], 3)
+    still_busy = not busy.query()
+    t_add = time.perf_counter() - t0 - t_enq
+    busy.synchronize()
+    t_all = time.perf_counter() - t0
+    assert I[0, 0] == 15000
+    assert still_busy, f"the add waited for an unrelated stream ({t_add * 1e3:.1f} ms of {t_all * 1e3:.1f} ms)"
+    # a search in flight on a caller stream IS waited for: its results are those of the pre-add matrix
+    s = torch.cuda.Stream(dev)
+    qt = torch.from_numpy(_corpus(4, d, seed=3)).to(dev)
+    Dd = torch.empty((4, 5), dtype=torch.float32, device=dev)
+    Id = torch.empty((4, 5), dtype=torch.int64, device=dev)
+    with torch.cuda.stream(s):
+        idx.search_device(qt.data_ptr(), 4, 5, Dd.data_ptr(), Id.data_ptr(), stream=s.cuda_stream)
+    idx.add(qt.cpu().numpy() * 3.0, normalize=True)   # rows 20000..20003 = the queries themselves
+    s.synchronize()
+    assert (Id.cpu().numpy() < 20000).all()
+    D2, I2 = idx.search(qt.cpu().numpy(), 1)
+    assert I2[:, 0].tolist() == [20000, 20001, 20002, 20003]
+    idx.close()
+
+
 # ---- bitmap-selected search and resident row sets (reference: the per-query sub-index, vector_database.py:508-523) --------
 @pytest.mark.parametrize("d,metric", [(512, flat.METRIC_IP), (100, flat.METRIC_IP), (384, flat.METRIC_L2)])
 @pytest.mark.parametrize("frac", [0.01, 0.5, 0.99])
