@@ -78,7 +78,8 @@ struct Knobs {
     bool split_stats = false;        // MVDB_SPLIT_STATS
     bool split_one_phase = false;    // MVDB_SPLIT_ONE_PHASE
     bool disable_mfma_scan = false, disable_l2_mfma = false, disable_gemm_scan = false, disable_split_scan = false,
-         disable_split32 = false, disable_half_scan = false, disable_masked_batch = false;  // MVDB_DISABLE_*
+         disable_split32 = false, disable_half_scan = false, disable_masked_batch = false,
+         disable_l2_cert = false;    // MVDB_DISABLE_* (L2_CERT: L2 batches back on the exact fp32 kernels)
     bool hq_pipe = true;             // MVDB_HQ_PIPE (0: refill and conversion behind the MFMAs)
     bool half_ksplit = false;        // MVDB_HALF_KSPLIT
     bool half_small_stages = false;  // MVDB_HALF_SMALL_STAGES

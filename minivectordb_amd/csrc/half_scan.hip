@@ -845,15 +845,25 @@ __global__ __launch_bounds__(1024) void half_certify_kernel(HalfCertifyArgs a) {
             const hs_f4* xr = reinterpret_cast<const hs_f4*>(a.X + (int64_t)row * a.ld);
             const hs_f4* qr = reinterpret_cast<const hs_f4*>(a.q + (int64_t)qi * a.ld);
             float s = 0.f;
-            for (int c = lane; c < a.d4; c += 64) {
-                const hs_f4 x = xr[c], w = qr[c];
-                s = fmaf(x[0], w[0], s);
-                s = fmaf(x[1], w[1], s);
-                s = fmaf(x[2], w[2], s);
-                s = fmaf(x[3], w[3], s);
+            if (a.l2) {
+                for (int c = lane; c < a.d4; c += 64) {
+                    const hs_f4 t = qr[c] - xr[c];
+                    s = fmaf(t[0], t[0], s);
+                    s = fmaf(t[1], t[1], s);
+                    s = fmaf(t[2], t[2], s);
+                    s = fmaf(t[3], t[3], s);
+                }
+            } else {
+                for (int c = lane; c < a.d4; c += 64) {
+                    const hs_f4 x = xr[c], w = qr[c];
+                    s = fmaf(x[0], w[0], s);
+                    s = fmaf(x[1], w[1], s);
+                    s = fmaf(x[2], w[2], s);
+                    s = fmaf(x[3], w[3], s);
+                }
             }
             for (int off = 32; off; off >>= 1) s += __shfl_xor(s, off);
-            ek = make_key(s, row);
+            ek = make_key(a.l2 ? -s : s, row);   // larger key = better: the smaller distance
         }
         if (lane == 0) exact[i] = ek;
     }
@@ -869,12 +879,12 @@ __global__ __launch_bounds__(1024) void half_certify_kernel(HalfCertifyArgs a) {
 #pragma unroll 8
         for (int j = 0; j < kHalfRescore; ++j) rank += exact[j] > mine;
         if (mine && rank < a.k) {
-            a.D[(int64_t)qi * a.k + rank] = key_score(mine);
+            a.D[(int64_t)qi * a.k + rank] = a.l2 ? -key_score(mine) : key_score(mine);
             a.I[(int64_t)qi * a.k + rank] = a.label_offset + (int64_t)key_row(mine);
         }
         const int valid = __popcll(__ballot(mine != 0ull));
         if (lane >= valid && lane < a.k) {  // fewer rows than k: faiss' missing-result convention
-            a.D[(int64_t)qi * a.k + lane] = -3.402823466e+38f;
+            a.D[(int64_t)qi * a.k + lane] = a.l2 ? 3.402823466e+38f : -3.402823466e+38f;
             a.I[(int64_t)qi * a.k + lane] = -1;
         }
         // certification: needed as soon as any row was left out (u > -inf)
@@ -884,7 +894,7 @@ __global__ __launch_bounds__(1024) void half_certify_kernel(HalfCertifyArgs a) {
             if (holder) {
                 const int hl = __ffsll((long long)holder) - 1;
                 const float t = key_score(exact[hl]);
-                ok = t > u + a.eps * a.qnorm[qi];
+                ok = a.l2 ? l2_certified(-t, u, a.eps * a.qnorm[qi], a.qnorm[qi], a.n2lo) : t > u + a.eps * a.qnorm[qi];
             }
             if (!ok) {
                 atomicAdd(a.uncertified, 1);

@@ -44,6 +44,11 @@ struct HalfCertifyArgs {
     int64_t* I;
     int* uncertified;      // incremented once per query that fails the certificate
     int* failed;           // [nq] set to 1 for a query that fails it
+    int l2 = 0;            // 1: the index' metric is squared L2.  Nomination is STILL by inner product (the keys hold approximate
+                           // q.x); the nominees are re-scored as sum (q - x)^2 in fp32, ordered by smallest distance, and the
+                           // certificate bounds every dropped row's distance from below through |x|^2 >= n2lo:
+                           //   d(y) >= |q|^2 + n2lo - 2 (U + eps |q|)  >  r(k-th)        (topk_device.hpp: l2_certified)
+    float n2lo = 0.f;      // lower bound of |x|^2 over the stored rows (l2 only)
 };
 
 // queries per corpus pass of the widest instantiation for dimension d (0: no kernel for this d)

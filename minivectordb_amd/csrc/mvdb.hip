@@ -62,6 +62,7 @@ Knobs read_knobs() {
     k.disable_split32 = env_int("MVDB_DISABLE_SPLIT32", 0) != 0;
     k.disable_half_scan = env_int("MVDB_DISABLE_HALF_SCAN", 0) != 0;
     k.disable_masked_batch = env_int("MVDB_DISABLE_MASKED_BATCH", 0) != 0;
+    k.disable_l2_cert = env_int("MVDB_DISABLE_L2_CERT", 0) != 0;
     {
         const char* v = getenv("MVDB_HQ_PIPE");
         k.hq_pipe = !(v && *v == '0');
@@ -247,6 +248,7 @@ struct mvdb_index {
     float* X = nullptr;
     int64_t n = 0, cap = 0;
     float row_norm_bound = 0.f;  // upper bound of |row| over the stored rows (INFINITY: unknown, raw adds)
+    float norm2_lo = INFINITY, norm2_hi = 0.f;  // L2 metric only: bounds of |row|^2 over the stored rows (true values inside)
     uint64_t renumbered = 0;     // bumped whenever stored rows change their numbers (remove_rows, reset): resident row sets
                                  // built before are stale
     Knobs kn;                    // the MVDB_* hooks as read at creation (mvdb_index_reload_env re-reads)
@@ -340,7 +342,10 @@ constexpr int kMaxC = 16;  // d <= 4096
 
 template <int G, int C, int U, int METRIC, int MODE, bool NT, int SEL, bool MASKED>
 int launch_scan_kern(const ScanArgs& a, int nq, int device, hipStream_t stream, int* nblocks_out) {
-    auto kern = flat_scan_kernel<G, C, U, METRIC, MODE, NT, SEL, MASKED>;
+    void (*kern)(ScanArgs) = flat_scan_kernel<G, C, U, METRIC, MODE, NT, SEL, MASKED>;
+    if constexpr (METRIC == 1 && MODE == kModeTopK && SEL == 0) {
+        if (a.gate) kern = flat_scan_kernel<G, C, U, METRIC, MODE, NT, SEL, MASKED, true>;  // device-gated exact re-run (L2)
+    }
     const int occ_hw = cached_occupancy((const void*)kern, kScanThreads, 0, 4);  // blocks per CU this instantiation sustains
     int occ;
     {
@@ -691,9 +696,17 @@ constexpr int kHalfMaxK = 32;
 bool half_path_ok(const mvdb_index* idx);
 int mfma_gated_queries(const mvdb_index* idx);
 
+// L2 metric on the certified passes: they nominate by inner product, which ranks like the distance when the stored rows have
+// (nearly) one norm — every row of the drop-in classes is normalised.  The certificate (topk_device.hpp: l2_certified) is
+// exact for ANY spread, but a wide one would make most queries fail it; beyond 2^-10 relative the exact kernels serve.
+bool l2_cert_ok(const mvdb_index* idx) {
+    return idx->metric == MVDB_METRIC_L2 && idx->norm2_hi > 0.f && std::isfinite(idx->norm2_hi) &&
+           idx->norm2_hi - idx->norm2_lo <= idx->norm2_hi * (1.0f / 1024.0f) && !idx->kn.disable_l2_cert;
+}
+
 bool split_path_ok(const mvdb_index* idx, int nq, int k, const int64_t* rows_dev) {
     if (idx->kn.disable_split_scan) return false;
-    if (nq < 2 || rows_dev || idx->metric != MVDB_METRIC_IP) return false;
+    if (nq < 2 || rows_dev || (idx->metric != MVDB_METRIC_IP && !l2_cert_ok(idx))) return false;
     // (k > 16 also needs the gated fp32-MFMA pass for the exact re-runs: the GEMM-tiled scan keeps 16 results per query)
     if (k > kSplitMaxK && !(k <= kHalfMaxK && nq >= idx->kn.split_scan_min_nq && half_path_ok(idx) &&
                             (k <= kGemmScanMaxK || mfma_gated_queries(idx) > 0)))
@@ -858,6 +871,8 @@ int launch_split_scan(const mvdb_index* idx, Workspace* ws, const float* q, int 
     c.I = I;
     c.uncertified = flag;
     c.failed = failed;
+    c.l2 = idx->metric == MVDB_METRIC_L2;
+    c.n2lo = idx->norm2_lo;
     hipLaunchKernelGGL(split_certify_kernel, dim3(nq), dim3(1024), 0, stream, c);
     MVDB_HIP(hipGetLastError());
     if (a.stats) {
@@ -956,6 +971,8 @@ int launch_half_pass(const mvdb_index* idx, Workspace* ws, const float* q, int n
     c.I = I;
     c.uncertified = flag;
     c.failed = failed;
+    c.l2 = idx->metric == MVDB_METRIC_L2;
+    c.n2lo = idx->norm2_lo;
     MVDB_TRY(launch_half_certify(c, nq, stream));
     if (a.stats) {
         unsigned int st[2] = {0, 0};
@@ -1116,7 +1133,36 @@ int search_core(const mvdb_index* idx, Workspace* ws, const float* q_dev, int nq
             const int per_pass = mfma_gated_queries(idx);
             const int KB = idx->d / 16;
             int off = 0;
-            if (per_pass > 0 && !idx->kn.disable_mfma_scan) {
+            if (idx->metric == MVDB_METRIC_L2) {
+                // L2: the exact single-query scan (sum (q - x)^2 directly), 32 compact queries per launch, each query's
+                // blocks enabled on the device
+                const int per = 32;
+                MVDB_TRY(ws->cand.reserve((size_t)per * scan_grid_upper_bound(idx->device) * k));
+                for (; off < R; off += per) {
+                    const int take = std::min(per, R - off);
+                    ScanArgs ga = a;
+                    ga.q = qc + (int64_t)off * idx->ld;
+                    ga.normalize_q = 0;
+                    ga.cand = ws->cand.p;
+                    ga.gate = ws->nfail.p;
+                    ga.gate_lo = off;
+                    int nblocks = 0;
+                    MVDB_TRY(launch_scan(idx->metric, kModeTopK, ga, take, idx->device, s, &nblocks));
+                    MergeArgs mg;
+                    mg.keys = ws->cand.p;
+                    mg.nlists = nblocks;
+                    mg.k = k;
+                    mg.metric = idx->metric;
+                    mg.label_offset = label_offset;
+                    mg.D = Dt + (int64_t)off * k;
+                    mg.I = It + (int64_t)off * k;
+                    mg.gate = ws->nfail.p;
+                    mg.gate_lo = off;
+                    hipLaunchKernelGGL(merge_keys_kernel, dim3(take), dim3(kMergeThreads), 0, s, mg);
+                    MVDB_HIP(hipGetLastError());
+                }
+                off = R;
+            } else if (per_pass > 0 && !idx->kn.disable_mfma_scan) {
                 MVDB_TRY(ws->cand.reserve((size_t)32 * scan_grid_upper_bound(idx->device) * k));
                 // (the GEMM scan keeps k <= 16 and takes no bitmap: those re-runs are all fp32-MFMA passes)
                 const int max_passes = (k > kGemmScanMaxK || mask_dev) ? (R + per_pass - 1) / per_pass : 2;
@@ -1532,6 +1578,8 @@ int mvdb_index_reset(mvdb_index* idx) {
     MVDB_TRY(quiesce(idx));
     idx->n = 0;
     idx->row_norm_bound = 0.f;
+    idx->norm2_lo = INFINITY;
+    idx->norm2_hi = 0.f;
     ++idx->renumbered;
     return 0;
 }
@@ -1567,28 +1615,46 @@ int mvdb_index_reserve(mvdb_index* idx, int64_t n) {
 // Keeps idx->row_norm_bound >= |row| for every stored row: 1 for rows normalised on the device, one
 // extra read of the new rows otherwise (non-finite rows leave the bound non-finite).
 static int note_row_norms(mvdb_index* idx, const float* dst, int64_t n, int normalize) {
-    if (normalize) {
+    const bool l2 = idx->metric == MVDB_METRIC_L2;
+    if (normalize && !l2) {
         // |row| after normalize_rows_kernel: |x| / sqrt(fl(|x|^2)) with an fp32 sum of depth <= 4 * 16 + 6 (d <= 4096),
         // one sqrt, one divide, one multiply: <= 1 + (70 / 2 + 3) * 2^-24 = 1 + 2.3e-6
         idx->row_norm_bound = std::max(idx->row_norm_bound, 1.000004f);
         return 0;
     }
-    if (!idx->normmax) MVDB_HIP(hipMalloc((void**)&idx->normmax, sizeof(unsigned int)));
+    // raw rows — and every row of an L2 index, whose certified batch passes need BOTH ends of the norm range (a zero row
+    // that normalisation left alone has norm 0): one extra read of the new rows
+    if (!idx->normmax) MVDB_HIP(hipMalloc((void**)&idx->normmax, 2 * sizeof(unsigned int)));
     unsigned int* dmax = idx->normmax;
-    unsigned int bits = 0;
-    hipError_t e = hipMemsetAsync(dmax, 0, sizeof(unsigned int), idx->mut);
+    unsigned int bits[2] = {0u, 0x7F800000u};  // max = 0, min = +inf
+    hipError_t e = hipMemcpyAsync(dmax, bits, sizeof(bits), hipMemcpyHostToDevice, idx->mut);
+    if (e == hipSuccess) e = hipStreamSynchronize(idx->mut);  // (bits is a stack buffer)
     if (e == hipSuccess) {
         const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((n + 3) / 4, (int64_t)device_cus(idx->device) * 16));
-        hipLaunchKernelGGL(max_row_norm2_kernel, dim3(grid), dim3(256), 0, idx->mut, dst, n, idx->ld, idx->d4, dmax);
+        if (l2)
+            hipLaunchKernelGGL(row_norm2_range_kernel, dim3(grid), dim3(256), 0, idx->mut, dst, n, idx->ld, idx->d4, dmax);
+        else
+            hipLaunchKernelGGL(max_row_norm2_kernel, dim3(grid), dim3(256), 0, idx->mut, dst, n, idx->ld, idx->d4, dmax);
         e = hipGetLastError();
     }
-    if (e == hipSuccess) e = hipMemcpyAsync(&bits, dmax, sizeof(bits), hipMemcpyDeviceToHost, idx->mut);
+    if (e == hipSuccess) e = hipMemcpyAsync(bits, dmax, sizeof(bits), hipMemcpyDeviceToHost, idx->mut);
     if (e == hipSuccess) e = hipStreamSynchronize(idx->mut);
     MVDB_HIP(e);
-    float n2;
-    memcpy(&n2, &bits, sizeof(n2));
+    float n2, lo2;
+    memcpy(&n2, &bits[0], sizeof(n2));
+    memcpy(&lo2, &bits[1], sizeof(lo2));
     const float bound = std::isfinite(n2) ? std::sqrt(n2) * 1.000001f : INFINITY;
-    idx->row_norm_bound = std::max(idx->row_norm_bound, bound);
+    idx->row_norm_bound = std::max(idx->row_norm_bound, normalize ? std::max(bound, 1.000004f) : bound);
+    if (l2) {
+        // the kernel's fp32 sums carry <= (depth + 1) 2^-24 < 5e-6 relative error: widen to bounds of the TRUE squared norms
+        if (std::isfinite(n2) && std::isfinite(lo2)) {
+            idx->norm2_hi = std::max(idx->norm2_hi, n2 * 1.00001f);
+            idx->norm2_lo = std::min(idx->norm2_lo, lo2 * 0.99999f);
+        } else {
+            idx->norm2_hi = INFINITY;
+            idx->norm2_lo = 0.f;
+        }
+    }
     return 0;
 }
 

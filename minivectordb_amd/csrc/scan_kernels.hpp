@@ -42,6 +42,8 @@ struct ScanArgs {
                           // scored at the full scan's rate, rows whose bit is clear are never offered; labels = row numbers
     uint64_t* cand;       // kModeTopK : [nq, gridDim.x, k] sorted block lists
     float* scores;        // kModeScores: [nq, n]
+    const int* gate = nullptr;  // GATED instantiations only: query blockIdx.y is scanned iff *gate > gate_lo + blockIdx.y
+    int gate_lo = 0;
 };
 
 template <int G>
@@ -61,8 +63,11 @@ __device__ __forceinline__ float group_reduce_add(float v) {
 //          fills every lane the loads are unconditional: no exec-mask branches in the loop.
 // (Explicit register double-buffering of batches was measured and dropped: 3-5 % slower than relying
 //  on the other resident waves, profiles/r01_sweep_scan_variants.txt lineage.)
-template <int G, int C, int U, int METRIC, int MODE, bool NT = true, int SEL = 0, bool MASKED = true>
+// GATED  : the launch is enabled per query ON THE DEVICE (the exact re-run of the L2 queries a certified batch pass could
+//          not certify, mvdb.hip): a separate instantiation — the ungated kernels carry no test.
+template <int G, int C, int U, int METRIC, int MODE, bool NT = true, int SEL = 0, bool MASKED = true, bool GATED = false>
 __global__ __launch_bounds__(kScanThreads) void flat_scan_kernel(ScanArgs a) {
+    if (GATED && *a.gate <= a.gate_lo + (int)blockIdx.y) return;
     constexpr bool SUBSET = SEL == 1;
     constexpr int RPI = kWave / G;  // rows per wave-instruction
     constexpr int RB = RPI * U;     // rows per wave batch

@@ -653,6 +653,11 @@ struct SplitCertifyArgs {
     int64_t* I;
     int* uncertified;      // incremented once per query that fails the test
     int* failed;           // [nq] set to 1 for a query that fails it (the host re-runs exactly those)
+    int l2 = 0;            // 1: the index' metric is squared L2.  Nomination is STILL by inner product (the keys hold approximate
+                           // q.x); the nominees are re-scored as sum (q - x)^2 in fp32, ordered by smallest distance, and the
+                           // certificate bounds every dropped row's distance from below through |x|^2 >= n2lo:
+                           //   d(y) >= |q|^2 + n2lo - 2 (U + eps |q|)  >  r(k-th)        (topk_device.hpp: l2_certified)
+    float n2lo = 0.f;      // lower bound of |x|^2 over the stored rows (l2 only)
 };
 
 __global__ __launch_bounds__(1024) void split_certify_kernel(SplitCertifyArgs a) {
@@ -682,15 +687,25 @@ __global__ __launch_bounds__(1024) void split_certify_kernel(SplitCertifyArgs a)
             const f32x4m* xr = reinterpret_cast<const f32x4m*>(a.X + (int64_t)row * a.ld);
             const f32x4m* qr = reinterpret_cast<const f32x4m*>(a.q + (int64_t)qi * a.ld);
             float s = 0.f;
-            for (int c = lane; c < a.d4; c += 64) {
-                const f32x4m x = xr[c], w = qr[c];
-                s = fmaf(x[0], w[0], s);
-                s = fmaf(x[1], w[1], s);
-                s = fmaf(x[2], w[2], s);
-                s = fmaf(x[3], w[3], s);
+            if (a.l2) {
+                for (int c = lane; c < a.d4; c += 64) {
+                    const f32x4m t = qr[c] - xr[c];
+                    s = fmaf(t[0], t[0], s);
+                    s = fmaf(t[1], t[1], s);
+                    s = fmaf(t[2], t[2], s);
+                    s = fmaf(t[3], t[3], s);
+                }
+            } else {
+                for (int c = lane; c < a.d4; c += 64) {
+                    const f32x4m x = xr[c], w = qr[c];
+                    s = fmaf(x[0], w[0], s);
+                    s = fmaf(x[1], w[1], s);
+                    s = fmaf(x[2], w[2], s);
+                    s = fmaf(x[3], w[3], s);
+                }
             }
             for (int off = 32; off; off >>= 1) s += __shfl_xor(s, off);
-            ek = make_key(s, row);
+            ek = make_key(a.l2 ? -s : s, row);   // larger key = better: the smaller distance
         }
         if (lane == 0) exact[wave] = ek;
     }
@@ -701,12 +716,12 @@ __global__ __launch_bounds__(1024) void split_certify_kernel(SplitCertifyArgs a)
 #pragma unroll
         for (int j = 0; j < kSplitKeep; ++j) rank += exact[j] > mine;
         if (mine && rank < a.k) {
-            a.D[(int64_t)qi * a.k + rank] = key_score(mine);
+            a.D[(int64_t)qi * a.k + rank] = a.l2 ? -key_score(mine) : key_score(mine);
             a.I[(int64_t)qi * a.k + rank] = a.label_offset + (int64_t)key_row(mine);
         }
         const int valid = __popcll(__ballot(mine != 0ull));
         if (lane >= valid && lane < a.k) {  // fewer rows than k: faiss' missing-result convention
-            a.D[(int64_t)qi * a.k + lane] = -3.402823466e+38f;
+            a.D[(int64_t)qi * a.k + lane] = a.l2 ? 3.402823466e+38f : -3.402823466e+38f;
             a.I[(int64_t)qi * a.k + lane] = -1;
         }
         // certification: only needed when rows were left out (all 16 nominee slots taken)
@@ -717,7 +732,8 @@ __global__ __launch_bounds__(1024) void split_certify_kernel(SplitCertifyArgs a)
             if (holder) {
                 const int hl = __ffsll((long long)holder) - 1;
                 const float t = key_score(exact[hl]);
-                ok = t > key_score(last) + a.eps * a.qnorm[qi];
+                ok = a.l2 ? l2_certified(-t, key_score(last), a.eps * a.qnorm[qi], a.qnorm[qi], a.n2lo)
+                          : t > key_score(last) + a.eps * a.qnorm[qi];
             }
             if (!ok) {
                 atomicAdd(a.uncertified, 1);

@@ -77,6 +77,16 @@ struct WaveTopK {
     }
 };
 
+// Certificate of the L2 metric's batch passes, which nominate by INNER PRODUCT (rows of nearly equal norm: the IP ranking is
+// the L2 ranking up to the spread of |x|^2).  u bounds the approximate inner product of every row that was dropped, eps_q =
+// eps |q| its error: such a row's true distance is at least |q|^2 + n2lo - 2 (u + eps_q).  rk is the fp32 re-score
+// sum (q - x)^2 of the k-th result: a sum of non-negative terms, relative error <= (depth + 2) 2^-23 < 2e-5 for d <= 4096.
+// |q| carries <= 4e-6 relative error (fp32 tree sum + sqrt); the last term covers the rounding of this expression itself.
+__device__ __forceinline__ bool l2_certified(float rk, float u, float eps_q, float qn, float n2lo) {
+    const float lower = fmaf(qn * 0.99999f, qn, n2lo) - 2.0f * (u + eps_q);
+    return rk * 1.00002f < lower - 1e-6f * (qn * qn + fabsf(n2lo) + 2.0f * fabsf(u));
+}
+
 // wave-cooperative sorted insert into an LDS list; returns the list's new k-th key
 __device__ __forceinline__ uint64_t lds_list_insert(uint64_t* list, int k, uint64_t key, int lane) {
     const uint64_t cur = lane < k ? list[lane] : 0ull;

@@ -64,6 +64,33 @@ __global__ __launch_bounds__(256) void max_row_norm2_kernel(const float* __restr
     if (lane == 0) atomicMax(out, bad ? 0x7FC00000u : __float_as_uint(best));
 }
 
+// min AND max over rows of |row|^2: out[0] = max (as above), out[1] = min (atomicMin on the bit pattern; the caller sets it
+// to +inf first).  The L2 metric's certified batch passes nominate by inner product and need both ends of the norm range.
+__global__ __launch_bounds__(256) void row_norm2_range_kernel(const float* __restrict__ X, int64_t n, int64_t ld,
+                                                              int d4, unsigned int* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t gw = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    float hi = 0.f, lo = INFINITY;
+    bool bad = false;
+    for (int64_t r = gw; r < n; r += nw) {
+        const float* row = X + r * ld;
+        float nr = 0.f;
+        for (int c = lane; c < d4; c += 64) {
+            const f32x4u v = *reinterpret_cast<const f32x4u*>(row + c * 4);
+            nr += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+        }
+        for (int m = 32; m >= 1; m >>= 1) nr += __shfl_xor(nr, m);
+        bad |= !(nr >= 0.f);  // NaN
+        hi = fmaxf(hi, nr);
+        lo = fminf(lo, nr);
+    }
+    if (lane == 0 && gw < n) {
+        atomicMax(out, bad ? 0x7FC00000u : __float_as_uint(hi));
+        atomicMin(out + 1, bad ? 0u : __float_as_uint(lo));
+    }
+}
+
 // ---- synthetic stream -------------------------------------------------------------------------
 // element(seed, i, j): a counter-based hash of (seed, i*d + j) split into four 16-bit uniforms,
 // summed (Irwin-Hall, bell-shaped, zero mean) and scaled by an exact power of two.  Integer

