@@ -216,13 +216,19 @@ def test_l2_metric_extension(native):
     idx.close()
 
 
-@pytest.mark.parametrize("d,nq,k", [(128, 2, 10), (512, 8, 10), (384, 32, 5), (512, 40, 64), (768, 20, 10), (1024, 5, 3), (100, 4, 7)])
+@pytest.mark.parametrize("d,nq,k", [(128, 2, 10), (512, 8, 10), (384, 32, 5), (512, 40, 64), (768, 20, 10), (1024, 5, 3), (100, 4, 7),
+                                    (512, 24, 10), (512, 64, 10), (512, 128, 10), (512, 256, 10), (384, 200, 12), (256, 100, 32),
+                                    (1024, 70, 10), (640, 130, 16)])   # round 4: the certified passes (14+ queries)
 @pytest.mark.parametrize("normalized", [True, False])
 def test_l2_batches_share_corpus_passes(native, d, nq, k, normalized):
-    """Squared L2 with several queries per call: the staged fp32-MFMA pass computes |q|^2 + |x|^2 - 2 q.x (whole rows go
-    through its LDS ring, so |x|^2 costs no extra read); one query at a time the scan sums (q - x)^2 directly.  Both must
-    agree with the float64 adjudication (the expansion cancels: tolerance scales with the magnitude of the distances), ties
-    (a planted duplicate row) resolve to the lower row, and a query equal to a stored row finds it at distance ~0."""
+    """Squared L2 with several queries per call.  Up to 13 queries (and whenever the stored rows' norms differ by more than
+    2^-10 — `normalized=False` here): the staged fp32-MFMA pass computes |q|^2 + |x|^2 - 2 q.x (whole rows go through its
+    LDS ring, so |x|^2 costs no extra read).  14+ queries over rows of (nearly) one norm: the certified passes of the inner
+    product — bf16-split / fp16 nomination by q.x, the nominees re-scored as sum (q - x)^2, the certificate bounding every
+    dropped row's distance through min |x|^2 (mvdb.hip: l2_cert_ok) — at the inner product's speed.  One query at a time the
+    scan sums (q - x)^2 directly.  All must agree with the float64 adjudication (the expansion cancels: tolerance scales with
+    the magnitude of the distances), ties (a planted duplicate row) resolve to the lower row, and a query equal to a stored
+    row finds it at distance ~0."""
     n = 30_000
     x = flat.synth(n, d, 21)
     if normalized:
@@ -234,7 +240,19 @@ def test_l2_batches_share_corpus_passes(native, d, nq, k, normalized):
     q[0] = x[123]
     idx = native.FlatIndex(d, metric=native.METRIC_L2)
     idx.add(x)
-    D, I = idx.search(q, k)
+    native.prof_enable(True)
+    try:
+        _split_launches(native)  # drain
+        D, I = idx.search(q, k)
+        certified_pass = _split_launches(native) > 0
+    finally:
+        native.prof_enable(False)
+    # the certified passes serve exactly the batches of 14+ queries (k <= 12, or k <= 32 where the fp16 pass has a kernel)
+    # over rows of one norm
+    small = 14 <= nq <= 32 and k <= 12 and d in (64, 128, 256, 384, 512)          # flat_scan_split32_kernel's widths
+    big = nq >= 33 and ((native.half_max_queries(d) > 0 and k <= 32) or (k <= 12 and d % 32 == 0))
+    expect = normalized and (small or big)
+    assert certified_pass == expect, (certified_pass, expect)
     assert I[0, :2].tolist() == [123, 17_000]
     mag = float(max(1.0, np.abs(D).max()))
     assert abs(D[0, 0]) <= 4e-6 * mag
@@ -663,6 +681,52 @@ def test_split_certificate_at_the_margin(native, d, frac, must_rerun):
             ok, msg = flat.adjudicate(x, q[qi], k, D[qi], I[qi], tol=TOL)
             assert ok, msg
         np.testing.assert_allclose(D[qi], t[I[qi]], atol=TOL, rtol=0)
+    idx.close()
+
+
+@pytest.mark.parametrize("nq", [24, 40])
+@pytest.mark.parametrize("frac,must_rerun", [(1 / 48, True), (0.9, False)])
+def test_l2_certificate_at_the_margin(native, nq, frac, must_rerun):
+    """The L2 metric on the certified passes (24 queries: bf16 split, 16 nominees; 40: fp16 nomination, 64 nominees):
+    nomination is by inner product, the certificate bounds a dropped row's DISTANCE through min |x|^2.  30 unit rows graded
+    `frac * eps` apart in cosine (2 frac eps apart in squared distance), stored contiguously: steps of eps / 48 MUST be
+    refused — and come back exact from the device-gated single-query scan —, steps of 0.9 eps must certify.  One stored
+    row is shrunk by 2^-12 so that the norm range measured at add is not degenerate: the certificate then gives up
+    (1 - min |x|^2) / 2 = 2.4e-4 of its margin (a dropped row of that norm would be that much nearer than its inner
+    product says) and must still certify the 0.9-eps case."""
+    n, d, k = 20000, 512, 10
+    eps = native.half_eps(d) if nq >= 33 else native.split_eps(d)
+    spacing = frac * eps
+    rs = np.random.RandomState(int(frac * 1e4) + nq)
+    x = _corpus(n, d)
+    q = _corpus(nq, d, seed=4242)
+    cos = 0.9 - spacing * np.arange(30)
+    for qi, base in ((0, 500), (nq // 2, 9000), (nq - 1, 15000)):
+        rows = _graded_rows(q[qi], cos, rs)
+        x[base:base + 30] = rows[rs.permutation(30)]
+    x[3000] *= np.float32(1.0 - 2.0 ** -12)        # the norm range is measured at add: 2^-11 relative in |x|^2
+    idx = native.FlatIndex(d, metric=native.METRIC_L2)
+    idx.add(x)
+    before = native.split_rerun_count()
+    native.prof_enable(True)
+    try:
+        _split_launches(native)
+        D, I = idx.search(q, k)
+        assert _split_launches(native) > 0, "the certified pass did not run"
+    finally:
+        native.prof_enable(False)
+    reran = native.split_rerun_count() - before
+    assert (reran >= 1) == must_rerun, (reran, eps)
+    x64 = x.astype(np.float64)
+    for qi in range(nq):
+        d2 = ((x64 - q[qi].astype(np.float64)) ** 2).sum(axis=1)
+        want = np.argsort(d2, kind="stable")[:k]
+        if spacing >= 1e-5 or qi not in (0, nq // 2, nq - 1):
+            assert I[qi].tolist() == want.tolist(), (qi, I[qi], want)
+        else:
+            ok, msg = flat.adjudicate(x, q[qi], k, D[qi], I[qi], metric=flat.METRIC_L2, tol=TOL, tie_eps=4e-6)
+            assert ok, msg
+        np.testing.assert_allclose(D[qi], d2[I[qi]], atol=TOL, rtol=0)
     idx.close()
 
 
