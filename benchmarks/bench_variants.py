@@ -121,11 +121,18 @@ def main():
     dt = timeit(lambda: idxl.search(q[0], 10), 20)
     print(json.dumps({"what": "L2 metric full search k=10", "ms": round(dt * 1e3, 3), "GBps": round(n * row_bytes / dt / 1e9, 1)}),
           flush=True)
-    ql = flat.synth(32, d, 77)
+    ql = flat.synth(256, d, 77)
     flat.normalize_l2(ql)
-    out = {"what": "L2 metric, several queries per call (fp32-MFMA pass: |q|^2 + |x|^2 - 2 q.x), k=10"}
-    for nb in (8, 32):
+    out = {"what": "L2 metric, several queries per call, k=10 (up to 13: fp32-MFMA pass, |q|^2 + |x|^2 - 2 q.x; 14+ over rows "
+                   "of one norm: the inner product's certified passes with an L2 re-score and a norm-range certificate)"}
+    for nb in (8, 32, 128, 256):
         out[f"nq{nb}_ms"] = round(timeit(lambda: idxl.search(ql[:nb], 10), 5) * 1e3, 3)
+    idxl.reload_env()
+    os.environ["MVDB_DISABLE_L2_CERT"] = "1"
+    idxl.reload_env()
+    for nb in (32, 128):
+        out[f"nq{nb}_ms_exact_fp32_kernels (MVDB_DISABLE_L2_CERT=1)"] = round(timeit(lambda: idxl.search(ql[:nb], 10), 3) * 1e3, 3)
+    del os.environ["MVDB_DISABLE_L2_CERT"]
     print(json.dumps(out), flush=True)
     idxl.close()
 
