@@ -775,9 +775,12 @@ struct X3NoDma {
 // NP > 0: the wave's NP LDS-DMA instructions of the look-ahead stage are issued BETWEEN the MFMAs of the first k-block,
 // one every (3 TM TN) / NP MFMAs, instead of as a burst behind the barrier: a global_load_lds costs its wave 60 - 180
 // cycles of issue (address path), which is matrix-core time when both waves of a SIMD pay it at the same moment.
+// dma_ks (wave-uniform): the k-block whose MFMAs carry the pieces.  Experiment MVDB_X3_STAGGER: the upper half of a
+// workgroup's waves issues its pieces in k-block 1, the lower half in k-block 0, so that half as many waves queue on the CU's
+// one vector-memory path at a time.
 template <int TM, int TN, int SHAPE = 0, int NP = 0, class Dma = X3NoDma>
 __device__ __forceinline__ void x3_kstep(const unsigned char* sb, const int (&a_off)[2][2], const int (&b_off)[2][2],
-                                         f32x16 (&acc)[TM][TN], Dma dma = Dma()) {
+                                         f32x16 (&acc)[TM][TN], Dma dma = Dma(), int dma_ks = 0) {
     x3_h8 ah[2][TM], al[2][TM], bh[2][TN], bl[2][TN];
     auto read_first = [&](int ks) {  // what the first product (wh . al) needs
 #pragma unroll
@@ -793,7 +796,7 @@ __device__ __forceinline__ void x3_kstep(const unsigned char* sb, const int (&a_
     };
     constexpr int SP = NP > 0 ? (3 * TM * TN / NP > 0 ? 3 * TM * TN / NP : 1) : 1;
     auto after = [&](int ks, int m) {  // m: MFMAs of this k-block issued so far
-        if (NP > 0 && ks == 0 && m % SP == 0 && m / SP - 1 < NP) {
+        if (NP > 0 && ks == dma_ks && m % SP == 0 && m / SP - 1 < NP) {
             __builtin_amdgcn_sched_barrier(0);
             dma(m / SP - 1);
             __builtin_amdgcn_sched_barrier(0);
@@ -938,6 +941,12 @@ __host__ __device__ inline bool x3_big_form(int64_t T, int N, int bn, int cus) {
     return tiles >= cus && (tiles >= 4 * (int64_t)cus || tiles * 100 >= rounds * cus * 85);
 }
 
+#ifdef MVDB_X3_STAGGER
+#define X3_DMA_KS(wave, nwaves) ((wave) >= (nwaves) / 2 ? 1 : 0)
+#else
+#define X3_DMA_KS(wave, nwaves) 0
+#endif
+
 #ifdef MVDB_X3_ABLATE
 // DBG == 5 (ablation build only): the real kernel plus a per-tile timeline — 16 words per tile:
 // [tile id, HW_ID, XCC_ID, t start, t first stage landed, t K loop done, t stores issued, t stores acknowledged,
@@ -1077,7 +1086,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_x3_dma_kernel(const _Float16*
             continue;
         }
         if (SPREAD)
-            x3_kstep<TM, TN, 0, NI>(sb, a_off, b_off, acc, [&](int i) { issue_piece(akt, abuf, i); });
+            x3_kstep<TM, TN, 0, NI>(sb, a_off, b_off, acc, [&](int i) { issue_piece(akt, abuf, i); }, X3_DMA_KS(wave, WAVES));
         else
             x3_kstep_plain<TM, TN>(sb, a_off, b_off, acc);
         st = st == NST - 1 ? 0 : st + 1;
@@ -1210,7 +1219,7 @@ __global__ __launch_bounds__(512) void gemm_x3_big_kernel(const _Float16* __rest
             const int lm = more ? m0 : m1, ln = more ? n0 : n1, lk = more ? kt + 1 : 0;
             auto dma = [&](int i) { issue_piece(lm, ln, lk, st ^ 1, i); };
             if (SPREAD)
-                x3_kstep<TM, TN, DBG == 6 ? 1 : 0, NI>(xsm + st * kStage, a_off, b_off, acc, dma);
+                x3_kstep<TM, TN, DBG == 6 ? 1 : 0, NI>(xsm + st * kStage, a_off, b_off, acc, dma, X3_DMA_KS(wave, WAVES));
             else {
 #pragma unroll
                 for (int i = 0; i < NI; ++i) dma(i);
@@ -1325,12 +1334,12 @@ __device__ __forceinline__ void x3_kstep_hook(const unsigned char* sb, const int
 constexpr int kPipeNano = 8 * 5;  // nano-steps of one wave tile: 8 half sub-tiles x (4 element pairs + 1 exchange-and-store)
 // nano-steps placed behind MFMA slot `slot` of the (NK - 2) x 24 slots that carry them: [first, end)
 __host__ __device__ constexpr int pipe_nano_first(int slot, int slots) { return (int)((long long)slot * kPipeNano / slots); }
-// 16-byte stores issued by the nano-steps of K-step kt (two per exchange-and-store step)
-__host__ __device__ constexpr int pipe_step_stores(int kt, int nk) {
+// 16-byte stores issued by the nano-steps behind MFMA slots [lo, hi) of K-step kt (two per exchange-and-store step)
+__host__ __device__ constexpr int pipe_step_stores(int kt, int nk, int lo = 0, int hi = 24) {
     if (kt < 0 || kt >= nk - 2) return 0;
     const int slots = (nk - 2) * 24;
     int c = 0;
-    for (int n = pipe_nano_first(kt * 24, slots); n < pipe_nano_first((kt + 1) * 24, slots); ++n) c += (n % 5) == 4 ? 2 : 0;
+    for (int n = pipe_nano_first(kt * 24 + lo, slots); n < pipe_nano_first(kt * 24 + hi, slots); ++n) c += (n % 5) == 4 ? 2 : 0;
     return c;
 }
 
@@ -1387,17 +1396,18 @@ __global__ __launch_bounds__(512) void gemm_x3_pipe_kernel(const _Float16* __res
             loff[i] = r * (uint32_t)(K * 4) + (lslot ^ ((i & 1) ? 64u : 0u));
         }
     };
-    auto issue = [&](int m0, int n0, int kt, int stage) {
+    auto issue_piece = [&](int m0, int n0, int kt, int stage, int i) {
         uint64_t pa = reinterpret_cast<uint64_t>(A) + ((uint64_t)m0 * K * 4 + (uint64_t)kt * 128);
         uint64_t pw = reinterpret_cast<uint64_t>(Wp) + ((uint64_t)n0 * K * 4 + (uint64_t)kt * 128);
         asm volatile("" : "+s"(pa), "+s"(pw));
+        const int q = wave * NI + i;
+        const char* base = reinterpret_cast<const char*>(q < NA ? pa : pw);
+        __builtin_amdgcn_global_load_lds((enc_gbl_ptr)(base + loff[i]),
+                                         (enc_lds_ptr)(xsm + stage * kStage + (q < NA ? q * 1024 : kA + (q - NA) * 1024)), 16, 0, 0);
+    };
+    auto issue = [&](int m0, int n0, int kt, int stage) {
 #pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const int q = wave * NI + i;
-            const char* base = reinterpret_cast<const char*>(q < NA ? pa : pw);
-            __builtin_amdgcn_global_load_lds((enc_gbl_ptr)(base + loff[i]),
-                                             (enc_lds_ptr)(xsm + stage * kStage + (q < NA ? q * 1024 : kA + (q - NA) * 1024)), 16, 0, 0);
-        }
+        for (int i = 0; i < NI; ++i) issue_piece(m0, n0, kt, stage, i);
     };
     int a_off[2][2], b_off[2][2];
     const int ga = (fr >> 1) & 7;
@@ -1474,8 +1484,16 @@ __global__ __launch_bounds__(512) void gemm_x3_pipe_kernel(const _Float16* __res
             constexpr bool E = decltype(with_epi)::value;
             x3_static_for<NK>([&](auto KT) {
                 constexpr int kt = decltype(KT)::value;
-                // outstanding at most: the pieces of stage kt + 1 and the stores of the two steps before this one
-                constexpr int allow = NI + (E ? pipe_step_stores(kt - 1, NK) + pipe_step_stores(kt - 2, NK) : 0);
+                // Order of a wave's vector-memory operations in a step: DMA piece i of stage kt + 2 behind MFMA slot i (a
+                // global_load_lds costs its wave 60 - 180 cycles of issue: spread between the MFMAs, not a burst that every
+                // wave pays at the barrier), the stores of a nano-step behind its slot.  Stage kt has landed once at most
+                // these are outstanding: the pieces of stage kt + 1, the stores of step kt - 1, and the stores of step
+                // kt - 2 that were issued behind its last piece.
+#ifdef MVDB_X3_STAGGER
+                constexpr int allow = NI + (E ? pipe_step_stores(kt - 1, NK) + pipe_step_stores(kt - 2, NK, 12 + NI - 1, 24) : 0);  // the stricter half
+#else
+                constexpr int allow = NI + (E ? pipe_step_stores(kt - 1, NK) + pipe_step_stores(kt - 2, NK, NI - 1, 24) : 0);
+#endif
                 static_assert(allow < 64, "vmcnt is a 6-bit count");
                 __builtin_amdgcn_sched_barrier(0);
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"(allow) : "memory");
@@ -1485,11 +1503,21 @@ __global__ __launch_bounds__(512) void gemm_x3_pipe_kernel(const _Float16* __res
                 // tile's last steps); the last tile re-fetches its own first stages into buffers nobody reads
                 constexpr bool more = kt + 2 < NK;
                 if constexpr (kt + 2 == NK) lane_offsets(m1);  // from here on the pieces belong to the next tile
-                issue(more ? m0 : m1, more ? n0 : n1, more ? kt + 2 : kt + 2 - NK, st == 0 ? 2 : st - 1);
-                __builtin_amdgcn_sched_barrier(0);
+                const int abuf = st == 0 ? 2 : st - 1;
                 x3_kstep_hook<TM, TN>(xsm + st * kStage, a_off, b_off, acc, [&](auto M) {
+                    constexpr int m = decltype(M)::value;
+#ifdef MVDB_X3_STAGGER
+                    if constexpr (m < NI) {
+                        if (wave < 4) issue_piece(more ? m0 : m1, more ? n0 : n1, more ? kt + 2 : kt + 2 - NK, abuf, m);
+                    }
+                    if constexpr (m >= 12 && m < 12 + NI) {
+                        if (wave >= 4) issue_piece(more ? m0 : m1, more ? n0 : n1, more ? kt + 2 : kt + 2 - NK, abuf, m - 12);
+                    }
+#else
+                    if constexpr (m < NI) issue_piece(more ? m0 : m1, more ? n0 : n1, more ? kt + 2 : kt + 2 - NK, abuf, m);
+#endif
                     if constexpr (E && kt < NK - 2) {
-                        constexpr int slot = kt * 24 + decltype(M)::value;
+                        constexpr int slot = kt * 24 + m;
                         constexpr int first = pipe_nano_first(slot, SLOTS), end = pipe_nano_first(slot + 1, SLOTS);
                         static_assert(end - first <= 1, "at most one nano-step per MFMA slot");
                         if constexpr (end > first) nano(std::integral_constant<int, first>{});
@@ -1632,7 +1660,7 @@ __global__ __launch_bounds__(WM * 256) void gemm_x3_ln_kernel(const _Float16* __
                 continue;
             }
             if (SPREAD)
-                x3_kstep<TM, TN, 0, NI>(sb, a_off, b_off, acc, [&](int i) { issue_piece(amb, akt, abuf, i); });
+                x3_kstep<TM, TN, 0, NI>(sb, a_off, b_off, acc, [&](int i) { issue_piece(amb, akt, abuf, i); }, X3_DMA_KS(wave, WM * 4));
             else
                 x3_kstep_plain<TM, TN>(sb, a_off, b_off, acc);
             st = st == NST - 1 ? 0 : st + 1;
