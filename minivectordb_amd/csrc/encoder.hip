@@ -28,8 +28,6 @@
 #include <cstdlib>
 #include <map>
 #include <tuple>
-#include <type_traits>
-#include <utility>
 
 #include "common.hpp"
 
@@ -645,7 +643,6 @@ constexpr int HBK = 32;       // k granularity of the split-precision images
 typedef _Float16 x3_h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 x3_h2 __attribute__((ext_vector_type(2)));
 typedef float x3_f2 __attribute__((ext_vector_type(2)));
-typedef float f32x2e __attribute__((ext_vector_type(2)));
 typedef unsigned int x3_u2 __attribute__((ext_vector_type(2)));
 
 // max |in[i]| as the bits of a non-negative float (atomicMax on the integer image is order-preserving)
@@ -775,12 +772,9 @@ struct X3NoDma {
 // NP > 0: the wave's NP LDS-DMA instructions of the look-ahead stage are issued BETWEEN the MFMAs of the first k-block,
 // one every (3 TM TN) / NP MFMAs, instead of as a burst behind the barrier: a global_load_lds costs its wave 60 - 180
 // cycles of issue (address path), which is matrix-core time when both waves of a SIMD pay it at the same moment.
-// dma_ks (wave-uniform): the k-block whose MFMAs carry the pieces.  Experiment MVDB_X3_STAGGER: the upper half of a
-// workgroup's waves issues its pieces in k-block 1, the lower half in k-block 0, so that half as many waves queue on the CU's
-// one vector-memory path at a time.
 template <int TM, int TN, int SHAPE = 0, int NP = 0, class Dma = X3NoDma>
 __device__ __forceinline__ void x3_kstep(const unsigned char* sb, const int (&a_off)[2][2], const int (&b_off)[2][2],
-                                         f32x16 (&acc)[TM][TN], Dma dma = Dma(), int dma_ks = 0) {
+                                         f32x16 (&acc)[TM][TN], Dma dma = Dma()) {
     x3_h8 ah[2][TM], al[2][TM], bh[2][TN], bl[2][TN];
     auto read_first = [&](int ks) {  // what the first product (wh . al) needs
 #pragma unroll
@@ -796,7 +790,7 @@ __device__ __forceinline__ void x3_kstep(const unsigned char* sb, const int (&a_
     };
     constexpr int SP = NP > 0 ? (3 * TM * TN / NP > 0 ? 3 * TM * TN / NP : 1) : 1;
     auto after = [&](int ks, int m) {  // m: MFMAs of this k-block issued so far
-        if (NP > 0 && ks == dma_ks && m % SP == 0 && m / SP - 1 < NP) {
+        if (NP > 0 && ks == 0 && m % SP == 0 && m / SP - 1 < NP) {
             __builtin_amdgcn_sched_barrier(0);
             dma(m / SP - 1);
             __builtin_amdgcn_sched_barrier(0);
@@ -941,12 +935,6 @@ __host__ __device__ inline bool x3_big_form(int64_t T, int N, int bn, int cus) {
     return tiles >= cus && (tiles >= 4 * (int64_t)cus || tiles * 100 >= rounds * cus * 85);
 }
 
-#ifdef MVDB_X3_STAGGER
-#define X3_DMA_KS(wave, nwaves) ((wave) >= (nwaves) / 2 ? 1 : 0)
-#else
-#define X3_DMA_KS(wave, nwaves) 0
-#endif
-
 #ifdef MVDB_X3_ABLATE
 // DBG == 5 (ablation build only): the real kernel plus a per-tile timeline — 16 words per tile:
 // [tile id, HW_ID, XCC_ID, t start, t first stage landed, t K loop done, t stores issued, t stores acknowledged,
@@ -1086,7 +1074,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_x3_dma_kernel(const _Float16*
             continue;
         }
         if (SPREAD)
-            x3_kstep<TM, TN, 0, NI>(sb, a_off, b_off, acc, [&](int i) { issue_piece(akt, abuf, i); }, X3_DMA_KS(wave, WAVES));
+            x3_kstep<TM, TN, 0, NI>(sb, a_off, b_off, acc, [&](int i) { issue_piece(akt, abuf, i); });
         else
             x3_kstep_plain<TM, TN>(sb, a_off, b_off, acc);
         st = st == NST - 1 ? 0 : st + 1;
@@ -1219,7 +1207,7 @@ __global__ __launch_bounds__(512) void gemm_x3_big_kernel(const _Float16* __rest
             const int lm = more ? m0 : m1, ln = more ? n0 : n1, lk = more ? kt + 1 : 0;
             auto dma = [&](int i) { issue_piece(lm, ln, lk, st ^ 1, i); };
             if (SPREAD)
-                x3_kstep<TM, TN, DBG == 6 ? 1 : 0, NI>(xsm + st * kStage, a_off, b_off, acc, dma, X3_DMA_KS(wave, WAVES));
+                x3_kstep<TM, TN, DBG == 6 ? 1 : 0, NI>(xsm + st * kStage, a_off, b_off, acc, dma);
             else {
 #pragma unroll
                 for (int i = 0; i < NI; ++i) dma(i);
@@ -1252,297 +1240,6 @@ __global__ __launch_bounds__(512) void gemm_x3_big_kernel(const _Float16* __rest
         n0 = n1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-}
-
-// =================================================================================================
-// gemm_x3_pipe_kernel (round 4) — the image-writing GEMMs (QKV, FFN1 + GELU) of a LONG batch with the epilogue of tile t
-// executed INSIDE the K loop of tile t + 1.
-// Round 3's ablations (profiles/r03_x3_ablations.txt) put a third of each of these GEMMs into an epilogue during which the
-// matrix cores idle — FFN1 at T = 131072: 525 us = 352 K loop + 182 epilogue, nothing overlapped (one workgroup per CU: the
-// accumulators ARE the registers) — and the epilogue is VALU-issue-bound (GELU + the (hi, lo) split: ~25 instructions per
-// element), i.e. exactly the work the vector pipe could do while the matrix pipe runs.  So:
-//   * tiles of 256 x 128 (eight waves 4 x 2, wave tile 64 x 64: 64 accumulator registers), ONE persistent workgroup per CU;
-//     the finished tile's accumulators are kept (64 more registers) while the next tile accumulates;
-//   * the kept tile's epilogue is cut into NANO-STEPS — bias + GELU + (hi, lo) split of one element pair, or one half
-//     sub-tile's lane exchange + two 16-byte stores — and one nano-step is placed behind every sixth MFMA of the next K loop
-//     (x3_kstep_hook: the K loop is unrolled over its NK steps, so every index is a compile-time constant); 40 nano-steps
-//     over the 24 (NK - 2) MFMA slots of all but the last two K-steps;
-//   * a THREE-stage LDS ring (3 x 48 KiB; the 256 x 256 form has room for two 64-KiB stages): the DMA of K-step s + 2 is
-//     issued at the top of step s, so a stage has two steps to land; the bias lives in LDS behind the ring (the epilogue
-//     must not issue vector loads: a load's wait would drain the ring);
-//   * the counted waits include the epilogue's stores: at the top of step s a wave may have outstanding the 6 DMA pieces of
-//     stage s + 1 plus the stores of steps s - 1 and s - 2 — static counts, zero for the last two steps of a tile, so the
-//     count is the same whether or not the tile before had an epilogue to run (first tile of a workgroup).
-// Cost: (256 + 128) rows of operands per 256 x 128 outputs — 1.5 x the L2 -> LDS bytes of the 256 x 256 form.
-// The last tile of a workgroup runs the same nano-steps back to back after its K loop: every row goes through the same
-// arithmetic wherever it sits.  Epilogues: EPI_BIAS_GELU and EPI_BIAS_QKV (both write (hi | lo) images).
-// =================================================================================================
-// compile-time loop: f(std::integral_constant<int, 0>{}) ... f(std::integral_constant<int, N - 1>{})
-template <int... I, class F>
-__device__ __forceinline__ void x3_static_for_impl(std::integer_sequence<int, I...>, F&& f) {
-    (f(std::integral_constant<int, I>{}), ...);
-}
-template <int N, class F>
-__device__ __forceinline__ void x3_static_for(F&& f) {
-    x3_static_for_impl(std::make_integer_sequence<int, N>{}, f);
-}
-
-template <int TM, int TN, class Hook>
-__device__ __forceinline__ void x3_kstep_hook(const unsigned char* sb, const int (&a_off)[2][2], const int (&b_off)[2][2],
-                                              f32x16 (&acc)[TM][TN], Hook hook) {
-    // x3_kstep's order (fragments of a product group requested while the group before it runs); hook(integral_constant<m>)
-    // runs behind the m-th MFMA of the K-step (0 .. 6 TM TN - 1): every index a compile-time constant
-    x3_h8 ah[2][TM], al[2][TM], bh[2][TN], bl[2][TN];
-    auto read_first = [&](int ks) {
-#pragma unroll
-        for (int j = 0; j < TN; ++j) bh[ks][j] = *reinterpret_cast<const x3_h8*>(sb + b_off[ks][0] + j * 4096);
-#pragma unroll
-        for (int i = 0; i < TM; ++i) al[ks][i] = *reinterpret_cast<const x3_h8*>(sb + a_off[ks][1] + i * 4096);
-    };
-    auto read_rest = [&](int ks) {
-#pragma unroll
-        for (int j = 0; j < TN; ++j) bl[ks][j] = *reinterpret_cast<const x3_h8*>(sb + b_off[ks][1] + j * 4096);
-#pragma unroll
-        for (int i = 0; i < TM; ++i) ah[ks][i] = *reinterpret_cast<const x3_h8*>(sb + a_off[ks][0] + i * 4096);
-    };
-    constexpr int P = TM * TN;
-    read_first(0);
-    read_rest(0);
-    __builtin_amdgcn_sched_barrier(0);
-    x3_static_for<2>([&](auto KS) {
-        constexpr int ks = decltype(KS)::value;
-        x3_static_for<3 * P>([&](auto M) {
-            constexpr int m = decltype(M)::value, prod = m / P, i = (m % P) / TN, j = m % TN;
-            if constexpr (prod == 0) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[ks][j], al[ks][i], acc[i][j], 0, 0, 0);
-            if constexpr (prod == 1) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[ks][j], ah[ks][i], acc[i][j], 0, 0, 0);
-            if constexpr (prod == 2) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[ks][j], ah[ks][i], acc[i][j], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            hook(std::integral_constant<int, ks * 3 * P + m>{});
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (ks == 0 && m == 2 * P - 1) {  // under the leading product of k-block 0 ...
-                read_first(1);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if constexpr (ks == 0 && m == 3 * P - 1) {  // ... and under the first product of k-block 1
-                read_rest(1);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        });
-    });
-}
-
-constexpr int kPipeNano = 8 * 5;  // nano-steps of one wave tile: 8 half sub-tiles x (4 element pairs + 1 exchange-and-store)
-// nano-steps placed behind MFMA slot `slot` of the (NK - 2) x 24 slots that carry them: [first, end)
-__host__ __device__ constexpr int pipe_nano_first(int slot, int slots) { return (int)((long long)slot * kPipeNano / slots); }
-// 16-byte stores issued by the nano-steps behind MFMA slots [lo, hi) of K-step kt (two per exchange-and-store step)
-__host__ __device__ constexpr int pipe_step_stores(int kt, int nk, int lo = 0, int hi = 24) {
-    if (kt < 0 || kt >= nk - 2) return 0;
-    const int slots = (nk - 2) * 24;
-    int c = 0;
-    for (int n = pipe_nano_first(kt * 24 + lo, slots); n < pipe_nano_first(kt * 24 + hi, slots); ++n) c += (n % 5) == 4 ? 2 : 0;
-    return c;
-}
-
-template <int EPI, int NK>
-__global__ __launch_bounds__(512) void gemm_x3_pipe_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ Wp,
-                                                           float inv_wscale, const float* __restrict__ bias,
-                                                           float* __restrict__ C, const int* __restrict__ Tptr, int N,
-                                                           int sel_bn, int sel_cus, int qcols, float qscale) {
-    static_assert(EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_QKV, "image-writing epilogues only");
-    static_assert(NK >= 4, "the nano-steps need NK - 2 K-steps");
-    if (sel_bn != 0 && x3_big_form(*Tptr, N, sel_bn > 0 ? sel_bn : -sel_bn, sel_cus) != (sel_bn > 0)) return;
-    constexpr int BM = 256, BN = 128, WAVES = 8, WM = 4, TM = 2, TN = 2, NST = 3, K = NK * 32;
-    constexpr int kA = BM * 128, kStage = kA + BN * 128;
-    constexpr int NA = BM / 8, NI = (NA + BN / 8) / WAVES;
-    constexpr int SLOTS = (NK - 2) * 24;
-    static_assert((NA + BN / 8) % WAVES == 0, "whole DMA instructions per wave");
-    extern __shared__ __attribute__((aligned(16))) unsigned char xsm[];
-    float* bias_l = reinterpret_cast<float*>(xsm + NST * kStage);  // [N]
-    const int T = *Tptr;
-    const unsigned gx = (unsigned)(N / BN);
-    const unsigned active = gx * (unsigned)((T + BM - 1) / BM), chunk = active >> 3;
-    unsigned v = blockIdx.x;
-    if (v >= active) return;
-    auto tile_of = [&](unsigned vl, int& m0, int& n0) {
-        unsigned lin = vl;
-        if (lin < (chunk << 3)) lin = (lin & 7u) * chunk + (lin >> 3);
-        m0 = (int)(lin / gx) * BM;
-        n0 = (int)(lin % gx) * BN;
-    };
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    const int fr = lane & 31, fh = lane >> 5;
-    for (int c = tid; c < N; c += 512) bias_l[c] = bias[c];
-    // DMA roles: instruction q = wave NI + i of a stage moves 8 rows of A (q < NA) or of W.  Row of a lane = 8 q' + (lane >> 3);
-    // its swizzled slot (lane & 7) ^ ((row >> 1) & 7) = (lane & 7) ^ ((lane >> 4) + 4 (q' & 1)): q' and i have the same parity
-    // (NI and NA are even), so odd pieces use the even pieces' slot ^ 4
-    static_assert(NI % 2 == 0 && NA % 2 == 0, "piece parity");
-    const uint32_t lsub = (uint32_t)(lane >> 3);
-    const uint32_t lslot = (uint32_t)(16 * ((lane & 7) ^ (lane >> 4)));
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the bias loads are the only vector loads this kernel's waits do not count
-    __syncthreads();
-    // Source of piece i = a WAVE-UNIFORM 64-bit base (tile, K-step, A or W: scalar registers, made opaque per use so that
-    // hipcc keeps the scalar-base + 32-bit-lane-offset form of the instruction — given the unrolled K loop it otherwise
-    // materialises one 64-bit vector address per (K-step, piece) and spills them) + the lane's offset inside the tile
-    uint32_t loff[NI];
-    auto lane_offsets = [&](int m0) {  // per tile: rows past the edge are clamped (masked in the epilogue); N % BN == 0
-        const uint32_t rlim = (uint32_t)(T - 1 - m0);
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const int q = wave * NI + i;
-            const uint32_t lrow = (uint32_t)(8 * (q < NA ? q : q - NA)) + lsub;
-            const uint32_t r = q < NA ? (lrow < rlim ? lrow : rlim) : lrow;
-            loff[i] = r * (uint32_t)(K * 4) + (lslot ^ ((i & 1) ? 64u : 0u));
-        }
-    };
-    auto issue_piece = [&](int m0, int n0, int kt, int stage, int i) {
-        uint64_t pa = reinterpret_cast<uint64_t>(A) + ((uint64_t)m0 * K * 4 + (uint64_t)kt * 128);
-        uint64_t pw = reinterpret_cast<uint64_t>(Wp) + ((uint64_t)n0 * K * 4 + (uint64_t)kt * 128);
-        asm volatile("" : "+s"(pa), "+s"(pw));
-        const int q = wave * NI + i;
-        const char* base = reinterpret_cast<const char*>(q < NA ? pa : pw);
-        __builtin_amdgcn_global_load_lds((enc_gbl_ptr)(base + loff[i]),
-                                         (enc_lds_ptr)(xsm + stage * kStage + (q < NA ? q * 1024 : kA + (q - NA) * 1024)), 16, 0, 0);
-    };
-    auto issue = [&](int m0, int n0, int kt, int stage) {
-#pragma unroll
-        for (int i = 0; i < NI; ++i) issue_piece(m0, n0, kt, stage, i);
-    };
-    int a_off[2][2], b_off[2][2];
-    const int ga = (fr >> 1) & 7;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int pl = 0; pl < 2; ++pl) {
-            a_off[ks][pl] = (wm * (BM / WM) + fr) * 128 + (((4 * pl + 2 * ks + fh) ^ ga) << 4);
-            b_off[ks][pl] = kA + (wn * (BN / 2) + fr) * 128 + (((4 * pl + 2 * ks + fh) ^ ga) << 4);
-        }
-
-    // ---- the kept tile and its epilogue in nano-steps -----------------------------------------------------------------
-    f32x16 prev[TM][TN];
-    int pm0 = 0, pn0 = 0;
-    uint32_t hi[4], lo[4];  // the half sub-tile in flight, as (hi, lo) fp16 pairs
-    auto nano = [&](auto NC) {
-        constexpr int n = decltype(NC)::value, u = n / 5, ph = n % 5;
-        constexpr int i = u >> 2, j = (u >> 1) & 1, p2 = u & 1;
-        const int cb = pn0 + wn * (BN / 2) + j * 32;  // first column of the sub-tile
-        if constexpr (ph < 4) {
-            // elements 2 ph, 2 ph + 1 of the half sub-tile: registers 8 p2 + 2 ph (+ 1) = columns 8 g + 4 fh + e (+ 1)
-            constexpr int g = 2 * p2 + (ph >> 1), e = 2 * (ph & 1);
-            const f32x2e b2 = *reinterpret_cast<const f32x2e*>(bias_l + cb + 8 * g + 4 * fh + e);
-            float x0 = prev[i][j][4 * g + e] * inv_wscale + b2[0];  // exact: the weight scale is a power of two
-            float x1 = prev[i][j][4 * g + e + 1] * inv_wscale + b2[1];
-            if (EPI == EPI_BIAS_GELU) {
-                x0 = 0.5f * x0 * (1.0f + x3_erf(x0 * 0.70710678118654752440f));
-                x1 = 0.5f * x1 * (1.0f + x3_erf(x1 * 0.70710678118654752440f));
-            }
-            if (EPI == EPI_BIAS_QKV) {  // uniform per tile (qcols % 32 == 0)
-                x0 = cb < qcols ? x0 * qscale : x0;
-                x1 = cb < qcols ? x1 * qscale : x1;
-            }
-            x3_split2(x0, x1, hi[ph], lo[ph]);
-        } else {
-            // x3t_store_image's exchange: lane half 0 keeps (own columns 0..3, partner's 0..3) = 16 p2 .. + 7, half 1 the rest
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const x3_u2 sh = __builtin_amdgcn_permlane32_swap(hi[e], hi[2 + e], false, false);
-                const x3_u2 sl = __builtin_amdgcn_permlane32_swap(lo[e], lo[2 + e], false, false);
-                hi[e] = sh[0];
-                hi[2 + e] = sh[1];
-                lo[e] = sl[0];
-                lo[2 + e] = sl[1];
-            }
-            const int row = pm0 + wm * (BM / WM) + i * 32 + fr;
-            if (row < T) {
-                unsigned char* line = reinterpret_cast<unsigned char*>(C + (int64_t)row * N + cb);
-                *reinterpret_cast<uint4*>(line + 32 * p2 + 16 * fh) = uint4{hi[0], hi[1], hi[2], hi[3]};
-                *reinterpret_cast<uint4*>(line + 64 + 32 * p2 + 16 * fh) = uint4{lo[0], lo[1], lo[2], lo[3]};
-            }
-        }
-    };
-
-    int m0, n0;
-    tile_of(v, m0, n0);
-    lane_offsets(m0);
-    issue(m0, n0, 0, 0);
-    issue(m0, n0, 1, 1);
-    bool have_prev = false;
-    int st = 0;  // buffer of the K-step about to run
-    for (;;) {
-        f32x16 acc[TM][TN];
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-        const unsigned vn = v + gridDim.x;
-        int m1 = m0, n1 = n0;
-        if (vn < active) tile_of(vn, m1, n1);
-        auto kloop = [&](auto with_epi) {
-            constexpr bool E = decltype(with_epi)::value;
-            x3_static_for<NK>([&](auto KT) {
-                constexpr int kt = decltype(KT)::value;
-                // Order of a wave's vector-memory operations in a step: DMA piece i of stage kt + 2 behind MFMA slot i (a
-                // global_load_lds costs its wave 60 - 180 cycles of issue: spread between the MFMAs, not a burst that every
-                // wave pays at the barrier), the stores of a nano-step behind its slot.  Stage kt has landed once at most
-                // these are outstanding: the pieces of stage kt + 1, the stores of step kt - 1, and the stores of step
-                // kt - 2 that were issued behind its last piece.
-#ifdef MVDB_X3_STAGGER
-                constexpr int allow = NI + (E ? pipe_step_stores(kt - 1, NK) + pipe_step_stores(kt - 2, NK, 12 + NI - 1, 24) : 0);  // the stricter half
-#else
-                constexpr int allow = NI + (E ? pipe_step_stores(kt - 1, NK) + pipe_step_stores(kt - 2, NK, NI - 1, 24) : 0);
-#endif
-                static_assert(allow < 64, "vmcnt is a 6-bit count");
-                __builtin_amdgcn_sched_barrier(0);
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(allow) : "memory");
-                __builtin_amdgcn_s_barrier();
-                __builtin_amdgcn_sched_barrier(0);
-                // look-ahead: K-step kt + 2 of this tile, or the next tile's first two stages (they land under this
-                // tile's last steps); the last tile re-fetches its own first stages into buffers nobody reads
-                constexpr bool more = kt + 2 < NK;
-                if constexpr (kt + 2 == NK) lane_offsets(m1);  // from here on the pieces belong to the next tile
-                const int abuf = st == 0 ? 2 : st - 1;
-                x3_kstep_hook<TM, TN>(xsm + st * kStage, a_off, b_off, acc, [&](auto M) {
-                    constexpr int m = decltype(M)::value;
-#ifdef MVDB_X3_STAGGER
-                    if constexpr (m < NI) {
-                        if (wave < 4) issue_piece(more ? m0 : m1, more ? n0 : n1, more ? kt + 2 : kt + 2 - NK, abuf, m);
-                    }
-                    if constexpr (m >= 12 && m < 12 + NI) {
-                        if (wave >= 4) issue_piece(more ? m0 : m1, more ? n0 : n1, more ? kt + 2 : kt + 2 - NK, abuf, m - 12);
-                    }
-#else
-                    if constexpr (m < NI) issue_piece(more ? m0 : m1, more ? n0 : n1, more ? kt + 2 : kt + 2 - NK, abuf, m);
-#endif
-                    if constexpr (E && kt < NK - 2) {
-                        constexpr int slot = kt * 24 + m;
-                        constexpr int first = pipe_nano_first(slot, SLOTS), end = pipe_nano_first(slot + 1, SLOTS);
-                        static_assert(end - first <= 1, "at most one nano-step per MFMA slot");
-                        if constexpr (end > first) nano(std::integral_constant<int, first>{});
-                    }
-                });
-                st = st == NST - 1 ? 0 : st + 1;
-            });
-        };
-        if (have_prev) kloop(std::true_type{});
-        else kloop(std::false_type{});
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) prev[i][j] = acc[i][j];
-        pm0 = m0;
-        pn0 = n0;
-        have_prev = true;
-        if (vn >= active) break;
-        v = vn;
-        m0 = m1;
-        n0 = n1;
-    }
-    // the last tile's epilogue: the same nano-steps, back to back
-    x3_static_for<kPipeNano>([&](auto NC) { nano(NC); });
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the clamped look-ahead DMAs must land before the LDS is released
 }
 
 // =================================================================================================
@@ -1660,7 +1357,7 @@ __global__ __launch_bounds__(WM * 256) void gemm_x3_ln_kernel(const _Float16* __
                 continue;
             }
             if (SPREAD)
-                x3_kstep<TM, TN, 0, NI>(sb, a_off, b_off, acc, [&](int i) { issue_piece(amb, akt, abuf, i); }, X3_DMA_KS(wave, WM * 4));
+                x3_kstep<TM, TN, 0, NI>(sb, a_off, b_off, acc, [&](int i) { issue_piece(amb, akt, abuf, i); });
             else
                 x3_kstep_plain<TM, TN>(sb, a_off, b_off, acc);
             st = st == NST - 1 ? 0 : st + 1;
@@ -2709,28 +2406,7 @@ int launch_gemm_x3(const float* Aimg, const _Float16* Wp, float inv_wscale, cons
         const int sel_big = big8env == 1 ? 0 : bign;
         // one persistent workgroup per CU walking the tile list (gemm_x3_big_kernel); MVDB_GEMM_X3_PERSIST=0: one workgroup per tile
         static const bool persist = []() { const char* v = getenv("MVDB_GEMM_X3_PERSIST"); return !(v && *v == '0'); }();
-        // round 4: the image-writing GEMMs run their epilogue inside the next tile's K loop (gemm_x3_pipe_kernel, 256 x 128
-        // tiles); MVDB_GEMM_X3_PIPE=0: the 256 x 256 / 256 x 192 forms below
-        static const bool pipe = []() { const char* v = getenv("MVDB_GEMM_X3_PIPE"); return !(v && *v == '0'); }();
-        bool piped = false;
-        if constexpr (EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_QKV) {
-            if (persist && pipe && N % 128 == 0 && N <= 4096 && (K == 384 || K == 1024)) {
-                const unsigned gpp = (unsigned)std::min<int64_t>((int64_t)(N / 128) * ((Tmax + 255) / 256), cus);
-                const int ldsq = 3 * (256 * 128 + 128 * 128) + N * 4;
-                if (K == 384) {
-                    auto kq = gemm_x3_pipe_kernel<EPI, 12>;
-                    MVDB_TRY(x3_set_lds((const void*)kq, ldsq, device));
-                    hipLaunchKernelGGL(kq, dim3(gpp), dim3(512), ldsq, s, A, Wp, inv_wscale, bias, C, Tptr, N, sel_big, cus, qcols, qscale);
-                } else {
-                    auto kq = gemm_x3_pipe_kernel<EPI, 32>;
-                    MVDB_TRY(x3_set_lds((const void*)kq, ldsq, device));
-                    hipLaunchKernelGGL(kq, dim3(gpp), dim3(512), ldsq, s, A, Wp, inv_wscale, bias, C, Tptr, N, sel_big, cus, qcols, qscale);
-                }
-                piped = true;
-            }
-        }
-        if (piped) {
-        } else if (persist) {
+        if (persist) {
             const unsigned gp = (unsigned)std::min<int64_t>((int64_t)gridb.x * gridb.y, cus);
             static const bool spread = []() { const char* v = getenv("MVDB_GEMM_X3_SPREAD"); return !(v && *v == '0'); }();
             if (bign == 256) {
