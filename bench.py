@@ -252,10 +252,31 @@ def encoder_and_config5(native, dev, k, no_cpu):
             step()
         torch.cuda.synchronize()
         t_all = (time.perf_counter() - t0) / reps
+        # the same chain as ONE hipGraph (the search never synchronises: tests/test_config5_gpu.py checks the replay bit for
+        # bit): no host launches between the encoder's graph and the search's ~25 kernels
+        t_graph = None
+        try:
+            g = torch.cuda.CUDAGraph()
+            emb_g = torch.empty((B, H), dtype=torch.float32, device=dev)
+            with torch.cuda.graph(g, stream=torch.cuda.current_stream(), capture_error_mode="thread_local"):
+                e_, _ = enc.forward_device(ids_d, mask_d)
+                emb_g.copy_(e_)
+                idx5.search_device(emb_g.data_ptr(), B, k, D.data_ptr(), I.data_ptr(), stream=stream)
+            g.replay()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                g.replay()
+            torch.cuda.synchronize()
+            t_graph = (time.perf_counter() - t0) / reps
+            del g
+        except Exception as e:  # noqa: BLE001 - a capture problem must not cost the bench line
+            print(f"[bench] config 5 graph capture skipped: {e}", file=sys.stderr)
         passes = -(-B // max(native.half_max_queries(H), 128))
         knn_gbs = passes * n5 * H * 4 / max(t_all - t_enc, 1e-9) / 1e9
         c5["shapes"].append({"S": S, "ragged": True, "tokens": int(lens.sum()), "encoder_ms": round(t_enc * 1e3, 3),
                              "knn_ms": round((t_all - t_enc) * 1e3, 3), "end_to_end_ms": round(t_all * 1e3, 3),
+                             "end_to_end_one_graph_ms": None if t_graph is None else round(t_graph * 1e3, 3),
                              "sentences_per_s": round(B / t_all, 1), "knn_corpus_passes": passes,
                              # query chunks that held a query the certified pass could not certify (re-run exactly, on the device)
                              "uncertified_chunks_per_search": (native.split_rerun_count() - reruns0) / reps,
