@@ -471,7 +471,10 @@ def main():
         if scan_name == "ip_scan_half":
             # fp16 nomination pass: the seed launch (ip_scan_half_seed) covers the first 32-row tile of every CU
             chunk = native.half_max_queries(d)
-            bytes_per_launch = (n - min((n + 31) // 32, cus) * 32) * d * 4
+            # round 4: where the index keeps an fp16 shadow of its rows the main launches stream THAT — 2 bytes per element
+            # are the pass's algorithmic bytes (the fp32 matrix is read by the seed launch and the re-scores only)
+            shadow = native.prof_symbol(scan_name).startswith("flat_scan_h16_kernel")
+            bytes_per_launch = (n - min((n + 31) // 32, cus) * 32) * d * (2 if shadow else 4)
         passes = K * ((nq + chunk - 1) // chunk)
         if scan_name in ("ip_scan_split", "ip_scan_split32", "ip_scan_half"):
             # one corpus pass = the seed launch + up to three main launches of growing size (phases, admission floors
@@ -531,7 +534,9 @@ def main():
                 "kernel": {"ip_scan": "flat_scan_kernel", "ip_scan_mfma": "flat_scan_mfma2_kernel",
                            "ip_scan_split": "flat_scan_split_kernel",
                            "ip_scan_split32": "flat_scan_split32_kernel",
-                           "ip_scan_half": "flat_scan_hq_kernel" if d <= 512 else "flat_scan_half_kernel"}[scan_name],
+                           "ip_scan_half": (launched.split("<")[0] or "flat_scan_half_kernel")}[scan_name],
+                "operand": ("fp16 shadow of the corpus (2 B per element; the fp32 matrix stays resident beside it)"
+                            if launched.startswith("flat_scan_h16_kernel") else "fp32 corpus (4 B per element)"),
                 "launches": launches,
                 "avg_launch_ms": round(avg_ms, 4),
                 "algorithmic_bytes_per_launch": int(bytes_per_launch),

@@ -806,6 +806,233 @@ __global__ __launch_bounds__(WV * 64) void flat_scan_hq_kernel(HalfScanArgs a) {
     }
 }
 
+// ---- the same pass over the fp16 SHADOW of the corpus (round 4) -------------------------------------------------------
+// flat_scan_hq_kernel reads fp32 rows and converts every 32-row tile to fp16 on its way to the matrix cores: for a
+// nomination pass that is twice the bytes the arithmetic needs, plus a raw staging ring, the conversion's VALU work and a
+// second LDS round trip per element.  An index that answers batches keeps — lazily, from its first 33+-query search on — an
+// fp16 copy of its rows, Xh[n][d] = fp16(s_x x) (mvdb.hip: shadow; exactly the values the conversion produces, so the
+// certificate and its bound are unchanged; 2 bytes per element on top of the 4 of the fp32 matrix, which stays the home of
+// the exact scans and of the re-scores).  This kernel streams THAT:
+//   * a stage = KS 16-k blocks of a 32-row tile = 32 rows x 32 KS bytes (8 KiB at KS = 8, 16 KiB at 16), DMA'd straight into
+//     the image the MFMA fragments are read from: no conversion, no second buffer.  The LDS image of a DMA is lane-linear,
+//     so the bank swizzle (16-byte slot p of row r holds the row's logical slot p ^ (r & 15): conflict-free b128 fragment
+//     reads at 16 or 32 slots per row) is applied to the per-lane SOURCE address;
+//   * NST stages in flight per workgroup (each wave issues its share and waits for its own with a counted vmcnt; one bare
+//     s_barrier per stage), the queries' fragments in registers for the whole launch as in flat_scan_hq_kernel;
+//   * gate, lists, bitmap: flat_scan_hq_kernel's.
+// ALGORITHMIC bytes per launch = rows scanned x d x 2 (the pass's operand is the shadow).  At 256 queries per pass and d = 512
+// the matrix cores (2 x 16 MFMAs per SIMD and stage = 1,024 cycles) and HBM (16 KiB per CU and stage = ~1,200 cycles) are
+// about co-limiting; at 128 queries HBM bounds.
+template <int KT, int KS, int WV, int NST>
+__global__ __launch_bounds__(WV * 64) void flat_scan_h16_kernel(HalfScanArgs a) {
+    constexpr int K = KT * 16;
+    constexpr int NSTG = KT / KS;            // stages per tile
+    constexpr int HSL = KS * 2;              // 16-byte slots (8 fp16) per row and stage
+    constexpr int kStage = 32 * HSL * 16;    // bytes
+    constexpr int NP = kStage / 1024;        // DMA instructions per stage
+    constexpr int DPW = NP / WV;             // ... per wave
+    static_assert(KT % KS == 0 && (HSL == 16 || HSL == 32) && NP % WV == 0 && DPW >= 1, "shape");
+    static_assert((NST - 1) * DPW <= 63, "vmcnt is a 6-bit counter");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // NST stages
+    __shared__ uint64_t lists[WV * 32 * kHalfKeep];                         // [wave][32 queries][16] keys
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int fr = lane & 31, fk = lane >> 5;
+    uint64_t* mylists = lists + (size_t)wave * 32 * kHalfKeep;
+    for (int e = lane; e < 32 * kHalfKeep; e += 64) mylists[e] = 0ull;
+
+    // ---- this wave's 32 queries over the whole K: B[k = 16 kb + 8 fk + j][query fr]
+    hs_h8 Q[KT];
+#pragma unroll
+    for (int kb = 0; kb < KT; ++kb)
+        Q[kb] = *reinterpret_cast<const hs_h8*>(a.qf + (int64_t)(wave * 32 + fr) * K + kb * 16 + fk * 8);
+    const int myq = wave * 32 + fr;
+    float floor0 = myq < a.nq ? (a.thr0 ? a.thr0[myq] : -INFINITY) : INFINITY;
+    float thr = floor0;
+    float inv = a.qinv[myq];
+    // consume every global load here (see flat_scan_half_kernel)
+#pragma unroll
+    for (int kb = 0; kb < KT; ++kb) asm volatile("" : "+v"(Q[kb]));
+    asm volatile("" : "+v"(floor0), "+v"(thr), "+v"(inv));
+
+    const int64_t ntiles = a.tile1 - a.tile0;
+    const int64_t last = a.n - 1;
+    // DMA roles: piece p = wave DPW + i of a stage fills LDS bytes [1024 p, 1024 p + 1024) = rows (64 p + lane) / HSL
+    uint32_t voff[DPW];
+#pragma unroll
+    for (int i = 0; i < DPW; ++i) {
+        const int j = (wave * DPW + i) * 64 + lane;
+        const int row = j / HSL, ps = j % HSL;
+        voff[i] = (uint32_t)(row * (K * 2) + ((ps ^ (row & 15)) << 4));
+    }
+    const int64_t step = gridDim.x;
+    int64_t tile = blockIdx.x;
+    // stage c of the block's flat sequence = (tile + (c / NSTG) step, K part c % NSTG); tiles past the end are clamped
+    auto issue_stage = [&](int64_t base, int c, int buf) {
+        int64_t t = base + (int64_t)(c / NSTG) * step;
+        t = t < ntiles ? t : (base < ntiles ? base : 0);
+        const char* sbase = reinterpret_cast<const char*>(a.Xh) + ((a.tile0 + t) * 32 * (int64_t)K + (c % NSTG) * KS * 16) * 2;
+        unsigned char* dst = smem + buf * kStage + wave * DPW * 1024;
+#pragma unroll
+        for (int i = 0; i < DPW; ++i)
+            __builtin_amdgcn_global_load_lds((hs_gbl_ptr)(sbase + voff[i]), (hs_lds_ptr)(dst + i * 1024), 16, 0, 2 /* nt */);
+    };
+    const int frow = fr * HSL * 16;
+    const int fsw = fr & 15;
+    unsigned n_ins = 0, n_slow = 0;
+    hs_f16 acc;
+    auto gate = [&](int64_t m0) {
+        float sc[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) sc[e] = acc[e] * inv;  // exact: 1 / (s_q s_x) is a power of two
+        float mx = sc[0];
+#pragma unroll
+        for (int e = 1; e < 16; ++e) mx = fmaxf(mx, sc[e]);
+        if (__ballot(mx >= thr) != 0ull) {
+            ++n_slow;
+            const uint32_t mw = a.mask ? a.mask[m0 >> 5] : 0xffffffffu;  // row selection: looked at on the slow path only
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int rl = (e & 3) + 8 * (e >> 2);
+                const float s = sc[e];
+                uint64_t mask = __ballot(m0 + rl + 4 * fk <= last && ((mw >> (rl + 4 * fk)) & 1u) && s >= thr);
+                while (mask) {
+                    const int srcl = __ffsll((long long)mask) - 1;
+                    mask &= mask - 1;
+                    ++n_ins;
+                    const int sq = srcl & 31;
+                    const float sv = __uint_as_float(__builtin_amdgcn_readlane((int)__float_as_uint(s), srcl));
+                    const uint32_t rv = (uint32_t)(m0 + rl + 4 * (srcl >> 5));
+                    const uint64_t kth = lds_list_insert(mylists + (size_t)sq * kHalfKeep, kHalfKeep, make_key(sv, rv), lane);
+                    if (fr == sq) thr = kth ? fmaxf(key_score(kth), floor0) : floor0;  // both lane halves
+                }
+            }
+        }
+    };
+
+    if (tile < ntiles) {
+#pragma unroll
+        for (int c = 0; c < NST - 1; ++c) issue_stage(tile, c, c);
+    }
+    int buf = 0;
+    while (tile < ntiles) {
+        const int64_t m0 = (a.tile0 + tile) * 32;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int sg = 0; sg < NSTG; ++sg) {
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * DPW) : "memory");  // this wave's pieces of the stage have landed
+            __builtin_amdgcn_s_barrier();  // everybody's have; and every wave is done reading the stage before
+            __builtin_amdgcn_sched_barrier(0);
+            issue_stage(tile, sg + NST - 1, buf == 0 ? NST - 1 : buf - 1);  // into the buffer of the stage before
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned char* src = smem + buf * kStage + frow;
+            auto frag = [&](int kb) { return *reinterpret_cast<const hs_h8*>(src + (((2 * kb + fk) ^ fsw) << 4)); };
+            constexpr int AHEAD = KS < 6 ? KS : 6;
+            hs_h8 f[AHEAD + 1];
+#pragma unroll
+            for (int u = 0; u < AHEAD; ++u) f[u] = frag(u);
+#pragma unroll
+            for (int kb = 0; kb < KS; ++kb) {
+                if (kb + AHEAD < KS) f[(kb + AHEAD) % (AHEAD + 1)] = frag(kb + AHEAD);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[kb % (AHEAD + 1)], Q[sg * KS + kb], acc, 0, 0, 0);
+            }
+            // the order the scheduler must keep: the first fragments up front, then one fragment read per MFMA
+            __builtin_amdgcn_sched_group_barrier(0x100, AHEAD, 0);
+#pragma unroll
+            for (int kb = 0; kb < KS; ++kb) {
+                if (kb + AHEAD < KS) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the fragments are in registers before the buffer may be refilled)
+            buf = buf == NST - 1 ? 0 : buf + 1;
+        }
+        gate(m0);
+        tile += step;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the clamped look-ahead DMAs must land before the LDS is released
+    if (a.stats && lane == 0) {
+        atomicAdd(a.stats, n_ins);
+        atomicAdd(a.stats + 1, n_slow);
+    }
+#pragma unroll 1
+    for (int q = 0; q < 32; ++q) {
+        const int qq = wave * 32 + q;
+        if (qq >= a.nq) break;
+        if (lane < kHalfKeep)
+            a.cand[((int64_t)qq * gridDim.x + blockIdx.x) * kHalfKeep + lane] = mylists[(size_t)q * kHalfKeep + lane];
+    }
+}
+
+// fp32 rows -> the shadow: Xh[r][c] = fp16(s_x X[r][c]) (RNE; s_x a power of two: the product is exact) — the values
+// flat_scan_hq_kernel's conversion produces
+__global__ __launch_bounds__(256) void half_shadow_kernel(const float* __restrict__ X, int64_t ld, int d, int64_t n, float xscale,
+                                                          _Float16* __restrict__ Xh) {
+    const int64_t total = n * (int64_t)(d / 4);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / (d / 4);
+        const int c = (int)(i % (d / 4)) * 4;
+        const hs_f4 v = *reinterpret_cast<const hs_f4*>(X + r * ld + c);
+        union {
+            hs_h2 p[2];
+            hs_f2 f;
+        } u;
+        u.p[0] = __builtin_convertvector(hs_f2{v[0], v[1]} * hs_f2{xscale, xscale}, hs_h2);
+        u.p[1] = __builtin_convertvector(hs_f2{v[2], v[3]} * hs_f2{xscale, xscale}, hs_h2);
+        *reinterpret_cast<hs_f2*>(Xh + r * d + c) = u.f;
+    }
+}
+
+int launch_half_shadow(const float* X, int64_t ld, int d, int64_t n, float xscale, _Float16* Xh, int device, hipStream_t stream) {
+    if (n <= 0) return 0;
+    const int64_t total = n * (int64_t)(d / 4);
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((total + 255) / 256, (int64_t)device_cus(device) * 16));
+    hipLaunchKernelGGL(half_shadow_kernel, dim3(grid), dim3(256), 0, stream, X, ld, d, n, xscale, Xh);
+    MVDB_HIP(hipGetLastError());
+    return 0;
+}
+
+bool half_shadow_dim(int d) { return d == 256 || d == 384 || d == 512; }
+
+template <int KT, int KS, int WV, int NST>
+static int launch_h16_inst(const HalfScanArgs& a, int device, hipStream_t stream, int* nblocks_out) {
+    auto kern = flat_scan_h16_kernel<KT, KS, WV, NST>;
+    constexpr size_t lds = (size_t)NST * 32 * KS * 2 * 16;
+    static_assert(lds + WV * 32 * kHalfKeep * 8 <= 160 * 1024, "LDS budget of a CU");
+    {
+        static std::mutex mu;
+        static std::map<int, bool> done;
+        std::lock_guard<std::mutex> lk(mu);
+        if (!done[device]) {
+            MVDB_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            done[device] = true;
+        }
+    }
+    const int64_t ntiles = a.tile1 - a.tile0;
+    const int nblocks = (int)std::max<int64_t>(1, std::min<int64_t>(ntiles, (int64_t)device_cus(device)));
+    *nblocks_out = nblocks;
+    prof_symbol("ip_scan_half", "flat_scan_h16_kernel<%d, %d, %d, %d>", KT, KS, WV, NST);
+    int slot = prof_begin("ip_scan_half", stream);
+    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(WV * 64), lds, stream, a);
+    prof_end(slot, stream);
+    MVDB_HIP(hipGetLastError());
+    return 0;
+}
+
+// main launches over the shadow: d = 256 / 384 (8-k-block stages, 8 KiB) and 512 (16-k-block stages, 16 KiB)
+static int launch_h16(int d, int nqpad, const HalfScanArgs& a, int device, hipStream_t stream, int* nb) {
+    const bool wide = nqpad == 256;
+    if (nqpad != 128 && nqpad != 256) return fail(MVDB_ERR_ARG, "no fp16-shadow kernel for %d queries per pass", nqpad);
+    switch (d) {
+        case 256: return wide ? launch_h16_inst<16, 8, 8, 8>(a, device, stream, nb) : launch_h16_inst<16, 8, 4, 8>(a, device, stream, nb);
+        case 384: return wide ? launch_h16_inst<24, 8, 8, 8>(a, device, stream, nb) : launch_h16_inst<24, 8, 4, 8>(a, device, stream, nb);
+        case 512: return wide ? launch_h16_inst<32, 16, 8, 6>(a, device, stream, nb) : launch_h16_inst<32, 16, 4, 6>(a, device, stream, nb);
+        default: return fail(MVDB_ERR_ARG, "no fp16-shadow kernel for d = %d", d);
+    }
+}
+
 // ---- certification ------------------------------------------------------------------------------------------------
 // One block per query.  U = max(last floor, 16th score of every full block list); R = the 64 best candidates by
 // approximate score; U is raised to a(64th) when R is full; fp32 re-score of R (one wave per nominee, the arithmetic
@@ -1050,6 +1277,7 @@ static int launch_half_kq(int nqpad, bool seed, const HalfScanArgs& a, const Kno
 }
 
 int launch_half_scan(int d, int nqpad, bool seed, const HalfScanArgs& a, const Knobs& kn, int device, hipStream_t stream, int* nblocks_out) {
+    if (!seed && a.Xh && half_shadow_dim(d)) return launch_h16(d, nqpad, a, device, stream, nblocks_out);
     switch (half_kq(d)) {
         case 4: return launch_half_kq<4, 0>(nqpad, seed, a, kn, device, stream, nblocks_out);
         case 6: return launch_half_kq<6, 0>(nqpad, seed, a, kn, device, stream, nblocks_out);

@@ -25,6 +25,8 @@ struct HalfScanArgs {
     const float* thr0;    // [nq] admission floors, or NULL
     unsigned int* stats;  // NULL, or [2]: list inserts, wave-tiles that reached the slow path (diagnostics)
     const uint32_t* mask = nullptr;  // NULL, or one bit per row (bit r & 31 of word r >> 5): only rows whose bit is set may be nominated
+    const _Float16* Xh = nullptr;    // NULL, or the fp16 shadow of the corpus, [n][d] = fp16(xscale * X): the main launches stream IT
+                                     // (flat_scan_h16_kernel: half the bytes, no conversion) where a kernel exists (half_shadow_dim)
 };
 
 struct HalfCertifyArgs {
@@ -63,5 +65,8 @@ int launch_half_queries(const float* q, int64_t ld, int d, int nq, int nqpad, fl
 // seed: one tile per block over [tile0, tile1), every score dumped ([nq, blocks, 32] keys); *nblocks_out = blocks
 int launch_half_scan(int d, int nqpad, bool seed, const HalfScanArgs& a, const Knobs& kn, int device, hipStream_t stream, int* nblocks_out);
 int launch_half_certify(const HalfCertifyArgs& a, int nq, hipStream_t stream);
+// the fp16 shadow of rows [0, n) of X (ld floats per row) into Xh (d halves per row); dimensions the shadow kernels serve
+int launch_half_shadow(const float* X, int64_t ld, int d, int64_t n, float xscale, _Float16* Xh, int device, hipStream_t stream);
+bool half_shadow_dim(int d);
 
 }  // namespace mvdb

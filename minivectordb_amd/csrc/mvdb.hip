@@ -63,6 +63,7 @@ Knobs read_knobs() {
     k.disable_half_scan = env_int("MVDB_DISABLE_HALF_SCAN", 0) != 0;
     k.disable_masked_batch = env_int("MVDB_DISABLE_MASKED_BATCH", 0) != 0;
     k.disable_l2_cert = env_int("MVDB_DISABLE_L2_CERT", 0) != 0;
+    k.disable_half_shadow = env_int("MVDB_DISABLE_HALF_SHADOW", 0) != 0;
     {
         const char* v = getenv("MVDB_HQ_PIPE");
         k.hq_pipe = !(v && *v == '0');
@@ -255,6 +256,14 @@ struct mvdb_index {
     hipStream_t mut = nullptr;   // the mutators' own non-blocking stream: add / remove_rows never touch the legacy stream,
                                  // so work other libraries have in flight on the device (an encoder forward) is not stalled
     unsigned int* normmax = nullptr;  // 4-byte scratch of note_row_norms (raw adds)
+    // fp16 shadow of the rows (half_scan.hip: flat_scan_h16_kernel): built by the first batch search that can use it, extended
+    // by add, dropped by whatever renumbers rows or changes the scale.  Searches (shared lock) build / read it under
+    // shadow_mu; mutators (exclusive lock, searches quiesced) edit it directly.
+    mutable std::mutex shadow_mu;
+    mutable _Float16* Xh = nullptr;
+    mutable int64_t xh_cap = 0, xh_rows = 0;   // rows allocated (+ kRowSlack behind them) / rows converted
+    mutable float xh_scale = 0.f;
+    mutable bool xh_failed = false;            // allocation failed: not retried until the index changes
     mutable std::shared_mutex mu;  // search: shared; add/reset/remove/free: exclusive
     mutable std::mutex ws_mu;
     mutable std::vector<Workspace*> free_ws;           // synchronous searches
@@ -901,6 +910,8 @@ bool half_path_ok(const mvdb_index* idx) {
     return half_max_queries(idx->d) > 0 && idx->ld == idx->d && half_xscale(idx->row_norm_bound) > 0.f;
 }
 
+const _Float16* ensure_shadow(const mvdb_index* idx, hipStream_t s, float xscale);
+
 int launch_half_pass(const mvdb_index* idx, Workspace* ws, const float* q, int nq, int nqpad, int k, int64_t n,
                      int64_t label_offset, float* D, int64_t* I, int* flag, int* failed, const uint32_t* mask = nullptr) {
     hipStream_t stream = ws->stream;
@@ -919,6 +930,7 @@ int launch_half_pass(const mvdb_index* idx, Workspace* ws, const float* q, int n
     a.xscale = xscale;
     a.nq = nq;
     a.mask = mask;
+    a.Xh = ensure_shadow(idx, stream, xscale);
     a.stats = idx->kn.split_stats ? reinterpret_cast<unsigned int*>(ws->flags.p) + (ws->flags.cap - 32) : nullptr;
     if (a.stats) MVDB_HIP(hipMemsetAsync(a.stats, 0, 8, stream));
     const int64_t ntiles = (n + 31) / 32;
@@ -1472,6 +1484,52 @@ int check_search_args(const mvdb_index* idx, const void* q, int nq, int k, const
 // are read, scored and never nominated) so that their DMA issue needs no per-lane bounds handling.
 constexpr int64_t kRowSlack = 32;
 
+void drop_shadow(const mvdb_index* idx) {
+    if (idx->Xh) (void)hipFree(idx->Xh);
+    idx->Xh = nullptr;
+    idx->xh_cap = idx->xh_rows = 0;
+    idx->xh_scale = 0.f;
+    idx->xh_failed = false;
+}
+
+// The shadow for a batch search on stream s (caller holds the index shared): the existing one if it covers the rows at
+// this scale, else built here — once: 10M x 512 convert in ~5 ms — and published after a wait for s, so that searches on
+// other streams find complete data.  NULL (the fp32 path serves): no kernel for d, switched off, allocation failed, or the
+// stream is being captured (a build allocates and synchronises).
+const _Float16* ensure_shadow(const mvdb_index* idx, hipStream_t s, float xscale) {
+    if (!half_shadow_dim(idx->d) || idx->ld != idx->d || idx->kn.disable_half_shadow || !(xscale > 0.f)) return nullptr;
+    std::lock_guard<std::mutex> lk(idx->shadow_mu);
+    if (idx->Xh && idx->xh_scale == xscale && idx->xh_rows == idx->n) return idx->Xh;
+    if (idx->xh_failed) return nullptr;
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (s && hipStreamIsCapturing(s, &st) == hipSuccess && st == hipStreamCaptureStatusActive) return nullptr;
+    // (a stale shadow can only be one whose rows are a prefix at another scale or count: mutators drop or extend it while no
+    //  search is in flight, so nobody else is reading what is rebuilt here)
+    if (idx->Xh && (idx->xh_scale != xscale || idx->xh_cap < idx->n)) drop_shadow(idx);
+    if (!idx->Xh) {
+        _Float16* p = nullptr;
+        const int64_t cap = std::max<int64_t>(idx->cap, idx->n);
+        if (hipMalloc((void**)&p, (size_t)(cap + kRowSlack) * idx->d * sizeof(_Float16)) != hipSuccess) {
+            (void)hipGetLastError();
+            idx->xh_failed = true;
+            return nullptr;
+        }
+        idx->Xh = p;
+        idx->xh_cap = cap;
+        idx->xh_rows = 0;
+        idx->xh_scale = xscale;
+    }
+    if (launch_half_shadow(idx->X + idx->xh_rows * idx->ld, idx->ld, idx->d, idx->n - idx->xh_rows, xscale,
+                           idx->Xh + idx->xh_rows * idx->d, idx->device, s) != 0 ||
+        hipStreamSynchronize(s) != hipSuccess) {
+        drop_shadow(idx);
+        idx->xh_failed = true;
+        return nullptr;
+    }
+    idx->xh_rows = idx->n;
+    return idx->Xh;
+}
+
 int grow(mvdb_index* idx, int64_t need) {
     if (need <= idx->cap) return 0;
     int64_t cap = std::max<int64_t>(need, idx->cap + idx->cap / 2);
@@ -1491,6 +1549,7 @@ int grow(mvdb_index* idx, int64_t need) {
     if (idx->X) (void)hipFree(idx->X);
     idx->X = nx;
     idx->cap = cap;
+    drop_shadow(idx);  // sized for the old capacity: rebuilt by the next batch search
     return 0;
 }
 
@@ -1564,6 +1623,7 @@ int mvdb_index_free(mvdb_index* idx) {
         (void)quiesce(idx);
         if (idx->mut) (void)hipStreamDestroy(idx->mut);
         if (idx->normmax) (void)hipFree(idx->normmax);
+        drop_shadow(idx);
         for (Workspace* w : idx->free_ws) {
             w->destroy();
             delete w;
@@ -1588,6 +1648,7 @@ int mvdb_index_reset(mvdb_index* idx) {
     DeviceGuard dg(idx->device);
     MVDB_TRY(quiesce(idx));
     idx->n = 0;
+    drop_shadow(idx);
     idx->row_norm_bound = 0.f;
     idx->norm2_lo = INFINITY;
     idx->norm2_hi = 0.f;
@@ -1620,6 +1681,7 @@ int mvdb_index_reserve(mvdb_index* idx, int64_t n) {
     if (idx->X) (void)hipFree(idx->X);
     idx->X = nx;
     idx->cap = n;
+    drop_shadow(idx);
     return 0;
 }
 
@@ -1669,6 +1731,24 @@ static int note_row_norms(mvdb_index* idx, const float* dst, int64_t n, int norm
     return 0;
 }
 
+// add: the shadow follows when it is there, still fits and the scale the new norm bound asks for is the one it was built with
+static int extend_shadow(mvdb_index* idx, int64_t n_new) {
+    if (!idx->Xh) {
+        idx->xh_failed = false;
+        return 0;
+    }
+    const float xscale = half_xscale(idx->row_norm_bound);
+    if (idx->xh_rows != idx->n || idx->xh_cap < idx->n + n_new || xscale != idx->xh_scale) {
+        drop_shadow(idx);
+        return 0;
+    }
+    MVDB_TRY(launch_half_shadow(idx->X + idx->n * idx->ld, idx->ld, idx->d, n_new, xscale, idx->Xh + idx->n * idx->d, idx->device,
+                                idx->mut));
+    MVDB_HIP(hipStreamSynchronize(idx->mut));
+    idx->xh_rows = idx->n + n_new;
+    return 0;
+}
+
 int mvdb_index_add(mvdb_index* idx, const float* x_host, int64_t n, int normalize) {
     if (!idx) return fail(MVDB_ERR_ARG, "index is NULL");
     if (n < 0) return fail(MVDB_ERR_ARG, "negative row count");
@@ -1692,6 +1772,7 @@ int mvdb_index_add(mvdb_index* idx, const float* x_host, int64_t n, int normaliz
     if (normalize) MVDB_TRY(normalize_range(idx, dst, n, idx->mut));
     MVDB_HIP(hipStreamSynchronize(idx->mut));  // the caller's buffer is free again, the rows are in place
     MVDB_TRY(note_row_norms(idx, dst, n, normalize));
+    MVDB_TRY(extend_shadow(idx, n));
     idx->n += n;
     return 0;
 }
@@ -1725,6 +1806,7 @@ int mvdb_index_add_device(mvdb_index* idx, const float* x_dev, int64_t n, int no
     if (normalize) MVDB_TRY(normalize_range(idx, dst, n, idx->mut));
     MVDB_HIP(hipStreamSynchronize(idx->mut));
     MVDB_TRY(note_row_norms(idx, dst, n, normalize));
+    MVDB_TRY(extend_shadow(idx, n));
     idx->n += n;
     return 0;
 }
@@ -1750,6 +1832,7 @@ int mvdb_index_add_synthetic(mvdb_index* idx, int64_t n, uint64_t seed, int64_t 
     if (normalize) MVDB_TRY(normalize_range(idx, dst, n, idx->mut));
     MVDB_HIP(hipStreamSynchronize(idx->mut));
     MVDB_TRY(note_row_norms(idx, dst, n, normalize));
+    MVDB_TRY(extend_shadow(idx, n));
     idx->n += n;
     return 0;
 }
@@ -1790,6 +1873,7 @@ int mvdb_index_remove_rows(mvdb_index* idx, const int64_t* rows_host, int64_t m)
     DeviceGuard dg(idx->device);
     MVDB_TRY(quiesce(idx));
     ++idx->renumbered;
+    drop_shadow(idx);  // rows are renumbered: rebuilt by the next batch search
     const int64_t n_new = idx->n - m;
     if (n_new == 0) {
         idx->n = 0;
