@@ -72,6 +72,14 @@ int64_t mvdb_index_ntotal(const mvdb_index* idx);
 int mvdb_index_dim(const mvdb_index* idx);
 int mvdb_index_device(const mvdb_index* idx);
 
+/* Rows held in the index' fp16 SHADOW (0: none).  An index that answers batches of 33+ queries at d = 256 / 384 / 512 keeps —
+ * lazily, from the first such search on — an fp16 copy of its rows next to the fp32 matrix (2 more bytes per element): the
+ * nomination pass of those batches streams it instead of converting fp32 rows on the fly (half the bytes; the fp32 matrix stays
+ * the home of the exact scans and of every returned score).  add extends it, remove_rows / reset / a re-allocation drop it (the
+ * next batch search rebuilds it: ~5 ms per 10M x 512 rows); an allocation failure simply leaves the fp32 path in charge.
+ * MVDB_DISABLE_HALF_SHADOW=1 switches it off.  No reference counterpart. */
+int64_t mvdb_index_shadow_rows(const mvdb_index* idx);
+
 /* Reserve device capacity for at least n rows in total (amortises repeated add). */
 int mvdb_index_reserve(mvdb_index* idx, int64_t n);
 

@@ -62,6 +62,7 @@ PROTOTYPES = {
     "mvdb_index_reload_env": (ctypes.c_int, [c_vp]),
     "mvdb_index_reset": (ctypes.c_int, [c_vp]),
     "mvdb_index_ntotal": (ctypes.c_int64, [c_vp]),
+    "mvdb_index_shadow_rows": (ctypes.c_int64, [c_vp]),
     "mvdb_index_dim": (ctypes.c_int, [c_vp]),
     "mvdb_index_device": (ctypes.c_int, [c_vp]),
     "mvdb_index_reserve": (ctypes.c_int, [c_vp, ctypes.c_int64]),
@@ -220,6 +221,11 @@ class FlatIndex:
     @property
     def ntotal(self):
         return int(lib().mvdb_index_ntotal(self._h))
+
+    @property
+    def shadow_rows(self):
+        """Rows in the fp16 shadow the batch passes stream (0: none yet / not applicable)."""
+        return int(lib().mvdb_index_shadow_rows(self._h))
 
     def reset(self):
         check(lib().mvdb_index_reset(self._h))

@@ -813,16 +813,16 @@ __global__ __launch_bounds__(WV * 64) void flat_scan_hq_kernel(HalfScanArgs a) {
 // fp16 copy of its rows, Xh[n][d] = fp16(s_x x) (mvdb.hip: shadow; exactly the values the conversion produces, so the
 // certificate and its bound are unchanged; 2 bytes per element on top of the 4 of the fp32 matrix, which stays the home of
 // the exact scans and of the re-scores).  This kernel streams THAT:
-//   * a stage = KS 16-k blocks of a 32-row tile = 32 rows x 32 KS bytes (8 KiB at KS = 8, 16 KiB at 16), DMA'd straight into
+//   * a stage = KS 16-k blocks of a 32-row tile = 32 rows x 32 KS bytes (in use: KS = KT, the whole tile), DMA'd straight into
 //     the image the MFMA fragments are read from: no conversion, no second buffer.  The LDS image of a DMA is lane-linear,
-//     so the bank swizzle (16-byte slot p of row r holds the row's logical slot p ^ (r & 15): conflict-free b128 fragment
-//     reads at 16 or 32 slots per row) is applied to the per-lane SOURCE address;
+//     so the bank swizzle (16-byte slot p of row r holds the row's logical slot p ^ (r & 15), inside aligned groups of 16
+//     slots: conflict-free b128 fragment reads for any multiple of 16 slots per row) is applied to the per-lane SOURCE address;
 //   * NST stages in flight per workgroup (each wave issues its share and waits for its own with a counted vmcnt; one bare
 //     s_barrier per stage), the queries' fragments in registers for the whole launch as in flat_scan_hq_kernel;
 //   * gate, lists, bitmap: flat_scan_hq_kernel's.
 // ALGORITHMIC bytes per launch = rows scanned x d x 2 (the pass's operand is the shadow).  At 256 queries per pass and d = 512
-// the matrix cores (2 x 16 MFMAs per SIMD and stage = 1,024 cycles) and HBM (16 KiB per CU and stage = ~1,200 cycles) are
-// about co-limiting; at 128 queries HBM bounds.
+// the matrix cores bound (2 x 32 MFMAs per SIMD and tile = 2,048 cycles against ~2,400 for the tile's 32 KiB at the HBM
+// rate ... at a clock the chip lowers under this load); at 128 queries HBM bounds.
 template <int KT, int KS, int WV, int NST>
 __global__ __launch_bounds__(WV * 64) void flat_scan_h16_kernel(HalfScanArgs a) {
     constexpr int K = KT * 16;
@@ -831,7 +831,7 @@ __global__ __launch_bounds__(WV * 64) void flat_scan_h16_kernel(HalfScanArgs a) 
     constexpr int kStage = 32 * HSL * 16;    // bytes
     constexpr int NP = kStage / 1024;        // DMA instructions per stage
     constexpr int DPW = NP / WV;             // ... per wave
-    static_assert(KT % KS == 0 && (HSL == 16 || HSL == 32) && NP % WV == 0 && DPW >= 1, "shape");
+    static_assert(KT % KS == 0 && HSL % 16 == 0 && NP % WV == 0 && DPW >= 1, "shape");
     static_assert((NST - 1) * DPW <= 63, "vmcnt is a 6-bit counter");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // NST stages
     __shared__ uint64_t lists[WV * 32 * kHalfKeep];                         // [wave][32 queries][16] keys
@@ -868,14 +868,16 @@ __global__ __launch_bounds__(WV * 64) void flat_scan_h16_kernel(HalfScanArgs a) 
     const int64_t step = gridDim.x;
     int64_t tile = blockIdx.x;
     // stage c of the block's flat sequence = (tile + (c / NSTG) step, K part c % NSTG); tiles past the end are clamped
-    auto issue_stage = [&](int64_t base, int c, int buf) {
+    auto issue_piece = [&](int64_t base, int c, int buf, int i) {
         int64_t t = base + (int64_t)(c / NSTG) * step;
         t = t < ntiles ? t : (base < ntiles ? base : 0);
         const char* sbase = reinterpret_cast<const char*>(a.Xh) + ((a.tile0 + t) * 32 * (int64_t)K + (c % NSTG) * KS * 16) * 2;
         unsigned char* dst = smem + buf * kStage + wave * DPW * 1024;
+        __builtin_amdgcn_global_load_lds((hs_gbl_ptr)(sbase + voff[i]), (hs_lds_ptr)(dst + i * 1024), 16, 0, 2 /* nt */);
+    };
+    auto issue_stage = [&](int64_t base, int c, int buf) {
 #pragma unroll
-        for (int i = 0; i < DPW; ++i)
-            __builtin_amdgcn_global_load_lds((hs_gbl_ptr)(sbase + voff[i]), (hs_lds_ptr)(dst + i * 1024), 16, 0, 2 /* nt */);
+        for (int i = 0; i < DPW; ++i) issue_piece(base, c, buf, i);
     };
     const int frow = fr * HSL * 16;
     const int fsw = fr & 15;
@@ -925,7 +927,8 @@ __global__ __launch_bounds__(WV * 64) void flat_scan_h16_kernel(HalfScanArgs a) 
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * DPW) : "memory");  // this wave's pieces of the stage have landed
             __builtin_amdgcn_s_barrier();  // everybody's have; and every wave is done reading the stage before
             __builtin_amdgcn_sched_barrier(0);
-            issue_stage(tile, sg + NST - 1, buf == 0 ? NST - 1 : buf - 1);  // into the buffer of the stage before
+            const int abuf = buf == 0 ? NST - 1 : buf - 1;  // the look-ahead stage goes into the buffer of the stage before
+            issue_stage(tile, sg + NST - 1, abuf);
             __builtin_amdgcn_sched_barrier(0);
             const unsigned char* src = smem + buf * kStage + frow;
             auto frag = [&](int kb) { return *reinterpret_cast<const hs_h8*>(src + (((2 * kb + fk) ^ fsw) << 4)); };
@@ -996,11 +999,11 @@ int launch_half_shadow(const float* X, int64_t ld, int d, int64_t n, float xscal
 
 bool half_shadow_dim(int d) { return d == 256 || d == 384 || d == 512; }
 
-template <int KT, int KS, int WV, int NST>
+template <int KT, int KS, int WV, int NST, int BPC = 1>
 static int launch_h16_inst(const HalfScanArgs& a, int device, hipStream_t stream, int* nblocks_out) {
     auto kern = flat_scan_h16_kernel<KT, KS, WV, NST>;
     constexpr size_t lds = (size_t)NST * 32 * KS * 2 * 16;
-    static_assert(lds + WV * 32 * kHalfKeep * 8 <= 160 * 1024, "LDS budget of a CU");
+    static_assert(BPC * (lds + WV * 32 * kHalfKeep * 8) <= 160 * 1024, "LDS budget of a CU");
     {
         static std::mutex mu;
         static std::map<int, bool> done;
@@ -1011,7 +1014,7 @@ static int launch_h16_inst(const HalfScanArgs& a, int device, hipStream_t stream
         }
     }
     const int64_t ntiles = a.tile1 - a.tile0;
-    const int nblocks = (int)std::max<int64_t>(1, std::min<int64_t>(ntiles, (int64_t)device_cus(device)));
+    const int nblocks = (int)std::max<int64_t>(1, std::min<int64_t>(ntiles, (int64_t)device_cus(device) * BPC));
     *nblocks_out = nblocks;
     prof_symbol("ip_scan_half", "flat_scan_h16_kernel<%d, %d, %d, %d>", KT, KS, WV, NST);
     int slot = prof_begin("ip_scan_half", stream);
@@ -1021,14 +1024,19 @@ static int launch_h16_inst(const HalfScanArgs& a, int device, hipStream_t stream
     return 0;
 }
 
-// main launches over the shadow: d = 256 / 384 (8-k-block stages, 8 KiB) and 512 (16-k-block stages, 16 KiB)
+// main launches over the shadow.  A stage = a whole 32-row tile (KS = KT: 16 / 24 / 32 KiB at d = 256 / 384 / 512: one barrier
+// per tile).  256 queries per pass: eight waves (two per SIMD), a ring of 3 - 4 tiles.  128 queries per pass: four waves and
+// TWO workgroups per CU — the second workgroup's waves issue MFMAs while the first's sit at their barrier or in the gate —,
+// 2 - 4 tiles per ring.  Sweep at 10M x 512 (profiles/r04_h16_variants.txt): 128 queries 66.5k q/s with one workgroup per CU
+// (KS 16, ring of 6), 72.3k with two (KS 32, ring of 2); 256 queries 89.2k (KS 16, ring of 6) -> 92.1k (KS 32, ring of 3);
+// DMA pieces spread between the MFMAs: +-1 %; 8-KiB stages: -5 %.
 static int launch_h16(int d, int nqpad, const HalfScanArgs& a, int device, hipStream_t stream, int* nb) {
     const bool wide = nqpad == 256;
     if (nqpad != 128 && nqpad != 256) return fail(MVDB_ERR_ARG, "no fp16-shadow kernel for %d queries per pass", nqpad);
     switch (d) {
-        case 256: return wide ? launch_h16_inst<16, 8, 8, 8>(a, device, stream, nb) : launch_h16_inst<16, 8, 4, 8>(a, device, stream, nb);
-        case 384: return wide ? launch_h16_inst<24, 8, 8, 8>(a, device, stream, nb) : launch_h16_inst<24, 8, 4, 8>(a, device, stream, nb);
-        case 512: return wide ? launch_h16_inst<32, 16, 8, 6>(a, device, stream, nb) : launch_h16_inst<32, 16, 4, 6>(a, device, stream, nb);
+        case 256: return wide ? launch_h16_inst<16, 16, 8, 4>(a, device, stream, nb) : launch_h16_inst<16, 16, 4, 4, 2>(a, device, stream, nb);
+        case 384: return wide ? launch_h16_inst<24, 24, 8, 4>(a, device, stream, nb) : launch_h16_inst<24, 24, 4, 2, 2>(a, device, stream, nb);
+        case 512: return wide ? launch_h16_inst<32, 32, 8, 3>(a, device, stream, nb) : launch_h16_inst<32, 32, 4, 2, 2>(a, device, stream, nb);
         default: return fail(MVDB_ERR_ARG, "no fp16-shadow kernel for d = %d", d);
     }
 }

@@ -1657,6 +1657,11 @@ int mvdb_index_reset(mvdb_index* idx) {
 }
 
 int64_t mvdb_index_ntotal(const mvdb_index* idx) { return idx ? idx->n : -1; }
+int64_t mvdb_index_shadow_rows(const mvdb_index* idx) {
+    if (!idx) return -1;
+    std::lock_guard<std::mutex> lk(idx->shadow_mu);
+    return idx->Xh ? idx->xh_rows : 0;
+}
 int mvdb_index_dim(const mvdb_index* idx) { return idx ? idx->d : -1; }
 int mvdb_index_device(const mvdb_index* idx) { return idx ? idx->device : -1; }
 

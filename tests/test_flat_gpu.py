@@ -921,6 +921,53 @@ def test_batch_search_never_syncs_and_is_capturable(native):
     idx.close()
 
 
+def test_fp16_shadow_follows_the_index(native):
+    """Batches of 33+ queries at d = 256 / 384 / 512 nominate from an fp16 SHADOW of the rows (flat_scan_h16_kernel: half the
+    bytes of the fp32 rows, no conversion).  It is built by the first such search, extended by add, dropped by remove_rows and
+    by adds that change the scale (a larger row norm), rebuilt on demand — and every result equals the oracle's and, bit for
+    bit, what the same index returns with the shadow switched off (the nomination arithmetic is the same; the returned scores are
+    fp32 re-scores either way)."""
+    import os
+    for d in (512, 384, 256):
+        n, k, nq = 50000, 10, 130
+        x = _corpus(n + 2000, d)
+        q = _corpus(nq, d, seed=31)
+        idx = native.FlatIndex(d)
+        idx.reserve(n + 4000)
+        idx.add(x[:30000], normalize=True)
+        assert idx.shadow_rows == 0
+        D1, I1 = idx.search(q[:8], k)            # fewer than 33 queries: no shadow
+        assert idx.shadow_rows == 0
+        D, I = idx.search(q, k)
+        assert idx.shadow_rows == 30000
+        _check(native, x[:30000], q, k, D, I)
+        idx.add(x[30000:n], normalize=True)      # fits the reservation: the shadow is extended in place
+        assert idx.shadow_rows == n
+        D, I = idx.search(q, k)
+        _check(native, x[:n], q, k, D, I)
+        os.environ["MVDB_DISABLE_HALF_SHADOW"] = "1"
+        idx.reload_env()
+        try:
+            D0, I0 = idx.search(q, k)
+        finally:
+            del os.environ["MVDB_DISABLE_HALF_SHADOW"]
+            idx.reload_env()
+        assert np.array_equal(I0, I) and np.array_equal(D0, D)
+        idx.remove_rows(np.array([5, 40000], np.int64))
+        assert idx.shadow_rows == 0
+        cur = np.delete(x[:n], [5, 40000], 0)
+        D, I = idx.search(q, k)
+        assert idx.shadow_rows == n - 2
+        _check(native, cur, q, k, D, I)
+        idx.add(x[n:n + 2000] * np.float32(3.0))   # raw rows of norm 3: the scale of the fp16 image changes -> rebuilt
+        assert idx.shadow_rows == 0
+        cur = np.concatenate([cur, x[n:n + 2000] * np.float32(3.0)])
+        D, I = idx.search(q, k)
+        assert idx.shadow_rows == cur.shape[0]
+        _check(native, cur, q, k, D, I)
+        idx.close()
+
+
 def test_captured_search_survives_a_larger_eager_call_on_its_stream(native):
     """A captured search names its stream's workspace buffers.  A later, LARGER eager call on the same stream must not free
     them (it allocates new ones and parks the old): replaying the earlier graph still answers correctly."""
