@@ -68,7 +68,7 @@ struct Knobs {
     int mfma_ng2 = -1;               // MVDB_MFMA_NG2 (-1: on for the staged kernel, off otherwise)
     int gemm_scan_min_nq = 104;      // MVDB_GEMM_SCAN_MIN_NQ
     int gemm_scan_blocks_per_cu = 2; // MVDB_GEMM_SCAN_BLOCKS_PER_CU
-    int split_scan_min_nq = 33;      // MVDB_SPLIT_SCAN_MIN_NQ
+    int split_scan_min_nq = -1;      // MVDB_SPLIT_SCAN_MIN_NQ (-1: by corpus size and operand, mvdb.hip half_min_nq; else the value)
     int split32_min_nq = 14;         // MVDB_SPLIT32_MIN_NQ
     int split32_blocks_per_cu = 2;   // MVDB_SPLIT32_BLOCKS_PER_CU
     int split_phase_growth = 8;      // MVDB_SPLIT_PHASE_GROWTH

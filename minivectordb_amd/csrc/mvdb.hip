@@ -46,7 +46,7 @@ Knobs read_knobs() {
     k.mfma_ng2 = env_int("MVDB_MFMA_NG2", -1);
     k.gemm_scan_min_nq = env_int("MVDB_GEMM_SCAN_MIN_NQ", 104);
     k.gemm_scan_blocks_per_cu = env_int("MVDB_GEMM_SCAN_BLOCKS_PER_CU", 2);
-    k.split_scan_min_nq = env_int("MVDB_SPLIT_SCAN_MIN_NQ", 33);
+    k.split_scan_min_nq = env_int("MVDB_SPLIT_SCAN_MIN_NQ", -1);
     k.split32_min_nq = env_int("MVDB_SPLIT32_MIN_NQ", 14);
     k.split32_blocks_per_cu = env_int("MVDB_SPLIT32_BLOCKS_PER_CU", 2);
     k.split_phase_growth = env_int("MVDB_SPLIT_PHASE_GROWTH", 8);
@@ -724,11 +724,27 @@ bool l2_cert_ok(const mvdb_index* idx) {
            idx->norm2_hi - idx->norm2_lo <= idx->norm2_hi * (1.0f / 1024.0f) && !idx->kn.disable_l2_cert;
 }
 
-bool split_path_ok(const mvdb_index* idx, int nq, int k, const int64_t* rows_dev) {
+// Fewest queries of a call that go to the certified passes.  Where the fp16 nomination pass streams the SHADOW of the rows
+// (d = 256 / 384 / 512), one pass over n rows costs about what 0.55 n rows cost the exact scans, whatever the number of
+// queries up to 128 — it beats the fp32-MFMA pass from TWO queries on once the corpus is big enough to bury its fixed cost
+// (seed launch, phase merges, certification: ~0.1 ms).  Measured, device time per call, default / certified
+// (profiles/r04_small_batch_crossover.jsonl): 10M x 512: 2 queries 2.93 / 1.61 ms, 32 queries 3.06 / 1.63; 1M rows: 2 queries
+// 0.33 / 0.26, 13 queries 0.44 / 0.27; 100k rows: 2 queries 0.068 / 0.114, 8 queries 0.123 / 0.122, 13 queries 0.170 / 0.126.
+// Elsewhere: 33 (and the bf16-split pass from 14).  MVDB_SPLIT_SCAN_MIN_NQ overrides.
+int half_min_nq(const mvdb_index* idx, int64_t n) {
+    if (idx->kn.split_scan_min_nq >= 0) return idx->kn.split_scan_min_nq;
+    if (half_shadow_dim(idx->d) && idx->ld == idx->d && !idx->kn.disable_half_shadow && !idx->xh_failed) {
+        if (n >= 500000) return 2;
+        if (n >= 100000) return 8;
+    }
+    return 33;
+}
+
+bool split_path_ok(const mvdb_index* idx, int nq, int k, const int64_t* rows_dev, int64_t n) {
     if (idx->kn.disable_split_scan) return false;
     if (nq < 2 || rows_dev || (idx->metric != MVDB_METRIC_IP && !l2_cert_ok(idx))) return false;
     // (k > 16 also needs the gated fp32-MFMA pass for the exact re-runs: the GEMM-tiled scan keeps 16 results per query)
-    if (k > kSplitMaxK && !(k <= kHalfMaxK && nq >= idx->kn.split_scan_min_nq && half_path_ok(idx) &&
+    if (k > kSplitMaxK && !(k <= kHalfMaxK && nq >= half_min_nq(idx, n) && half_path_ok(idx) &&
                             (k <= kGemmScanMaxK || mfma_gated_queries(idx) > 0)))
         return false;
     // rows of known, sane norm only: the bound scales with max|x|, and bf16 keeps fp32's exponent range only up
@@ -1054,7 +1070,7 @@ int search_core(const mvdb_index* idx, Workspace* ws, const float* q_dev, int nq
                               mfma_gated_queries(idx) > 0 && !idx->kn.disable_masked_batch;
     if (mask_dev) {
         rows_dev = nullptr;
-        if (!masked_batch || !half_path_ok(idx) || nq < idx->kn.split_scan_min_nq) allow_split = false;
+        if (!masked_batch || !half_path_ok(idx) || nq < half_min_nq(idx, n)) allow_split = false;
     }
     // the other multi-query passes take neither a row list nor a bitmap
     const int64_t* restricted = mask_dev ? reinterpret_cast<const int64_t*>(mask_dev) : rows_dev;
@@ -1081,7 +1097,7 @@ int search_core(const mvdb_index* idx, Workspace* ws, const float* q_dev, int nq
     // Batches of >= 33 queries (past one 32-query fp32 pass), k <= 12, rows of known norm: split-precision pass on the bf16 matrix cores
     // (scan_split_kernels.hpp), 128 queries per corpus pass, every result certified against exact fp32
     // re-scores; chunks holding an uncertified query are re-run on the exact paths below.
-    if (allow_split && split_path_ok(idx, nq, k, rows_dev)) {
+    if (allow_split && split_path_ok(idx, nq, k, rows_dev, n)) {
         const float* qsrc = q_dev;
         if (normalize_q) {
             MVDB_TRY(ws->qn.reserve((size_t)nq * idx->ld));
@@ -1093,9 +1109,9 @@ int search_core(const mvdb_index* idx, Workspace* ws, const float* q_dev, int nq
         // chunk plan: 128 queries per pass while >= 33 remain, then one 14..32-query pass where that kernel exists
         // (below ~14 queries the fp32 pass, whose cost grows with the query count, is faster than the fixed seed +
         // certification overhead: measured crossover 11 queries at 100k rows, 14 at 10M)
-        const int min_nq = idx->kn.split_scan_min_nq;
-        // where the fp16 single-product pass has a kernel (half_scan.hip) it serves the >= 33-query chunks
+        // where the fp16 single-product pass has a kernel (half_scan.hip) it serves the chunks of min_nq queries and more
         const bool use_half = half_path_ok(idx);
+        const int min_nq = use_half ? half_min_nq(idx, n) : (idx->kn.split_scan_min_nq >= 0 ? idx->kn.split_scan_min_nq : 33);
         const int chunk = use_half ? half_max_queries(idx->d) : 128;
         std::vector<std::pair<int, int>> plan;  // (first query, count)
         int q0 = 0;
