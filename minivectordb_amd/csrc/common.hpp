@@ -81,6 +81,7 @@ struct Knobs {
          disable_split32 = false, disable_half_scan = false, disable_masked_batch = false,
          disable_l2_cert = false,    // MVDB_DISABLE_* (L2_CERT: L2 batches back on the exact fp32 kernels)
          disable_half_shadow = false;  // MVDB_DISABLE_HALF_SHADOW: the fp16 nomination pass converts the fp32 rows on the fly again
+    bool shadow_single_query = false;  // MVDB_SHADOW_SINGLE_QUERY (1: single queries through the certified fp16-shadow pass too)
     bool hq_pipe = true;             // MVDB_HQ_PIPE (0: refill and conversion behind the MFMAs)
     bool half_ksplit = false;        // MVDB_HALF_KSPLIT
     bool half_small_stages = false;  // MVDB_HALF_SMALL_STAGES
