@@ -997,7 +997,9 @@ int launch_half_shadow(const float* X, int64_t ld, int d, int64_t n, float xscal
     return 0;
 }
 
-bool half_shadow_dim(int d) { return d == 256 || d == 384 || d == 512; }
+// d <= 512: 128 and 256 queries per pass; d = 640 .. 1024 (e5-large / bge-m3 widths): 128 queries per pass, one wave per SIMD
+// (160 - 256 registers of query fragments)
+bool half_shadow_dim(int d) { return d == 256 || d == 384 || d == 512 || d == 640 || d == 768 || d == 896 || d == 1024; }
 
 template <int KT, int KS, int WV, int NST, int BPC = 1>
 static int launch_h16_inst(const HalfScanArgs& a, int device, hipStream_t stream, int* nblocks_out) {
@@ -1037,8 +1039,13 @@ static int launch_h16(int d, int nqpad, const HalfScanArgs& a, int device, hipSt
         case 256: return wide ? launch_h16_inst<16, 16, 8, 4>(a, device, stream, nb) : launch_h16_inst<16, 16, 4, 4, 2>(a, device, stream, nb);
         case 384: return wide ? launch_h16_inst<24, 24, 8, 4>(a, device, stream, nb) : launch_h16_inst<24, 24, 4, 2, 2>(a, device, stream, nb);
         case 512: return wide ? launch_h16_inst<32, 32, 8, 3>(a, device, stream, nb) : launch_h16_inst<32, 32, 4, 2, 2>(a, device, stream, nb);
-        default: return fail(MVDB_ERR_ARG, "no fp16-shadow kernel for d = %d", d);
+        case 640: if (!wide) return launch_h16_inst<40, 40, 4, 3>(a, device, stream, nb); break;
+        case 768: if (!wide) return launch_h16_inst<48, 48, 4, 3>(a, device, stream, nb); break;
+        case 896: if (!wide) return launch_h16_inst<56, 56, 4, 2>(a, device, stream, nb); break;
+        case 1024: if (!wide) return launch_h16_inst<64, 64, 4, 2>(a, device, stream, nb); break;
+        default: break;
     }
+    return fail(MVDB_ERR_ARG, "no fp16-shadow kernel for %d queries per pass at d = %d", nqpad, d);
 }
 
 // ---- certification ------------------------------------------------------------------------------------------------
