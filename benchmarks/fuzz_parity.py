@@ -3,7 +3,10 @@ each query adjudicated against the float64 oracle.  usage: fuzz_parity.py SEED S
 `split` biases the cases towards the certified batch passes (nq >= 40, k <= 32, d % 32 == 0, up to 400k rows so
 that the seed launch runs too) and reports how many chunks fell back to the exact kernels; `masked` is `split` under a
 random BITMAP (density 0.02 .. 0.99, any nq >= 2: the fp16 pass, the fp32-MFMA pass and the one-query scan all take it),
-half of the cases through a resident row set."""
+half of the cases through a resident row set; `shadow` (round 4) is `split` over LARGER corpora (100k - 620k rows, d in
+{256, 384, 512, 768, 1024}) with small and large batches (2 .. 300 queries) and both metrics over normalised rows: the
+fp16-shadow nomination pass from 2 / 8 queries on, the L2 certificate, the device-gated L2 re-run; only queries whose ids or
+distances differ from the multi-threaded fp32 oracle are adjudicated in float64."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -13,7 +16,8 @@ rs = np.random.RandomState(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 dims = [1,2,3,4,5,7,8,16,31,32,33,48,64,96,100,128,160,192,224,256,300,384,512,640,768,1000,1024,1100,2048,4096]
 t_end = time.time() + float(sys.argv[2]) if len(sys.argv) > 2 else time.time() + 120
 masked_mode = len(sys.argv) > 3 and sys.argv[3] == "masked"
-split_mode = masked_mode or (len(sys.argv) > 3 and sys.argv[3] == "split")
+shadow_mode = len(sys.argv) > 3 and sys.argv[3] == "shadow"
+split_mode = masked_mode or shadow_mode or (len(sys.argv) > 3 and sys.argv[3] == "split")
 cases = fails = 0
 reruns0 = native.split_rerun_count()
 while time.time() < t_end:
@@ -29,9 +33,14 @@ while time.time() < t_end:
         k = int(rs.randint(1, 33))
         metric = 0
         if masked_mode: nq = int(rs.choice([2, 8, 31, 32, 33, nq, nq]))
-    if n * d > 30_000_000: n = 30_000_000 // d
+        if shadow_mode:
+            d = int(rs.choice([256, 384, 512, 512, 768, 1024]))
+            n = int(rs.choice([rs.randint(100_000, 130_000), rs.randint(500_000, 620_000), rs.randint(20_000, 60_000)]))
+            nq = int(rs.choice([2, 3, 8, 9, 13, 14, 24, 32, 33, 100, 128, 129, 256, rs.randint(2, 300)]))
+            metric = int(rs.choice([0, 0, 1]))
+    if n * d > (330_000_000 if shadow_mode else 30_000_000): n = (330_000_000 if shadow_mode else 30_000_000) // d
     x = flat.synth(n, d, rs.randint(1<<30)); 
-    if rs.rand() < 0.7: flat.normalize_l2(x)
+    if shadow_mode or rs.rand() < 0.7: flat.normalize_l2(x)
     if rs.rand() < 0.2 and n > 4: x[rs.randint(n)] = x[rs.randint(n)]   # duplicate row -> exact tie
     q = flat.synth(nq, d, rs.randint(1<<30))
     normq = bool(rs.rand() < 0.5)
@@ -57,10 +66,12 @@ while time.time() < t_end:
         D, I = idx.search(q, k, normalize_q=normq)
     qq = q.copy()
     if normq: flat.normalize_l2(qq)
-    Do, Io = flat.flat_search(x, qq, k, metric=metric, rows=subset)
+    Do, Io = flat.flat_search(x, qq, k, metric=metric, rows=subset, nthreads=flat.max_threads() if shadow_mode else 1)
     cases += 1
     bad = None
     for i in range(nq):
+        if shadow_mode and np.array_equal(I[i], Io[i]) and np.abs(D[i] - Do[i]).max() <= 2e-6:
+            continue   # id for id the fp32 oracle's answer: nothing for float64 to adjudicate
         # un-normalised data: tolerances scale with the magnitude of the scores (an fp32 ulp at 90 is 7.6e-6)
         mag = max(1.0, float(np.abs(Do[i][Io[i]>=0]).max()) if (Io[i]>=0).any() else 1.0)
         ok, msg = flat.adjudicate(x, qq[i], k, D[i], I[i], metric=metric, rows=subset, tol=1e-4 * mag, tie_eps=2e-6 * mag)
