@@ -1,7 +1,7 @@
 # Collects the round's evidence on the GPU box into gpurun_out/<tag>/ (copied into profiles/ afterwards):
 # bench lines, rocprofv3 kernel traces and separate PMC passes (FETCH_SIZE / WRITE_SIZE / MFMA busy) per batch size.
 # usage: bash benchmarks/collect_profiles.sh <tag>
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
@@ -14,13 +14,20 @@ python3 $R/bench.py --nq 128 --dim 384 --steps 60 --warmup 10 --no-cpu-baseline 
 python3 $R/bench.py --nq 256 --dim 384 --steps 60 --warmup 10 --no-cpu-baseline > $OUT/${TAG}_bench_nq256_d384.json 2>> $OUT/bench.err
 python3 $R/bench.py --nq 128 --k 32 --steps 60 --warmup 10 --no-cpu-baseline > $OUT/${TAG}_bench_nq128_k32.json 2>> $OUT/bench.err
 python3 $R/bench.py --nq 128 --dim 640 --rows 8000000 --steps 60 --warmup 10 --no-cpu-baseline > $OUT/${TAG}_bench_nq128_d640.json 2>> $OUT/bench.err
+python3 $R/bench.py --nq 128 --dim 768 --rows 5000000 --steps 60 --warmup 10 --no-cpu-baseline --no-encoder > $OUT/${TAG}_bench_nq128_d768.json 2>> $OUT/bench.err
+python3 $R/bench.py --nq 128 --dim 1024 --rows 5000000 --steps 60 --warmup 10 --no-cpu-baseline --no-encoder > $OUT/${TAG}_bench_nq128_d1024.json 2>> $OUT/bench.err
+python3 $R/bench.py --nq 8 --steps 100 --warmup 10 --no-cpu-baseline --no-encoder > $OUT/${TAG}_bench_nq8.json 2>> $OUT/bench.err
+# the same batches on the fp32 rows (round 3's kernels): A/B on this box
+for nq in 8 32 128 256; do
+  MVDB_DISABLE_HALF_SHADOW=1 python3 $R/bench.py --nq $nq --steps 60 --warmup 10 --no-cpu-baseline --no-encoder > $OUT/${TAG}_bench_nq${nq}_no_shadow.json 2>> $OUT/bench.err
+done
 python3 $R/bench.py --rows 1000000 --steps 500 --warmup 50 --no-cpu-baseline --no-encoder > $OUT/${TAG}_config2_1M.json 2>> $OUT/bench.err
 for nq in 1 32 128 256; do
   steps=60; [ $nq = 1 ] && steps=200
   rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/tr_$nq -- python3 $R/bench.py --nq $nq --steps $steps --warmup 10 --no-cpu-baseline --no-encoder > $OUT/${TAG}_final_nq${nq}_bench_under_rocprof.json 2>/dev/null
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/fe_$nq -- python3 $R/bench.py --nq $nq --steps 20 --warmup 5 --no-cpu-baseline --no-encoder > /dev/null 2>&1
   rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/wr_$nq -- python3 $R/bench.py --nq $nq --steps 20 --warmup 5 --no-cpu-baseline --no-encoder > /dev/null 2>&1
-  (cd $R/profiles && python3 summarize_pmc.py ${TAG}_final_nq$nq /tmp/tr_$nq /tmp/fe_$nq /tmp/wr_$nq) > $OUT/summarize_nq$nq.log 2>&1
+  (cd $R/profiles && python3 summarize_pmc.py ${TAG}_final_nq$nq /tmp/tr_$nq /tmp/fe_$nq /tmp/wr_$nq $MVDB_GIT_HEAD) > $OUT/summarize_nq$nq.log 2>&1
   mv $R/profiles/${TAG}_final_nq${nq}_kernel_stats.csv $R/profiles/${TAG}_final_nq${nq}_pmc_summary.json $OUT/ 2>/dev/null
 done
 for nq in 128 256; do
@@ -41,6 +48,7 @@ cp $OUT/enc_pmc/pmc_summary.txt $OUT/${TAG}_encoder_s32_pmc.txt
 python3 $R/benchmarks/scale_check.py > $OUT/${TAG}_scale_check_80M.json 2>> $OUT/bench.err
 python3 $R/benchmarks/bench_dropin.py > $OUT/${TAG}_dropin_1M.json 2>> $OUT/bench.err
 python3 $R/benchmarks/bench_variants.py > $OUT/${TAG}_secondary_paths.jsonl 2>> $OUT/bench.err
+python3 $R/benchmarks/small_batch_probe.py > $OUT/${TAG}_small_batch_routing.jsonl 2>> $OUT/bench.err
 python3 $R/benchmarks/bench_subset.py > $OUT/${TAG}_subset_device_side.jsonl 2>> $OUT/bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/subs -- python3 $R/benchmarks/bench_subset.py > /dev/null 2>&1
 cp $(find /tmp/subs -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_subset_kernel_stats.csv

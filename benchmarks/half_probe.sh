@@ -14,15 +14,17 @@ run() { # label, env..., -- bench args
 run "d512 nq128" X=1 -- --nq 128 --steps 20 --warmup 3
 
 run "d512 nq256" X=1 -- --nq 256 --steps 20 --warmup 3
+run "d512 nq128 on the fp32 rows" MVDB_DISABLE_HALF_SHADOW=1 -- --nq 128 --steps 20 --warmup 3
+run "d512 nq256 on the fp32 rows" MVDB_DISABLE_HALF_SHADOW=1 -- --nq 256 --steps 20 --warmup 3
 run "d512 nq64" X=1 -- --nq 64 --steps 20 --warmup 3
 run "d384 nq128" X=1 -- --nq 128 --dim 384 --steps 20 --warmup 3
 run "d384 nq256" X=1 -- --nq 256 --dim 384 --steps 20 --warmup 3
-run "d384 nq256 old" MVDB_DISABLE_HALF_SCAN=1 -- --nq 256 --dim 384 --steps 20 --warmup 3
+run "d384 nq256 on the fp32 rows" MVDB_DISABLE_HALF_SHADOW=1 -- --nq 256 --dim 384 --steps 20 --warmup 3
 run "d256 nq256" X=1 -- --nq 256 --dim 256 --steps 20 --warmup 3
 run "d1024 nq128" X=1 -- --nq 128 --dim 1024 --rows 5000000 --steps 20 --warmup 3
-run "d1024 nq128 old" MVDB_DISABLE_HALF_SCAN=1 -- --nq 128 --dim 1024 --rows 5000000 --steps 20 --warmup 3
+run "d1024 nq128 on the fp32 rows" MVDB_DISABLE_HALF_SHADOW=1 -- --nq 128 --dim 1024 --rows 5000000 --steps 20 --warmup 3
 run "d768 nq128" X=1 -- --nq 128 --dim 768 --rows 5000000 --steps 20 --warmup 3
-run "d768 nq128 old" MVDB_DISABLE_HALF_SCAN=1 -- --nq 128 --dim 768 --rows 5000000 --steps 20 --warmup 3
+run "d768 nq128 on the fp32 rows" MVDB_DISABLE_HALF_SHADOW=1 -- --nq 128 --dim 768 --rows 5000000 --steps 20 --warmup 3
 python - <<'PY'
 import json
 for l in open("gpurun_out/half_probe.jsonl"):
