@@ -8,6 +8,10 @@ half of the cases through a resident row set; `shadow` (round 4) is `split` over
 fp16-shadow nomination pass from 2 / 8 queries on, the L2 certificate, the device-gated L2 re-run; only queries whose ids or
 distances differ from the multi-threaded fp32 oracle are adjudicated in float64."""
 import os, sys, time
+# the float64 adjudication is thousands of SMALL numpy / OpenMP products: with one thread per core of a 256-thread host each
+# costs ~0.1 s (tests/conftest.py has the same bound); the big fp32 oracle scans below name their thread count explicitly
+for _v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+    os.environ.setdefault(_v, "8")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from oracle import flat
@@ -66,7 +70,7 @@ while time.time() < t_end:
         D, I = idx.search(q, k, normalize_q=normq)
     qq = q.copy()
     if normq: flat.normalize_l2(qq)
-    Do, Io = flat.flat_search(x, qq, k, metric=metric, rows=subset, nthreads=flat.max_threads() if shadow_mode else 1)
+    Do, Io = flat.flat_search(x, qq, k, metric=metric, rows=subset, nthreads=min(64, os.cpu_count() or 8) if shadow_mode else 1)
     cases += 1
     bad = None
     for i in range(nq):
