@@ -75,3 +75,17 @@ def test_row_store_matches_numpy_model():
             np.testing.assert_allclose(got, model_raw[r], atol=1e-6)
             got[:] = 123.0                     # a copy: the store must not change under the caller's edit
             np.testing.assert_allclose(st.row(r, idx), model_raw[r], atol=1e-6)
+
+
+def test_pack_row_mask_takes_lists_sets_and_arrays():
+    """`excluded=np.ndarray` used to die on `if excluded:`; an empty array must mean "exclude nothing"."""
+    from minivectordb_amd._native import pack_row_mask
+    full = pack_row_mask(70)
+    assert full.dtype == np.uint64 and full.shape == (2,) and int(full[0]) == 2 ** 64 - 1 and int(full[1]) == 2 ** 6 - 1
+    for excluded in ([1, 65], {1, 65}, np.array([1, 65]), np.array([65, 1], dtype=np.int32)):
+        m = pack_row_mask(70, excluded=excluded)
+        assert int(m[0]) == 2 ** 64 - 1 - 2 and int(m[1]) == 2 ** 6 - 1 - 2
+    assert np.array_equal(pack_row_mask(70, excluded=np.array([], dtype=np.int64)), full)
+    assert np.array_equal(pack_row_mask(70, excluded=[]), full)
+    m = pack_row_mask(70, rows=np.array([0, 64, 69]))
+    assert int(m[0]) == 1 and int(m[1]) == 1 + 2 ** 5
