@@ -376,8 +376,8 @@ int launch_scan_kern(const ScanArgs& a, int nq, int device, hipStream_t stream, 
     int nblocks = (int)std::max<int64_t>(1, std::min(want, cap));
     if (nblocks_out) *nblocks_out = nblocks;
     const char* pname = MODE == kModeTopK ? "ip_scan" : "ip_scan_scores";
-    prof_symbol(pname, "flat_scan_kernel<%d, %d, %d, %d, %d, %s, %d, %s>", G, C, U, METRIC, MODE, NT ? "true" : "false", SEL,
-                MASKED ? "true" : "false");
+    prof_symbol(pname, "flat_scan_kernel<%d, %d, %d, %d, %d, %s, %d, %s, %s>", G, C, U, METRIC, MODE, NT ? "true" : "false", SEL,
+                MASKED ? "true" : "false", a.gate ? "true" : "false");
     int slot = prof_begin(pname, stream);
     hipLaunchKernelGGL(kern, dim3(nblocks, nq), dim3(kScanThreads), 0, stream, a);
     prof_end(slot, stream);
