@@ -106,7 +106,9 @@ int mvdb_index_add_synthetic(mvdb_index* idx, int64_t n, uint64_t seed, int64_t 
 int mvdb_index_get_rows(const mvdb_index* idx, int64_t row0, int64_t n, float* out_host);
 
 /* Remove the given rows (ascending or not, duplicates rejected) and compact the matrix so the
- * remaining rows keep their relative order — the numbering np.delete leaves behind
+ * remaining rows keep their relative order — the numbering np.delete leaves behind.  Rows before
+ * the first deleted one do not move; the tail is compacted in place through a bounded staging
+ * buffer (512 MiB, kept by the index), so the call needs no memory proportional to the index.
  *                                                minivectordb/vector_database.py:126, :139-152 */
 int mvdb_index_remove_rows(mvdb_index* idx, const int64_t* rows_host, int64_t m);
 

@@ -86,6 +86,7 @@ struct Knobs {
     bool half_ksplit = false;        // MVDB_HALF_KSPLIT
     bool half_small_stages = false;  // MVDB_HALF_SMALL_STAGES
     bool hq_w4 = false;              // MVDB_HQ_W4
+    long long compact_bytes = 512ll << 20;  // MVDB_COMPACT_BYTES: staging buffer of a row compaction (mvdb_index_remove_rows)
 };
 Knobs read_knobs();
 

@@ -72,6 +72,8 @@ Knobs read_knobs() {
     k.half_ksplit = getenv("MVDB_HALF_KSPLIT") != nullptr;
     k.half_small_stages = getenv("MVDB_HALF_SMALL_STAGES") != nullptr;
     k.hq_w4 = getenv("MVDB_HQ_W4") != nullptr;
+    if (const char* v = getenv("MVDB_COMPACT_BYTES"))
+        if (*v) k.compact_bytes = std::max(1ll, atoll(v));
     return k;
 }
 
@@ -257,6 +259,8 @@ struct mvdb_index {
     hipStream_t mut = nullptr;   // the mutators' own non-blocking stream: add / remove_rows never touch the legacy stream,
                                  // so work other libraries have in flight on the device (an encoder forward) is not stalled
     unsigned int* normmax = nullptr;  // 4-byte scratch of note_row_norms (raw adds)
+    float* ctmp = nullptr;            // bounded staging buffer of mvdb_index_remove_rows (kept once a delete has run)
+    size_t ctmp_bytes = 0;
     // fp16 shadow of the rows (half_scan.hip: flat_scan_h16_kernel): built by the first batch search that can use it, extended
     // by add, dropped by whatever renumbers rows or changes the scale.  Searches (shared lock) build / read it under
     // shadow_mu; mutators (exclusive lock, searches quiesced) edit it directly.
@@ -1643,6 +1647,7 @@ int mvdb_index_free(mvdb_index* idx) {
         (void)quiesce(idx);
         if (idx->mut) (void)hipStreamDestroy(idx->mut);
         if (idx->normmax) (void)hipFree(idx->normmax);
+        if (idx->ctmp) (void)hipFree(idx->ctmp);
         drop_shadow(idx);
         for (Workspace* w : idx->free_ws) {
             w->destroy();
@@ -1904,43 +1909,45 @@ int mvdb_index_remove_rows(mvdb_index* idx, const int64_t* rows_host, int64_t m)
         idx->n = 0;
         return 0;
     }
-    // rows before the first deleted one do not move: compact only the tail [first, n)
+    // rows before the first deleted one do not move: compact only the tail [first, n).  Every kept row moves UP, so the
+    // tail is compacted in place, in ascending chunks through a bounded staging buffer (512 MiB, MVDB_COMPACT_BYTES; kept by the index):
+    // chunk c gathers the sources of the new rows [r0, r0 + rows) — all at or above r0 + 1 — into the buffer, then copies
+    // the buffer over [r0, r0 + rows); stream order makes the next chunk's sources (all >= r0 + rows) untouched by that
+    // copy.  (Until round 4 the whole tail went through a temporary of its own size: one early delete in a 164 GB index
+    // needed another 164 GB.)  The source row of a new row is found by binary search in the sorted list of deleted rows.
     const int64_t first = del[0];
     const int64_t tail_new = n_new - first;
     if (tail_new > 0) {
-        int64_t *del_dev = nullptr, *map_dev = nullptr;
-        float* tmp = nullptr;
-        // stream-ordered temporaries: hipFree would synchronise the whole device
-        MVDB_HIP(hipMallocAsync((void**)&del_dev, (size_t)m * sizeof(int64_t), idx->mut));
-        hipError_t e1 = hipMallocAsync((void**)&map_dev, (size_t)tail_new * sizeof(int64_t), idx->mut);
-        hipError_t e2 = hipMallocAsync((void**)&tmp, (size_t)tail_new * idx->ld * sizeof(float), idx->mut);
-        int rc = 0;
-        if (e1 != hipSuccess || e2 != hipSuccess) {
-            rc = fail(MVDB_ERR_OOM, "device allocation for row compaction failed");
-        } else {
-            for (auto& v : del) v -= first;  // positions relative to the tail
-            hipError_t e = hipMemcpyAsync(del_dev, del.data(), (size_t)m * sizeof(int64_t),
-                                          hipMemcpyHostToDevice, idx->mut);
-            if (e == hipSuccess) {
-                hipLaunchKernelGGL(build_keep_map_kernel, dim3((unsigned)((tail_new + 255) / 256)),
-                                   dim3(256), 0, idx->mut, del_dev, m, tail_new, map_dev);
-                const int64_t total = tail_new * idx->d4;
-                const int grid = (int)std::max<int64_t>(
-                    1, std::min<int64_t>((total + 255) / 256, (int64_t)device_cus(idx->device) * 16));
-                float* tail = idx->X + first * idx->ld;
-                hipLaunchKernelGGL(gather_rows_kernel, dim3(grid), dim3(256), 0, idx->mut, tmp, tail,
-                                   map_dev, tail_new, idx->ld);
-                e = hipMemcpyAsync(tail, tmp, (size_t)tail_new * idx->ld * sizeof(float),
-                                   hipMemcpyDeviceToDevice, idx->mut);
-                if (e == hipSuccess) e = hipStreamSynchronize(idx->mut);
+        const size_t row_bytes = (size_t)idx->ld * sizeof(float);
+        const size_t want = std::min<size_t>((size_t)tail_new * row_bytes, std::max<size_t>((size_t)idx->kn.compact_bytes, row_bytes));
+        if (idx->ctmp_bytes < want) {
+            if (idx->ctmp) (void)hipFree(idx->ctmp);
+            idx->ctmp = nullptr;
+            idx->ctmp_bytes = 0;
+            if (hipMalloc((void**)&idx->ctmp, want) != hipSuccess) {
+                (void)hipGetLastError();
+                return fail(MVDB_ERR_OOM, "device allocation for row compaction failed (%zu bytes)", want);
             }
-            if (e != hipSuccess) rc = fail(MVDB_ERR_HIP, "row compaction failed: %s", hipGetErrorString(e));
+            idx->ctmp_bytes = want;
         }
-        if (del_dev) (void)hipFreeAsync(del_dev, idx->mut);
-        if (map_dev) (void)hipFreeAsync(map_dev, idx->mut);
-        if (tmp) (void)hipFreeAsync(tmp, idx->mut);
-        (void)hipStreamSynchronize(idx->mut);  // (the pool returns the memory to the device at this point)
-        if (rc) return rc;
+        const int64_t chunk_rows = (int64_t)(idx->ctmp_bytes / row_bytes);
+        int64_t* del_dev = nullptr;
+        MVDB_HIP(hipMallocAsync((void**)&del_dev, (size_t)m * sizeof(int64_t), idx->mut));  // stream-ordered: hipFree would synchronise the device
+        for (auto& v : del) v -= first;  // positions relative to the tail
+        hipError_t e = hipMemcpyAsync(del_dev, del.data(), (size_t)m * sizeof(int64_t), hipMemcpyHostToDevice, idx->mut);
+        float* tail = idx->X + first * idx->ld;
+        for (int64_t r0 = 0; r0 < tail_new && e == hipSuccess; r0 += chunk_rows) {
+            const int64_t rows = std::min(chunk_rows, tail_new - r0);
+            const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((rows + 3) / 4, (int64_t)device_cus(idx->device) * 16));
+            hipLaunchKernelGGL(gather_kept_rows_kernel, dim3(grid), dim3(256), 0, idx->mut, idx->ctmp, tail, del_dev, m, r0, rows,
+                               idx->ld);
+            e = hipMemcpyAsync(tail + r0 * idx->ld, idx->ctmp, (size_t)rows * row_bytes, hipMemcpyDeviceToDevice, idx->mut);
+        }
+        (void)hipFreeAsync(del_dev, idx->mut);
+        if (e == hipSuccess) e = hipGetLastError();
+        const hipError_t es = hipStreamSynchronize(idx->mut);
+        if (e == hipSuccess) e = es;
+        if (e != hipSuccess) return fail(MVDB_ERR_HIP, "row compaction failed: %s", hipGetErrorString(e));
     }
     idx->n = n_new;
     return 0;

@@ -129,22 +129,6 @@ __global__ __launch_bounds__(256) void synth_fill_kernel(float* __restrict__ X, 
     }
 }
 
-// dst[r, :] = src[map[r], :]  (row compaction after deletes; 16-B chunks)
-__global__ __launch_bounds__(256) void gather_rows_kernel(float* __restrict__ dst,
-                                                          const float* __restrict__ src,
-                                                          const int64_t* __restrict__ map,
-                                                          int64_t n, int64_t ld) {
-    const int64_t d4 = ld / 4;
-    const int64_t total = n * d4;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-         i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t r = i / d4;
-        const int64_t c = i - r * d4;
-        *reinterpret_cast<f32x4u*>(dst + r * ld + c * 4) =
-            *reinterpret_cast<const f32x4u*>(src + map[r] * ld + c * 4);
-    }
-}
-
 // results of a compact re-run back into the rows of the queries they belong to: D[map[r], :] = Dt[r, :] (same for I)
 __global__ __launch_bounds__(256) void scatter_results_kernel(const float* __restrict__ Dt, const int64_t* __restrict__ It,
                                                               const int64_t* __restrict__ map, int64_t nb, int k,
@@ -208,22 +192,29 @@ __global__ __launch_bounds__(256) void scatter_failed_kernel(const float* __rest
     I[map[r] * k + c] = It[i];
 }
 
-// new row r keeps old row r + (number of deleted rows <= that old row); del[] ascending, unique.
-__global__ __launch_bounds__(256) void build_keep_map_kernel(const int64_t* __restrict__ del,
-                                                             int64_t m, int64_t n_new,
-                                                             int64_t* __restrict__ map) {
-    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n_new) return;
-    // smallest j in [0,m] with del[j] - j > r  (del[j]-j is non-decreasing)
-    int64_t lo = 0, hi = m;
-    while (lo < hi) {
-        const int64_t mid = (lo + hi) >> 1;
-        if (del[mid] - mid > r)
-            hi = mid;
-        else
-            lo = mid + 1;
+// Row compaction after deletes, one chunk: dst[i, :] = src[r + lo(r), :] for the new rows r = r0 + i, i < rows, where lo(r) =
+// the number of deleted rows at or below the old position = the smallest j in [0, m] with del[j] - j > r (del[] ascending,
+// unique; del[j] - j is non-decreasing).  A wave per row: every lane runs the same search (one broadcast load per step),
+// then the lanes move the row in 16-byte pieces.
+__global__ __launch_bounds__(256) void gather_kept_rows_kernel(float* __restrict__ dst, const float* __restrict__ src,
+                                                               const int64_t* __restrict__ del, int64_t m, int64_t r0,
+                                                               int64_t rows, int64_t ld) {
+    const int lane = threadIdx.x & 63;
+    const int64_t d4 = ld / 4;
+    for (int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); i < rows; i += (int64_t)gridDim.x * 4) {
+        const int64_t r = r0 + i;
+        int64_t lo = 0, hi = m;
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (del[mid] - mid > r)
+                hi = mid;
+            else
+                lo = mid + 1;
+        }
+        const f32x4u* s = reinterpret_cast<const f32x4u*>(src + (r + lo) * ld);
+        f32x4u* t = reinterpret_cast<f32x4u*>(dst + i * ld);
+        for (int64_t c = lane; c < d4; c += 64) t[c] = s[c];
     }
-    map[r] = r + lo;
 }
 
 // dense [n,d] -> padded [n,ld] copy (device to device), zero padding

@@ -67,6 +67,19 @@ def test_config4_whole_corpus_80m_x_512_on_one_gpu(gpu):
                          oracle_cost=cost))
     Db, Ib = idx.search(q100, k)
     bigcheck.report(bigcheck.compare(idx, q100, Db, Ib, *oracle, "config4 80M x 512 on one GPU, 100 queries per call"))
+    # deleting an EARLY row at this size: the 164 GB tail moves up one row, in place, through the 512 MiB staging buffer
+    # (until round 4 the compaction wanted a temporary as large as the tail, which this GPU does not have left)
+    probe = [7, 8, 40_000_000, n + nq - 2]
+    before = {r: idx.get_rows(r, 1)[0].copy() for r in probe + [6, n + nq - 1]}
+    idx.remove_rows(np.array([7], dtype=np.int64))
+    assert idx.ntotal == n + nq - 1
+    assert idx.get_rows(6, 1)[0].tobytes() == before[6].tobytes()
+    assert idx.get_rows(7, 1)[0].tobytes() == before[8].tobytes()
+    assert idx.get_rows(n + nq - 2, 1)[0].tobytes() == before[n + nq - 1].tobytes()
+    D, I = idx.search(q[:3], k)
+    assert np.array_equal(I[:, 0], want[:3] - 1) and np.allclose(D[:, 0], 1.0, atol=1e-5)
+    D, I = idx.search(q[:1], k)
+    assert I[0, 0] == n - 1
     idx.close()
 
 

@@ -268,10 +268,16 @@ def test_l2_batches_share_corpus_passes(native, d, nq, k, normalized):
     idx.close()
 
 
-def test_remove_rows_matches_np_delete(native):
+@pytest.mark.parametrize("staging_bytes", [None, 256, 1792, 100_000])
+def test_remove_rows_matches_np_delete(native, monkeypatch, staging_bytes):
+    """mvdb_index_remove_rows compacts the tail in place, chunk by chunk through a bounded staging buffer (512 MiB;
+    MVDB_COMPACT_BYTES): one row per chunk (256 B = a 64-float row), 7 rows, 390 rows and the whole tail at once."""
     n, d = 3000, 64
     x = _corpus(n, d)
     idx = native.FlatIndex(d)
+    if staging_bytes is not None:
+        monkeypatch.setenv("MVDB_COMPACT_BYTES", str(staging_bytes))
+        idx.reload_env()
     idx.add(x)
     rng = np.random.RandomState(1)
     cur = x
