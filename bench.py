@@ -156,6 +156,44 @@ E5_SMALL = {"model_type": "bert", "vocab_size": 250037, "hidden_size": 384, "num
             "layer_norm_eps": 1e-12, "hidden_act": "gelu", "pad_token_id": 0}
 
 
+def power_probe(step, what, sync, seconds=1.5):
+    """Package power and shader clock under a sustained load (informational; round 4: the fp16x3 encoder forward at 256 x 512
+    tokens and the 128- / 256-query scan passes run AT the 1400 W package cap with the shader clock pulled to 1.7 - 2.0 GHz —
+    the bound neither the HBM nor the MFMA roofline shows).  `step` is enqueued back to back; after `seconds` of load one
+    `rocm-smi --showpower --showclocks --showmaxpower` child process samples the SMU while the load keeps running."""
+    import re
+    import shutil
+    import subprocess
+    smi = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+    if not os.path.exists(smi):
+        return None
+    try:
+        t0, proc, n = time.perf_counter(), None, 0
+        while True:
+            step()
+            n += 1
+            if n % 4 == 0:
+                sync()  # bound the launch queue
+            el = time.perf_counter() - t0
+            if proc is None and el >= seconds:
+                proc = subprocess.Popen([smi, "--showpower", "--showclocks", "--showmaxpower"], stdout=subprocess.PIPE,
+                                        stderr=subprocess.DEVNULL, text=True)
+            if (proc is not None and proc.poll() is not None) or el > 20.0:
+                break
+        sync()
+        text = proc.communicate(timeout=20)[0] if proc is not None else ""
+        w = re.search(r"Current Socket Graphics Package Power \(W\): ([\d.]+)", text)
+        cap = re.search(r"Max Graphics Package Power \(W\): ([\d.]+)", text)
+        clk = re.search(r"sclk clock level: \d+: \((\d+)Mhz\)", text)
+        if not w:
+            return None
+        return {"load": what, "package_w": float(w.group(1)), "cap_w": float(cap.group(1)) if cap else None,
+                "sclk_mhz": int(clk.group(1)) if clk else None, "steps_under_load": n,
+                "source": "rocm-smi, one sample after %.1f s of back-to-back steps" % seconds}
+    except Exception as e:  # noqa: BLE001 - informational only
+        return {"error": f"{type(e).__name__}: {e}"}
+
+
 def encoder_flops(lens, cfg):
     """Algorithmic FLOPs of one forward: the four GEMMs per layer + the two attention products."""
     H, F, L = cfg["hidden_size"], cfg["intermediate_size"], cfg["num_hidden_layers"]
@@ -216,6 +254,9 @@ def encoder_and_config5(native, dev, k, no_cpu):
                                           "unit": "TFLOP/s", "frac": round(tf / MFMA_PEAK_TF[mode], 4),
                                           "mfma_products_per_algorithmic_product": products,
                                           "algorithmic_tflop_per_forward": round(flops / 1e12, 4)}}
+            if not ragged:
+                rec["power"] = power_probe(lambda: enc.forward_device(ids_d, mask_d, compute=2),
+                                           f"fp16x3 forward, 256 x {S} tokens, back to back", torch.cuda.synchronize)
             out["shapes"].append(rec)
     out["default_mode"] = "fp16x3 (split-precision: a.w ~ al.wh + ah.wl + ah.wh in fp16 pieces, fp32 accumulate)"
 
@@ -272,6 +313,12 @@ def encoder_and_config5(native, dev, k, no_cpu):
             del g
         except Exception as e:  # noqa: BLE001 - a capture problem must not cost the bench line
             print(f"[bench] config 5 graph capture skipped: {e}", file=sys.stderr)
+        uncertified = (native.split_rerun_count() - reruns0) / reps
+        knn_power = None
+        if S == 32:
+            emb_fix = enc.forward_device(ids_d, mask_d)[0].clone()
+            knn_power = power_probe(lambda: idx5.search_device(emb_fix.data_ptr(), B, k, D.data_ptr(), I.data_ptr(), stream=stream),
+                                    f"256-query kNN over {n5} x {H}, back to back", torch.cuda.synchronize)
         passes = -(-B // max(native.half_max_queries(H), 128))
         # the batch's nomination pass streams the index' fp16 shadow where it keeps one (2 B per element: its algorithmic bytes)
         shadow5 = int(native.lib().mvdb_index_shadow_rows(idx5.handle)) >= n5
@@ -281,7 +328,8 @@ def encoder_and_config5(native, dev, k, no_cpu):
                              "end_to_end_one_graph_ms": None if t_graph is None else round(t_graph * 1e3, 3),
                              "sentences_per_s": round(B / t_all, 1), "knn_corpus_passes": passes,
                              # query chunks that held a query the certified pass could not certify (re-run exactly, on the device)
-                             "uncertified_chunks_per_search": (native.split_rerun_count() - reruns0) / reps,
+                             "uncertified_chunks_per_search": uncertified,
+                             "knn_power": knn_power,
                              "knn_roofline": {"bound": "hbm", "achieved": round(knn_gbs, 1), "peak": HBM_PEAK_GBS,
                                               "unit": "GB/s", "frac": round(knn_gbs / HBM_PEAK_GBS, 4),
                                               "operand": "fp16 shadow (2 B per element)" if shadow5 else "fp32 corpus (4 B per element)",
@@ -590,6 +638,14 @@ def main():
                 finally:
                     os.environ.pop("MVDB_SHADOW_SINGLE_QUERY", None)
                     idx.reload_env()
+            pq = [0]
+
+            def one_step():
+                i = W + pq[0] % K
+                pq[0] += 1
+                searcher.search_device(queries[i * nq:(i + 1) * nq])
+
+            out["power"] = power_probe(one_step, f"the timed step (nq={nq}) back to back", torch.cuda.synchronize)
             out["host_api_qps"] = round(len(hl) / sum(hl), 3)
             out["host_api_p50_ms"] = round(float(np.median(hl)) * 1e3, 4)
             if not args.no_cpu_baseline and nq == 1:
