@@ -75,7 +75,8 @@ def pmc_traffic(n, d, nq=1, scan_name=None, launched=""):
     best, refused = None, None
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")))
     files.sort(key=lambda f: f"nq{nq}_" in os.path.basename(f))  # the pass profiled at this nq wins
-    batch = any(t in launched for t in ("split", "half", "hq"))
+    batch = any(t in launched for t in ("split", "half", "hq", "h16"))
+    elem = 2.0 if launched.startswith("flat_scan_h16_kernel") else 4.0  # the h16 pass streams the fp16 shadow of the rows
     for f in files:
         try:
             recs = json.load(open(f))
@@ -89,7 +90,7 @@ def pmc_traffic(n, d, nq=1, scan_name=None, launched=""):
             t = rec["hbm_traffic_bytes_per_launch_avg"]
             # a corpus pass of the split-precision kernels is up to four main launches (phases): the profile
             # holds the average over those launches, like `algorithmic_bytes_per_launch`
-            if not any(abs(t * per_pass / (n * d * 4.0) - 1.0) < 0.25 for per_pass in ((1, 2, 3, 4) if batch else (1,))):
+            if not any(abs(t * per_pass / (n * d * elem) - 1.0) < 0.25 for per_pass in ((1, 2, 3, 4) if batch else (1,))):
                 continue   # another workload size
             if squeeze(launched) not in squeeze(rec["kernel"]):
                 refused = f"refused: {os.path.basename(f)} profiled {rec['kernel']}, this run launched {launched}"

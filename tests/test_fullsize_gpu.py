@@ -125,3 +125,28 @@ def test_config3_10M_x_512_every_pass_vs_oracle(native):
     bigcheck.report({"what": "config3 certified-pass re-runs during the comparison",
                      "chunks_rerun": native.split_rerun_count() - reruns})
     idx.close()
+
+
+def test_config3_10M_x_512_l2_vs_oracle(native):
+    """The L2 metric at the headline size (north_star: "flat inner-product / L2 kNN"): 128 queries against the oracle over all
+    10M rows, one per call (the exact GEMV scan), 8 per call (fp32-MFMA pass) and 32 / 128 per call (round 4: the inner
+    product's certified passes over the fp16 shadow, L2 re-score, norm-range certificate, device-gated exact re-run)."""
+    n, d, k, nq = 10_000_000, 512, 10, 128
+    idx = native.FlatIndex(d, metric=native.METRIC_L2)
+    idx.reserve(n)
+    idx.add_synthetic(n, 1234, normalize=True)
+    q = _queries(nq, d)
+    (oracle,), cost = bigcheck.oracle_topk_streamed(idx, n, q, k, metric=flat.METRIC_L2)
+    Do, Io = oracle
+    reruns = native.split_rerun_count()
+    D, I = _in_chunks(lambda qs: idx.search(qs, k), q[:32], 1)
+    bigcheck.report(dict(bigcheck.compare(idx, q[:32], D, I, Do[:32], Io[:32], "config3 L2 10M x 512, 1 query per call",
+                                          metric=flat.METRIC_L2), oracle_cost=cost))
+    for per_call in (8, 32, 128):
+        D, I = _in_chunks(lambda qs: idx.search(qs, k), q, per_call)
+        bigcheck.report(bigcheck.compare(idx, q, D, I, Do, Io, f"config3 L2 10M x 512, {per_call} queries per call",
+                                         metric=flat.METRIC_L2))
+    assert idx.shadow_rows == n   # the batches did run over the fp16 shadow
+    bigcheck.report({"what": "config3 L2 certified-pass re-runs during the comparison",
+                     "chunks_rerun": native.split_rerun_count() - reruns})
+    idx.close()
