@@ -439,25 +439,59 @@ def main():
                                                      torch.cuda.current_stream().cuda_stream))
     torch.cuda.synchronize()
 
-    # A scaling run must measure the in-library RCCL route, not a silent fallback to torch's all-gather — and when that
-    # route cannot be brought up the run must say so in ONE parseable line, not die on a traceback.
+    # A scaling run should measure the in-library RCCL route (ncclAllGather issued from libmvdb.so).  That route has never
+    # run with more than one rank (the build boxes have one GPU), so its first N-GPU run must end in a number or in ONE
+    # parseable line, never in a traceback or a silent hang:
+    #   * the bring-up raises (every rank together: Collective agrees on the outcome by a MIN all-reduce)  ->  the run falls
+    #     back, LOUDLY, to torch.distributed's all-gather (RCCL as well) and the line carries `native_route_error` next to
+    #     `collective`; MVDB_BENCH_REQUIRE_NATIVE=1 turns the fallback off (one JSON error line, exit 3);
+    #   * the bring-up or the warm-up HANGS  ->  a watchdog prints the JSON error line and ends the process after
+    #     MVDB_BENCH_BRINGUP_TIMEOUT_S (default 300 s; torchrun then ends the other ranks).
     want_native = world > 1 and backend == "nccl" and not share_gpu and os.environ.get("MVDB_COLLECTIVE") != "torch"
-    try:
+
+    def error_line(msg):
+        return json.dumps({"error": msg, "collective": "ncclAllGather (mvdb_allgather_topk, libmvdb.so)",
+                           "rank": rank, "n_gpus": world, "rccl": _rccl_version(),
+                           "hint": "MVDB_COLLECTIVE=torch benches torch.distributed's all-gather instead; "
+                                   "NCCL_DEBUG=INFO shows RCCL's own bring-up log"})
+
+    watchdog = None
+    if world > 1:
+        import threading
+        limit = float(os.environ.get("MVDB_BENCH_BRINGUP_TIMEOUT_S", "300"))
+
+        def bail():
+            stream = sys.stdout if rank == 0 else sys.stderr
+            print(error_line(f"rank {rank}: the exchange bring-up / warm-up did not finish within {limit:.0f} s"), file=stream,
+                  flush=True)
+            os._exit(3)
+
+        watchdog = threading.Timer(limit, bail)
+        watchdog.daemon = True
+        watchdog.start()
+
+    native_route_error = None
+    searcher = None
+    if want_native:
+        try:
+            searcher = ShardedSearcher(idx, k, rank=rank, world=world, rows_per_rank=n, device=dev, collective="native")
+            if not searcher.collective.startswith("ncclAllGather"):
+                raise RuntimeError(f"the exchange came up as {searcher.collective!r}")
+        except Exception as e:  # noqa: BLE001 - every failure of the bring-up ends the same way
+            native_route_error = f"{type(e).__name__}: {e}"
+            searcher = None
+            print(f"[bench] rank {rank}: {error_line(native_route_error)}", file=sys.stderr, flush=True)
+            if os.environ.get("MVDB_BENCH_REQUIRE_NATIVE") == "1":
+                if rank == 0:
+                    print(error_line(native_route_error), flush=True)
+                try:
+                    dist.destroy_process_group()
+                except Exception:  # noqa: BLE001
+                    pass
+                raise SystemExit(3)
+    if searcher is None:
         searcher = ShardedSearcher(idx, k, rank=rank, world=world, rows_per_rank=n, device=dev,
-                                   collective="native" if want_native else None)
-        if want_native and not searcher.collective.startswith("ncclAllGather"):
-            raise RuntimeError(f"the exchange fell back to {searcher.collective!r}")
-    except Exception as e:  # noqa: BLE001 - every failure of the bring-up ends the same way
-        print(json.dumps({"error": f"{type(e).__name__}: {e}", "collective": "ncclAllGather (mvdb_allgather_topk, libmvdb.so)",
-                          "rank": rank, "n_gpus": world, "rccl": _rccl_version(),
-                          "hint": "MVDB_COLLECTIVE=torch benches torch.distributed's all-gather instead; "
-                                  "NCCL_DEBUG=INFO shows RCCL's own bring-up log"}), flush=True)
-        if world > 1:
-            try:
-                dist.destroy_process_group()
-            except Exception:  # noqa: BLE001
-                pass
-        raise SystemExit(3)
+                                   collective="torch" if native_route_error is not None else None)
 
     def barrier():
         if world > 1:
@@ -466,6 +500,9 @@ def main():
     for i in range(W):
         searcher.search_device(queries[i * nq:(i + 1) * nq])
     torch.cuda.synchronize()
+    barrier()
+    if watchdog is not None:
+        watchdog.cancel()   # every rank got through the bring-up and the warm-up exchanges
     for name in scan_names:
         native.prof_read(name)  # drop warm-up launches
     native.prof_enable(True)
@@ -562,6 +599,7 @@ def main():
             "corpus_rows_per_s": round(world * n * K * nq / dt, 1),
             "shard_passes_per_s": round(world * passes / dt, 3),
             "collective": searcher.collective,
+            "native_route_error": native_route_error,   # not None: the in-library RCCL route failed, torch's all-gather ran
             "roofline": None,
         }
         if scan_name == "ip_scan_gemm":
