@@ -131,18 +131,38 @@ class _RowStore:
         self.npending += rows.shape[0]
         self._cache = None
 
+    DIRECT_UPLOAD_BYTES = 8 << 20
+
     def flush(self, index):
         """Upload the pending rows (normalised on the device, vector_database.py:45-46) and forget the host copies:
-        ONE `mvdb_index_add` per build — 1,000 single-row stores followed by a query cost one upload and one wait on the
-        index's own stream, not 1,000."""
+        one `mvdb_index_add` per run of small blocks — 1,000 single-row stores followed by a query cost one upload and one
+        wait on the index's own stream, not 1,000."""
         if not self.pending:
             return
-        block = self.pending[0] if len(self.pending) == 1 else np.concatenate(self.pending, axis=0)
-        index.add(block, normalize=True)    # all or nothing: a failed add leaves the pending rows where they were
-        self.synced += block.shape[0]
-        self.pending = []
-        self.npending = 0
-        self._cache = None
+        # runs of SMALL blocks are stacked into one upload; a block of >= 8 MiB goes up as it stands (stacking ten 200 MB
+        # batches cost 155 ms of host memcpy before a 37 ms upload)
+        groups, small = [], []
+        for block in self.pending:
+            if block.nbytes >= self.DIRECT_UPLOAD_BYTES:
+                if small:
+                    groups.append(small)
+                    small = []
+                groups.append([block])
+            else:
+                small.append(block)
+        if small:
+            groups.append(small)
+        done = 0
+        try:
+            for group in groups:
+                block = group[0] if len(group) == 1 else np.concatenate(group, axis=0)
+                index.add(block, normalize=True)    # a failed add leaves ITS rows (and the later ones) pending
+                self.synced += block.shape[0]
+                done += len(group)
+        finally:
+            self.pending = self.pending[done:]
+            self.npending = sum(b.shape[0] for b in self.pending)
+            self._cache = None
 
     def delete(self, rows, index):
         """Remove the given stacked row numbers (np.delete semantics: later rows move up)."""

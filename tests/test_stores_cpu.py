@@ -2,6 +2,7 @@
 (id <-> row with handle arithmetic instead of renumbering loops, vector_database.py:139-152) and `_RowStore` (device
 rows + pending host rows instead of np.vstack / np.delete on one host matrix, :72, :126) against naive models."""
 import numpy as np
+import pytest
 
 from minivectordb_amd._dbcore import _IdIndex, _RowStore
 from oracle_backend import OracleIndex
@@ -75,6 +76,46 @@ def test_row_store_matches_numpy_model():
             np.testing.assert_allclose(got, model_raw[r], atol=1e-6)
             got[:] = 123.0                     # a copy: the store must not change under the caller's edit
             np.testing.assert_allclose(st.row(r, idx), model_raw[r], atol=1e-6)
+
+
+def test_row_store_uploads_big_blocks_as_they_stand(monkeypatch):
+    """flush: runs of small pending blocks are stacked into one add, a block of DIRECT_UPLOAD_BYTES or more goes up alone;
+    an add that fails leaves its rows and the later ones pending, the earlier ones synced."""
+    d = 8
+    monkeypatch.setattr(_RowStore, "DIRECT_UPLOAD_BYTES", 10 * d * 4)   # 10 rows
+    rs = np.random.RandomState(2)
+    blocks = [rs.randn(m, d).astype(np.float32) for m in (1, 3, 12, 2, 10, 1, 1)]
+
+    class Recorder(OracleIndex):
+        def __init__(self, d, fail_at=None):
+            super().__init__(d)
+            self.sizes, self.fail_at = [], fail_at
+
+        def add(self, x, normalize=False):
+            if self.fail_at is not None and len(self.sizes) == self.fail_at:
+                raise RuntimeError("device allocation failed")
+            self.sizes.append(x.shape[0])
+            return super().add(x, normalize=normalize)
+
+    idx, st = Recorder(d), _RowStore(d)
+    for b in blocks:
+        st.append(b)
+    st.flush(idx)
+    assert idx.sizes == [4, 12, 2, 10, 2] and st.synced == 30 == idx.ntotal and st.npending == 0
+    want = np.vstack(blocks)
+    want /= np.linalg.norm(want, axis=1, keepdims=True)
+    np.testing.assert_allclose(st.materialize(idx), want, atol=1e-6)
+
+    idx, st = Recorder(d, fail_at=2), _RowStore(d)
+    for b in blocks:
+        st.append(b)
+    with pytest.raises(RuntimeError):
+        st.flush(idx)
+    assert idx.sizes == [4, 12] and st.synced == 16 == idx.ntotal and st.npending == 14 and st.n == 30
+    idx.fail_at = None
+    st.flush(idx)
+    assert st.synced == 30 and st.npending == 0
+    np.testing.assert_allclose(st.materialize(idx), want, atol=1e-6)
 
 
 def test_pack_row_mask_takes_lists_sets_and_arrays():
