@@ -135,6 +135,25 @@ def main():
     del os.environ["MVDB_DISABLE_L2_CERT"]
     print(json.dumps(out), flush=True)
     idxl.close()
+    # rows of MIXED norms (un-normalised synthetic rows: |x|^2 spread of a few per cent, far beyond the 2^-10 of the norm-range
+    # certificate): the shadow pass nominates by q.x - |x|^2 / 2 with per-row offsets (round 4)
+    idxm = native.FlatIndex(d, metric=native.METRIC_L2)
+    idxm.reserve(n)
+    idxm.add_synthetic(n, 1234, normalize=False)
+    qm = flat.synth(256, d, 78)
+    out = {"what": "L2 metric over rows of mixed norms, several queries per call, k=10 (2+ queries: nomination over the fp16 shadow by "
+                   "q.x - |x|^2 / 2, per-row offsets through the scalar cache, L2 re-score, certificate)"}
+    reruns = native.split_rerun_count()
+    for nb in (8, 32, 128, 256):
+        out[f"nq{nb}_ms"] = round(timeit(lambda: idxm.search(qm[:nb], 10), 5) * 1e3, 3)
+    out["chunks_rerun_on_exact_kernels"] = native.split_rerun_count() - reruns
+    os.environ["MVDB_DISABLE_L2_CERT"] = "1"
+    idxm.reload_env()
+    for nb in (32, 128):
+        out[f"nq{nb}_ms_exact_fp32_kernels (MVDB_DISABLE_L2_CERT=1)"] = round(timeit(lambda: idxm.search(qm[:nb], 10), 3) * 1e3, 3)
+    del os.environ["MVDB_DISABLE_L2_CERT"]
+    print(json.dumps(out), flush=True)
+    idxm.close()
 
 
 if __name__ == "__main__":

@@ -36,7 +36,9 @@ while time.time() < t_end:
         nq = int(rs.choice([40, 41, 64, 127, 128, 129, 200, 256, rs.randint(40, 300)]))
         k = int(rs.randint(1, 33))
         metric = 0
-        if masked_mode: nq = int(rs.choice([2, 8, 31, 32, 33, nq, nq]))
+        if masked_mode:
+            nq = int(rs.choice([2, 8, 31, 32, 33, nq, nq]))
+            metric = int(rs.choice([0, 0, 0, 1]))   # round 4: L2 batches under a bitmap go through the fp16 nomination pass too
         if shadow_mode:
             d = int(rs.choice([256, 384, 512, 512, 768, 1024]))
             n = int(rs.choice([rs.randint(100_000, 130_000), rs.randint(500_000, 620_000), rs.randint(20_000, 60_000)]))
@@ -45,8 +47,11 @@ while time.time() < t_end:
     if n * d > (330_000_000 if shadow_mode else 30_000_000): n = (330_000_000 if shadow_mode else 30_000_000) // d
     x = flat.synth(n, d, rs.randint(1<<30)); 
     if shadow_mode or rs.rand() < 0.7: flat.normalize_l2(x)
+    if shadow_mode and rs.rand() < 0.5:   # rows of mixed norms (a factor of up to 100 apart): the L2 pass over the shadow nominates with per-row offsets
+        x *= np.exp(rs.uniform(np.log(0.1), np.log(10.0), size=(n, 1))).astype(np.float32)
     if rs.rand() < 0.2 and n > 4: x[rs.randint(n)] = x[rs.randint(n)]   # duplicate row -> exact tie
     q = flat.synth(nq, d, rs.randint(1<<30))
+    if shadow_mode and rs.rand() < 0.3: q *= np.exp(rs.uniform(np.log(0.02), np.log(5.0), size=(nq, 1))).astype(np.float32)
     normq = bool(rs.rand() < 0.5)
     idx = native.FlatIndex(d, metric=metric)
     idx.add(x)

@@ -120,8 +120,11 @@ int mvdb_index_remove_rows(mvdb_index* idx, const int64_t* rows_host, int64_t m)
  * 128 or 256 queries per corpus pass), then re-scored in fp32 and certified per query against the nomination's
  * worst-case error bound; queries that cannot be certified are re-run on the exact fp32 kernels
  * (mvdb_split_rerun_count counts the chunks that held one).  MVDB_METRIC_L2 (an extension: the reference builds
- * IndexFlatIP only): one query sums (q - x)^2 directly; several queries share corpus passes on the fp32 matrix cores
- * as |q|^2 + |x|^2 - 2 q.x (d % 128 == 0, d <= 768; differences of the two forms are at the rounding level of the norms).
+ * IndexFlatIP only): one query sums (q - x)^2 directly; several queries share corpus passes — on the certified passes
+ * above where the rows have one norm (nomination by inner product, distance re-score, norm-range certificate) or, over the
+ * fp16 shadow of the rows, for ANY norms (nomination by q.x - |x|^2 / 2 with per-row offsets), also under a bitmap; else
+ * on the fp32 matrix cores as |q|^2 + |x|^2 - 2 q.x (d % 128 == 0, d <= 768; differences of the two forms are at the
+ * rounding level of the norms).
  * Replaces faiss.normalize_L2(embedding) + index.search(embedding, search_k)
  *                                                minivectordb/vector_database.py:475, :497
  *                                                minivectordb/sharded_vector_database.py:604, :626 */

@@ -887,6 +887,23 @@ __global__ __launch_bounds__(WV * 64) void flat_scan_h16_kernel(HalfScanArgs a) 
         float sc[16];
 #pragma unroll
         for (int e = 0; e < 16; ++e) sc[e] = acc[e] * inv;  // exact: 1 / (s_q s_x) is a power of two
+        if (a.hn) {
+            // L2 metric: nominate by q.x - |x|^2 / 2.  The tile's 32 offsets come through the SCALAR cache (lgkmcnt): the
+            // vector-memory counter stays the DMA ring's alone.  acc[e] is row (e & 3) + 8 (e >> 2) + 4 fk of the tile.
+            hs_f16 h0, h1;
+            const float* hp = a.hn + m0;
+            asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %2, 0x40\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&s"(h0), "=&s"(h1)
+                         : "s"(hp)
+                         : "memory");
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int rl = (e & 3) + 8 * (e >> 2);
+                const float lo = rl < 16 ? h0[rl & 15] : h1[rl & 15];
+                const float hi = rl + 4 < 16 ? h0[(rl + 4) & 15] : h1[(rl + 4) & 15];
+                sc[e] -= fk ? hi : lo;
+            }
+        }
         float mx = sc[0];
 #pragma unroll
         for (int e = 1; e < 16; ++e) mx = fmaxf(mx, sc[e]);
@@ -997,6 +1014,33 @@ int launch_half_shadow(const float* X, int64_t ld, int d, int64_t n, float xscal
     return 0;
 }
 
+// Hn[r] = |x_r|^2 / 2: a wave per row, every lane sums its 16-byte pieces with fmas, butterfly over the lanes
+__global__ __launch_bounds__(256) void half_norms_kernel(const float* __restrict__ X, int64_t ld, int d4, int64_t n,
+                                                         float* __restrict__ Hn) {
+    const int lane = threadIdx.x & 63;
+    for (int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < n; r += (int64_t)gridDim.x * 4) {
+        const hs_f4* xr = reinterpret_cast<const hs_f4*>(X + r * ld);
+        float s = 0.f;
+        for (int c = lane; c < d4; c += 64) {
+            const hs_f4 v = xr[c];
+            s = fmaf(v[0], v[0], s);
+            s = fmaf(v[1], v[1], s);
+            s = fmaf(v[2], v[2], s);
+            s = fmaf(v[3], v[3], s);
+        }
+        for (int off = 32; off; off >>= 1) s += __shfl_xor(s, off);
+        if (lane == 0) Hn[r] = 0.5f * s;
+    }
+}
+
+int launch_half_norms(const float* X, int64_t ld, int d, int64_t n, float* Hn, int device, hipStream_t stream) {
+    if (n <= 0) return 0;
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((n + 3) / 4, (int64_t)device_cus(device) * 16));
+    hipLaunchKernelGGL(half_norms_kernel, dim3(grid), dim3(256), 0, stream, X, ld, (d + 3) / 4, n, Hn);
+    MVDB_HIP(hipGetLastError());
+    return 0;
+}
+
 // d <= 512: 128 and 256 queries per pass; d = 640 .. 1024 (e5-large / bge-m3 widths): 128 queries per pass, one wave per SIMD
 // (160 - 256 registers of query fragments)
 bool half_shadow_dim(int d) { return d == 256 || d == 384 || d == 512 || d == 640 || d == 768 || d == 896 || d == 1024; }
@@ -1018,8 +1062,10 @@ static int launch_h16_inst(const HalfScanArgs& a, int device, hipStream_t stream
     const int64_t ntiles = a.tile1 - a.tile0;
     const int nblocks = (int)std::max<int64_t>(1, std::min<int64_t>(ntiles, (int64_t)device_cus(device) * BPC));
     *nblocks_out = nblocks;
-    prof_symbol("ip_scan_half", "flat_scan_h16_kernel<%d, %d, %d, %d>", KT, KS, WV, NST);
-    int slot = prof_begin("ip_scan_half", stream);
+    // (a launch without admission floors is the seed of an L2 pass over the shadow, mvdb.hip: launch_half_pass)
+    const char* pname = a.thr0 ? "ip_scan_half" : "ip_scan_half_seed";
+    prof_symbol(pname, "flat_scan_h16_kernel<%d, %d, %d, %d>", KT, KS, WV, NST);
+    int slot = prof_begin(pname, stream);
     hipLaunchKernelGGL(kern, dim3(nblocks), dim3(WV * 64), lds, stream, a);
     prof_end(slot, stream);
     MVDB_HIP(hipGetLastError());
@@ -1136,7 +1182,9 @@ __global__ __launch_bounds__(1024) void half_certify_kernel(HalfCertifyArgs a) {
             if (holder) {
                 const int hl = __ffsll((long long)holder) - 1;
                 const float t = key_score(exact[hl]);
-                ok = a.l2 ? l2_certified(-t, u, a.eps * a.qnorm[qi], a.qnorm[qi], a.n2lo) : t > u + a.eps * a.qnorm[qi];
+                ok = a.l2 == 2 ? l2_certified(-t, u, a.eps * a.qnorm[qi] + a.eps_h, a.qnorm[qi], 0.f)
+                     : a.l2    ? l2_certified(-t, u, a.eps * a.qnorm[qi], a.qnorm[qi], a.n2lo)
+                               : t > u + a.eps * a.qnorm[qi];
             }
             if (!ok) {
                 atomicAdd(a.uncertified, 1);

@@ -27,6 +27,8 @@ struct HalfScanArgs {
     const uint32_t* mask = nullptr;  // NULL, or one bit per row (bit r & 31 of word r >> 5): only rows whose bit is set may be nominated
     const _Float16* Xh = nullptr;    // NULL, or the fp16 shadow of the corpus, [n][d] = fp16(xscale * X): the main launches stream IT
                                      // (flat_scan_h16_kernel: half the bytes, no conversion) where a kernel exists (half_shadow_dim)
+    const float* hn = nullptr;       // NULL, or [n + slack] |x_r|^2 / 2 per row (L2 metric over the shadow): rows are nominated by
+                                     // q.x - |x|^2 / 2, which ranks exactly like the squared distance |q|^2 - 2 (q.x - |x|^2 / 2)
 };
 
 struct HalfCertifyArgs {
@@ -50,7 +52,11 @@ struct HalfCertifyArgs {
                            // q.x); the nominees are re-scored as sum (q - x)^2 in fp32, ordered by smallest distance, and the
                            // certificate bounds every dropped row's distance from below through |x|^2 >= n2lo:
                            //   d(y) >= |q|^2 + n2lo - 2 (U + eps |q|)  >  r(k-th)        (topk_device.hpp: l2_certified)
-    float n2lo = 0.f;      // lower bound of |x|^2 over the stored rows (l2 only)
+    float n2lo = 0.f;      // lower bound of |x|^2 over the stored rows (l2 == 1 only)
+                           // l2 == 2 (round 4, the pass ran with HalfScanArgs::hn): the keys hold approximate q.x - |x|^2 / 2 =: s(x),
+                           // and d(y) = |q|^2 - 2 s(y) >= |q|^2 - 2 (U + eps |q| + eps_h) for every dropped row, whatever the rows'
+                           // norms (the same inequality with n2lo = 0)
+    float eps_h = 0.f;     // l2 == 2: bound on the error of the stored |x|^2 / 2 and of the subtraction, absolute
 };
 
 // queries per corpus pass of the widest instantiation for dimension d (0: no kernel for this d)
@@ -68,5 +74,7 @@ int launch_half_certify(const HalfCertifyArgs& a, int nq, hipStream_t stream);
 // the fp16 shadow of rows [0, n) of X (ld floats per row) into Xh (d halves per row); dimensions the shadow kernels serve
 int launch_half_shadow(const float* X, int64_t ld, int d, int64_t n, float xscale, _Float16* Xh, int device, hipStream_t stream);
 bool half_shadow_dim(int d);
+// Hn[r] = |X[r]|^2 / 2 for rows [0, n) (fp32; a wave per row, lane-strided fmas + butterfly: relative error < 2^-18 for d <= 4096)
+int launch_half_norms(const float* X, int64_t ld, int d, int64_t n, float* Hn, int device, hipStream_t stream);
 
 }  // namespace mvdb

@@ -269,6 +269,8 @@ struct mvdb_index {
     mutable int64_t xh_cap = 0, xh_rows = 0;   // rows allocated (+ kRowSlack behind them) / rows converted
     mutable float xh_scale = 0.f;
     mutable bool xh_failed = false;            // allocation failed: not retried until the index changes
+    mutable float* Hn = nullptr;               // L2 over rows of mixed norms: |x_r|^2 / 2 of rows [0, hn_rows) (+ zeroed slack), dies with Xh
+    mutable int64_t hn_rows = 0;
     mutable std::shared_mutex mu;  // search: shared; add/reset/remove/free: exclusive
     mutable std::mutex ws_mu;
     mutable std::vector<Workspace*> free_ws;           // synchronous searches
@@ -728,6 +730,15 @@ bool l2_cert_ok(const mvdb_index* idx) {
     return idx->metric == MVDB_METRIC_L2 && idx->norm2_hi > 0.f && std::isfinite(idx->norm2_hi) &&
            idx->norm2_hi - idx->norm2_lo <= idx->norm2_hi * (1.0f / 1024.0f) && !idx->kn.disable_l2_cert;
 }
+// ... and rows of ANY norms where the nomination pass runs over the fp16 shadow: it then nominates by q.x - |x|^2 / 2 with
+// per-row offsets kept beside the shadow (launch_half_pass: l2off).  True when a batch of nq queries over n rows would take
+// that pass.
+bool half_path_ok(const mvdb_index* idx);
+int half_min_nq(const mvdb_index* idx, int64_t n);
+bool l2_offsets_ok(const mvdb_index* idx, int nq, int64_t n) {
+    return idx->metric == MVDB_METRIC_L2 && !idx->kn.disable_l2_cert && half_shadow_dim(idx->d) && idx->ld == idx->d &&
+           !idx->kn.disable_half_shadow && !idx->xh_failed && half_path_ok(idx) && nq >= half_min_nq(idx, n);
+}
 
 // Fewest queries of a call that go to the certified passes.  Where the fp16 nomination pass streams the SHADOW of the rows
 // (d = 256 / 384 / 512), one pass over n rows costs about what 0.55 n rows cost the exact scans, whatever the number of
@@ -750,7 +761,8 @@ int half_min_nq(const mvdb_index* idx, int64_t n) {
 bool split_path_ok(const mvdb_index* idx, int nq, int k, const int64_t* rows_dev, int64_t n) {
     if (idx->kn.disable_split_scan) return false;
     const bool single_ok = nq == 1 && idx->kn.shadow_single_query && half_path_ok(idx) && half_min_nq(idx, n) <= 1;
-    if ((nq < 2 && !single_ok) || rows_dev || (idx->metric != MVDB_METRIC_IP && !l2_cert_ok(idx))) return false;
+    if ((nq < 2 && !single_ok) || rows_dev || (idx->metric != MVDB_METRIC_IP && !l2_cert_ok(idx) && !l2_offsets_ok(idx, nq, n)))
+        return false;
     // (k > 16 also needs the gated fp32-MFMA pass for the exact re-runs: the GEMM-tiled scan keeps 16 results per query)
     if (k > kSplitMaxK && !(k <= kHalfMaxK && nq >= half_min_nq(idx, n) && half_path_ok(idx) &&
                             (k <= kGemmScanMaxK || mfma_gated_queries(idx) > 0)))
@@ -935,6 +947,7 @@ bool half_path_ok(const mvdb_index* idx) {
 }
 
 const _Float16* ensure_shadow(const mvdb_index* idx, hipStream_t s, float xscale);
+const float* ensure_offsets(const mvdb_index* idx, hipStream_t s);
 
 int launch_half_pass(const mvdb_index* idx, Workspace* ws, const float* q, int nq, int nqpad, int k, int64_t n,
                      int64_t label_offset, float* D, int64_t* I, int* flag, int* failed, const uint32_t* mask = nullptr) {
@@ -969,9 +982,22 @@ int launch_half_pass(const mvdb_index* idx, Workspace* ws, const float* q, int n
     a.tile0 = 0;
     a.tile1 = seed_tiles;
     a.thr0 = nullptr;
-    MVDB_TRY(launch_half_scan(idx->d, nqpad, true, a, idx->kn, idx->device, stream, &gx));
-    hipLaunchKernelGGL(split_seed_kernel, dim3(nq), dim3(1024), 0, stream, cand, 2 * gx, (const uint64_t*)nullptr,
-                       seed_keys, floors);
+    // L2 metric over rows of MIXED norms (round 4; rows of one norm keep the cheaper inner-product nomination with the norm-range
+    // certificate): rows are nominated by q.x - |x|^2 / 2 with the per-row offsets kept beside the shadow (section 4.3e); the
+    // seed is then the shadow kernel itself without a floor — one tile per block, its 16 best per query — because the fp32
+    // seed kernel knows no offsets.
+    const float* hn = idx->metric == MVDB_METRIC_L2 && a.Xh && !l2_cert_ok(idx) && !idx->kn.disable_l2_cert ? ensure_offsets(idx, stream)
+                                                                                                          : nullptr;
+    const bool l2off = hn != nullptr;
+    if (l2off) {
+        a.hn = hn;
+        MVDB_TRY(launch_half_scan(idx->d, nqpad, false, a, idx->kn, idx->device, stream, &gx));
+        hipLaunchKernelGGL(split_seed_kernel, dim3(nq), dim3(1024), 0, stream, cand, gx, (const uint64_t*)nullptr, seed_keys, floors);
+    } else {
+        MVDB_TRY(launch_half_scan(idx->d, nqpad, true, a, idx->kn, idx->device, stream, &gx));
+        hipLaunchKernelGGL(split_seed_kernel, dim3(nq), dim3(1024), 0, stream, cand, 2 * gx, (const uint64_t*)nullptr,
+                           seed_keys, floors);
+    }
     MVDB_HIP(hipGetLastError());
     a.thr0 = floors;
     // The rest of the corpus is scanned in PHASES of growing size; between phases split_seed_kernel folds the
@@ -1018,8 +1044,14 @@ int launch_half_pass(const mvdb_index* idx, Workspace* ws, const float* q, int n
     c.I = I;
     c.uncertified = flag;
     c.failed = failed;
-    c.l2 = idx->metric == MVDB_METRIC_L2;
+    c.l2 = l2off ? 2 : idx->metric == MVDB_METRIC_L2 ? 1 : 0;
     c.n2lo = idx->norm2_lo;
+    if (l2off) {
+        // the stored |x|^2 / 2 (relative error < 2^-18, half_norms_kernel) and the fp32 subtraction a(x) - h (2^-23 of the larger)
+        const double B = (double)idx->row_norm_bound;
+        c.eps_h = (float)((std::ldexp(1.0, -18) + std::ldexp(1.0, -22)) * 0.5 * B * B * (1.0 + 1e-6));
+        c.eps = (float)((double)c.eps + std::ldexp(1.0, -22) * B * (1.0 + 1e-6));
+    }
     MVDB_TRY(launch_half_certify(c, nq, stream));
     if (a.stats) {
         unsigned int st[2] = {0, 0};
@@ -1076,9 +1108,13 @@ int search_core(const mvdb_index* idx, Workspace* ws, const float* q_dev, int nq
     const uint32_t* mask32 = reinterpret_cast<const uint32_t*>(mask_dev);
     const bool masked_batch = mask_dev && nq >= 2 && k <= kMaxFusedK && idx->metric == MVDB_METRIC_IP && idx->ld == idx->d &&
                               mfma_gated_queries(idx) > 0 && !idx->kn.disable_masked_batch;
+    // L2 under a bitmap (round 4): only through the fp16 nomination pass (its gate looks the bit up; the uncertified queries'
+    // re-run is the single-query scan, which takes the bitmap too); smaller batches answer one query at a time
+    const bool l2_masked_half = mask_dev && nq >= 2 && k <= kMaxFusedK && idx->metric == MVDB_METRIC_L2 && idx->ld == idx->d &&
+                                !idx->kn.disable_masked_batch && (l2_cert_ok(idx) || l2_offsets_ok(idx, nq, n));
     if (mask_dev) {
         rows_dev = nullptr;
-        if (!masked_batch || !half_path_ok(idx) || nq < half_min_nq(idx, n)) allow_split = false;
+        if (!(masked_batch || l2_masked_half) || !half_path_ok(idx) || nq < half_min_nq(idx, n)) allow_split = false;
     }
     // the other multi-query passes take neither a row list nor a bitmap
     const int64_t* restricted = mask_dev ? reinterpret_cast<const int64_t*>(mask_dev) : rows_dev;
@@ -1123,11 +1159,14 @@ int search_core(const mvdb_index* idx, Workspace* ws, const float* q_dev, int nq
         const int chunk = use_half ? half_max_queries(idx->d) : 128;
         std::vector<std::pair<int, int>> plan;  // (first query, count)
         int q0 = 0;
-        while (nq - q0 >= min_nq && (use_half || (k <= kSplitMaxK && !mask_dev))) {
+        // (L2 over rows of mixed norms: only the shadow pass knows the per-row offsets — the other certified kernels nominate by
+        //  inner product, which ranks like the distance for rows of one norm only)
+        const bool ip_ranks = idx->metric == MVDB_METRIC_IP || l2_cert_ok(idx);
+        while (nq - q0 >= min_nq && ((use_half && (ip_ranks || l2_offsets_ok(idx, nq - q0, n))) || (ip_ranks && k <= kSplitMaxK && !mask_dev))) {
             plan.emplace_back(q0, std::min(nq - q0, chunk));
             q0 += plan.back().second;
         }
-        if (!mask_dev && k <= kSplitMaxK && nq - q0 >= idx->kn.split32_min_nq && nq - q0 <= 32 && split32_ok(idx)) {
+        if (ip_ranks && !mask_dev && k <= kSplitMaxK && nq - q0 >= idx->kn.split32_min_nq && nq - q0 <= 32 && split32_ok(idx)) {
             plan.emplace_back(q0, nq - q0);
             q0 = nq;
         }
@@ -1510,6 +1549,9 @@ constexpr int64_t kRowSlack = 32;
 
 void drop_shadow(const mvdb_index* idx) {
     if (idx->Xh) (void)hipFree(idx->Xh);
+    if (idx->Hn) (void)hipFree(idx->Hn);
+    idx->Hn = nullptr;
+    idx->hn_rows = 0;
     idx->Xh = nullptr;
     idx->xh_cap = idx->xh_rows = 0;
     idx->xh_scale = 0.f;
@@ -1552,6 +1594,39 @@ const _Float16* ensure_shadow(const mvdb_index* idx, hipStream_t s, float xscale
     }
     idx->xh_rows = idx->n;
     return idx->Xh;
+}
+
+// L2 over rows of mixed norms (launch_half_pass: l2off): |x_r|^2 / 2 of the shadow's rows, 4 bytes per row beside it (+ zeroed
+// slack: the kernel fetches a whole tile's offsets), built on first use and caught up after appends here; dropped with the
+// shadow.  NULL: no complete shadow, allocation failed, or the stream is being captured before the array exists (the pass
+// then nominates by inner product and the norm-range certificate sends what it cannot certify to the exact kernels).
+const float* ensure_offsets(const mvdb_index* idx, hipStream_t s) {
+    std::lock_guard<std::mutex> lk(idx->shadow_mu);
+    if (!idx->Xh || idx->xh_rows != idx->n) return nullptr;
+    if (idx->Hn && idx->hn_rows == idx->n) return idx->Hn;
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (s && hipStreamIsCapturing(s, &st) == hipSuccess && st == hipStreamCaptureStatusActive) return nullptr;
+    if (!idx->Hn) {
+        float* h = nullptr;
+        const size_t bytes = (size_t)(idx->xh_cap + kRowSlack) * sizeof(float);
+        if (hipMalloc((void**)&h, bytes) != hipSuccess || hipMemsetAsync(h, 0, bytes, s) != hipSuccess) {
+            (void)hipGetLastError();
+            if (h) (void)hipFree(h);
+            return nullptr;
+        }
+        idx->Hn = h;
+        idx->hn_rows = 0;
+    }
+    if (launch_half_norms(idx->X + idx->hn_rows * idx->ld, idx->ld, idx->d, idx->n - idx->hn_rows, idx->Hn + idx->hn_rows, idx->device,
+                          s) != 0 ||
+        hipStreamSynchronize(s) != hipSuccess) {
+        (void)hipFree(idx->Hn);
+        idx->Hn = nullptr;
+        idx->hn_rows = 0;
+        return nullptr;
+    }
+    idx->hn_rows = idx->n;
+    return idx->Hn;
 }
 
 int grow(mvdb_index* idx, int64_t need) {

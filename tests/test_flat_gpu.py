@@ -251,7 +251,9 @@ def test_l2_batches_share_corpus_passes(native, d, nq, k, normalized):
     # over rows of one norm
     small = 14 <= nq <= 32 and k <= 12 and d in (64, 128, 256, 384, 512)          # flat_scan_split32_kernel's widths
     big = nq >= 33 and ((native.half_max_queries(d) > 0 and k <= 32) or (k <= 12 and d % 32 == 0))
-    expect = normalized and (small or big)
+    # round 4: over the fp16 shadow of the rows the pass nominates by q.x - |x|^2 / 2 with per-row offsets — rows of ANY norms
+    any_norms = nq >= 33 and k <= 32 and d in (256, 384, 512, 640, 768, 896, 1024)
+    expect = (normalized and (small or big)) or any_norms
     assert certified_pass == expect, (certified_pass, expect)
     assert I[0, :2].tolist() == [123, 17_000]
     mag = float(max(1.0, np.abs(D).max()))
@@ -690,6 +692,67 @@ def test_split_certificate_at_the_margin(native, d, frac, must_rerun):
     idx.close()
 
 
+@pytest.mark.parametrize("n,d,nq,k", [(120_000, 256, 8, 10), (120_000, 256, 32, 10), (110_000, 512, 130, 10), (520_000, 256, 2, 5),
+                                      (520_000, 256, 40, 32), (40_000, 384, 64, 10), (33_000, 768, 100, 12), (30_001, 1024, 33, 10)])
+def test_l2_rows_of_mixed_norms_on_the_shadow_pass(native, n, d, nq, k):
+    """L2 over rows whose norms differ by a factor of 30 (the inner product does NOT rank like the distance there): the
+    nomination pass over the fp16 shadow subtracts |x|^2 / 2 per row (kept beside the shadow, fetched through the scalar
+    cache), re-scores sum (q - x)^2 in fp32 and certifies with d(y) >= |q|^2 - 2 (U + eps).  Queries of small, equal and
+    large norm; a duplicated row (exact tie) and a query equal to a stored row.  The certified pass must have run, nearly
+    every query must certify, and every result is adjudicated in float64."""
+    rs = np.random.RandomState(n % 1000 + d + nq)
+    x = flat.synth(n, d, 31)
+    flat.normalize_l2(x)
+    x *= np.exp(rs.uniform(np.log(0.1), np.log(3.0), size=(n, 1))).astype(np.float32)
+    x[n - 7] = x[4321]
+    q = flat.synth(nq, d, 32)
+    flat.normalize_l2(q)
+    q *= np.exp(rs.uniform(np.log(0.05), np.log(4.0), size=(nq, 1))).astype(np.float32)
+    q[0] = x[4321]
+    idx = native.FlatIndex(d, metric=native.METRIC_L2)
+    idx.reserve(n + 1000)       # (an add that has to reallocate the matrix drops the shadow instead of extending it)
+    idx.add(x)
+    before = native.split_rerun_count()
+    native.prof_enable(True)
+    try:
+        _split_launches(native)
+        D, I = idx.search(q, k)
+        assert _split_launches(native) > 0, "the certified pass did not run"
+        assert native.prof_symbol("ip_scan_half").startswith("flat_scan_h16_kernel"), native.prof_symbol("ip_scan_half")
+    finally:
+        native.prof_enable(False)
+    assert idx.shadow_rows == n
+    reran = native.split_rerun_count() - before
+    assert I[0, :2].tolist() == [4321, n - 7]
+    mag = float(max(1.0, np.abs(D).max()))
+    assert np.all(np.diff(D, axis=1) >= -4e-6 * mag)
+    Do, Io = flat.flat_search(x, q, k, metric=flat.METRIC_L2, nthreads=flat.max_threads())
+    for i in range(nq):
+        if np.array_equal(I[i], Io[i]) and np.abs(D[i] - Do[i]).max() <= 4e-6 * mag:
+            continue
+        ok, msg = flat.adjudicate(x, q[i], k, D[i], I[i], metric=flat.METRIC_L2, tol=1e-4 * mag, tie_eps=4e-6 * mag)
+        assert ok, (i, msg)
+    assert reran <= 1 + nq // 128, reran     # (chunks that held an uncertified query)
+    # the same batch again after an append and a delete: the offsets follow the shadow
+    extra = flat.synth(100, d, 33)
+    flat.normalize_l2(extra)              # (rows beyond the norm bound would change the shadow's scale: rebuilt, not extended)
+    idx.add(extra)
+    assert idx.shadow_rows == n + 100
+    x2 = np.concatenate([x, extra])
+    D, I = idx.search(q, k)
+    for i in (0, nq - 1):
+        ok, msg = flat.adjudicate(x2, q[i], k, D[i], I[i], metric=flat.METRIC_L2, tol=1e-4 * mag, tie_eps=4e-6 * mag)
+        assert ok, (i, msg)
+    idx.remove_rows(np.array([5, 4321], np.int64))
+    x3 = np.delete(x2, [5, 4321], 0)
+    D, I = idx.search(q, k)
+    assert idx.shadow_rows == n + 98
+    for i in (0, nq // 2, nq - 1):
+        ok, msg = flat.adjudicate(x3, q[i], k, D[i], I[i], metric=flat.METRIC_L2, tol=1e-4 * mag, tie_eps=4e-6 * mag)
+        assert ok, (i, msg)
+    idx.close()
+
+
 @pytest.mark.parametrize("nq", [24, 40])
 @pytest.mark.parametrize("frac,must_rerun", [(1 / 48, True), (0.9, False)])
 def test_l2_certificate_at_the_margin(native, nq, frac, must_rerun):
@@ -1118,6 +1181,52 @@ def test_masked_batches_match_oracle(native, d, nq, k, frac):
     D, I = idx.search_masked(q, k, mask, labels="rows")
     assert sel[I].all()
     _check(native, x, q, k, D, np.searchsorted(rows, I), rows=rows)
+    Dp, Ip = idx.search_masked(q, k, mask, labels="positions")
+    assert np.array_equal(rows[Ip], I) and np.array_equal(Dp, D)
+    idx.close()
+
+
+@pytest.mark.parametrize("mixed", [False, True])
+@pytest.mark.parametrize("d,nq,k", [(512, 40, 10), (256, 130, 10), (384, 64, 32)])
+def test_l2_batches_under_a_bitmap(native, d, nq, k, mixed):
+    """The L2 metric, a bitmap and a batch (round 4): through the fp16 nomination pass — rows of one norm by inner product
+    with the norm-range certificate, rows of mixed norms by q.x - |x|^2 / 2 with per-row offsets —, the gate looks the bit up,
+    uncertified queries are re-run by the single-query scan under the same bitmap.  Perfect matches OUTSIDE the selection
+    must not come back; two queries have 30 exact copies of their nearest row inside it (their certificate must fail)."""
+    n = 60_000
+    rs = np.random.RandomState(d + nq + mixed)
+    x = _corpus(n, d)
+    if mixed:
+        x *= np.exp(rs.uniform(np.log(0.2), np.log(2.5), size=(n, 1))).astype(np.float32)
+    q = _corpus(nq, d, seed=41)
+    rows = np.sort(rs.choice(n, int(n * 0.6), replace=False)).astype(np.int64)
+    sel = np.zeros(n, bool)
+    sel[rows] = True
+    out = np.flatnonzero(~sel)
+    for j, qi in enumerate(range(0, nq, max(1, nq // 5))):
+        x[out[13 * j + 1]] = q[qi]                              # distance 0, not selected
+    for qi, base in ((1, 2000), (nq - 2, 30_000)):
+        sel[base:base + 30] = True
+        x[base:base + 30] = q[qi] * np.float32(0.999)
+    rows = np.flatnonzero(sel).astype(np.int64)
+    idx = native.FlatIndex(d, metric=native.METRIC_L2)
+    idx.add(x)
+    mask = native.pack_row_mask(n, rows=rows)
+    before = native.split_rerun_count()
+    native.prof_enable(True)
+    try:
+        _split_launches(native)
+        D, I = idx.search_masked(q, k, mask, labels="rows")
+        assert _split_launches(native) > 0, "the certified pass did not run"
+    finally:
+        native.prof_enable(False)
+    assert native.split_rerun_count() - before >= 1
+    assert sel[I].all()
+    mag = float(max(1.0, np.abs(D).max()))
+    pos = np.searchsorted(rows, I)
+    for i in range(nq):
+        ok, msg = flat.adjudicate(x, q[i], k, D[i], pos[i], metric=flat.METRIC_L2, rows=rows, tol=1e-4 * mag, tie_eps=4e-6 * mag)
+        assert ok, (i, msg)
     Dp, Ip = idx.search_masked(q, k, mask, labels="positions")
     assert np.array_equal(rows[Ip], I) and np.array_equal(Dp, D)
     idx.close()
