@@ -188,7 +188,8 @@ def power_probe(step, what, sync, seconds=1.5):
         clk = re.search(r"sclk clock level: \d+: \((\d+)Mhz\)", text)
         if not w:
             return None
-        return {"load": what, "package_w": float(w.group(1)), "cap_w": float(cap.group(1)) if cap else None,
+        pw, pc = float(w.group(1)), float(cap.group(1)) if cap else None
+        return {"load": what, "package_w": pw, "cap_w": pc, "at_cap": bool(pc and pw >= 0.985 * pc),
                 "sclk_mhz": int(clk.group(1)) if clk else None, "steps_under_load": n,
                 "source": "rocm-smi, one sample after %.1f s of back-to-back steps" % seconds}
     except Exception as e:  # noqa: BLE001 - informational only

@@ -31,7 +31,7 @@ def test_power_probe_parses_rocm_smi(tmp_path, monkeypatch):
     steps, syncs = [0], [0]
     got = bench.power_probe(lambda: steps.__setitem__(0, steps[0] + 1), "a test load",
                             lambda: syncs.__setitem__(0, syncs[0] + 1), seconds=0.05)
-    assert got["package_w"] == 1399.0 and got["cap_w"] == 1400.0 and got["sclk_mhz"] == 1706
+    assert got["package_w"] == 1399.0 and got["cap_w"] == 1400.0 and got["sclk_mhz"] == 1706 and got["at_cap"] is True
     assert got["load"] == "a test load" and got["steps_under_load"] == steps[0] > 0 and syncs[0] > 0
 
 
