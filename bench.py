@@ -157,31 +157,78 @@ E5_SMALL = {"model_type": "bert", "vocab_size": 250037, "hidden_size": 384, "num
             "layer_norm_eps": 1e-12, "hidden_act": "gelu", "pad_token_id": 0}
 
 
-def power_probe(step, what, sync, seconds=1.5):
+def _hwmon_of(dev_index):
+    """The hwmon directory of HIP device `dev_index` (matched by PCI address), or None."""
+    import glob
+    cards = sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*"))
+    if not cards:
+        return None
+    want = None
+    try:
+        import torch
+        pr = torch.cuda.get_device_properties(dev_index)
+        want = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+    except Exception:  # noqa: BLE001
+        pass
+    for h in cards:
+        addr = os.path.basename(os.path.realpath(os.path.join(h, "..", "..")))
+        if want and addr.lower() == want:
+            return h
+    return cards[0] if len(cards) == 1 else None
+
+
+def _read_int(path):
+    try:
+        with open(path) as f:
+            return int(f.read().strip())
+    except Exception:  # noqa: BLE001
+        return None
+
+
+def power_probe(step, what, sync, seconds=1.5, dev_index=0):
     """Package power and shader clock under a sustained load (informational; round 4: the fp16x3 encoder forward at 256 x 512
-    tokens and the 128- / 256-query scan passes run AT the 1400 W package cap with the shader clock pulled to 1.7 - 2.0 GHz —
-    the bound neither the HBM nor the MFMA roofline shows).  `step` is enqueued back to back; after `seconds` of load one
-    `rocm-smi --showpower --showclocks --showmaxpower` child process samples the SMU while the load keeps running."""
+    tokens and the 128- / 256-query scan passes run AT the 1400 W package cap with the shader clock pulled to 1.4 - 2.0 GHz —
+    the bound neither the HBM nor the MFMA roofline shows).  `step` is enqueued back to back; after `seconds` of load the
+    device's hwmon files (power1_input = PPT in microwatts, freq1_input = sclk in Hz, power1_cap) are read four times 0.15 s
+    apart while the load keeps running — no child process.  Where the hwmon directory cannot be matched to the device (and
+    no profiler is preloaded: a child process of a GPU process must not exec under one) `rocm-smi` is sampled once."""
     import re
     import shutil
     import subprocess
-    smi = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
-    if not os.path.exists(smi):
+    hw = _hwmon_of(dev_index)
+    profiled = any("rocprof" in v.lower() for k, v in os.environ.items() if k == "LD_PRELOAD" or k.startswith("ROCP"))
+    smi = None if hw or profiled else (shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi")
+    if not hw and not (smi and os.path.exists(smi)):
         return None
     try:
-        t0, proc, n = time.perf_counter(), None, 0
+        t0, proc, n, samples, next_at = time.perf_counter(), None, 0, [], seconds
         while True:
             step()
             n += 1
             if n % 4 == 0:
                 sync()  # bound the launch queue
             el = time.perf_counter() - t0
-            if proc is None and el >= seconds:
+            if hw and el >= next_at:
+                samples.append((_read_int(os.path.join(hw, "power1_input")), _read_int(os.path.join(hw, "freq1_input"))))
+                next_at = el + 0.15
+                if len(samples) >= 4:
+                    break
+            if not hw and proc is None and el >= seconds:
                 proc = subprocess.Popen([smi, "--showpower", "--showclocks", "--showmaxpower"], stdout=subprocess.PIPE,
                                         stderr=subprocess.DEVNULL, text=True)
             if (proc is not None and proc.poll() is not None) or el > 20.0:
                 break
         sync()
+        if hw:
+            pw = [p for p, _ in samples if p]
+            ck = [c for _, c in samples if c]
+            if not pw:
+                return None
+            cap = _read_int(os.path.join(hw, "power1_cap"))
+            pw_w, pc = float(np_median(pw)) / 1e6, cap / 1e6 if cap else None
+            return {"load": what, "package_w": round(pw_w, 1), "cap_w": pc, "at_cap": bool(pc and pw_w >= 0.985 * pc),
+                    "sclk_mhz": int(np_median(ck) / 1e6) if ck else None, "steps_under_load": n,
+                    "source": "hwmon power1_input / freq1_input, median of %d reads after %.1f s of back-to-back steps" % (len(pw), seconds)}
         text = proc.communicate(timeout=20)[0] if proc is not None else ""
         w = re.search(r"Current Socket Graphics Package Power \(W\): ([\d.]+)", text)
         cap = re.search(r"Max Graphics Package Power \(W\): ([\d.]+)", text)
@@ -194,6 +241,12 @@ def power_probe(step, what, sync, seconds=1.5):
                 "source": "rocm-smi, one sample after %.1f s of back-to-back steps" % seconds}
     except Exception as e:  # noqa: BLE001 - informational only
         return {"error": f"{type(e).__name__}: {e}"}
+
+
+def np_median(v):
+    v = sorted(v)
+    m = len(v) // 2
+    return v[m] if len(v) % 2 else 0.5 * (v[m - 1] + v[m])
 
 
 def encoder_flops(lens, cfg):

@@ -35,6 +35,16 @@ def test_power_probe_parses_rocm_smi(tmp_path, monkeypatch):
     assert got["load"] == "a test load" and got["steps_under_load"] == steps[0] > 0 and syncs[0] > 0
 
 
+def test_power_probe_reads_the_hwmon_files(tmp_path, monkeypatch):
+    import bench
+    for name, value in (("power1_input", 1398000000), ("freq1_input", 1534000000), ("power1_cap", 1400000000)):
+        (tmp_path / name).write_text(f"{value}\n")
+    monkeypatch.setattr(bench, "_hwmon_of", lambda dev_index: str(tmp_path))
+    got = bench.power_probe(lambda: None, "a test load", lambda: None, seconds=0.02)
+    assert got["package_w"] == 1398.0 and got["cap_w"] == 1400.0 and got["sclk_mhz"] == 1534 and got["at_cap"] is True
+    assert got["source"].startswith("hwmon") and got["steps_under_load"] > 0
+
+
 def test_power_probe_without_rocm_smi_output(tmp_path, monkeypatch):
     import bench
     fake = tmp_path / "rocm-smi"
