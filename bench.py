@@ -526,8 +526,11 @@ def main():
 
     native_route_error = None
     searcher = None
-    if want_native:
+    inject = world > 1 and os.environ.get("MVDB_BENCH_TEST_NATIVE_FAILURE") == "1"   # test hook: the failure path on a box without N GPUs
+    if want_native or inject:
         try:
+            if inject:
+                raise RuntimeError("injected by MVDB_BENCH_TEST_NATIVE_FAILURE (test hook)")
             searcher = ShardedSearcher(idx, k, rank=rank, world=world, rows_per_rank=n, device=dev, collective="native")
             if not searcher.collective.startswith("ncclAllGather"):
                 raise RuntimeError(f"the exchange came up as {searcher.collective!r}")

@@ -83,16 +83,16 @@ def test_config4_whole_corpus_80m_x_512_on_one_gpu(gpu):
     idx.close()
 
 
-def test_config4_two_rank_bench_path_on_a_shared_gpu(gpu, tmp_path):
-    from minivectordb_amd import _native as native
-    rows, d, k, steps, warmup = 1_000_000, 512, 10, 12, 2
-    dump = str(tmp_path / "dump.npz")
+def _two_rank_bench(tmp_path, rows, steps, warmup, d=512, k=10, dump=None, **extra_env):
+    """bench.py --gpus 2 as two ranks sharing GPU 0 over gloo; returns (returncode, stdout, stderr)."""
     env = dict(os.environ, MVDB_BENCH_SHARE_GPU="1", MVDB_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1",
-               HSA_ENABLE_IPC_MODE_LEGACY="0")
-    port = 23000 + os.getpid() % 4000
+               HSA_ENABLE_IPC_MODE_LEGACY="0", **extra_env)
+    port = 23000 + (os.getpid() + len(extra_env) * 131 + rows) % 4000
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", str(steps),
-           "--warmup", str(warmup), "--rows", str(rows), "--dim", str(d), "--k", str(k), "--dump", dump]
+           "--warmup", str(warmup), "--rows", str(rows), "--dim", str(d), "--k", str(k)]
+    if dump:
+        cmd += ["--dump", dump]
     # own session + faulthandler: if the two ranks ever hang, SIGABRT makes every Python process of the job print where
     import signal
     env["PYTHONFAULTHANDLER"] = "1"
@@ -108,7 +108,35 @@ def test_config4_two_rank_bench_path_on_a_shared_gpu(gpu, tmp_path):
             os.killpg(proc.pid, signal.SIGKILL)
             so, se = proc.communicate()
         pytest.fail("two-rank bench.py hung; tracebacks of its processes:\n" + so[-1500:] + se[-6000:])
-    assert proc.returncode == 0, so[-2000:] + se[-4000:]
+    return proc.returncode, so, se
+
+
+def test_two_rank_bench_survives_a_failed_native_route(gpu, tmp_path):
+    """bench.py --gpus N when the in-library RCCL route cannot be brought up (injected: this box has one GPU): the run falls
+    back, loudly, to torch.distributed's all-gather and still prints ONE bench line, which names the failure; with
+    MVDB_BENCH_REQUIRE_NATIVE=1 it prints ONE JSON error line instead and exits 3."""
+    rc, so, se = _two_rank_bench(tmp_path, 200_000, 6, 2, MVDB_BENCH_TEST_NATIVE_FAILURE="1")
+    assert rc == 0, so[-2000:] + se[-4000:]
+    lines = [l for l in so.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["value"] > 0 and out["collective"].startswith("torch.distributed")
+    assert "injected" in out["native_route_error"]
+    assert "injected" in se                      # every rank said so on stderr
+    rc, so, se = _two_rank_bench(tmp_path, 200_000, 6, 2, MVDB_BENCH_TEST_NATIVE_FAILURE="1", MVDB_BENCH_REQUIRE_NATIVE="1")
+    assert rc != 0
+    lines = [l for l in so.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, (lines, se[-2000:])
+    err = json.loads(lines[0])
+    assert "injected" in err["error"] and err["rank"] == 0 and err["n_gpus"] == 2 and "hint" in err
+
+
+def test_config4_two_rank_bench_path_on_a_shared_gpu(gpu, tmp_path):
+    from minivectordb_amd import _native as native
+    rows, d, k, steps, warmup = 1_000_000, 512, 10, 12, 2
+    dump = str(tmp_path / "dump.npz")
+    rc, so, se = _two_rank_bench(tmp_path, rows, steps, warmup, d=d, k=k, dump=dump)
+    assert rc == 0, so[-2000:] + se[-4000:]
     line = [l for l in so.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["corpus_rows"] == 2 * rows
@@ -117,6 +145,7 @@ def test_config4_two_rank_bench_path_on_a_shared_gpu(gpu, tmp_path):
     assert out["shard_passes_per_s"] == pytest.approx(2 * out["value"], rel=1e-3)
     assert out["roofline"]["peak"] == 16000.0 and len(out["roofline"]["per_rank_avg_launch_ms"]) == 2
     assert out["collective"].startswith("torch.distributed")   # gloo group: the RCCL route is not selectable here
+    assert out["native_route_error"] is None
     z = np.load(dump)
     assert int(z["world"]) == 2 and int(z["rows_per_rank"]) == rows
     # the same corpus in ONE index: rank r generated rows [r * rows, (r + 1) * rows) of stream 1234
