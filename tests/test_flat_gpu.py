@@ -800,6 +800,52 @@ def test_l2_certificate_at_the_margin(native, nq, frac, must_rerun):
 
 
 @pytest.mark.parametrize("frac,must_rerun", [(1 / 48, True), (0.9, False)])
+def test_l2_offsets_certificate_at_the_margin(native, frac, must_rerun):
+    """The certificate of the L2 pass with per-row offsets (rows of mixed norms: largest norm B = 2): 30 UNIT rows graded
+    `frac * eps * B` apart in q.x - |x|^2 / 2 (twice that in squared distance), stored contiguously so that one block list
+    holds them all.  Steps of eps B / 48: the 16 a block list keeps end 0.125 eps B below the 10th result — the certificate
+    (margin eps B |q| + eps_h) MUST refuse and the device-gated exact scan must return the right ids; steps of 0.9 eps B:
+    5.4 eps B of room — it must certify on its own.  Either way the ids are exact."""
+    n, d, k, nq = 20000, 512, 10, 40
+    B = 2.0
+    eps = native.half_eps(d) * B
+    spacing = frac * eps
+    rs = np.random.RandomState(int(frac * 1e4) + 7)
+    x = _corpus(n, d)
+    x *= np.exp(rs.uniform(np.log(0.5), np.log(1.9), size=(n, 1))).astype(np.float32)   # rows of mixed norms ...
+    x[777] *= np.float32(B / np.linalg.norm(x[777].astype(np.float64)))               # ... the largest exactly B
+    q = _corpus(nq, d, seed=4242)
+    cos = 0.9 - spacing * np.arange(30)
+    for qi, base in ((0, 500), (nq // 2, 9000), (nq - 1, 15000)):
+        rows = _graded_rows(q[qi], cos, rs)
+        x[base:base + 30] = rows[rs.permutation(30)]
+    idx = native.FlatIndex(d, metric=native.METRIC_L2)
+    idx.add(x)
+    before = native.split_rerun_count()
+    native.prof_enable(True)
+    try:
+        _split_launches(native)
+        D, I = idx.search(q, k)
+        assert _split_launches(native) > 0, "the certified pass did not run"
+        assert native.prof_symbol("ip_scan_half_seed").startswith("flat_scan_h16_kernel")   # the offsets form: the shadow kernel seeds
+    finally:
+        native.prof_enable(False)
+    reran = native.split_rerun_count() - before
+    assert (reran >= 1) == must_rerun, (reran, eps)
+    x64 = x.astype(np.float64)
+    for qi in range(nq):
+        d2 = ((x64 - q[qi].astype(np.float64)) ** 2).sum(axis=1)
+        want = np.argsort(d2, kind="stable")[:k]
+        if spacing >= 1e-5 or qi not in (0, nq // 2, nq - 1):
+            assert I[qi].tolist() == want.tolist(), (qi, I[qi], want)
+        else:
+            ok, msg = flat.adjudicate(x, q[qi], k, D[qi], I[qi], metric=flat.METRIC_L2, tol=TOL * 4, tie_eps=1.6e-5)
+            assert ok, msg
+        np.testing.assert_allclose(D[qi], d2[I[qi]], atol=TOL * 4, rtol=0)
+    idx.close()
+
+
+@pytest.mark.parametrize("frac,must_rerun", [(1 / 48, True), (0.9, False)])
 def test_fp16_certificate_at_the_margin_k32(native, frac, must_rerun):
     """k = 32 on the fp16 pass (64 nominees re-scored): 80 rows graded `frac * eps` apart, SCATTERED over the corpus (every
     block list holds at most a few).  Steps of eps / 48: the 64th nominee is only 0.67 eps below the 32nd result — the
