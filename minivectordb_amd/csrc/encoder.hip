@@ -801,6 +801,15 @@ __device__ __forceinline__ void x3_kstep(const unsigned char* sb, const int (&a_
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
+#ifdef MVDB_X3_ONE_PRODUCT  // timing experiment (results = plain fp16 products): the two cross products left out
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                after(ks, i * TN + j + 1);
+                after(ks, TM * TN + i * TN + j + 1);
+            }
+#else
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -816,6 +825,7 @@ __device__ __forceinline__ void x3_kstep(const unsigned char* sb, const int (&a_
                 x3_mfma<SHAPE>(bl[ks][j], ah[ks][i], acc[i][j], 1);
                 after(ks, TM * TN + i * TN + j + 1);
             }
+#endif
         __builtin_amdgcn_sched_barrier(0);
         if (ks == 0) read_first(1);  // under the leading product of k-block 0 ...
         __builtin_amdgcn_sched_barrier(0);
@@ -855,6 +865,7 @@ __device__ __forceinline__ void x3_kstep_plain(const unsigned char* sb, const in
             ah[i] = *reinterpret_cast<const x3_h8*>(sb + a_off[ks][0] + i * 4096);
             al[i] = *reinterpret_cast<const x3_h8*>(sb + a_off[ks][1] + i * 4096);
         }
+#ifndef MVDB_X3_ONE_PRODUCT
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -863,6 +874,7 @@ __device__ __forceinline__ void x3_kstep_plain(const unsigned char* sb, const in
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[j], ah[i], acc[i][j], 0, 0, 0);
+#endif
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -1152,6 +1164,8 @@ __global__ __launch_bounds__(512) void gemm_x3_big_kernel(const _Float16* __rest
         lslot[i] = (uint32_t)(16 * ((lane & 7) ^ ((row >> 1) & 7)));
     }
     auto issue_piece = [&](int m0, int n0, int kt, int stage, int i) {
+        if (DBG == 2) return;            // ablation: no DMA (the MFMAs run on whatever the LDS holds)
+        if (DBG == 7) m0 = n0 = 0;       // ablation: every tile stages the SAME operand rows (always L2-resident)
         const int q = wave * NI + i;
         const char* base = q < NA ? reinterpret_cast<const char*>(A) + ((int64_t)m0 * K * 4 + (int64_t)kt * 128)
                                   : reinterpret_cast<const char*>(Wp) + ((int64_t)n0 * K * 4 + (int64_t)kt * 128);
@@ -1206,6 +1220,13 @@ __global__ __launch_bounds__(512) void gemm_x3_big_kernel(const _Float16* __rest
             const bool more = kt + 1 < nk;
             const int lm = more ? m0 : m1, ln = more ? n0 : n1, lk = more ? kt + 1 : 0;
             auto dma = [&](int i) { issue_piece(lm, ln, lk, st ^ 1, i); };
+            if (DBG == 1) {              // ablation: the DMAs and the barriers only (no fragment reads, no MFMAs)
+#pragma unroll
+                for (int i = 0; i < NI; ++i) dma(i);
+                acc[0][0][0] += (float)kt;
+                st ^= 1;
+                continue;
+            }
             if (SPREAD)
                 x3_kstep<TM, TN, DBG == 6 ? 1 : 0, NI>(xsm + st * kStage, a_off, b_off, acc, dma);
             else {
@@ -2351,7 +2372,9 @@ int x3_set_lds(const void* kern, int lds, int device) {
      dbg == 3 ? gemm_x3_dma_kernel<__VA_ARGS__, 3> : dbg == 4 ? gemm_x3_dma_kernel<__VA_ARGS__, 4> :                 \
      dbg == 5 ? gemm_x3_dma_kernel<__VA_ARGS__, 5> : gemm_x3_dma_kernel<__VA_ARGS__, 0>)
 #define X3_BIG_KERN(...)                                                                                              \
-    (dbg == 3 ? gemm_x3_big_kernel<__VA_ARGS__, 3> : dbg == 4 ? gemm_x3_big_kernel<__VA_ARGS__, 4> :                 \
+    (dbg == 1 ? gemm_x3_big_kernel<__VA_ARGS__, 1> : dbg == 2 ? gemm_x3_big_kernel<__VA_ARGS__, 2> :                 \
+     dbg == 7 ? gemm_x3_big_kernel<__VA_ARGS__, 7> :                                                                  \
+     dbg == 3 ? gemm_x3_big_kernel<__VA_ARGS__, 3> : dbg == 4 ? gemm_x3_big_kernel<__VA_ARGS__, 4> :                 \
      dbg == 5 ? gemm_x3_big_kernel<__VA_ARGS__, 5> : dbg == 6 ? gemm_x3_big_kernel<__VA_ARGS__, 6> : gemm_x3_big_kernel<__VA_ARGS__, 0>)
 #define X3_LN_KERN(...)                                                                                               \
     (dbg == 1 ? gemm_x3_ln_kernel<__VA_ARGS__, 1> : dbg == 2 ? gemm_x3_ln_kernel<__VA_ARGS__, 2> :                   \
