@@ -1558,6 +1558,14 @@ void drop_shadow(const mvdb_index* idx) {
     idx->xh_failed = false;
 }
 
+// The rows changed their numbers or their scale but the allocation still fits: the shadow is emptied, not freed — hipFree waits
+// for the whole device and the next batch search would allocate the same bytes again — and rebuilt in place on demand.
+void invalidate_shadow(const mvdb_index* idx) {
+    idx->xh_rows = 0;
+    idx->hn_rows = 0;
+    idx->xh_failed = false;
+}
+
 // The shadow for a batch search on stream s (caller holds the index shared): the existing one if it covers the rows at
 // this scale, else built here — once: 10M x 512 convert in ~5 ms — and published after a wait for s, so that searches on
 // other streams find complete data.  NULL (the fp32 path serves): no kernel for d, switched off, allocation failed, or the
@@ -1571,7 +1579,11 @@ const _Float16* ensure_shadow(const mvdb_index* idx, hipStream_t s, float xscale
     if (s && hipStreamIsCapturing(s, &st) == hipSuccess && st == hipStreamCaptureStatusActive) return nullptr;
     // (a stale shadow can only be one whose rows are a prefix at another scale or count: mutators drop or extend it while no
     //  search is in flight, so nobody else is reading what is rebuilt here)
-    if (idx->Xh && (idx->xh_scale != xscale || idx->xh_cap < idx->n)) drop_shadow(idx);
+    if (idx->Xh && idx->xh_cap < idx->n) drop_shadow(idx);
+    if (idx->Xh && idx->xh_scale != xscale) {   // another scale: every row is converted again, into the same allocation
+        invalidate_shadow(idx);
+        idx->xh_scale = xscale;
+    }
     if (!idx->Xh) {
         _Float16* p = nullptr;
         const int64_t cap = std::max<int64_t>(idx->cap, idx->n);
@@ -1843,8 +1855,12 @@ static int extend_shadow(mvdb_index* idx, int64_t n_new) {
         return 0;
     }
     const float xscale = half_xscale(idx->row_norm_bound);
-    if (idx->xh_rows != idx->n || idx->xh_cap < idx->n + n_new || xscale != idx->xh_scale) {
+    if (idx->xh_cap < idx->n + n_new) {
         drop_shadow(idx);
+        return 0;
+    }
+    if (idx->xh_rows != idx->n || xscale != idx->xh_scale) {   // (the next batch search converts every row again, in place)
+        invalidate_shadow(idx);
         return 0;
     }
     MVDB_TRY(launch_half_shadow(idx->X + idx->n * idx->ld, idx->ld, idx->d, n_new, xscale, idx->Xh + idx->n * idx->d, idx->device,
@@ -1978,7 +1994,7 @@ int mvdb_index_remove_rows(mvdb_index* idx, const int64_t* rows_host, int64_t m)
     DeviceGuard dg(idx->device);
     MVDB_TRY(quiesce(idx));
     ++idx->renumbered;
-    drop_shadow(idx);  // rows are renumbered: rebuilt by the next batch search
+    invalidate_shadow(idx);  // rows are renumbered: the next batch search rebuilds the shadow in the allocation it already has
     const int64_t n_new = idx->n - m;
     if (n_new == 0) {
         idx->n = 0;

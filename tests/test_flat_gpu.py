@@ -1168,6 +1168,47 @@ def test_add_does_not_synchronise_the_device(native):
     idx.close()
 
 
+def test_delete_does_not_synchronise_the_device(native):
+    """remove_rows on an index that holds an fp16 shadow: the shadow is emptied, not freed (hipFree waits for the whole device),
+    the compaction runs on the index's own stream through the staging buffer the index keeps from its first delete on — so with
+    unrelated work queued on another stream a delete returns, rows renumbered and searchable, while that stream is still busy."""
+    import time
+    import torch
+    dev = torch.device("cuda", 0)
+    d, n = 256, 120_000
+    x = _corpus(n, d)
+    idx = native.FlatIndex(d)
+    idx.add(x, normalize=True)
+    q = _corpus(40, d, seed=9)
+    idx.search(q, 5)                                   # builds the shadow
+    assert idx.shadow_rows == n
+    idx.remove_rows(np.array([n - 1], np.int64))       # first delete: allocates the staging buffer (kept)
+    cur = x[:n - 1]
+    idx.search(q, 5)
+    assert idx.shadow_rows == n - 1
+    busy = torch.cuda.Stream(dev)
+    a = torch.randn((8192, 8192), device=dev)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    with torch.cuda.stream(busy):
+        for _ in range(40):
+            a = (a @ a).clamp_(-1, 1)
+    t_enq = time.perf_counter() - t0
+    idx.remove_rows(np.array([7, 50_000], np.int64))
+    D1, I1 = idx.search(x[60_000], 3)
+    still_busy = not busy.query()
+    t_del = time.perf_counter() - t0 - t_enq
+    busy.synchronize()
+    assert I1[0, 0] == 60_000 - 2 and idx.ntotal == n - 3
+    assert still_busy, f"the delete waited for an unrelated stream ({t_del * 1e3:.1f} ms)"
+    assert idx.shadow_rows == 0                        # emptied; the next batch rebuilds it in the same allocation
+    cur = np.delete(cur, [7, 50_000], 0)
+    D, I = idx.search(q, 5)
+    assert idx.shadow_rows == n - 3
+    _check(native, cur, q, 5, D, I)
+    idx.close()
+
+
 # ---- bitmap-selected search and resident row sets (reference: the per-query sub-index, vector_database.py:508-523) --------
 @pytest.mark.parametrize("d,metric", [(512, flat.METRIC_IP), (100, flat.METRIC_IP), (384, flat.METRIC_L2)])
 @pytest.mark.parametrize("frac", [0.01, 0.5, 0.99])
