@@ -64,6 +64,17 @@ int mvdb_index_free(mvdb_index* idx);
  * that flip a hook inside one process).  No reference counterpart. */
 int mvdb_index_reload_env(mvdb_index* idx);
 
+/* Per-index switches a caller sets in code rather than through the environment (the value survives until the next
+ * mvdb_index_reload_env).  No reference counterpart.
+ *   "shadow_single_query" (0 | 1, default 0): ONE query per call also goes through the certified nomination pass over the fp16
+ *       shadow of the rows (>= 500,000 rows at d = 256 / 384 / 512): the same ids and fp32 scores as the exact scan — nominees
+ *       re-scored in fp32, every result certified, uncertified queries re-run exactly — at about half the bytes per query
+ *       (10M x 512: 2.84 -> 1.58 ms), for 2 more bytes per stored element.  Off by default: the single-query scan is the exact
+ *       fp32 kernel the headline roofline is defined on.
+ *   "half_shadow" (0 | 1, default 1): 0 = batches nominate from the fp32 rows (no second copy of the corpus).
+ *   "compact_bytes" (> 0, default 512 MiB): staging buffer of mvdb_index_remove_rows. */
+int mvdb_index_set_option(mvdb_index* idx, const char* name, long long value);
+
 /* Drop all rows (capacity is kept). */
 int mvdb_index_reset(mvdb_index* idx);
 

@@ -400,6 +400,8 @@ class FilterAndRerankMixin:
         from . import _native
         if self.index is None:
             self.index = _native.FlatIndex(self.embedding_size, metric=_native.METRIC_IP, device=self._device)
+            if self.__dict__.get("_fast_single_query"):
+                self.index.set_option("shadow_single_query", 1)
         if self._mat.n > 0:
             self._mat.flush(self.index)
             self._embeddings_changed = False

@@ -60,6 +60,7 @@ PROTOTYPES = {
     "mvdb_index_create": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(c_vp)]),
     "mvdb_index_free": (ctypes.c_int, [c_vp]),
     "mvdb_index_reload_env": (ctypes.c_int, [c_vp]),
+    "mvdb_index_set_option": (ctypes.c_int, [c_vp, ctypes.c_char_p, ctypes.c_longlong]),
     "mvdb_index_reset": (ctypes.c_int, [c_vp]),
     "mvdb_index_ntotal": (ctypes.c_int64, [c_vp]),
     "mvdb_index_shadow_rows": (ctypes.c_int64, [c_vp]),
@@ -232,6 +233,11 @@ class FlatIndex:
 
     def reserve(self, n):
         check(lib().mvdb_index_reserve(self._h, int(n)))
+
+    def set_option(self, name, value):
+        """Per-index switch set in code (include/mvdb.h: mvdb_index_set_option): "shadow_single_query", "half_shadow",
+        "compact_bytes"."""
+        check(lib().mvdb_index_set_option(self._h, str(name).encode(), int(value)))
 
     def reload_env(self):
         """Re-read the MVDB_* hooks (the library reads them once, when the index is created)."""

@@ -1726,6 +1726,23 @@ int mvdb_index_reload_env(mvdb_index* idx) {
     return 0;
 }
 
+int mvdb_index_set_option(mvdb_index* idx, const char* name, long long value) {
+    if (!idx) return fail(MVDB_ERR_ARG, "index is NULL");
+    if (!name) return fail(MVDB_ERR_ARG, "option name is NULL");
+    std::unique_lock<std::shared_mutex> lk(idx->mu);
+    const std::string n(name);
+    if (n == "shadow_single_query")
+        idx->kn.shadow_single_query = value != 0;
+    else if (n == "half_shadow")
+        idx->kn.disable_half_shadow = value == 0;
+    else if (n == "compact_bytes") {
+        if (value <= 0) return fail(MVDB_ERR_ARG, "compact_bytes must be positive");
+        idx->kn.compact_bytes = value;
+    } else
+        return fail(MVDB_ERR_ARG, "unknown index option '%s' (shadow_single_query, half_shadow, compact_bytes)", name);
+    return 0;
+}
+
 int mvdb_index_free(mvdb_index* idx) {
     if (!idx) return 0;
     {

@@ -48,7 +48,10 @@ def shard_files_for_rank(storage_dir, rank, world):
 
 
 class ShardedVectorDatabase(FilterAndRerankMixin):
-    def __init__(self, storage_dir='db_shards', shard_size=5000, device=0):
+    def __init__(self, storage_dir='db_shards', shard_size=5000, device=0, fast_single_query=False):
+        """storage_dir, shard_size: as in the reference (sharded_vector_database.py:9).  device, fast_single_query: see
+        VectorDatabase."""
+        self._fast_single_query = bool(fast_single_query)
         self.hash_vectorizer = None
         self.embedding_size = None
         self.storage_dir = storage_dir

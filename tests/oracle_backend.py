@@ -33,6 +33,9 @@ class OracleIndex:
     def close(self):
         pass
 
+    def set_option(self, name, value):
+        self.calls.append(("set_option", name, int(value)))
+
     def reset(self):
         self.x = np.zeros((0, self.d), dtype=np.float32)
 

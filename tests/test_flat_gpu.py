@@ -1168,6 +1168,55 @@ def test_add_does_not_synchronise_the_device(native):
     idx.close()
 
 
+def test_single_queries_over_the_shadow_when_asked_for(native, tmp_path):
+    """mvdb_index_set_option("shadow_single_query", 1) — and VectorDatabase(fast_single_query=True) — send ONE query per call through the
+    certified nomination pass over the fp16 shadow too (>= 500,000 rows at d = 256 / 384 / 512): same ids as the exact scan and as
+    the oracle, fp32 re-scored distances; a query with 40 exact copies of its best row cannot be certified and comes back from the
+    exact re-run.  Off (the default) the single-query scan is the exact fp32 kernel and no shadow is built."""
+    n, d, k = 520_000, 256, 10
+    x = _corpus(n, d)
+    q = _corpus(24, d, seed=77)
+    x[1000:1040] = q[3]
+    idx = native.FlatIndex(d)
+    idx.add(x)
+    exact = [idx.search(q[i], k) for i in range(24)]
+    assert idx.shadow_rows == 0
+    idx.set_option("shadow_single_query", 1)
+    before = native.split_rerun_count()
+    native.prof_enable(True)
+    try:
+        _split_launches(native)
+        fast = [idx.search(q[i], k) for i in range(24)]
+        assert _split_launches(native) >= 24, "the certified pass did not serve the single queries"
+    finally:
+        native.prof_enable(False)
+    assert idx.shadow_rows == n
+    assert native.split_rerun_count() - before >= 1          # the query with 40 tied rows
+    for i in range(24):
+        assert np.array_equal(fast[i][1], exact[i][1]), i
+        np.testing.assert_allclose(fast[i][0], exact[i][0], atol=2e-6, rtol=0)
+    D = np.concatenate([f[0] for f in fast])
+    I = np.concatenate([f[1] for f in fast])
+    _check(native, x, q, k, D, I)
+    idx.set_option("shadow_single_query", 0)
+    with pytest.raises(ValueError):
+        idx.set_option("no_such_option", 1)
+    idx.close()
+    # the drop-in class: same answers with and without the switch
+    from minivectordb_amd import VectorDatabase
+    fastdb = VectorDatabase(storage_file=str(tmp_path / "fast.pkl"), fast_single_query=True)
+    plain = VectorDatabase(storage_file=str(tmp_path / "plain.pkl"))
+    ids = list(range(n))
+    for db in (fastdb, plain):
+        db.store_embeddings_batch(ids, x)
+    for i in (0, 3, 23):
+        a = fastdb.find_most_similar(q[i], k=k)
+        b = plain.find_most_similar(q[i], k=k)
+        assert list(a[0]) == list(b[0])
+        np.testing.assert_allclose(a[1], b[1], atol=2e-6, rtol=0)
+    assert fastdb.index.shadow_rows == n and plain.index.shadow_rows == 0
+
+
 def test_delete_does_not_synchronise_the_device(native):
     """remove_rows on an index that holds an fp16 shadow: the shadow is emptied, not freed (hipFree waits for the whole device),
     the compaction runs on the index's own stream through the staging buffer the index keeps from its first delete on — so with

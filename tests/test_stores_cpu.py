@@ -130,3 +130,21 @@ def test_pack_row_mask_takes_lists_sets_and_arrays():
     assert np.array_equal(pack_row_mask(70, excluded=[]), full)
     m = pack_row_mask(70, rows=np.array([0, 64, 69]))
     assert int(m[0]) == 1 and int(m[1]) == 1 + 2 ** 5
+
+
+def test_fast_single_query_kwarg_reaches_the_index(tmp_path, monkeypatch):
+    """VectorDatabase(fast_single_query=True) / ShardedVectorDatabase(...): the device index is created with the
+    "shadow_single_query" option set (include/mvdb.h: mvdb_index_set_option); the default leaves it alone."""
+    from minivectordb_amd import ShardedVectorDatabase, VectorDatabase, _native
+    monkeypatch.setattr(_native, "FlatIndex", OracleIndex)
+    x = np.random.RandomState(0).randn(6, 8).astype(np.float32)
+    for make in (lambda **kw: VectorDatabase(storage_file=str(tmp_path / f"a{len(kw)}.pkl"), **kw),
+                 lambda **kw: ShardedVectorDatabase(storage_dir=str(tmp_path / f"s{len(kw)}"), shard_size=4, **kw)):
+        db = make(fast_single_query=True)
+        db.store_embeddings_batch(list(range(6)), x)
+        db.find_most_similar(x[0], k=2)
+        assert ("set_option", "shadow_single_query", 1) in db.index.calls
+        db = make()
+        db.store_embeddings_batch(list(range(6)), x)
+        db.find_most_similar(x[0], k=2)
+        assert not any(c[0] == "set_option" for c in db.index.calls if isinstance(c, tuple))
