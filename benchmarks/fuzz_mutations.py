@@ -61,6 +61,8 @@ while time.time() < t_end:
     else:
         os.environ["MVDB_COMPACT_BYTES"] = str(int(staging))
     idx = native.FlatIndex(d, metric=metric)
+    if rs.rand() < 0.3:
+        idx.set_option("shadow_single_query", 1)
     mirror = flat.synth(n0, d, rs.randint(1 << 30))
     flat.normalize_l2(mirror)
     idx.add(mirror)

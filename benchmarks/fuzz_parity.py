@@ -42,7 +42,7 @@ while time.time() < t_end:
         if shadow_mode:
             d = int(rs.choice([256, 384, 512, 512, 768, 1024]))
             n = int(rs.choice([rs.randint(100_000, 130_000), rs.randint(500_000, 620_000), rs.randint(20_000, 60_000)]))
-            nq = int(rs.choice([2, 3, 8, 9, 13, 14, 24, 32, 33, 100, 128, 129, 256, rs.randint(2, 300)]))
+            nq = int(rs.choice([1, 1, 2, 3, 8, 9, 13, 14, 24, 32, 33, 100, 128, 129, 256, rs.randint(2, 300)]))
             metric = int(rs.choice([0, 0, 1]))
     if n * d > (330_000_000 if shadow_mode else 30_000_000): n = (330_000_000 if shadow_mode else 30_000_000) // d
     x = flat.synth(n, d, rs.randint(1<<30)); 
@@ -54,6 +54,7 @@ while time.time() < t_end:
     if shadow_mode and rs.rand() < 0.3: q *= np.exp(rs.uniform(np.log(0.02), np.log(5.0), size=(nq, 1))).astype(np.float32)
     normq = bool(rs.rand() < 0.5)
     idx = native.FlatIndex(d, metric=metric)
+    if shadow_mode and rs.rand() < 0.5: idx.set_option("shadow_single_query", 1)   # single queries through the certified pass too
     idx.add(x)
     subset = None
     if masked_mode and n > 1:
