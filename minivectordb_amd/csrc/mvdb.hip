@@ -262,7 +262,7 @@ struct mvdb_index {
     float* ctmp = nullptr;            // bounded staging buffer of mvdb_index_remove_rows (kept once a delete has run)
     size_t ctmp_bytes = 0;
     // fp16 shadow of the rows (half_scan.hip: flat_scan_h16_kernel): built by the first batch search that can use it, extended
-    // by add, dropped by whatever renumbers rows or changes the scale.  Searches (shared lock) build / read it under
+    // by add, emptied (allocation kept) by whatever renumbers rows or changes the scale, freed with the matrix.  Searches (shared lock) build / read it under
     // shadow_mu; mutators (exclusive lock, searches quiesced) edit it directly.
     mutable std::mutex shadow_mu;
     mutable _Float16* Xh = nullptr;

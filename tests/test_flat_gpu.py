@@ -1038,7 +1038,7 @@ def test_batch_search_never_syncs_and_is_capturable(native):
 
 def test_fp16_shadow_follows_the_index(native):
     """Batches of 33+ queries at d = 256 / 384 / 512 nominate from an fp16 SHADOW of the rows (flat_scan_h16_kernel: half the
-    bytes of the fp32 rows, no conversion).  It is built by the first such search, extended by add, dropped by remove_rows and
+    bytes of the fp32 rows, no conversion).  It is built by the first such search, extended by add, emptied by remove_rows and
     by adds that change the scale (a larger row norm), rebuilt on demand — and every result equals the oracle's and, bit for
     bit, what the same index returns with the shadow switched off (the nomination arithmetic is the same; the returned scores are
     fp32 re-scores either way)."""
