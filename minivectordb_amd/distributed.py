@@ -291,11 +291,13 @@ class DistributedShardedVectorDatabase:
     brought up once per database and shared by the per-k searchers; `close()` releases it.
 
     `index_factory` / `local_search` / `merge` exist for the world_size-2 ``gloo`` test on CPU; `collective`
-    ("native" | "torch") and `exchange_always` for the one-GPU test of the RCCL route at world = 1.
+    ("native" | "torch") and `exchange_always` for the one-GPU test of the RCCL route at world = 1.  `fast_single_query`:
+    VectorDatabase's switch, for every rank's local index.
     """
 
     def __init__(self, storage_dir='db_shards', rank=None, world=None, device=None, group=None,
-                 index_factory=None, local_search=None, merge=None, collective=None, exchange_always=False):
+                 index_factory=None, local_search=None, merge=None, collective=None, exchange_always=False,
+                 fast_single_query=False):
         import pickle
         from collections import defaultdict
 
@@ -356,6 +358,8 @@ class DistributedShardedVectorDatabase:
                 from . import _native
                 index_factory = lambda d: _native.FlatIndex(d, device=self.device.index or 0)  # noqa: E731
             self.index = index_factory(self.embedding_size)
+            if fast_single_query:   # single queries through the certified fp16-shadow pass too (VectorDatabase's switch)
+                self.index.set_option("shadow_single_query", 1)
             if pieces:
                 self.index.add(np.ascontiguousarray(np.concatenate(pieces, axis=0)), normalize=True)
         self._local_search = local_search
