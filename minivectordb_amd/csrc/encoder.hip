@@ -233,6 +233,33 @@ __global__ __launch_bounds__(256) void ln_kernel(const float* __restrict__ y,
     wave_layernorm<VPT, FULL>(v, H, lane, eps, gamma, beta, x + (int64_t)p * H, xp ? xp + (int64_t)p * H : nullptr);
 }
 
+// x[p,:] = LN(P[0][p,:] + ... + P[nparts - 1][p,:] + bias + x[p,:]): the planes of a split-K GEMM (EPI_PARTIAL), summed in plane
+// order, then the bias and the residual row (x itself: read whole before it is overwritten, by the wave that owns the row)
+template <int VPT, bool FULL>
+__global__ __launch_bounds__(256) void ln_partials_kernel(const float* __restrict__ P, int nparts, int64_t plane,
+                                                          const float* __restrict__ bias, const int* __restrict__ seq_start, int B,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                          int H, float* x, float* __restrict__ xp) {
+    const int T = seq_start[B];
+    const int lane = threadIdx.x & 63;
+    const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (p >= T) return;
+    float v[VPT];
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+        const int c = lane + i * 64;
+        const bool ok = FULL || c < H;
+        float a = 0.f;
+        if (ok) {
+            a = P[(int64_t)p * H + c];
+            for (int z = 1; z < nparts; ++z) a += P[z * plane + (int64_t)p * H + c];
+            a = (a + bias[c]) + x[(int64_t)p * H + c];
+        }
+        v[i] = a;
+    }
+    wave_layernorm<VPT, FULL>(v, H, lane, eps, gamma, beta, x + (int64_t)p * H, xp ? xp + (int64_t)p * H : nullptr);
+}
+
 // out[b,:] = normalize(mean over the sequence's tokens)   — average_pool + F.normalize(eps=1e-12)
 // pooling == 1: the first valid token (CLS) instead of the mean — BGE-M3's dense_vecs
 __global__ __launch_bounds__(256) void pool_norm_kernel(const float* __restrict__ x,
@@ -287,7 +314,8 @@ __global__ __launch_bounds__(256) void unpack_hidden_kernel(const float* __restr
 // =================================================================================================
 // EPI_BIAS_QKV (split-precision GEMM only): bias, the first `qcols` columns (the queries) scaled by `qscale`
 // (log2(e) / sqrt(head_dim): the attention kernel's score scale), output written as (hi | lo) fp16 lines
-enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_RESIDUAL = 2, EPI_BIAS_QKV = 3 };
+enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_RESIDUAL = 2, EPI_BIAS_QKV = 3,
+       EPI_PARTIAL = 4 };  // split-K (split-precision GEMM only): the bare partial sum acc / wscale of this workgroup's K range
 
 constexpr int GBK = 16;  // k granularity of the exact fp32 GEMM tiles (hidden / intermediate must be multiples)
 
@@ -902,7 +930,8 @@ __device__ __forceinline__ void x3_epilogue(const f32x16 (&acc)[TM][TN], int row
             float v[16];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias + cbc + 8 * g + 4 * fh);
+                f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+                if (EPI != EPI_PARTIAL) b4 = *reinterpret_cast<const f32x4*>(bias + cbc + 8 * g + 4 * fh);
                 f32x4 r4 = {0.f, 0.f, 0.f, 0.f};
                 if (EPI == EPI_BIAS_RESIDUAL) r4 = *reinterpret_cast<const f32x4*>(R + rbase + cbc + 8 * g + 4 * fh);
 #pragma unroll
@@ -1033,9 +1062,20 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_x3_dma_kernel(const _Float16*
             dsto[i] = kA + qq * 1024;
         }
     }
+    // EPI_PARTIAL (split-K, grid z = the split): this workgroup sums K-steps [kt_base, kt_base + nk) and stores the bare partial
+    // into plane z of C (planes `qcols` rows apart); ln_partials_kernel adds the planes, the bias and the residual
+    const int nk_all = K / 32;
+    int kt_base = 0, nk_mine = nk_all;
+    if (EPI == EPI_PARTIAL) {
+        const int per = (nk_all + (int)gridDim.z - 1) / (int)gridDim.z;
+        kt_base = (int)blockIdx.z * per;
+        nk_mine = nk_all - kt_base < per ? nk_all - kt_base : per;
+        if (nk_mine < 0) nk_mine = 0;
+        C += (int64_t)blockIdx.z * qcols * N;
+    }
     auto issue_piece = [&](int kt, int stage, int i) {
         if (DBG == 2) return;
-        const char* src = sbase[i] + (int64_t)kt * kstep[i];
+        const char* src = sbase[i] + (int64_t)(kt_base + kt) * kstep[i];
         __builtin_amdgcn_global_load_lds((enc_gbl_ptr)(src + voff[i]), (enc_lds_ptr)(xsm + stage * kStage + dsto[i]), 16, 0, 0);
     };
     auto issue = [&](int kt, int stage) {
@@ -1062,7 +1102,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_x3_dma_kernel(const _Float16*
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int nk = DBG == 4 ? 0 : K / 32;
+    const int nk = DBG == 4 ? 0 : nk_mine;
     // ring: NST - 1 stages in flight.  Stages past the end are issued too (clamped to the last K-step, into buffers
     // nobody reads) so that every counted wait sees a full ring.
     if (nk > 0) {
@@ -2584,6 +2624,42 @@ int ensure_x3_weights(mvdb_encoder* e, hipStream_t s) {
     return 0;
 }
 
+// Small batches (one sentence per call is the reference's own API shape): the N = H GEMM over K = F is 3 column tiles x a
+// handful of row bands, each walking all F / 32 K-steps alone — 21 us of a 60-us layer at T = 16.  Split over K instead:
+// `parts` planes of bare partial sums (EPI_PARTIAL), added up with the bias and the residual by ln_partials_kernel.
+// Used when the unsplit grid would leave three quarters of the CUs idle and K is long (x3_splitk_parts); the summation order over K
+// then differs from the unsplit kernel's (rounding-level differences between a sentence embedded alone and in a large batch).
+// MVDB_GEMM_X3_SPLITK=0 switches it off.
+int x3_splitk_parts(int64_t Tmax, int N, int K, int cus) {
+    static const bool on = []() { const char* v = getenv("MVDB_GEMM_X3_SPLITK"); return !(v && *v == '0'); }();
+    if (!on || K < 32 * 24 || K % 96) return 0;   // three planes of >= 8 K-steps each
+    const int64_t tiles = ((Tmax + 63) / 64) * ((N + 127) / 128);
+    return tiles * 4 <= cus ? 3 : 0;
+}
+
+int launch_gemm_x3_splitk(const float* Aimg, const _Float16* Wp, float inv_wscale, float* planes, const int* Tptr, int64_t Tmax,
+                          int N, int K, int parts, int device, hipStream_t s) {
+    const _Float16* A = reinterpret_cast<const _Float16*>(Aimg);
+    auto kern = gemm_x3_dma_kernel<EPI_PARTIAL, 64, 3, 4, 128, 1, 0>;
+    constexpr int lds = 3 * (64 * 128 + 128 * 128);
+    MVDB_TRY(x3_set_lds((const void*)kern, lds, device));
+    dim3 grid((N + 127) / 128, (unsigned)((Tmax + 63) / 64), (unsigned)parts);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, A, Wp, inv_wscale, (const float*)nullptr, (const float*)nullptr, planes, Tptr, N, K,
+                       0, device_cus(device), (int)Tmax, 1.f);
+    return 0;
+}
+
+template <int VPT>
+void launch_ln_partials(const float* planes, int parts, int64_t plane, const float* bias, const int* seq_start, int B, const float* g,
+                        const float* b, float eps, int H, float* x, float* xp, int64_t Tmax, hipStream_t s) {
+    if (H == VPT * 64)
+        hipLaunchKernelGGL((ln_partials_kernel<VPT, true>), dim3((unsigned)((Tmax + 3) / 4)), dim3(256), 0, s, planes, parts, plane, bias,
+                           seq_start, B, g, b, eps, H, x, xp);
+    else
+        hipLaunchKernelGGL((ln_partials_kernel<VPT, false>), dim3((unsigned)((Tmax + 3) / 4)), dim3(256), 0, s, planes, parts, plane, bias,
+                           seq_start, B, g, b, eps, H, x, xp);
+}
+
 template <int VPT>
 void launch_ln(const float* y, const int* seq_start, int B, const float* g, const float* b, float eps,
                int H, float* x, float* xp, int64_t Tmax, hipStream_t s) {
@@ -2664,6 +2740,7 @@ int enqueue_lane(mvdb_encoder* e, mvdb_encoder::Lane& w, const int32_t* ids, con
     // one the host knows) only at S = 512.  Default: from 128 token slots per CU.
     const int ln_env = e->opt_ln_fused;  // MVDB_GEMM_LN_FUSED as read when the encoder was created
     const bool ln_fused = compute == 2 && x3_ln_fusable(H) && ln_env != 0 && (ln_env == 2 || Tmax >= 128 * (int64_t)cus);
+    const int ffn2_parts = compute == 2 && !ln_fused ? x3_splitk_parts(Tmax, H, F, cus) : 0;
     for (const LayerW& L : e->layers) {
         if (compute == 2 && img_attn)
             MVDB_TRY(launch_gemm_x3<EPI_BIAS_QKV>(xp, L.wqkv_p, L.wqkv_is, L.bqkv, nullptr, w.qkv, Tptr, Tmax, 3 * H, H, e->device, s,
@@ -2742,6 +2819,8 @@ int enqueue_lane(mvdb_encoder* e, mvdb_encoder::Lane& w, const int32_t* ids, con
             MVDB_TRY(launch_gemm_x3<EPI_BIAS_GELU>(xp, L.w1_p, L.w1_is, L.b1, nullptr, w.ffn, Tptr, Tmax, F, H, e->device, s));
             if (ln_fused)
                 MVDB_TRY(launch_gemm_x3_ln(w.ffn, L.w2_p, L.w2_is, L.b2, L.ln2g, L.ln2b, c.ln_eps, w.x, xp, Tptr, Tmax, H, F, e->device, s));
+            else if (ffn2_parts)  // small batch: split over K into planes (the qkv buffer is free here: 3 H floats per token)
+                MVDB_TRY(launch_gemm_x3_splitk(w.ffn, L.w2_p, L.w2_is, w.qkv, Tptr, Tmax, H, F, ffn2_parts, e->device, s));
             else
                 MVDB_TRY(launch_gemm_x3<EPI_BIAS_RESIDUAL>(w.ffn, L.w2_p, L.w2_is, L.b2, w.x, w.y, Tptr, Tmax, H, F, e->device, s));
         } else {
@@ -2749,7 +2828,10 @@ int enqueue_lane(mvdb_encoder* e, mvdb_encoder::Lane& w, const int32_t* ids, con
             launch_gemm<EPI_BIAS_RESIDUAL>(w.ffn, L.w2, L.b2, w.x, w.y, Tptr, Tmax, H, F, cus, s);
         }
 #define LN2_CALL(V) launch_ln<V>(w.y, w.seq_start, B, L.ln2g, L.ln2b, c.ln_eps, H, w.x, xp, Tmax, s)
-        if (!ln_fused) { MVDB_VPT_SWITCH(LN2_CALL) }
+#define LN2P_CALL(V) launch_ln_partials<V>(w.qkv, ffn2_parts, Tmax * H, L.b2, w.seq_start, B, L.ln2g, L.ln2b, c.ln_eps, H, w.x, xp, Tmax, s)
+        if (!ln_fused && ffn2_parts) { MVDB_VPT_SWITCH(LN2P_CALL) }
+        else if (!ln_fused) { MVDB_VPT_SWITCH(LN2_CALL) }
+#undef LN2P_CALL
 #undef LN2_CALL
     }
 #undef MVDB_VPT_SWITCH

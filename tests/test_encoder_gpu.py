@@ -81,13 +81,16 @@ def test_split_precision_kernel_variants_match_golden(i, switches, gpu, monkeypa
 
 
 @pytest.mark.parametrize("env", [{"MVDB_GEMM_X3_BIG": "1"}, {"MVDB_GEMM_X3_BIG": "1", "MVDB_GEMM_X3_PERSIST": "0"},
-                                 {"MVDB_GEMM_X3_SPREAD": "0", "MVDB_GEMM_X3_SPREAD_SMALL": "0", "MVDB_GEMM_LN_SPREAD": "0"}],
-                         ids=["persistent-256-row-tiles-forced", "one-tile-per-workgroup-256-row-tiles-forced", "dma-burst"])
+                                 {"MVDB_GEMM_X3_SPREAD": "0", "MVDB_GEMM_X3_SPREAD_SMALL": "0", "MVDB_GEMM_LN_SPREAD": "0"},
+                                 {"MVDB_GEMM_X3_SPLITK": "0"}],
+                         ids=["persistent-256-row-tiles-forced", "one-tile-per-workgroup-256-row-tiles-forced", "dma-burst",
+                              "ffn2-unsplit-at-small-batches"])
 def test_gemm_tile_forms_match_golden_in_a_fresh_process(env, gpu):
     """The tile-form switches of the split-precision GEMMs are read once per process: a child pytest runs every split-mode
     golden case with (a) the persistent 256-row kernel FORCED onto batches it would never be chosen for (fewer tiles than
     CUs, a last row band of a few rows), (b) its one-tile-per-workgroup predecessor, (c) the LDS-DMA instructions issued as
-    one burst per K-step instead of between the MFMAs."""
+    one burst per K-step instead of between the MFMAs, (d) FFN2 unsplit at small batches (round 4: by default it runs split
+    over K there — which every golden case of the parent process exercises)."""
     import os
     import subprocess
     import sys
@@ -101,7 +104,8 @@ def test_gemm_tile_forms_match_golden_in_a_fresh_process(env, gpu):
 
 def test_batch_composition_does_not_change_a_row(gpu, monkeypatch):
     """A sentence's embedding is bit-for-bit the same whatever else is in the batch and wherever its rows fall in a tile
-    (the reference semantics are B = 1).  Round 3 found hipcc contracting `a * b + c` INTO the fp16 conversion of the
+    (the reference semantics are B = 1) — among batches served by the same GEMM form (here: up to 320 token slots, all on the
+    small-batch form; across the form boundaries at ~1,400 and 32,768 token slots the K sums associate differently, <= 1.2e-7).  Round 3 found hipcc contracting `a * b + c` INTO the fp16 conversion of the
     (hi | lo) split (v_fma_mixlo_f16) on one epilogue path and not on another: the inputs of the split are opaque now."""
     for fused in ("2", "0"):
         monkeypatch.setenv("MVDB_GEMM_LN_FUSED", fused)
