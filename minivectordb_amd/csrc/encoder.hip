@@ -2632,7 +2632,7 @@ int ensure_x3_weights(mvdb_encoder* e, hipStream_t s) {
 // MVDB_GEMM_X3_SPLITK=0 switches it off.
 int x3_splitk_parts(int64_t Tmax, int N, int K, int cus) {
     static const bool on = []() { const char* v = getenv("MVDB_GEMM_X3_SPLITK"); return !(v && *v == '0'); }();
-    if (!on || K < 32 * 24 || K % 96) return 0;   // three planes of >= 8 K-steps each
+    if (!on || K < 32 * 24) return 0;   // three planes of >= 8 K-steps each (ceil(K / 96) K-steps per plane, the last one the rest)
     const int64_t tiles = ((Tmax + 63) / 64) * ((N + 127) / 128);
     return tiles * 4 <= cus ? 3 : 0;
 }
@@ -2741,6 +2741,7 @@ int enqueue_lane(mvdb_encoder* e, mvdb_encoder::Lane& w, const int32_t* ids, con
     const int ln_env = e->opt_ln_fused;  // MVDB_GEMM_LN_FUSED as read when the encoder was created
     const bool ln_fused = compute == 2 && x3_ln_fusable(H) && ln_env != 0 && (ln_env == 2 || Tmax >= 128 * (int64_t)cus);
     const int ffn2_parts = compute == 2 && !ln_fused ? x3_splitk_parts(Tmax, H, F, cus) : 0;
+    const int wo_parts = compute == 2 && !ln_fused ? x3_splitk_parts(Tmax, H, H, cus) : 0;   // (H >= 768 only: e5-large / bge-m3)
     for (const LayerW& L : e->layers) {
         if (compute == 2 && img_attn)
             MVDB_TRY(launch_gemm_x3<EPI_BIAS_QKV>(xp, L.wqkv_p, L.wqkv_is, L.bqkv, nullptr, w.qkv, Tptr, Tmax, 3 * H, H, e->device, s,
@@ -2807,13 +2808,18 @@ int enqueue_lane(mvdb_encoder* e, mvdb_encoder::Lane& w, const int32_t* ids, con
             }
             if (ln_fused)
                 MVDB_TRY(launch_gemm_x3_ln(ctx_img, L.wo_p, L.wo_is, L.bo, L.ln1g, L.ln1b, c.ln_eps, w.x, xp, Tptr, Tmax, H, H, e->device, s));
+            else if (wo_parts)  // small batch, long K (H >= 768): split over K like FFN2 (attention is done with qkv)
+                MVDB_TRY(launch_gemm_x3_splitk(ctx_img, L.wo_p, L.wo_is, w.qkv, Tptr, Tmax, H, H, wo_parts, e->device, s));
             else
                 MVDB_TRY(launch_gemm_x3<EPI_BIAS_RESIDUAL>(ctx_img, L.wo_p, L.wo_is, L.bo, w.x, w.y, Tptr, Tmax, H, H, e->device, s));
         }
         else
             launch_gemm<EPI_BIAS_RESIDUAL>(w.ctx, L.wo, L.bo, w.x, w.y, Tptr, Tmax, H, H, cus, s);
 #define LN1_CALL(V) launch_ln<V>(w.y, w.seq_start, B, L.ln1g, L.ln1b, c.ln_eps, H, w.x, xp, Tmax, s)
-        if (!ln_fused) { MVDB_VPT_SWITCH(LN1_CALL) }
+#define LN1P_CALL(V) launch_ln_partials<V>(w.qkv, wo_parts, Tmax * H, L.bo, w.seq_start, B, L.ln1g, L.ln1b, c.ln_eps, H, w.x, xp, Tmax, s)
+        if (!ln_fused && wo_parts) { MVDB_VPT_SWITCH(LN1P_CALL) }
+        else if (!ln_fused) { MVDB_VPT_SWITCH(LN1_CALL) }
+#undef LN1P_CALL
 #undef LN1_CALL
         if (compute == 2) {
             MVDB_TRY(launch_gemm_x3<EPI_BIAS_GELU>(xp, L.w1_p, L.w1_is, L.b1, nullptr, w.ffn, Tptr, Tmax, F, H, e->device, s));
