@@ -100,6 +100,15 @@ def main():
     inc["store_1000_singles_s"] = round(t_store, 4)
     inc["query_after_1000_single_stores_ms (one coalesced add)"] = round((time.perf_counter() - t0) * 1e3, 3)
     assert "burst500" in idsb[:2]
+    # the batch API (an extension): 64 queries under no filter / under one filter in ONE call
+    qb = q[:64]
+    db.find_most_similar_batch(qb, k=10)
+    t0 = time.perf_counter(); many = db.find_most_similar_batch(qb, k=10)
+    inc["find_most_similar_batch_64_queries_ms"] = round((time.perf_counter() - t0) * 1e3, 3)
+    db.find_most_similar_batch(qb, k=10, metadata_filter={"bucket": 31})
+    t0 = time.perf_counter(); db.find_most_similar_batch(qb, k=10, metadata_filter={"bucket": 31})
+    inc["find_most_similar_batch_64_queries_filtered_ms"] = round((time.perf_counter() - t0) * 1e3, 3)
+    assert list(many[5][0]) == list(db.find_most_similar(qb[5], k=10)[0])
     v = db.get_vector("new0")
     assert abs(float(np.linalg.norm(v)) - 1.0) < 1e-5   # read back from the device, normalised there
     t_append_query, t_delete_query = float(np.median(app)), float(np.median(dele))

@@ -265,3 +265,33 @@ def test_shard_cursor_equals_the_scan(tmp_path, oracle_backend):
     assert again.unique_ids == stacked and sorted(stacked) == sorted(alive)
     ids, _, metas = again.find_most_similar(x[alive[0]], k=1)
     assert ids[0] == alive[0] and metas[0] == {"i": alive[0]}
+
+
+def test_find_most_similar_batch_equals_one_query_at_a_time(tmp_path, monkeypatch):
+    """find_most_similar_batch (an extension: several queries under one filter in one call) returns, per query, exactly what
+    find_most_similar returns — ids, distances, metadata, the empty-result and autocut conventions — for both classes."""
+    import numpy as np
+    from minivectordb_amd import ShardedVectorDatabase, VectorDatabase, _native
+    from oracle_backend import OracleIndex
+    monkeypatch.setattr(_native, "FlatIndex", OracleIndex)
+    rs = np.random.RandomState(3)
+    n, d = 300, 16
+    x = rs.randn(n, d).astype(np.float32)
+    meta = [{"bucket": i % 5, "tag": "a" if i % 2 else "b"} for i in range(n)]
+    q = rs.randn(9, d).astype(np.float32)
+    for db in (VectorDatabase(storage_file=str(tmp_path / "f.pkl")),
+               ShardedVectorDatabase(storage_dir=str(tmp_path / "s"), shard_size=64)):
+        assert db.find_most_similar_batch(q, k=3) == [([], [], [])] * 9          # empty database
+        db.store_embeddings_batch([f"id{i}" for i in range(n)], x, meta)
+        for kwargs in ({}, {"metadata_filter": {"bucket": 2}}, {"exclude_filter": {"tag": "a"}},
+                       {"or_filters": [{"bucket": 1}, {"bucket": 4}], "k": 7}, {"metadata_filter": {"bucket": 99}},
+                       {"k": 12, "autocut": True}):
+            many = db.find_most_similar_batch(q, **kwargs)
+            assert len(many) == 9
+            for i in range(9):
+                one = db.find_most_similar(q[i], **kwargs)
+                assert list(many[i][0]) == list(one[0]) and list(many[i][2]) == list(one[2]), (kwargs, i)
+                np.testing.assert_allclose(np.asarray(many[i][1], dtype=np.float64), np.asarray(one[1], dtype=np.float64), atol=1e-6)
+                assert type(many[i][0]) is type(one[0])
+        with __import__("pytest").raises(ValueError):
+            db.find_most_similar_batch(q[0], k=3)
