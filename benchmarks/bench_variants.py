@@ -90,6 +90,23 @@ def main():
             out[f"nq{nb}_qps"] = round(nb / dtb, 1)
         rse.close()
         print(json.dumps(out), flush=True)
+    # BATCHES under a resident row LIST (a filter keeping 30 % / 5 % of the rows stays a list): round 4 — the list's bitmap twin lets
+    # a batch share corpus passes where that beats one gathered scan per query
+    for frac in (0.3, 0.05):
+        keep = np.sort(rs.choice(n, int(n * frac), replace=False)).astype(np.int64)
+        rsl = idx.rowset(keep)
+        out = {"what": f"batches under a resident row LIST keeping {frac:g} of the rows, k=10, host API", "is_bitmap": bool(rsl.is_bitmap)}
+        for nb in (1, 8, 64, 256):
+            out[f"nq{nb}_ms"] = round(timeit(lambda: idx.search_rowset(qb[:nb], 10, rsl), 5) * 1e3, 3)
+        os.environ["MVDB_DISABLE_MASKED_BATCH"] = "1"
+        idx.reload_env()
+        for nb in (8, 64):
+            out[f"nq{nb}_ms_one_gathered_scan_per_query (MVDB_DISABLE_MASKED_BATCH=1)"] = round(
+                timeit(lambda: idx.search_rowset(qb[:nb], 10, rsl), 3) * 1e3, 3)
+        del os.environ["MVDB_DISABLE_MASKED_BATCH"]
+        idx.reload_env()
+        rsl.close()
+        print(json.dumps(out), flush=True)
     rows = rs.permutation(n)[:n // 10].astype(np.int64)
     dt = timeit(lambda: idx.search_subset(q[0], 10, rows), 10)
     print(json.dumps({"what": "subset search, 0.1 of the rows (random order), k=10", "rows": len(rows),

@@ -206,7 +206,9 @@ int mvdb_index_search_masked_device(const mvdb_index* idx, const float* q_dev, i
  * over the list nor its upload again.  excluded == 0: the m listed rows (labels order ties by list position, as
  * mvdb_index_search_subset); excluded != 0: every row BUT the listed ones (an exclude-filter: m is small, the set is
  * ~ntotal rows).  The library picks the representation: a bitmap (n / 8 bytes; one full-rate pass per search) for excluded
- * sets and for sorted lists that keep >= 90 % of the rows, a device row list otherwise.  A set belongs to the index state it
+ * sets and for sorted lists that keep >= 90 % of the rows, a device row list otherwise — a SORTED list (>= 1 row in 64) also
+ * carries its bitmap, under which a BATCH of queries shares corpus passes where that beats one gathered scan per query (10M x
+ * 512, 30 % of the rows: 64 queries 1.7 ms instead of 58 ms).  A set belongs to the index state it
  * was built against: rows appended later are not part of it; after a removal (rows renumbered) searching it fails with
  * MVDB_ERR_ARG. */
 typedef struct mvdb_rowset mvdb_rowset;

@@ -2267,6 +2267,13 @@ int mvdb_index_search_masked(const mvdb_index* idx, const float* q_host, int nq,
 // row list on the device.  Results carry ROW NUMBERS.
 }  // extern "C"
 
+// would search_core answer a bitmap-selected batch of nq queries on shared corpus passes? (its own conditions, restated)
+static bool masked_batch_possible(const mvdb_index* idx, int nq, int k, int64_t n) {
+    if (nq < 2 || k > kMaxFusedK || idx->ld != idx->d || idx->kn.disable_masked_batch) return false;
+    if (idx->metric == MVDB_METRIC_IP) return mfma_gated_queries(idx) > 0;
+    return (l2_cert_ok(idx) || l2_offsets_ok(idx, nq, n)) && half_path_ok(idx) && nq >= half_min_nq(idx, n);
+}
+
 struct mvdb_rowset {
     int device = 0;
     int64_t n_at_create = 0;  // the index's row count the set was built against
@@ -2274,6 +2281,8 @@ struct mvdb_rowset {
     int64_t count = 0;        // rows selected
     int64_t* rows = nullptr;  // list form (device), in the caller's order
     uint64_t* mask = nullptr; // bitmap form (device)
+    uint64_t* twin = nullptr; // list form, sorted, n >= 4096: the same rows as a bitmap too (n / 8 bytes) — what a BATCH of queries
+                              // is searched under when sharing corpus passes beats one gathered scan per query (rowset_search_core)
 };
 
 extern "C" {
@@ -2334,10 +2343,22 @@ int mvdb_rowset_create(const mvdb_index* idx, const int64_t* rows_host, int64_t 
         rs->count = m;
         e = hipMalloc((void**)&rs->rows, (size_t)std::max<int64_t>(m, 1) * sizeof(int64_t));
         if (e == hipSuccess && m > 0) e = hipMemcpy(rs->rows, rows_host, (size_t)m * sizeof(int64_t), hipMemcpyHostToDevice);
+        if (e == hipSuccess && sorted && n >= 4096 && m * 64 >= n) {   // (sparser than 1 row in 64: no batch is better off under a bitmap)
+            const size_t words = (size_t)((n + 63) / 64);
+            std::vector<uint64_t> w(words, 0ull);
+            for (int64_t i = 0; i < m; ++i) w[rows_host[i] >> 6] |= 1ull << (rows_host[i] & 63);
+            if (hipMalloc((void**)&rs->twin, words * sizeof(uint64_t)) != hipSuccess ||
+                hipMemcpy(rs->twin, w.data(), words * sizeof(uint64_t), hipMemcpyHostToDevice) != hipSuccess) {
+                (void)hipGetLastError();   // the twin is an optimisation: without it batches answer one query at a time
+                if (rs->twin) (void)hipFree(rs->twin);
+                rs->twin = nullptr;
+            }
+        }
     }
     if (e != hipSuccess) {
         if (rs->mask) (void)hipFree(rs->mask);
         if (rs->rows) (void)hipFree(rs->rows);
+        if (rs->twin) (void)hipFree(rs->twin);
         delete rs;
         return fail(MVDB_ERR_HIP, "row set upload failed: %s", hipGetErrorString(e));
     }
@@ -2354,6 +2375,7 @@ int mvdb_rowset_free(mvdb_rowset* rs) {
         DeviceGuard dg(rs->device);
         if (rs->mask) (void)hipFree(rs->mask);
         if (rs->rows) (void)hipFree(rs->rows);
+        if (rs->twin) (void)hipFree(rs->twin);
     }
     delete rs;
     return 0;
@@ -2380,6 +2402,18 @@ static int rowset_search_core(const mvdb_index* idx, Workspace* ws, const float*
     }
     if (rs->mask)
         return search_core(idx, ws, q, nq, k, normalize_q, nullptr, rs->n_at_create, label_offset, D_dev, I_dev, true, rs->mask);
+    // A batch under a LIST: one gathered scan per query costs nq x (fraction of the rows) full passes; under the list's bitmap
+    // twin the queries share corpus passes (the certified pass over the fp16 shadow: ~0.6 of a full pass per 128 / 256
+    // queries; else the fp32-MFMA pass: one per 16 / 32 queries).  Same labels, same tie order (the list is sorted).
+    if (rs->twin && masked_batch_possible(idx, nq, k, rs->n_at_create)) {
+        const int64_t n = rs->n_at_create;
+        const bool half = half_path_ok(idx) && nq >= half_min_nq(idx, n);
+        const int per = half ? std::max(1, half_max_queries(idx->d)) : std::max(1, mfma_gated_queries(idx));
+        const double shared = (double)((nq + per - 1) / per) * (half && idx->Xh ? 0.6 : 1.0);
+        const double gathered = (double)nq * (double)rs->count / (double)n * 1.1;
+        if (shared < gathered)
+            return search_core(idx, ws, q, nq, k, normalize_q, nullptr, n, label_offset, D_dev, I_dev, true, rs->twin);
+    }
     MVDB_TRY(search_core(idx, ws, q, nq, k, normalize_q, rs->rows, rs->count, 0, D_dev, I_dev));
     hipLaunchKernelGGL(map_subset_labels_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ws->stream, I_dev, total,
                        (const int64_t*)rs->rows, label_offset);

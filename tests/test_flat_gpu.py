@@ -1434,6 +1434,54 @@ def test_masked_search_edge_cases(native):
     idx.close()
 
 
+@pytest.mark.parametrize("metric", [flat.METRIC_IP, flat.METRIC_L2])
+def test_batches_under_a_resident_row_list_share_corpus_passes(native, metric):
+    """A sorted row LIST kept resident (a filter keeping 30 % of the rows stays a list: one gathered scan per query costs
+    0.3 passes) also carries its bitmap twin: a BATCH of 40 queries under it is searched on shared corpus passes (round 4) —
+    same row labels, ties to the lower row as in the list —, a single query and an UNSORTED list keep the gathered scan."""
+    n, d, k, nq = 200_000, 256, 10, 40
+    x = _corpus(n, d)
+    q = _corpus(nq, d, seed=12)
+    rs = np.random.RandomState(4)
+    rows = np.sort(rs.choice(n, int(0.3 * n), replace=False)).astype(np.int64)
+    x[rows[100]] = x[rows[5000]]                                 # an exact tie inside the selection
+    q[3] = x[rows[100]]
+    idx = native.FlatIndex(d, metric=native.METRIC_L2 if metric == flat.METRIC_L2 else native.METRIC_IP)
+    idx.add(x)
+    s = idx.rowset(rows)
+    assert not s.is_bitmap and len(s) == len(rows)
+    native.prof_enable(True)
+    try:
+        _split_launches(native)
+        D, I = idx.search_rowset(q, k, s)
+        assert _split_launches(native) > 0, "the batch did not share corpus passes"
+        D1, I1 = idx.search_rowset(q[3], k, s)                  # one query: the gathered scan
+        assert _split_launches(native) == 0
+    finally:
+        native.prof_enable(False)
+    sel = np.zeros(n, bool)
+    sel[rows] = True
+    assert sel[I].all()
+    assert I[3, :2].tolist() == sorted([int(rows[100]), int(rows[5000])])
+    assert np.array_equal(I1[0], I[3])
+    np.testing.assert_allclose(D1[0], D[3], atol=4e-6, rtol=0)
+    _check(native, x, q, k, D, np.searchsorted(rows, I), rows=rows, metric=metric)
+    shuffled = rows[rs.permutation(len(rows))]
+    s2 = idx.rowset(shuffled)
+    native.prof_enable(True)
+    try:
+        _split_launches(native)
+        D2, I2 = idx.search_rowset(q[:4], k, s2)
+        assert _split_launches(native) == 0                     # caller's order decides ties: no bitmap twin
+    finally:
+        native.prof_enable(False)
+    for i in (0, 1, 2):
+        assert np.array_equal(I2[i], I[i])
+    s.close()
+    s2.close()
+    idx.close()
+
+
 def test_resident_row_sets(native):
     """mvdb_rowset: a filter's rows made resident once.  An unsorted list stays a list (ties by list position, as the
     reference's sub-index); a sorted list that keeps 90 % of the rows, and every 'all but these' set, become bitmaps;
