@@ -243,6 +243,14 @@ class _IdIndex:
         self.uids.append(uid)
         self._touched()
 
+    def extend(self, uids):
+        """append() for a whole batch (a later duplicate id takes the handle over, as one append after the other would)."""
+        uids = list(uids)
+        self.handle.update(zip(uids, range(self.next, self.next + len(uids))))
+        self.next += len(uids)
+        self.uids.extend(uids)
+        self._touched()
+
     def row(self, uid):
         h = self.handle[uid]
         return h - bisect.bisect_left(self.deleted, h) if self.deleted else h
@@ -416,16 +424,22 @@ class FilterAndRerankMixin:
             self._mat = _RowStore(self.embedding_size)
         first = self._mat.n
         if len(vectors):
-            self._mat.append(vectors[0] if len(vectors) == 1 else np.vstack(vectors))
+            if isinstance(vectors, np.ndarray) and vectors.ndim == 2:   # a batch that arrived as ONE float32 matrix: no per-row work
+                self._mat.append(vectors[0] if vectors.shape[0] == 1 else vectors)
+            else:
+                self._mat.append(vectors[0] if len(vectors) == 1 else np.vstack(vectors))
         self.metadata.extend(metadata_dicts)
         values = self._live_value_index()
+        handle = self._ids.next
+        self._ids.extend(unique_ids)
+        inverted = self.inverted_index
         for uid, meta in zip(unique_ids, metadata_dicts):
-            handle = self._ids.next
-            self._ids.append(uid)
-            for key in meta:
-                self.inverted_index[key].add(uid)
-            if values is not None and meta:
-                values.note_store(handle, meta)
+            if meta:
+                for key in meta:
+                    inverted[key].add(uid)
+                if values is not None:
+                    values.note_store(handle, meta)
+            handle += 1
         self._note_write()
         self._embeddings_changed = True
         return first

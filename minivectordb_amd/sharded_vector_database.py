@@ -216,7 +216,10 @@ class ShardedVectorDatabase(FilterAndRerankMixin):
         with self.lock:
             if len(unique_ids) != len(embeddings):
                 raise ValueError("Number of unique IDs must match number of embeddings.")
-            vectors = self._convert_ndarray_float32_batch(embeddings)
+            if isinstance(embeddings, np.ndarray) and embeddings.ndim == 2 and len(embeddings) > 1:
+                vectors = np.array(embeddings, dtype=np.float32)   # one copy of the whole batch instead of one array per row
+            else:
+                vectors = self._convert_ndarray_float32_batch(embeddings)
             for uid in unique_ids:
                 if uid in self._ids:
                     raise ValueError(f"Unique ID {uid} already exists.")

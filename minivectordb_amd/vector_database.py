@@ -124,7 +124,10 @@ class VectorDatabase(FilterAndRerankMixin):
         with self.lock:
             if any(uid in self._ids for uid in unique_ids):
                 raise ValueError("Unique ID already exists.")
-            vectors = self._convert_ndarray_float32_batch(embeddings)
+            if isinstance(embeddings, np.ndarray) and embeddings.ndim == 2 and len(embeddings) > 1:
+                vectors = np.array(embeddings, dtype=np.float32)   # one copy of the whole batch instead of one array per row
+            else:
+                vectors = self._convert_ndarray_float32_batch(embeddings)
             # like the reference: a partial metadata list is an error, an empty one means "no metadata"
             if 0 < len(metadata_dicts) < len(unique_ids):
                 raise ValueError("Metadata dictionaries must be provided for all unique IDs.")
