@@ -499,6 +499,10 @@ class DistributedShardedVectorDatabase:
             q_dev = torch.from_numpy(q).to(self.device)
         Dg, Ig = self._searcher(search_k).search_device(q_dev, rows=rows, normalize_q=True)
         Dg, Ig = self._host_results(Dg, Ig)
+        return self._package_row(Ig, Dg, autocut)
+
+    def _package_row(self, Ig, Dg, autocut):
+        """One query's merged (global row, distance) pairs -> (ids, distances, metadatas) in the reference's conventions."""
         found = [(self.unique_ids[i], d, self.metadata[i]) for i, d in zip(Ig, Dg) if i >= 0]
         ids, distances, metadatas = zip(*found) if found else ([], [], [])
         if autocut and len(distances) > 1:
@@ -508,3 +512,31 @@ class DistributedShardedVectorDatabase:
                 distances = [distances[i] for i in range(len(distances)) if i not in remove]
                 metadatas = [metadatas[i] for i in range(len(metadatas)) if i not in remove]
         return ids, distances, metadatas
+
+    def find_most_similar_batch(self, embeddings, metadata_filter=None, exclude_filter=None, or_filters=None, k=5,
+                                autocut=False):
+        """Several queries under ONE filter in one collective call (every rank passes the same queries): element i is what
+        ``find_most_similar(embeddings[i], ...)`` returns.  One local batch search per rank, one all-gather of the packed
+        per-shard top-k of all queries, one merge (the shape `bench.py --nq N` times)."""
+        np = self._np
+        queries = np.ascontiguousarray(np.asarray(embeddings, dtype=np.float32))
+        if queries.ndim != 2:
+            raise ValueError("embeddings must be a 2-D array-like, one query per row")
+        nq = queries.shape[0]
+        n_total = len(self.unique_ids)
+        empty = [([], [], []) for _ in range(nq)]
+        if nq == 0 or n_total == 0 or self.index is None:
+            return empty
+        if metadata_filter or exclude_filter or or_filters:
+            hits, rows = self._local_rows_of(metadata_filter, exclude_filter, or_filters)
+        else:
+            hits, rows = n_total, None
+        if not hits:
+            return empty
+        search_k = min(k, hits)
+        if self.world * search_k > 16384:
+            raise NotImplementedError("DistributedShardedVectorDatabase merges at most 16384 / world results per query")
+        q_dev = torch.from_numpy(queries).to(self.device)
+        Dg, Ig = self._searcher(search_k).search_device(q_dev, rows=rows, normalize_q=True)
+        Dh, Ih = Dg.cpu().numpy(), Ig.cpu().numpy()
+        return [self._package_row(Ih[i], Dh[i], autocut) for i in range(nq)]

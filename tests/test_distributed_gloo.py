@@ -194,6 +194,14 @@ def _dist_worker(rank, world, port, path, out_dir):
         again = db.find_most_similar(q[i], **kw)
         assert list(again[0]) == res[i][0]
     assert db.rowsets_built == built and [c for c in db.index.calls if c[0] == "rowset"] == uploads
+    # the batch form: every rank passes the same queries, element j is the single-query answer under that filter
+    for i, kw in enumerate(QUERIES):
+        many = db.find_most_similar_batch(q[:4], **kw)
+        assert len(many) == 4
+        assert list(many[i][0]) == res[i][0] if i < 4 else True
+        for j in range(4):
+            one = db.find_most_similar(q[j], **kw)
+            assert list(many[j][0]) == list(one[0]) and list(many[j][2]) == list(one[2]), (kw, j)
     with open(os.path.join(out_dir, f"res{rank}.pkl"), "wb") as f:
         pickle.dump((res, db.first_row, db.local_rows), f)
     db.close()

@@ -147,6 +147,15 @@ def test_native_rccl_route_through_the_distributed_database(native, tmp_path):
                 built = db.rowsets_built
                 assert built >= 5
         assert db.rowsets_built == built
+        # several queries in one collective call: element j is the single-query answer
+        for kw in queries:
+            many = db.find_most_similar_batch(q[:5], **kw)
+            assert len(many) == 5
+            for j in range(5):
+                want = ref.find_most_similar(q[j], **kw)
+                assert list(many[j][0]) == list(want[0]), (kw, j)
+                np.testing.assert_allclose(np.array(many[j][1], dtype=np.float64), np.array(want[1], dtype=np.float64), atol=2e-6)
+                assert list(many[j][2]) == list(want[2])
         assert db._searcher(5).collective.startswith("ncclAllGather")
         db.close()
     finally:
