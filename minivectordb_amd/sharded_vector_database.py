@@ -178,6 +178,23 @@ class ShardedVectorDatabase(FilterAndRerankMixin):
     # ---- ingest (sharded_vector_database.py:104-132, :243-287) -----------------------------------------
     def _assign_to_shards(self, unique_ids, vectors, metadata_dicts):
         """One shard per row by first fit, then ONE rewrite per touched shard file (:276-287)."""
+        if isinstance(vectors, np.ndarray) and vectors.ndim == 2 and len(unique_ids) == vectors.shape[0] == len(metadata_dicts):
+            # a batch that arrived as one matrix: first fit places RUNS of consecutive rows (a shard takes rows until it is
+            # full, then the next one does) — the same placement, one slice per touched shard instead of one array per row
+            unique_ids = list(unique_ids)
+            at, total = 0, len(unique_ids)
+            while at < total:
+                shard_id = self._get_available_shard_id()
+                if shard_id not in self.box_item_map:
+                    self.box_item_map[shard_id] = []
+                    self._shard_order.append(shard_id)
+                take = min(max(1, self.shard_size - len(self.box_item_map[shard_id])), total - at)
+                run = unique_ids[at:at + take]
+                self.box_item_map[shard_id].extend(run)
+                self.inverse_box_item_map.update(dict.fromkeys(run, shard_id))
+                self._persist_to_shard_multiple(shard_id, run, vectors[at:at + take], metadata_dicts[at:at + take])
+                at += take
+            return
         placed = defaultdict(lambda: ([], [], []))
         for uid, vec, meta in zip(unique_ids, vectors, metadata_dicts):
             shard_id = self._get_available_shard_id()
@@ -204,7 +221,10 @@ class ShardedVectorDatabase(FilterAndRerankMixin):
 
     def _persist_to_shard_multiple(self, shard_id, unique_ids, embeddings, metadata_dicts):
         shard = self._read_shard(shard_id)
-        shard['embeddings'] = np.vstack([shard['embeddings']] + [np.atleast_2d(e) for e in embeddings])
+        if isinstance(embeddings, np.ndarray) and embeddings.ndim == 2:
+            shard['embeddings'] = np.vstack([shard['embeddings'], embeddings])
+        else:
+            shard['embeddings'] = np.vstack([shard['embeddings']] + [np.atleast_2d(e) for e in embeddings])
         shard['metadata'].extend(metadata_dicts)
         shard['unique_ids'].extend(unique_ids)
         for uid, meta in zip(unique_ids, metadata_dicts):

@@ -148,3 +148,41 @@ def test_fast_single_query_kwarg_reaches_the_index(tmp_path, monkeypatch):
         db.store_embeddings_batch(list(range(6)), x)
         db.find_most_similar(x[0], k=2)
         assert not any(c[0] == "set_option" for c in db.index.calls if isinstance(c, tuple))
+
+
+def test_matrix_batches_are_stored_exactly_like_row_lists(tmp_path, monkeypatch):
+    """store_embeddings_batch fast paths (a batch that arrives as ONE float32 matrix: no per-row arrays, shard placement by runs):
+    the shard files are byte-identical to those of the per-row path, the bookkeeping and the searches equal — both classes,
+    batches that straddle shard boundaries, a partly filled last shard, a single-row batch."""
+    import filecmp
+    import os
+    from minivectordb_amd import ShardedVectorDatabase, VectorDatabase, _native
+    monkeypatch.setattr(_native, "FlatIndex", OracleIndex)
+    rs = np.random.RandomState(5)
+    n, d = 1000, 12
+    x = rs.randn(n, d).astype(np.float32)
+    meta = [{"bucket": i % 7, "i": i} if i % 3 else {} for i in range(n)]
+    cuts = [0, 1, 130, 131, 640, 1000]
+    dbs = []
+    for as_matrix in (True, False):
+        sdir = str(tmp_path / f"s{int(as_matrix)}")
+        sh = ShardedVectorDatabase(storage_dir=sdir, shard_size=64)
+        fl = VectorDatabase(storage_file=str(tmp_path / f"f{int(as_matrix)}.pkl"))
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            block = x[a:b] if as_matrix else [row for row in x[a:b]]
+            sh.store_embeddings_batch([f"u{i}" for i in range(a, b)], block, list(meta[a:b]))
+            fl.store_embeddings_batch([f"u{i}" for i in range(a, b)], block, list(meta[a:b]))
+        dbs.append((sh, fl, sdir))
+    (sh1, fl1, d1), (sh0, fl0, d0) = dbs
+    names = sorted(os.listdir(d1))
+    assert names == sorted(os.listdir(d0)) and len(names) == 16
+    assert all(filecmp.cmp(os.path.join(d1, f), os.path.join(d0, f), shallow=False) for f in names)
+    assert sh1.box_item_map == sh0.box_item_map and sh1.inverse_box_item_map == sh0.inverse_box_item_map
+    assert sh1.unique_ids == sh0.unique_ids and sh1.metadata == sh0.metadata
+    assert dict(sh1.inverted_index) == dict(sh0.inverted_index) and dict(fl1.inverted_index) == dict(fl0.inverted_index)
+    assert fl1.inverse_id_map == fl0.inverse_id_map and fl1.metadata == fl0.metadata
+    assert np.array_equal(fl1.embeddings, fl0.embeddings) and np.array_equal(sh1.embeddings, sh0.embeddings)
+    for a, b in ((sh1, sh0), (fl1, fl0)):
+        r1 = a.find_most_similar(x[77], k=5, metadata_filter={"bucket": 0})
+        r0 = b.find_most_similar(x[77], k=5, metadata_filter={"bucket": 0})
+        assert list(r1[0]) == list(r0[0]) and list(r1[2]) == list(r0[2])
