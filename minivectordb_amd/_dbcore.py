@@ -317,6 +317,9 @@ class _IdIndex:
         return self._row_dict
 
 
+_NO_FIELD = object()
+
+
 class _ValueIndex:
     """Equality filters without the reference's pass over every id per query (vector_database.py:283-302, :332-345).
 
@@ -335,12 +338,31 @@ class _ValueIndex:
         self.keys = {}   # key -> (by_value: {value: array('q') of handles}, odd: {handle: unhashable field})
 
     def _build(self, key, uids, ids, metadata):
+        by_value, odd = {}, {}
+        if 2 * len(uids) >= len(metadata) == len(ids.uids):
+            # most rows carry the key: walk the rows in order — handles ascend with the rows, so nothing is sorted and no id is
+            # looked up (a million rows: ~0.15 s instead of ~0.3 s)
+            missing = _NO_FIELD
+            handle_of = ids.handle
+            handles = range(len(metadata)) if not ids.deleted and ids.next == len(metadata) else [handle_of[u] for u in ids.uids]
+            for h, meta in zip(handles, metadata):
+                field = meta.get(key, missing)
+                if field is missing:
+                    continue
+                try:
+                    slot = by_value.get(field)
+                    if slot is None:
+                        slot = by_value[field] = array('q')
+                    slot.append(h)
+                except TypeError:   # list / dict metadata value
+                    odd[h] = field
+            self.keys[key] = (by_value, odd)
+            return by_value, odd
         pairs = []
         for uid in uids:
             if uid in ids.handle:
                 pairs.append((ids.handle[uid], metadata[ids.row(uid)].get(key, None)))
         pairs.sort(key=lambda p: p[0])
-        by_value, odd = {}, {}
         for h, field in pairs:
             try:
                 slot = by_value.get(field)
