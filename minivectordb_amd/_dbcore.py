@@ -645,7 +645,12 @@ class FilterAndRerankMixin:
         # operators (and unhashable operands) look at every row that has the key, like the reference; an exception of
         # the comparison itself ($gt against None, $in on a number) propagates, as there
         ids, found = self._ids, []
-        for uid in list(self.inverted_index.get(key, ())):
+        holders = self.inverted_index.get(key, ())
+        if 2 * len(holders) >= len(self.metadata) == len(ids.uids):
+            # most rows carry the key: one pass over the rows in order (no id lookups, nothing to sort)
+            return np.fromiter((row for row, meta in enumerate(self.metadata) if key in meta and predicate(meta[key])),
+                               dtype=np.int64)
+        for uid in list(holders):
             if uid in ids.handle:
                 row = ids.row(uid)
                 if predicate(self.metadata[row].get(key, None)):
