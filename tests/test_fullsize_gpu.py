@@ -150,3 +150,30 @@ def test_config3_10M_x_512_l2_vs_oracle(native):
     bigcheck.report({"what": "config3 L2 certified-pass re-runs during the comparison",
                      "chunks_rerun": native.split_rerun_count() - reruns})
     idx.close()
+
+
+def test_config2_1M_x_512_l2_mixed_norms_vs_oracle(native):
+    """L2 over UN-normalised rows at config 2's size (the squared norms spread over a few per cent: far beyond what the norm-range
+    certificate tolerates, so batches nominate by q.x - |x|^2 / 2 with per-row offsets, round 4): 128 queries of assorted
+    norms against the streamed oracle, 1 / 8 / 32 / 128 per call, and under a bitmap keeping half of the rows."""
+    n, d, k, nq = 1_000_000, 512, 10, 128
+    idx = native.FlatIndex(d, metric=native.METRIC_L2)
+    idx.reserve(n)
+    idx.add_synthetic(n, 1234, normalize=False)
+    q = flat.synth(nq, d, 5678)
+    q *= np.exp(np.random.RandomState(1).uniform(np.log(0.3), np.log(2.0), size=(nq, 1))).astype(np.float32)
+    keep = (np.random.RandomState(2).rand(n) < 0.5).astype(np.uint8)
+    (everything, half), cost = bigcheck.oracle_topk_streamed(idx, n, q, k, keeps=(None, keep), metric=flat.METRIC_L2)
+    reruns = native.split_rerun_count()
+    for per_call in (1, 8, 32, 128):
+        D, I = _in_chunks(lambda qs: idx.search(qs, k), q, per_call)
+        bigcheck.report(dict(bigcheck.compare(idx, q, D, I, *everything, f"config2 L2 mixed norms, {per_call} queries per call",
+                                              metric=flat.METRIC_L2), oracle_cost=cost))
+    assert idx.shadow_rows == n
+    words = _bitmap(keep)
+    for per_call in (1, 64):
+        D, I = _in_chunks(lambda qs: idx.search_masked(qs, k, words), q, per_call)
+        bigcheck.report(bigcheck.compare(idx, q, D, I, *half, f"config2 L2 mixed norms under a 50 % bitmap, {per_call} queries per call",
+                                         metric=flat.METRIC_L2))
+    bigcheck.report({"what": "config2 L2 mixed norms: certified-pass re-runs", "chunks_rerun": native.split_rerun_count() - reruns})
+    idx.close()
