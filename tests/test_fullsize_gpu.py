@@ -122,6 +122,11 @@ def test_config3_10M_x_512_every_pass_vs_oracle(native):
     for per_call in (32, 128):
         D, I = _in_chunks(lambda qs: idx.search_masked(qs, k, words), q, per_call)
         bigcheck.report(bigcheck.compare(idx, q, D, I, *half, f"config3 bitmap keeping 50 %, {per_call} queries per call"))
+    # the opt-in single-query route over the fp16 shadow (mvdb_index_set_option "shadow_single_query"): the same 100 queries
+    idx.set_option("shadow_single_query", 1)
+    D, I = _in_chunks(lambda qs: idx.search(qs, k), q[:100], 1)
+    idx.set_option("shadow_single_query", 0)
+    bigcheck.report(bigcheck.compare(idx, q[:100], D, I, Do[:100], Io[:100], "config3 10M x 512, 1 query per call over the fp16 shadow (opt-in)"))
     bigcheck.report({"what": "config3 certified-pass re-runs during the comparison",
                      "chunks_rerun": native.split_rerun_count() - reruns})
     idx.close()
