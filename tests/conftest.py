@@ -37,3 +37,23 @@ def gpu():
     """GPU tests must run on a GPU box: fail loudly instead of skipping when the device is missing."""
     assert _has_gpu(), "this test is marked gpu but no HIP device is visible"
     return 0
+
+
+def assert_product_native():
+    """The GPU tests compare the HIP library with the oracle: refuse to run them on a stand-in.  `_native.FlatIndex`
+    must be the product class and the in-tree libmvdb.so must be mapped into this process."""
+    from minivectordb_amd import _native
+    assert _native.FlatIndex.__module__ == "minivectordb_amd._native", \
+        f"_native.FlatIndex is {_native.FlatIndex!r}: a test left a stand-in behind"
+    _native.lib()
+    with open("/proc/self/maps") as f:
+        maps = f.read()
+    assert os.path.realpath(_native.LIB_PATH) in maps, f"{_native.LIB_PATH} is not mapped into this process"
+    return _native
+
+
+@pytest.fixture(autouse=True)
+def _gpu_tests_run_on_the_product(request):
+    if request.node.get_closest_marker("gpu") is not None:
+        assert_product_native()
+    yield

@@ -121,11 +121,11 @@ def _np_merge(gathered, D_out, I_out):
             I_out[qi, j] = cands[j][1] if j < len(cands) else -1
 
 
-def _build_shards(path, n=95, d=48):
+def _build_shards(path, monkeypatch, n=95, d=48):
     from minivectordb_amd import ShardedVectorDatabase, _native
     from oracle import flat
     from oracle_backend import OracleIndex
-    _native.FlatIndex = OracleIndex  # this process only builds / checks with the stand-in
+    monkeypatch.setattr(_native, "FlatIndex", OracleIndex)  # undone at the end of THIS test: the stand-in never outlives it
     db = ShardedVectorDatabase(storage_dir=path, shard_size=10)
     x = flat.synth(n, d, 321)
     colours = ["red", "green", "blue"]
@@ -209,11 +209,11 @@ def _dist_worker(rank, world, port, path, out_dir):
     dist.destroy_process_group()
 
 
-def test_distributed_database_equals_single_process(tmp_path):
+def test_distributed_database_equals_single_process(tmp_path, monkeypatch):
     import pickle
     from oracle import flat
     path = str(tmp_path / "shards")
-    ref = _build_shards(path)
+    ref = _build_shards(path, monkeypatch)
     world = 2
     port = 31500 + (os.getpid() % 2000)
     mp.spawn(_dist_worker, args=(world, port, path, str(tmp_path)), nprocs=world, join=True)
