@@ -334,6 +334,11 @@ int mvdb_encoder_forward_device(mvdb_encoder* enc, const int32_t* ids_dev, const
                                 int B, int S, int compute, float* out_dev, float* hidden_dev,
                                 void* stream);
 
+/* 1 when a forward of B x S token slots runs as the ONE layer-walking launch (csrc/encoder_walk.hpp: at most 64 token slots —
+ * one sentence per call is the reference's only shape, embedding_model.py:62-71 —, exact fp32 matrix cores whatever `compute`
+ * says), 0 when it runs the per-op kernels.  MVDB_ENCODER_WALK=0 (read at mvdb_encoder_create) switches the launch off. */
+int mvdb_encoder_walks(const mvdb_encoder* enc, int B, int S);
+
 /* Which tile form of the split-precision GEMM a batch of `tokens` packed tokens selects for an N-wide product on a
  * device with `compute_units` CUs: 256 or 192 = the 256-row form on 256 x 256 / 256 x 192 tiles (one eight-wave workgroup
  * per CU; N % 256 == 0 resp. N % 192 == 0 and the tiles make whole rounds of the CUs: >= 1 round, and >= 4 rounds or a

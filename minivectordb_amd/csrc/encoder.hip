@@ -38,6 +38,10 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+}  // namespace
+#include "encoder_walk.hpp"
+namespace {
+
 // =================================================================================================
 // packing
 // =================================================================================================
@@ -2260,6 +2264,12 @@ struct mvdb_encoder {
     float* out_stage = nullptr;
     int64_t stage_cap = 0, out_cap = 0;
     hipStream_t stream = nullptr;
+    // small batches (<= walk::kTmax token slots): the layer-walking persistent launch (encoder_walk.hpp)
+    int opt_walk = 1;                       // MVDB_ENCODER_WALK as read when the encoder was created (0: the per-op kernels)
+    walk::LayerPtrs* walk_layers = nullptr; // device copy of the per-layer weight pointers
+    float *walk_x = nullptr, *walk_x1 = nullptr, *walk_qkv = nullptr, *walk_pl = nullptr;
+    unsigned int* walk_bar = nullptr;
+    int walk_np3 = 0, walk_grid = 0;
 
     void free_ws() {
         lane[0].release();
@@ -2671,6 +2681,102 @@ void launch_ln(const float* y, const int* seq_start, int B, const float* g, cons
                            g, b, eps, H, x, xp);
 }
 
+
+// ---- the layer-walking launch for small batches (encoder_walk.hpp) ------------------------------------------------------
+// Eligible: at most walk::kTmax token slots, widths the column units tile (H, F multiples of 16, H <= 1024).
+bool walk_eligible(const mvdb_encoder* e, int B, int S) {
+    const mvdb_encoder_cfg& c = e->cfg;
+    return e->opt_walk && (int64_t)B * S <= walk::kTmax && c.hidden % 16 == 0 && c.intermediate % 16 == 0 && c.hidden <= 1024;
+}
+
+int ensure_walk(mvdb_encoder* e) {
+    if (e->walk_layers) return 0;
+    const mvdb_encoder_cfg& c = e->cfg;
+    const int64_t H = c.hidden, F = c.intermediate;
+    const int cus = device_cus(e->device);
+    e->walk_np3 = (int)std::min<int64_t>(std::min<int64_t>(F / 16, walk::kMaxPlanes), cus);
+    {
+        const char* v = getenv("MVDB_WALK_PLANES");  // A/B: workgroups (= partial planes) of the FFN phase
+        if (v && *v) e->walk_np3 = std::max(1, std::min(e->walk_np3, atoi(v)));
+    }
+    int grid = std::max<int>({16, (int)(3 * H / 16), e->walk_np3});
+    {
+        const char* v = getenv("MVDB_WALK_GRID");    // A/B: workgroups of the launch
+        if (v && *v) grid = std::max(atoi(v), e->walk_np3);
+    }
+    e->walk_grid = std::min(grid, cus);              // one workgroup per CU: all resident, the grid barrier cannot starve
+    e->walk_np3 = std::min(e->walk_np3, e->walk_grid);
+    std::vector<walk::LayerPtrs> lp;
+    for (const LayerW& L : e->layers)
+        lp.push_back(walk::LayerPtrs{L.wqkv, L.bqkv, L.wo, L.bo, L.ln1g, L.ln1b, L.w1, L.b1, L.w2, L.b2, L.ln2g, L.ln2b});
+    const int64_t planes = std::max<int64_t>(c.heads, e->walk_np3);
+    MVDB_TRY(dev_alloc(&e->walk_x, walk::kTmax * H));
+    MVDB_TRY(dev_alloc(&e->walk_x1, walk::kTmax * H));
+    MVDB_TRY(dev_alloc(&e->walk_qkv, walk::kTmax * 3 * H));
+    MVDB_TRY(dev_alloc(&e->walk_pl, planes * walk::kTmax * H));
+    MVDB_TRY(dev_alloc(&e->walk_bar, 2));
+    MVDB_HIP(hipMemset(e->walk_bar, 0, 2 * sizeof(unsigned int)));
+    walk::LayerPtrs* dev = nullptr;
+    MVDB_TRY(dev_alloc(&dev, (int64_t)lp.size()));
+    MVDB_HIP(hipMemcpy(dev, lp.data(), lp.size() * sizeof(walk::LayerPtrs), hipMemcpyHostToDevice));
+    e->walk_layers = dev;
+    return 0;
+}
+
+template <int MT, int HC>
+int launch_walk_inst(mvdb_encoder* e, const walk::Args& a, size_t lds, hipStream_t s) {
+    auto kern = walk::encoder_walk_kernel<MT, HC>;
+    MVDB_TRY(x3_set_lds((const void*)kern, (int)lds, e->device));
+    hipLaunchKernelGGL(kern, dim3(e->walk_grid), dim3(walk::kThreads), lds, s, a);
+    MVDB_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_walk(mvdb_encoder* e, const int32_t* ids, const int32_t* mask, int B, int S, float* out, float* hidden, hipStream_t s) {
+    MVDB_TRY(ensure_walk(e));
+    const mvdb_encoder_cfg& c = e->cfg;
+    walk::Args a;
+    a.ids = ids;
+    a.mask = mask;
+    a.B = B;
+    a.S = S;
+    a.H = c.hidden;
+    a.F = c.intermediate;
+    a.heads = c.heads;
+    a.hd = c.hidden / c.heads;
+    a.nlayers = c.layers;
+    a.position_offset = c.position_offset;
+    a.vocab = c.vocab_size;
+    a.pooling = c.pooling;
+    a.eps = c.ln_eps;
+    a.word = e->word;
+    a.pos = e->pos;
+    a.type = e->type;
+    a.embg = e->embg;
+    a.embb = e->embb;
+    a.layers = e->walk_layers;
+    a.X = e->walk_x;
+    a.X1 = e->walk_x1;
+    a.QKV = e->walk_qkv;
+    a.PL = e->walk_pl;
+    a.bar = e->walk_bar;
+    a.out = out;
+    a.hidden = hidden;
+    a.np3 = e->walk_np3;
+    const int ntiles = c.hidden / 16;
+    a.nsplit = std::max(1, std::min(e->walk_grid / std::max(1, B * c.heads), std::max(1, ntiles / walk::kWaves)));
+    const int slots = B * S;
+    const int mt = slots <= 16 ? 1 : slots <= 32 ? 2 : 4;
+    const int hc = c.hidden <= 128 ? 1 : c.hidden <= 384 ? 3 : 8;
+    const size_t lds = walk::lds_bytes(mt, c.hidden, a.hd);
+#define MVDB_WALK_CASE(M, C) if (mt == M && hc == C) return launch_walk_inst<M, C>(e, a, lds, s)
+    MVDB_WALK_CASE(1, 1); MVDB_WALK_CASE(2, 1); MVDB_WALK_CASE(4, 1);
+    MVDB_WALK_CASE(1, 3); MVDB_WALK_CASE(2, 3); MVDB_WALK_CASE(4, 3);
+    MVDB_WALK_CASE(1, 8); MVDB_WALK_CASE(2, 8); MVDB_WALK_CASE(4, 8);
+#undef MVDB_WALK_CASE
+    return fail(MVDB_ERR_ARG, "no walker instantiation for this shape");
+}
+
 // Enqueue every kernel of one forward on `s` (no allocation, no host sync: capturable in a hipGraph).
 int enqueue_lane(mvdb_encoder* e, mvdb_encoder::Lane& w, const int32_t* ids, const int32_t* mask, int B, int S,
                  int compute, float* out, float* hidden, hipStream_t s) {
@@ -2882,6 +2988,16 @@ int forward_core(mvdb_encoder* e, const int32_t* ids, const int32_t* mask, int B
     if (B <= 0 || S <= 0) return fail(MVDB_ERR_ARG, "B and S must be positive");
     if (S + (c.position_offset > 0 ? c.position_offset : 0) > c.max_positions)
         return fail(MVDB_ERR_ARG, "sequence length %d exceeds max_positions %d", S, c.max_positions);
+    if (walk_eligible(e, B, S)) {
+        // <= 64 token slots (one sentence per call is the reference's only shape): ONE launch walks the layers, exact fp32 in
+        // both modes; a plain launch (no graph: one node) that also joins a caller's capture
+        hipStreamCaptureStatus cap0 = hipStreamCaptureStatusNone;
+        const bool captured = s && hipStreamIsCapturing(s, &cap0) == hipSuccess && cap0 != hipStreamCaptureStatusNone;
+        const int pslot0 = captured ? -1 : prof_begin("encoder", s);
+        const int rc0 = launch_walk(e, ids, mask, B, S, out, hidden, s);
+        prof_end(pslot0, s);
+        return rc0;
+    }
     if (compute == 2) {
         if (c.hidden % HBK || c.intermediate % HBK)
             return fail(MVDB_ERR_ARG, "the split-precision mode needs hidden and intermediate to be multiples of %d", HBK);
@@ -2985,6 +3101,8 @@ int mvdb_encoder_create(const mvdb_encoder_cfg* cfg, const void* const* w, int d
         e->opt_ln_fused = v && *v ? atoi(v) : 1;
         v = getenv("MVDB_ATTENTION_IMG");
         e->opt_img_attn = !(v && *v == '0');
+        v = getenv("MVDB_ENCODER_WALK");
+        e->opt_walk = !(v && *v == '0');
     }
     e->word = (const float*)w[0];
     e->pos = (const float*)w[1];
@@ -3038,6 +3156,10 @@ int mvdb_encoder_create(const mvdb_encoder_cfg* cfg, const void* const* w, int d
     return 0;
 }
 
+int mvdb_encoder_walks(const mvdb_encoder* e, int B, int S) {
+    return e && B > 0 && S > 0 && walk_eligible(e, B, S) ? 1 : 0;
+}
+
 int mvdb_encoder_gemm_tile_form(int64_t tokens, int n, int compute_units) {
     if (tokens <= 0 || n <= 0 || compute_units <= 0) return 0;
     const int bn = n % 256 == 0 ? 256 : n % 192 == 0 ? 192 : 0;
@@ -3056,6 +3178,9 @@ int mvdb_encoder_free(mvdb_encoder* e) {
         if (e->ids_stage) (void)hipFree(e->ids_stage);
         if (e->mask_stage) (void)hipFree(e->mask_stage);
         if (e->out_stage) (void)hipFree(e->out_stage);
+        void* walk_bufs[] = {e->walk_layers, e->walk_x, e->walk_x1, e->walk_qkv, e->walk_pl, e->walk_bar};
+        for (void* p : walk_bufs)
+            if (p) (void)hipFree(p);
         if (e->stream) (void)hipStreamDestroy(e->stream);
         if (e->stream2) (void)hipStreamDestroy(e->stream2);
         if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);

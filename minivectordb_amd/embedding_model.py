@@ -101,6 +101,10 @@ class GpuEncoder:
         except Exception:
             pass
 
+    def walks(self, B, S):
+        """True when a [B,S] forward runs as the one layer-walking launch (<= 64 token slots, exact fp32 in both modes)."""
+        return bool(self._native.lib().mvdb_encoder_walks(self._h, int(B), int(S)))
+
     def forward(self, ids, mask, compute=None):
         """ids, mask: int arrays [B,S] (host).  Returns pooled + normalised float32 [B,H]."""
         compute = self.default_compute if compute is None else compute
