@@ -2266,9 +2266,11 @@ struct mvdb_encoder {
     hipStream_t stream = nullptr;
     // small batches (<= walk::kTmax token slots): the layer-walking persistent launch (encoder_walk.hpp)
     int opt_walk = 1;                       // MVDB_ENCODER_WALK as read when the encoder was created (0: the per-op kernels)
+    int opt_walk_fused = 1;                 // MVDB_WALK_FUSED (0: QKV as its own phase at every shape)
     walk::LayerPtrs* walk_layers = nullptr; // device copy of the per-layer weight pointers
     float *walk_x = nullptr, *walk_x1 = nullptr, *walk_qkv = nullptr, *walk_pl = nullptr;
     unsigned int* walk_bar = nullptr;
+    unsigned long long* walk_trace = nullptr;  // ablation build only
     int walk_np3 = 0, walk_grid = 0;
 
     void free_ws() {
@@ -2714,8 +2716,8 @@ int ensure_walk(mvdb_encoder* e) {
     MVDB_TRY(dev_alloc(&e->walk_x1, walk::kTmax * H));
     MVDB_TRY(dev_alloc(&e->walk_qkv, walk::kTmax * 3 * H));
     MVDB_TRY(dev_alloc(&e->walk_pl, planes * walk::kTmax * H));
-    MVDB_TRY(dev_alloc(&e->walk_bar, 2));
-    MVDB_HIP(hipMemset(e->walk_bar, 0, 2 * sizeof(unsigned int)));
+    MVDB_TRY(dev_alloc(&e->walk_bar, walk::kCtrCount * walk::kReplicas * walk::kCtrStride));
+    MVDB_HIP(hipMemset(e->walk_bar, 0, walk::kCtrCount * walk::kReplicas * walk::kCtrStride * sizeof(unsigned int)));
     walk::LayerPtrs* dev = nullptr;
     MVDB_TRY(dev_alloc(&dev, (int64_t)lp.size()));
     MVDB_HIP(hipMemcpy(dev, lp.data(), lp.size() * sizeof(walk::LayerPtrs), hipMemcpyHostToDevice));
@@ -2723,9 +2725,9 @@ int ensure_walk(mvdb_encoder* e) {
     return 0;
 }
 
-template <int MT, int HC>
+template <int MT, int HC, bool FUSED>
 int launch_walk_inst(mvdb_encoder* e, const walk::Args& a, size_t lds, hipStream_t s) {
-    auto kern = walk::encoder_walk_kernel<MT, HC>;
+    auto kern = walk::encoder_walk_kernel<MT, HC, FUSED>;
     MVDB_TRY(x3_set_lds((const void*)kern, (int)lds, e->device));
     hipLaunchKernelGGL(kern, dim3(e->walk_grid), dim3(walk::kThreads), lds, s, a);
     MVDB_HIP(hipGetLastError());
@@ -2765,15 +2767,26 @@ int launch_walk(mvdb_encoder* e, const int32_t* ids, const int32_t* mask, int B,
     a.np3 = e->walk_np3;
     const int ntiles = c.hidden / 16;
     a.nsplit = std::max(1, std::min(e->walk_grid / std::max(1, B * c.heads), std::max(1, ntiles / walk::kWaves)));
+    a.trace = nullptr;
+#ifdef MVDB_X3_ABLATE
+    if (!e->walk_trace) MVDB_TRY(dev_alloc(&e->walk_trace, (int64_t)e->walk_grid * walk::kTraceSlots));
+    MVDB_HIP(hipMemsetAsync(e->walk_trace, 0, sizeof(unsigned long long) * e->walk_grid * walk::kTraceSlots, s));
+    a.trace = e->walk_trace;
+#endif
     const int slots = B * S;
     const int mt = slots <= 16 ? 1 : slots <= 32 ? 2 : 4;
     const int hc = c.hidden <= 128 ? 1 : c.hidden <= 384 ? 3 : 8;
-    const size_t lds = walk::lds_bytes(mt, c.hidden, a.hd);
-#define MVDB_WALK_CASE(M, C) if (mt == M && hc == C) return launch_walk_inst<M, C>(e, a, lds, s)
+    // one sentence of <= 32 tokens on an e5-small-like shape: the head's workgroup computes its own QKV columns (a phase fewer)
+    const bool fused = e->opt_walk_fused && B == 1 && mt <= 2 && hc <= 3 && a.hd == 32 && c.heads <= e->walk_grid;
+    const size_t lds = walk::lds_bytes(mt, c.hidden, a.hd, fused);
+#define MVDB_WALK_CASE(M, C) if (mt == M && hc == C) return launch_walk_inst<M, C, false>(e, a, lds, s)
+#define MVDB_WALK_FUSED(M, C) if (fused && mt == M && hc == C) return launch_walk_inst<M, C, true>(e, a, lds, s)
+    MVDB_WALK_FUSED(1, 1); MVDB_WALK_FUSED(2, 1); MVDB_WALK_FUSED(1, 3); MVDB_WALK_FUSED(2, 3);
     MVDB_WALK_CASE(1, 1); MVDB_WALK_CASE(2, 1); MVDB_WALK_CASE(4, 1);
     MVDB_WALK_CASE(1, 3); MVDB_WALK_CASE(2, 3); MVDB_WALK_CASE(4, 3);
     MVDB_WALK_CASE(1, 8); MVDB_WALK_CASE(2, 8); MVDB_WALK_CASE(4, 8);
 #undef MVDB_WALK_CASE
+#undef MVDB_WALK_FUSED
     return fail(MVDB_ERR_ARG, "no walker instantiation for this shape");
 }
 
@@ -3065,6 +3078,16 @@ int mvdb_debug_x3_trace(unsigned long long* out, int nblocks) {
     MVDB_HIP(hipMemset(sym, 0, sizeof(unsigned long long) * kX3TraceWords * kX3TraceBlocks));
     return 0;
 }
+
+// ablation build only: the s_memrealtime stamps (100 MHz) of the last layer-walking launch, [workgroups][256]; returns the
+// number of workgroups (or a negative error)
+int mvdb_debug_walk_trace(mvdb_encoder* e, unsigned long long* out, int max_wg) {
+    if (!e || !out || !e->walk_trace) return -1;
+    (void)hipDeviceSynchronize();
+    const int n = std::min(max_wg, e->walk_grid);
+    if (hipMemcpy(out, e->walk_trace, sizeof(unsigned long long) * n * walk::kTraceSlots, hipMemcpyDeviceToHost) != hipSuccess) return -2;
+    return n;
+}
 #endif
 
 
@@ -3103,6 +3126,8 @@ int mvdb_encoder_create(const mvdb_encoder_cfg* cfg, const void* const* w, int d
         e->opt_img_attn = !(v && *v == '0');
         v = getenv("MVDB_ENCODER_WALK");
         e->opt_walk = !(v && *v == '0');
+        v = getenv("MVDB_WALK_FUSED");
+        e->opt_walk_fused = !(v && *v == '0');
     }
     e->word = (const float*)w[0];
     e->pos = (const float*)w[1];
@@ -3178,7 +3203,7 @@ int mvdb_encoder_free(mvdb_encoder* e) {
         if (e->ids_stage) (void)hipFree(e->ids_stage);
         if (e->mask_stage) (void)hipFree(e->mask_stage);
         if (e->out_stage) (void)hipFree(e->out_stage);
-        void* walk_bufs[] = {e->walk_layers, e->walk_x, e->walk_x1, e->walk_qkv, e->walk_pl, e->walk_bar};
+        void* walk_bufs[] = {e->walk_layers, e->walk_x, e->walk_x1, e->walk_qkv, e->walk_pl, e->walk_bar, e->walk_trace};
         for (void* p : walk_bufs)
             if (p) (void)hipFree(p);
         if (e->stream) (void)hipStreamDestroy(e->stream);

@@ -4,9 +4,16 @@
 // 4 .. 60 tokens.  As a chain of per-op kernels that forward is ~76 launches of 4.5-9 us each (0.60 ms, round 4): the
 // arithmetic (2.7 GFLOP at 64 tokens) and the weight bytes (85 MB, Infinity-Cache resident) are a few tens of us.  Here
 // one persistent launch of G <= #CU workgroups (one per CU, all resident) runs
-//     embeddings + LN | per layer: QKV | attention + out-proj partials | sum + LN | FFN partials | sum + LN | pooling
-// with a grid-wide barrier between the phases and every hand-off through L2 (write-through `sc1` stores, L1-bypassing
-// `sc1` loads: MI355X_MICROARCH.md "Workgroup dispatch, XCD placement & inter-workgroup visibility", first table row).
+//     embeddings + LN | per layer: [QKV |] attention + out-proj partials | sum + LN | FFN partials | sum + LN | pooling
+// as a chain of PHASES.  Each phase has its own monotonic arrival counter: the workgroups that produce in a phase add to it
+// once their (write-through, `sc1`) stores have drained, and a workgroup polls a counter only in front of a phase it has work
+// in — then one agent-scope acquire, and plain loads (MI355X_MICROARCH.md "Workgroup dispatch, XCD placement &
+// inter-workgroup visibility": "ONE relaxed poll -> ONE agent acquire -> s_waitcnt vmcnt(0) -> __syncthreads() -> plain
+// loads").  A workgroup with nothing to do in a phase neither arrives nor polls: it goes straight to the wait in front of
+// its next phase, with that phase's weights already on their way (weights do not depend on other workgroups, so every
+// phase issues its weight / bias loads BEFORE it polls).  Buffers are reused safely because the phases form a chain: a
+// phase's producers start only when ALL producers of the phase before have arrived, so whoever overwrites a buffer has,
+// transitively, waited for every reader of its previous contents.
 //
 // Arithmetic: exact fp32 on v_mfma_f32_16x16x4_f32 (the parity mode's arithmetic; at <= 64 tokens no phase is bound by the
 // matrix pipe, so the split-precision mode would buy nothing).  Op order as encoder.hip's header (modeling_bert.py).
@@ -52,32 +59,70 @@ struct Args {
     float *X, *X1;            // [kTmax, H]   layer input / post-attention state
     float* QKV;               // [kTmax, 3H]
     float* PL;                // [planes, kTmax, H] partial planes
-    unsigned int* bar;        // [2]: arrivals of the running launch, exits
+    unsigned int* bar;        // [kCtrCount][8 replicas][32 words] arrival counters of the phases (monotonic within a launch) + exits
     float* out;               // [B, H]
     float* hidden;            // NULL or [B, S, H]
     int np3;                  // workgroups (= planes) of the FFN phase
     int nsplit;               // column splits of the out-projection per (sentence, head)
+    unsigned long long* trace;  // NULL, or [G][kTraceSlots] s_memrealtime stamps (ablation build: mvdb_debug_walk_trace)
 };
+constexpr int kTraceSlots = 512;
 
 __device__ __forceinline__ rsrc_t make_rsrc(const void* p) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, 0x00020000);
 }
+// Loads of handed-off bytes: sc1 (L1-bypassing), so that no acquire is needed in front of them — the hand-off is the first
+// row of MI355X_MICROARCH.md's table of hand-offs measured with sc1 loads in place of the acquire: one lane per storing
+// workgroup adds to the counter behind the workgroup's drained sc1 stores, an sc1 poll, the other waves load behind a
+// workgroup barrier, hipMalloc memory, one workgroup per CU, 16-byte sc1 stores and loads.  A/B (MVDB_WALK_ACQUIRE_LOADS
+// build: one agent-scope acquire per wait, then plain loads): 13 / 16 / 62 us slower per forward at 8 / 32 / 64 tokens
+// (profiles/r05_walk_ab.txt) — the acquire costs ~0.7 us per wait and the activations are read once per workgroup anyway.
 __device__ __forceinline__ f32x4 ld4(rsrc_t r, int byte_off) {
+#ifdef MVDB_WALK_ACQUIRE_LOADS
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0));
+#else
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, kSc1));
+#endif
 }
 __device__ __forceinline__ void st4(rsrc_t r, int byte_off, f32x4 v) {
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, byte_off, 0, kSc1);
 }
 
-// Grid-wide barrier: one monotonic arrival counter.  Every wave drains its own (write-through) stores, the workgroup meets,
-// one lane adds and polls with L1-bypassing loads, the workgroup meets again; every load of handed-off bytes after it is sc1.
-__device__ __forceinline__ void grid_sync(unsigned int* bar, unsigned int& epoch, unsigned int nwg) {
+// ---- phase counters ------------------------------------------------------------------------------------------------------
+enum { kCtrEmbed = 0, kCtrQkv, kCtrAttn, kCtrLn1, kCtrFfn, kCtrLn2, kCtrExit, kCtrCount };
+
+// stamps of (layer, phase): wait begins, released, arrived — ablation build only (a.trace != NULL)
+__device__ __forceinline__ void stamp(unsigned long long* trace, int layer, int phase, int what) {
+    if (trace && threadIdx.x == 0) {
+        const int slot = (layer * 6 + phase) * 3 + what;
+        if (slot < kTraceSlots) trace[slot] = __builtin_amdgcn_s_memrealtime();
+    }
+}
+
+// Every counter is kept in kReplicas copies, each on a 128-byte line of its own: an arriving workgroup adds to ALL of them
+// with ONE wave instruction (lane i -> replica i), a waiting workgroup polls replica (workgroup & 7) — 96 FFN workgroups
+// polling one word were released over 1.8 us (first to last), and the atomics of 96 arrivals queue on one word.
+constexpr int kReplicas = 8, kCtrStride = 32;  // words
+__device__ __forceinline__ unsigned int* ctr_word(unsigned int* bar, int ctr, int replica) {
+    return bar + (ctr * kReplicas + replica) * kCtrStride;
+}
+
+// This workgroup has produced its share of a phase: every wave drains its own stores, the workgroup meets, eight lanes add.
+__device__ __forceinline__ void phase_arrive(unsigned int* bar, int ctr) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    epoch += nwg;
+    if (threadIdx.x < kReplicas) __hip_atomic_fetch_add(ctr_word(bar, ctr, threadIdx.x), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Wait until `target` producers have arrived at counter `ctr`: one lane polls with L1-bypassing loads, the workgroup meets.
+__device__ __forceinline__ void phase_wait(unsigned int* bar, int ctr, unsigned int target) {
     if (threadIdx.x == 0) {
-        __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch) __builtin_amdgcn_s_sleep(1);
+        const unsigned int* w = ctr_word(bar, ctr, blockIdx.x & (kReplicas - 1));
+        while (__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
+#ifdef MVDB_WALK_ACQUIRE_LOADS
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // buffer_inv sc1: this CU's L1 forgets what other CUs have rewritten
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the workgroup barrier below holds until the invalidate has completed
+#endif
     }
     __syncthreads();
 }
@@ -97,14 +142,8 @@ __device__ __forceinline__ float block_sum(float v, float* red8, int lane, int w
 
 // LayerNorm of one row held 4 columns per thread (thread t < H / 4 holds columns 4t .. 4t + 3; the others pass zeros and
 // active = false), biased variance, eps inside the sqrt; the normalised row goes to `out` (sc1) at byte offset row_off.
-__device__ __forceinline__ void row_layernorm(f32x4 v, bool active, int t, int H, float eps, const float* __restrict__ gamma,
-                                              const float* __restrict__ beta, rsrc_t out, int row_off, float* red8, int lane,
-                                              int wave) {
-    f32x4 g4 = {0.f, 0.f, 0.f, 0.f}, b4 = {0.f, 0.f, 0.f, 0.f};
-    if (active) {
-        g4 = *reinterpret_cast<const f32x4*>(gamma + 4 * t);
-        b4 = *reinterpret_cast<const f32x4*>(beta + 4 * t);
-    }
+__device__ __forceinline__ void row_layernorm(f32x4 v, bool active, int t, int H, float eps, f32x4 g4, f32x4 b4, rsrc_t out,
+                                              int row_off, float* red8, int lane, int wave) {
     const float s = block_sum(active ? (v[0] + v[1]) + (v[2] + v[3]) : 0.f, red8, lane, wave);
     const float mean = s / (float)H;
     f32x4 d = v - mean;
@@ -113,47 +152,46 @@ __device__ __forceinline__ void row_layernorm(f32x4 v, bool active, int t, int H
     if (active) st4(out, row_off + 16 * t, d * rstd * g4 + b4);
 }
 
-// One column unit: acc[mt] += W[n0 .. n0 + 15][this wave's k chunks] . X[rows of tile mt][same k]^T.
-// Wrow0 = &W[n0][0] (row-major [N, K]); Ar = the activations [T, K] (sc1 loads); rows beyond T - 1 read row T - 1.
-template <int MT, int HC>
-__device__ __forceinline__ void colunit_gemm(const float* __restrict__ Wrow0, int K, rsrc_t Ar, int T, int mtc, f32x4 (&acc)[MT],
-                                             int lane, int wave) {
-    const int r = lane & 15, g = lane >> 4;
-    const int nch = K >> 4;
-    constexpr int CB = HC > 4 ? (MT > 2 ? 2 : 4) : HC;  // chunks in flight per wave: 8 chunks x 4 row tiles of operands would not fit beside the FFN accumulators
+// ---- column units ------------------------------------------------------------------------------------------------------------
+// acc[mt] += W[n0 .. n0 + 15][this wave's k chunks] . X[rows of tile mt][same k]^T, K split over the waves in chunks of 16:
+// chunk c = wave + 8 i, i < HC.  Everything is branch-free so that every load of a batch is issued before the first MFMA (with
+// `if (chunk exists)` / `if (tile exists)` around the loads hipcc emitted load, wait, MFMA group by group: one memory round
+// trip per group, 10 us per QKV phase at 64 tokens): a chunk beyond K re-reads the last one against a zeroed weight
+// fragment, row tiles beyond T read row T - 1 and their sums are never stored.
+template <int HC>
+__device__ __forceinline__ void colunit_load_w(const float* __restrict__ Wrow0, int K, f32x4 (&a)[HC], int lane, int wave) {
+    const int r = lane & 15, g = lane >> 4, nch = K >> 4;
 #pragma unroll
-    for (int i0 = 0; i0 < HC; i0 += CB) {
-        f32x4 a[CB], b[CB][MT];
-#pragma unroll
-        for (int i = 0; i < CB; ++i) {
-            const int c = wave + (i0 + i) * kWaves;
-            if (c < nch) {
-                a[i] = *reinterpret_cast<const f32x4*>(Wrow0 + (int64_t)r * K + 16 * c + 4 * g);
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-                    if (mt < mtc) b[i][mt] = ld4(Ar, (min(mt * 16 + r, T - 1) * K + 16 * c + 4 * g) * 4);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < CB; ++i) {
-            const int c = wave + (i0 + i) * kWaves;
-            if (c < nch) {
-#pragma unroll
-                for (int m = 0; m < 4; ++m)
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt)
-                        if (mt < mtc) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][m], b[i][mt][m], acc[mt], 0, 0, 0);
-            }
-        }
+    for (int i = 0; i < HC; ++i) {
+        const int c = wave + i * kWaves;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(Wrow0 + (int64_t)r * K + 16 * min(c, nch - 1) + 4 * g);
+        a[i] = c < nch ? v : f32x4{0.f, 0.f, 0.f, 0.f};
     }
 }
-
-// wave partials of a column unit -> LDS; after the barrier, wave mt (< mtc) owns tile mt and adds the 8 partials in wave order
-template <int MT>
-__device__ __forceinline__ void colunit_publish(const f32x4 (&acc)[MT], int mtc, f32x4* red, int lane, int wave) {
+template <int MT, int HC>
+__device__ __forceinline__ void colunit_load_x(rsrc_t Ar, int K, int T, f32x4 (&b)[HC][MT], int lane, int wave) {
+    const int r = lane & 15, g = lane >> 4, nch = K >> 4;
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-        if (mt < mtc) red[(wave * MT + mt) * 64 + lane] = acc[mt];
+    for (int i = 0; i < HC; ++i) {
+        const int cc = min(wave + i * kWaves, nch - 1);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) b[i][mt] = ld4(Ar, (min(mt * 16 + r, T - 1) * K + 16 * cc + 4 * g) * 4);
+    }
+}
+template <int MT, int HC>
+__device__ __forceinline__ void colunit_mfma(const f32x4 (&a)[HC], const f32x4 (&b)[HC][MT], f32x4 (&acc)[MT]) {
+#pragma unroll
+    for (int i = 0; i < HC; ++i)
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][m], b[i][mt][m], acc[mt], 0, 0, 0);
+}
+// wave partials of a column unit -> LDS; after the barrier the partials are added in wave order
+template <int MT>
+__device__ __forceinline__ void colunit_publish(const f32x4 (&acc)[MT], f32x4* red, int lane, int wave) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) red[(wave * MT + mt) * 64 + lane] = acc[mt];
 }
 template <int MT>
 __device__ __forceinline__ f32x4 colunit_total(const f32x4* red, int mt, int lane) {
@@ -163,45 +201,153 @@ __device__ __forceinline__ f32x4 colunit_total(const f32x4* red, int mt, int lan
     return s;
 }
 
-// x[row] = LayerNorm(sum of `np` planes + bias + residual[row]) for the rows this workgroup owns (row = wg, wg + G, ...).
-// Thread t = pg * (H / 4) + q sums planes pg, pg + npg, ... of column quad q (eight loads in flight), the plane groups are
-// added in group order through LDS, then the LayerNorm over the workgroup.
-__device__ __forceinline__ void phase_reduce_ln(const Args& a, rsrc_t PLr, int np, const float* __restrict__ bias, rsrc_t Rr,
-                                                const float* __restrict__ gamma, const float* __restrict__ beta, rsrc_t Or, int T,
-                                                f32x4* comb, float* red8, int wg, int G, int tid, int lane, int wave) {
+// ---- attention of one sentence's head from LDS tiles --------------------------------------------------------------------------
+// Qs [rows][hd + 4] (scaled by log2(e) / sqrt(hd)), Ks [rows][hd + 4], Vt [hd][68] (V transposed), Cs [rows][hd + 4] receives
+// the context.  Wave qi < ceil(len / 16) owns query tile qi.  Key tiles beyond the sentence must hold FINITE values (they are
+// masked to -inf by index, and their V columns meet p = 0).
+template <int MT>
+__device__ __forceinline__ void attention_tile(const float* Qs, const float* Ks, const float* Vt, float* Cs, int hd, int len, int qi,
+                                               int lane) {
+    const int r = lane & 15, g = lane >> 4, hd4 = hd + 4;
+    f32x4 sc[MT];
+#pragma unroll
+    for (int kj = 0; kj < MT; ++kj) sc[kj] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < (hd >> 4); ++c) {
+        const f32x4 qb = *reinterpret_cast<const f32x4*>(Qs + (16 * qi + r) * hd4 + 16 * c + 4 * g);
+#pragma unroll
+        for (int kj = 0; kj < MT; ++kj) {
+            const f32x4 ka = *reinterpret_cast<const f32x4*>(Ks + (16 * kj + r) * hd4 + 16 * c + 4 * g);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) sc[kj] = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[m], qb[m], sc[kj], 0, 0, 0);
+        }
+    }
+    // sc[kj][v] = score(query 16 qi + r, key 16 kj + 4 g + v): softmax over the keys of this query
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kj = 0; kj < MT; ++kj)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            sc[kj][v] = 16 * kj + 4 * g + v < len ? sc[kj][v] : -INFINITY;
+            mx = fmaxf(mx, sc[kj][v]);
+        }
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float sum = 0.f;
+#pragma unroll
+    for (int kj = 0; kj < MT; ++kj)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            sc[kj][v] = __builtin_amdgcn_exp2f(sc[kj][v] - mx);  // masked keys: 2^(-inf) = 0
+            sum += sc[kj][v];
+        }
+    sum += __shfl_xor(sum, 16);
+    sum += __shfl_xor(sum, 32);
+    const float inv = 1.0f / sum;
+#pragma unroll
+    for (int kj = 0; kj < MT; ++kj) sc[kj] *= inv;
+    // ctx^T = V^T P^T: A = V^T (i = d), B = P^T straight from the score accumulators (k = key)
+    for (int dt = 0; dt < (hd >> 4); ++dt) {
+        f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kj = 0; kj < MT; ++kj) {
+            const f32x4 va = *reinterpret_cast<const f32x4*>(Vt + (16 * dt + r) * 68 + 16 * kj + 4 * g);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) o = __builtin_amdgcn_mfma_f32_16x16x4f32(va[m], sc[kj][m], o, 0, 0, 0);
+        }
+        *reinterpret_cast<f32x4*>(Cs + (16 * qi + r) * hd4 + 16 * dt + 4 * g) = o;  // ctx[query 16 qi + r][16 dt + 4 g ..]
+    }
+}
+
+// plane[h][s0 + query][16 nt ..] = sum_d ctx[query][d] Wo[16 nt ..][h hd + d] for one column tile; wa = the tile's Wo fragments
+template <int MT>
+__device__ __forceinline__ void outproj_tile(const f32x4 (&wa)[4], const float* Cs, int hd, int len, rsrc_t PLr, int plane_row0, int H,
+                                             int nt, int lane) {
+    const int r = lane & 15, g = lane >> 4, hd4 = hd + 4, nc = hd >> 4;
+#pragma unroll
+    for (int qi = 0; qi < MT; ++qi) {  // query tiles beyond the sentence: never stored
+        f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const f32x4 cb = *reinterpret_cast<const f32x4*>(Cs + (16 * qi + r) * hd4 + 16 * min(c, nc - 1) + 4 * g);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) o = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[c][m], cb[m], o, 0, 0, 0);
+        }
+        if (16 * qi + r < len) st4(PLr, ((plane_row0 + 16 * qi + r) * H + 16 * nt + 4 * g) * 4, o);
+    }
+}
+__device__ __forceinline__ void outproj_load_w(const float* __restrict__ wo, int H, int h, int hd, int nt, f32x4 (&wa)[4], int lane) {
+    const int r = lane & 15, g = lane >> 4, nc = hd >> 4;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {  // branch-free: a chunk beyond the head re-reads the last one, zeroed
+        const f32x4 v = *reinterpret_cast<const f32x4*>(wo + (int64_t)(16 * nt + r) * H + h * hd + 16 * min(c, nc - 1) + 4 * g);
+        wa[c] = c < nc ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+}
+
+// ---- x[row] = LayerNorm(sum of `np` planes + bias + residual[row]) for the rows this workgroup owns (row = wg, wg + G, ...) ---
+// Thread t = pg * (H / 4) + q sums planes pg, pg + npg, ... of column quad q (up to 24 loads in flight), the plane groups are
+// added in group order through LDS, then the LayerNorm over the workgroup.  bias / gamma / beta were loaded before the wait.
+struct LnWeights { f32x4 bias, gamma, beta; };
+__device__ __forceinline__ LnWeights ln_load_w(const float* __restrict__ bias, const float* __restrict__ gamma,
+                                               const float* __restrict__ beta, int H, int tid) {
+    LnWeights w;
+    const int t = min(tid, (H >> 2) - 1);
+    w.bias = *reinterpret_cast<const f32x4*>(bias + 4 * t);
+    w.gamma = *reinterpret_cast<const f32x4*>(gamma + 4 * t);
+    w.beta = *reinterpret_cast<const f32x4*>(beta + 4 * t);
+    return w;
+}
+template <int RB>  // plane loads in flight per thread
+__device__ __forceinline__ void reduce_ln_rows(const Args& a, rsrc_t PLr, int np, const LnWeights& lw, rsrc_t Rr, rsrc_t Or, int T,
+                                               f32x4* comb, float* red8, int wg, int G, int tid, int lane, int wave,
+                                               unsigned long long* trace, int layer) {
     const int H = a.H, HQ = H >> 2;
     const int npg = min(kWaves, kThreads / HQ);
     const int pg = tid / HQ, q = tid - pg * HQ;
     for (int row = wg; row < T; row += G) {
+        const bool active = tid < HQ;
+        f32x4 res = {0.f, 0.f, 0.f, 0.f};
+        if (active) res = ld4(Rr, (row * H + 4 * tid) * 4);
         f32x4 s = {0.f, 0.f, 0.f, 0.f};
         if (pg < npg) {
-            for (int p0 = pg; p0 < np; p0 += 8 * npg) {
-                f32x4 v[8];
+            for (int p0 = pg; p0 < np; p0 += RB * npg) {
+                f32x4 v[RB];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int pl = p0 + u * npg;
-                    if (pl < np) v[u] = ld4(PLr, ((pl * kTmax + row) * H + 4 * q) * 4);
-                }
+                for (int u = 0; u < RB; ++u)  // branch-free: a plane beyond np reads the last one and adds nothing
+                    v[u] = ld4(PLr, ((min(p0 + u * npg, np - 1) * kTmax + row) * H + 4 * q) * 4);
 #pragma unroll
-                for (int u = 0; u < 8; ++u)
-                    if (p0 + u * npg < np) s += v[u];
+                for (int u = 0; u < RB; ++u) s += p0 + u * npg < np ? v[u] : f32x4{0.f, 0.f, 0.f, 0.f};
             }
             comb[pg * HQ + q] = s;
         }
         __syncthreads();
-        const bool active = tid < HQ;
+        stamp(trace, layer, 5, 0);  // the planes have landed
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (active) {
             v = comb[tid];
             for (int j = 1; j < npg; ++j) v += comb[j * HQ + tid];
-            v = (v + *reinterpret_cast<const f32x4*>(bias + 4 * tid)) + ld4(Rr, (row * H + 4 * tid) * 4);
+            v = (v + lw.bias) + res;
         }
-        row_layernorm(v, active, tid, H, a.eps, gamma, beta, Or, row * H * 4, red8, lane, wave);
+        row_layernorm(v, active, tid, H, a.eps, lw.gamma, lw.beta, Or, row * H * 4, red8, lane, wave);
         __syncthreads();  // comb free for the next row
     }
 }
+// The batch of loads a thread keeps in flight is sized to its share of the planes (12 head planes over 5 plane groups = 3
+// each; 96 FFN planes = 20 each): a fixed batch of 24 issued 21 duplicate loads of the last plane per thread for the head planes.
+__device__ __forceinline__ void phase_reduce_ln(const Args& a, rsrc_t PLr, int np, const LnWeights& lw, rsrc_t Rr, rsrc_t Or, int T,
+                                                f32x4* comb, float* red8, int wg, int G, int tid, int lane, int wave,
+                                                unsigned long long* trace = nullptr, int layer = 0) {
+    const int npg = min(kWaves, kThreads / (a.H >> 2));
+    const int share = (np + npg - 1) / npg;
+    if (share <= 4) reduce_ln_rows<4>(a, PLr, np, lw, Rr, Or, T, comb, red8, wg, G, tid, lane, wave, trace, layer);
+    else if (share <= 8) reduce_ln_rows<8>(a, PLr, np, lw, Rr, Or, T, comb, red8, wg, G, tid, lane, wave, trace, layer);
+    else if (share <= 12) reduce_ln_rows<12>(a, PLr, np, lw, Rr, Or, T, comb, red8, wg, G, tid, lane, wave, trace, layer);
+    else reduce_ln_rows<20>(a, PLr, np, lw, Rr, Or, T, comb, red8, wg, G, tid, lane, wave, trace, layer);
+}
 
-template <int MT, int HC>
+// FUSED (one sentence, hd = 32, H <= 384, <= 32 tokens): the QKV columns of a head are computed by the head's own workgroup,
+// straight into the attention's LDS tiles — one phase (and one trip through L2) fewer per layer.
+template <int MT, int HC, bool FUSED>
 __global__ __launch_bounds__(kThreads) void encoder_walk_kernel(const Args a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     // ---- LDS map -------------------------------------------------------------------------------------------------------
@@ -238,193 +384,299 @@ __global__ __launch_bounds__(kThreads) void encoder_walk_kernel(const Args a) {
     }
     __syncthreads();
     const int T = s_seq[a.B];
-    const int mtc = (T + 15) >> 4;
-    unsigned int epoch = 0;
+    unsigned long long* trace = a.trace ? a.trace + (size_t)wg * kTraceSlots : nullptr;
+    if (trace && tid == 0) {
+        trace[kTraceSlots - 2] = __builtin_amdgcn_s_memrealtime();
+        trace[kTraceSlots - 4] = __builtin_readcyclecounter();  // shader clock: (end - start) / realtime = the clock the launch ran at
+    }
     const rsrc_t Xr = make_rsrc(a.X), X1r = make_rsrc(a.X1), Qr = make_rsrc(a.QKV), PLr = make_rsrc(a.PL);
+    const int HQ = H >> 2;
+    // producers per phase (what the consumers of a phase wait for, per layer)
+    const unsigned int prodRow = (unsigned int)min(T, G);                      // embeddings, sum + LN
+    const int ntiles = H >> 4;
+    const int ntu = (ntiles + a.nsplit - 1) / a.nsplit;
+    const int attn_units = FUSED ? a.heads : a.B * a.heads * a.nsplit;
+    const unsigned int prodQkv = (unsigned int)min((3 * H) >> 4, G);
+    const unsigned int prodAttn = (unsigned int)min(attn_units, G);
+    const unsigned int prodFfn = (unsigned int)a.np3;
 
     if (T > 0) {
         // ---- embeddings + LayerNorm -> X (one workgroup per row) ---------------------------------------------------------------
-        {
-            const int HQ = H >> 2;
+        if (wg < (int)prodRow) {
+            const bool active = tid < HQ;
+            const int tq = min(tid, HQ - 1);
+            const f32x4 g4 = *reinterpret_cast<const f32x4*>(a.embg + 4 * tq), b4 = *reinterpret_cast<const f32x4*>(a.embb + 4 * tq);
             for (int p = wg; p < T; p += G) {
-                const bool active = tid < HQ;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (active) {
-                    const f32x4 w4 = *reinterpret_cast<const f32x4*>(a.word + (int64_t)s_tok_id[p] * H + 4 * tid);
-                    const f32x4 t4 = *reinterpret_cast<const f32x4*>(a.type + 4 * tid);
-                    const f32x4 p4 = *reinterpret_cast<const f32x4*>(a.pos + (int64_t)s_tok_pos[p] * H + 4 * tid);
-                    v = (w4 + t4) + p4;  // HF: inputs_embeds + token_type, then + position
-                }
-                row_layernorm(v, active, tid, H, a.eps, a.embg, a.embb, Xr, p * H * 4, red8, lane, wave);
+                const f32x4 w4 = *reinterpret_cast<const f32x4*>(a.word + (int64_t)s_tok_id[p] * H + 4 * tq);
+                const f32x4 t4 = *reinterpret_cast<const f32x4*>(a.type + 4 * tq);
+                const f32x4 p4 = *reinterpret_cast<const f32x4*>(a.pos + (int64_t)s_tok_pos[p] * H + 4 * tq);
+                const f32x4 v = (w4 + t4) + p4;  // HF: inputs_embeds + token_type, then + position
+                row_layernorm(v, active, tid, H, a.eps, g4, b4, Xr, p * H * 4, red8, lane, wave);
             }
+            phase_arrive(a.bar, kCtrEmbed);
         }
-        grid_sync(a.bar, epoch, G);
 
         const float qscale = 1.4426950408889634f / sqrtf((float)hd);  // log2(e) / sqrt(hd): softmax by exp2
         const int hd4 = hd + 4;
         for (int layer = 0; layer < a.nlayers; ++layer) {
             const LayerPtrs L = a.layers[layer];
-            // ---- QKV: column units over 3H -> QKV[T, 3H] ----------------------------------------------------------------------
-            {
-                f32x4* red = reinterpret_cast<f32x4*>(work);
-                for (int u = wg; u < (3 * H) >> 4; u += G) {
-                    f32x4 acc[MT];
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    colunit_gemm<MT, HC>(L.wqkv + (int64_t)u * 16 * H, H, Xr, T, mtc, acc, lane, wave);
-                    colunit_publish<MT>(acc, mtc, red, lane, wave);
-                    __syncthreads();
-                    if (wave < mtc) {
-                        const int tok = wave * 16 + r, n = u * 16 + 4 * g;
-                        const f32x4 v = colunit_total<MT>(red, wave, lane) + *reinterpret_cast<const f32x4*>(L.bqkv + n);
-                        if (tok < T) st4(Qr, (tok * 3 * H + n) * 4, v);
-                    }
-                    __syncthreads();
-                }
-            }
-            grid_sync(a.bar, epoch, G);
+            const unsigned int lay1 = (unsigned int)layer + 1u;
+            // what the first phase of a layer waits for: the embeddings, or the previous layer's last sum + LN
+            const int in_ctr = layer == 0 ? kCtrEmbed : kCtrLn2;
+            const unsigned int in_target = (layer == 0 ? 1u : (unsigned int)layer) * prodRow;
 
-            // ---- attention per (sentence, head, column split) + out-projection partial -> plane[head] --------------------------------
-            {
-                float* Qs = work;                 // [64][hd + 4]  queries, scaled
-                float* Ks = Qs + 64 * hd4;        // [64][hd + 4]
-                float* Vt = Ks + 64 * hd4;        // [hd][68]      V transposed
-                float* Cs = Vt + hd * 68;         // [64][hd + 4]  context of this head
-                const int ntiles = H >> 4;
-                const int ntu = (ntiles + a.nsplit - 1) / a.nsplit;
-                const int units = a.B * a.heads * a.nsplit;
-                for (int u = wg; u < units; u += G) {
-                    const int ns = u % a.nsplit, bh = u / a.nsplit;
-                    const int h = bh % a.heads, b = bh / a.heads;
-                    const int s0 = s_seq[b], len = s_seq[b + 1] - s0;
-                    if (len <= 0) continue;  // uniform over the workgroup
-                    const int mtb = (len + 15) >> 4;
-                    // Q, K, V of (sentence b, head h): rows < len from QKV, the rest of the 16-row tiles zero
-                    const int q4 = hd >> 2;  // float4 per row
-                    for (int e = tid; e < mtb * 16 * q4; e += kThreads) {
-                        const int row = e / q4, c4 = e - row * q4;
-                        f32x4 qv = {0.f, 0.f, 0.f, 0.f}, kv = qv, vv = qv;
-                        if (row < len) {
-                            const int base = ((s0 + row) * 3 * H + h * hd + 4 * c4) * 4;
-                            qv = ld4(Qr, base) * qscale;
-                            kv = ld4(Qr, base + H * 4);
-                            vv = ld4(Qr, base + 2 * H * 4);
-                        }
-                        *reinterpret_cast<f32x4*>(Qs + row * hd4 + 4 * c4) = qv;
-                        *reinterpret_cast<f32x4*>(Ks + row * hd4 + 4 * c4) = kv;
+            if constexpr (FUSED) {
+                // ---- head h = wg: QKV columns of the head -> LDS tiles -> attention -> out-projection partial -> plane[h] ------------
+                if (wg < (int)prodAttn) {
+                    constexpr int NU = 6;  // column units of a head: hd = 32 -> Q0 Q1 K0 K1 V0 V1
+                    f32x4* red = reinterpret_cast<f32x4*>(work);                 // [8 waves][NU][MT][64]
+                    float* Qs = work + kWaves * NU * MT * 64 * 4;                // [MT * 16][36]
+                    float* Ks = Qs + MT * 16 * 36;
+                    float* Vt = Ks + MT * 16 * 36;                               // [32][68]
+                    float* Cs = Vt + 32 * 68;                                    // [MT * 16][36]
+                    const int h = wg;
+                    f32x4 wq[NU][HC], bq[NU];
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) Vt[(4 * c4 + j) * 68 + row] = vv[j];
+                    for (int u = 0; u < NU; ++u) {
+                        const int n0 = (u >> 1) * H + h * 32 + 16 * (u & 1);
+                        colunit_load_w<HC>(L.wqkv + (int64_t)n0 * H, H, wq[u], lane, wave);
+                        bq[u] = *reinterpret_cast<const f32x4*>(L.bqkv + n0 + 4 * g);
+                    }
+                    f32x4 wo[HC][4];  // out-projection: column tile wave + 8 i of this wave, the head's 2 chunks
+#pragma unroll
+                    for (int i = 0; i < HC; ++i) outproj_load_w(L.wo, H, h, 32, min(wave + i * kWaves, ntiles - 1), wo[i], lane);
+                    stamp(trace, layer, 1, 0);
+                    phase_wait(a.bar, in_ctr, in_target);
+                    stamp(trace, layer, 1, 1);
+                    f32x4 xb[HC][MT];
+                    colunit_load_x<MT, HC>(Xr, H, T, xb, lane, wave);
+#pragma unroll
+                    for (int u = 0; u < NU; ++u) {
+                        f32x4 acc[MT];
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        colunit_mfma<MT, HC>(wq[u], xb, acc);
+                        colunit_publish<MT>(acc, red + u * kWaves * MT * 64, lane, wave);
                     }
                     __syncthreads();
-                    if (wave < mtb) {
-                        const int qi = wave;
-                        f32x4 sc[MT];
+                    stamp(trace, layer, 5, 1);  // QKV partials published
+                    // (unit, row tile) pairs over the waves: total + bias -> Q (scaled) / K / V^T tiles.  Rows beyond T are copies
+                    // of row T - 1: finite, masked as keys, never stored as queries.
+                    for (int pair = wave; pair < NU * MT; pair += kWaves) {
+                        const int u = pair / MT, mt = pair - u * MT;
+                        f32x4 v = colunit_total<MT>(red + u * kWaves * MT * 64, mt, lane);
+                        f32x4 bias = bq[0];
 #pragma unroll
-                        for (int kj = 0; kj < MT; ++kj) {
-                            sc[kj] = f32x4{0.f, 0.f, 0.f, 0.f};
-                            if (kj < mtb) {
-                                for (int c = 0; c < (hd >> 4); ++c) {
-                                    const f32x4 ka = *reinterpret_cast<const f32x4*>(Ks + (16 * kj + r) * hd4 + 16 * c + 4 * g);
-                                    const f32x4 qb = *reinterpret_cast<const f32x4*>(Qs + (16 * qi + r) * hd4 + 16 * c + 4 * g);
+                        for (int uu = 1; uu < NU; ++uu) bias = u == uu ? bq[uu] : bias;
+                        v += bias;
+                        const int tok = mt * 16 + r, col = 16 * (u & 1) + 4 * g;
+                        if ((u >> 1) == 0) *reinterpret_cast<f32x4*>(Qs + tok * 36 + col) = v * qscale;
+                        else if ((u >> 1) == 1) *reinterpret_cast<f32x4*>(Ks + tok * 36 + col) = v;
+                        else {
 #pragma unroll
-                                    for (int m = 0; m < 4; ++m)
-                                        sc[kj] = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[m], qb[m], sc[kj], 0, 0, 0);
-                                }
-                            }
-                        }
-                        // sc[kj][v] = score(query 16 qi + r, key 16 kj + 4 g + v): softmax over the keys of this query
-                        float mx = -INFINITY;
-#pragma unroll
-                        for (int kj = 0; kj < MT; ++kj)
-#pragma unroll
-                            for (int v = 0; v < 4; ++v) {
-                                const bool ok = kj < mtb && 16 * kj + 4 * g + v < len;
-                                sc[kj][v] = ok ? sc[kj][v] : -INFINITY;
-                                mx = fmaxf(mx, sc[kj][v]);
-                            }
-                        mx = fmaxf(mx, __shfl_xor(mx, 16));
-                        mx = fmaxf(mx, __shfl_xor(mx, 32));
-                        float sum = 0.f;
-#pragma unroll
-                        for (int kj = 0; kj < MT; ++kj)
-#pragma unroll
-                            for (int v = 0; v < 4; ++v) {
-                                sc[kj][v] = __builtin_amdgcn_exp2f(sc[kj][v] - mx);  // masked keys: 2^(-inf) = 0
-                                sum += sc[kj][v];
-                            }
-                        sum += __shfl_xor(sum, 16);
-                        sum += __shfl_xor(sum, 32);
-                        const float inv = 1.0f / sum;
-#pragma unroll
-                        for (int kj = 0; kj < MT; ++kj) sc[kj] *= inv;
-                        // ctx^T = V^T P^T: A = V^T (i = d), B = P^T straight from the score accumulators (k = key)
-                        for (int dt = 0; dt < (hd >> 4); ++dt) {
-                            f32x4 o = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                            for (int kj = 0; kj < MT; ++kj) {
-                                if (kj < mtb) {
-                                    const f32x4 va = *reinterpret_cast<const f32x4*>(Vt + (16 * dt + r) * 68 + 16 * kj + 4 * g);
-#pragma unroll
-                                    for (int m = 0; m < 4; ++m) o = __builtin_amdgcn_mfma_f32_16x16x4f32(va[m], sc[kj][m], o, 0, 0, 0);
-                                }
-                            }
-                            // o[v] = ctx[query 16 qi + r][d = 16 dt + 4 g + v]
-                            *reinterpret_cast<f32x4*>(Cs + (16 * qi + r) * hd4 + 16 * dt + 4 * g) = o;
+                            for (int e = 0; e < 4; ++e) Vt[(col + e) * 68 + tok] = v[e];
                         }
                     }
                     __syncthreads();
-                    // plane[h][s0 + query][n] = sum_d ctx[query][d] * Wo[n][h * hd + d] for this unit's column tiles
-                    const int nt0 = ns * ntu, nt1 = min(ntiles, nt0 + ntu);
-                    for (int nt = nt0 + wave; nt < nt1; nt += kWaves) {
-                        f32x4 wa[4];
+                    const int mtb = (T + 15) >> 4;
+                    stamp(trace, layer, 5, 2);  // Q / K / V tiles ready
+                    if (wave < mtb) attention_tile<MT>(Qs, Ks, Vt, Cs, 32, T, wave, lane);
+                    __syncthreads();
+                    stamp(trace, layer, 0, 2);  // context ready (fused form: the QKV phase's slots are free)
 #pragma unroll
-                        for (int c = 0; c < 4; ++c)
-                            if (c < (hd >> 4))
-                                wa[c] = *reinterpret_cast<const f32x4*>(L.wo + (int64_t)(16 * nt + r) * H + h * hd + 16 * c + 4 * g);
+                    for (int i = 0; i < HC; ++i) {
+                        const int nt = wave + i * kWaves;
+                        if (nt < ntiles) outproj_tile<MT>(wo[i], Cs, 32, T, PLr, h * kTmax, H, nt, lane);
+                    }
+                    stamp(trace, layer, 1, 2);
+                    phase_arrive(a.bar, kCtrAttn);
+                }
+            } else {
+                // ---- QKV: column units over 3H -> QKV[T, 3H] ----------------------------------------------------------------------
+                if (wg < (int)prodQkv) {
+                    f32x4* red = reinterpret_cast<f32x4*>(work);
+                    constexpr int CB = HC > 4 ? (MT > 2 ? 2 : 4) : HC;  // chunk batches: HC x MT operand fragments must fit the registers
+                    bool first = true;
+                    for (int u = wg; u < (3 * H) >> 4; u += G) {
+                        f32x4 acc[MT];
 #pragma unroll
-                        for (int qi = 0; qi < MT; ++qi) {
-                            if (qi < mtb) {
-                                f32x4 o = {0.f, 0.f, 0.f, 0.f};
+                        for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        const f32x4 bias = *reinterpret_cast<const f32x4*>(L.bqkv + u * 16 + 4 * g);
+                        if constexpr (CB == HC) {
+                            f32x4 wa[HC], xb[HC][MT];
+                            colunit_load_w<HC>(L.wqkv + (int64_t)u * 16 * H, H, wa, lane, wave);
+                            if (first) {
+                                stamp(trace, layer, 0, 0);
+                                phase_wait(a.bar, in_ctr, in_target);
+                                stamp(trace, layer, 0, 1);
+                                first = false;
+                            }
+                            colunit_load_x<MT, HC>(Xr, H, T, xb, lane, wave);
+                            colunit_mfma<MT, HC>(wa, xb, acc);
+                        } else {
+                            if (first) {
+                                stamp(trace, layer, 0, 0);
+                                phase_wait(a.bar, in_ctr, in_target);
+                                stamp(trace, layer, 0, 1);
+                                first = false;
+                            }
+                            const int nch = H >> 4;
 #pragma unroll
-                                for (int c = 0; c < 4; ++c) {
-                                    if (c < (hd >> 4)) {
-                                        const f32x4 cb = *reinterpret_cast<const f32x4*>(Cs + (16 * qi + r) * hd4 + 16 * c + 4 * g);
+                            for (int i0 = 0; i0 < HC; i0 += CB) {  // chunks wave + 8 (i0 + i), CB at a time
+                                f32x4 wa[CB], xb[CB][MT];
 #pragma unroll
-                                        for (int m = 0; m < 4; ++m) o = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[c][m], cb[m], o, 0, 0, 0);
-                                    }
+                                for (int i = 0; i < CB; ++i) {
+                                    const int c = wave + (i0 + i) * kWaves, cc = min(c, nch - 1);
+                                    const f32x4 v = *reinterpret_cast<const f32x4*>(L.wqkv + (int64_t)(u * 16 + r) * H + 16 * cc + 4 * g);
+                                    wa[i] = c < nch ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                                    for (int mt = 0; mt < MT; ++mt) xb[i][mt] = ld4(Xr, (min(mt * 16 + r, T - 1) * H + 16 * cc + 4 * g) * 4);
                                 }
-                                if (16 * qi + r < len) st4(PLr, ((h * kTmax + s0 + 16 * qi + r) * H + 16 * nt + 4 * g) * 4, o);
+                                colunit_mfma<MT, CB>(wa, xb, acc);
                             }
                         }
+                        colunit_publish<MT>(acc, red, lane, wave);
+                        __syncthreads();
+                        if (wave < MT) {
+                            const int tok = wave * 16 + r, n = u * 16 + 4 * g;
+                            const f32x4 v = colunit_total<MT>(red, wave, lane) + bias;
+                            if (tok < T) st4(Qr, (tok * 3 * H + n) * 4, v);
+                        }
+                        __syncthreads();
                     }
-                    __syncthreads();  // Q / K / V / ctx tiles free for the next unit
+                    stamp(trace, layer, 0, 2);
+                    phase_arrive(a.bar, kCtrQkv);
+                }
+
+                // ---- attention per (sentence, head, column split) + out-projection partial -> plane[head] --------------------------------
+                if (wg < (int)prodAttn) {
+                    float* Qs = work;                 // [64][hd + 4]  queries, scaled
+                    float* Ks = Qs + 64 * hd4;        // [64][hd + 4]
+                    float* Vt = Ks + 64 * hd4;        // [hd][68]      V transposed
+                    float* Cs = Vt + hd * 68;         // [64][hd + 4]  context of this head
+                    bool first = true;
+                    for (int u = wg; u < attn_units; u += G) {
+                        const int ns = u % a.nsplit, bh = u / a.nsplit;
+                        const int h = bh % a.heads, b = bh / a.heads;
+                        const int s0 = s_seq[b], len = s_seq[b + 1] - s0;
+                        const int nt0 = ns * ntu, nt1 = min(ntiles, nt0 + ntu);
+                        f32x4 wo0[4];  // the first column tile's fragments before the wait
+                        outproj_load_w(L.wo, H, h, hd, min(nt0 + wave, ntiles - 1), wo0, lane);
+                        if (first) {
+                            stamp(trace, layer, 1, 0);
+                            phase_wait(a.bar, kCtrQkv, lay1 * prodQkv);
+                            stamp(trace, layer, 1, 1);
+                            first = false;
+                        }
+                        if (len <= 0) continue;  // uniform over the workgroup
+                        const int mtb = (len + 15) >> 4;
+                        // Q, K, V of (sentence b, head h): rows < len from QKV, the rest of the row tiles zero
+                        const int q4 = hd >> 2;  // float4 per row
+                        for (int e = tid; e < MT * 16 * q4; e += kThreads) {
+                            const int row = e / q4, c4 = e - row * q4;
+                            f32x4 qv = {0.f, 0.f, 0.f, 0.f}, kv = qv, vv = qv;
+                            if (row < len) {
+                                const int base = ((s0 + row) * 3 * H + h * hd + 4 * c4) * 4;
+                                qv = ld4(Qr, base) * qscale;
+                                kv = ld4(Qr, base + H * 4);
+                                vv = ld4(Qr, base + 2 * H * 4);
+                            }
+                            *reinterpret_cast<f32x4*>(Qs + row * hd4 + 4 * c4) = qv;
+                            *reinterpret_cast<f32x4*>(Ks + row * hd4 + 4 * c4) = kv;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) Vt[(4 * c4 + j) * 68 + row] = vv[j];
+                        }
+                        __syncthreads();
+                        if (wave < mtb) attention_tile<MT>(Qs, Ks, Vt, Cs, hd, len, wave, lane);
+                        __syncthreads();
+                        for (int nt = nt0 + wave; nt < nt1; nt += kWaves) {
+                            f32x4 wa[4];
+                            if (nt == nt0 + wave) {
+#pragma unroll
+                                for (int c = 0; c < 4; ++c) wa[c] = wo0[c];
+                            } else {
+                                outproj_load_w(L.wo, H, h, hd, nt, wa, lane);
+                            }
+                            outproj_tile<MT>(wa, Cs, hd, len, PLr, h * kTmax + s0, H, nt, lane);
+                        }
+                        __syncthreads();  // Q / K / V / ctx tiles free for the next unit
+                    }
+                    stamp(trace, layer, 1, 2);
+                    phase_arrive(a.bar, kCtrAttn);
                 }
             }
-            grid_sync(a.bar, epoch, G);
 
             // ---- x1 = LN(sum of head planes + bo + x) -> X1 ---------------------------------------------------------------------
-            phase_reduce_ln(a, PLr, a.heads, L.bo, Xr, L.ln1g, L.ln1b, X1r, T, reinterpret_cast<f32x4*>(work), red8, wg, G, tid, lane,
-                            wave);
-            grid_sync(a.bar, epoch, G);
+            if (wg < (int)prodRow) {
+                const LnWeights lw = ln_load_w(L.bo, L.ln1g, L.ln1b, H, tid);
+                stamp(trace, layer, 2, 0);
+                phase_wait(a.bar, kCtrAttn, lay1 * prodAttn);
+                stamp(trace, layer, 2, 1);
+                phase_reduce_ln(a, PLr, a.heads, lw, Xr, X1r, T, reinterpret_cast<f32x4*>(work), red8, wg, G, tid, lane, wave, trace, layer);
+                stamp(trace, layer, 2, 2);
+                phase_arrive(a.bar, kCtrLn1);
+            }
 
             // ---- FFN: workgroup wg < np3 owns the 16-wide slices wg, wg + np3, ... of F -> plane[wg] ---------------------------------
             if (wg < a.np3) {
                 f32x4* red = reinterpret_cast<f32x4*>(work);
                 float* hbuf = work + kWaves * MT * 64 * 4;  // [64][20]: GELU(x1 W1_slice^T + b1)
+                constexpr bool kWhole = HC <= 4;            // the slice's W1 and W2 fragments (and x1's) fit the registers at once
                 f32x4 acc2[HC][MT];
 #pragma unroll
                 for (int i = 0; i < HC; ++i)
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt) acc2[i][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                bool first = true;
                 for (int j = wg; j < (F >> 4); j += a.np3) {
                     f32x4 acc[MT];
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    colunit_gemm<MT, HC>(L.w1 + (int64_t)j * 16 * H, H, X1r, T, mtc, acc, lane, wave);
-                    colunit_publish<MT>(acc, mtc, red, lane, wave);
+                    const f32x4 b1 = *reinterpret_cast<const f32x4*>(L.b1 + 16 * j + 4 * g);
+                    f32x4 w2f[kWhole ? HC : 1];
+                    if constexpr (kWhole) {
+                        f32x4 wa[HC], xb[HC][MT];
+                        colunit_load_w<HC>(L.w1 + (int64_t)j * 16 * H, H, wa, lane, wave);
+#pragma unroll
+                        for (int i = 0; i < HC; ++i) {  // a tile beyond H recomputes the last one and is never stored
+                            const int nt = min(wave + i * kWaves, ntiles - 1);
+                            w2f[i] = *reinterpret_cast<const f32x4*>(L.w2 + (int64_t)(16 * nt + r) * F + 16 * j + 4 * g);
+                        }
+                        if (first) {
+                            stamp(trace, layer, 3, 0);
+                            phase_wait(a.bar, kCtrLn1, lay1 * prodRow);
+                            stamp(trace, layer, 3, 1);
+                            first = false;
+                        }
+                        colunit_load_x<MT, HC>(X1r, H, T, xb, lane, wave);
+                        colunit_mfma<MT, HC>(wa, xb, acc);
+                    } else {
+                        if (first) {
+                            stamp(trace, layer, 3, 0);
+                            phase_wait(a.bar, kCtrLn1, lay1 * prodRow);
+                            stamp(trace, layer, 3, 1);
+                            first = false;
+                        }
+                        constexpr int CB = MT > 2 ? 2 : 4;
+                        const int nch = H >> 4;
+#pragma unroll
+                        for (int i0 = 0; i0 < HC; i0 += CB) {
+                            f32x4 wa[CB], xb[CB][MT];
+#pragma unroll
+                            for (int i = 0; i < CB; ++i) {
+                                const int c = wave + (i0 + i) * kWaves, cc = min(c, nch - 1);
+                                const f32x4 v = *reinterpret_cast<const f32x4*>(L.w1 + (int64_t)(j * 16 + r) * H + 16 * cc + 4 * g);
+                                wa[i] = c < nch ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                                for (int mt = 0; mt < MT; ++mt) xb[i][mt] = ld4(X1r, (min(mt * 16 + r, T - 1) * H + 16 * cc + 4 * g) * 4);
+                            }
+                            colunit_mfma<MT, CB>(wa, xb, acc);
+                        }
+                    }
+                    colunit_publish<MT>(acc, red, lane, wave);
                     __syncthreads();
-                    if (wave < mtc) {
-                        f32x4 v = colunit_total<MT>(red, wave, lane) + *reinterpret_cast<const f32x4*>(L.b1 + 16 * j + 4 * g);
+                    if (wave < MT) {
+                        f32x4 v = colunit_total<MT>(red, wave, lane) + b1;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = 0.5f * v[e] * (1.0f + erff(v[e] * 0.70710678118654752440f));
                         *reinterpret_cast<f32x4*>(hbuf + (wave * 16 + r) * 20 + 4 * g) = v;
@@ -432,18 +684,14 @@ __global__ __launch_bounds__(kThreads) void encoder_walk_kernel(const Args a) {
                     __syncthreads();
 #pragma unroll
                     for (int i = 0; i < HC; ++i) {
-                        const int nt = wave + i * kWaves;
-                        if (nt < (H >> 4)) {
-                            const f32x4 wa = *reinterpret_cast<const f32x4*>(L.w2 + (int64_t)(16 * nt + r) * F + 16 * j + 4 * g);
+                        const int nt = min(wave + i * kWaves, ntiles - 1);
+                        const f32x4 wa = kWhole ? w2f[kWhole ? i : 0]
+                                                : *reinterpret_cast<const f32x4*>(L.w2 + (int64_t)(16 * nt + r) * F + 16 * j + 4 * g);
 #pragma unroll
-                            for (int mt = 0; mt < MT; ++mt) {
-                                if (mt < mtc) {
-                                    const f32x4 hb = *reinterpret_cast<const f32x4*>(hbuf + (mt * 16 + r) * 20 + 4 * g);
+                        for (int mt = 0; mt < MT; ++mt) {  // row tiles beyond T: never stored
+                            const f32x4 hb = *reinterpret_cast<const f32x4*>(hbuf + (mt * 16 + r) * 20 + 4 * g);
 #pragma unroll
-                                    for (int m = 0; m < 4; ++m)
-                                        acc2[i][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[m], hb[m], acc2[i][mt], 0, 0, 0);
-                                }
-                            }
+                            for (int m = 0; m < 4; ++m) acc2[i][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[m], hb[m], acc2[i][mt], 0, 0, 0);
                         }
                     }
                     __syncthreads();  // red / hbuf free for the next slice
@@ -451,25 +699,32 @@ __global__ __launch_bounds__(kThreads) void encoder_walk_kernel(const Args a) {
 #pragma unroll
                 for (int i = 0; i < HC; ++i) {
                     const int nt = wave + i * kWaves;
-                    if (nt < (H >> 4)) {
+                    if (nt < ntiles) {
 #pragma unroll
                         for (int mt = 0; mt < MT; ++mt)
-                            if (mt < mtc && mt * 16 + r < T) st4(PLr, ((wg * kTmax + mt * 16 + r) * H + 16 * nt + 4 * g) * 4, acc2[i][mt]);
+                            if (mt * 16 + r < T) st4(PLr, ((wg * kTmax + mt * 16 + r) * H + 16 * nt + 4 * g) * 4, acc2[i][mt]);
                     }
                 }
+                stamp(trace, layer, 3, 2);
+                phase_arrive(a.bar, kCtrFfn);
             }
-            grid_sync(a.bar, epoch, G);
 
             // ---- x = LN(sum of FFN planes + b2 + x1) -> X -----------------------------------------------------------------------
-            phase_reduce_ln(a, PLr, min(a.np3, F >> 4), L.b2, X1r, L.ln2g, L.ln2b, Xr, T, reinterpret_cast<f32x4*>(work), red8, wg, G, tid,
-                            lane, wave);
-            grid_sync(a.bar, epoch, G);
+            if (wg < (int)prodRow) {
+                const LnWeights lw = ln_load_w(L.b2, L.ln2g, L.ln2b, H, tid);
+                stamp(trace, layer, 4, 0);
+                phase_wait(a.bar, kCtrFfn, lay1 * prodFfn);
+                stamp(trace, layer, 4, 1);
+                phase_reduce_ln(a, PLr, a.np3, lw, X1r, Xr, T, reinterpret_cast<f32x4*>(work), red8, wg, G, tid, lane, wave);
+                stamp(trace, layer, 4, 2);
+                phase_arrive(a.bar, kCtrLn2);
+            }
         }
     }
 
     // ---- pooling + L2 normalise (average_pool + F.normalize(eps = 1e-12); pooling 1: first valid token) ------------------------
-    {
-        const int HQ = H >> 2;
+    if (wg < a.B || (a.hidden && wg < a.B * a.S)) {
+        if (T > 0) phase_wait(a.bar, kCtrLn2, (unsigned int)a.nlayers * prodRow);
         for (int b = wg; b < a.B; b += G) {
             const int s0 = s_seq[b], len = s_seq[b + 1] - s0;
             const int span = a.pooling == 1 ? (len > 0 ? 1 : 0) : len;
@@ -503,23 +758,29 @@ __global__ __launch_bounds__(kThreads) void encoder_walk_kernel(const Args a) {
             }
         }
     }
-    // ---- the last workgroup out re-arms the barrier words for the next launch -------------------------------------------------
+    if (trace && tid == 0) {
+        trace[kTraceSlots - 1] = __builtin_amdgcn_s_memrealtime();
+        trace[kTraceSlots - 3] = __builtin_readcyclecounter();
+    }
+    // ---- the last workgroup out re-arms the counters for the next launch ------------------------------------------------------
     __syncthreads();
     if (tid == 0) {
-        const unsigned int left = __hip_atomic_fetch_add(a.bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned int left = __hip_atomic_fetch_add(ctr_word(a.bar, kCtrExit, 0), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (left == (unsigned int)G - 1u) {
-            __hip_atomic_store(a.bar, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(a.bar + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int i = 0; i < kCtrCount * kReplicas; ++i)
+                __hip_atomic_store(a.bar + i * kCtrStride, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
 
 // LDS bytes of a launch
-inline size_t lds_bytes(int mt, int H, int hd) {
+inline size_t lds_bytes(int mt, int H, int hd, bool fused) {
     const size_t colunit = (size_t)kWaves * mt * 64 * 16 + 64 * 20 * 4;             // wave partials + GELU tile
     const size_t attn = (size_t)(3 * 64 * (hd + 4) + hd * 68) * 4;                  // Q, K, ctx, V^T
     const size_t reduce = (size_t)kThreads * 16;                                    // plane-group partials
-    return 272 * 4 + std::max(colunit, std::max(attn, reduce));
+    const size_t fusedb = (size_t)kWaves * 6 * mt * 64 * 16 + (size_t)(3 * mt * 16 * 36 + 32 * 68) * 4;
+    // never less than half a CU's LDS + 1 KiB: two workgroups of a launch cannot share a CU (the measured sc1 hand-off is "one per CU")
+    return std::max<size_t>(272 * 4 + std::max(std::max(colunit, fused ? fusedb : attn), reduce), 81 * 1024);
 }
 
 }  // namespace walk

@@ -113,8 +113,12 @@ def test_batch_composition_does_not_change_a_row(gpu, monkeypatch):
         enc = _model(cfg, E.make_weights(cfg, 21))
         ids, mask = E.make_inputs(cfg, 8, 40, 22)
         ref = enc.forward(ids, mask)
-        for nb in (1, 2, 3, 5, 7):
+        for nb in (2, 3, 5, 7):
             assert np.array_equal(enc.forward(ids[:nb], mask[:nb]), ref[:nb]), (fused, nb)
+        # one sentence of <= 64 token slots runs the layer-walking launch (exact fp32, its own summation order): another form
+        # boundary, rounding-level agreement; its own batch-independence test is tests/test_encoder_walk_gpu.py
+        assert enc.walks(1, 40)
+        np.testing.assert_allclose(enc.forward(ids[:1], mask[:1]), ref[:1], atol=5e-7, rtol=0)
         enc.close()
 
 
@@ -231,8 +235,9 @@ def test_split_mode_recomputes_exactly_when_an_activation_leaves_fp16_range(gpu)
     w = E.make_weights(cfg, 3)
     w = {k: v.copy() for k, v in w.items()}
     w["encoder.layer.0.intermediate.dense.weight"] *= np.float32(1e6)
-    ids, mask = E.make_inputs(cfg, 3, 9, 4)
+    ids, mask = E.make_inputs(cfg, 9, 9, 4)   # 81 token slots: the per-op kernels (<= 64 slots run the exact-fp32 walking launch in both modes)
     enc = _model(cfg, w)
+    assert not enc.walks(9, 9)
     import torch
     dev = torch.device("cuda", 0)
     raw, _ = enc.forward_device(torch.from_numpy(ids).to(dev), torch.from_numpy(mask).to(dev), compute=2)
