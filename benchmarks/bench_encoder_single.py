@@ -21,12 +21,15 @@ from oracle.encoder import make_weights  # noqa: E402
 cfg = {"model_type": "bert", "vocab_size": 30000, "hidden_size": 384, "num_hidden_layers": 12,
        "num_attention_heads": 12, "intermediate_size": 1536, "max_position_embeddings": 512,
        "type_vocab_size": 2, "layer_norm_eps": 1e-12, "hidden_act": "gelu", "pad_token_id": 0}
+LARGE = "--large" in sys.argv   # the e5-large / bge-m3 shape (XLM-R large widths): H 1024, 24 layers, 16 heads, FFN 4096
+if LARGE:
+    cfg.update(hidden_size=1024, num_hidden_layers=24, num_attention_heads=16, intermediate_size=4096)
 w = make_weights(cfg, 1)
 enc = GpuEncoder(cfg, {k: torch.from_numpy(v) for k, v in w.items()}, device=0)
 rs = np.random.RandomState(0)
 enc.forward(rs.randint(5, 30000, size=(1, 7)).astype(np.int32), np.ones((1, 7), np.int32))   # weights' fp16 images, workspace
-out = {"what": "e5-small-shaped encoder, ONE sentence per call, host in / host out (GpuEncoder.forward), default fp16x3 mode",
-       "per_length": []}
+out = {"what": ("e5-large / bge-m3-shaped" if LARGE else "e5-small-shaped") + " encoder, ONE sentence per call, host in / host out "
+       "(GpuEncoder.forward), default mode", "walks": {str(S): bool(enc.walks(1, S)) for S in (8, 64, 128)}, "per_length": []}
 for S in (8, 16, 24, 32, 64, 128, 256):
     ids = rs.randint(5, 30000, size=(1, S)).astype(np.int32)
     mask = np.ones((1, S), np.int32)

@@ -2266,12 +2266,11 @@ struct mvdb_encoder {
     hipStream_t stream = nullptr;
     // small batches (<= walk::kTmax token slots): the layer-walking persistent launch (encoder_walk.hpp)
     int opt_walk = 1;                       // MVDB_ENCODER_WALK as read when the encoder was created (0: the per-op kernels)
-    int opt_walk_fused = 1;                 // MVDB_WALK_FUSED (0: QKV as its own phase at every shape)
     walk::LayerPtrs* walk_layers = nullptr; // device copy of the per-layer weight pointers
     float *walk_x = nullptr, *walk_x1 = nullptr, *walk_qkv = nullptr, *walk_pl = nullptr;
     unsigned int* walk_bar = nullptr;
     unsigned long long* walk_trace = nullptr;  // ablation build only
-    int walk_np3 = 0, walk_grid = 0;
+    int walk_np3 = 0, walk_grid = 0, walk_grid_env = 0;
 
     void free_ws() {
         lane[0].release();
@@ -2701,13 +2700,10 @@ int ensure_walk(mvdb_encoder* e) {
         const char* v = getenv("MVDB_WALK_PLANES");  // A/B: workgroups (= partial planes) of the FFN phase
         if (v && *v) e->walk_np3 = std::max(1, std::min(e->walk_np3, atoi(v)));
     }
-    int grid = std::max<int>({16, (int)(3 * H / 16), e->walk_np3});
     {
-        const char* v = getenv("MVDB_WALK_GRID");    // A/B: workgroups of the launch
-        if (v && *v) grid = std::max(atoi(v), e->walk_np3);
+        const char* v = getenv("MVDB_WALK_GRID");    // A/B: workgroups of the launch (0: by shape, launch_walk)
+        e->walk_grid_env = v && *v ? atoi(v) : 0;
     }
-    e->walk_grid = std::min(grid, cus);              // one workgroup per CU: all resident, the grid barrier cannot starve
-    e->walk_np3 = std::min(e->walk_np3, e->walk_grid);
     std::vector<walk::LayerPtrs> lp;
     for (const LayerW& L : e->layers)
         lp.push_back(walk::LayerPtrs{L.wqkv, L.bqkv, L.wo, L.bo, L.ln1g, L.ln1b, L.w1, L.b1, L.w2, L.b2, L.ln2g, L.ln2b});
@@ -2725,11 +2721,11 @@ int ensure_walk(mvdb_encoder* e) {
     return 0;
 }
 
-template <int MT, int HC, bool FUSED>
-int launch_walk_inst(mvdb_encoder* e, const walk::Args& a, size_t lds, hipStream_t s) {
-    auto kern = walk::encoder_walk_kernel<MT, HC, FUSED>;
+template <int MT, int HC, int RH>
+int launch_walk_inst(mvdb_encoder* e, const walk::Args& a, size_t lds, int grid, hipStream_t s) {
+    auto kern = walk::encoder_walk_kernel<MT, HC, RH>;
     MVDB_TRY(x3_set_lds((const void*)kern, (int)lds, e->device));
-    hipLaunchKernelGGL(kern, dim3(e->walk_grid), dim3(walk::kThreads), lds, s, a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(walk::kThreads), lds, s, a);
     MVDB_HIP(hipGetLastError());
     return 0;
 }
@@ -2766,27 +2762,27 @@ int launch_walk(mvdb_encoder* e, const int32_t* ids, const int32_t* mask, int B,
     a.hidden = hidden;
     a.np3 = e->walk_np3;
     const int ntiles = c.hidden / 16;
-    a.nsplit = std::max(1, std::min(e->walk_grid / std::max(1, B * c.heads), std::max(1, ntiles / walk::kWaves)));
+    const int slots = B * S;
+    // <= 16 / <= 32 token slots: one / two row tiles per column unit; more: two tiles and the units split once more by rows
+    const int mt = slots <= 16 ? 1 : 2, rh = slots <= 32 ? 1 : 2;
+    const int hc = c.hidden <= 128 ? 1 : c.hidden <= 384 ? 3 : 8;
+    const int cus = device_cus(e->device);
+    int grid = std::min(cus, std::max<int>({16, 3 * c.hidden / 16 * rh, e->walk_np3 * rh}));  // one workgroup per CU: all resident
+    if (e->walk_grid_env > 0) grid = std::min(cus, std::max(e->walk_grid_env, e->walk_np3));
+    e->walk_grid = grid;
+    a.nsplit = std::max(1, std::min(grid / std::max(1, B * c.heads), std::max(1, ntiles / walk::kWaves)));
     a.trace = nullptr;
 #ifdef MVDB_X3_ABLATE
-    if (!e->walk_trace) MVDB_TRY(dev_alloc(&e->walk_trace, (int64_t)e->walk_grid * walk::kTraceSlots));
-    MVDB_HIP(hipMemsetAsync(e->walk_trace, 0, sizeof(unsigned long long) * e->walk_grid * walk::kTraceSlots, s));
+    if (!e->walk_trace) MVDB_TRY(dev_alloc(&e->walk_trace, (int64_t)cus * walk::kTraceSlots));
+    MVDB_HIP(hipMemsetAsync(e->walk_trace, 0, sizeof(unsigned long long) * cus * walk::kTraceSlots, s));
     a.trace = e->walk_trace;
 #endif
-    const int slots = B * S;
-    const int mt = slots <= 16 ? 1 : slots <= 32 ? 2 : 4;
-    const int hc = c.hidden <= 128 ? 1 : c.hidden <= 384 ? 3 : 8;
-    // one sentence of <= 32 tokens on an e5-small-like shape: the head's workgroup computes its own QKV columns (a phase fewer)
-    const bool fused = e->opt_walk_fused && B == 1 && mt <= 2 && hc <= 3 && a.hd == 32 && c.heads <= e->walk_grid;
-    const size_t lds = walk::lds_bytes(mt, c.hidden, a.hd, fused);
-#define MVDB_WALK_CASE(M, C) if (mt == M && hc == C) return launch_walk_inst<M, C, false>(e, a, lds, s)
-#define MVDB_WALK_FUSED(M, C) if (fused && mt == M && hc == C) return launch_walk_inst<M, C, true>(e, a, lds, s)
-    MVDB_WALK_FUSED(1, 1); MVDB_WALK_FUSED(2, 1); MVDB_WALK_FUSED(1, 3); MVDB_WALK_FUSED(2, 3);
-    MVDB_WALK_CASE(1, 1); MVDB_WALK_CASE(2, 1); MVDB_WALK_CASE(4, 1);
-    MVDB_WALK_CASE(1, 3); MVDB_WALK_CASE(2, 3); MVDB_WALK_CASE(4, 3);
-    MVDB_WALK_CASE(1, 8); MVDB_WALK_CASE(2, 8); MVDB_WALK_CASE(4, 8);
+    const size_t lds = walk::lds_bytes(mt, c.hidden, a.hd);
+#define MVDB_WALK_CASE(M, C, R) if (mt == M && hc == C && rh == R) return launch_walk_inst<M, C, R>(e, a, lds, grid, s)
+    MVDB_WALK_CASE(1, 1, 1); MVDB_WALK_CASE(2, 1, 1); MVDB_WALK_CASE(2, 1, 2);
+    MVDB_WALK_CASE(1, 3, 1); MVDB_WALK_CASE(2, 3, 1); MVDB_WALK_CASE(2, 3, 2);
+    MVDB_WALK_CASE(1, 8, 1); MVDB_WALK_CASE(2, 8, 1); MVDB_WALK_CASE(2, 8, 2);
 #undef MVDB_WALK_CASE
-#undef MVDB_WALK_FUSED
     return fail(MVDB_ERR_ARG, "no walker instantiation for this shape");
 }
 
@@ -3126,8 +3122,6 @@ int mvdb_encoder_create(const mvdb_encoder_cfg* cfg, const void* const* w, int d
         e->opt_img_attn = !(v && *v == '0');
         v = getenv("MVDB_ENCODER_WALK");
         e->opt_walk = !(v && *v == '0');
-        v = getenv("MVDB_WALK_FUSED");
-        e->opt_walk_fused = !(v && *v == '0');
     }
     e->word = (const float*)w[0];
     e->pos = (const float*)w[1];

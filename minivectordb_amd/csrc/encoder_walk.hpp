@@ -169,13 +169,13 @@ __device__ __forceinline__ void colunit_load_w(const float* __restrict__ Wrow0, 
     }
 }
 template <int MT, int HC>
-__device__ __forceinline__ void colunit_load_x(rsrc_t Ar, int K, int T, f32x4 (&b)[HC][MT], int lane, int wave) {
+__device__ __forceinline__ void colunit_load_x(rsrc_t Ar, int K, int T, f32x4 (&b)[HC][MT], int lane, int wave, int row0 = 0) {
     const int r = lane & 15, g = lane >> 4, nch = K >> 4;
 #pragma unroll
     for (int i = 0; i < HC; ++i) {
         const int cc = min(wave + i * kWaves, nch - 1);
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) b[i][mt] = ld4(Ar, (min(mt * 16 + r, T - 1) * K + 16 * cc + 4 * g) * 4);
+        for (int mt = 0; mt < MT; ++mt) b[i][mt] = ld4(Ar, (min(row0 + mt * 16 + r, T - 1) * K + 16 * cc + 4 * g) * 4);
     }
 }
 template <int MT, int HC>
@@ -345,9 +345,13 @@ __device__ __forceinline__ void phase_reduce_ln(const Args& a, rsrc_t PLr, int n
     else reduce_ln_rows<20>(a, PLr, np, lw, Rr, Or, T, comb, red8, wg, G, tid, lane, wave, trace, layer);
 }
 
-// FUSED (one sentence, hd = 32, H <= 384, <= 32 tokens): the QKV columns of a head are computed by the head's own workgroup,
-// straight into the attention's LDS tiles — one phase (and one trip through L2) fewer per layer.
-template <int MT, int HC, bool FUSED>
+// MT = row tiles (of 16 tokens) a column unit computes, RH = row halves: at more than 32 tokens the column units are split
+// once more by rows — unit (columns u, half hf) computes rows [32 hf, 32 hf + 32) — so that a 64-token forward spreads over
+// twice the workgroups and each loads and stores half the activations; AT = MT * RH row tiles for the attention, which
+// needs every key of a sentence.  (Tried and removed: the QKV columns of a head computed by the head's own workgroup
+// straight into the attention's LDS tiles, one phase fewer per layer — 12 CUs then do the whole QKV product on the fp32
+// matrix pipe: 0.33 / 0.43 ms per forward at 8 / 32 tokens against 0.27 / 0.34 with QKV as its own 72-workgroup phase.)
+template <int MT, int HC, int RH>
 __global__ __launch_bounds__(kThreads) void encoder_walk_kernel(const Args a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     // ---- LDS map -------------------------------------------------------------------------------------------------------
@@ -395,10 +399,12 @@ __global__ __launch_bounds__(kThreads) void encoder_walk_kernel(const Args a) {
     const unsigned int prodRow = (unsigned int)min(T, G);                      // embeddings, sum + LN
     const int ntiles = H >> 4;
     const int ntu = (ntiles + a.nsplit - 1) / a.nsplit;
-    const int attn_units = FUSED ? a.heads : a.B * a.heads * a.nsplit;
-    const unsigned int prodQkv = (unsigned int)min((3 * H) >> 4, G);
+    const int attn_units = a.B * a.heads * a.nsplit;
+    constexpr int AT = MT * RH;                                               // row tiles of the attention
+    const int ncol = (3 * H) >> 4;                                            // column units of the QKV product
+    const unsigned int prodQkv = (unsigned int)min(ncol * RH, G);
     const unsigned int prodAttn = (unsigned int)min(attn_units, G);
-    const unsigned int prodFfn = (unsigned int)a.np3;
+    const unsigned int prodFfn = (unsigned int)min(a.np3 * RH, G);
 
     if (T > 0) {
         // ---- embeddings + LayerNorm -> X (one workgroup per row) ---------------------------------------------------------------
@@ -425,79 +431,14 @@ __global__ __launch_bounds__(kThreads) void encoder_walk_kernel(const Args a) {
             const int in_ctr = layer == 0 ? kCtrEmbed : kCtrLn2;
             const unsigned int in_target = (layer == 0 ? 1u : (unsigned int)layer) * prodRow;
 
-            if constexpr (FUSED) {
-                // ---- head h = wg: QKV columns of the head -> LDS tiles -> attention -> out-projection partial -> plane[h] ------------
-                if (wg < (int)prodAttn) {
-                    constexpr int NU = 6;  // column units of a head: hd = 32 -> Q0 Q1 K0 K1 V0 V1
-                    f32x4* red = reinterpret_cast<f32x4*>(work);                 // [8 waves][NU][MT][64]
-                    float* Qs = work + kWaves * NU * MT * 64 * 4;                // [MT * 16][36]
-                    float* Ks = Qs + MT * 16 * 36;
-                    float* Vt = Ks + MT * 16 * 36;                               // [32][68]
-                    float* Cs = Vt + 32 * 68;                                    // [MT * 16][36]
-                    const int h = wg;
-                    f32x4 wq[NU][HC], bq[NU];
-#pragma unroll
-                    for (int u = 0; u < NU; ++u) {
-                        const int n0 = (u >> 1) * H + h * 32 + 16 * (u & 1);
-                        colunit_load_w<HC>(L.wqkv + (int64_t)n0 * H, H, wq[u], lane, wave);
-                        bq[u] = *reinterpret_cast<const f32x4*>(L.bqkv + n0 + 4 * g);
-                    }
-                    f32x4 wo[HC][4];  // out-projection: column tile wave + 8 i of this wave, the head's 2 chunks
-#pragma unroll
-                    for (int i = 0; i < HC; ++i) outproj_load_w(L.wo, H, h, 32, min(wave + i * kWaves, ntiles - 1), wo[i], lane);
-                    stamp(trace, layer, 1, 0);
-                    phase_wait(a.bar, in_ctr, in_target);
-                    stamp(trace, layer, 1, 1);
-                    f32x4 xb[HC][MT];
-                    colunit_load_x<MT, HC>(Xr, H, T, xb, lane, wave);
-#pragma unroll
-                    for (int u = 0; u < NU; ++u) {
-                        f32x4 acc[MT];
-#pragma unroll
-                        for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-                        colunit_mfma<MT, HC>(wq[u], xb, acc);
-                        colunit_publish<MT>(acc, red + u * kWaves * MT * 64, lane, wave);
-                    }
-                    __syncthreads();
-                    stamp(trace, layer, 5, 1);  // QKV partials published
-                    // (unit, row tile) pairs over the waves: total + bias -> Q (scaled) / K / V^T tiles.  Rows beyond T are copies
-                    // of row T - 1: finite, masked as keys, never stored as queries.
-                    for (int pair = wave; pair < NU * MT; pair += kWaves) {
-                        const int u = pair / MT, mt = pair - u * MT;
-                        f32x4 v = colunit_total<MT>(red + u * kWaves * MT * 64, mt, lane);
-                        f32x4 bias = bq[0];
-#pragma unroll
-                        for (int uu = 1; uu < NU; ++uu) bias = u == uu ? bq[uu] : bias;
-                        v += bias;
-                        const int tok = mt * 16 + r, col = 16 * (u & 1) + 4 * g;
-                        if ((u >> 1) == 0) *reinterpret_cast<f32x4*>(Qs + tok * 36 + col) = v * qscale;
-                        else if ((u >> 1) == 1) *reinterpret_cast<f32x4*>(Ks + tok * 36 + col) = v;
-                        else {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) Vt[(col + e) * 68 + tok] = v[e];
-                        }
-                    }
-                    __syncthreads();
-                    const int mtb = (T + 15) >> 4;
-                    stamp(trace, layer, 5, 2);  // Q / K / V tiles ready
-                    if (wave < mtb) attention_tile<MT>(Qs, Ks, Vt, Cs, 32, T, wave, lane);
-                    __syncthreads();
-                    stamp(trace, layer, 0, 2);  // context ready (fused form: the QKV phase's slots are free)
-#pragma unroll
-                    for (int i = 0; i < HC; ++i) {
-                        const int nt = wave + i * kWaves;
-                        if (nt < ntiles) outproj_tile<MT>(wo[i], Cs, 32, T, PLr, h * kTmax, H, nt, lane);
-                    }
-                    stamp(trace, layer, 1, 2);
-                    phase_arrive(a.bar, kCtrAttn);
-                }
-            } else {
+            {
                 // ---- QKV: column units over 3H -> QKV[T, 3H] ----------------------------------------------------------------------
                 if (wg < (int)prodQkv) {
                     f32x4* red = reinterpret_cast<f32x4*>(work);
                     constexpr int CB = HC > 4 ? (MT > 2 ? 2 : 4) : HC;  // chunk batches: HC x MT operand fragments must fit the registers
                     bool first = true;
-                    for (int u = wg; u < (3 * H) >> 4; u += G) {
+                    for (int uu = wg; uu < ncol * RH; uu += G) {
+                        const int hf = uu / ncol, u = uu - hf * ncol, row0 = hf * MT * 16;  // columns u, row half hf
                         f32x4 acc[MT];
 #pragma unroll
                         for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -511,7 +452,7 @@ __global__ __launch_bounds__(kThreads) void encoder_walk_kernel(const Args a) {
                                 stamp(trace, layer, 0, 1);
                                 first = false;
                             }
-                            colunit_load_x<MT, HC>(Xr, H, T, xb, lane, wave);
+                            colunit_load_x<MT, HC>(Xr, H, T, xb, lane, wave, row0);
                             colunit_mfma<MT, HC>(wa, xb, acc);
                         } else {
                             if (first) {
@@ -530,7 +471,7 @@ __global__ __launch_bounds__(kThreads) void encoder_walk_kernel(const Args a) {
                                     const f32x4 v = *reinterpret_cast<const f32x4*>(L.wqkv + (int64_t)(u * 16 + r) * H + 16 * cc + 4 * g);
                                     wa[i] = c < nch ? v : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                                    for (int mt = 0; mt < MT; ++mt) xb[i][mt] = ld4(Xr, (min(mt * 16 + r, T - 1) * H + 16 * cc + 4 * g) * 4);
+                                    for (int mt = 0; mt < MT; ++mt) xb[i][mt] = ld4(Xr, (min(row0 + mt * 16 + r, T - 1) * H + 16 * cc + 4 * g) * 4);
                                 }
                                 colunit_mfma<MT, CB>(wa, xb, acc);
                             }
@@ -538,7 +479,7 @@ __global__ __launch_bounds__(kThreads) void encoder_walk_kernel(const Args a) {
                         colunit_publish<MT>(acc, red, lane, wave);
                         __syncthreads();
                         if (wave < MT) {
-                            const int tok = wave * 16 + r, n = u * 16 + 4 * g;
+                            const int tok = row0 + wave * 16 + r, n = u * 16 + 4 * g;
                             const f32x4 v = colunit_total<MT>(red, wave, lane) + bias;
                             if (tok < T) st4(Qr, (tok * 3 * H + n) * 4, v);
                         }
@@ -572,7 +513,7 @@ __global__ __launch_bounds__(kThreads) void encoder_walk_kernel(const Args a) {
                         const int mtb = (len + 15) >> 4;
                         // Q, K, V of (sentence b, head h): rows < len from QKV, the rest of the row tiles zero
                         const int q4 = hd >> 2;  // float4 per row
-                        for (int e = tid; e < MT * 16 * q4; e += kThreads) {
+                        for (int e = tid; e < AT * 16 * q4; e += kThreads) {
                             const int row = e / q4, c4 = e - row * q4;
                             f32x4 qv = {0.f, 0.f, 0.f, 0.f}, kv = qv, vv = qv;
                             if (row < len) {
@@ -587,7 +528,7 @@ __global__ __launch_bounds__(kThreads) void encoder_walk_kernel(const Args a) {
                             for (int j = 0; j < 4; ++j) Vt[(4 * c4 + j) * 68 + row] = vv[j];
                         }
                         __syncthreads();
-                        if (wave < mtb) attention_tile<MT>(Qs, Ks, Vt, Cs, hd, len, wave, lane);
+                        if (wave < mtb) attention_tile<AT>(Qs, Ks, Vt, Cs, hd, len, wave, lane);
                         __syncthreads();
                         for (int nt = nt0 + wave; nt < nt1; nt += kWaves) {
                             f32x4 wa[4];
@@ -597,7 +538,7 @@ __global__ __launch_bounds__(kThreads) void encoder_walk_kernel(const Args a) {
                             } else {
                                 outproj_load_w(L.wo, H, h, hd, nt, wa, lane);
                             }
-                            outproj_tile<MT>(wa, Cs, hd, len, PLr, h * kTmax + s0, H, nt, lane);
+                            outproj_tile<AT>(wa, Cs, hd, len, PLr, h * kTmax + s0, H, nt, lane);
                         }
                         __syncthreads();  // Q / K / V / ctx tiles free for the next unit
                     }
@@ -618,7 +559,8 @@ __global__ __launch_bounds__(kThreads) void encoder_walk_kernel(const Args a) {
             }
 
             // ---- FFN: workgroup wg < np3 owns the 16-wide slices wg, wg + np3, ... of F -> plane[wg] ---------------------------------
-            if (wg < a.np3) {
+            if (wg < (int)prodFfn) {
+                const int hf = wg / a.np3, pl = wg - hf * a.np3, row0 = hf * MT * 16;  // plane (= first slice) pl, row half hf
                 f32x4* red = reinterpret_cast<f32x4*>(work);
                 float* hbuf = work + kWaves * MT * 64 * 4;  // [64][20]: GELU(x1 W1_slice^T + b1)
                 constexpr bool kWhole = HC <= 4;            // the slice's W1 and W2 fragments (and x1's) fit the registers at once
@@ -628,7 +570,7 @@ __global__ __launch_bounds__(kThreads) void encoder_walk_kernel(const Args a) {
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt) acc2[i][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
                 bool first = true;
-                for (int j = wg; j < (F >> 4); j += a.np3) {
+                for (int j = pl; j < (F >> 4); j += a.np3) {
                     f32x4 acc[MT];
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -648,7 +590,7 @@ __global__ __launch_bounds__(kThreads) void encoder_walk_kernel(const Args a) {
                             stamp(trace, layer, 3, 1);
                             first = false;
                         }
-                        colunit_load_x<MT, HC>(X1r, H, T, xb, lane, wave);
+                        colunit_load_x<MT, HC>(X1r, H, T, xb, lane, wave, row0);
                         colunit_mfma<MT, HC>(wa, xb, acc);
                     } else {
                         if (first) {
@@ -668,7 +610,7 @@ __global__ __launch_bounds__(kThreads) void encoder_walk_kernel(const Args a) {
                                 const f32x4 v = *reinterpret_cast<const f32x4*>(L.w1 + (int64_t)(j * 16 + r) * H + 16 * cc + 4 * g);
                                 wa[i] = c < nch ? v : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                                for (int mt = 0; mt < MT; ++mt) xb[i][mt] = ld4(X1r, (min(mt * 16 + r, T - 1) * H + 16 * cc + 4 * g) * 4);
+                                for (int mt = 0; mt < MT; ++mt) xb[i][mt] = ld4(X1r, (min(row0 + mt * 16 + r, T - 1) * H + 16 * cc + 4 * g) * 4);
                             }
                             colunit_mfma<MT, CB>(wa, xb, acc);
                         }
@@ -702,7 +644,7 @@ __global__ __launch_bounds__(kThreads) void encoder_walk_kernel(const Args a) {
                     if (nt < ntiles) {
 #pragma unroll
                         for (int mt = 0; mt < MT; ++mt)
-                            if (mt * 16 + r < T) st4(PLr, ((wg * kTmax + mt * 16 + r) * H + 16 * nt + 4 * g) * 4, acc2[i][mt]);
+                            if (row0 + mt * 16 + r < T) st4(PLr, ((pl * kTmax + row0 + mt * 16 + r) * H + 16 * nt + 4 * g) * 4, acc2[i][mt]);
                     }
                 }
                 stamp(trace, layer, 3, 2);
@@ -774,13 +716,12 @@ __global__ __launch_bounds__(kThreads) void encoder_walk_kernel(const Args a) {
 }
 
 // LDS bytes of a launch
-inline size_t lds_bytes(int mt, int H, int hd, bool fused) {
+inline size_t lds_bytes(int mt, int H, int hd) {
     const size_t colunit = (size_t)kWaves * mt * 64 * 16 + 64 * 20 * 4;             // wave partials + GELU tile
     const size_t attn = (size_t)(3 * 64 * (hd + 4) + hd * 68) * 4;                  // Q, K, ctx, V^T
     const size_t reduce = (size_t)kThreads * 16;                                    // plane-group partials
-    const size_t fusedb = (size_t)kWaves * 6 * mt * 64 * 16 + (size_t)(3 * mt * 16 * 36 + 32 * 68) * 4;
     // never less than half a CU's LDS + 1 KiB: two workgroups of a launch cannot share a CU (the measured sc1 hand-off is "one per CU")
-    return std::max<size_t>(272 * 4 + std::max(std::max(colunit, fused ? fusedb : attn), reduce), 81 * 1024);
+    return std::max<size_t>(272 * 4 + std::max(std::max(colunit, attn), reduce), 81 * 1024);
 }
 
 }  // namespace walk
