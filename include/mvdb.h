@@ -83,8 +83,11 @@ int64_t mvdb_index_ntotal(const mvdb_index* idx);
 int mvdb_index_dim(const mvdb_index* idx);
 int mvdb_index_device(const mvdb_index* idx);
 
-/* Rows held in the index' fp16 SHADOW (0: none).  An index that answers batches of 33+ queries at d = 256 / 384 / 512 keeps —
- * lazily, from the first such search on — an fp16 copy of its rows next to the fp32 matrix (2 more bytes per element): the
+/* Rows held in the index' fp16 SHADOW (0: none).  An index of width d = 256 / 384 / 512 / 640 / 768 / 896 / 1024 (unpadded rows)
+ * that answers a batch the certified passes take — 2+ queries from 500k rows, 8+ from 100k, 33+ below (thresholds measured at
+ * d = 512 and applied to every shadow width: the pass is bound by the shadow's bytes at all of them) — keeps, lazily, from the
+ * first such search on (that search builds it: one blocking conversion pass and a hipMalloc inside an otherwise asynchronous
+ * call), an fp16 copy of its rows next to the fp32 matrix (2 more bytes per element = +50 % of the index's device memory): the
  * nomination pass of those batches streams it instead of converting fp32 rows on the fly (half the bytes; the fp32 matrix stays
  * the home of the exact scans and of every returned score).  add extends it, remove_rows / reset / a re-allocation drop it (the
  * next batch search rebuilds it: ~5 ms per 10M x 512 rows); an allocation failure simply leaves the fp32 path in charge.

@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <atomic>
 #include <map>
+#include <tuple>
 #include <vector>
 #include <shared_mutex>
 
@@ -79,13 +80,16 @@ Knobs read_knobs() {
 
 int cached_occupancy(const void* kern, int threads, size_t lds, int dflt) {
     static std::mutex mu;
-    static std::map<std::pair<const void*, size_t>, int> cache;
+    static std::map<std::tuple<const void*, size_t, int, int>, int> cache;  // (kernel, dynamic LDS, threads, current device)
+    int dev = 0;
+    (void)hipGetDevice(&dev);
     std::lock_guard<std::mutex> lk(mu);
-    auto it = cache.find({kern, lds});
+    const auto key = std::make_tuple(kern, lds, threads, dev);
+    auto it = cache.find(key);
     if (it != cache.end()) return it->second;
     int nb = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, threads, lds) != hipSuccess || nb <= 0) nb = dflt;
-    cache[{kern, lds}] = nb;
+    cache[key] = nb;
     return nb;
 }
 
@@ -268,7 +272,8 @@ struct mvdb_index {
     mutable _Float16* Xh = nullptr;
     mutable int64_t xh_cap = 0, xh_rows = 0;   // rows allocated (+ kRowSlack behind them) / rows converted
     mutable float xh_scale = 0.f;
-    mutable bool xh_failed = false;            // allocation failed: not retried until the index changes
+    mutable std::atomic<bool> xh_failed{false};  // allocation failed: not retried until the index changes (read by routing code
+                                                 // that holds only the shared lock, written under shadow_mu: atomic)
     mutable float* Hn = nullptr;               // L2 over rows of mixed norms: |x_r|^2 / 2 of rows [0, hn_rows) (+ zeroed slack), dies with Xh
     mutable int64_t hn_rows = 0;
     mutable std::shared_mutex mu;  // search: shared; add/reset/remove/free: exclusive
@@ -359,9 +364,16 @@ constexpr int kMaxC = 16;  // d <= 4096
 template <int G, int C, int U, int METRIC, int MODE, bool NT, int SEL, bool MASKED>
 int launch_scan_kern(const ScanArgs& a, int nq, int device, hipStream_t stream, int* nblocks_out) {
     void (*kern)(ScanArgs) = flat_scan_kernel<G, C, U, METRIC, MODE, NT, SEL, MASKED>;
-    if constexpr (METRIC == 1 && MODE == kModeTopK && SEL == 0) {
-        if (a.gate) kern = flat_scan_kernel<G, C, U, METRIC, MODE, NT, SEL, MASKED, true>;  // device-gated exact re-run (L2)
+    bool gated = false;
+    // device-gated exact re-run of an L2 batch's queries: over the whole index (SEL 0) and under a bitmap (SEL 2 — round-4
+    // advisor finding: without the gated instantiation every query of a certified masked L2 batch paid a full masked scan)
+    if constexpr (METRIC == 1 && MODE == kModeTopK && (SEL == 0 || SEL == 2)) {
+        if (a.gate) {
+            kern = flat_scan_kernel<G, C, U, METRIC, MODE, NT, SEL, MASKED, true>;
+            gated = true;
+        }
     }
+    if (a.gate && !gated) return fail(MVDB_ERR_ARG, "internal: a device-gated scan was requested for a kernel form that has no gated instantiation");
     const int occ_hw = cached_occupancy((const void*)kern, kScanThreads, 0, 4);  // blocks per CU this instantiation sustains
     int occ;
     {
@@ -383,7 +395,7 @@ int launch_scan_kern(const ScanArgs& a, int nq, int device, hipStream_t stream, 
     if (nblocks_out) *nblocks_out = nblocks;
     const char* pname = MODE == kModeTopK ? "ip_scan" : "ip_scan_scores";
     prof_symbol(pname, "flat_scan_kernel<%d, %d, %d, %d, %d, %s, %d, %s, %s>", G, C, U, METRIC, MODE, NT ? "true" : "false", SEL,
-                MASKED ? "true" : "false", a.gate ? "true" : "false");
+                MASKED ? "true" : "false", gated ? "true" : "false");
     int slot = prof_begin(pname, stream);
     hipLaunchKernelGGL(kern, dim3(nblocks, nq), dim3(kScanThreads), 0, stream, a);
     prof_end(slot, stream);
@@ -502,7 +514,28 @@ int normalize_range(const mvdb_index* idx, float* base, int64_t n, hipStream_t s
 // keeps running.  The mutators then work on the index's own non-blocking stream (idx->mut) and wait for that stream only.
 int quiesce(mvdb_index* idx) {
     std::lock_guard<std::mutex> lk(idx->ws_mu);
-    for (auto& kv : idx->stream_ws) MVDB_HIP(hipStreamSynchronize((hipStream_t)kv.first));
+    // A caller may have destroyed a stream it once searched on (hipStreamDestroy completes the stream's work first), or be
+    // capturing one: neither may wedge the index (round-4 advisor finding: the error made every later add / remove_rows /
+    // reset / reserve fail).  A dead handle is forgotten with its workspace; any other failure falls back to the device-wide
+    // wait the mutators used before round 4.
+    bool device_wide = false;
+    for (auto it = idx->stream_ws.begin(); it != idx->stream_ws.end();) {
+        const hipError_t e = hipStreamSynchronize((hipStream_t)it->first);
+        if (e == hipSuccess) {
+            ++it;
+            continue;
+        }
+        (void)hipGetLastError();
+        if (e == hipErrorInvalidHandle || e == hipErrorInvalidResourceHandle || e == hipErrorContextIsDestroyed) {
+            it->second->destroy();
+            delete it->second;
+            it = idx->stream_ws.erase(it);
+        } else {
+            device_wide = true;
+            ++it;
+        }
+    }
+    if (device_wide) MVDB_HIP(hipDeviceSynchronize());
     if (idx->default_stream_ws) MVDB_HIP(hipStreamSynchronize(nullptr));
     if (!idx->mut) MVDB_HIP(hipStreamCreateWithFlags(&idx->mut, hipStreamNonBlocking));
     return 0;
@@ -1645,6 +1678,9 @@ int grow(mvdb_index* idx, int64_t need) {
     if (need <= idx->cap) return 0;
     int64_t cap = std::max<int64_t>(need, idx->cap + idx->cap / 2);
     cap = std::max<int64_t>(cap, 1024);
+    // the fp16 shadow (50 % of the matrix's bytes) goes first: it is sized for the old capacity anyway (rebuilt by the next
+    // batch search), and an add on a nearly full device must not fail for a copy that is about to be dropped
+    drop_shadow(idx);
     float* nx = nullptr;
     MVDB_HIP(hipMalloc((void**)&nx, (size_t)(cap + kRowSlack) * idx->ld * sizeof(float)));
     if (idx->n > 0) {
@@ -1660,7 +1696,6 @@ int grow(mvdb_index* idx, int64_t need) {
     if (idx->X) (void)hipFree(idx->X);
     idx->X = nx;
     idx->cap = cap;
-    drop_shadow(idx);  // sized for the old capacity: rebuilt by the next batch search
     return 0;
 }
 
@@ -1802,6 +1837,7 @@ int mvdb_index_reserve(mvdb_index* idx, int64_t n) {
     if (n <= idx->cap) return 0;
     MVDB_TRY(quiesce(idx));
     // exact-size growth (no 1.5x slack): the caller knows the final size
+    drop_shadow(idx);  // before the new matrix is allocated (see grow)
     float* nx = nullptr;
     MVDB_HIP(hipMalloc((void**)&nx, (size_t)(n + kRowSlack) * idx->ld * sizeof(float)));
     if (idx->n > 0) {
@@ -2409,7 +2445,8 @@ static int rowset_search_core(const mvdb_index* idx, Workspace* ws, const float*
         const int64_t n = rs->n_at_create;
         const bool half = half_path_ok(idx) && nq >= half_min_nq(idx, n);
         const int per = half ? std::max(1, half_max_queries(idx->d)) : std::max(1, mfma_gated_queries(idx));
-        const double shared = (double)((nq + per - 1) / per) * (half && idx->Xh ? 0.6 : 1.0);
+        const bool have_shadow = __atomic_load_n(&idx->Xh, __ATOMIC_RELAXED) != nullptr;  // a heuristic read: ensure_shadow writes it under shadow_mu
+        const double shared = (double)((nq + per - 1) / per) * (half && have_shadow ? 0.6 : 1.0);
         const double gathered = (double)nq * (double)rs->count / (double)n * 1.1;
         if (shared < gathered)
             return search_core(idx, ws, q, nq, k, normalize_q, nullptr, n, label_offset, D_dev, I_dev, true, rs->twin);

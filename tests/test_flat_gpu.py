@@ -1168,6 +1168,41 @@ def test_add_does_not_synchronise_the_device(native):
     idx.close()
 
 
+def test_a_destroyed_caller_stream_does_not_wedge_the_index(native):
+    """Round-4 advisor finding: mutators wait on every stream that ever searched the index; a caller that destroyed such a
+    stream made every later add / remove_rows / reset / reserve fail.  The dead handle is forgotten (hipStreamDestroy has
+    completed its work), anything else falls back to a device-wide wait."""
+    import ctypes
+    import torch
+    dev = torch.device("cuda", 0)
+    hip = ctypes.CDLL(None)   # the process's one HIP runtime (torch's, bound RTLD_GLOBAL)
+    hip.hipStreamCreate.argtypes = [ctypes.POINTER(ctypes.c_void_p)]
+    hip.hipStreamDestroy.argtypes = [ctypes.c_void_p]
+    hip.hipStreamSynchronize.argtypes = [ctypes.c_void_p]
+    d = 128
+    idx = native.FlatIndex(d)
+    x = _corpus(5000, d)
+    idx.add(x[:4000], normalize=True)
+    s = ctypes.c_void_p()
+    assert hip.hipStreamCreate(ctypes.byref(s)) == 0
+    qt = torch.from_numpy(_corpus(2, d, seed=3)).to(dev)
+    Dd = torch.empty((2, 5), dtype=torch.float32, device=dev)
+    Id = torch.empty((2, 5), dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+    idx.search_device(qt.data_ptr(), 2, 5, Dd.data_ptr(), Id.data_ptr(), stream=s.value)
+    assert hip.hipStreamSynchronize(s) == 0
+    want = Id.cpu().numpy().copy()
+    assert hip.hipStreamDestroy(s) == 0
+    idx.add(x[4000:], normalize=True)            # waited on the dead stream before the fix: every mutator failed from here on
+    idx.remove_rows(np.arange(4000, 4500, dtype=np.int64))
+    idx.reserve(20000)
+    D, I = idx.search(qt.cpu().numpy(), 5)
+    assert I.shape == (2, 5) and idx.ntotal == 4500
+    Do, Io = flat.flat_search(idx.get_rows(0, 4500), qt.cpu().numpy(), 5)
+    assert np.array_equal(I, Io) and (want < 4000).all()
+    idx.close()
+
+
 def test_single_queries_over_the_shadow_when_asked_for(native, tmp_path):
     """mvdb_index_set_option("shadow_single_query", 1) — and VectorDatabase(fast_single_query=True) — send ONE query per call through the
     certified nomination pass over the fp16 shadow too (>= 500,000 rows at d = 256 / 384 / 512): same ids as the exact scan and as
@@ -1354,6 +1389,10 @@ def test_l2_batches_under_a_bitmap(native, d, nq, k, mixed):
         _split_launches(native)
         D, I = idx.search_masked(q, k, mask, labels="rows")
         assert _split_launches(native) > 0, "the certified pass did not run"
+        # the exact re-run under the bitmap is enabled per query ON THE DEVICE (round-4 advisor finding: the masked form had no
+        # gated instantiation, so every query of the batch paid a full masked scan behind the certified pass)
+        sym = native.prof_symbol("ip_scan")
+        assert sym.startswith("flat_scan_kernel<") and sym.endswith(", true>"), sym
     finally:
         native.prof_enable(False)
     assert native.split_rerun_count() - before >= 1
