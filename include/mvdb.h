@@ -75,6 +75,13 @@ int mvdb_index_reload_env(mvdb_index* idx);
  *   "compact_bytes" (> 0, default 512 MiB): staging buffer of mvdb_index_remove_rows. */
 int mvdb_index_set_option(mvdb_index* idx, const char* name, long long value);
 
+/* The opt-in single-query route over the shadow ("shadow_single_query") costs more than the exact scan whenever its certificate
+ * is refused (clustered / duplicate-heavy corpora: the nomination pass AND the exact scan).  The library watches the refusals
+ * (a device counter mirrored into host-mapped memory: no synchronisation) in windows of 32 such calls; when half of a window
+ * was refused the next 512 single queries take the exact scan directly, then the route probes again.  Returns how many times
+ * that has happened on this index (diagnostics; -1 for NULL).  Results are identical either way. */
+long long mvdb_index_single_route_suspensions(const mvdb_index* idx);
+
 /* Drop all rows (capacity is kept). */
 int mvdb_index_reset(mvdb_index* idx);
 
@@ -336,6 +343,13 @@ int mvdb_encoder_forward(mvdb_encoder* enc, const int32_t* ids_host, const int32
 int mvdb_encoder_forward_device(mvdb_encoder* enc, const int32_t* ids_dev, const int32_t* mask_dev,
                                 int B, int S, int compute, float* out_dev, float* hidden_dev,
                                 void* stream);
+
+/* Device address of ONE uint32 that every forward clears when it starts and ORs 1 into when a pooled row of a non-empty sentence
+ * is not finite — the split-precision mode (compute = 2) takes activations as fp16 pieces, so an activation beyond 65504
+ * overflows.  mvdb_encoder_forward_device never synchronises: its callers (and a graph that chains the forward into a search)
+ * test this word on the device, or read it back behind their own synchronisation, and re-run in the exact mode (compute = 0) —
+ * which is what mvdb_encoder_forward's Python wrapper does on the host path.  Valid until mvdb_encoder_free. */
+const unsigned int* mvdb_encoder_overflow_flag(const mvdb_encoder* enc);
 
 /* 1 when a forward of B x S token slots runs as the ONE layer-walking launch (csrc/encoder_walk.hpp: at most 64 token slots —
  * one sentence per call is the reference's only shape, embedding_model.py:62-71 —, exact fp32 matrix cores whatever `compute`

@@ -266,9 +266,11 @@ __global__ __launch_bounds__(256) void ln_partials_kernel(const float* __restric
 
 // out[b,:] = normalize(mean over the sequence's tokens)   — average_pool + F.normalize(eps=1e-12)
 // pooling == 1: the first valid token (CLS) instead of the mean — BGE-M3's dense_vecs
+// flag: one word the launch ORs 1 into when a pooled row of a NON-empty sentence is not finite (an activation left the fp16 range
+// of the split-precision GEMMs): callers of the device entry test it without reading the embeddings back
 __global__ __launch_bounds__(256) void pool_norm_kernel(const float* __restrict__ x,
                                                         const int* __restrict__ seq_start, int H,
-                                                        int pooling, float* __restrict__ out) {
+                                                        int pooling, float* __restrict__ out, unsigned int* __restrict__ flag) {
     __shared__ float red[256];
     const int b = blockIdx.x;
     const int s0 = seq_start[b], len = seq_start[b + 1] - s0;
@@ -298,6 +300,7 @@ __global__ __launch_bounds__(256) void pool_norm_kernel(const float* __restrict_
         __syncthreads();
     }
     const float denom = fmaxf(sqrtf(red[0]), 1e-12f);
+    if (flag && threadIdx.x == 0 && span > 0 && !(red[0] < INFINITY)) atomicOr(flag, 1u);  // NaN or inf among the row's squares
     for (int c = threadIdx.x; c < H; c += blockDim.x) out[(int64_t)b * H + c] /= denom;
 }
 
@@ -2270,6 +2273,7 @@ struct mvdb_encoder {
     float *walk_x = nullptr, *walk_x1 = nullptr, *walk_qkv = nullptr, *walk_pl = nullptr;
     unsigned int* walk_bar = nullptr;
     unsigned long long* walk_trace = nullptr;  // ablation build only
+    unsigned int* overflow_flag = nullptr;     // device word: 1 after a forward whose pooled rows were not all finite
     int walk_np3 = 0, walk_grid = 0, walk_grid_env = 0;
 
     void free_ws() {
@@ -2956,7 +2960,7 @@ int enqueue_lane(mvdb_encoder* e, mvdb_encoder::Lane& w, const int32_t* ids, con
 #undef LN2_CALL
     }
 #undef MVDB_VPT_SWITCH
-    hipLaunchKernelGGL(pool_norm_kernel, dim3(B), dim3(256), 0, s, w.x, w.seq_start, H, c.pooling, out);
+    hipLaunchKernelGGL(pool_norm_kernel, dim3(B), dim3(256), 0, s, w.x, w.seq_start, H, c.pooling, out, e->overflow_flag);
     if (hidden)
         hipLaunchKernelGGL(unpack_hidden_kernel, dim3((unsigned)Tmax), dim3(256), 0, s, w.x, w.rank,
                            w.seq_start, S, H, hidden);
@@ -2975,6 +2979,7 @@ int enqueue_forward(mvdb_encoder* e, const int32_t* ids, const int32_t* mask, in
         return v ? atoi(v) : 1;
     }();
     const bool split = split_mode && s && compute == 0 && B >= 64 && (int64_t)B * S >= 32768 && e->stream2;
+    MVDB_HIP(hipMemsetAsync(e->overflow_flag, 0, sizeof(unsigned int), s));  // (a memset node of the captured graph)
     if (!split) return enqueue_lane(e, e->lane[0], ids, mask, B, S, compute, out, hidden, s);
     const int b0 = B / 2, b1 = B - b0;
     const int H = e->cfg.hidden;
@@ -3003,6 +3008,7 @@ int forward_core(mvdb_encoder* e, const int32_t* ids, const int32_t* mask, int B
         hipStreamCaptureStatus cap0 = hipStreamCaptureStatusNone;
         const bool captured = s && hipStreamIsCapturing(s, &cap0) == hipSuccess && cap0 != hipStreamCaptureStatusNone;
         const int pslot0 = captured ? -1 : prof_begin("encoder", s);
+        MVDB_HIP(hipMemsetAsync(e->overflow_flag, 0, sizeof(unsigned int), s));  // exact fp32: nothing to overflow into
         const int rc0 = launch_walk(e, ids, mask, B, S, out, hidden, s);
         prof_end(pslot0, s);
         return rc0;
@@ -3167,6 +3173,9 @@ int mvdb_encoder_create(const mvdb_encoder_cfg* cfg, const void* const* w, int d
         rc = fail(MVDB_ERR_HIP, "stream / event creation for the split forward failed");
     if (!rc && hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess)
         rc = fail(MVDB_ERR_HIP, "stream creation failed");
+    if (!rc && (hipMalloc((void**)&e->overflow_flag, sizeof(unsigned int)) != hipSuccess ||
+                hipMemset(e->overflow_flag, 0, sizeof(unsigned int)) != hipSuccess))
+        rc = fail(MVDB_ERR_OOM, "device allocation for the overflow flag failed");
     if (rc) {
         mvdb_encoder_free(e);
         return rc;
@@ -3174,6 +3183,8 @@ int mvdb_encoder_create(const mvdb_encoder_cfg* cfg, const void* const* w, int d
     *out = e;
     return 0;
 }
+
+const unsigned int* mvdb_encoder_overflow_flag(const mvdb_encoder* e) { return e ? e->overflow_flag : nullptr; }
 
 int mvdb_encoder_walks(const mvdb_encoder* e, int B, int S) {
     return e && B > 0 && S > 0 && walk_eligible(e, B, S) ? 1 : 0;
@@ -3197,7 +3208,7 @@ int mvdb_encoder_free(mvdb_encoder* e) {
         if (e->ids_stage) (void)hipFree(e->ids_stage);
         if (e->mask_stage) (void)hipFree(e->mask_stage);
         if (e->out_stage) (void)hipFree(e->out_stage);
-        void* walk_bufs[] = {e->walk_layers, e->walk_x, e->walk_x1, e->walk_qkv, e->walk_pl, e->walk_bar, e->walk_trace};
+        void* walk_bufs[] = {e->walk_layers, e->walk_x, e->walk_x1, e->walk_qkv, e->walk_pl, e->walk_bar, e->walk_trace, e->overflow_flag};
         for (void* p : walk_bufs)
             if (p) (void)hipFree(p);
         if (e->stream) (void)hipStreamDestroy(e->stream);

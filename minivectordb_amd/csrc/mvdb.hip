@@ -276,6 +276,17 @@ struct mvdb_index {
                                                  // that holds only the shared lock, written under shadow_mu: atomic)
     mutable float* Hn = nullptr;               // L2 over rows of mixed norms: |x_r|^2 / 2 of rows [0, hn_rows) (+ zeroed slack), dies with Xh
     mutable int64_t hn_rows = 0;
+    // The opt-in single-query route over the shadow costs MORE than the exact scan when its certificate is refused (the
+    // nomination pass, then the exact scan anyway: 0.59 against 0.31 ms per query on a clustered 1M x 512 corpus,
+    // BENCH certified_passes_on_unfriendly_data).  The device keeps a running count of refused single-query certificates and
+    // mirrors it into a host-mapped word; the routing looks at windows of 32 such calls and, when half of a window was
+    // refused, sends the next 512 single queries straight to the exact scan before it probes again.  No synchronisation: the
+    // word lags by the calls in flight, which a heuristic can afford.
+    mutable unsigned int* sq_fail_dev = nullptr;
+    mutable PinnedBuf sq_fail_host;
+    mutable std::atomic<unsigned int> sq_calls{0}, sq_window_calls{0}, sq_window_fail{0};
+    mutable std::atomic<int> sq_suspend_left{0};
+    mutable std::atomic<unsigned long long> sq_suspensions{0};
     mutable std::shared_mutex mu;  // search: shared; add/reset/remove/free: exclusive
     mutable std::mutex ws_mu;
     mutable std::vector<Workspace*> free_ws;           // synchronous searches
@@ -780,12 +791,33 @@ bool l2_offsets_ok(const mvdb_index* idx, int nq, int64_t n) {
 // (profiles/r04_small_batch_crossover.jsonl): 10M x 512: 2 queries 2.93 / 1.61 ms, 32 queries 3.06 / 1.63; 1M rows: 2 queries
 // 0.33 / 0.26, 13 queries 0.44 / 0.27; 100k rows: 2 queries 0.068 / 0.114, 8 queries 0.123 / 0.122, 13 queries 0.170 / 0.126.
 // Elsewhere: 33 (and the bf16-split pass from 14).  MVDB_SPLIT_SCAN_MIN_NQ overrides.
+thread_local bool tls_single_suspended = false;  // decided once per search (search_core), read by every routing question of that call
+constexpr int kSingleWindow = 32, kSingleSuspend = 512;
+// One decision per single-query search that asks for the shadow route: true = this call takes the exact scan.
+bool single_route_suspended(const mvdb_index* idx) {
+    if (idx->sq_suspend_left.load(std::memory_order_relaxed) > 0) {
+        idx->sq_suspend_left.fetch_sub(1, std::memory_order_relaxed);
+        return true;
+    }
+    const unsigned int calls = idx->sq_calls.fetch_add(1, std::memory_order_relaxed) + 1;
+    if (calls - idx->sq_window_calls.load(std::memory_order_relaxed) >= (unsigned int)kSingleWindow && idx->sq_fail_host.p) {
+        const unsigned int fails = *reinterpret_cast<volatile unsigned int*>(idx->sq_fail_host.p);
+        if ((fails - idx->sq_window_fail.load(std::memory_order_relaxed)) * 2 >= (unsigned int)kSingleWindow) {
+            idx->sq_suspend_left.store(kSingleSuspend, std::memory_order_relaxed);
+            idx->sq_suspensions.fetch_add(1, std::memory_order_relaxed);
+        }
+        idx->sq_window_calls.store(calls, std::memory_order_relaxed);
+        idx->sq_window_fail.store(fails, std::memory_order_relaxed);
+    }
+    return false;
+}
+
 int half_min_nq(const mvdb_index* idx, int64_t n) {
     if (idx->kn.split_scan_min_nq >= 0) return idx->kn.split_scan_min_nq;
     if (half_shadow_dim(idx->d) && idx->ld == idx->d && !idx->kn.disable_half_shadow && !idx->xh_failed) {
         // (opt-in, MVDB_SHADOW_SINGLE_QUERY=1: ONE query too — 10M x 512: 2.86 -> ~1.6 ms per query, certified like any batch; off
         //  by default: the single-query scan is the headline's exact fp32 kernel and its roofline is defined on the fp32 bytes)
-        if (n >= 500000) return idx->kn.shadow_single_query ? 1 : 2;
+        if (n >= 500000) return idx->kn.shadow_single_query && !tls_single_suspended ? 1 : 2;
         if (n >= 100000) return 8;
     }
     return 33;
@@ -793,7 +825,7 @@ int half_min_nq(const mvdb_index* idx, int64_t n) {
 
 bool split_path_ok(const mvdb_index* idx, int nq, int k, const int64_t* rows_dev, int64_t n) {
     if (idx->kn.disable_split_scan) return false;
-    const bool single_ok = nq == 1 && idx->kn.shadow_single_query && half_path_ok(idx) && half_min_nq(idx, n) <= 1;
+    const bool single_ok = nq == 1 && idx->kn.shadow_single_query && !tls_single_suspended && half_path_ok(idx) && half_min_nq(idx, n) <= 1;
     if ((nq < 2 && !single_ok) || rows_dev || (idx->metric != MVDB_METRIC_IP && !l2_cert_ok(idx) && !l2_offsets_ok(idx, nq, n)))
         return false;
     // (k > 16 also needs the gated fp32-MFMA pass for the exact re-runs: the GEMM-tiled scan keeps 16 results per query)
@@ -1132,6 +1164,7 @@ int search_core(const mvdb_index* idx, Workspace* ws, const float* q_dev, int nq
                 float* D_dev, int64_t* I_dev, bool allow_split = true, const uint64_t* mask_dev = nullptr) {
     KnobScope knobs(&idx->kn);
     hipStream_t s = ws->stream;
+    if (allow_split) tls_single_suspended = nq == 1 && idx->kn.shadow_single_query && single_route_suspended(idx);
     // row list: its m entries; bitmap: the first m rows when the caller says how many rows the bitmap covers (a resident
     // row set built before later appends), else every row
     const int64_t n = rows_dev ? m : (mask_dev && m > 0 ? std::min<int64_t>(m, idx->n) : idx->n);
@@ -1240,8 +1273,25 @@ int search_core(const mvdb_index* idx, Workspace* ws, const float* q_dev, int nq
             int64_t* It = map + R;
             float* qc = ws->requery.p;
             float* Dt = qc + (size_t)(R + 128) * idx->ld;
+            unsigned int *sq_dev = nullptr, *sq_host = nullptr;
+            if (nq == 1 && idx->kn.shadow_single_query) {  // the opt-in single-query route reports its refusals (single_route_suspended)
+                std::lock_guard<std::mutex> lk(idx->shadow_mu);
+                if (!idx->sq_fail_dev && hipMalloc((void**)&idx->sq_fail_dev, sizeof(unsigned int)) == hipSuccess) {
+                    if (hipMemsetAsync(idx->sq_fail_dev, 0, sizeof(unsigned int), s) != hipSuccess || idx->sq_fail_host.reserve(64) != 0) {
+                        (void)hipFree(idx->sq_fail_dev);
+                        idx->sq_fail_dev = nullptr;
+                    } else {
+                        *reinterpret_cast<volatile unsigned int*>(idx->sq_fail_host.p) = 0u;
+                    }
+                }
+                (void)hipGetLastError();
+                if (idx->sq_fail_dev && idx->sq_fail_host.p) {
+                    sq_dev = idx->sq_fail_dev;
+                    sq_host = reinterpret_cast<unsigned int*>(idx->sq_fail_host.p);
+                }
+            }
             hipLaunchKernelGGL(split_plan_kernel, dim3(1), dim3(64), 0, s, (const int*)ws->flags.p, nchunks, (const int*)ws->qfail.p, q0,
-                               map, ws->nfail.p, ctr);
+                               map, ws->nfail.p, ctr, sq_dev, (volatile unsigned int*)sq_host);
             {
                 const int64_t rows = R + 128, gtotal = rows * (idx->ld / 4);
                 const int ggrid = (int)std::min<int64_t>((gtotal + 255) / 256, (int64_t)device_cus(idx->device) * 8);
@@ -1766,9 +1816,12 @@ int mvdb_index_set_option(mvdb_index* idx, const char* name, long long value) {
     if (!name) return fail(MVDB_ERR_ARG, "option name is NULL");
     std::unique_lock<std::shared_mutex> lk(idx->mu);
     const std::string n(name);
-    if (n == "shadow_single_query")
+    if (n == "shadow_single_query") {
         idx->kn.shadow_single_query = value != 0;
-    else if (n == "half_shadow")
+        idx->sq_suspend_left.store(0);   // a fresh start: the route probes again from its next call
+        idx->sq_window_calls.store(idx->sq_calls.load());
+        if (idx->sq_fail_host.p) idx->sq_window_fail.store(*reinterpret_cast<volatile unsigned int*>(idx->sq_fail_host.p));
+    } else if (n == "half_shadow")
         idx->kn.disable_half_shadow = value == 0;
     else if (n == "compact_bytes") {
         if (value <= 0) return fail(MVDB_ERR_ARG, "compact_bytes must be positive");
@@ -1776,6 +1829,10 @@ int mvdb_index_set_option(mvdb_index* idx, const char* name, long long value) {
     } else
         return fail(MVDB_ERR_ARG, "unknown index option '%s' (shadow_single_query, half_shadow, compact_bytes)", name);
     return 0;
+}
+
+long long mvdb_index_single_route_suspensions(const mvdb_index* idx) {
+    return idx ? (long long)idx->sq_suspensions.load() : -1;
 }
 
 int mvdb_index_free(mvdb_index* idx) {
@@ -1787,6 +1844,8 @@ int mvdb_index_free(mvdb_index* idx) {
         if (idx->mut) (void)hipStreamDestroy(idx->mut);
         if (idx->normmax) (void)hipFree(idx->normmax);
         if (idx->ctmp) (void)hipFree(idx->ctmp);
+        if (idx->sq_fail_dev) (void)hipFree(idx->sq_fail_dev);
+        idx->sq_fail_host.release();
         drop_shadow(idx);
         for (Workspace* w : idx->free_ws) {
             w->destroy();

@@ -109,22 +109,52 @@ __host__ __device__ inline float synth_element(uint32_t seed_lo, uint32_t seed_h
     return (float)(sum - 131070) * (1.0f / 131072.0f);  // in (-1, 1), exact
 }
 
+// Three FAMILIES of rows, chosen by the seed's top byte (seed >> 56), all exact in fp32 on host and device alike
+// (oracle/flat_oracle.c restates this function bit for bit):
+//   0  zero-mean bell-shaped elements (above): the stream of every BASELINE config.  After normalisation the scores of a
+//      query spread widely: the certified batch passes always certify on it.
+//   1  all-positive rows, uniform in [0, 1) — what the reference's own tests store (numpy.random.rand:
+//      tests/test_sharded_multithreaded_operations.py:22).  Normalised, every pair of rows has cosine ~0.75: a narrow cone.
+//   2  clustered: row = centre[c] + noise, c = one of 4,096 centres SHARED by every seed (queries drawn from the family fall
+//      beside the corpus' centres, as sentence embeddings of one domain do); noise = 2^-4 x a family-0 element (~6 % of the
+//      centre's norm), except 1 row in 256 with none at all (EXACT duplicates of one another) and 1 in 256 at 2^-13 (near
+//      duplicates).  Thousands of rows per centre score within 1e-3 of each other: certification fails by design.
+constexpr uint64_t kSynthFamilyShift = 56;
+constexpr uint32_t kSynthCentreSeed = 0xC3A5C85Cu;  // the centres' own stream (independent of the row seed)
+__host__ __device__ inline float synth_value(uint64_t seed, uint64_t row, uint32_t col, uint32_t d) {
+    const uint32_t slo = (uint32_t)seed, shi = (uint32_t)(seed >> 32);
+    const uint32_t family = (uint32_t)(seed >> kSynthFamilyShift);
+    const uint64_t ctr = row * (uint64_t)d + col;
+    if (family == 0) return synth_element(slo, shi, ctr);
+    if (family == 1) {
+        const uint32_t lo = (uint32_t)ctr, hi = (uint32_t)(ctr >> 32);
+        const uint32_t h = pcg_hash32(lo ^ pcg_hash32(hi ^ pcg_hash32(slo ^ pcg_hash32(shi))));
+        return (float)(h >> 8) * (1.0f / 16777216.0f);  // 24 bits: exact, in [0, 1)
+    }
+    const uint32_t rlo = (uint32_t)row, rhi = (uint32_t)(row >> 32);
+    const uint32_t hr = pcg_hash32(rlo ^ pcg_hash32(rhi ^ pcg_hash32(slo ^ pcg_hash32(shi ^ 0x5BD1E995u))));
+    const uint32_t centre = hr & 4095u, kind = (hr >> 12) & 255u;
+    const float c = synth_element(kSynthCentreSeed, 2u, (uint64_t)centre * d + col);
+    if (kind == 0) return c;                                   // exact duplicate of every other noise-free row of the centre
+    const float e = synth_element(slo, shi, ctr);
+    return c + e * (kind == 1 ? 1.0f / 8192.0f : 1.0f / 16.0f);  // power-of-two scale: the product is exact, ONE rounding in the sum
+}
+
 __global__ __launch_bounds__(256) void synth_fill_kernel(float* __restrict__ X, int64_t n,
                                                          int64_t ld, int d, uint64_t seed,
                                                          int64_t first_row) {
     const int64_t d4 = ld / 4;
     const int64_t total = n * d4;
-    const uint32_t slo = (uint32_t)seed, shi = (uint32_t)(seed >> 32);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t r = i / d4;
         const int c = (int)(i - r * d4);
-        const uint64_t base = (uint64_t)(first_row + r) * (uint64_t)d + (uint64_t)c * 4;
+        const uint64_t row = (uint64_t)(first_row + r);
         f32x4u v;
-        v.x = (c * 4 + 0 < d) ? synth_element(slo, shi, base + 0) : 0.f;
-        v.y = (c * 4 + 1 < d) ? synth_element(slo, shi, base + 1) : 0.f;
-        v.z = (c * 4 + 2 < d) ? synth_element(slo, shi, base + 2) : 0.f;
-        v.w = (c * 4 + 3 < d) ? synth_element(slo, shi, base + 3) : 0.f;
+        v.x = (c * 4 + 0 < d) ? synth_value(seed, row, c * 4 + 0, d) : 0.f;
+        v.y = (c * 4 + 1 < d) ? synth_value(seed, row, c * 4 + 1, d) : 0.f;
+        v.z = (c * 4 + 2 < d) ? synth_value(seed, row, c * 4 + 2, d) : 0.f;
+        v.w = (c * 4 + 3 < d) ? synth_value(seed, row, c * 4 + 3, d) : 0.f;
         *reinterpret_cast<f32x4u*>(X + r * ld + c * 4) = v;
     }
 }
@@ -145,7 +175,9 @@ __global__ __launch_bounds__(256) void scatter_results_kernel(const float* __res
 // queries that failed (map[0 .. nb)), publishes nb and adds the number of chunks that held one to the re-run counter.
 __global__ __launch_bounds__(64) void split_plan_kernel(const int* __restrict__ chunk_flags, int nchunks,
                                                         const int* __restrict__ qfail, int nq, int64_t* __restrict__ map,
-                                                        int* __restrict__ nb_out, unsigned long long* __restrict__ rerun_ctr) {
+                                                        int* __restrict__ nb_out, unsigned long long* __restrict__ rerun_ctr,
+                                                        unsigned int* __restrict__ fail_dev = nullptr,
+                                                        volatile unsigned int* fail_host = nullptr) {
     const int lane = threadIdx.x;
     int bad = 0;
     for (int c = lane; c < nchunks; c += 64) bad += chunk_flags[c] != 0;
@@ -161,6 +193,9 @@ __global__ __launch_bounds__(64) void split_plan_kernel(const int* __restrict__ 
     if (lane == 0) {
         *nb_out = run;
         if (bad) atomicAdd(rerun_ctr, (unsigned long long)bad);
+        // the opt-in single-query route: a running count of refused certificates, mirrored into a host-mapped word that the
+        // routing reads WITHOUT synchronising (mvdb.hip: single_route_suspended)
+        if (fail_dev && run) *fail_host = atomicAdd(fail_dev, (unsigned int)run) + (unsigned int)run;
     }
 }
 

@@ -125,11 +125,36 @@ class GpuEncoder:
                 ctypes.c_void_p(out.ctypes.data)))
         return out
 
-    def forward_device(self, ids, mask, compute=None, want_hidden=False):
+    @property
+    def overflow_flag_ptr(self):
+        """Device address of the uint32 a forward sets to 1 when a pooled row of a non-empty sentence is not finite."""
+        return int(self._native.lib().mvdb_encoder_overflow_flag(self._h) or 0)
+
+    def overflow_flag(self):
+        """The flag as a 1-element int32 torch tensor living in the encoder's own device word (no copy, no synchronisation):
+        `enc.overflow_flag().item()` behind the caller's own stream wait, or a device-side test inside a graph."""
+        import torch
+
+        class _Word:  # __cuda_array_interface__ view of the library's word
+            def __init__(self, ptr):
+                self.__cuda_array_interface__ = {"shape": (1,), "typestr": "<i4", "data": (ptr, False), "version": 2}
+
+        return torch.as_tensor(_Word(self.overflow_flag_ptr), device=self.device)
+
+    def forward_device(self, ids, mask, compute=None, want_hidden=False, rerun_on_overflow=False):
         """ids, mask: int32 torch tensors [B,S] on this device.  Returns (pooled [B,H], hidden [B,S,H] or
-        None) as torch tensors; enqueued on torch's current stream."""
+        None) as torch tensors; enqueued on torch's current stream.  The split-precision mode (compute = 2) overflows when an
+        activation leaves the fp16 range: the forward then raises the device-side overflow flag (`overflow_flag()`), which a
+        caller can test without reading the embeddings; rerun_on_overflow=True does it here (ONE stream wait per call) and runs
+        the exact mode again when it is set, like the host entry."""
         import torch
         compute = self.default_compute if compute is None else compute
+        if rerun_on_overflow and compute == 2:
+            out, hidden = self.forward_device(ids, mask, compute=2, want_hidden=want_hidden)
+            torch.cuda.current_stream().synchronize()
+            if int(self.overflow_flag().item()):
+                return self.forward_device(ids, mask, compute=0, want_hidden=want_hidden)
+            return out, hidden
         B, S = ids.shape
         out = torch.empty((B, self.hidden), dtype=torch.float32, device=self.device)
         hidden = torch.empty((B, S, self.hidden), dtype=torch.float32, device=self.device) if want_hidden else None

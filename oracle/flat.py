@@ -70,6 +70,11 @@ def _i64(a):
     return a, a.ctypes.data_as(ctypes.POINTER(ctypes.c_int64))
 
 
+# families of the synthetic stream (the seed's top byte; flat_oracle.c synth_value): OR one into a seed
+SYNTH_POSITIVE = 1 << 56    # uniform [0, 1) rows — the reference's own test vectors (numpy.random.rand), a narrow cone once normalised
+SYNTH_CLUSTERED = 2 << 56   # 4,096 shared centres + 6 % noise, exact and near duplicates: the certified passes' unfriendly case
+
+
 def synth(n, d, seed, first_row=0):
     """Rows [first_row, first_row+n) of synthetic stream `seed` (un-normalised), float32 [n,d]."""
     out = np.empty((n, d), dtype=np.float32)
@@ -164,6 +169,18 @@ def first_touch_copy(x, nthreads):
     lib().oracle_first_touch_copy(out.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
                                   x.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), x.shape[0], x.shape[1], int(nthreads))
     return out
+
+
+def first_touch_copy_block(dst, src, nthreads, row0):
+    """src [m,d] -> rows [row0, row0+m) of dst [n,d] (np.empty: untouched pages), each row first touched by the thread that
+    scans it in flat_search(dst, ..., nthreads=nthreads): a corpus streamed in blocks lands NUMA-placed."""
+    assert dst.dtype == np.float32 and dst.flags["C_CONTIGUOUS"] and src.dtype == np.float32 and src.flags["C_CONTIGUOUS"]
+    assert src.shape[1] == dst.shape[1] and row0 + src.shape[0] <= dst.shape[0]
+    fp = ctypes.POINTER(ctypes.c_float)
+    f = lib().oracle_first_touch_copy_block
+    f.argtypes = [fp, fp, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int64]
+    f.restype = None
+    f(dst.ctypes.data_as(fp), src.ctypes.data_as(fp), dst.shape[0], dst.shape[1], int(nthreads), int(row0), src.shape[0])
 
 
 def max_threads():

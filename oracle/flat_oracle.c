@@ -48,12 +48,35 @@ static inline float synth_element(uint32_t seed_lo, uint32_t seed_hi, uint64_t c
     const int32_t sum = (int32_t)((h0 & 0xFFFFu) + (h0 >> 16) + (h1 & 0xFFFFu) + (h1 >> 16));
     return (float)(sum - 131070) * (1.0f / 131072.0f);
 }
-void oracle_synth_fill(float* out, int64_t n, int d, uint64_t seed, int64_t first_row) {
+/* The three families of rows (seed >> 56): 0 zero-mean bell (every BASELINE config), 1 all-positive uniform [0, 1) (what the
+ * reference's own tests store: numpy.random.rand, tests/test_sharded_multithreaded_operations.py:22), 2 clustered (4,096
+ * centres shared by every seed + 2^-4 noise; 1 row in 256 noise-free = exact duplicates, 1 in 256 at 2^-13 = near
+ * duplicates).  Bit for bit minivectordb_amd/csrc/util_kernels.hpp synth_value: integer hashes, exact conversions,
+ * power-of-two scales, at most ONE rounding (the sum of family 2; volatile keeps the compiler from fusing it differently). */
+static inline float synth_value(uint64_t seed, uint64_t row, uint32_t col, uint32_t d) {
     const uint32_t slo = (uint32_t)seed, shi = (uint32_t)(seed >> 32);
+    const uint32_t family = (uint32_t)(seed >> 56);
+    const uint64_t ctr = row * (uint64_t)d + col;
+    if (family == 0) return synth_element(slo, shi, ctr);
+    if (family == 1) {
+        const uint32_t lo = (uint32_t)ctr, hi = (uint32_t)(ctr >> 32);
+        const uint32_t h = pcg_hash32(lo ^ pcg_hash32(hi ^ pcg_hash32(slo ^ pcg_hash32(shi))));
+        return (float)(h >> 8) * (1.0f / 16777216.0f);
+    }
+    const uint32_t rlo = (uint32_t)row, rhi = (uint32_t)(row >> 32);
+    const uint32_t hr = pcg_hash32(rlo ^ pcg_hash32(rhi ^ pcg_hash32(slo ^ pcg_hash32(shi ^ 0x5BD1E995u))));
+    const uint32_t centre = hr & 4095u, kind = (hr >> 12) & 255u;
+    const float c = synth_element(0xC3A5C85Cu, 2u, (uint64_t)centre * d + col);
+    if (kind == 0) return c;
+    const float e = synth_element(slo, shi, ctr);
+    const float scaled = e * (kind == 1 ? 1.0f / 8192.0f : 1.0f / 16.0f);  /* exact */
+    return c + scaled;
+}
+void oracle_synth_fill(float* out, int64_t n, int d, uint64_t seed, int64_t first_row) {
 #pragma omp parallel for schedule(static)
     for (int64_t i = 0; i < n; ++i)
         for (int j = 0; j < d; ++j)
-            out[i * d + j] = synth_element(slo, shi, (uint64_t)(first_row + i) * (uint64_t)d + j);
+            out[i * d + j] = synth_value(seed, (uint64_t)(first_row + i), (uint32_t)j, (uint32_t)d);
 }
 
 /* ---- fp32 kernels with a fixed summation order ---------------------------------------------- */
@@ -351,6 +374,20 @@ int oracle_max_threads(void) {
  * touches) exactly the row range [n t / nthreads, n (t + 1) / nthreads) that it will scan in oracle_flat_search with
  * the same thread count, so each thread's rows sit in memory local to it (one thread touching the whole matrix puts
  * it behind a single memory controller). */
+/* The same placement, one block at a time: src[0, m) becomes rows [row0, row0 + m) of dst[n_total, d], each row written (first
+ * touched) by the thread that scans it when dst is searched with `nthreads` threads — a corpus streamed from the GPU in
+ * blocks lands NUMA-placed without ever existing twice on the host. */
+void oracle_first_touch_copy_block(float* dst, const float* src, int64_t n_total, int d, int nthreads, int64_t row0, int64_t m) {
+    if (nthreads < 1) nthreads = 1;
+#pragma omp parallel for num_threads(nthreads) schedule(static, 1)
+    for (int t = 0; t < nthreads; ++t) {
+        int64_t r0 = n_total * t / nthreads, r1 = n_total * (t + 1) / nthreads;
+        if (r0 < row0) r0 = row0;
+        if (r1 > row0 + m) r1 = row0 + m;
+        if (r1 > r0) memcpy(dst + r0 * d, src + (r0 - row0) * d, (size_t)(r1 - r0) * d * sizeof(float));
+    }
+}
+
 void oracle_first_touch_copy(float* dst, const float* src, int64_t n, int d, int nthreads) {
     if (nthreads < 1) nthreads = 1;
 #pragma omp parallel for num_threads(nthreads) schedule(static, 1)

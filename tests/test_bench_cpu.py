@@ -76,3 +76,35 @@ def test_bench_refuses_to_run_without_a_hip_device():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0"], cwd=ROOT,
                        capture_output=True, text=True, timeout=300)
     assert p.returncode != 0 and "no CPU fallback" in (p.stderr + p.stdout)
+
+
+def test_cpu_baseline_times_the_whole_corpus_unscaled():
+    """cpu_baseline streams EVERY row of the resident corpus to the host (round-4 review: the first 1M of 10M rows were timed
+    and the rate scaled x0.1) and times the oracle over all of it; the streamed, NUMA-placed copy holds the rows bit for bit."""
+    import numpy as np
+    import bench
+    from oracle import flat
+
+    n, d, k = 30_000, 64, 5
+    x = flat.synth(n, d, 1234)
+    flat.normalize_l2(x)
+    q = flat.synth(4, d, 5678)
+    flat.normalize_l2(q)
+
+    class Idx:
+        fetched = 0
+
+        def get_rows(self, row0, m, out=None):
+            self.fetched += m
+            out[...] = x[row0:row0 + m]
+            return out
+
+    idx = Idx()
+    got = bench.cpu_baseline(None, idx, d, k, q, n, budget_s=0.6)
+    assert idx.fetched == n
+    assert got["kind"] == "port" and got["cores"] == 1 and got["value"] > 0 and got["multithread_value"] > 0
+    assert f"{n} of {n} rows" in got["sample"] and "nothing scaled" in got["sample"]
+    dst = np.empty((n, d), dtype=np.float32)
+    for b in range(0, n, 7000):
+        flat.first_touch_copy_block(dst, np.ascontiguousarray(x[b:b + 7000]), 3, b)
+    assert dst.tobytes() == x.tobytes()

@@ -240,11 +240,28 @@ def test_split_mode_recomputes_exactly_when_an_activation_leaves_fp16_range(gpu)
     assert not enc.walks(9, 9)
     import torch
     dev = torch.device("cuda", 0)
-    raw, _ = enc.forward_device(torch.from_numpy(ids).to(dev), torch.from_numpy(mask).to(dev), compute=2)
-    assert not torch.isfinite(raw).all()                    # the device path reports what the kernels produced
+    ids_d, mask_d = torch.from_numpy(ids).to(dev), torch.from_numpy(mask).to(dev)
+    raw, _ = enc.forward_device(ids_d, mask_d, compute=2)
+    assert not torch.isfinite(raw).all()                    # the device path reports what the kernels produced ...
+    torch.cuda.synchronize()
+    assert int(enc.overflow_flag().item()) == 1              # ... and raises the device-side flag (no embedding is read back for it)
     e2 = enc.forward(ids, mask, compute=2)
     e0 = enc.forward(ids, mask, compute=0)
     assert np.isfinite(e0).all() and np.array_equal(e2, e0)
+    torch.cuda.synchronize()
+    assert int(enc.overflow_flag().item()) == 0              # cleared by the next forward (the exact one)
+    fixed, _ = enc.forward_device(ids_d, mask_d, compute=2, rerun_on_overflow=True)
+    torch.cuda.synchronize()
+    assert np.array_equal(fixed.cpu().numpy(), e0)
+    # a sentence of padding only pools 0 / 0 = NaN (the reference's average_pool): not an overflow
+    mask2 = mask.copy()
+    mask2[1] = 0
+    w_ok = E.make_weights(cfg, 3)
+    enc2 = _model(cfg, w_ok)
+    out2, _ = enc2.forward_device(torch.from_numpy(ids).to(dev), torch.from_numpy(mask2).to(dev), compute=2)
+    torch.cuda.synchronize()
+    assert torch.isnan(out2[1]).all() and int(enc2.overflow_flag().item()) == 0
+    enc2.close()
     enc.close()
 
 

@@ -44,7 +44,9 @@ def _check(native, x, q, k, D, I, metric=flat.METRIC_IP, rows=None, exact_vs_ora
 
 
 def test_synth_generator_bit_exact(native):
-    for n, d, seed, first in [(1000, 512, 1234, 0), (257, 100, 99, 12345), (64, 3, 7, 1 << 33)]:
+    for n, d, seed, first in [(1000, 512, 1234, 0), (257, 100, 99, 12345), (64, 3, 7, 1 << 33),
+                              (1000, 512, 1234 | flat.SYNTH_POSITIVE, 0), (300, 384, 5678 | flat.SYNTH_POSITIVE, (1 << 33) + 3),
+                              (4000, 512, 1234 | flat.SYNTH_CLUSTERED, 0), (513, 100, 77 | flat.SYNTH_CLUSTERED, (1 << 34) + 11)]:
         idx = native.FlatIndex(d)
         idx.add_synthetic(n, seed, first_row=first, normalize=False)
         got = idx.get_rows(0, n)
@@ -1165,6 +1167,42 @@ def test_add_does_not_synchronise_the_device(native):
     assert (Id.cpu().numpy() < 20000).all()
     D2, I2 = idx.search(qt.cpu().numpy(), 1)
     assert I2[:, 0].tolist() == [20000, 20001, 20002, 20003]
+    idx.close()
+
+
+def test_single_query_shadow_route_suspends_itself_on_a_clustered_corpus(native):
+    """The opt-in single-query route costs more than the exact scan when its certificate is refused.  On a clustered corpus (1M
+    rows: every query's 10th and 64th best within 1e-3) every call is refused; the library notices within a window of 32 calls
+    (a device counter mirrored into host-mapped memory, no synchronisation) and sends the next 512 single queries to the exact
+    scan.  Results are the exact scan's in every phase."""
+    n, d, k = 1_000_000, 256, 10
+    idx = native.FlatIndex(d)
+    idx.reserve(n)
+    idx.add_synthetic(n, 1234 | flat.SYNTH_CLUSTERED, normalize=True)
+    q = flat.synth(200, d, 5678 | flat.SYNTH_CLUSTERED)
+    flat.normalize_l2(q)
+    exact = [idx.search(q[i], k) for i in range(200)]
+    lib = native.lib()
+    assert lib.mvdb_index_single_route_suspensions(idx.handle) == 0
+    idx.set_option("shadow_single_query", 1)
+    before = native.split_rerun_count()
+    for i in range(200):
+        D, I = idx.search(q[i], k)
+        assert np.array_equal(I, exact[i][1]) and np.array_equal(D, exact[i][0]), i
+    reruns = native.split_rerun_count() - before
+    assert lib.mvdb_index_single_route_suspensions(idx.handle) == 1
+    assert 16 <= reruns <= 96, reruns          # the first window (plus what was in flight) paid the nomination pass, the rest did not
+    idx.close()
+    # a friendly corpus never suspends
+    idx = native.FlatIndex(d)
+    idx.reserve(n)
+    idx.add_synthetic(n, 1234, normalize=True)
+    q = flat.synth(100, d, 5678)
+    flat.normalize_l2(q)
+    idx.set_option("shadow_single_query", 1)
+    for i in range(100):
+        idx.search(q[i], k)
+    assert lib.mvdb_index_single_route_suspensions(idx.handle) == 0
     idx.close()
 
 

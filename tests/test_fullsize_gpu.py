@@ -182,3 +182,39 @@ def test_config2_1M_x_512_l2_mixed_norms_vs_oracle(native):
                                          metric=flat.METRIC_L2))
     bigcheck.report({"what": "config2 L2 mixed norms: certified-pass re-runs", "chunks_rerun": native.split_rerun_count() - reruns})
     idx.close()
+
+
+@pytest.mark.parametrize("family,name", [(flat.SYNTH_POSITIVE, "all-positive"), (flat.SYNTH_CLUSTERED, "clustered")])
+@pytest.mark.parametrize("n", [1_000_000, 10_000_000])
+def test_certified_passes_on_unfriendly_corpora_vs_oracle(native, n, family, name):
+    """Every full-size record above is on the zero-mean stream, where the 10th and 64th scores of a query are 6e-3 apart and the
+    certified passes (fp16 nomination + exact fp32 re-score + margin test, eps(512) = 1.04e-3) always certify.  Here: the
+    reference's own kind of test vector (numpy.random.rand rows, tests/test_sharded_multithreaded_operations.py:22 — SURVEY.md
+    section 8(d)), and a clustered corpus with thousands of rows within 1e-3 of a query's best, exact duplicates included.  256
+    queries of the same family, 1 / 32 / 128 / 256 per call and the opt-in single-query shadow route, id for id against the
+    streamed oracle; what failed certification is re-run exactly, and how often that happens is reported."""
+    d, k, nq = 512, 10, 256
+    idx = native.FlatIndex(d)
+    idx.reserve(n)
+    idx.add_synthetic(n, 1234 | family, normalize=True)
+    q = flat.synth(nq, d, 5678 | family)
+    flat.normalize_l2(q)
+    (oracle,), cost = bigcheck.oracle_topk_streamed(idx, n, q, k)
+    Do, Io = oracle
+    gap = float(np.median(Do[:, 0] - Do[:, k - 1]))
+    nsingle = 64 if n > 1_000_000 else 256
+    D, I = _in_chunks(lambda qs: idx.search(qs, k), q[:nsingle], 1)
+    bigcheck.report(dict(bigcheck.compare(idx, q[:nsingle], D, I, Do[:nsingle], Io[:nsingle], f"{name} {n} x 512, 1 query per call"),
+                         oracle_cost=cost, median_gap_best_to_kth=gap))
+    for per_call in (32, 128, 256):
+        before = native.split_rerun_count()
+        D, I = _in_chunks(lambda qs: idx.search(qs, k), q, per_call)
+        rec = bigcheck.compare(idx, q, D, I, Do, Io, f"{name} {n} x 512, {per_call} queries per call")
+        bigcheck.report(dict(rec, chunks_rerun=native.split_rerun_count() - before, calls=(nq + per_call - 1) // per_call))
+    idx.set_option("shadow_single_query", 1)
+    before = native.split_rerun_count()
+    D, I = _in_chunks(lambda qs: idx.search(qs, k), q[:nsingle], 1)
+    idx.set_option("shadow_single_query", 0)
+    rec = bigcheck.compare(idx, q[:nsingle], D, I, Do[:nsingle], Io[:nsingle], f"{name} {n} x 512, 1 query per call over the fp16 shadow (opt-in)")
+    bigcheck.report(dict(rec, chunks_rerun=native.split_rerun_count() - before, calls=nsingle))
+    idx.close()

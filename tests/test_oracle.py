@@ -96,6 +96,32 @@ def test_synth_known_answers():
     assert abs(float(big.mean())) < 2e-3 and abs(float(big.std()) - 0.2887) < 5e-3  # Irwin-Hall(4)/2 spread
 
 
+def test_synth_families_known_answers_and_shape():
+    """The two unfriendly families of the synthetic stream ("a numpy.random.rand-style all-positive variant
+    (what the reference tests use, tests/test_sharded_multithreaded_operations.py:22) as a stress case for near-ties"; and a
+    clustered one with exact / near duplicates): known-answer vectors (the device generator is held against the host's on the
+    GPU) and the properties the certified passes are measured against."""
+    v = flat.synth(2, 4, 1234 | flat.SYNTH_POSITIVE, 7)
+    want = np.array([[0.431235134601593, 0.19885194301605225, 0.1625680923461914, 0.5594544410705566],
+                     [0.5369088053703308, 0.8322985768318176, 0.5937770009040833, 0.6396514773368835]], np.float32)
+    assert v.tobytes() == want.tobytes(), v.tolist()
+    w = flat.synth(1, 3, 5678 | flat.SYNTH_CLUSTERED, (1 << 33) + 5)
+    want2 = np.array([[-0.3460564613342285, 0.20024538040161133, -0.6225290298461914]], np.float32)
+    assert w.tobytes() == want2.tobytes(), w.tolist()
+    pos = flat.synth(20000, 64, 1234 | flat.SYNTH_POSITIVE)
+    assert pos.min() >= 0.0 and pos.max() < 1.0 and abs(float(pos.mean()) - 0.5) < 5e-3
+    flat.normalize_l2(pos)
+    cos = pos[:200] @ pos[200:400].T
+    assert 0.5 < float(cos.min()) and float(cos.max()) < 0.95 and abs(float(cos.mean()) - 0.75) < 0.02   # a narrow cone around 0.75
+    clu = flat.synth(100000, 32, 1234 | flat.SYNTH_CLUSTERED)
+    assert 5 <= 100000 - np.unique(clu, axis=0).shape[0] <= 400        # exact duplicates exist (noise-free rows sharing a centre)
+    flat.normalize_l2(clu)
+    q = flat.synth(8, 32, 5678 | flat.SYNTH_CLUSTERED)                 # another seed: the SAME centres
+    flat.normalize_l2(q)
+    s = np.sort(clu @ q.T, axis=0)[::-1]
+    assert (s[0] > 0.99).all() and (s[0] - s[9] < 3e-3).all()          # ten rows within 3e-3 of the best: near-ties by design
+
+
 def test_block_search_and_merge_equal_the_sequential_scan():
     """oracle_flat_search_block + oracle_merge_topk (what tests/bigcheck.py streams a 10M-row device corpus through) must
     return bit for bit what the per-query sequential scan returns: IP and L2, ragged block sizes, duplicate rows (ties
