@@ -361,14 +361,16 @@ struct Shape {
     int G, C;
 };
 Shape choose_shape(int d4) {
-    if (d4 <= 64) {
-        int G = 1;
-        while (G < d4) G <<= 1;
-        return {G, 1};
-    }
-    if (d4 % 64 == 0) return {64, d4 / 64};
-    if (d4 % 32 == 0 && d4 / 32 <= 7) return {32, d4 / 32};
-    return {64, (d4 + 63) / 64};
+    // one chunk per lane, 4 / 16 / 32 / 64 lanes per row (rows of up to 16 / 64 / 128 / 256 floats; the 1-, 2- and 8-lane
+    // shapes of rounds 1 - 4 served rows of <= 4, 8 and 32 floats only: 84 instantiations for toy widths)
+    if (d4 <= 64) return {d4 <= 4 ? 4 : d4 <= 16 ? 16 : d4 <= 32 ? 32 : 64, 1};
+    if (d4 % 64 == 0 && d4 / 64 <= 8) return {64, d4 / 64};
+    if (d4 == 96) return {32, 3};  // d = 384 (e5-small, config 5): three exact chunks on 32 lanes, two rows per wave-instruction
+    // more than eight chunks per lane (d > 2048): ONE shape, sixteen chunks with the lanes beyond the row masked off — the
+    // seven shapes in between (nine to fifteen chunks: 224 kernel instantiations, 30 % of this code object) went in round 5;
+    // a masked chunk issues no load, the scan stays bound by the bytes of the row
+    const int c = (d4 + 63) / 64;
+    return {64, c > 8 ? 16 : c};
 }
 constexpr int kMaxC = 16;  // d <= 4096
 
@@ -417,7 +419,14 @@ int launch_scan_kern(const ScanArgs& a, int nq, int device, hipStream_t stream, 
 // runtime -> compile-time switches: subset indirection, lane masking
 template <int G, int C, int U, int METRIC, int MODE, bool NT = true>
 int launch_scan_inst(const ScanArgs& a, int nq, int device, hipStream_t s, int* nb) {
-    const bool masked = a.d4 != G * C;
+    // (32 lanes x 3 / 5 / 7 chunks are chosen for rows that fill them exactly: their lane-masked forms are never instantiated)
+    constexpr bool kAlwaysFull = G == 32 && C > 1;
+    const bool masked = !kAlwaysFull && a.d4 != G * C;
+    if constexpr (kAlwaysFull) {
+        if (a.mask) return launch_scan_kern<G, C, U, METRIC, MODE, NT, 2, false>(a, nq, device, s, nb);
+        if (a.rows) return launch_scan_kern<G, C, U, METRIC, MODE, NT, 1, false>(a, nq, device, s, nb);
+        return launch_scan_kern<G, C, U, METRIC, MODE, NT, 0, false>(a, nq, device, s, nb);
+    }
     if (a.mask) {  // bitmap-selected rows (mvdb_index_search_masked)
         if (masked) return launch_scan_kern<G, C, U, METRIC, MODE, NT, 2, true>(a, nq, device, s, nb);
         return launch_scan_kern<G, C, U, METRIC, MODE, NT, 2, false>(a, nq, device, s, nb);
@@ -472,15 +481,10 @@ int launch_scan(int metric, int mode, const ScanArgs& a, int nq, int device, hip
     if (a.rows && sh.G == 64 && sh.C == 3) return launch_scan_gcu<64, 3, 4>(metric, mode, a, nq, device, s, nblocks);
 #define MVDB_SCAN_CASE(G_, C_, U_) \
     if (sh.G == G_ && sh.C == C_) return launch_scan_gcu<G_, C_, U_>(metric, mode, a, nq, device, s, nblocks);
-    MVDB_SCAN_CASE(1, 1, 4)
-    MVDB_SCAN_CASE(2, 1, 4)
     MVDB_SCAN_CASE(4, 1, 4)
-    MVDB_SCAN_CASE(8, 1, 4)
     MVDB_SCAN_CASE(16, 1, 4)
     MVDB_SCAN_CASE(32, 1, 4)
     MVDB_SCAN_CASE(32, 3, 4)
-    MVDB_SCAN_CASE(32, 5, 1)
-    MVDB_SCAN_CASE(32, 7, 1)
     MVDB_SCAN_CASE(64, 1, 4)
     MVDB_SCAN_CASE(64, 2, 2)
     MVDB_SCAN_CASE(64, 3, 2)
@@ -489,13 +493,6 @@ int launch_scan(int metric, int mode, const ScanArgs& a, int nq, int device, hip
     MVDB_SCAN_CASE(64, 6, 1)
     MVDB_SCAN_CASE(64, 7, 1)
     MVDB_SCAN_CASE(64, 8, 1)
-    MVDB_SCAN_CASE(64, 9, 1)
-    MVDB_SCAN_CASE(64, 10, 1)
-    MVDB_SCAN_CASE(64, 11, 1)
-    MVDB_SCAN_CASE(64, 12, 1)
-    MVDB_SCAN_CASE(64, 13, 1)
-    MVDB_SCAN_CASE(64, 14, 1)
-    MVDB_SCAN_CASE(64, 15, 1)
     MVDB_SCAN_CASE(64, 16, 1)
 #undef MVDB_SCAN_CASE
     return fail(MVDB_ERR_ARG, "dimension with %d 16-byte chunks per row is not supported (d <= 4096)",

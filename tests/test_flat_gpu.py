@@ -1181,14 +1181,17 @@ def test_single_query_shadow_route_suspends_itself_on_a_clustered_corpus(native)
     idx.add_synthetic(n, 1234 | flat.SYNTH_CLUSTERED, normalize=True)
     q = flat.synth(200, d, 5678 | flat.SYNTH_CLUSTERED)
     flat.normalize_l2(q)
-    exact = [idx.search(q[i], k) for i in range(200)]
+    stored = idx.get_rows(0, n)
     lib = native.lib()
     assert lib.mvdb_index_single_route_suspensions(idx.handle) == 0
     idx.set_option("shadow_single_query", 1)
     before = native.split_rerun_count()
     for i in range(200):
         D, I = idx.search(q[i], k)
-        assert np.array_equal(I, exact[i][1]) and np.array_equal(D, exact[i][0]), i
+        # (the exact kernels behind the two routes sum in different orders: rows within 2e-6 of each other may swap, which the
+        #  float64 adjudication accepts — and nothing else)
+        ok, msg = flat.adjudicate(stored, q[i], k, D[0], I[0], tol=1e-4, tie_eps=2e-6)
+        assert ok, (i, msg)
     reruns = native.split_rerun_count() - before
     assert lib.mvdb_index_single_route_suspensions(idx.handle) == 1
     assert 16 <= reruns <= 96, reruns          # the first window (plus what was in flight) paid the nomination pass, the rest did not
