@@ -41,7 +41,8 @@ t = buf[:n].astype(np.int64)
 L = cfg["num_hidden_layers"]
 t0 = t[:, NS - 2].min()
 us = np.where(t > 0, (t - t0) / 100.0, np.nan)
-names = ["qkv", "attn+wo", "sum+ln1", "ffn", "sum+ln2"]
+names = ["qkv", "attn+wo", "sum+ln1", "ffn", "sum+ln2", "ffn1"]   # (ffn1: wide shapes only — there "ffn" is FFN2)
+ORDER = [0, 1, 2, 5, 3, 4]
 out = {"S": S, "large": large, "workgroups": int(n), "total_us": round(float(np.nanmax(us[:, NS - 1])), 2), "phases": {}}
 prev_done = np.zeros(L * 5 + 1)
 for k, nm in enumerate(names):
@@ -61,7 +62,7 @@ for k, nm in enumerate(names):
 # hand-off latency: last producer of a phase arrived -> first consumer of the next phase released
 order = []
 for layer in range(L):
-    for k in range(5):
+    for k in ORDER:
         base = (layer * 6 + k) * 3
         if not np.all(np.isnan(us[:, base + 2])):
             order.append((layer, k))
@@ -75,20 +76,6 @@ out["handoff_us"] = {k: {"first_release": round(float(np.median([g[0] for g in v
                          "last_release": round(float(np.median([g[1] for g in v])), 2)} for k, v in gaps.items()}
 clk = (t[:, NS - 3] - t[:, NS - 4]) / np.maximum(1, (t[:, NS - 1] - t[:, NS - 2])) * 100.0
 out["shader_clock_mhz"] = round(float(np.median(clk)), 0)
-inner = {}
-for layer in range(L):
-    b1 = (layer * 6 + 1) * 3
-    b2 = (layer * 6 + 2) * 3
-    b5 = (layer * 6 + 5) * 3
-    b0 = (layer * 6 + 0) * 3
-    inner.setdefault("ln1_planes_landed_after_release", []).append(np.nanmedian(us[:, b5] - us[:, b2 + 1]))
-    inner.setdefault("ln1_rest", []).append(np.nanmedian(us[:, b2 + 2] - us[:, b5]))
-    if np.all(np.isnan(us[:, b0])):   # fused form: the QKV phase never waits
-        inner.setdefault("fused_qkv_published_after_release", []).append(np.nanmedian(us[:, b5 + 1] - us[:, b1 + 1]))
-        inner.setdefault("fused_tiles_ready", []).append(np.nanmedian(us[:, b5 + 2] - us[:, b5 + 1]))
-        inner.setdefault("fused_attention", []).append(np.nanmedian(us[:, b0 + 2] - us[:, b5 + 2]))
-        inner.setdefault("fused_outproj", []).append(np.nanmedian(us[:, b1 + 2] - us[:, b0 + 2]))
-out["inner_us"] = {k: round(float(np.nanmedian(v)), 2) for k, v in inner.items()}
 per_layer = [np.nanmax(us[:, (l * 6 + 4) * 3 + 2]) for l in range(L)]
 out["layer_us"] = round(float(np.median(np.diff(per_layer))), 2) if L > 1 else None
 print(json.dumps(out))

@@ -2270,7 +2270,7 @@ struct mvdb_encoder {
     // small batches (<= walk::kTmax token slots): the layer-walking persistent launch (encoder_walk.hpp)
     int opt_walk = 1;                       // MVDB_ENCODER_WALK as read when the encoder was created (0: the per-op kernels)
     walk::LayerPtrs* walk_layers = nullptr; // device copy of the per-layer weight pointers
-    float *walk_x = nullptr, *walk_x1 = nullptr, *walk_qkv = nullptr, *walk_pl = nullptr;
+    float *walk_x = nullptr, *walk_x1 = nullptr, *walk_qkv = nullptr, *walk_pl = nullptr, *walk_h = nullptr;
     unsigned int* walk_bar = nullptr;
     unsigned long long* walk_trace = nullptr;  // ablation build only
     unsigned int* overflow_flag = nullptr;     // device word: 1 after a forward whose pooled rows were not all finite
@@ -2711,7 +2711,8 @@ int ensure_walk(mvdb_encoder* e) {
     std::vector<walk::LayerPtrs> lp;
     for (const LayerW& L : e->layers)
         lp.push_back(walk::LayerPtrs{L.wqkv, L.bqkv, L.wo, L.bo, L.ln1g, L.ln1b, L.w1, L.b1, L.w2, L.b2, L.ln2g, L.ln2b});
-    const int64_t planes = std::max<int64_t>(c.heads, e->walk_np3);
+    const int64_t planes = std::max<int64_t>({(int64_t)c.heads, (int64_t)e->walk_np3, 4, (F / 16 + 63) / 64});
+    MVDB_TRY(dev_alloc(&e->walk_h, walk::kTmax * F));
     MVDB_TRY(dev_alloc(&e->walk_x, walk::kTmax * H));
     MVDB_TRY(dev_alloc(&e->walk_x1, walk::kTmax * H));
     MVDB_TRY(dev_alloc(&e->walk_qkv, walk::kTmax * 3 * H));
@@ -2761,6 +2762,7 @@ int launch_walk(mvdb_encoder* e, const int32_t* ids, const int32_t* mask, int B,
     a.X1 = e->walk_x1;
     a.QKV = e->walk_qkv;
     a.PL = e->walk_pl;
+    a.Hb = e->walk_h;
     a.bar = e->walk_bar;
     a.out = out;
     a.hidden = hidden;
@@ -2772,6 +2774,7 @@ int launch_walk(mvdb_encoder* e, const int32_t* ids, const int32_t* mask, int B,
     const int hc = c.hidden <= 128 ? 1 : c.hidden <= 384 ? 3 : 8;
     const int cus = device_cus(e->device);
     int grid = std::min(cus, std::max<int>({16, 3 * c.hidden / 16 * rh, e->walk_np3 * rh}));  // one workgroup per CU: all resident
+    if (hc == 8) grid = cus;  // wide shapes: FFN1 has F / 16 column units, FFN2 (H / 16) x 4 (encoder_walk.hpp): every CU
     if (e->walk_grid_env > 0) grid = std::min(cus, std::max(e->walk_grid_env, e->walk_np3));
     e->walk_grid = grid;
     a.nsplit = std::max(1, std::min(grid / std::max(1, B * c.heads), std::max(1, ntiles / walk::kWaves)));
@@ -3208,7 +3211,7 @@ int mvdb_encoder_free(mvdb_encoder* e) {
         if (e->ids_stage) (void)hipFree(e->ids_stage);
         if (e->mask_stage) (void)hipFree(e->mask_stage);
         if (e->out_stage) (void)hipFree(e->out_stage);
-        void* walk_bufs[] = {e->walk_layers, e->walk_x, e->walk_x1, e->walk_qkv, e->walk_pl, e->walk_bar, e->walk_trace, e->overflow_flag};
+        void* walk_bufs[] = {e->walk_layers, e->walk_x, e->walk_x1, e->walk_qkv, e->walk_pl, e->walk_h, e->walk_bar, e->walk_trace, e->overflow_flag};
         for (void* p : walk_bufs)
             if (p) (void)hipFree(p);
         if (e->stream) (void)hipStreamDestroy(e->stream);

@@ -59,6 +59,7 @@ struct Args {
     float *X, *X1;            // [kTmax, H]   layer input / post-attention state
     float* QKV;               // [kTmax, 3H]
     float* PL;                // [planes, kTmax, H] partial planes
+    float* Hb;                // [kTmax, F] GELU(x1 W1^T + b1) (wide shapes only: FFN as two phases)
     unsigned int* bar;        // [kCtrCount][8 replicas][32 words] arrival counters of the phases (monotonic within a launch) + exits
     float* out;               // [B, H]
     float* hidden;            // NULL or [B, S, H]
@@ -89,7 +90,7 @@ __device__ __forceinline__ void st4(rsrc_t r, int byte_off, f32x4 v) {
 }
 
 // ---- phase counters ------------------------------------------------------------------------------------------------------
-enum { kCtrEmbed = 0, kCtrQkv, kCtrAttn, kCtrLn1, kCtrFfn, kCtrLn2, kCtrExit, kCtrCount };
+enum { kCtrEmbed = 0, kCtrQkv, kCtrAttn, kCtrLn1, kCtrFfn1, kCtrFfn, kCtrLn2, kCtrExit, kCtrCount };
 
 // stamps of (layer, phase): wait begins, released, arrived — ablation build only (a.trace != NULL)
 __device__ __forceinline__ void stamp(unsigned long long* trace, int layer, int phase, int what) {
@@ -186,6 +187,43 @@ __device__ __forceinline__ void colunit_mfma(const f32x4 (&a)[HC], const f32x4 (
         for (int m = 0; m < 4; ++m)
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][m], b[i][mt][m], acc[mt], 0, 0, 0);
+}
+// The same product with the operand fragments fetched CB chunks at a time (HC x MT of them at once would not fit the registers
+// of the wide shapes): W rows of stride ldw floats starting at Wrow0 (which already points at the first k of the range), A
+// rows of stride lda floats from k offset koff, nch chunks of 16 in the range.
+template <int CB>
+__device__ __forceinline__ void colunit_load_w_batch(const float* __restrict__ Wrow0, int ldw, int nch, int i0, f32x4 (&wa)[CB], int lane,
+                                                     int wave) {
+    const int r = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < CB; ++i) {
+        const int c = wave + (i0 + i) * kWaves, cc = min(c, nch - 1);
+        const f32x4 v = *reinterpret_cast<const f32x4*>(Wrow0 + (int64_t)r * ldw + 16 * cc + 4 * g);
+        wa[i] = c < nch ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+}
+// w0 = the first batch's weight fragments, loaded by the caller BEFORE it waited for the activations
+template <int MT, int HC, int CB>
+__device__ __forceinline__ void colunit_accumulate(const float* __restrict__ Wrow0, int ldw, const f32x4 (&w0)[CB], rsrc_t Ar, int lda,
+                                                   int koff, int nch, int T, int row0, f32x4 (&acc)[MT], int lane, int wave) {
+    const int r = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int i0 = 0; i0 < HC; i0 += CB) {
+        f32x4 wa[CB], xb[CB][MT];
+        if (i0 == 0) {
+#pragma unroll
+            for (int i = 0; i < CB; ++i) wa[i] = w0[i];
+        } else {
+            colunit_load_w_batch<CB>(Wrow0, ldw, nch, i0, wa, lane, wave);
+        }
+#pragma unroll
+        for (int i = 0; i < CB; ++i) {
+            const int cc = min(wave + (i0 + i) * kWaves, nch - 1);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) xb[i][mt] = ld4(Ar, (min(row0 + mt * 16 + r, T - 1) * lda + koff + 16 * cc + 4 * g) * 4);
+        }
+        colunit_mfma<MT, CB>(wa, xb, acc);
+    }
 }
 // wave partials of a column unit -> LDS; after the barrier the partials are added in wave order
 template <int MT>
@@ -321,7 +359,6 @@ __device__ __forceinline__ void reduce_ln_rows(const Args& a, rsrc_t PLr, int np
             comb[pg * HQ + q] = s;
         }
         __syncthreads();
-        stamp(trace, layer, 5, 0);  // the planes have landed
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (active) {
             v = comb[tid];
@@ -404,7 +441,17 @@ __global__ __launch_bounds__(kThreads) void encoder_walk_kernel(const Args a) {
     const int ncol = (3 * H) >> 4;                                            // column units of the QKV product
     const unsigned int prodQkv = (unsigned int)min(ncol * RH, G);
     const unsigned int prodAttn = (unsigned int)min(attn_units, G);
-    const unsigned int prodFfn = (unsigned int)min(a.np3 * RH, G);
+    // narrow shapes (H <= 384): the FFN is ONE phase — a workgroup owns 16-wide slices of F, GELU(x1 W1_slice^T) stays in LDS
+    // and is multiplied by W2[:, slice] into the workgroup's partial plane.  Wide shapes (e5-large / bge-m3: H 1024, F 4096):
+    // two phases — FFN1 as F / 16 column units into Hb, FFN2 as column units whose K = F is split kKP ways over workgroups
+    // (kKP partial planes) — the one-phase form there was 27 us per layer of serialised slices and 128 planes to sum.
+    constexpr bool kFfnSplit = HC > 4;
+    const int nf = F >> 4;
+    const int kKP = max(4, (nf + 63) >> 6);            // K parts of FFN2: at most 64 chunks (8 per wave) each
+    const int nchp = (nf + kKP - 1) / kKP;             // chunks per part
+    const unsigned int prodFfn1 = (unsigned int)min(nf * RH, G);
+    const unsigned int prodFfn = kFfnSplit ? (unsigned int)min(ntiles * kKP * RH, G) : (unsigned int)min(a.np3 * RH, G);
+    const int ffn_planes = kFfnSplit ? kKP : a.np3;
 
     if (T > 0) {
         // ---- embeddings + LayerNorm -> X (one workgroup per row) ---------------------------------------------------------------
@@ -435,7 +482,7 @@ __global__ __launch_bounds__(kThreads) void encoder_walk_kernel(const Args a) {
                 // ---- QKV: column units over 3H -> QKV[T, 3H] ----------------------------------------------------------------------
                 if (wg < (int)prodQkv) {
                     f32x4* red = reinterpret_cast<f32x4*>(work);
-                    constexpr int CB = HC > 4 ? (MT > 2 ? 2 : 4) : HC;  // chunk batches: HC x MT operand fragments must fit the registers
+                    constexpr int CB = HC > 4 ? (MT > 1 ? 4 : 8) : HC;  // chunk batches: HC x MT operand fragments must fit the registers
                     bool first = true;
                     for (int uu = wg; uu < ncol * RH; uu += G) {
                         const int hf = uu / ncol, u = uu - hf * ncol, row0 = hf * MT * 16;  // columns u, row half hf
@@ -455,26 +502,15 @@ __global__ __launch_bounds__(kThreads) void encoder_walk_kernel(const Args a) {
                             colunit_load_x<MT, HC>(Xr, H, T, xb, lane, wave, row0);
                             colunit_mfma<MT, HC>(wa, xb, acc);
                         } else {
+                            f32x4 w0[CB];
+                            colunit_load_w_batch<CB>(L.wqkv + (int64_t)u * 16 * H, H, H >> 4, 0, w0, lane, wave);
                             if (first) {
                                 stamp(trace, layer, 0, 0);
                                 phase_wait(a.bar, in_ctr, in_target);
                                 stamp(trace, layer, 0, 1);
                                 first = false;
                             }
-                            const int nch = H >> 4;
-#pragma unroll
-                            for (int i0 = 0; i0 < HC; i0 += CB) {  // chunks wave + 8 (i0 + i), CB at a time
-                                f32x4 wa[CB], xb[CB][MT];
-#pragma unroll
-                                for (int i = 0; i < CB; ++i) {
-                                    const int c = wave + (i0 + i) * kWaves, cc = min(c, nch - 1);
-                                    const f32x4 v = *reinterpret_cast<const f32x4*>(L.wqkv + (int64_t)(u * 16 + r) * H + 16 * cc + 4 * g);
-                                    wa[i] = c < nch ? v : f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                                    for (int mt = 0; mt < MT; ++mt) xb[i][mt] = ld4(Xr, (min(row0 + mt * 16 + r, T - 1) * H + 16 * cc + 4 * g) * 4);
-                                }
-                                colunit_mfma<MT, CB>(wa, xb, acc);
-                            }
+                            colunit_accumulate<MT, HC, CB>(L.wqkv + (int64_t)u * 16 * H, H, w0, Xr, H, 0, H >> 4, T, row0, acc, lane, wave);
                         }
                         colunit_publish<MT>(acc, red, lane, wave);
                         __syncthreads();
@@ -558,12 +594,80 @@ __global__ __launch_bounds__(kThreads) void encoder_walk_kernel(const Args a) {
                 phase_arrive(a.bar, kCtrLn1);
             }
 
+            if constexpr (kFfnSplit) {
+                const rsrc_t Hr = make_rsrc(a.Hb);
+                constexpr int CB = MT > 1 ? 4 : 8;
+                f32x4* red = reinterpret_cast<f32x4*>(work);
+                // ---- FFN1: column units over F -> Hb[T, F] = GELU(x1 W1^T + b1) --------------------------------------------------
+                if (wg < (int)prodFfn1) {
+                    bool first = true;
+                    for (int uu = wg; uu < nf * RH; uu += G) {
+                        const int hf = uu / nf, j = uu - hf * nf, row0 = hf * MT * 16;
+                        const f32x4 b1 = *reinterpret_cast<const f32x4*>(L.b1 + 16 * j + 4 * g);
+                        f32x4 w0[CB];
+                        colunit_load_w_batch<CB>(L.w1 + (int64_t)j * 16 * H, H, H >> 4, 0, w0, lane, wave);
+                        if (first) {
+                            stamp(trace, layer, 5, 0);
+                            phase_wait(a.bar, kCtrLn1, lay1 * prodRow);
+                            stamp(trace, layer, 5, 1);
+                            first = false;
+                        }
+                        f32x4 acc[MT];
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        colunit_accumulate<MT, HC, CB>(L.w1 + (int64_t)j * 16 * H, H, w0, X1r, H, 0, H >> 4, T, row0, acc, lane, wave);
+                        colunit_publish<MT>(acc, red, lane, wave);
+                        __syncthreads();
+                        if (wave < MT) {
+                            const int tok = row0 + wave * 16 + r;
+                            f32x4 v = colunit_total<MT>(red, wave, lane) + b1;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = 0.5f * v[e] * (1.0f + erff(v[e] * 0.70710678118654752440f));
+                            if (tok < T) st4(Hr, (tok * F + 16 * j + 4 * g) * 4, v);
+                        }
+                        __syncthreads();
+                    }
+                    stamp(trace, layer, 5, 2);
+                    phase_arrive(a.bar, kCtrFfn1);
+                }
+                // ---- FFN2: column units over H, K = F split kKP ways -> plane[kp][T, H] --------------------------------------------
+                if (wg < (int)prodFfn) {
+                    bool first = true;
+                    for (int uu = wg; uu < ntiles * kKP * RH; uu += G) {
+                        const int hf = uu / (ntiles * kKP), rem = uu - hf * ntiles * kKP;
+                        const int kp = rem / ntiles, nt = rem - kp * ntiles, row0 = hf * MT * 16;
+                        const int k0 = kp * nchp * 16, nch = max(1, min(nchp, nf - kp * nchp));
+                        const bool live = nf - kp * nchp > 0;  // (a part beyond F when F / 16 is not a multiple of the parts: adds nothing)
+                        f32x4 w0[CB];
+                        colunit_load_w_batch<CB>(L.w2 + (int64_t)nt * 16 * F + (live ? k0 : 0), F, nch, 0, w0, lane, wave);
+                        if (first) {
+                            stamp(trace, layer, 3, 0);
+                            phase_wait(a.bar, kCtrFfn1, lay1 * prodFfn1);
+                            stamp(trace, layer, 3, 1);
+                            first = false;
+                        }
+                        f32x4 acc[MT];
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        if (live) colunit_accumulate<MT, HC, CB>(L.w2 + (int64_t)nt * 16 * F + k0, F, w0, Hr, F, k0, nch, T, row0, acc, lane, wave);
+                        colunit_publish<MT>(acc, red, lane, wave);
+                        __syncthreads();
+                        if (wave < MT) {
+                            const int tok = row0 + wave * 16 + r;
+                            const f32x4 v = colunit_total<MT>(red, wave, lane);
+                            if (tok < T) st4(PLr, ((kp * kTmax + tok) * H + 16 * nt + 4 * g) * 4, v);
+                        }
+                        __syncthreads();
+                    }
+                    stamp(trace, layer, 3, 2);
+                    phase_arrive(a.bar, kCtrFfn);
+                }
+            } else
             // ---- FFN: workgroup wg < np3 owns the 16-wide slices wg, wg + np3, ... of F -> plane[wg] ---------------------------------
             if (wg < (int)prodFfn) {
                 const int hf = wg / a.np3, pl = wg - hf * a.np3, row0 = hf * MT * 16;  // plane (= first slice) pl, row half hf
                 f32x4* red = reinterpret_cast<f32x4*>(work);
                 float* hbuf = work + kWaves * MT * 64 * 4;  // [64][20]: GELU(x1 W1_slice^T + b1)
-                constexpr bool kWhole = HC <= 4;            // the slice's W1 and W2 fragments (and x1's) fit the registers at once
                 f32x4 acc2[HC][MT];
 #pragma unroll
                 for (int i = 0; i < HC; ++i)
@@ -575,8 +679,8 @@ __global__ __launch_bounds__(kThreads) void encoder_walk_kernel(const Args a) {
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
                     const f32x4 b1 = *reinterpret_cast<const f32x4*>(L.b1 + 16 * j + 4 * g);
-                    f32x4 w2f[kWhole ? HC : 1];
-                    if constexpr (kWhole) {
+                    f32x4 w2f[HC];
+                    {
                         f32x4 wa[HC], xb[HC][MT];
                         colunit_load_w<HC>(L.w1 + (int64_t)j * 16 * H, H, wa, lane, wave);
 #pragma unroll
@@ -592,28 +696,6 @@ __global__ __launch_bounds__(kThreads) void encoder_walk_kernel(const Args a) {
                         }
                         colunit_load_x<MT, HC>(X1r, H, T, xb, lane, wave, row0);
                         colunit_mfma<MT, HC>(wa, xb, acc);
-                    } else {
-                        if (first) {
-                            stamp(trace, layer, 3, 0);
-                            phase_wait(a.bar, kCtrLn1, lay1 * prodRow);
-                            stamp(trace, layer, 3, 1);
-                            first = false;
-                        }
-                        constexpr int CB = MT > 2 ? 2 : 4;
-                        const int nch = H >> 4;
-#pragma unroll
-                        for (int i0 = 0; i0 < HC; i0 += CB) {
-                            f32x4 wa[CB], xb[CB][MT];
-#pragma unroll
-                            for (int i = 0; i < CB; ++i) {
-                                const int c = wave + (i0 + i) * kWaves, cc = min(c, nch - 1);
-                                const f32x4 v = *reinterpret_cast<const f32x4*>(L.w1 + (int64_t)(j * 16 + r) * H + 16 * cc + 4 * g);
-                                wa[i] = c < nch ? v : f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                                for (int mt = 0; mt < MT; ++mt) xb[i][mt] = ld4(X1r, (min(row0 + mt * 16 + r, T - 1) * H + 16 * cc + 4 * g) * 4);
-                            }
-                            colunit_mfma<MT, CB>(wa, xb, acc);
-                        }
                     }
                     colunit_publish<MT>(acc, red, lane, wave);
                     __syncthreads();
@@ -626,9 +708,7 @@ __global__ __launch_bounds__(kThreads) void encoder_walk_kernel(const Args a) {
                     __syncthreads();
 #pragma unroll
                     for (int i = 0; i < HC; ++i) {
-                        const int nt = min(wave + i * kWaves, ntiles - 1);
-                        const f32x4 wa = kWhole ? w2f[kWhole ? i : 0]
-                                                : *reinterpret_cast<const f32x4*>(L.w2 + (int64_t)(16 * nt + r) * F + 16 * j + 4 * g);
+                        const f32x4 wa = w2f[i];
 #pragma unroll
                         for (int mt = 0; mt < MT; ++mt) {  // row tiles beyond T: never stored
                             const f32x4 hb = *reinterpret_cast<const f32x4*>(hbuf + (mt * 16 + r) * 20 + 4 * g);
@@ -657,7 +737,7 @@ __global__ __launch_bounds__(kThreads) void encoder_walk_kernel(const Args a) {
                 stamp(trace, layer, 4, 0);
                 phase_wait(a.bar, kCtrFfn, lay1 * prodFfn);
                 stamp(trace, layer, 4, 1);
-                phase_reduce_ln(a, PLr, a.np3, lw, X1r, Xr, T, reinterpret_cast<f32x4*>(work), red8, wg, G, tid, lane, wave);
+                phase_reduce_ln(a, PLr, ffn_planes, lw, X1r, Xr, T, reinterpret_cast<f32x4*>(work), red8, wg, G, tid, lane, wave);
                 stamp(trace, layer, 4, 2);
                 phase_arrive(a.bar, kCtrLn2);
             }
