@@ -2777,7 +2777,7 @@ int launch_walk(mvdb_encoder* e, const int32_t* ids, const int32_t* mask, int B,
     if (hc == 8) grid = cus;  // wide shapes: FFN1 has F / 16 column units, FFN2 (H / 16) x 4 (encoder_walk.hpp): every CU
     if (e->walk_grid_env > 0) grid = std::min(cus, std::max(e->walk_grid_env, e->walk_np3));
     e->walk_grid = grid;
-    a.nsplit = std::max(1, std::min(grid / std::max(1, B * c.heads), std::max(1, ntiles / walk::kWaves)));
+    a.nsplit = std::max(1, std::min(grid / std::max(1, B * c.heads * rh), std::max(1, ntiles / walk::kWaves)));
     a.trace = nullptr;
 #ifdef MVDB_X3_ABLATE
     if (!e->walk_trace) MVDB_TRY(dev_alloc(&e->walk_trace, (int64_t)cus * walk::kTraceSlots));

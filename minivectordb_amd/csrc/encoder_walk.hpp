@@ -101,8 +101,10 @@ __device__ __forceinline__ void stamp(unsigned long long* trace, int layer, int 
 }
 
 // Every counter is kept in kReplicas copies, each on a 128-byte line of its own: an arriving workgroup adds to ALL of them
-// with ONE wave instruction (lane i -> replica i), a waiting workgroup polls replica (workgroup & 7) — 96 FFN workgroups
-// polling one word were released over 1.8 us (first to last), and the atomics of 96 arrivals queue on one word.
+// with ONE wave instruction (lane i -> replica i), a waiting workgroup polls replica (workgroup & 7).  (One word: 96 pollers
+// were released over 1.8 us, first to last, and 96 arrivals queued on it — replicas cut the hand-offs from ~3 to 1.1 - 3.7 us.
+// Tried instead, and slower by 8 - 16 us per forward: eight SHARDS — one atomic per arrival on shard (workgroup & 7), every
+// waiter polling all eight with one 8-lane load — an eighth of the atomics but eight lines per poll.)
 constexpr int kReplicas = 8, kCtrStride = 32;  // words
 __device__ __forceinline__ unsigned int* ctr_word(unsigned int* bar, int ctr, int replica) {
     return bar + (ctr * kReplicas + replica) * kCtrStride;
@@ -115,9 +117,11 @@ __device__ __forceinline__ void phase_arrive(unsigned int* bar, int ctr) {
     if (threadIdx.x < kReplicas) __hip_atomic_fetch_add(ctr_word(bar, ctr, threadIdx.x), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// Wait until `target` producers have arrived at counter `ctr`: one lane polls with L1-bypassing loads, the workgroup meets.
-__device__ __forceinline__ void phase_wait(unsigned int* bar, int ctr, unsigned int target) {
+// Wait until the `producers` workgroups of a phase have each arrived `epochs` times at counter `ctr`: one lane polls its
+// replica with L1-bypassing loads, the workgroup meets.
+__device__ __forceinline__ void phase_wait(unsigned int* bar, int ctr, unsigned int epochs, unsigned int producers) {
     if (threadIdx.x == 0) {
+        const unsigned int target = epochs * producers;
         const unsigned int* w = ctr_word(bar, ctr, blockIdx.x & (kReplicas - 1));
         while (__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
 #ifdef MVDB_WALK_ACQUIRE_LOADS
@@ -297,20 +301,21 @@ __device__ __forceinline__ void attention_tile(const float* Qs, const float* Ks,
 }
 
 // plane[h][s0 + query][16 nt ..] = sum_d ctx[query][d] Wo[16 nt ..][h hd + d] for one column tile; wa = the tile's Wo fragments
-template <int MT>
+template <int MT>  // MT query tiles from query row q0 on
 __device__ __forceinline__ void outproj_tile(const f32x4 (&wa)[4], const float* Cs, int hd, int len, rsrc_t PLr, int plane_row0, int H,
-                                             int nt, int lane) {
+                                             int nt, int lane, int q0 = 0) {
     const int r = lane & 15, g = lane >> 4, hd4 = hd + 4, nc = hd >> 4;
 #pragma unroll
     for (int qi = 0; qi < MT; ++qi) {  // query tiles beyond the sentence: never stored
+        const int row = q0 + 16 * qi + r;
         f32x4 o = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            const f32x4 cb = *reinterpret_cast<const f32x4*>(Cs + (16 * qi + r) * hd4 + 16 * min(c, nc - 1) + 4 * g);
+            const f32x4 cb = *reinterpret_cast<const f32x4*>(Cs + row * hd4 + 16 * min(c, nc - 1) + 4 * g);
 #pragma unroll
             for (int m = 0; m < 4; ++m) o = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[c][m], cb[m], o, 0, 0, 0);
         }
-        if (16 * qi + r < len) st4(PLr, ((plane_row0 + 16 * qi + r) * H + 16 * nt + 4 * g) * 4, o);
+        if (row < len) st4(PLr, ((plane_row0 + row) * H + 16 * nt + 4 * g) * 4, o);
     }
 }
 __device__ __forceinline__ void outproj_load_w(const float* __restrict__ wo, int H, int h, int hd, int nt, f32x4 (&wa)[4], int lane) {
@@ -436,7 +441,7 @@ __global__ __launch_bounds__(kThreads) void encoder_walk_kernel(const Args a) {
     const unsigned int prodRow = (unsigned int)min(T, G);                      // embeddings, sum + LN
     const int ntiles = H >> 4;
     const int ntu = (ntiles + a.nsplit - 1) / a.nsplit;
-    const int attn_units = a.B * a.heads * a.nsplit;
+    const int attn_units = a.B * a.heads * a.nsplit * RH;  // (sentence, head, column split of the out-projection, query half)
     constexpr int AT = MT * RH;                                               // row tiles of the attention
     const int ncol = (3 * H) >> 4;                                            // column units of the QKV product
     const unsigned int prodQkv = (unsigned int)min(ncol * RH, G);
@@ -476,7 +481,7 @@ __global__ __launch_bounds__(kThreads) void encoder_walk_kernel(const Args a) {
             const unsigned int lay1 = (unsigned int)layer + 1u;
             // what the first phase of a layer waits for: the embeddings, or the previous layer's last sum + LN
             const int in_ctr = layer == 0 ? kCtrEmbed : kCtrLn2;
-            const unsigned int in_target = (layer == 0 ? 1u : (unsigned int)layer) * prodRow;
+            const unsigned int in_epochs = layer == 0 ? 1u : (unsigned int)layer;
 
             {
                 // ---- QKV: column units over 3H -> QKV[T, 3H] ----------------------------------------------------------------------
@@ -495,7 +500,7 @@ __global__ __launch_bounds__(kThreads) void encoder_walk_kernel(const Args a) {
                             colunit_load_w<HC>(L.wqkv + (int64_t)u * 16 * H, H, wa, lane, wave);
                             if (first) {
                                 stamp(trace, layer, 0, 0);
-                                phase_wait(a.bar, in_ctr, in_target);
+                                phase_wait(a.bar, in_ctr, in_epochs, prodRow);
                                 stamp(trace, layer, 0, 1);
                                 first = false;
                             }
@@ -506,7 +511,7 @@ __global__ __launch_bounds__(kThreads) void encoder_walk_kernel(const Args a) {
                             colunit_load_w_batch<CB>(L.wqkv + (int64_t)u * 16 * H, H, H >> 4, 0, w0, lane, wave);
                             if (first) {
                                 stamp(trace, layer, 0, 0);
-                                phase_wait(a.bar, in_ctr, in_target);
+                                phase_wait(a.bar, in_ctr, in_epochs, prodRow);
                                 stamp(trace, layer, 0, 1);
                                 first = false;
                             }
@@ -533,7 +538,8 @@ __global__ __launch_bounds__(kThreads) void encoder_walk_kernel(const Args a) {
                     float* Cs = Vt + hd * 68;         // [64][hd + 4]  context of this head
                     bool first = true;
                     for (int u = wg; u < attn_units; u += G) {
-                        const int ns = u % a.nsplit, bh = u / a.nsplit;
+                        const int qh = u % RH, u1 = u / RH;                 // query tiles [qh MT, qh MT + MT) of the sentence
+                        const int ns = u1 % a.nsplit, bh = u1 / a.nsplit;
                         const int h = bh % a.heads, b = bh / a.heads;
                         const int s0 = s_seq[b], len = s_seq[b + 1] - s0;
                         const int nt0 = ns * ntu, nt1 = min(ntiles, nt0 + ntu);
@@ -541,7 +547,7 @@ __global__ __launch_bounds__(kThreads) void encoder_walk_kernel(const Args a) {
                         outproj_load_w(L.wo, H, h, hd, min(nt0 + wave, ntiles - 1), wo0, lane);
                         if (first) {
                             stamp(trace, layer, 1, 0);
-                            phase_wait(a.bar, kCtrQkv, lay1 * prodQkv);
+                            phase_wait(a.bar, kCtrQkv, lay1, prodQkv);
                             stamp(trace, layer, 1, 1);
                             first = false;
                         }
@@ -564,7 +570,7 @@ __global__ __launch_bounds__(kThreads) void encoder_walk_kernel(const Args a) {
                             for (int j = 0; j < 4; ++j) Vt[(4 * c4 + j) * 68 + row] = vv[j];
                         }
                         __syncthreads();
-                        if (wave < mtb) attention_tile<AT>(Qs, Ks, Vt, Cs, hd, len, wave, lane);
+                        if (wave < MT && qh * MT + wave < mtb) attention_tile<AT>(Qs, Ks, Vt, Cs, hd, len, qh * MT + wave, lane);
                         __syncthreads();
                         for (int nt = nt0 + wave; nt < nt1; nt += kWaves) {
                             f32x4 wa[4];
@@ -574,7 +580,7 @@ __global__ __launch_bounds__(kThreads) void encoder_walk_kernel(const Args a) {
                             } else {
                                 outproj_load_w(L.wo, H, h, hd, nt, wa, lane);
                             }
-                            outproj_tile<AT>(wa, Cs, hd, len, PLr, h * kTmax + s0, H, nt, lane);
+                            outproj_tile<MT>(wa, Cs, hd, len, PLr, h * kTmax + s0, H, nt, lane, qh * MT * 16);
                         }
                         __syncthreads();  // Q / K / V / ctx tiles free for the next unit
                     }
@@ -587,7 +593,7 @@ __global__ __launch_bounds__(kThreads) void encoder_walk_kernel(const Args a) {
             if (wg < (int)prodRow) {
                 const LnWeights lw = ln_load_w(L.bo, L.ln1g, L.ln1b, H, tid);
                 stamp(trace, layer, 2, 0);
-                phase_wait(a.bar, kCtrAttn, lay1 * prodAttn);
+                phase_wait(a.bar, kCtrAttn, lay1, prodAttn);
                 stamp(trace, layer, 2, 1);
                 phase_reduce_ln(a, PLr, a.heads, lw, Xr, X1r, T, reinterpret_cast<f32x4*>(work), red8, wg, G, tid, lane, wave, trace, layer);
                 stamp(trace, layer, 2, 2);
@@ -608,7 +614,7 @@ __global__ __launch_bounds__(kThreads) void encoder_walk_kernel(const Args a) {
                         colunit_load_w_batch<CB>(L.w1 + (int64_t)j * 16 * H, H, H >> 4, 0, w0, lane, wave);
                         if (first) {
                             stamp(trace, layer, 5, 0);
-                            phase_wait(a.bar, kCtrLn1, lay1 * prodRow);
+                            phase_wait(a.bar, kCtrLn1, lay1, prodRow);
                             stamp(trace, layer, 5, 1);
                             first = false;
                         }
@@ -642,7 +648,7 @@ __global__ __launch_bounds__(kThreads) void encoder_walk_kernel(const Args a) {
                         colunit_load_w_batch<CB>(L.w2 + (int64_t)nt * 16 * F + (live ? k0 : 0), F, nch, 0, w0, lane, wave);
                         if (first) {
                             stamp(trace, layer, 3, 0);
-                            phase_wait(a.bar, kCtrFfn1, lay1 * prodFfn1);
+                            phase_wait(a.bar, kCtrFfn1, lay1, prodFfn1);
                             stamp(trace, layer, 3, 1);
                             first = false;
                         }
@@ -690,7 +696,7 @@ __global__ __launch_bounds__(kThreads) void encoder_walk_kernel(const Args a) {
                         }
                         if (first) {
                             stamp(trace, layer, 3, 0);
-                            phase_wait(a.bar, kCtrLn1, lay1 * prodRow);
+                            phase_wait(a.bar, kCtrLn1, lay1, prodRow);
                             stamp(trace, layer, 3, 1);
                             first = false;
                         }
@@ -735,7 +741,7 @@ __global__ __launch_bounds__(kThreads) void encoder_walk_kernel(const Args a) {
             if (wg < (int)prodRow) {
                 const LnWeights lw = ln_load_w(L.b2, L.ln2g, L.ln2b, H, tid);
                 stamp(trace, layer, 4, 0);
-                phase_wait(a.bar, kCtrFfn, lay1 * prodFfn);
+                phase_wait(a.bar, kCtrFfn, lay1, prodFfn);
                 stamp(trace, layer, 4, 1);
                 phase_reduce_ln(a, PLr, ffn_planes, lw, X1r, Xr, T, reinterpret_cast<f32x4*>(work), red8, wg, G, tid, lane, wave);
                 stamp(trace, layer, 4, 2);
@@ -746,7 +752,7 @@ __global__ __launch_bounds__(kThreads) void encoder_walk_kernel(const Args a) {
 
     // ---- pooling + L2 normalise (average_pool + F.normalize(eps = 1e-12); pooling 1: first valid token) ------------------------
     if (wg < a.B || (a.hidden && wg < a.B * a.S)) {
-        if (T > 0) phase_wait(a.bar, kCtrLn2, (unsigned int)a.nlayers * prodRow);
+        if (T > 0) phase_wait(a.bar, kCtrLn2, (unsigned int)a.nlayers, prodRow);
         for (int b = wg; b < a.B; b += G) {
             const int s0 = s_seq[b], len = s_seq[b + 1] - s0;
             const int span = a.pooling == 1 ? (len > 0 ? 1 : 0) : len;
