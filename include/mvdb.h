@@ -351,7 +351,7 @@ int mvdb_encoder_forward_device(mvdb_encoder* enc, const int32_t* ids_dev, const
  * which is what mvdb_encoder_forward's Python wrapper does on the host path.  Valid until mvdb_encoder_free. */
 const unsigned int* mvdb_encoder_overflow_flag(const mvdb_encoder* enc);
 
-/* 1 when a forward of B x S token slots runs as the ONE layer-walking launch (csrc/encoder_walk.hpp: at most 64 token slots —
+/* 1 when a forward of B x S token slots runs as the ONE layer-walking launch (csrc/encoder_walk.hpp: at most 128 token slots —
  * one sentence per call is the reference's only shape, embedding_model.py:62-71 —, exact fp32 matrix cores whatever `compute`
  * says), 0 when it runs the per-op kernels.  MVDB_ENCODER_WALK=0 (read at mvdb_encoder_create) switches the launch off. */
 int mvdb_encoder_walks(const mvdb_encoder* enc, int B, int S);

@@ -2769,8 +2769,8 @@ int launch_walk(mvdb_encoder* e, const int32_t* ids, const int32_t* mask, int B,
     a.np3 = e->walk_np3;
     const int ntiles = c.hidden / 16;
     const int slots = B * S;
-    // <= 16 / <= 32 token slots: one / two row tiles per column unit; more: two tiles and the units split once more by rows
-    const int mt = slots <= 16 ? 1 : 2, rh = slots <= 32 ? 1 : 2;
+    // <= 16 / <= 32 token slots: one / two row tiles per column unit; more: two tiles and the units split by row groups of 32 too
+    const int mt = slots <= 16 ? 1 : 2, rh = slots <= 32 ? 1 : slots <= 64 ? 2 : 4;
     const int hc = c.hidden <= 128 ? 1 : c.hidden <= 384 ? 3 : 8;
     const int cus = device_cus(e->device);
     int grid = std::min(cus, std::max<int>({16, 3 * c.hidden / 16 * rh, e->walk_np3 * rh}));  // one workgroup per CU: all resident
@@ -2784,11 +2784,11 @@ int launch_walk(mvdb_encoder* e, const int32_t* ids, const int32_t* mask, int B,
     MVDB_HIP(hipMemsetAsync(e->walk_trace, 0, sizeof(unsigned long long) * cus * walk::kTraceSlots, s));
     a.trace = e->walk_trace;
 #endif
-    const size_t lds = walk::lds_bytes(mt, c.hidden, a.hd);
+    const size_t lds = walk::lds_bytes(mt, rh, c.hidden, a.hd);
 #define MVDB_WALK_CASE(M, C, R) if (mt == M && hc == C && rh == R) return launch_walk_inst<M, C, R>(e, a, lds, grid, s)
-    MVDB_WALK_CASE(1, 1, 1); MVDB_WALK_CASE(2, 1, 1); MVDB_WALK_CASE(2, 1, 2);
-    MVDB_WALK_CASE(1, 3, 1); MVDB_WALK_CASE(2, 3, 1); MVDB_WALK_CASE(2, 3, 2);
-    MVDB_WALK_CASE(1, 8, 1); MVDB_WALK_CASE(2, 8, 1); MVDB_WALK_CASE(2, 8, 2);
+    MVDB_WALK_CASE(1, 1, 1); MVDB_WALK_CASE(2, 1, 1); MVDB_WALK_CASE(2, 1, 2); MVDB_WALK_CASE(2, 1, 4);
+    MVDB_WALK_CASE(1, 3, 1); MVDB_WALK_CASE(2, 3, 1); MVDB_WALK_CASE(2, 3, 2); MVDB_WALK_CASE(2, 3, 4);
+    MVDB_WALK_CASE(1, 8, 1); MVDB_WALK_CASE(2, 8, 1); MVDB_WALK_CASE(2, 8, 2); MVDB_WALK_CASE(2, 8, 4);
 #undef MVDB_WALK_CASE
     return fail(MVDB_ERR_ARG, "no walker instantiation for this shape");
 }
@@ -3006,7 +3006,7 @@ int forward_core(mvdb_encoder* e, const int32_t* ids, const int32_t* mask, int B
     if (S + (c.position_offset > 0 ? c.position_offset : 0) > c.max_positions)
         return fail(MVDB_ERR_ARG, "sequence length %d exceeds max_positions %d", S, c.max_positions);
     if (walk_eligible(e, B, S)) {
-        // <= 64 token slots (one sentence per call is the reference's only shape): ONE launch walks the layers, exact fp32 in
+        // <= 128 token slots (one sentence per call is the reference's only shape): ONE launch walks the layers, exact fp32 in
         // both modes; a plain launch (no graph: one node) that also joins a caller's capture
         hipStreamCaptureStatus cap0 = hipStreamCaptureStatusNone;
         const bool captured = s && hipStreamIsCapturing(s, &cap0) == hipSuccess && cap0 != hipStreamCaptureStatusNone;

@@ -38,9 +38,10 @@ namespace walk {
 
 constexpr int kWaves = 8;
 constexpr int kThreads = kWaves * 64;
-constexpr int kTmax = 64;     // packed tokens (and token slots B * S) per launch
+constexpr int kTmax = 128;    // packed tokens (and token slots B * S) per launch
 constexpr int kSc1 = 16;      // cache-policy bit of the buffer builtins on gfx950: sc1
 constexpr int kMaxPlanes = 128;
+constexpr int kLdsHead = 4 * kTmax + 16;  // floats in front of the phase scratch: packing tables [3][kTmax], sentence starts [kTmax + 1 (+ pad)], 8 reduction slots
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
@@ -244,12 +245,13 @@ __device__ __forceinline__ f32x4 colunit_total(const f32x4* red, int mt, int lan
 }
 
 // ---- attention of one sentence's head from LDS tiles --------------------------------------------------------------------------
-// Qs [rows][hd + 4] (scaled by log2(e) / sqrt(hd)), Ks [rows][hd + 4], Vt [hd][68] (V transposed), Cs [rows][hd + 4] receives
+// Qs [rows][hd + 4] (scaled by log2(e) / sqrt(hd)), Ks [rows][hd + 4], Vt [hd][16 MT + 4] (V transposed), Cs [rows][hd + 4] receives
 // the context.  Wave qi < ceil(len / 16) owns query tile qi.  Key tiles beyond the sentence must hold FINITE values (they are
 // masked to -inf by index, and their V columns meet p = 0).
 template <int MT>
 __device__ __forceinline__ void attention_tile(const float* Qs, const float* Ks, const float* Vt, float* Cs, int hd, int len, int qi,
                                                int lane) {
+    constexpr int VS = MT * 16 + 4;  // row stride of V^T: every key of the MT tiles + one 16-byte pad
     const int r = lane & 15, g = lane >> 4, hd4 = hd + 4;
     f32x4 sc[MT];
 #pragma unroll
@@ -292,7 +294,7 @@ __device__ __forceinline__ void attention_tile(const float* Qs, const float* Ks,
         f32x4 o = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kj = 0; kj < MT; ++kj) {
-            const f32x4 va = *reinterpret_cast<const f32x4*>(Vt + (16 * dt + r) * 68 + 16 * kj + 4 * g);
+            const f32x4 va = *reinterpret_cast<const f32x4*>(Vt + (16 * dt + r) * VS + 16 * kj + 4 * g);
 #pragma unroll
             for (int m = 0; m < 4; ++m) o = __builtin_amdgcn_mfma_f32_16x16x4f32(va[m], sc[kj][m], o, 0, 0, 0);
         }
@@ -387,46 +389,55 @@ __device__ __forceinline__ void phase_reduce_ln(const Args& a, rsrc_t PLr, int n
     else reduce_ln_rows<20>(a, PLr, np, lw, Rr, Or, T, comb, red8, wg, G, tid, lane, wave, trace, layer);
 }
 
-// MT = row tiles (of 16 tokens) a column unit computes, RH = row halves: at more than 32 tokens the column units are split
-// once more by rows — unit (columns u, half hf) computes rows [32 hf, 32 hf + 32) — so that a 64-token forward spreads over
-// twice the workgroups and each loads and stores half the activations; AT = MT * RH row tiles for the attention, which
-// needs every key of a sentence.  (Tried and removed: the QKV columns of a head computed by the head's own workgroup
+// MT = row tiles (of 16 tokens) a column unit computes, RH = row groups: at more than 32 tokens the column units are split
+// by rows too — unit (columns u, group hf) computes rows [32 hf, 32 hf + 32), RH = 2 up to 64 tokens, 4 up to 128 — so that a
+// long sentence spreads over more workgroups and each loads and stores a share of the activations; AT = MT * RH row tiles
+// for the attention, which needs every key of a sentence.  (Tried and removed: the QKV columns of a head computed by the head's own workgroup
 // straight into the attention's LDS tiles, one phase fewer per layer — 12 CUs then do the whole QKV product on the fp32
 // matrix pipe: 0.33 / 0.43 ms per forward at 8 / 32 tokens against 0.27 / 0.34 with QKV as its own 72-workgroup phase.)
 template <int MT, int HC, int RH>
 __global__ __launch_bounds__(kThreads) void encoder_walk_kernel(const Args a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     // ---- LDS map -------------------------------------------------------------------------------------------------------
-    int* s_tok_id = reinterpret_cast<int*>(lds);   // [64] packed token -> vocabulary id
-    int* s_tok_pos = s_tok_id + 64;                 // [64] packed token -> position id
-    int* s_slot_p = s_tok_pos + 64;                 // [64] token slot (b * S + t) -> packed token, or -1
-    int* s_seq = s_slot_p + 64;                     // [B + 1 <= 65] first packed token of each sentence
-    float* red8 = lds + 264;                        // [8]
-    float* work = lds + 272;                        // phase scratch (16-byte aligned: 272 * 4 = 1088)
+    int* s_tok_id = reinterpret_cast<int*>(lds);   // [128] packed token -> vocabulary id
+    int* s_tok_pos = s_tok_id + kTmax;              // [128] packed token -> position id
+    int* s_slot_p = s_tok_pos + kTmax;              // [128] token slot (b * S + t) -> packed token, or -1
+    int* s_seq = s_slot_p + kTmax;                  // [B + 1 <= 129] first packed token of each sentence
+    float* red8 = lds + kLdsHead - 8;               // [8]
+    float* work = lds + kLdsHead;                   // phase scratch (16-byte aligned)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wg = blockIdx.x, G = gridDim.x;
     const int H = a.H, F = a.F, hd = a.hd;
     const int r = lane & 15, g = lane >> 4;
 
-    // ---- packing: every workgroup derives it from the mask (B * S <= 64 slots = one ballot) --------------------------------
+    // ---- packing: every workgroup derives it from the mask (B * S <= 128 slots = two ballots) ------------------------------
     if (wave == 0) {
         const int slots = a.B * a.S;
-        const bool v = lane < slots && a.mask[lane] != 0;
-        const unsigned long long m = __ballot(v);
-        const int p = __popcll(m & ((1ull << lane) - 1ull));
-        const int b = lane < slots ? lane / a.S : 0, t = lane - b * a.S;
-        const int lo = b * a.S;
-        const int sb = __popcll(m & (lo >= 64 ? ~0ull : (1ull << lo) - 1ull));
-        if (lane < slots) s_slot_p[lane] = v ? p : -1;
-        if (v) {
-            const int id = a.ids[lane];
-            s_tok_id[p] = id < 0 ? 0 : (id >= a.vocab ? a.vocab - 1 : id);
-            s_tok_pos[p] = a.position_offset > 0 ? (p - sb) + a.position_offset : t;
+        const bool v0 = lane < slots && a.mask[lane] != 0;
+        const bool v1 = lane + 64 < slots && a.mask[lane + 64] != 0;
+        const unsigned long long m0 = __ballot(v0), m1 = __ballot(v1);
+        const int n0 = __popcll(m0);
+        // valid slots in [0, e)
+        auto below = [&](int e) {
+            const int lo = min(e, 64), hi = max(e - 64, 0);
+            return __popcll(m0 & (lo >= 64 ? ~0ull : (1ull << lo) - 1ull)) + __popcll(m1 & (hi >= 64 ? ~0ull : (1ull << hi) - 1ull));
+        };
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int slot = lane + 64 * half;
+            const bool v = half ? v1 : v0;
+            const int p = half ? n0 + __popcll(m1 & ((1ull << lane) - 1ull)) : __popcll(m0 & ((1ull << lane) - 1ull));
+            const int b = slot < slots ? slot / a.S : 0, t = slot - b * a.S;
+            const int sb = below(b * a.S);
+            if (slot < slots) s_slot_p[slot] = v ? p : -1;
+            if (v) {
+                const int id = a.ids[slot];
+                s_tok_id[p] = id < 0 ? 0 : (id >= a.vocab ? a.vocab - 1 : id);
+                s_tok_pos[p] = a.position_offset > 0 ? (p - sb) + a.position_offset : t;
+            }
+            if (slot <= a.B) s_seq[slot] = below(slot * a.S);
         }
-        if (lane <= a.B) {
-            const int e = lane * a.S;
-            s_seq[lane] = __popcll(m & (e >= 64 ? ~0ull : (1ull << e) - 1ull));
-        }
+        if (lane == 0) s_seq[a.B] = n0 + __popcll(m1);  // (B = 128 sentences of one token: slot 128 is nobody's)
     }
     __syncthreads();
     const int T = s_seq[a.B];
@@ -532,10 +543,11 @@ __global__ __launch_bounds__(kThreads) void encoder_walk_kernel(const Args a) {
 
                 // ---- attention per (sentence, head, column split) + out-projection partial -> plane[head] --------------------------------
                 if (wg < (int)prodAttn) {
-                    float* Qs = work;                 // [64][hd + 4]  queries, scaled
-                    float* Ks = Qs + 64 * hd4;        // [64][hd + 4]
-                    float* Vt = Ks + 64 * hd4;        // [hd][68]      V transposed
-                    float* Cs = Vt + hd * 68;         // [64][hd + 4]  context of this head
+                    constexpr int VS = AT * 16 + 4;          // row stride of V^T
+                    float* Qs = work;                       // [AT * 16][hd + 4]  queries, scaled
+                    float* Ks = Qs + AT * 16 * hd4;          // [AT * 16][hd + 4]
+                    float* Vt = Ks + AT * 16 * hd4;          // [hd][AT * 16 + 4]  V transposed
+                    float* Cs = Vt + hd * VS;               // [AT * 16][hd + 4]  context of this head
                     bool first = true;
                     for (int u = wg; u < attn_units; u += G) {
                         const int qh = u % RH, u1 = u / RH;                 // query tiles [qh MT, qh MT + MT) of the sentence
@@ -567,7 +579,7 @@ __global__ __launch_bounds__(kThreads) void encoder_walk_kernel(const Args a) {
                             *reinterpret_cast<f32x4*>(Qs + row * hd4 + 4 * c4) = qv;
                             *reinterpret_cast<f32x4*>(Ks + row * hd4 + 4 * c4) = kv;
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) Vt[(4 * c4 + j) * 68 + row] = vv[j];
+                            for (int j = 0; j < 4; ++j) Vt[(4 * c4 + j) * VS + row] = vv[j];
                         }
                         __syncthreads();
                         if (wave < MT && qh * MT + wave < mtb) attention_tile<AT>(Qs, Ks, Vt, Cs, hd, len, qh * MT + wave, lane);
@@ -671,15 +683,16 @@ __global__ __launch_bounds__(kThreads) void encoder_walk_kernel(const Args a) {
             } else
             // ---- FFN: workgroup wg < np3 owns the 16-wide slices wg, wg + np3, ... of F -> plane[wg] ---------------------------------
             if (wg < (int)prodFfn) {
-                const int hf = wg / a.np3, pl = wg - hf * a.np3, row0 = hf * MT * 16;  // plane (= first slice) pl, row half hf
                 f32x4* red = reinterpret_cast<f32x4*>(work);
-                float* hbuf = work + kWaves * MT * 64 * 4;  // [64][20]: GELU(x1 W1_slice^T + b1)
+                float* hbuf = work + kWaves * MT * 64 * 4;  // [MT * 16][20]: GELU(x1 W1_slice^T + b1)
+                bool first = true;
+              for (int uu = wg; uu < a.np3 * RH; uu += G) {   // units (plane, row group): more than one per workgroup above 64 tokens
+                const int hf = uu / a.np3, pl = uu - hf * a.np3, row0 = hf * MT * 16;  // plane (= first slice) pl, row group hf
                 f32x4 acc2[HC][MT];
 #pragma unroll
                 for (int i = 0; i < HC; ++i)
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt) acc2[i][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-                bool first = true;
                 for (int j = pl; j < (F >> 4); j += a.np3) {
                     f32x4 acc[MT];
 #pragma unroll
@@ -733,6 +746,7 @@ __global__ __launch_bounds__(kThreads) void encoder_walk_kernel(const Args a) {
                             if (row0 + mt * 16 + r < T) st4(PLr, ((pl * kTmax + row0 + mt * 16 + r) * H + 16 * nt + 4 * g) * 4, acc2[i][mt]);
                     }
                 }
+              }
                 stamp(trace, layer, 3, 2);
                 phase_arrive(a.bar, kCtrFfn);
             }
@@ -802,12 +816,13 @@ __global__ __launch_bounds__(kThreads) void encoder_walk_kernel(const Args a) {
 }
 
 // LDS bytes of a launch
-inline size_t lds_bytes(int mt, int H, int hd) {
-    const size_t colunit = (size_t)kWaves * mt * 64 * 16 + 64 * 20 * 4;             // wave partials + GELU tile
-    const size_t attn = (size_t)(3 * 64 * (hd + 4) + hd * 68) * 4;                  // Q, K, ctx, V^T
-    const size_t reduce = (size_t)kThreads * 16;                                    // plane-group partials
+inline size_t lds_bytes(int mt, int rh, int H, int hd) {
+    const int at = mt * rh;                                                          // row tiles of the attention
+    const size_t colunit = (size_t)kWaves * mt * 64 * 16 + (size_t)mt * 16 * 20 * 4;  // wave partials + GELU tile
+    const size_t attn = (size_t)(3 * at * 16 * (hd + 4) + hd * (at * 16 + 4)) * 4;   // Q, K, ctx, V^T
+    const size_t reduce = (size_t)kThreads * 16;                                     // plane-group partials
     // never less than half a CU's LDS + 1 KiB: two workgroups of a launch cannot share a CU (the measured sc1 hand-off is "one per CU")
-    return std::max<size_t>(272 * 4 + std::max(std::max(colunit, attn), reduce), 81 * 1024);
+    return std::max<size_t>((size_t)kLdsHead * 4 + std::max(std::max(colunit, attn), reduce), 81 * 1024);
 }
 
 }  // namespace walk

@@ -102,7 +102,7 @@ class GpuEncoder:
             pass
 
     def walks(self, B, S):
-        """True when a [B,S] forward runs as the one layer-walking launch (<= 64 token slots, exact fp32 in both modes)."""
+        """True when a [B,S] forward runs as the one layer-walking launch (<= 128 token slots, exact fp32 in both modes)."""
         return bool(self._native.lib().mvdb_encoder_walks(self._h, int(B), int(S)))
 
     def forward(self, ids, mask, compute=None):

@@ -1,4 +1,4 @@
-"""The layer-walking launch (csrc/encoder_walk.hpp: <= 64 token slots, the reference's one-sentence-per-call shape,
+"""The layer-walking launch (csrc/encoder_walk.hpp: <= 128 token slots, the reference's one-sentence-per-call shape,
 minivectordb/embedding_model.py:62-71) against the float64 restatement and against the per-op kernels of the same library.
 Tolerances as test_encoder_gpu.py: 2e-5 on the unit-norm embeddings, 1e-4 on hidden states (values up to ~6)."""
 import numpy as np
@@ -18,7 +18,8 @@ def _model(cfg, weights, **kw):
 SHAPES = [("tiny", 1, 5), ("tiny", 3, 9), ("tiny", 4, 16), ("hd64", 2, 17), ("hd64", 1, 64), ("xlmr-tiny", 3, 11), ("h96", 2, 23),
           ("e5-small-dims", 1, 7), ("e5-small-dims", 1, 16), ("e5-small-dims", 1, 33), ("e5-small-dims", 1, 64),
           ("e5-small-dims", 3, 21), ("e5-small-dims", 4, 16), ("xlmr-large-dims", 1, 12), ("xlmr-large-dims", 2, 30),
-          ("xlmr-large-dims", 1, 64)]
+          ("xlmr-large-dims", 1, 64), ("e5-small-dims", 1, 100), ("e5-small-dims", 1, 128), ("e5-small-dims", 5, 25), ("e5-small-dims", 128, 1),
+          ("xlmr-large-dims", 1, 97), ("xlmr-large-dims", 2, 64), ("hd64", 3, 40), ("h96", 5, 23)]
 
 
 @pytest.mark.parametrize("name,B,S", SHAPES, ids=[f"{n}-{b}x{s}" for n, b, s in SHAPES])
