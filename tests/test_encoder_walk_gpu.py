@@ -106,3 +106,37 @@ def test_walk_all_padding_sentence_is_nan_like_the_reference(gpu):
     _, e64 = E.numpy_forward(cfg, E.make_weights(cfg, 3), ids[[0, 2]], mask[[0, 2]])
     np.testing.assert_allclose(out[[0, 2]], e64, atol=2e-5, rtol=0)
     enc.close()
+
+
+def test_walk_fuzz_random_batches_and_masks(gpu):
+    """60 random small batches (1..12 sentences, 1..128 token slots, ragged lengths, holes in the masks, all-padding rows) on
+    four model shapes — head widths 32 and 64, XLM-R position ids, a width that is not a multiple of 64 — against the float64
+    restatement, and each batch row against its own one-sentence forward bit for bit."""
+    rs = np.random.RandomState(2024)
+    encs = {}
+    for trial in range(60):
+        name = ("tiny", "hd64", "xlmr-tiny", "h96")[trial % 4]
+        cfg = E.make_config(name)
+        if name not in encs:
+            w = E.make_weights(cfg, 40 + trial)
+            encs[name] = (_model(cfg, w), w)
+        enc, w = encs[name]
+        B = int(rs.randint(1, 13))
+        smax = min(128 // B, cfg["max_position_embeddings"] - 2)
+        S = int(rs.randint(1, smax + 1))
+        ids, mask = E.make_inputs(cfg, B, S, 1000 + trial)
+        if S > 3 and trial % 3 == 0:
+            mask[rs.randint(0, B), rs.randint(1, S)] = 0          # a hole
+        if B > 2 and trial % 5 == 0:
+            mask[rs.randint(1, B)] = 0                           # a sentence of padding only
+        assert enc.walks(B, S)
+        live = mask.sum(axis=1) > 0
+        with np.errstate(invalid="ignore", divide="ignore"):
+            _, e64 = E.numpy_forward(cfg, w, ids[live], mask[live])
+        got = enc.forward(ids, mask)
+        np.testing.assert_allclose(got[live], e64, atol=2e-5, rtol=0, err_msg=f"trial {trial}: {name} {B}x{S}")
+        assert np.isnan(got[~live]).all()
+        b = int(np.flatnonzero(live)[rs.randint(0, live.sum())])
+        assert np.array_equal(enc.forward(ids[b:b + 1], mask[b:b + 1])[0], got[b]), (trial, b)
+    for enc, _ in encs.values():
+        enc.close()
