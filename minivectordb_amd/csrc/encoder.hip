@@ -2274,6 +2274,9 @@ struct mvdb_encoder {
     unsigned int* walk_bar = nullptr;
     unsigned long long* walk_trace = nullptr;  // ablation build only
     unsigned int* overflow_flag = nullptr;     // device word: 1 after a forward whose pooled rows were not all finite
+    hipEvent_t walk_done = nullptr;            // recorded behind every forward of the device entry: the next one — on whatever
+                                               // stream — waits for it (forwards share the staging buffers, the workspace and the
+                                               // walking launch's phase counters: two resident walking grids would never finish)
     int walk_np3 = 0, walk_grid = 0, walk_grid_env = 0;
 
     void free_ws() {
@@ -3218,6 +3221,7 @@ int mvdb_encoder_free(mvdb_encoder* e) {
         if (e->stream2) (void)hipStreamDestroy(e->stream2);
         if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
         if (e->ev_join) (void)hipEventDestroy(e->ev_join);
+        if (e->walk_done) (void)hipEventDestroy(e->walk_done);
     }
     delete e;
     return 0;
@@ -3259,10 +3263,19 @@ int mvdb_encoder_forward_device(mvdb_encoder* e, const int32_t* ids_dev, const i
     // addresses) is reused whatever tensors the caller passes: three small device-to-device copies.
     const int64_t tokens = (int64_t)B * S, outn = (int64_t)B * e->cfg.hidden;
     MVDB_TRY(ensure_stage(e, tokens, outn));
+    // One forward at a time per encoder ON THE DEVICE too, whatever streams the callers use (the host lock above only orders
+    // the enqueues): an event behind every forward, waited for by the next.  Not while the caller captures the stream.
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    const bool capturing = hipStreamIsCapturing(s, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
+    if (!capturing) {
+        if (!e->walk_done) MVDB_HIP(hipEventCreateWithFlags(&e->walk_done, hipEventDisableTiming));
+        else MVDB_HIP(hipStreamWaitEvent(s, e->walk_done, 0));
+    }
     MVDB_HIP(hipMemcpyAsync(e->ids_stage, ids_dev, tokens * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
     MVDB_HIP(hipMemcpyAsync(e->mask_stage, mask_dev, tokens * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
     MVDB_TRY(forward_core(e, e->ids_stage, e->mask_stage, B, S, compute, e->out_stage, nullptr, s));
     MVDB_HIP(hipMemcpyAsync(out_dev, e->out_stage, outn * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (!capturing) MVDB_HIP(hipEventRecord(e->walk_done, s));
     return 0;
 }
 
@@ -3280,6 +3293,7 @@ int mvdb_encoder_forward(mvdb_encoder* e, const int32_t* ids_host, const int32_t
         if (mask_host[i] && (ids_host[i] < 0 || ids_host[i] >= e->cfg.vocab_size))
             return fail(MVDB_ERR_ARG, "token id %d at %lld outside the vocabulary [0,%d)", ids_host[i],
                         (long long)i, e->cfg.vocab_size);
+    if (e->walk_done) MVDB_HIP(hipStreamWaitEvent(e->stream, e->walk_done, 0));  // a device-entry forward may still be running
     MVDB_HIP(hipMemcpyAsync(e->ids_stage, ids_host, tokens * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
     MVDB_HIP(hipMemcpyAsync(e->mask_stage, mask_host, tokens * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
     MVDB_TRY(forward_core(e, e->ids_stage, e->mask_stage, B, S, compute, e->out_stage, nullptr, e->stream));

@@ -140,3 +140,29 @@ def test_walk_fuzz_random_batches_and_masks(gpu):
         assert np.array_equal(enc.forward(ids[b:b + 1], mask[b:b + 1])[0], got[b]), (trial, b)
     for enc, _ in encs.values():
         enc.close()
+
+
+def test_walk_launches_from_two_streams_are_ordered(gpu):
+    """Two callers, two streams, one encoder: the walking launches share the encoder's phase counters and buffers, so the
+    library orders them on the device (an event behind every launch, waited for by the next) — overlapping grids would
+    corrupt each other's counters and never finish."""
+    import torch
+    cfg = E.make_config("e5-small-dims")
+    w = E.make_weights(cfg, 77)
+    enc = _model(cfg, w)
+    dev = torch.device("cuda", 0)
+    ids, mask = E.make_inputs(cfg, 2, 40, 78)
+    _, e64 = E.numpy_forward(cfg, w, ids, mask)
+    s1, s2 = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+    ia = [torch.from_numpy(ids[b:b + 1]).to(dev) for b in range(2)]
+    ma = [torch.from_numpy(mask[b:b + 1]).to(dev) for b in range(2)]
+    torch.cuda.synchronize()
+    outs = []
+    for rep in range(40):
+        for b, st in ((0, s1), (1, s2)):
+            with torch.cuda.stream(st):
+                outs.append((b, enc.forward_device(ia[b], ma[b])[0]))
+    torch.cuda.synchronize()
+    for b, o in outs:
+        np.testing.assert_allclose(o.cpu().numpy()[0], e64[b], atol=2e-5, rtol=0)
+    enc.close()
