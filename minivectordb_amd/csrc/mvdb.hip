@@ -1331,7 +1331,10 @@ int search_core(const mvdb_index* idx, Workspace* ws, const float* q_dev, int nq
             } else if (per_pass > 0 && !idx->kn.disable_mfma_scan) {
                 MVDB_TRY(ws->cand.reserve((size_t)32 * scan_grid_upper_bound(idx->device) * k));
                 // (the GEMM scan keeps k <= 16 and takes no bitmap: those re-runs are all fp32-MFMA passes)
-                const int max_passes = (k > kGemmScanMaxK || mask_dev) ? (R + per_pass - 1) / per_pass : 2;
+                // every refused query through the gated fp32-MFMA pass, 32 at a time (launches beyond the refused count return at
+                // once).  Until round 5 the batch went to the 128-query GEMM-tiled scan after two such passes — 20-25 ms per 128
+                // queries at 10M x 512 where four MFMA passes take 14.
+                const int max_passes = (R + per_pass - 1) / per_pass;
                 for (int pass = 0; pass < max_passes && off < R; ++pass) {
                     const int take = std::min(per_pass, R - off);
                     MfmaScanArgs ma;
