@@ -176,6 +176,9 @@ __global__ __launch_bounds__(256) void flat_scan_half_kernel(HalfScanArgs a) {
                 Q[kb][r][j] = *reinterpret_cast<const hs_h8*>(a.qf + (int64_t)query * K + (wave * KQ + kb) * 16 + fk * 8);
             }
     float floor0[NR], thr[NR], inv[NR];
+    uint32_t thr_row[NR];  // row of the list's k-th key while thr is its score (ties are decided by the row: beats_key), else 0
+#pragma unroll
+    for (int r = 0; r < NR; ++r) thr_row[r] = 0u;
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
         const int myq = (r * NW + wave) * 32 + fr;
@@ -330,7 +333,7 @@ __global__ __launch_bounds__(256) void flat_scan_half_kernel(HalfScanArgs a) {
                 for (int e = 0; e < 16; ++e) {
                     const int rl = (e & 3) + 8 * (e >> 2);
                     const float s = sc[e];
-                    uint64_t mask = __ballot(m0 + rl + 4 * fk <= last && ((mw >> (rl + 4 * fk)) & 1u) && s >= thr[r]);
+                    uint64_t mask = __ballot(m0 + rl + 4 * fk <= last && ((mw >> (rl + 4 * fk)) & 1u) && beats_key(s, (uint32_t)(m0 + rl + 4 * fk), thr[r], thr_row[r]));
                     while (mask) {
                         const int srcl = __ffsll((long long)mask) - 1;
                         mask &= mask - 1;
@@ -339,7 +342,7 @@ __global__ __launch_bounds__(256) void flat_scan_half_kernel(HalfScanArgs a) {
                         const float sv = __uint_as_float(__builtin_amdgcn_readlane((int)__float_as_uint(s), srcl));
                         const uint32_t rv = (uint32_t)(m0 + rl + 4 * (srcl >> 5));
                         const uint64_t kth = lds_list_insert(rl_lists + (size_t)sq * kHalfKeep, kHalfKeep, make_key(sv, rv), lane);
-                        if (fr == sq) thr[r] = kth ? fmaxf(key_score(kth), floor0[r]) : floor0[r];  // both lane halves
+                        if (fr == sq) set_threshold(kth, floor0[r], thr[r], thr_row[r]);  // both lane halves
                     }
                 }
             }
@@ -524,6 +527,9 @@ __global__ __launch_bounds__(WV * 64) void flat_scan_hq_kernel(HalfScanArgs a) {
         for (int g = 0; g < G; ++g)
             Q[kb][g] = *reinterpret_cast<const hs_h8*>(a.qf + (int64_t)((wave * G + g) * 32 + fr) * K + kb * 16 + fk * 8);
     float floor0[G], thr[G], inv[G];
+    uint32_t thr_row[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) thr_row[g] = 0u;
 #pragma unroll
     for (int g = 0; g < G; ++g) {
         const int myq = (wave * G + g) * 32 + fr;
@@ -711,7 +717,7 @@ __global__ __launch_bounds__(WV * 64) void flat_scan_hq_kernel(HalfScanArgs a) {
                 for (int e = 0; e < 16; ++e) {
                     const int rl = (e & 3) + 8 * (e >> 2);
                     const float s = sc[e];
-                    uint64_t mask = __ballot(m0 + rl + 4 * fk <= last && ((mw >> (rl + 4 * fk)) & 1u) && s >= thr[g]);
+                    uint64_t mask = __ballot(m0 + rl + 4 * fk <= last && ((mw >> (rl + 4 * fk)) & 1u) && beats_key(s, (uint32_t)(m0 + rl + 4 * fk), thr[g], thr_row[g]));
                     while (mask) {
                         const int srcl = __ffsll((long long)mask) - 1;
                         mask &= mask - 1;
@@ -720,7 +726,7 @@ __global__ __launch_bounds__(WV * 64) void flat_scan_hq_kernel(HalfScanArgs a) {
                         const float sv = __uint_as_float(__builtin_amdgcn_readlane((int)__float_as_uint(s), srcl));
                         const uint32_t rv = (uint32_t)(m0 + rl + 4 * (srcl >> 5));
                         const uint64_t kth = lds_list_insert(gl + (size_t)sq * kHalfKeep, kHalfKeep, make_key(sv, rv), lane);
-                        if (fr == sq) thr[g] = kth ? fmaxf(key_score(kth), floor0[g]) : floor0[g];  // both lane halves
+                        if (fr == sq) set_threshold(kth, floor0[g], thr[g], thr_row[g]);  // both lane halves
                     }
                 }
             }
@@ -849,6 +855,7 @@ __global__ __launch_bounds__(WV * 64) void flat_scan_h16_kernel(HalfScanArgs a) 
     const int myq = wave * 32 + fr;
     float floor0 = myq < a.nq ? (a.thr0 ? a.thr0[myq] : -INFINITY) : INFINITY;
     float thr = floor0;
+    uint32_t thr_row = 0u;
     float inv = a.qinv[myq];
     // consume every global load here (see flat_scan_half_kernel)
 #pragma unroll
@@ -914,7 +921,7 @@ __global__ __launch_bounds__(WV * 64) void flat_scan_h16_kernel(HalfScanArgs a) 
             for (int e = 0; e < 16; ++e) {
                 const int rl = (e & 3) + 8 * (e >> 2);
                 const float s = sc[e];
-                uint64_t mask = __ballot(m0 + rl + 4 * fk <= last && ((mw >> (rl + 4 * fk)) & 1u) && s >= thr);
+                uint64_t mask = __ballot(m0 + rl + 4 * fk <= last && ((mw >> (rl + 4 * fk)) & 1u) && beats_key(s, (uint32_t)(m0 + rl + 4 * fk), thr, thr_row));
                 while (mask) {
                     const int srcl = __ffsll((long long)mask) - 1;
                     mask &= mask - 1;
@@ -923,7 +930,7 @@ __global__ __launch_bounds__(WV * 64) void flat_scan_h16_kernel(HalfScanArgs a) 
                     const float sv = __uint_as_float(__builtin_amdgcn_readlane((int)__float_as_uint(s), srcl));
                     const uint32_t rv = (uint32_t)(m0 + rl + 4 * (srcl >> 5));
                     const uint64_t kth = lds_list_insert(mylists + (size_t)sq * kHalfKeep, kHalfKeep, make_key(sv, rv), lane);
-                    if (fr == sq) thr = kth ? fmaxf(key_score(kth), floor0) : floor0;  // both lane halves
+                    if (fr == sq) set_threshold(kth, floor0, thr, thr_row);  // both lane halves
                 }
             }
         }

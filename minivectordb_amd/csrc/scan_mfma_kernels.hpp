@@ -44,14 +44,14 @@ struct MfmaScanArgs {
 // of corpus row (tile*16 + (l&15)) against query g*16 + 4*(l>>4) + r.  thr[g][r] gates (score only);
 // the exact 64-bit order is decided by the insert.  Wave-uniform control flow.
 template <int NG>
-__device__ __forceinline__ void mfma_tile_select(const f32x4m (&acc)[NG], float (&thr)[NG][4], bool rvalid,
+__device__ __forceinline__ void mfma_tile_select(const f32x4m (&acc)[NG], float (&thr)[NG][4], uint32_t (&thr_row)[NG][4], bool rvalid,
                                                  uint32_t rowid, int nq, int k, uint64_t* mylists, int lane) {
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const float s = acc[g][r];
-            uint64_t mask = __ballot(rvalid && s >= thr[g][r]);
+            uint64_t mask = __ballot(rvalid && beats_key(s, rowid, thr[g][r], thr_row[g][r]));
             while (mask) {
                 const int src = __ffsll((long long)mask) - 1;
                 mask &= mask - 1;
@@ -60,8 +60,7 @@ __device__ __forceinline__ void mfma_tile_select(const f32x4m (&acc)[NG], float 
                 const float sv = __uint_as_float(__builtin_amdgcn_readlane((int)__float_as_uint(s), src));
                 const uint32_t rv = (uint32_t)__builtin_amdgcn_readlane((int)rowid, src);
                 const uint64_t kth = lds_list_insert(mylists + (size_t)qq * k, k, make_key(sv, rv), lane);
-                const float t = kth ? key_score(kth) : -INFINITY;
-                if ((lane >> 4) == (src >> 4)) thr[g][r] = t;
+                if ((lane >> 4) == (src >> 4)) set_threshold(kth, -INFINITY, thr[g][r], thr_row[g][r]);
             }
         }
     }
@@ -103,11 +102,14 @@ __device__ __forceinline__ void flat_scan_mfma_body(const MfmaScanArgs& a) {
     __syncthreads();
 
     float thr[NG][4];
+    uint32_t thr_row[NG][4];
 #pragma unroll
     for (int g = 0; g < NG; ++g)
 #pragma unroll
-        for (int r = 0; r < 4; ++r)  // padded query slots never pass the gate
+        for (int r = 0; r < 4; ++r) {  // padded query slots never pass the gate
             thr[g][r] = (g * 16 + 4 * (lane >> 4) + r) < a.nq ? -INFINITY : INFINITY;
+            thr_row[g][r] = 0u;
+        }
 
     const int64_t ntiles = (a.n + 15) / 16;
     const int64_t nwaves_total = (int64_t)gridDim.x * kScanWaves;
@@ -137,7 +139,7 @@ __device__ __forceinline__ void flat_scan_mfma_body(const MfmaScanArgs& a) {
                 }
             }
         }
-        mfma_tile_select<NG>(acc, thr, rvalid, (uint32_t)(tile * 16 + (lane & 15)), a.nq, k, mylists, lane);
+        mfma_tile_select<NG>(acc, thr, thr_row, rvalid, (uint32_t)(tile * 16 + (lane & 15)), a.nq, k, mylists, lane);
     }
 
     __syncthreads();
@@ -203,10 +205,14 @@ __device__ __forceinline__ void flat_scan_mfma2_body(const MfmaScanArgs& a) {
             qa[g][kb] = qi < a.nq ? *reinterpret_cast<const f32x4m*>(qp + 16 * kb) : f32x4m{0, 0, 0, 0};
     }
     float thr[NG][4];
+    uint32_t thr_row[NG][4];
 #pragma unroll
     for (int g = 0; g < NG; ++g)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) thr[g][r] = (g * 16 + 4 * (lane >> 4) + r) < a.nq ? -INFINITY : INFINITY;
+        for (int r = 0; r < 4; ++r) {
+            thr[g][r] = (g * 16 + 4 * (lane >> 4) + r) < a.nq ? -INFINITY : INFINITY;
+            thr_row[g][r] = 0u;
+        }
     // METRIC 1 (squared L2 by |q|^2 + |x|^2 - 2 q.x; the lists keep -distance as everywhere): |q|^2 of the four queries
     // whose scores this lane's accumulator registers hold — query g 16 + 4 (lane >> 4) + r
     float qn[NG][4];
@@ -324,7 +330,7 @@ __device__ __forceinline__ void flat_scan_mfma2_body(const MfmaScanArgs& a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[g][r] = (2.f * acc[g][r] - xs) - qn[g][r];  // -(|q|^2 + |x|^2 - 2 q.x)
         }
-        mfma_tile_select<NG>(acc, thr, tile * 16 + fr <= last && ((mw >> ((int)(tile & 1) * 16 + fr)) & 1u), (uint32_t)(tile * 16 + fr), a.nq, k,
+        mfma_tile_select<NG>(acc, thr, thr_row, tile * 16 + fr <= last && ((mw >> ((int)(tile & 1) * 16 + fr)) & 1u), (uint32_t)(tile * 16 + fr), a.nq, k,
                              mylists, lane);
         tile = next_tile;
     }
@@ -389,6 +395,7 @@ __device__ __forceinline__ void flat_scan_gemm_body(const GemmScanArgs& a) {
 
     // thresholds of this lane's two queries (query = n0 + wn*64 + j*32 + fr)
     float thr[2];
+    uint32_t thr_row[2] = {0u, 0u};
 #pragma unroll
     for (int j = 0; j < 2; ++j) thr[j] = (n0 + wn * 64 + j * 32 + fr) < a.nq ? -INFINITY : INFINITY;
 
@@ -483,7 +490,7 @@ __device__ __forceinline__ void flat_scan_gemm_body(const GemmScanArgs& a) {
                 for (int r = 0; r < 16; ++r) {
                     const int64_t row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
                     const float s = acc[i][j][r];
-                    uint64_t mask = __ballot(row < a.n && s >= thr[j]);
+                    uint64_t mask = __ballot(row < a.n && beats_key(s, (uint32_t)row, thr[j], thr_row[j]));
                     while (mask) {
                         const int src = __ffsll((long long)mask) - 1;
                         mask &= mask - 1;
@@ -491,8 +498,7 @@ __device__ __forceinline__ void flat_scan_gemm_body(const GemmScanArgs& a) {
                         const float sv = __uint_as_float(__builtin_amdgcn_readlane((int)__float_as_uint(s), src));
                         const uint32_t rv = (uint32_t)(m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (src >> 5));
                         const uint64_t kth = lds_list_insert(mylists + (size_t)sq * k, k, make_key(sv, rv), lane);
-                        const float t = kth ? key_score(kth) : -INFINITY;
-                        if (ql == sq) thr[j] = t;  // both lane halves of that query
+                        if (ql == sq) set_threshold(kth, -INFINITY, thr[j], thr_row[j]);  // both lane halves of that query
                     }
                 }
             }

@@ -118,6 +118,7 @@ __global__ __launch_bounds__(kSplitThreads) void flat_scan_split_kernel(SplitSca
     uint64_t* mylists = lists + (size_t)wave * 64 * kSplitKeep;
     for (int e = lane; e < 64 * kSplitKeep; e += 64) mylists[e] = 0ull;
     float thr[2], floor0[2];
+    uint32_t thr_row[2] = {0u, 0u};  // row of the k-th key while thr is its score (beats_key), else 0
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int qq = n0 + wq * 64 + j * 32 + fr;
@@ -216,7 +217,7 @@ __global__ __launch_bounds__(kSplitThreads) void flat_scan_split_kernel(SplitSca
                 for (int r = 0; r < 16; ++r) {
                     const int rl = wr * 32 + (r & 3) + 8 * (r >> 2);
                     const float s = acc[j][r];
-                    uint64_t mask = __ballot(m0 + rl + 4 * fk <= last && s >= thr[j]);
+                    uint64_t mask = __ballot(m0 + rl + 4 * fk <= last && beats_key(s, (uint32_t)(m0 + rl + 4 * fk), thr[j], thr_row[j]));
                     if (DBG & 128) {
                         if (mask == 0x123456789ull) thr[j] = 1.f;
                         mask = 0;
@@ -233,7 +234,7 @@ __global__ __launch_bounds__(kSplitThreads) void flat_scan_split_kernel(SplitSca
                             kth = make_key(sv * 0.5f, rv);  // ablation: no LDS round trips
                         else
                             kth = lds_list_insert(mylists + (size_t)sq * kSplitKeep, kSplitKeep, make_key(sv, rv), lane);
-                        if (ql == sq) thr[j] = kth ? fmaxf(key_score(kth), floor0[j]) : floor0[j];  // both lane halves
+                        if (ql == sq) set_threshold(kth, floor0[j], thr[j], thr_row[j]);  // both lane halves
                     }
                 }
             }
@@ -490,6 +491,7 @@ __global__ __launch_bounds__(kScanThreads) void flat_scan_split32_kernel(Split32
     }
     float floor0 = fr < a.nq ? (a.thr0 ? a.thr0[fr] : -INFINITY) : INFINITY;
     float thr = floor0;
+    uint32_t thr_row = 0u;
     // consume every load here: the hand-placed vmcnt waits below are invisible to hipcc (see the kernel above)
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) asm volatile("" : "+v"(qh[kb]), "+v"(ql[kb]));
@@ -578,7 +580,7 @@ __global__ __launch_bounds__(kScanThreads) void flat_scan_split32_kernel(Split32
                 for (int r = 0; r < 16; ++r) {
                     const int rl = (r & 3) + 8 * (r >> 2);
                     const float s = acc[r];
-                    uint64_t mask = __ballot(m0 + rl + 4 * fk <= last && s >= thr);
+                    uint64_t mask = __ballot(m0 + rl + 4 * fk <= last && beats_key(s, (uint32_t)(m0 + rl + 4 * fk), thr, thr_row));
                     while (mask) {
                         const int src = __ffsll((long long)mask) - 1;
                         mask &= mask - 1;
@@ -587,7 +589,7 @@ __global__ __launch_bounds__(kScanThreads) void flat_scan_split32_kernel(Split32
                         const uint32_t rv = (uint32_t)(m0 + rl + 4 * (src >> 5));
                         const uint64_t kth = lds_list_insert(mylists + (size_t)sq * kSplitKeep, kSplitKeep,
                                                              make_key(sv, rv), lane);
-                        if (fr == sq) thr = kth ? fmaxf(key_score(kth), floor0) : floor0;  // both lane halves
+                        if (fr == sq) set_threshold(kth, floor0, thr, thr_row);  // both lane halves
                     }
                 }
             }

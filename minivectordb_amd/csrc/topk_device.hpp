@@ -87,6 +87,23 @@ __device__ __forceinline__ bool l2_certified(float rk, float u, float eps_q, flo
     return rk * 1.00002f < lower - 1e-6f * (qn * qn + fabsf(n2lo) + 2.0f * fabsf(u));
 }
 
+// The gate in front of the list inserts of the multi-query passes.  A lane keeps, per query, the SCORE its list's k-th key holds
+// (or an admission floor) and the ROW of that key: a candidate goes to the insert only if its (score, row) key beats it —
+// a higher score, or the same score and a lower row.  Until round 5 the gate compared scores alone (`s >= thr`) and left the
+// tie to the insert: on a corpus of duplicates every row tied with the k-th score and paid a wave-cooperative insert attempt
+// that the key order then refused — 64 queries over 1M identical rows took 21.8 ms instead of 0.33
+// (benchmarks/ties_probe.py).  A floor (no list key behind the score) carries row 0: nothing ties its way past a floor —
+// floors come from rows of earlier phases, i.e. lower rows.
+__device__ __forceinline__ bool beats_key(float s, uint32_t row, float thr, uint32_t thr_row) {
+    return s > thr || (s == thr && row < thr_row);
+}
+__device__ __forceinline__ void set_threshold(uint64_t kth, float floor0, float& thr, uint32_t& thr_row) {
+    const float ks = kth ? key_score(kth) : -INFINITY;
+    const bool from_list = kth != 0ull && ks >= floor0;
+    thr = from_list ? ks : floor0;
+    thr_row = from_list ? key_row(kth) : 0u;
+}
+
 // wave-cooperative sorted insert into an LDS list; returns the list's new k-th key
 __device__ __forceinline__ uint64_t lds_list_insert(uint64_t* list, int k, uint64_t key, int lane) {
     const uint64_t cur = lane < k ? list[lane] : 0ull;
