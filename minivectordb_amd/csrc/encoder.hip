@@ -2690,6 +2690,32 @@ void launch_ln(const float* y, const int* seq_start, int B, const float* g, cons
 }
 
 
+// Walking launches are persistent grids whose workgroups spin on each other: two of them resident at once — two encoders
+// of one process on two streams — can each hold CUs the other's missing workgroups need, and neither finishes.  One walking
+// launch at a time per DEVICE: an event behind every launch, waited for by the next (whatever encoder or stream it comes
+// from).  Not while the caller captures the stream (a captured launch cannot wait for an outside event: callers that capture
+// walking launches of several encoders replay them on one stream).  Two PROCESSES walking on one GPU are not ordered.
+std::mutex g_walk_mu;
+std::map<int, hipEvent_t> g_walk_done;
+
+int walk_serialize_begin(int device, hipStream_t s) {
+    std::lock_guard<std::mutex> lk(g_walk_mu);
+    auto it = g_walk_done.find(device);
+    if (it == g_walk_done.end()) {
+        hipEvent_t ev = nullptr;
+        MVDB_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        g_walk_done[device] = ev;
+        return 0;
+    }
+    MVDB_HIP(hipStreamWaitEvent(s, it->second, 0));
+    return 0;
+}
+int walk_serialize_end(int device, hipStream_t s) {
+    std::lock_guard<std::mutex> lk(g_walk_mu);
+    MVDB_HIP(hipEventRecord(g_walk_done[device], s));
+    return 0;
+}
+
 // ---- the layer-walking launch for small batches (encoder_walk.hpp) ------------------------------------------------------
 // Eligible: at most walk::kTmax token slots, widths the column units tile (H, F multiples of 16, H <= 1024).
 bool walk_eligible(const mvdb_encoder* e, int B, int S) {
@@ -3015,7 +3041,9 @@ int forward_core(mvdb_encoder* e, const int32_t* ids, const int32_t* mask, int B
         const bool captured = s && hipStreamIsCapturing(s, &cap0) == hipSuccess && cap0 != hipStreamCaptureStatusNone;
         const int pslot0 = captured ? -1 : prof_begin("encoder", s);
         MVDB_HIP(hipMemsetAsync(e->overflow_flag, 0, sizeof(unsigned int), s));  // exact fp32: nothing to overflow into
+        if (!captured) MVDB_TRY(walk_serialize_begin(e->device, s));
         const int rc0 = launch_walk(e, ids, mask, B, S, out, hidden, s);
+        if (!captured && !rc0) MVDB_TRY(walk_serialize_end(e->device, s));
         prof_end(pslot0, s);
         return rc0;
     }

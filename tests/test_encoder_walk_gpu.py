@@ -166,3 +166,31 @@ def test_walk_launches_from_two_streams_are_ordered(gpu):
     for b, o in outs:
         np.testing.assert_allclose(o.cpu().numpy()[0], e64[b], atol=2e-5, rtol=0)
     enc.close()
+
+
+def test_walk_launches_of_two_encoders_are_ordered_on_the_device(gpu):
+    """Two encoders of one process, two streams: their walking launches are persistent grids that spin on their own
+    workgroups — resident together they could each hold CUs the other's missing workgroups need.  The library orders every
+    walking launch of a device behind the one before (the large shape asks for every CU: two of those cannot coexist)."""
+    import torch
+    dev = torch.device("cuda", 0)
+    cfgs = [E.make_config("xlmr-large-dims"), E.make_config("e5-small-dims")]
+    ws = [E.make_weights(cfgs[0], 5), E.make_weights(cfgs[1], 6)]
+    encs = [_model(cfgs[0], ws[0]), _model(cfgs[1], ws[1])]
+    streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+    data, want = [], []
+    for cfg, w in zip(cfgs, ws):
+        ids, mask = E.make_inputs(cfg, 1, 24, 17)
+        data.append((torch.from_numpy(ids).to(dev), torch.from_numpy(mask).to(dev)))
+        want.append(E.numpy_forward(cfg, w, ids, mask)[1])
+    torch.cuda.synchronize()
+    outs = []
+    for rep in range(30):
+        for i in (0, 1):
+            with torch.cuda.stream(streams[i]):
+                outs.append((i, encs[i].forward_device(*data[i])[0]))
+    torch.cuda.synchronize()
+    for i, o in outs:
+        np.testing.assert_allclose(o.cpu().numpy(), want[i], atol=2e-5, rtol=0)
+    for e in encs:
+        e.close()
