@@ -598,6 +598,8 @@ def certified_passes_on_unfriendly_data(native, dev, k, n=10_000_000, d=512, nq=
         rec["single_query_over_fp16_shadow_opt_in"] = timed(1, 32, 2)
         same1 = bool(np.array_equal(I[:32].cpu().numpy(), exact_ids))
         idx.set_option("shadow_single_query", 0)
+        # (raw equality with the exact single-query scan; on the clustered corpora rows within 2e-6 of each other may swap between
+        #  two exact kernels' summation orders — tests/test_fullsize_gpu.py adjudicates every such difference in float64)
         rec["ids_equal_exact_scan_first_32_queries"] = {"256_per_call": same256, "single_query_over_fp16_shadow": same1}
         out["corpora"][name] = rec
         idx.close()
@@ -851,6 +853,8 @@ def main():
                 "frac": round(achieved / (HBM_PEAK_GBS * world), 4),
                 "traffic": traffic["bytes"],
                 "traffic_source": traffic["source"],
+                "traffic_note": ("HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (FETCH_SIZE x 2 per "
+                                 "the guide + WRITE_SIZE) — not a counter of this run: counters cannot be collected inside the timed process"),
                 "launched": launched,
                 "kernel": {"ip_scan": "flat_scan_kernel", "ip_scan_mfma": "flat_scan_mfma2_kernel",
                            "ip_scan_split": "flat_scan_split_kernel",
