@@ -59,7 +59,7 @@ int mvdb_device_count(int* count);
 int mvdb_index_create(int d, int metric, int device, mvdb_index** out);
 int mvdb_index_free(mvdb_index* idx);
 
-/* The MVDB_* tuning / A-B hooks of the search path are read from the environment ONCE, by
+/* The MVDB_* tuning / A-B hooks of the search path (docs/DESIGN_NOTES.md section 7) are read from the environment ONCE, by
  * mvdb_index_create; the search path itself never calls getenv.  This re-reads them for an existing index (A/B runs and tests
  * that flip a hook inside one process).  No reference counterpart. */
 int mvdb_index_reload_env(mvdb_index* idx);
@@ -294,13 +294,13 @@ int64_t mvdb_split_rerun_count(void);
 
 /* The certificate's error bound per unit |q| * max|x| at dimension d: operand truncation of the bf16 split,
  * worst-case fp32 accumulation of the 3 d products in any order, the fp32 re-score, |q| and the comparison's own
- * rounding (tests/test_split_bound.py restates and checks the formula).  Diagnostic. */
+ * rounding (docs/DESIGN_NOTES.md section 4.3b; tests/test_split_bound.py restates and checks the formula).  Diagnostic. */
 double mvdb_split_eps(int d);
 
 /* Same for the fp16 single-product nomination pass that serves chunks of >= 33 queries where it has a kernel
  * (half_scan.hip: both operands rounded to fp16, d products accumulated in fp32, 64 nominees per query re-scored
  * in fp32): rounding of both operands, elements below fp16's normal range, worst-case fp32 accumulation, the fp32
- * re-score, |q| and the comparison (tests/test_split_bound.py).  Diagnostic.
+ * re-score, |q| and the comparison (docs/DESIGN_NOTES.md section 4.3d; tests/test_split_bound.py).  Diagnostic.
  * mvdb_half_max_queries: queries per corpus pass of that pass at dimension d, 0 where it has no kernel. */
 double mvdb_half_eps(int d);
 int mvdb_half_max_queries(int d);

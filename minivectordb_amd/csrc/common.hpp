@@ -59,7 +59,7 @@ void prof_symbol(const char* label, const char* fmt, ...);
 
 // Every MVDB_* tuning / A-B hook of the SEARCH path.  The environment is read ONCE per index — at mvdb_index_create, and
 // again only when the caller asks (mvdb_index_reload_env: A/B runs and tests that flip a hook inside one process) — never on
-// the search path.  Defaults are the measured best.
+// the search path.  Defaults are the measured best (docs/DESIGN_NOTES.md section 7).
 struct Knobs {
     int scan_blocks_per_cu = 0;      // MVDB_SCAN_BLOCKS_PER_CU (0: the measured default per shape)
     int mfma_blocks_per_cu = 0;      // MVDB_MFMA_BLOCKS_PER_CU (0: 4 for the fragment-load kernel, 2 for the staged ones)

@@ -735,7 +735,7 @@ unsigned long long* rerun_counter(int device) {
 }
 
 // Worst-case bound, per unit |q| * max|x|, on everything that separates the quantities the certificate compares
-// from the real-number scores t(x) = q.x (derivation: DESIGN.md section 4.3b; checked in tests/test_split_bound.py):
+// from the real-number scores t(x) = q.x (derivation: docs/DESIGN_NOTES.md section 4.3b; checked in tests/test_split_bound.py):
 //   (1) the products the split drops:  q x - (qh xh + qh xl + ql xh) = rq (x - rx) + ql xl + rx q  with
 //       |rx| <= 2^-16 |x|, |xl| <= 2^-8 (1 + 2^-8) |x| (bf16 = 8 significand bits, RNE) and the same for q;
 //       summed with Cauchy-Schwarz:  <= 2^-16 (3 + 2^-7 + 2^-15) |q| |x|;
