@@ -78,4 +78,19 @@ clk = (t[:, NS - 3] - t[:, NS - 4]) / np.maximum(1, (t[:, NS - 1] - t[:, NS - 2]
 out["shader_clock_mhz"] = round(float(np.median(clk)), 0)
 per_layer = [np.nanmax(us[:, (l * 6 + 4) * 3 + 2]) for l in range(L)]
 out["layer_us"] = round(float(np.median(np.diff(per_layer))), 2) if L > 1 else None
+if os.environ.get("WALK_TRACE_PER_WG"):
+    # per workgroup, layer 5: when each phase released it, relative to the last arrival of the phase before
+    layer = 5
+    per = {}
+    seq = [(l, k) for (l, k) in order if l == layer]
+    for (l1, k1) in seq:
+        idx = order.index((l1, k1))
+        if idx == 0:
+            continue
+        l0, k0 = order[idx - 1]
+        last_arr = np.nanmax(us[:, (l0 * 6 + k0) * 3 + 2])
+        rel = us[:, (l1 * 6 + k1) * 3 + 1] - last_arr
+        wait0 = us[:, (l1 * 6 + k1) * 3 + 0] - last_arr      # when the workgroup began to wait (after issuing its weight loads)
+        per[names[k1]] = [[int(w), round(float(wait0[w]), 2), round(float(rel[w]), 2)] for w in range(n) if not np.isnan(rel[w])]
+    out["per_wg_layer5 [wg, began waiting, released] us after the previous phase's last arrival"] = per
 print(json.dumps(out))

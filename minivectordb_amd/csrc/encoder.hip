@@ -2269,6 +2269,7 @@ struct mvdb_encoder {
     hipStream_t stream = nullptr;
     // small batches (<= walk::kTmax token slots): the layer-walking persistent launch (encoder_walk.hpp)
     int opt_walk = 1;                       // MVDB_ENCODER_WALK as read when the encoder was created (0: the per-op kernels)
+    int opt_walk_roles = 1;                 // MVDB_WALK_ROLES (0: every phase based at workgroup 0, the form before role placement)
     walk::LayerPtrs* walk_layers = nullptr; // device copy of the per-layer weight pointers
     float *walk_x = nullptr, *walk_x1 = nullptr, *walk_qkv = nullptr, *walk_pl = nullptr, *walk_h = nullptr;
     unsigned int* walk_bar = nullptr;
@@ -2812,7 +2813,22 @@ int launch_walk(mvdb_encoder* e, const int32_t* ids, const int32_t* mask, int B,
     if (hc == 8) grid = cus;  // wide shapes: FFN1 has F / 16 column units, FFN2 (H / 16) x 4 (encoder_walk.hpp): every CU
     if (e->walk_grid_env > 0) grid = std::min(cus, std::max(e->walk_grid_env, e->walk_np3));
     e->walk_grid = grid;
-    a.nsplit = std::max(1, std::min(grid / std::max(1, B * c.heads * rh), std::max(1, ntiles / walk::kWaves)));
+    a.nsplit = std::max(1, std::min(std::max(grid, 96) / std::max(1, B * c.heads * rh), std::max(1, ntiles / walk::kWaves)));
+    // Role placement (encoder_walk.hpp "ROLES"): rows | QKV | attention side by side, the FFN over the QKV / attention workgroups
+    // (not adjacent phases) — every producer / consumer pair of adjacent phases on disjoint workgroups where the CUs allow:
+    // e5-small shape, <= 32 slots: 32 + 72 + 36 = 140 workgroups; 64 slots: 64 + 144 + 72 wraps at 256 (24 attention
+    // units land on row-owning workgroups).  Wide shapes use every CU in every GEMM phase: no separation to be had.
+    a.off_rows = a.off_qkv = a.off_attn = a.off_ffn = 0;
+    // (A/B on the host clock, `profiles/r05_walk_roles_ab.txt`: 5 - 7 us per forward at <= 32 slots; at 64 slots the grid would
+    //  grow to every CU and the forward LOSES 15 us: roles are placed up to 32 slots only)
+    if (hc != 8 && rh == 1 && !e->walk_grid_env && e->opt_walk_roles) {
+        const int r = std::min(slots, cus), q = 3 * c.hidden / 16 * rh, at = B * c.heads * a.nsplit * rh, f = e->walk_np3 * rh;
+        grid = std::min(cus, std::max({16, r + q + at, r + f}));
+        a.off_qkv = r % grid;
+        a.off_attn = (r + q) % grid;
+        a.off_ffn = r % grid;
+        e->walk_grid = grid;
+    }
     a.trace = nullptr;
 #ifdef MVDB_X3_ABLATE
     if (!e->walk_trace) MVDB_TRY(dev_alloc(&e->walk_trace, (int64_t)cus * walk::kTraceSlots));
@@ -3168,6 +3184,8 @@ int mvdb_encoder_create(const mvdb_encoder_cfg* cfg, const void* const* w, int d
         e->opt_img_attn = !(v && *v == '0');
         v = getenv("MVDB_ENCODER_WALK");
         e->opt_walk = !(v && *v == '0');
+        v = getenv("MVDB_WALK_ROLES");
+        e->opt_walk_roles = !(v && *v == '0');
     }
     e->word = (const float*)w[0];
     e->pos = (const float*)w[1];

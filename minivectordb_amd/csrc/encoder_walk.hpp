@@ -66,6 +66,7 @@ struct Args {
     float* hidden;            // NULL or [B, S, H]
     int np3;                  // workgroups (= planes) of the FFN phase
     int nsplit;               // column splits of the out-projection per (sentence, head)
+    int off_rows, off_qkv, off_attn, off_ffn;  // first workgroup of the row phases (embeddings, sum + LN, pooling) / QKV / attention / FFN
     unsigned long long* trace;  // NULL, or [G][kTraceSlots] s_memrealtime stamps (ablation build: mvdb_debug_walk_trace)
 };
 constexpr int kTraceSlots = 512;
@@ -448,6 +449,12 @@ __global__ __launch_bounds__(kThreads) void encoder_walk_kernel(const Args a) {
     }
     const rsrc_t Xr = make_rsrc(a.X), X1r = make_rsrc(a.X1), Qr = make_rsrc(a.QKV), PLr = make_rsrc(a.PL);
     const int HQ = H >> 2;
+    // ROLES.  A workgroup's index inside a phase is its distance from the phase's base (mod G): the host places the bases so
+    // that, where the grid allows, no workgroup produces in one phase AND consumes in the next.  Such a workgroup reaches its
+    // wait late (it has to drain its own stores first, then issues the next phase's weight loads, then polls): with every
+    // phase based at workgroup 0 the row-owning workgroups 0 .. T-1 were released 1.4 - 2.2 us after a phase's last arrival
+    // where everybody else was at 0.8 - 0.9 (profiles/r05_walk_roles_before.json) — and a phase ends with its last workgroup.
+    const int wr = (wg - a.off_rows + G) % G, wq = (wg - a.off_qkv + G) % G, wa_ = (wg - a.off_attn + G) % G, wf = (wg - a.off_ffn + G) % G;
     // producers per phase (what the consumers of a phase wait for, per layer)
     const unsigned int prodRow = (unsigned int)min(T, G);                      // embeddings, sum + LN
     const int ntiles = H >> 4;
@@ -471,11 +478,11 @@ __global__ __launch_bounds__(kThreads) void encoder_walk_kernel(const Args a) {
 
     if (T > 0) {
         // ---- embeddings + LayerNorm -> X (one workgroup per row) ---------------------------------------------------------------
-        if (wg < (int)prodRow) {
+        if (wr < (int)prodRow) {
             const bool active = tid < HQ;
             const int tq = min(tid, HQ - 1);
             const f32x4 g4 = *reinterpret_cast<const f32x4*>(a.embg + 4 * tq), b4 = *reinterpret_cast<const f32x4*>(a.embb + 4 * tq);
-            for (int p = wg; p < T; p += G) {
+            for (int p = wr; p < T; p += G) {
                 const f32x4 w4 = *reinterpret_cast<const f32x4*>(a.word + (int64_t)s_tok_id[p] * H + 4 * tq);
                 const f32x4 t4 = *reinterpret_cast<const f32x4*>(a.type + 4 * tq);
                 const f32x4 p4 = *reinterpret_cast<const f32x4*>(a.pos + (int64_t)s_tok_pos[p] * H + 4 * tq);
@@ -496,11 +503,11 @@ __global__ __launch_bounds__(kThreads) void encoder_walk_kernel(const Args a) {
 
             {
                 // ---- QKV: column units over 3H -> QKV[T, 3H] ----------------------------------------------------------------------
-                if (wg < (int)prodQkv) {
+                if (wq < (int)prodQkv) {
                     f32x4* red = reinterpret_cast<f32x4*>(work);
                     constexpr int CB = HC > 4 ? (MT > 1 ? 4 : 8) : HC;  // chunk batches: HC x MT operand fragments must fit the registers
                     bool first = true;
-                    for (int uu = wg; uu < ncol * RH; uu += G) {
+                    for (int uu = wq; uu < ncol * RH; uu += G) {
                         const int hf = uu / ncol, u = uu - hf * ncol, row0 = hf * MT * 16;  // columns u, row half hf
                         f32x4 acc[MT];
 #pragma unroll
@@ -542,14 +549,14 @@ __global__ __launch_bounds__(kThreads) void encoder_walk_kernel(const Args a) {
                 }
 
                 // ---- attention per (sentence, head, column split) + out-projection partial -> plane[head] --------------------------------
-                if (wg < (int)prodAttn) {
+                if (wa_ < (int)prodAttn) {
                     constexpr int VS = AT * 16 + 4;          // row stride of V^T
                     float* Qs = work;                       // [AT * 16][hd + 4]  queries, scaled
                     float* Ks = Qs + AT * 16 * hd4;          // [AT * 16][hd + 4]
                     float* Vt = Ks + AT * 16 * hd4;          // [hd][AT * 16 + 4]  V transposed
                     float* Cs = Vt + hd * VS;               // [AT * 16][hd + 4]  context of this head
                     bool first = true;
-                    for (int u = wg; u < attn_units; u += G) {
+                    for (int u = wa_; u < attn_units; u += G) {
                         const int qh = u % RH, u1 = u / RH;                 // query tiles [qh MT, qh MT + MT) of the sentence
                         const int ns = u1 % a.nsplit, bh = u1 / a.nsplit;
                         const int h = bh % a.heads, b = bh / a.heads;
@@ -602,12 +609,12 @@ __global__ __launch_bounds__(kThreads) void encoder_walk_kernel(const Args a) {
             }
 
             // ---- x1 = LN(sum of head planes + bo + x) -> X1 ---------------------------------------------------------------------
-            if (wg < (int)prodRow) {
+            if (wr < (int)prodRow) {
                 const LnWeights lw = ln_load_w(L.bo, L.ln1g, L.ln1b, H, tid);
                 stamp(trace, layer, 2, 0);
                 phase_wait(a.bar, kCtrAttn, lay1, prodAttn);
                 stamp(trace, layer, 2, 1);
-                phase_reduce_ln(a, PLr, a.heads, lw, Xr, X1r, T, reinterpret_cast<f32x4*>(work), red8, wg, G, tid, lane, wave, trace, layer);
+                phase_reduce_ln(a, PLr, a.heads, lw, Xr, X1r, T, reinterpret_cast<f32x4*>(work), red8, wr, G, tid, lane, wave, trace, layer);
                 stamp(trace, layer, 2, 2);
                 phase_arrive(a.bar, kCtrLn1);
             }
@@ -617,9 +624,9 @@ __global__ __launch_bounds__(kThreads) void encoder_walk_kernel(const Args a) {
                 constexpr int CB = MT > 1 ? 4 : 8;
                 f32x4* red = reinterpret_cast<f32x4*>(work);
                 // ---- FFN1: column units over F -> Hb[T, F] = GELU(x1 W1^T + b1) --------------------------------------------------
-                if (wg < (int)prodFfn1) {
+                if (wf < (int)prodFfn1) {
                     bool first = true;
-                    for (int uu = wg; uu < nf * RH; uu += G) {
+                    for (int uu = wf; uu < nf * RH; uu += G) {
                         const int hf = uu / nf, j = uu - hf * nf, row0 = hf * MT * 16;
                         const f32x4 b1 = *reinterpret_cast<const f32x4*>(L.b1 + 16 * j + 4 * g);
                         f32x4 w0[CB];
@@ -649,9 +656,9 @@ __global__ __launch_bounds__(kThreads) void encoder_walk_kernel(const Args a) {
                     phase_arrive(a.bar, kCtrFfn1);
                 }
                 // ---- FFN2: column units over H, K = F split kKP ways -> plane[kp][T, H] --------------------------------------------
-                if (wg < (int)prodFfn) {
+                if (wf < (int)prodFfn) {
                     bool first = true;
-                    for (int uu = wg; uu < ntiles * kKP * RH; uu += G) {
+                    for (int uu = wf; uu < ntiles * kKP * RH; uu += G) {
                         const int hf = uu / (ntiles * kKP), rem = uu - hf * ntiles * kKP;
                         const int kp = rem / ntiles, nt = rem - kp * ntiles, row0 = hf * MT * 16;
                         const int k0 = kp * nchp * 16, nch = max(1, min(nchp, nf - kp * nchp));
@@ -682,11 +689,11 @@ __global__ __launch_bounds__(kThreads) void encoder_walk_kernel(const Args a) {
                 }
             } else
             // ---- FFN: workgroup wg < np3 owns the 16-wide slices wg, wg + np3, ... of F -> plane[wg] ---------------------------------
-            if (wg < (int)prodFfn) {
+            if (wf < (int)prodFfn) {
                 f32x4* red = reinterpret_cast<f32x4*>(work);
                 float* hbuf = work + kWaves * MT * 64 * 4;  // [MT * 16][20]: GELU(x1 W1_slice^T + b1)
                 bool first = true;
-              for (int uu = wg; uu < a.np3 * RH; uu += G) {   // units (plane, row group): more than one per workgroup above 64 tokens
+              for (int uu = wf; uu < a.np3 * RH; uu += G) {   // units (plane, row group): more than one per workgroup above 64 tokens
                 const int hf = uu / a.np3, pl = uu - hf * a.np3, row0 = hf * MT * 16;  // plane (= first slice) pl, row group hf
                 f32x4 acc2[HC][MT];
 #pragma unroll
@@ -752,12 +759,12 @@ __global__ __launch_bounds__(kThreads) void encoder_walk_kernel(const Args a) {
             }
 
             // ---- x = LN(sum of FFN planes + b2 + x1) -> X -----------------------------------------------------------------------
-            if (wg < (int)prodRow) {
+            if (wr < (int)prodRow) {
                 const LnWeights lw = ln_load_w(L.b2, L.ln2g, L.ln2b, H, tid);
                 stamp(trace, layer, 4, 0);
                 phase_wait(a.bar, kCtrFfn, lay1, prodFfn);
                 stamp(trace, layer, 4, 1);
-                phase_reduce_ln(a, PLr, ffn_planes, lw, X1r, Xr, T, reinterpret_cast<f32x4*>(work), red8, wg, G, tid, lane, wave);
+                phase_reduce_ln(a, PLr, ffn_planes, lw, X1r, Xr, T, reinterpret_cast<f32x4*>(work), red8, wr, G, tid, lane, wave);
                 stamp(trace, layer, 4, 2);
                 phase_arrive(a.bar, kCtrLn2);
             }
@@ -765,9 +772,9 @@ __global__ __launch_bounds__(kThreads) void encoder_walk_kernel(const Args a) {
     }
 
     // ---- pooling + L2 normalise (average_pool + F.normalize(eps = 1e-12); pooling 1: first valid token) ------------------------
-    if (wg < a.B || (a.hidden && wg < a.B * a.S)) {
+    if (wr < a.B || (a.hidden && wr < a.B * a.S)) {
         if (T > 0) phase_wait(a.bar, kCtrLn2, (unsigned int)a.nlayers, prodRow);
-        for (int b = wg; b < a.B; b += G) {
+        for (int b = wr; b < a.B; b += G) {
             const int s0 = s_seq[b], len = s_seq[b + 1] - s0;
             const int span = a.pooling == 1 ? (len > 0 ? 1 : 0) : len;
             const bool active = tid < HQ;
@@ -790,7 +797,7 @@ __global__ __launch_bounds__(kThreads) void encoder_walk_kernel(const Args a) {
             if (active) *reinterpret_cast<f32x4*>(a.out + (int64_t)b * H + 4 * tid) = e / denom;
         }
         if (a.hidden) {  // hidden[b, t, :] = x[packed(b, t), :] for valid tokens, 0 for padding
-            for (int slot = wg; slot < a.B * a.S; slot += G) {
+            for (int slot = wr; slot < a.B * a.S; slot += G) {
                 const int p = s_slot_p[slot];
                 if (tid < HQ) {
                     f32x4 v = {0.f, 0.f, 0.f, 0.f};
