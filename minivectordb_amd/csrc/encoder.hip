@@ -2270,11 +2270,13 @@ struct mvdb_encoder {
     // small batches (<= walk::kTmax token slots): the layer-walking persistent launch (encoder_walk.hpp)
     int opt_walk = 1;                       // MVDB_ENCODER_WALK as read when the encoder was created (0: the per-op kernels)
     int opt_walk_roles = 1;                 // MVDB_WALK_ROLES (0: every phase based at workgroup 0, the form before role placement)
+    int opt_walk_pinned = 1;                // MVDB_WALK_PINNED (0: the host entry stages ids / mask / out through device buffers)
     walk::LayerPtrs* walk_layers = nullptr; // device copy of the per-layer weight pointers
     float *walk_x = nullptr, *walk_x1 = nullptr, *walk_qkv = nullptr, *walk_pl = nullptr, *walk_h = nullptr;
     unsigned int* walk_bar = nullptr;
     unsigned long long* walk_trace = nullptr;  // ablation build only
     unsigned int* overflow_flag = nullptr;     // device word: 1 after a forward whose pooled rows were not all finite
+    PinnedBuf walk_pin;                        // host entry of the walking launch: [ids | mask | out] in ONE host-mapped buffer
     hipEvent_t walk_done = nullptr;            // recorded behind every forward of the device entry: the next one — on whatever
                                                // stream — waits for it (forwards share the staging buffers, the workspace and the
                                                // walking launch's phase counters: two resident walking grids would never finish)
@@ -2697,23 +2699,26 @@ void launch_ln(const float* y, const int* seq_start, int B, const float* g, cons
 // from).  Not while the caller captures the stream (a captured launch cannot wait for an outside event: callers that capture
 // walking launches of several encoders replay them on one stream).  Two PROCESSES walking on one GPU are not ordered.
 std::mutex g_walk_mu;
-std::map<int, hipEvent_t> g_walk_done;
+struct WalkOrder {
+    hipEvent_t done = nullptr;
+    hipStream_t last = nullptr;  // stream of the last walking launch: the next one on the SAME stream is ordered by the stream
+    bool any = false;
+};
+std::map<int, WalkOrder> g_walk_order;
 
 int walk_serialize_begin(int device, hipStream_t s) {
     std::lock_guard<std::mutex> lk(g_walk_mu);
-    auto it = g_walk_done.find(device);
-    if (it == g_walk_done.end()) {
-        hipEvent_t ev = nullptr;
-        MVDB_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-        g_walk_done[device] = ev;
-        return 0;
-    }
-    MVDB_HIP(hipStreamWaitEvent(s, it->second, 0));
+    WalkOrder& o = g_walk_order[device];
+    if (!o.done) MVDB_HIP(hipEventCreateWithFlags(&o.done, hipEventDisableTiming));
+    if (o.any && o.last != s) MVDB_HIP(hipStreamWaitEvent(s, o.done, 0));
     return 0;
 }
 int walk_serialize_end(int device, hipStream_t s) {
     std::lock_guard<std::mutex> lk(g_walk_mu);
-    MVDB_HIP(hipEventRecord(g_walk_done[device], s));
+    WalkOrder& o = g_walk_order[device];
+    MVDB_HIP(hipEventRecord(o.done, s));
+    o.last = s;
+    o.any = true;
     return 0;
 }
 
@@ -2794,6 +2799,7 @@ int launch_walk(mvdb_encoder* e, const int32_t* ids, const int32_t* mask, int B,
     a.PL = e->walk_pl;
     a.Hb = e->walk_h;
     a.bar = e->walk_bar;
+    a.flag = e->overflow_flag;
     a.out = out;
     a.hidden = hidden;
     a.np3 = e->walk_np3;
@@ -3062,8 +3068,7 @@ int forward_core(mvdb_encoder* e, const int32_t* ids, const int32_t* mask, int B
         hipStreamCaptureStatus cap0 = hipStreamCaptureStatusNone;
         const bool captured = s && hipStreamIsCapturing(s, &cap0) == hipSuccess && cap0 != hipStreamCaptureStatusNone;
         const int pslot0 = captured ? -1 : prof_begin("encoder", s);
-        MVDB_HIP(hipMemsetAsync(e->overflow_flag, 0, sizeof(unsigned int), s));  // exact fp32: nothing to overflow into
-        if (!captured) MVDB_TRY(walk_serialize_begin(e->device, s));
+        if (!captured) MVDB_TRY(walk_serialize_begin(e->device, s));  // (the launch clears the overflow flag itself: exact fp32)
         const int rc0 = launch_walk(e, ids, mask, B, S, out, hidden, s);
         if (!captured && !rc0) MVDB_TRY(walk_serialize_end(e->device, s));
         prof_end(pslot0, s);
@@ -3186,6 +3191,8 @@ int mvdb_encoder_create(const mvdb_encoder_cfg* cfg, const void* const* w, int d
         e->opt_walk = !(v && *v == '0');
         v = getenv("MVDB_WALK_ROLES");
         e->opt_walk_roles = !(v && *v == '0');
+        v = getenv("MVDB_WALK_PINNED");
+        e->opt_walk_pinned = !(v && *v == '0');
     }
     e->word = (const float*)w[0];
     e->pos = (const float*)w[1];
@@ -3274,6 +3281,7 @@ int mvdb_encoder_free(mvdb_encoder* e) {
         if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
         if (e->ev_join) (void)hipEventDestroy(e->ev_join);
         if (e->walk_done) (void)hipEventDestroy(e->walk_done);
+        e->walk_pin.release();
     }
     delete e;
     return 0;
@@ -3340,11 +3348,27 @@ int mvdb_encoder_forward(mvdb_encoder* e, const int32_t* ids_host, const int32_t
     DeviceGuard dg(e->device);
     const int64_t tokens = (int64_t)B * S;
     const int64_t outn = (int64_t)B * e->cfg.hidden;
-    MVDB_TRY(ensure_stage(e, tokens, outn));
     for (int64_t i = 0; i < tokens; ++i)
         if (mask_host[i] && (ids_host[i] < 0 || ids_host[i] >= e->cfg.vocab_size))
             return fail(MVDB_ERR_ARG, "token id %d at %lld outside the vocabulary [0,%d)", ids_host[i],
                         (long long)i, e->cfg.vocab_size);
+    if (walk_eligible(e, B, S) && e->opt_walk_pinned) {
+        // ONE sentence per call: the launch reads the ids and the mask from host-mapped memory and writes the embedding there —
+        // no copy engine work at all around it (two H2D copies, a memset and a D2H copy before: ~20 us of a 0.27 ms call)
+        const size_t in_bytes = 2 * (size_t)walk::kTmax * sizeof(int32_t);
+        MVDB_TRY(e->walk_pin.reserve(in_bytes + (size_t)walk::kTmax * e->cfg.hidden * sizeof(float)));
+        int32_t* pin_ids = reinterpret_cast<int32_t*>(e->walk_pin.p);
+        int32_t* pin_mask = pin_ids + walk::kTmax;
+        float* pin_out = reinterpret_cast<float*>(reinterpret_cast<char*>(e->walk_pin.p) + in_bytes);
+        memcpy(pin_ids, ids_host, tokens * sizeof(int32_t));
+        memcpy(pin_mask, mask_host, tokens * sizeof(int32_t));
+        if (e->walk_done) MVDB_HIP(hipStreamWaitEvent(e->stream, e->walk_done, 0));
+        MVDB_TRY(forward_core(e, pin_ids, pin_mask, B, S, compute, pin_out, nullptr, e->stream));
+        MVDB_HIP(hipStreamSynchronize(e->stream));
+        memcpy(out_host, pin_out, outn * sizeof(float));
+        return 0;
+    }
+    MVDB_TRY(ensure_stage(e, tokens, outn));
     if (e->walk_done) MVDB_HIP(hipStreamWaitEvent(e->stream, e->walk_done, 0));  // a device-entry forward may still be running
     MVDB_HIP(hipMemcpyAsync(e->ids_stage, ids_host, tokens * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
     MVDB_HIP(hipMemcpyAsync(e->mask_stage, mask_host, tokens * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));

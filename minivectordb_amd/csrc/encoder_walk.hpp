@@ -62,6 +62,7 @@ struct Args {
     float* PL;                // [planes, kTmax, H] partial planes
     float* Hb;                // [kTmax, F] GELU(x1 W1^T + b1) (wide shapes only: FFN as two phases)
     unsigned int* bar;        // [kCtrCount][8 replicas][32 words] arrival counters of the phases (monotonic within a launch) + exits
+    unsigned int* flag;       // the encoder's overflow word: cleared by the launch (exact fp32: nothing overflows into it)
     float* out;               // [B, H]
     float* hidden;            // NULL or [B, S, H]
     int np3;                  // workgroups (= planes) of the FFN phase
@@ -440,6 +441,7 @@ __global__ __launch_bounds__(kThreads) void encoder_walk_kernel(const Args a) {
         }
         if (lane == 0) s_seq[a.B] = n0 + __popcll(m1);  // (B = 128 sentences of one token: slot 128 is nobody's)
     }
+    if (wg == 0 && tid == 0 && a.flag) *a.flag = 0u;
     __syncthreads();
     const int T = s_seq[a.B];
     unsigned long long* trace = a.trace ? a.trace + (size_t)wg * kTraceSlots : nullptr;
