@@ -51,8 +51,8 @@ Knobs read_knobs() {
     k.split32_min_nq = env_int("MVDB_SPLIT32_MIN_NQ", 14);
     k.split32_blocks_per_cu = env_int("MVDB_SPLIT32_BLOCKS_PER_CU", 2);
     k.split_phase_growth = env_int("MVDB_SPLIT_PHASE_GROWTH", 8);
-    k.half_phase_growth = env_int("MVDB_HALF_PHASE_GROWTH", 16);
-    k.half_last_growth = env_int("MVDB_HALF_LAST_GROWTH", 6);
+    k.half_phase_growth = env_int("MVDB_HALF_PHASE_GROWTH", 0);   // 0: by the pass width (launch_half_pass)
+    k.half_last_growth = env_int("MVDB_HALF_LAST_GROWTH", 0);
     k.split_dbg = env_int("MVDB_SPLIT_DBG", 0);
     k.split_stats = env_int("MVDB_SPLIT_STATS", 0) != 0;
     k.split_one_phase = env_int("MVDB_SPLIT_ONE_PHASE", 0) != 0;
@@ -1067,8 +1067,16 @@ int launch_half_pass(const mvdb_index* idx, Workspace* ws, const float* q, int n
     // refreshed floors its lists take hundreds of serial LDS inserts per wave).  Planned backwards: the LAST phase
     // covers at most `last_growth` times the rows before it — that leaves ~16 x last_growth candidates above its
     // floor for the 64-nominee certificate —, the earlier ones up to `growth` times.
-    const int growth = std::max(2, idx->kn.half_phase_growth);
-    const int last_growth = std::max(2, idx->kn.half_last_growth);
+    // Growth 16 / 6 (three main launches at 10M rows) up to 128 queries per pass; 6 / 4 (four) at 256, where a wave's insert
+    // path stalls eight waves at the tile barrier and the rounds it takes scale with the sum of the growth factors
+    // (profiles/r05_h16_phase_sweep.txt: 256 queries +3 - 5 % at 10M rows, +1 % at 1M; 128 / 32 queries lose 0.5 - 8 % to the extra
+    // launch and merge, and keep 16 / 6).
+    // (k <= 16 only: the floor the last phase starts from is the 16th best of the rows before it, and the k-th result has to
+    //  beat it — with a quarter of the corpus before the last phase and k = 32, 16 of the 32 best fall into that quarter once
+    //  in ~500 queries and the query is refused and re-run; a sixth: once in 1e5)
+    const bool wide_pass = nqpad == 256 && k <= kHalfKeep;
+    const int growth = std::max(2, idx->kn.half_phase_growth ? idx->kn.half_phase_growth : wide_pass ? 6 : 16);
+    const int last_growth = std::max(2, idx->kn.half_last_growth ? idx->kn.half_last_growth : wide_pass ? 4 : 6);
     std::vector<int64_t> ends;
     for (int64_t b = ntiles, g = last_growth; b > seed_tiles; g = growth) {
         ends.push_back(b);
