@@ -1184,6 +1184,13 @@ __global__ __launch_bounds__(1024) void half_certify_kernel(HalfCertifyArgs a) {
         }
         // certification: needed as soon as any row was left out (u > -inf)
         const uint64_t holder = __ballot(mine && rank == a.k - 1);
+        if (lane == 0 && a.floor_out) {
+            float fl = -INFINITY;
+            // (one ulp further down: a floor admits nothing that merely TIES with it, and with |q| = 0 the margin is 0 and every
+            //  row ties with the k-th score)
+            if (holder && !a.l2) fl = nextafterf(key_score(exact[__ffsll((long long)holder) - 1]) - a.floor_margin * a.qnorm[qi], -INFINITY);
+            a.floor_out[qi] = fl == fl ? fl : -INFINITY;
+        }
         if (lane == 0 && u > -INFINITY) {
             bool ok = false;
             if (holder) {

@@ -57,6 +57,10 @@ struct HalfCertifyArgs {
                            // and d(y) = |q|^2 - 2 s(y) >= |q|^2 - 2 (U + eps |q| + eps_h) for every dropped row, whatever the rows'
                            // norms (the same inequality with n2lo = 0)
     float eps_h = 0.f;     // l2 == 2: bound on the error of the stored |x|^2 / 2 and of the subtraction, absolute
+    float* floor_out = nullptr;  // NULL, or [nq]: for a REFUSED query the k-th exact score of its nominees less floor_margin |q| — a
+                                 // lower bound of its k-th result in any fp32 summation order, the admission floor of its exact
+                                 // re-run (inner-product index only; -inf where fewer than k nominees were re-scored)
+    float floor_margin = 0.f;    // 2 d 2^-24 max|x|: the two fp32 dot products (this kernel's, the re-run's) may differ by that much
 };
 
 // queries per corpus pass of the widest instantiation for dimension d (0: no kernel for this d)

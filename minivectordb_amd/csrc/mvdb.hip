@@ -62,6 +62,7 @@ Knobs read_knobs() {
     k.disable_split_scan = env_int("MVDB_DISABLE_SPLIT_SCAN", 0) != 0;
     k.disable_split32 = env_int("MVDB_DISABLE_SPLIT32", 0) != 0;
     k.disable_half_scan = env_int("MVDB_DISABLE_HALF_SCAN", 0) != 0;
+    k.disable_rerun_floor = env_int("MVDB_DISABLE_RERUN_FLOOR", 0) != 0;
     k.disable_masked_batch = env_int("MVDB_DISABLE_MASKED_BATCH", 0) != 0;
     k.disable_l2_cert = env_int("MVDB_DISABLE_L2_CERT", 0) != 0;
     k.disable_half_shadow = env_int("MVDB_DISABLE_HALF_SHADOW", 0) != 0;
@@ -206,6 +207,7 @@ struct Workspace {
     DevBuf<float> requery;  // the failed queries, gathered, and their exact results [D | I]
     DevBuf<int64_t> relabel;
     DevBuf<int> nfail;      // number of uncertified queries of the call (device-side gate of the exact re-run)
+    DevBuf<float> qfloor;   // per query: the admission floor of its exact re-run (half_certify_kernel), behind them the compact copy
     SelectState* st = nullptr;
     PinnedBuf pin;
     std::mutex use_mu;  // stream workspaces are shared by every host thread that names the stream: one search at a time
@@ -578,7 +580,10 @@ int launch_mfma2_gated_inst(const MfmaScanArgs& a, int device, hipStream_t strea
     const int64_t want = (ntiles + kScanWaves - 1) / kScanWaves;
     const int nblocks = (int)std::max<int64_t>(1, std::min<int64_t>(want, (int64_t)device_cus(device) * nb));
     *nblocks_out = nblocks;
+    prof_symbol("ip_scan_rerun", "flat_scan_mfma2_gated_kernel<%d, %d, %d, %s>", KB, NG, SKB, a.mask ? "true" : "false");
+    int slot = prof_begin("ip_scan_rerun", stream);
     hipLaunchKernelGGL(kern, dim3(nblocks), dim3(kScanThreads), lds, stream, a, gate, gate_lo);
+    prof_end(slot, stream);
     MVDB_HIP(hipGetLastError());
     return 0;
 }
@@ -1012,7 +1017,8 @@ const _Float16* ensure_shadow(const mvdb_index* idx, hipStream_t s, float xscale
 const float* ensure_offsets(const mvdb_index* idx, hipStream_t s);
 
 int launch_half_pass(const mvdb_index* idx, Workspace* ws, const float* q, int nq, int nqpad, int k, int64_t n,
-                     int64_t label_offset, float* D, int64_t* I, int* flag, int* failed, const uint32_t* mask = nullptr) {
+                     int64_t label_offset, float* D, int64_t* I, int* flag, int* failed, const uint32_t* mask = nullptr,
+                     float* floor_out = nullptr) {
     hipStream_t stream = ws->stream;
     _Float16* qf = reinterpret_cast<_Float16*>(ws->qsplit.p);
     float* qnorm = ws->qnorm.p;
@@ -1116,6 +1122,8 @@ int launch_half_pass(const mvdb_index* idx, Workspace* ws, const float* q, int n
     c.failed = failed;
     c.l2 = l2off ? 2 : idx->metric == MVDB_METRIC_L2 ? 1 : 0;
     c.n2lo = idx->norm2_lo;
+    c.floor_out = floor_out;
+    c.floor_margin = (float)(2.0 * idx->d * std::ldexp(1.0, -24) * (double)idx->row_norm_bound * (1.0 + 1e-6));
     if (l2off) {
         // the stored |x|^2 / 2 (relative error < 2^-18, half_norms_kernel) and the fp32 subtraction a(x) - h (2^-23 of the larger)
         const double B = (double)idx->row_norm_bound;
@@ -1248,13 +1256,16 @@ int search_core(const mvdb_index* idx, Workspace* ws, const float* q_dev, int nq
             MVDB_TRY(ws->flags.reserve((size_t)std::max(nchunks, 64) + 32));  // + diagnostics counters in the last 32 slots
             MVDB_TRY(ws->cand.reserve((size_t)std::max(128, chunk) * (scan_grid_upper_bound(idx->device) + 1) * kSplitKeep));
             MVDB_TRY(ws->qfail.reserve((size_t)q0));
+            MVDB_TRY(ws->qfloor.reserve((size_t)2 * q0 + 128));  // [q0] per query | [q0 + 128] per compact slot
+            MVDB_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ws->qfloor.p), 0xff800000u, (size_t)q0, s));  // -inf: no floor
             MVDB_HIP(hipMemsetAsync(ws->flags.p, 0, (size_t)nchunks * sizeof(int), s));
             MVDB_HIP(hipMemsetAsync(ws->qfail.p, 0, (size_t)q0 * sizeof(int), s));
             for (int c = 0; c < nchunks; ++c) {
                 const int c0 = plan[c].first, take = plan[c].second;
                 if (use_half && take >= min_nq)
                     MVDB_TRY(launch_half_pass(idx, ws, qsrc + (int64_t)c0 * idx->ld, take, half_chunk_queries(idx->d, take), k, n, label_offset,
-                                              D_dev + (int64_t)c0 * k, I_dev + (int64_t)c0 * k, ws->flags.p + c, ws->qfail.p + c0, mask32));
+                                              D_dev + (int64_t)c0 * k, I_dev + (int64_t)c0 * k, ws->flags.p + c, ws->qfail.p + c0, mask32,
+                                              ws->qfloor.p + c0));
                 else
                     MVDB_TRY(launch_split_scan(idx, ws, qsrc + (int64_t)c0 * idx->ld, take, k, n, label_offset,
                                                D_dev + (int64_t)c0 * k, I_dev + (int64_t)c0 * k, ws->flags.p + c, ws->qfail.p + c0));
@@ -1301,7 +1312,7 @@ int search_core(const mvdb_index* idx, Workspace* ws, const float* q_dev, int nq
                 const int64_t rows = R + 128, gtotal = rows * (idx->ld / 4);
                 const int ggrid = (int)std::min<int64_t>((gtotal + 255) / 256, (int64_t)device_cus(idx->device) * 8);
                 hipLaunchKernelGGL(gather_failed_kernel, dim3(ggrid), dim3(256), 0, s, qc, qsrc, (const int64_t*)map,
-                                   (const int*)ws->nfail.p, rows, idx->ld);
+                                   (const int*)ws->nfail.p, rows, idx->ld, (const float*)ws->qfloor.p, ws->qfloor.p + q0);
             }
             MVDB_HIP(hipGetLastError());
             const int per_pass = mfma_gated_queries(idx);
@@ -1354,6 +1365,7 @@ int search_core(const mvdb_index* idx, Workspace* ws, const float* q_dev, int nq
                     ma.k = k;
                     ma.cand = ws->cand.p;
                     ma.mask = mask32;
+                    ma.thr0 = idx->kn.disable_rerun_floor ? nullptr : ws->qfloor.p + q0 + off;
                     int nblocks = 0;
                     MVDB_TRY(launch_mfma2_gated(KB, ma, idx->device, s, &nblocks, ws->nfail.p, off));
                     MergeArgs mg;

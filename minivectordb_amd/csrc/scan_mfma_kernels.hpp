@@ -38,6 +38,10 @@ struct MfmaScanArgs {
     int k;           // <= kMaxFusedK
     uint64_t* cand;  // [nq, gridDim.x, k]
     const uint32_t* mask = nullptr;  // NULL, or one bit per row: only rows whose bit is set are offered to the lists
+    const float* thr0 = nullptr;     // NULL, or [nq] admission floors: a row scoring below its query's floor is never offered (the
+                                     // re-run of a refused query starts from the k-th exact score of its nominees, less a rounding
+                                     // margin: without it every wave's list fills from -inf — k ln(rows per wave / k) inserts per query
+                                     // and wave, 2.5 per ROW at 1M rows x 32 queries, where the pass took 0.82 ms instead of 0.4)
 };
 
 // Offer one 16-row tile's scores to the per-wave, per-query LDS lists.  acc[g][r] of lane l is the score
@@ -45,7 +49,7 @@ struct MfmaScanArgs {
 // the exact 64-bit order is decided by the insert.  Wave-uniform control flow.
 template <int NG>
 __device__ __forceinline__ void mfma_tile_select(const f32x4m (&acc)[NG], float (&thr)[NG][4], uint32_t (&thr_row)[NG][4], bool rvalid,
-                                                 uint32_t rowid, int nq, int k, uint64_t* mylists, int lane) {
+                                                 uint32_t rowid, int nq, int k, uint64_t* mylists, int lane, const float (&floor0)[NG][4]) {
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
 #pragma unroll
@@ -60,7 +64,7 @@ __device__ __forceinline__ void mfma_tile_select(const f32x4m (&acc)[NG], float 
                 const float sv = __uint_as_float(__builtin_amdgcn_readlane((int)__float_as_uint(s), src));
                 const uint32_t rv = (uint32_t)__builtin_amdgcn_readlane((int)rowid, src);
                 const uint64_t kth = lds_list_insert(mylists + (size_t)qq * k, k, make_key(sv, rv), lane);
-                if ((lane >> 4) == (src >> 4)) set_threshold(kth, -INFINITY, thr[g][r], thr_row[g][r]);
+                if ((lane >> 4) == (src >> 4)) set_threshold(kth, floor0[g][r], thr[g][r], thr_row[g][r]);
             }
         }
     }
@@ -101,7 +105,7 @@ __device__ __forceinline__ void flat_scan_mfma_body(const MfmaScanArgs& a) {
     for (int e = lane; e < NG * 16 * k; e += 64) mylists[e] = 0ull;
     __syncthreads();
 
-    float thr[NG][4];
+    float thr[NG][4], floor0[NG][4];
     uint32_t thr_row[NG][4];
 #pragma unroll
     for (int g = 0; g < NG; ++g)
@@ -109,6 +113,7 @@ __device__ __forceinline__ void flat_scan_mfma_body(const MfmaScanArgs& a) {
         for (int r = 0; r < 4; ++r) {  // padded query slots never pass the gate
             thr[g][r] = (g * 16 + 4 * (lane >> 4) + r) < a.nq ? -INFINITY : INFINITY;
             thr_row[g][r] = 0u;
+            floor0[g][r] = -INFINITY;
         }
 
     const int64_t ntiles = (a.n + 15) / 16;
@@ -139,7 +144,7 @@ __device__ __forceinline__ void flat_scan_mfma_body(const MfmaScanArgs& a) {
                 }
             }
         }
-        mfma_tile_select<NG>(acc, thr, thr_row, rvalid, (uint32_t)(tile * 16 + (lane & 15)), a.nq, k, mylists, lane);
+        mfma_tile_select<NG>(acc, thr, thr_row, rvalid, (uint32_t)(tile * 16 + (lane & 15)), a.nq, k, mylists, lane, floor0);
     }
 
     __syncthreads();
@@ -204,13 +209,15 @@ __device__ __forceinline__ void flat_scan_mfma2_body(const MfmaScanArgs& a) {
         for (int kb = 0; kb < KB; ++kb)
             qa[g][kb] = qi < a.nq ? *reinterpret_cast<const f32x4m*>(qp + 16 * kb) : f32x4m{0, 0, 0, 0};
     }
-    float thr[NG][4];
+    float thr[NG][4], floor0[NG][4];
     uint32_t thr_row[NG][4];
 #pragma unroll
     for (int g = 0; g < NG; ++g)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            thr[g][r] = (g * 16 + 4 * (lane >> 4) + r) < a.nq ? -INFINITY : INFINITY;
+            const int qi = g * 16 + 4 * (lane >> 4) + r;
+            floor0[g][r] = qi < a.nq && a.thr0 ? a.thr0[qi] : -INFINITY;   // (a floor carries row 0: nothing ties its way past it)
+            thr[g][r] = qi < a.nq ? floor0[g][r] : INFINITY;
             thr_row[g][r] = 0u;
         }
     // METRIC 1 (squared L2 by |q|^2 + |x|^2 - 2 q.x; the lists keep -distance as everywhere): |q|^2 of the four queries
@@ -331,7 +338,7 @@ __device__ __forceinline__ void flat_scan_mfma2_body(const MfmaScanArgs& a) {
                 for (int r = 0; r < 4; ++r) acc[g][r] = (2.f * acc[g][r] - xs) - qn[g][r];  // -(|q|^2 + |x|^2 - 2 q.x)
         }
         mfma_tile_select<NG>(acc, thr, thr_row, tile * 16 + fr <= last && ((mw >> ((int)(tile & 1) * 16 + fr)) & 1u), (uint32_t)(tile * 16 + fr), a.nq, k,
-                             mylists, lane);
+                             mylists, lane, floor0);
         tile = next_tile;
     }
 

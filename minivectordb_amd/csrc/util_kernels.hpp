@@ -204,17 +204,21 @@ __global__ __launch_bounds__(64) void split_plan_kernel(const int* __restrict__ 
 // held k rows, every further row tied with the k-th score, passed the score gate and went through a wave-cooperative insert
 // attempt that the 64-bit key order then refused: 10M attempts per padded slot.  A refused 32-query chunk at 10M x 512 cost
 // 63 ms instead of the ~3.5 ms of one fp32-MFMA pass — found by benchmarks/scratch/refusal_probe.py on the clustered corpus.)
+// floors (NULL, or one admission floor per ORIGINAL query) travel with the queries into floors_c (one per compact slot)
 __global__ __launch_bounds__(256) void gather_failed_kernel(float* __restrict__ dst, const float* __restrict__ src,
                                                             const int64_t* __restrict__ map, const int* __restrict__ nb,
-                                                            int64_t rows, int64_t ld) {
+                                                            int64_t rows, int64_t ld, const float* __restrict__ floors,
+                                                            float* __restrict__ floors_c) {
     const int64_t d4 = ld / 4;
     const int64_t total = rows * d4;
     const int64_t live = *nb;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t r = i / d4, c = i - r * d4;
         f32x4u v = {0.f, 0.f, 0.f, 0.f};
-        if (live > 0) v = *reinterpret_cast<const f32x4u*>(src + map[r < live ? r : live - 1] * ld + c * 4);
+        const int64_t from = live > 0 ? map[r < live ? r : live - 1] : 0;
+        if (live > 0) v = *reinterpret_cast<const f32x4u*>(src + from * ld + c * 4);
         *reinterpret_cast<f32x4u*>(dst + r * ld + c * 4) = v;
+        if (c == 0 && floors_c) floors_c[r] = live > 0 && floors ? floors[from] : -INFINITY;
     }
 }
 

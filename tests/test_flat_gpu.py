@@ -1170,6 +1170,38 @@ def test_add_does_not_synchronise_the_device(native):
     idx.close()
 
 
+@pytest.mark.parametrize("n,d,nq", [(300_000, 512, 96), (1_000_000, 384, 256)])
+def test_refused_queries_rerun_from_an_admission_floor_with_identical_results(native, monkeypatch, n, d, nq):
+    """A refused query's exact re-run starts its lists from the k-th exact score of the nominees (less a rounding margin) instead
+    of -inf (half_certify_kernel -> gather_failed_kernel -> flat_scan_mfma2_gated_kernel).  On a clustered corpus — every batch
+    holds refused queries — the results are bit for bit those of the re-run without floors (MVDB_DISABLE_RERUN_FLOOR=1: same
+    kernel, same arithmetic), and the float64 adjudication accepts them."""
+    k = 10
+    q = flat.synth(nq, d, 5678 | flat.SYNTH_CLUSTERED)
+    flat.normalize_l2(q)
+    got = {}
+    for floors in (True, False):
+        if floors:
+            monkeypatch.delenv("MVDB_DISABLE_RERUN_FLOOR", raising=False)
+        else:
+            monkeypatch.setenv("MVDB_DISABLE_RERUN_FLOOR", "1")
+        idx = native.FlatIndex(d)
+        idx.reserve(n)
+        idx.add_synthetic(n, 1234 | flat.SYNTH_CLUSTERED, normalize=True)
+        before = native.split_rerun_count()
+        D, I = idx.search(q, k)
+        assert native.split_rerun_count() > before, "the clustered corpus must refuse some certificates"
+        got[floors] = (D.copy(), I.copy())
+        if floors:
+            stored = idx.get_rows(0, n)
+            for i in range(0, nq, 7):
+                ok, msg = flat.adjudicate(stored, q[i], k, D[i], I[i], tol=1e-4, tie_eps=2e-6)
+                assert ok, (i, msg)
+        idx.close()
+    assert np.array_equal(got[True][1], got[False][1])
+    assert np.array_equal(got[True][0].view(np.uint32), got[False][0].view(np.uint32))
+
+
 def test_single_query_shadow_route_suspends_itself_on_a_clustered_corpus(native):
     """The opt-in single-query route costs more than the exact scan when its certificate is refused.  On a clustered corpus (1M
     rows: every query's 10th and 64th best within 1e-3) every call is refused; the library notices within a window of 32 calls
