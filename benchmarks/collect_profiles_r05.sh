@@ -11,7 +11,7 @@ for nq in 32 128 256; do
 done
 python3 $R/bench.py --nq 256 --dim 384 --steps 60 --warmup 10 --no-cpu-baseline --no-encoder > $OUT/${TAG}_bench_nq256_d384.json 2>> $OUT/bench.err
 python3 $R/bench.py --nq 128 --k 32 --steps 60 --warmup 10 --no-cpu-baseline --no-encoder > $OUT/${TAG}_bench_nq128_k32.json 2>> $OUT/bench.err
-python3 $R/benchmarks/refusal_probe.py > $OUT/${TAG}_refusal_probe.txt 2>&1
+python3 $R/benchmarks/refusal_probe2.py > $OUT/${TAG}_refusal_probe.txt 2>&1
 python3 $R/benchmarks/ties_probe.py > $OUT/${TAG}_ties_probe.txt 2>&1
 python3 $R/bench.py --rows 1000000 --steps 500 --warmup 50 --no-cpu-baseline --no-encoder > $OUT/${TAG}_config2_1M.json 2>> $OUT/bench.err
 # the headline kernel: kernel trace + separate PMC passes (FETCH_SIZE / WRITE_SIZE), as the guide prescribes
