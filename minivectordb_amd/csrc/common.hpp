@@ -72,6 +72,7 @@ struct Knobs {
     int split32_min_nq = 14;         // MVDB_SPLIT32_MIN_NQ
     int split32_blocks_per_cu = 2;   // MVDB_SPLIT32_BLOCKS_PER_CU
     int split_phase_growth = 8;      // MVDB_SPLIT_PHASE_GROWTH
+    bool disable_rescue = false;       // MVDB_DISABLE_RESCUE: refused queries go straight to the exact passes (A/B)
     bool disable_rerun_floor = false;  // MVDB_DISABLE_RERUN_FLOOR: the exact re-run of refused queries starts every list from -inf (A/B)
     int half_phase_growth = 0;       // MVDB_HALF_PHASE_GROWTH (0: by the pass width — 16 / 6 up to 128 queries per pass, 6 / 4 at 256)
     int half_last_growth = 0;        // MVDB_HALF_LAST_GROWTH

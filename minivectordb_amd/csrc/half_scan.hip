@@ -829,8 +829,9 @@ __global__ __launch_bounds__(WV * 64) void flat_scan_hq_kernel(HalfScanArgs a) {
 // ALGORITHMIC bytes per launch = rows scanned x d x 2 (the pass's operand is the shadow).  At 256 queries per pass and d = 512
 // the matrix cores bound (2 x 32 MFMAs per SIMD and tile = 2,048 cycles against ~2,400 for the tile's 32 KiB at the HBM
 // rate ... at a clock the chip lowers under this load); at 128 queries HBM bounds.
-template <int KT, int KS, int WV, int NST>
+template <int KT, int KS, int WV, int NST, int DEPTH = kHalfKeep>
 __global__ __launch_bounds__(WV * 64) void flat_scan_h16_kernel(HalfScanArgs a) {
+    if (a.gate && *a.gate <= a.gate_lo) return;  // (rescue launches: nothing was refused / not this many)
     constexpr int K = KT * 16;
     constexpr int NSTG = KT / KS;            // stages per tile
     constexpr int HSL = KS * 2;              // 16-byte slots (8 fp16) per row and stage
@@ -840,12 +841,12 @@ __global__ __launch_bounds__(WV * 64) void flat_scan_h16_kernel(HalfScanArgs a) 
     static_assert(KT % KS == 0 && HSL % 16 == 0 && NP % WV == 0 && DPW >= 1, "shape");
     static_assert((NST - 1) * DPW <= 63, "vmcnt is a 6-bit counter");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // NST stages
-    __shared__ uint64_t lists[WV * 32 * kHalfKeep];                         // [wave][32 queries][16] keys
+    __shared__ uint64_t lists[WV * 32 * DEPTH];                         // [wave][32 queries][16] keys
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int fr = lane & 31, fk = lane >> 5;
-    uint64_t* mylists = lists + (size_t)wave * 32 * kHalfKeep;
-    for (int e = lane; e < 32 * kHalfKeep; e += 64) mylists[e] = 0ull;
+    uint64_t* mylists = lists + (size_t)wave * 32 * DEPTH;
+    for (int e = lane; e < 32 * DEPTH; e += 64) mylists[e] = 0ull;
 
     // ---- this wave's 32 queries over the whole K: B[k = 16 kb + 8 fk + j][query fr]
     hs_h8 Q[KT];
@@ -853,7 +854,8 @@ __global__ __launch_bounds__(WV * 64) void flat_scan_h16_kernel(HalfScanArgs a) 
     for (int kb = 0; kb < KT; ++kb)
         Q[kb] = *reinterpret_cast<const hs_h8*>(a.qf + (int64_t)(wave * 32 + fr) * K + kb * 16 + fk * 8);
     const int myq = wave * 32 + fr;
-    float floor0 = myq < a.nq ? (a.thr0 ? a.thr0[myq] : -INFINITY) : INFINITY;
+    float floor0 = myq < a.nq ? (a.thr0 ? a.thr0[myq] - (a.thr_qn ? a.thr_eps * a.thr_qn[myq] : 0.f) : -INFINITY) : INFINITY;
+    if (!(floor0 == floor0)) floor0 = -INFINITY;  // (inf - inf: a query outside the fp16 range keeps no floor)
     float thr = floor0;
     uint32_t thr_row = 0u;
     float inv = a.qinv[myq];
@@ -929,7 +931,7 @@ __global__ __launch_bounds__(WV * 64) void flat_scan_h16_kernel(HalfScanArgs a) 
                     const int sq = srcl & 31;
                     const float sv = __uint_as_float(__builtin_amdgcn_readlane((int)__float_as_uint(s), srcl));
                     const uint32_t rv = (uint32_t)(m0 + rl + 4 * (srcl >> 5));
-                    const uint64_t kth = lds_list_insert(mylists + (size_t)sq * kHalfKeep, kHalfKeep, make_key(sv, rv), lane);
+                    const uint64_t kth = lds_list_insert(mylists + (size_t)sq * DEPTH, DEPTH, make_key(sv, rv), lane);
                     if (fr == sq) set_threshold(kth, floor0, thr, thr_row);  // both lane halves
                 }
             }
@@ -988,8 +990,8 @@ __global__ __launch_bounds__(WV * 64) void flat_scan_h16_kernel(HalfScanArgs a) 
     for (int q = 0; q < 32; ++q) {
         const int qq = wave * 32 + q;
         if (qq >= a.nq) break;
-        if (lane < kHalfKeep)
-            a.cand[((int64_t)qq * gridDim.x + blockIdx.x) * kHalfKeep + lane] = mylists[(size_t)q * kHalfKeep + lane];
+        if (lane < DEPTH)
+            a.cand[((int64_t)qq * gridDim.x + blockIdx.x) * DEPTH + lane] = mylists[(size_t)q * DEPTH + lane];
     }
 }
 
@@ -1099,6 +1101,122 @@ static int launch_h16(int d, int nqpad, const HalfScanArgs& a, int device, hipSt
         default: break;
     }
     return fail(MVDB_ERR_ARG, "no fp16-shadow kernel for %d queries per pass at d = %d", nqpad, d);
+}
+
+// ---- the rescue pass (round 5) -----------------------------------------------------------------------------------------
+// A refused query is not an unknown one: half_certify_kernel has re-scored its 64 nominees exactly, and the k-th of those scores,
+// t, bounds the k-th result from below.  Every row of the top k therefore has an APPROXIMATE score >= t - margin - eps |q| =: f.
+// The rescue launch streams the shadow ONCE more for up to 128 refused queries with f as the admission floor and 32-deep lists per
+// (block, query): unless a list fills, the lists hold EVERY row that can be in the top k; half_rescue_certify_kernel re-scores
+// all of them in fp32 and takes the top k — exact, no certificate needed.  A full list (a neighbourhood of more than ~30 rows per
+// block inside the band) raises the query's `need` word and its 32-query exact pass runs as before.
+template <int KT, int NST>
+static int launch_h16_rescue_inst(const HalfScanArgs& a, int device, hipStream_t stream, int* nblocks_out) {
+    auto kern = flat_scan_h16_kernel<KT, KT, 4, NST, kRescueKeep>;
+    constexpr size_t lds = (size_t)NST * 32 * KT * 2 * 16;
+    static_assert(lds + 4 * 32 * kRescueKeep * 8 <= 160 * 1024, "LDS budget of a CU");
+    {
+        static std::mutex mu;
+        static std::map<int, bool> done;
+        std::lock_guard<std::mutex> lk(mu);
+        if (!done[device]) {
+            MVDB_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            done[device] = true;
+        }
+    }
+    const int64_t ntiles = a.tile1 - a.tile0;
+    const int nblocks = (int)std::max<int64_t>(1, std::min<int64_t>(ntiles, (int64_t)device_cus(device)));
+    *nblocks_out = nblocks;
+    prof_symbol("ip_scan_rescue", "flat_scan_h16_kernel<%d, %d, 4, %d, %d>", KT, KT, NST, kRescueKeep);
+    int slot = prof_begin("ip_scan_rescue", stream);
+    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(256), lds, stream, a);
+    prof_end(slot, stream);
+    MVDB_HIP(hipGetLastError());
+    return 0;
+}
+bool half_rescue_dim(int d) { return d == 256 || d == 384 || d == 512; }
+int launch_half_rescue_scan(int d, const HalfScanArgs& a, int device, hipStream_t stream, int* nb) {
+    switch (d) {
+        case 256: return launch_h16_rescue_inst<16, 4>(a, device, stream, nb);
+        case 384: return launch_h16_rescue_inst<24, 3>(a, device, stream, nb);
+        case 512: return launch_h16_rescue_inst<32, 3>(a, device, stream, nb);
+        default: return fail(MVDB_ERR_ARG, "no rescue kernel for d = %d", d);
+    }
+}
+
+// One block per compact query.  Collects the rescue lists' keys; a full list or more than kRescueCap keys: the query stays with the
+// exact pass (need word raised).  Else every candidate is re-scored in fp32 (the arithmetic of half_certify_kernel) and the k
+// best (score, row) keys are the query's results.
+__global__ __launch_bounds__(1024) void half_rescue_certify_kernel(HalfRescueArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int slot = blockIdx.x;                    // compact query gate_lo + slot
+    if (*a.gate <= a.gate_lo + slot) return;
+    __shared__ uint64_t cand[kRescueCap];           // approximate keys, then exact keys
+    __shared__ int s_cnt, s_full;
+    __shared__ uint64_t wmax[16];
+    if (threadIdx.x == 0) {
+        s_cnt = 0;
+        s_full = 0;
+    }
+    __syncthreads();
+    const int64_t total = (int64_t)a.nlists * kRescueKeep;
+    const uint64_t* src = a.keys + (int64_t)slot * total;
+    for (int64_t i = threadIdx.x; i < total; i += 1024) {
+        const uint64_t key = src[i];
+        if (!key) continue;
+        if ((i % kRescueKeep) == kRescueKeep - 1) s_full = 1;   // the list's last slot is taken: rows may have been dropped
+        const int at = atomicAdd(&s_cnt, 1);
+        if (at < kRescueCap) cand[at] = key;
+    }
+    __syncthreads();
+    const int cnt = s_cnt;
+    if (s_full || cnt > kRescueCap || cnt < a.k) {
+        if (threadIdx.x == 0) atomicOr(a.need + slot / 32, 1);
+        return;
+    }
+    const hs_f4* qr = reinterpret_cast<const hs_f4*>(a.q + (int64_t)slot * a.ld);
+    for (int i = wave; i < cnt; i += 16) {
+        const uint32_t row = key_row(cand[i]);
+        const hs_f4* xr = reinterpret_cast<const hs_f4*>(a.X + (int64_t)row * a.ld);
+        float s = 0.f;
+        for (int c = lane; c < a.d4; c += 64) {
+            const hs_f4 x = xr[c], w = qr[c];
+            s = fmaf(x[0], w[0], s);
+            s = fmaf(x[1], w[1], s);
+            s = fmaf(x[2], w[2], s);
+            s = fmaf(x[3], w[3], s);
+        }
+        for (int off = 32; off; off >>= 1) s += __shfl_xor(s, off);
+        if (lane == 0) cand[i] = make_key(s, row);
+    }
+    __syncthreads();
+    // k rounds of a block-wide maximum over the exact keys (unique: the row is part of the key)
+    for (int r = 0; r < a.k; ++r) {
+        uint64_t best = 0ull;
+        for (int i = threadIdx.x; i < cnt; i += 1024) best = cand[i] > best ? cand[i] : best;
+        for (int off = 32; off; off >>= 1) {
+            const uint64_t o = __shfl_xor(best, off);
+            best = o > best ? o : best;
+        }
+        if (lane == 0) wmax[wave] = best;
+        __syncthreads();
+        best = wmax[0];
+#pragma unroll
+        for (int w = 1; w < 16; ++w) best = wmax[w] > best ? wmax[w] : best;
+        if (threadIdx.x == 0) {
+            a.D[(int64_t)slot * a.k + r] = key_score(best);
+            a.I[(int64_t)slot * a.k + r] = a.label_offset + (int64_t)key_row(best);
+        }
+        for (int i = threadIdx.x; i < cnt; i += 1024)
+            if (cand[i] == best) cand[i] = 0ull;
+        __syncthreads();
+    }
+}
+
+int launch_half_rescue_certify(const HalfRescueArgs& a, hipStream_t stream) {
+    hipLaunchKernelGGL(half_rescue_certify_kernel, dim3(kRescueQueries), dim3(1024), 0, stream, a);
+    MVDB_HIP(hipGetLastError());
+    return 0;
 }
 
 // ---- certification ------------------------------------------------------------------------------------------------

@@ -27,6 +27,12 @@ struct HalfScanArgs {
     const uint32_t* mask = nullptr;  // NULL, or one bit per row (bit r & 31 of word r >> 5): only rows whose bit is set may be nominated
     const _Float16* Xh = nullptr;    // NULL, or the fp16 shadow of the corpus, [n][d] = fp16(xscale * X): the main launches stream IT
                                      // (flat_scan_h16_kernel: half the bytes, no conversion) where a kernel exists (half_shadow_dim)
+    // second pass for REFUSED queries (launch_half_rescue): the launch is enabled on the device (*gate > gate_lo), and a query's
+    // admission floor is thr0[q] - thr_eps * thr_qn[q] (the k-th exact score of its nominees less the nomination error)
+    const int* gate = nullptr;
+    int gate_lo = 0;
+    float thr_eps = 0.f;
+    const float* thr_qn = nullptr;
     const float* hn = nullptr;       // NULL, or [n + slack] |x_r|^2 / 2 per row (L2 metric over the shadow): rows are nominated by
                                      // q.x - |x|^2 / 2, which ranks exactly like the squared distance |q|^2 - 2 (q.x - |x|^2 / 2)
 };
@@ -62,6 +68,29 @@ struct HalfCertifyArgs {
                                  // re-run (inner-product index only; -inf where fewer than k nominees were re-scored)
     float floor_margin = 0.f;    // 2 d 2^-24 max|x|: the two fp32 dot products (this kernel's, the re-run's) may differ by that much
 };
+
+// ---- the RESCUE pass: refused queries once more over the shadow, every row above the floor kept and re-scored ----------------
+constexpr int kRescueKeep = 32;      // rows per (block, query) list of the rescue pass: a FULL list sends the query on to the exact pass
+constexpr int kRescueQueries = 128;  // compact queries per rescue launch
+constexpr int kRescueCap = 8192;     // candidates per query the re-score holds (256 lists x 32)
+struct HalfRescueArgs {
+    const uint64_t* keys;   // [kRescueQueries, nlists, kRescueKeep]
+    int nlists;
+    const float* X;
+    int64_t ld;
+    int d4;
+    const float* q;         // [kRescueQueries, ld] the compact queries of this launch
+    int k;
+    int64_t label_offset;
+    float* D;               // [kRescueQueries, k] compact results
+    int64_t* I;
+    const int* gate;        // number of refused queries of the call
+    int gate_lo;            // first compact query of this launch
+    int* need;              // [ceil(kRescueQueries / 32)] one word per exact 32-query pass: raised when one of its queries stays unanswered
+};
+int launch_half_rescue_scan(int d, const HalfScanArgs& a, int device, hipStream_t stream, int* nblocks_out);
+int launch_half_rescue_certify(const HalfRescueArgs& a, hipStream_t stream);
+bool half_rescue_dim(int d);
 
 // queries per corpus pass of the widest instantiation for dimension d (0: no kernel for this d)
 int half_max_queries(int d);

@@ -63,6 +63,7 @@ Knobs read_knobs() {
     k.disable_split32 = env_int("MVDB_DISABLE_SPLIT32", 0) != 0;
     k.disable_half_scan = env_int("MVDB_DISABLE_HALF_SCAN", 0) != 0;
     k.disable_rerun_floor = env_int("MVDB_DISABLE_RERUN_FLOOR", 0) != 0;
+    k.disable_rescue = env_int("MVDB_DISABLE_RESCUE", 0) != 0;
     k.disable_masked_batch = env_int("MVDB_DISABLE_MASKED_BATCH", 0) != 0;
     k.disable_l2_cert = env_int("MVDB_DISABLE_L2_CERT", 0) != 0;
     k.disable_half_shadow = env_int("MVDB_DISABLE_HALF_SHADOW", 0) != 0;
@@ -207,6 +208,7 @@ struct Workspace {
     DevBuf<float> requery;  // the failed queries, gathered, and their exact results [D | I]
     DevBuf<int64_t> relabel;
     DevBuf<int> nfail;      // number of uncertified queries of the call (device-side gate of the exact re-run)
+    DevBuf<int> need;       // one word per 32-query exact re-run pass: raised by the rescue pass where a query stays unanswered
     DevBuf<float> qfloor;   // per query: the admission floor of its exact re-run (half_certify_kernel), behind them the compact copy
     SelectState* st = nullptr;
     PinnedBuf pin;
@@ -570,7 +572,8 @@ int launch_mfma_inst(const MfmaScanArgs& a, int device, hipStream_t stream, int*
 }
 
 template <int KB, int NG, int SKB>
-int launch_mfma2_gated_inst(const MfmaScanArgs& a, int device, hipStream_t stream, int* nblocks_out, const int* gate, int gate_lo) {
+int launch_mfma2_gated_inst(const MfmaScanArgs& a, int device, hipStream_t stream, int* nblocks_out, const int* gate, int gate_lo,
+                            const int* need) {
     auto kern = a.mask ? flat_scan_mfma2_gated_kernel<KB, NG, SKB, true> : flat_scan_mfma2_gated_kernel<KB, NG, SKB, false>;
     const size_t lds = (size_t)kScanWaves * mfma2_wave_lds_bytes(SKB) + (size_t)kScanWaves * NG * 16 * a.k * 8;
     MVDB_TRY(ensure_dynamic_lds((const void*)kern, lds, device));
@@ -582,7 +585,7 @@ int launch_mfma2_gated_inst(const MfmaScanArgs& a, int device, hipStream_t strea
     *nblocks_out = nblocks;
     prof_symbol("ip_scan_rerun", "flat_scan_mfma2_gated_kernel<%d, %d, %d, %s>", KB, NG, SKB, a.mask ? "true" : "false");
     int slot = prof_begin("ip_scan_rerun", stream);
-    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(kScanThreads), lds, stream, a, gate, gate_lo);
+    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(kScanThreads), lds, stream, a, gate, gate_lo, need);
     prof_end(slot, stream);
     MVDB_HIP(hipGetLastError());
     return 0;
@@ -648,25 +651,26 @@ int mfma_gated_queries(const mvdb_index* idx) {
     if (idx->d % 128 != 0) return 0;  // the staged kernel only
     return KB <= 32 ? 32 : (KB == 48 || KB == 64) ? 16 : 0;
 }
-int launch_mfma2_gated(int KB, const MfmaScanArgs& a, int device, hipStream_t s, int* nb, const int* gate, int gate_lo) {
+int launch_mfma2_gated(int KB, const MfmaScanArgs& a, int device, hipStream_t s, int* nb, const int* gate, int gate_lo,
+                       const int* need = nullptr) {
     if (a.nq <= 16) {
         // one query group: with two, a pass of <= 16 queries issues twice the MFMAs it needs and is bound by them (8 queries
         // under a bitmap at 10M x 512: 3.67 ms against 3.0 unfiltered)
         switch (KB) {
-            case 8: return launch_mfma2_gated_inst<8, 1, 8>(a, device, s, nb, gate, gate_lo);
-            case 16: return launch_mfma2_gated_inst<16, 1, 8>(a, device, s, nb, gate, gate_lo);
-            case 24: return launch_mfma2_gated_inst<24, 1, 8>(a, device, s, nb, gate, gate_lo);
-            case 32: return launch_mfma2_gated_inst<32, 1, 8>(a, device, s, nb, gate, gate_lo);
+            case 8: return launch_mfma2_gated_inst<8, 1, 8>(a, device, s, nb, gate, gate_lo, need);
+            case 16: return launch_mfma2_gated_inst<16, 1, 8>(a, device, s, nb, gate, gate_lo, need);
+            case 24: return launch_mfma2_gated_inst<24, 1, 8>(a, device, s, nb, gate, gate_lo, need);
+            case 32: return launch_mfma2_gated_inst<32, 1, 8>(a, device, s, nb, gate, gate_lo, need);
             default: break;
         }
     }
     switch (KB) {
-        case 8: return launch_mfma2_gated_inst<8, 2, 8>(a, device, s, nb, gate, gate_lo);
-        case 16: return launch_mfma2_gated_inst<16, 2, 8>(a, device, s, nb, gate, gate_lo);
-        case 24: return launch_mfma2_gated_inst<24, 2, 8>(a, device, s, nb, gate, gate_lo);
-        case 32: return launch_mfma2_gated_inst<32, 2, 8>(a, device, s, nb, gate, gate_lo);
-        case 48: return launch_mfma2_gated_inst<48, 1, 8>(a, device, s, nb, gate, gate_lo);
-        case 64: return launch_mfma2_gated_inst<64, 1, 8>(a, device, s, nb, gate, gate_lo);
+        case 8: return launch_mfma2_gated_inst<8, 2, 8>(a, device, s, nb, gate, gate_lo, need);
+        case 16: return launch_mfma2_gated_inst<16, 2, 8>(a, device, s, nb, gate, gate_lo, need);
+        case 24: return launch_mfma2_gated_inst<24, 2, 8>(a, device, s, nb, gate, gate_lo, need);
+        case 32: return launch_mfma2_gated_inst<32, 2, 8>(a, device, s, nb, gate, gate_lo, need);
+        case 48: return launch_mfma2_gated_inst<48, 1, 8>(a, device, s, nb, gate, gate_lo, need);
+        case 64: return launch_mfma2_gated_inst<64, 1, 8>(a, device, s, nb, gate, gate_lo, need);
         default: break;
     }
     return fail(MVDB_ERR_ARG, "no gated multi-query kernel for d = %d", KB * 16);
@@ -1348,6 +1352,67 @@ int search_core(const mvdb_index* idx, Workspace* ws, const float* q_dev, int nq
                 }
                 off = R;
             } else if (per_pass > 0 && !idx->kn.disable_mfma_scan) {
+                // ---- the RESCUE pass (half_scan.hip): refused queries once more over the shadow, 128 at a time, every row above
+                // (k-th exact score of the nominees - margin - eps |q|) kept and re-scored; what it answers the exact passes skip
+                const int* need = nullptr;
+                const float xs = half_xscale(idx->row_norm_bound);
+                if (per_pass == 32 && use_half && half_rescue_dim(idx->d) && idx->ld == idx->d && k <= kRescueKeep && !idx->kn.disable_rescue &&
+                    !idx->kn.disable_rerun_floor && xs > 0.f) {
+                    const _Float16* Xh = ensure_shadow(idx, s, xs);
+                    if (Xh) {
+                        const int grid_ub = scan_grid_upper_bound(idx->device);
+                        MVDB_TRY(ws->need.reserve((size_t)(R + kRescueQueries) / 32 + 8));
+                        MVDB_TRY(ws->cand.reserve((size_t)kRescueQueries * (grid_ub + 1) * kRescueKeep));
+                        MVDB_TRY(ws->qsplit.reserve((size_t)2 * kRescueQueries * idx->d));
+                        MVDB_TRY(ws->qnorm.reserve((size_t)3 * kRescueQueries));
+                        MVDB_HIP(hipMemsetAsync(ws->need.p, 0, ((size_t)(R + kRescueQueries) / 32 + 8) * sizeof(int), s));
+                        _Float16* qf = reinterpret_cast<_Float16*>(ws->qsplit.p);
+                        float* qn2 = ws->qnorm.p;
+                        float* qinv = qn2 + 2 * kRescueQueries;
+                        const float eps = (float)(half_eps(idx->d) * (double)idx->row_norm_bound * (1.0 + 1e-6));
+                        for (int off2 = 0; off2 < R; off2 += kRescueQueries) {
+                            MVDB_TRY(launch_half_queries(qc + (int64_t)off2 * idx->ld, idx->ld, idx->d, kRescueQueries, kRescueQueries, xs, qf, qn2,
+                                                         qinv, s));
+                            HalfScanArgs ra;
+                            ra.X = idx->X;
+                            ra.n = n;
+                            ra.ld = idx->ld;
+                            ra.qf = qf;
+                            ra.qinv = qinv;
+                            ra.xscale = xs;
+                            ra.nq = kRescueQueries;
+                            ra.mask = mask32;
+                            ra.Xh = Xh;
+                            ra.stats = nullptr;
+                            ra.cand = ws->cand.p;
+                            ra.tile0 = 0;
+                            ra.tile1 = (n + 31) / 32;
+                            ra.thr0 = ws->qfloor.p + q0 + off2;
+                            ra.thr_eps = eps;
+                            ra.thr_qn = qn2;
+                            ra.gate = ws->nfail.p;
+                            ra.gate_lo = off2;
+                            int gx = 0;
+                            MVDB_TRY(launch_half_rescue_scan(idx->d, ra, idx->device, s, &gx));
+                            HalfRescueArgs rc;
+                            rc.keys = ws->cand.p;
+                            rc.nlists = gx;
+                            rc.X = idx->X;
+                            rc.ld = idx->ld;
+                            rc.d4 = idx->d4;
+                            rc.q = qc + (int64_t)off2 * idx->ld;
+                            rc.k = k;
+                            rc.label_offset = label_offset;
+                            rc.D = Dt + (int64_t)off2 * k;
+                            rc.I = It + (int64_t)off2 * k;
+                            rc.gate = ws->nfail.p;
+                            rc.gate_lo = off2;
+                            rc.need = ws->need.p + off2 / 32;
+                            MVDB_TRY(launch_half_rescue_certify(rc, s));
+                        }
+                        need = ws->need.p;
+                    }
+                }
                 MVDB_TRY(ws->cand.reserve((size_t)32 * scan_grid_upper_bound(idx->device) * k));
                 // (the GEMM scan keeps k <= 16 and takes no bitmap: those re-runs are all fp32-MFMA passes)
                 // every refused query through the gated fp32-MFMA pass, 32 at a time (launches beyond the refused count return at
@@ -1367,8 +1432,9 @@ int search_core(const mvdb_index* idx, Workspace* ws, const float* q_dev, int nq
                     ma.mask = mask32;
                     ma.thr0 = idx->kn.disable_rerun_floor ? nullptr : ws->qfloor.p + q0 + off;
                     int nblocks = 0;
-                    MVDB_TRY(launch_mfma2_gated(KB, ma, idx->device, s, &nblocks, ws->nfail.p, off));
+                    MVDB_TRY(launch_mfma2_gated(KB, ma, idx->device, s, &nblocks, ws->nfail.p, off, need ? need + off / 32 : nullptr));
                     MergeArgs mg;
+                    mg.need = need ? need + off / 32 : nullptr;
                     mg.keys = ws->cand.p;
                     mg.nlists = nblocks;
                     mg.k = k;

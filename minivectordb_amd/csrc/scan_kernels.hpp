@@ -262,6 +262,7 @@ struct MergeArgs {
     int64_t* I;  // [nq, k]
     const int* gate = nullptr;  // optional device-side enable: query blockIdx.x is merged iff *gate > gate_lo + blockIdx.x
     int gate_lo = 0;
+    const int* need = nullptr;  // optional second enable (one word for the launch): nothing is merged while *need == 0
 };
 
 constexpr int kMergeThreads = 1024;
@@ -270,6 +271,7 @@ constexpr int kMergeUnroll = 8;
 
 __global__ __launch_bounds__(kMergeThreads) void merge_keys_kernel(MergeArgs a) {
     if (a.gate && *a.gate <= a.gate_lo + (int)blockIdx.x) return;
+    if (a.need && *a.need == 0) return;
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x >> 6;
     const int qi = blockIdx.x;

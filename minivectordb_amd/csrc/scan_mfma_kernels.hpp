@@ -353,8 +353,10 @@ __global__ __launch_bounds__(kScanThreads) void flat_scan_mfma2_kernel(MfmaScanA
 // enabled by a device-side count (the whole pass runs iff *gate > gate_lo; gate == NULL: always): see flat_scan_gated_kernel.
 // MASKED: only rows whose bit is set in a.mask are offered to the lists (bitmap-selected batches and their exact re-runs).
 template <int KB, int NG, int SKB, bool MASKED = false>
-__global__ __launch_bounds__(kScanThreads) void flat_scan_mfma2_gated_kernel(MfmaScanArgs a, const int* __restrict__ gate, int gate_lo) {
+__global__ __launch_bounds__(kScanThreads) void flat_scan_mfma2_gated_kernel(MfmaScanArgs a, const int* __restrict__ gate, int gate_lo,
+                                                                             const int* __restrict__ need) {
     if (gate && *gate <= gate_lo) return;
+    if (need && *need == 0) return;  // every refused query of this pass was answered by the rescue pass (half_scan.hip)
     flat_scan_mfma2_body<KB, NG, SKB, MASKED>(a);
 }
 

@@ -1175,31 +1175,53 @@ def test_refused_queries_rerun_from_an_admission_floor_with_identical_results(na
     """A refused query's exact re-run starts its lists from the k-th exact score of the nominees (less a rounding margin) instead
     of -inf (half_certify_kernel -> gather_failed_kernel -> flat_scan_mfma2_gated_kernel).  On a clustered corpus — every batch
     holds refused queries — the results are bit for bit those of the re-run without floors (MVDB_DISABLE_RERUN_FLOOR=1: same
-    kernel, same arithmetic), and the float64 adjudication accepts them."""
+    kernel, same arithmetic).  And the RESCUE pass in front of the re-run (default: the refused queries once more over the
+    shadow, every row above the floor kept and re-scored in fp32) answers them itself: the exact passes are skipped, the float64
+    adjudication accepts every result, and ids differ from the exact re-run's only inside near-ties."""
     k = 10
     q = flat.synth(nq, d, 5678 | flat.SYNTH_CLUSTERED)
     flat.normalize_l2(q)
     got = {}
-    for floors in (True, False):
-        if floors:
-            monkeypatch.delenv("MVDB_DISABLE_RERUN_FLOOR", raising=False)
-        else:
+    for mode in ("rescue", "floor", "plain"):
+        monkeypatch.delenv("MVDB_DISABLE_RERUN_FLOOR", raising=False)
+        monkeypatch.delenv("MVDB_DISABLE_RESCUE", raising=False)
+        if mode == "floor":
+            monkeypatch.setenv("MVDB_DISABLE_RESCUE", "1")
+        if mode == "plain":
             monkeypatch.setenv("MVDB_DISABLE_RERUN_FLOOR", "1")
         idx = native.FlatIndex(d)
         idx.reserve(n)
         idx.add_synthetic(n, 1234 | flat.SYNTH_CLUSTERED, normalize=True)
-        before = native.split_rerun_count()
-        D, I = idx.search(q, k)
-        assert native.split_rerun_count() > before, "the clustered corpus must refuse some certificates"
-        got[floors] = (D.copy(), I.copy())
-        if floors:
+        idx.search(q[:nq], k)  # (builds the shadow and sizes the workspace)
+        native.prof_enable(True)
+        try:
+            for f in ("ip_scan_rescue", "ip_scan_rerun"):
+                native.prof_read(f)
+            before = native.split_rerun_count()
+            D, I = idx.search(q, k)
+            assert native.split_rerun_count() > before, "the clustered corpus must refuse some certificates"
+            rescue, rerun = native.prof_read("ip_scan_rescue"), native.prof_read("ip_scan_rerun")
+        finally:
+            native.prof_enable(False)
+        if mode == "rescue":
+            assert rescue[0] >= 1 and rescue[1] > 0.02, rescue           # the rescue launches ran ...
+            assert rerun[1] < 0.05 * max(1, rerun[0]), rerun              # ... and every exact pass returned at its gate
             stored = idx.get_rows(0, n)
-            for i in range(0, nq, 7):
+            for i in range(0, nq, 3):
                 ok, msg = flat.adjudicate(stored, q[i], k, D[i], I[i], tol=1e-4, tie_eps=2e-6)
                 assert ok, (i, msg)
+        else:
+            assert rescue[0] == 0, rescue
+            assert rerun[1] > 0.05, rerun
+        got[mode] = (D.copy(), I.copy())
         idx.close()
-    assert np.array_equal(got[True][1], got[False][1])
-    assert np.array_equal(got[True][0].view(np.uint32), got[False][0].view(np.uint32))
+    assert np.array_equal(got["floor"][1], got["plain"][1])
+    assert np.array_equal(got["floor"][0].view(np.uint32), got["plain"][0].view(np.uint32))
+    # the rescue's scores are the certification kernel's fp32 sums, the re-run's the matrix cores': the same rows but for swaps of
+    # rows within rounding of each other
+    same = (got["rescue"][1] == got["floor"][1]).mean()
+    assert same > 0.9, same
+    np.testing.assert_allclose(np.sort(got["rescue"][0], axis=1), np.sort(got["floor"][0], axis=1), rtol=0, atol=2e-6)
 
 
 def test_single_query_shadow_route_suspends_itself_on_a_clustered_corpus(native):
