@@ -551,7 +551,7 @@ def certified_passes_on_unfriendly_data(native, dev, k, n=10_000_000, d=512, nq=
     clustered corpus (4,096 centres + 6 % noise, exact and near duplicates: thousands of rows within 1e-3 of a query's best).
     Per corpus: 256 queries of the same family, 256 / 32 per call and the opt-in single-query route over the fp16 shadow, with
     the exact single-query scan beside them; `uncertified_chunks_per_call` = chunks of a call that held a query the
-    certificate refused (re-run exactly, on the device)."""
+    certificate refused (answered exactly, on the device: by the rescue pass over the shadow, or by an exact fp32 pass)."""
     import numpy as np
     import torch
     # (clustered at 10M rows: ~19 noise-free / near-duplicate rows per centre outscore the centre's other 2,400 rows by 2e-3, so
@@ -593,6 +593,23 @@ def certified_passes_on_unfriendly_data(native, dev, k, n=10_000_000, d=512, nq=
         exact_ids = I[:32].cpu().numpy().copy()
         rec["256_per_call"] = timed(256, nq, 3)
         same256 = bool(np.array_equal(I[:32].cpu().numpy(), exact_ids))
+        # where a refused call spends its device time: the certified pass, the RESCUE pass (refused queries once more over the
+        # shadow, every row above their floor re-scored: exact), the gated exact fp32 passes behind it (launches that return at
+        # their gate included, ~7 us each)
+        native.prof_enable(True)
+        try:
+            fams = ("ip_scan_half", "ip_scan_half_seed", "ip_scan_rescue", "ip_scan_rerun")
+            for f in fams:
+                native.prof_read(f)
+            run(256, nq)
+            torch.cuda.synchronize()
+            t = {f: native.prof_read(f) for f in fams}
+        finally:
+            native.prof_enable(False)
+        rec["256_per_call"]["device_ms_by_tier"] = {
+            "certified_pass": round(t["ip_scan_half"][1] + t["ip_scan_half_seed"][1], 3),
+            "rescue_pass": round(t["ip_scan_rescue"][1], 3), "exact_rerun_passes": round(t["ip_scan_rerun"][1], 3),
+            "launches": {"rescue": t["ip_scan_rescue"][0], "exact_rerun": t["ip_scan_rerun"][0]}}
         rec["32_per_call"] = timed(32, nq, 2)
         idx.set_option("shadow_single_query", 1)
         rec["single_query_over_fp16_shadow_opt_in"] = timed(1, 32, 2)

@@ -1360,7 +1360,7 @@ int search_core(const mvdb_index* idx, Workspace* ws, const float* q_dev, int nq
                     !idx->kn.disable_rerun_floor && xs > 0.f) {
                     const _Float16* Xh = ensure_shadow(idx, s, xs);
                     if (Xh) {
-                        const int grid_ub = scan_grid_upper_bound(idx->device);
+                        const int grid_ub = device_cus(idx->device);  // the rescue launch is one workgroup per CU
                         MVDB_TRY(ws->need.reserve((size_t)(R + kRescueQueries) / 32 + 8));
                         MVDB_TRY(ws->cand.reserve((size_t)kRescueQueries * (grid_ub + 1) * kRescueKeep));
                         MVDB_TRY(ws->qsplit.reserve((size_t)2 * kRescueQueries * idx->d));
@@ -1380,7 +1380,7 @@ int search_core(const mvdb_index* idx, Workspace* ws, const float* q_dev, int nq
                             ra.qf = qf;
                             ra.qinv = qinv;
                             ra.xscale = xs;
-                            ra.nq = kRescueQueries;
+                            ra.nq = std::min(kRescueQueries, R - off2);  // (slots past the call's queries can never be live)
                             ra.mask = mask32;
                             ra.Xh = Xh;
                             ra.stats = nullptr;
