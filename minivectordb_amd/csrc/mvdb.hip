@@ -573,7 +573,7 @@ int launch_mfma_inst(const MfmaScanArgs& a, int device, hipStream_t stream, int*
 
 template <int KB, int NG, int SKB>
 int launch_mfma2_gated_inst(const MfmaScanArgs& a, int device, hipStream_t stream, int* nblocks_out, const int* gate, int gate_lo,
-                            const int* need) {
+                            const int* need, int npasses, int per_pass, int rtot, int64_t cand_stride) {
     auto kern = a.mask ? flat_scan_mfma2_gated_kernel<KB, NG, SKB, true> : flat_scan_mfma2_gated_kernel<KB, NG, SKB, false>;
     const size_t lds = (size_t)kScanWaves * mfma2_wave_lds_bytes(SKB) + (size_t)kScanWaves * NG * 16 * a.k * 8;
     MVDB_TRY(ensure_dynamic_lds((const void*)kern, lds, device));
@@ -585,7 +585,7 @@ int launch_mfma2_gated_inst(const MfmaScanArgs& a, int device, hipStream_t strea
     *nblocks_out = nblocks;
     prof_symbol("ip_scan_rerun", "flat_scan_mfma2_gated_kernel<%d, %d, %d, %s>", KB, NG, SKB, a.mask ? "true" : "false");
     int slot = prof_begin("ip_scan_rerun", stream);
-    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(kScanThreads), lds, stream, a, gate, gate_lo, need);
+    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(kScanThreads), lds, stream, a, gate, gate_lo, need, npasses, per_pass, rtot, cand_stride);
     prof_end(slot, stream);
     MVDB_HIP(hipGetLastError());
     return 0;
@@ -652,25 +652,27 @@ int mfma_gated_queries(const mvdb_index* idx) {
     return KB <= 32 ? 32 : (KB == 48 || KB == 64) ? 16 : 0;
 }
 int launch_mfma2_gated(int KB, const MfmaScanArgs& a, int device, hipStream_t s, int* nb, const int* gate, int gate_lo,
-                       const int* need = nullptr) {
+                       const int* need = nullptr, int npasses = 1, int per_pass = 0, int rtot = 0, int64_t cand_stride = 0) {
+    if (per_pass <= 0) per_pass = a.nq;   // one pass of a.nq queries
+    if (rtot <= 0) rtot = a.nq;
     if (a.nq <= 16) {
         // one query group: with two, a pass of <= 16 queries issues twice the MFMAs it needs and is bound by them (8 queries
         // under a bitmap at 10M x 512: 3.67 ms against 3.0 unfiltered)
         switch (KB) {
-            case 8: return launch_mfma2_gated_inst<8, 1, 8>(a, device, s, nb, gate, gate_lo, need);
-            case 16: return launch_mfma2_gated_inst<16, 1, 8>(a, device, s, nb, gate, gate_lo, need);
-            case 24: return launch_mfma2_gated_inst<24, 1, 8>(a, device, s, nb, gate, gate_lo, need);
-            case 32: return launch_mfma2_gated_inst<32, 1, 8>(a, device, s, nb, gate, gate_lo, need);
+            case 8: return launch_mfma2_gated_inst<8, 1, 8>(a, device, s, nb, gate, gate_lo, need, npasses, per_pass, rtot, cand_stride);
+            case 16: return launch_mfma2_gated_inst<16, 1, 8>(a, device, s, nb, gate, gate_lo, need, npasses, per_pass, rtot, cand_stride);
+            case 24: return launch_mfma2_gated_inst<24, 1, 8>(a, device, s, nb, gate, gate_lo, need, npasses, per_pass, rtot, cand_stride);
+            case 32: return launch_mfma2_gated_inst<32, 1, 8>(a, device, s, nb, gate, gate_lo, need, npasses, per_pass, rtot, cand_stride);
             default: break;
         }
     }
     switch (KB) {
-        case 8: return launch_mfma2_gated_inst<8, 2, 8>(a, device, s, nb, gate, gate_lo, need);
-        case 16: return launch_mfma2_gated_inst<16, 2, 8>(a, device, s, nb, gate, gate_lo, need);
-        case 24: return launch_mfma2_gated_inst<24, 2, 8>(a, device, s, nb, gate, gate_lo, need);
-        case 32: return launch_mfma2_gated_inst<32, 2, 8>(a, device, s, nb, gate, gate_lo, need);
-        case 48: return launch_mfma2_gated_inst<48, 1, 8>(a, device, s, nb, gate, gate_lo, need);
-        case 64: return launch_mfma2_gated_inst<64, 1, 8>(a, device, s, nb, gate, gate_lo, need);
+        case 8: return launch_mfma2_gated_inst<8, 2, 8>(a, device, s, nb, gate, gate_lo, need, npasses, per_pass, rtot, cand_stride);
+        case 16: return launch_mfma2_gated_inst<16, 2, 8>(a, device, s, nb, gate, gate_lo, need, npasses, per_pass, rtot, cand_stride);
+        case 24: return launch_mfma2_gated_inst<24, 2, 8>(a, device, s, nb, gate, gate_lo, need, npasses, per_pass, rtot, cand_stride);
+        case 32: return launch_mfma2_gated_inst<32, 2, 8>(a, device, s, nb, gate, gate_lo, need, npasses, per_pass, rtot, cand_stride);
+        case 48: return launch_mfma2_gated_inst<48, 1, 8>(a, device, s, nb, gate, gate_lo, need, npasses, per_pass, rtot, cand_stride);
+        case 64: return launch_mfma2_gated_inst<64, 1, 8>(a, device, s, nb, gate, gate_lo, need, npasses, per_pass, rtot, cand_stride);
         default: break;
     }
     return fail(MVDB_ERR_ARG, "no gated multi-query kernel for d = %d", KB * 16);
@@ -1419,34 +1421,39 @@ int search_core(const mvdb_index* idx, Workspace* ws, const float* q_dev, int nq
                 // once).  Until round 5 the batch went to the 128-query GEMM-tiled scan after two such passes — 20-25 ms per 128
                 // queries at 10M x 512 where four MFMA passes take 14.
                 const int max_passes = (R + per_pass - 1) / per_pass;
-                for (int pass = 0; pass < max_passes && off < R; ++pass) {
-                    const int take = std::min(per_pass, R - off);
+                {
+                    // ONE launch walks the passes on the device (pass p: compact queries [p per_pass, ...); each enabled by the
+                    // refused count and its `need` word), ONE merge launch covers every compact query
+                    const int64_t cand_stride = (int64_t)per_pass * scan_grid_upper_bound(idx->device) * k;
+                    MVDB_TRY(ws->cand.reserve((size_t)max_passes * cand_stride));
                     MfmaScanArgs ma;
                     ma.X = idx->X;
                     ma.n = n;
                     ma.ld = idx->ld;
-                    ma.q = qc + (int64_t)off * idx->ld;
-                    ma.nq = take;
+                    ma.q = qc;
+                    ma.nq = std::min(per_pass, R);
                     ma.k = k;
                     ma.cand = ws->cand.p;
                     ma.mask = mask32;
-                    ma.thr0 = idx->kn.disable_rerun_floor ? nullptr : ws->qfloor.p + q0 + off;
+                    ma.thr0 = idx->kn.disable_rerun_floor ? nullptr : ws->qfloor.p + q0;
                     int nblocks = 0;
-                    MVDB_TRY(launch_mfma2_gated(KB, ma, idx->device, s, &nblocks, ws->nfail.p, off, need ? need + off / 32 : nullptr));
+                    MVDB_TRY(launch_mfma2_gated(KB, ma, idx->device, s, &nblocks, ws->nfail.p, 0, need, max_passes, per_pass, R, cand_stride));
                     MergeArgs mg;
-                    mg.need = need ? need + off / 32 : nullptr;
                     mg.keys = ws->cand.p;
                     mg.nlists = nblocks;
                     mg.k = k;
                     mg.metric = idx->metric;
                     mg.label_offset = label_offset;
-                    mg.D = Dt + (int64_t)off * k;
-                    mg.I = It + (int64_t)off * k;
+                    mg.D = Dt;
+                    mg.I = It;
                     mg.gate = ws->nfail.p;
-                    mg.gate_lo = off;
-                    hipLaunchKernelGGL(merge_keys_kernel, dim3(take), dim3(kMergeThreads), 0, s, mg);
+                    mg.gate_lo = 0;
+                    mg.need = need;
+                    mg.per_pass = per_pass;
+                    mg.pass_stride = cand_stride;
+                    hipLaunchKernelGGL(merge_keys_kernel, dim3(R), dim3(kMergeThreads), 0, s, mg);
                     MVDB_HIP(hipGetLastError());
-                    off += take;
+                    off = R;
                 }
             }
             if (off < R && mask_dev) return fail(MVDB_ERR_ARG, "internal: bitmap re-run left to the GEMM scan");

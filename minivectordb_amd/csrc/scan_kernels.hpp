@@ -262,7 +262,9 @@ struct MergeArgs {
     int64_t* I;  // [nq, k]
     const int* gate = nullptr;  // optional device-side enable: query blockIdx.x is merged iff *gate > gate_lo + blockIdx.x
     int gate_lo = 0;
-    const int* need = nullptr;  // optional second enable (one word for the launch): nothing is merged while *need == 0
+    const int* need = nullptr;  // optional second enable, one word per PASS of per_pass queries: nothing of a pass is merged while its word is 0
+    int per_pass = 0;           // > 0: the launch covers several passes — query blockIdx.x belongs to pass blockIdx.x / per_pass, whose
+    int64_t pass_stride = 0;    //      lists start pass_stride keys after the pass before
 };
 
 constexpr int kMergeThreads = 1024;
@@ -271,12 +273,13 @@ constexpr int kMergeUnroll = 8;
 
 __global__ __launch_bounds__(kMergeThreads) void merge_keys_kernel(MergeArgs a) {
     if (a.gate && *a.gate <= a.gate_lo + (int)blockIdx.x) return;
-    if (a.need && *a.need == 0) return;
+    const int pass = a.per_pass > 0 ? (int)blockIdx.x / a.per_pass : 0;
+    if (a.need && a.need[pass] == 0) return;
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x >> 6;
     const int qi = blockIdx.x;
     const int64_t total = (int64_t)a.nlists * a.k;
-    const uint64_t* src = a.keys + (int64_t)qi * total;
+    const uint64_t* src = a.keys + (int64_t)pass * a.pass_stride + (int64_t)(qi - pass * a.per_pass) * total;
     WaveTopK tk;
     tk.init(a.k);
     // each wave walks its slice in steps of 64 x kMergeUnroll keys: the loads of a step are

@@ -353,11 +353,23 @@ __global__ __launch_bounds__(kScanThreads) void flat_scan_mfma2_kernel(MfmaScanA
 // enabled by a device-side count (the whole pass runs iff *gate > gate_lo; gate == NULL: always): see flat_scan_gated_kernel.
 // MASKED: only rows whose bit is set in a.mask are offered to the lists (bitmap-selected batches and their exact re-runs).
 template <int KB, int NG, int SKB, bool MASKED = false>
+// npasses > 1: ONE launch walks the passes of a compact batch of `rtot` queries, per_pass at a time (pass p: queries
+// [p per_pass, ...), floors and lists likewise, lists cand_stride keys apart) — eight gated launches that return at once cost a
+// certified 256-query call ~60 us of device time, 10 % of the call at 1M rows.
 __global__ __launch_bounds__(kScanThreads) void flat_scan_mfma2_gated_kernel(MfmaScanArgs a, const int* __restrict__ gate, int gate_lo,
-                                                                             const int* __restrict__ need) {
-    if (gate && *gate <= gate_lo) return;
-    if (need && *need == 0) return;  // every refused query of this pass was answered by the rescue pass (half_scan.hip)
-    flat_scan_mfma2_body<KB, NG, SKB, MASKED>(a);
+                                                                             const int* __restrict__ need, int npasses, int per_pass,
+                                                                             int rtot, int64_t cand_stride) {
+    for (int p = 0; p < npasses; ++p) {
+        if (gate && *gate <= gate_lo + p * per_pass) return;
+        if (need && need[p] == 0) continue;  // every refused query of this pass was answered by the rescue pass (half_scan.hip)
+        MfmaScanArgs b = a;
+        b.q = a.q + (int64_t)p * per_pass * a.ld;
+        b.nq = min(per_pass, rtot - p * per_pass);
+        b.cand = a.cand + (int64_t)p * cand_stride;
+        if (a.thr0) b.thr0 = a.thr0 + p * per_pass;
+        flat_scan_mfma2_body<KB, NG, SKB, MASKED>(b);
+        __syncthreads();  // the lists are re-initialised by the next pass
+    }
 }
 
 }  // namespace mvdb
