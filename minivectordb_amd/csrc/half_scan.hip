@@ -1134,12 +1134,16 @@ static int launch_h16_rescue_inst(const HalfScanArgs& a, int device, hipStream_t
     MVDB_HIP(hipGetLastError());
     return 0;
 }
-bool half_rescue_dim(int d) { return d == 256 || d == 384 || d == 512; }
+bool half_rescue_dim(int d) { return half_shadow_dim(d); }
 int launch_half_rescue_scan(int d, const HalfScanArgs& a, int device, hipStream_t stream, int* nb) {
     switch (d) {
         case 256: return launch_h16_rescue_inst<16, 4>(a, device, stream, nb);
         case 384: return launch_h16_rescue_inst<24, 3>(a, device, stream, nb);
         case 512: return launch_h16_rescue_inst<32, 3>(a, device, stream, nb);
+        case 640: return launch_h16_rescue_inst<40, 3>(a, device, stream, nb);   // (e5-large / bge-m3 widths: two-stage rings from 768 on)
+        case 768: return launch_h16_rescue_inst<48, 2>(a, device, stream, nb);
+        case 896: return launch_h16_rescue_inst<56, 2>(a, device, stream, nb);
+        case 1024: return launch_h16_rescue_inst<64, 2>(a, device, stream, nb);
         default: return fail(MVDB_ERR_ARG, "no rescue kernel for d = %d", d);
     }
 }
@@ -1171,7 +1175,7 @@ __global__ __launch_bounds__(1024) void half_rescue_certify_kernel(HalfRescueArg
     __syncthreads();
     const int cnt = s_cnt;
     if (s_full || cnt > kRescueCap || cnt < a.k) {
-        if (threadIdx.x == 0) atomicOr(a.need + slot / 32, 1);
+        if (threadIdx.x == 0) atomicOr(a.need + slot / a.per_pass, 1);
         return;
     }
     const hs_f4* qr = reinterpret_cast<const hs_f4*>(a.q + (int64_t)slot * a.ld);

@@ -86,7 +86,8 @@ struct HalfRescueArgs {
     int64_t* I;
     const int* gate;        // number of refused queries of the call
     int gate_lo;            // first compact query of this launch
-    int* need;              // [ceil(kRescueQueries / 32)] one word per exact 32-query pass: raised when one of its queries stays unanswered
+    int* need;              // one word per exact pass of per_pass queries: raised when one of its queries stays unanswered
+    int per_pass = 32;      // queries per exact pass (32 up to d = 512, 16 at the wider dimensions)
 };
 int launch_half_rescue_scan(int d, const HalfScanArgs& a, int device, hipStream_t stream, int* nblocks_out);
 int launch_half_rescue_certify(const HalfRescueArgs& a, hipStream_t stream);

@@ -1358,16 +1358,16 @@ int search_core(const mvdb_index* idx, Workspace* ws, const float* q_dev, int nq
                 // (k-th exact score of the nominees - margin - eps |q|) kept and re-scored; what it answers the exact passes skip
                 const int* need = nullptr;
                 const float xs = half_xscale(idx->row_norm_bound);
-                if (per_pass == 32 && use_half && half_rescue_dim(idx->d) && idx->ld == idx->d && k <= kRescueKeep && !idx->kn.disable_rescue &&
+                if (kRescueQueries % per_pass == 0 && use_half && half_rescue_dim(idx->d) && idx->ld == idx->d && k <= kRescueKeep && !idx->kn.disable_rescue &&
                     !idx->kn.disable_rerun_floor && xs > 0.f) {
                     const _Float16* Xh = ensure_shadow(idx, s, xs);
                     if (Xh) {
                         const int grid_ub = device_cus(idx->device);  // the rescue launch is one workgroup per CU
-                        MVDB_TRY(ws->need.reserve((size_t)(R + kRescueQueries) / 32 + 8));
+                        MVDB_TRY(ws->need.reserve((size_t)(R + kRescueQueries) / per_pass + 8));
                         MVDB_TRY(ws->cand.reserve((size_t)kRescueQueries * (grid_ub + 1) * kRescueKeep));
                         MVDB_TRY(ws->qsplit.reserve((size_t)2 * kRescueQueries * idx->d));
                         MVDB_TRY(ws->qnorm.reserve((size_t)3 * kRescueQueries));
-                        MVDB_HIP(hipMemsetAsync(ws->need.p, 0, ((size_t)(R + kRescueQueries) / 32 + 8) * sizeof(int), s));
+                        MVDB_HIP(hipMemsetAsync(ws->need.p, 0, ((size_t)(R + kRescueQueries) / per_pass + 8) * sizeof(int), s));
                         _Float16* qf = reinterpret_cast<_Float16*>(ws->qsplit.p);
                         float* qn2 = ws->qnorm.p;
                         float* qinv = qn2 + 2 * kRescueQueries;
@@ -1409,7 +1409,8 @@ int search_core(const mvdb_index* idx, Workspace* ws, const float* q_dev, int nq
                             rc.I = It + (int64_t)off2 * k;
                             rc.gate = ws->nfail.p;
                             rc.gate_lo = off2;
-                            rc.need = ws->need.p + off2 / 32;
+                            rc.need = ws->need.p + off2 / per_pass;
+                            rc.per_pass = per_pass;
                             MVDB_TRY(launch_half_rescue_certify(rc, s));
                         }
                         need = ws->need.p;

@@ -1170,7 +1170,7 @@ def test_add_does_not_synchronise_the_device(native):
     idx.close()
 
 
-@pytest.mark.parametrize("n,d,nq", [(300_000, 512, 96), (1_000_000, 384, 256)])
+@pytest.mark.parametrize("n,d,nq", [(300_000, 512, 96), (1_000_000, 384, 256), (200_000, 1024, 80), (250_000, 768, 40)])
 def test_refused_queries_rerun_from_an_admission_floor_with_identical_results(native, monkeypatch, n, d, nq):
     """A refused query's exact re-run starts its lists from the k-th exact score of the nominees (less a rounding margin) instead
     of -inf (half_certify_kernel -> gather_failed_kernel -> flat_scan_mfma2_gated_kernel).  On a clustered corpus — every batch
