@@ -1073,7 +1073,7 @@ static int launch_h16_inst(const HalfScanArgs& a, int device, hipStream_t stream
     *nblocks_out = nblocks;
     // (a launch without admission floors is the seed of an L2 pass over the shadow, mvdb.hip: launch_half_pass)
     const char* pname = a.thr0 ? "ip_scan_half" : "ip_scan_half_seed";
-    prof_symbol(pname, "flat_scan_h16_kernel<%d, %d, %d, %d>", KT, KS, WV, NST);
+    prof_symbol(pname, "flat_scan_h16_kernel<%d, %d, %d, %d, %d>", KT, KS, WV, NST, kHalfKeep);
     int slot = prof_begin(pname, stream);
     hipLaunchKernelGGL(kern, dim3(nblocks), dim3(WV * 64), lds, stream, a);
     prof_end(slot, stream);
