@@ -1225,6 +1225,43 @@ def test_refused_queries_rerun_from_an_admission_floor_with_identical_results(na
     np.testing.assert_allclose(np.sort(got["rescue"][0], axis=1), np.sort(got["floor"][0], axis=1), rtol=0, atol=2e-6)
 
 
+def test_rescue_pass_hands_an_overflowing_neighbourhood_to_the_exact_pass(native):
+    """60,000 rows within 1e-4 of one direction: for a query along it the rescue pass's 32-deep per-block lists fill (~230 rows
+    per block inside the band), the query's `need` word is raised and its exact fp32 pass runs; the other refused queries of the
+    batch are answered by the rescue pass.  Every result stands the float64 adjudication."""
+    n, d, k, nq = 200_000, 512, 10, 96
+    rs = np.random.RandomState(5)
+    x = _corpus(n, d)
+    v = rs.standard_normal(d).astype(np.float32)
+    v /= np.linalg.norm(v)
+    x[20_000:80_000] = v + 1e-4 * rs.standard_normal((60_000, d)).astype(np.float32)
+    flat.normalize_l2(x)
+    q = _corpus(nq, d, seed=41)
+    q[3] = v + 1e-3 * rs.standard_normal(d).astype(np.float32)
+    q[64] = -v                                   # the same neighbourhood at the bottom of the ranking: certifies
+    flat.normalize_l2(q)
+    idx = native.FlatIndex(d)
+    idx.add(x)
+    idx.search(q, k)                             # shadow, workspaces
+    native.prof_enable(True)
+    try:
+        for f in ("ip_scan_rescue", "ip_scan_rerun"):
+            native.prof_read(f)
+        before = native.split_rerun_count()
+        D, I = idx.search(q, k)
+        assert native.split_rerun_count() == before + 1
+        rescue, rerun = native.prof_read("ip_scan_rescue"), native.prof_read("ip_scan_rerun")
+    finally:
+        native.prof_enable(False)
+    assert rescue[0] == 1 and rescue[1] > 0.02, rescue       # the rescue launch ran ...
+    assert rerun[0] == 1 and rerun[1] > 0.03, rerun          # ... and so did the exact pass of the overflowing query
+    assert set(I[3].tolist()) <= set(range(20_000, 80_000))
+    for i in range(nq):
+        ok, msg = flat.adjudicate(x, q[i], k, D[i], I[i], tol=1e-4, tie_eps=2e-6)
+        assert ok, (i, msg)
+    idx.close()
+
+
 def test_single_query_shadow_route_suspends_itself_on_a_clustered_corpus(native):
     """The opt-in single-query route costs more than the exact scan when its certificate is refused.  On a clustered corpus (1M
     rows: every query's 10th and 64th best within 1e-3) every call is refused; the library notices within a window of 32 calls
