@@ -351,10 +351,25 @@ int mvdb_encoder_forward_device(mvdb_encoder* enc, const int32_t* ids_dev, const
  * which is what mvdb_encoder_forward's Python wrapper does on the host path.  Valid until mvdb_encoder_free. */
 const unsigned int* mvdb_encoder_overflow_flag(const mvdb_encoder* enc);
 
-/* 1 when a forward of B x S token slots runs as the ONE layer-walking launch (csrc/encoder_walk.hpp: at most 128 token slots —
- * one sentence per call is the reference's only shape, embedding_model.py:62-71 —, exact fp32 matrix cores whatever `compute`
- * says), 0 when it runs the per-op kernels.  MVDB_ENCODER_WALK=0 (read at mvdb_encoder_create) switches the launch off. */
+/* 1 when a forward of B x S token slots is of the shape the ONE layer-walking launch serves (csrc/encoder_walk.hpp: at most 128
+ * token slots — one sentence per call is the reference's only shape, embedding_model.py:62-71 —, exact fp32 matrix cores
+ * whatever `compute` says), 0 when it runs the per-op kernels.  MVDB_ENCODER_WALK=0 (read at mvdb_encoder_create) switches the
+ * launch off.  A forward of that shape still takes the per-op kernels when the caller is CAPTURING the stream, while another
+ * process holds the GPU's walking gate, and for a while after a launch was abandoned (next paragraph). */
 int mvdb_encoder_walks(const mvdb_encoder* enc, int B, int S);
+
+/* The walking launch is a persistent grid whose workgroups wait for each other, so it completes only when all of them are
+ * resident.  It is guarded three ways (csrc/encoder.hip "Walking launches ..."): one such launch at a time per device inside
+ * a process (whatever encoder, stream or host thread); an advisory flock on /dev/shm/mvdb_walk_<GPU UUID>.lock across
+ * processes (MVDB_WALK_LOCK=0 switches it off, MVDB_WALK_LOCK_DIR moves it); and BOUNDED waits inside the kernel: no wait
+ * outlasts MVDB_WALK_DEADLINE_US (default 20000, read when the encoder first walks) — the launch then abandons itself, fills
+ * `out` with NaN, raises the overflow word above and counts itself.  mvdb_encoder_forward notices that behind its own stream
+ * wait and re-runs the forward on the per-op kernels within the same call; a caller of mvdb_encoder_forward_device sees the
+ * overflow word (or `aborts` here) behind ITS stream wait and calls again.  After an abandoned launch the next 256 forwards of
+ * the encoder take the per-op kernels.  aborts = launches abandoned so far (completed ones), fallbacks = forwards
+ * mvdb_encoder_forward re-ran, suspended_calls = forwards left before the next walking attempt; any pointer may be NULL. */
+int mvdb_encoder_walk_stats(const mvdb_encoder* enc, unsigned long long* aborts, unsigned long long* fallbacks,
+                            int* suspended_calls);
 
 /* Which tile form of the split-precision GEMM a batch of `tokens` packed tokens selects for an N-wide product on a
  * device with `compute_units` CUs: 256 or 192 = the 256-row form on 256 x 256 / 256 x 192 tiles (one eight-wave workgroup

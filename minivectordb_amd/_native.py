@@ -119,6 +119,7 @@ PROTOTYPES = {
     "mvdb_encoder_gemm_tile_form": (ctypes.c_int, [ctypes.c_int64, ctypes.c_int, ctypes.c_int]),
     "mvdb_index_single_route_suspensions": (ctypes.c_longlong, [c_vp]),
     "mvdb_encoder_walks": (ctypes.c_int, [c_vp, ctypes.c_int, ctypes.c_int]),
+    "mvdb_encoder_walk_stats": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp]),
     "mvdb_encoder_overflow_flag": (c_vp, [c_vp]),
     "mvdb_encoder_forward": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_vp]),
     "mvdb_encoder_forward_device": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int,

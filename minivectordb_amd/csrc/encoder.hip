@@ -24,6 +24,13 @@
 //   * Q/K/V projections fused into one [3H,H] GEMM (weights concatenated once at create time).
 //   * bias / erf-GELU / residual fused into the GEMM epilogue; LayerNorm and pooling are
 //     one-wave-per-row kernels (HBM/L2-bound, tiny).
+#include <fcntl.h>
+#include <sys/file.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <cerrno>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <map>
@@ -2281,6 +2288,15 @@ struct mvdb_encoder {
                                                // stream — waits for it (forwards share the staging buffers, the workspace and the
                                                // walking launch's phase counters: two resident walking grids would never finish)
     int walk_np3 = 0, walk_grid = 0, walk_grid_env = 0;
+    // bounded waits (encoder_walk.hpp, Args::deadline): launches abandoned so far, on the device and mirrored into host-mapped
+    // memory; calls still to be served by the per-op kernels after an abandoned launch (the GPU is being shared with
+    // something that keeps the launch's workgroups from all being resident: do not pay the deadline on every call)
+    unsigned int* walk_aborts = nullptr;
+    unsigned int* walk_aborts_host = nullptr;  // hipHostMalloc'ed word (its device alias goes into the launch)
+    unsigned int walk_deadline = 0;            // ticks of s_memrealtime (100 MHz)
+    int walk_suspended = 0;
+    unsigned int walk_aborts_seen = 0;         // value of *walk_aborts_host the suspension was last decided on
+    unsigned long long walk_fallbacks = 0;     // forwards re-run on the per-op kernels after an abandoned launch
 
     void free_ws() {
         lane[0].release();
@@ -2693,34 +2709,113 @@ void launch_ln(const float* y, const int* seq_start, int B, const float* g, cons
 }
 
 
-// Walking launches are persistent grids whose workgroups spin on each other: two of them resident at once — two encoders
-// of one process on two streams — can each hold CUs the other's missing workgroups need, and neither finishes.  One walking
-// launch at a time per DEVICE: an event behind every launch, waited for by the next (whatever encoder or stream it comes
-// from).  Not while the caller captures the stream (a captured launch cannot wait for an outside event: callers that capture
-// walking launches of several encoders replay them on one stream).  Two PROCESSES walking on one GPU are not ordered.
-std::mutex g_walk_mu;
+// Walking launches are persistent grids whose workgroups spin on each other: two of them resident at once can each hold CUs the
+// other's missing workgroups need.  Three guards, from cheap to last resort:
+//  1. IN THE PROCESS: one walking launch at a time per DEVICE — an event behind every launch, waited for by the next (whatever
+//     encoder, stream or host thread it comes from), and g_walk_mu held across [wait for that event, launch, record it] so
+//     that two host threads cannot both enqueue behind the same predecessor (WalkTurn).
+//  2. ACROSS PROCESSES: an advisory flock on a file named after the GPU's UUID, held from before the launch until the launch
+//     has completed (the host entry waits for its stream anyway; the device entry releases it from a host callback behind
+//     the launch).  It is advisory: a process that cannot have it within kGateWaitUs runs that forward on the per-op kernels.
+//  3. IN THE KERNEL: every wait is bounded (encoder_walk.hpp, Args::deadline).  A launch that cannot complete — a foreign
+//     persistent kernel, a process that ignores the lock — abandons itself, is counted (mvdb_encoder_walk_aborts) and its
+//     forward re-runs on the per-op kernels; the GPU is never wedged.
+// A caller that CAPTURES the stream gets the per-op kernels: a captured launch can take part in none of 1 and 2.
+std::mutex g_walk_mu;   // the enqueue order of walking launches
+std::mutex g_gate_mu;   // the gates' bookkeeping only: never held across a HIP call (gate_release runs in a host callback)
 struct WalkOrder {
     hipEvent_t done = nullptr;
     hipStream_t last = nullptr;  // stream of the last walking launch: the next one on the SAME stream is ordered by the stream
     bool any = false;
 };
+struct WalkGate {
+    int fd = -2;       // -2: not opened yet, -1: no lock file to be had (guard 3 alone)
+    int inflight = 0;  // walking launches of THIS process between acquire and release: the flock is held while > 0
+};
 std::map<int, WalkOrder> g_walk_order;
+std::map<int, WalkGate> g_walk_gate;
+constexpr int kGateWaitUs = 50000;
+constexpr int kWalkSuspendCalls = 256;  // forwards on the per-op kernels after an abandoned launch, before the next attempt
 
-int walk_serialize_begin(int device, hipStream_t s) {
-    std::lock_guard<std::mutex> lk(g_walk_mu);
-    WalkOrder& o = g_walk_order[device];
-    if (!o.done) MVDB_HIP(hipEventCreateWithFlags(&o.done, hipEventDisableTiming));
-    if (o.any && o.last != s) MVDB_HIP(hipStreamWaitEvent(s, o.done, 0));
-    return 0;
+int gate_open(int device) {
+    const char* off = getenv("MVDB_WALK_LOCK");
+    if (off && *off == '0') return -1;
+    hipUUID u;
+    char name[80];
+    if (hipDeviceGetUuid(&u, device) == hipSuccess) {
+        char hex[33];
+        for (int i = 0; i < 16; ++i) snprintf(hex + 2 * i, 3, "%02x", (unsigned char)u.bytes[i]);
+        snprintf(name, sizeof(name), "mvdb_walk_%s.lock", hex);
+    } else {
+        (void)hipGetLastError();
+        char bus[32] = {0};
+        if (hipDeviceGetPCIBusId(bus, sizeof(bus), device) != hipSuccess) {
+            (void)hipGetLastError();
+            snprintf(bus, sizeof(bus), "dev%d", device);
+        }
+        for (char* c = bus; *c; ++c)
+            if (*c == ':' || *c == '.' || *c == '/') *c = '_';
+        snprintf(name, sizeof(name), "mvdb_walk_%s.lock", bus);
+    }
+    const char* dirs[] = {getenv("MVDB_WALK_LOCK_DIR"), "/dev/shm", "/tmp"};
+    for (const char* d : dirs) {
+        if (!d || !*d) continue;
+        char path[256];
+        snprintf(path, sizeof(path), "%s/%s", d, name);
+        const int fd = open(path, O_RDWR | O_CREAT | O_CLOEXEC, 0666);
+        if (fd >= 0) {
+            (void)fchmod(fd, 0666);  // other users' processes share the GPU too
+            return fd;
+        }
+    }
+    return -1;
 }
-int walk_serialize_end(int device, hipStream_t s) {
-    std::lock_guard<std::mutex> lk(g_walk_mu);
-    WalkOrder& o = g_walk_order[device];
-    MVDB_HIP(hipEventRecord(o.done, s));
-    o.last = s;
-    o.any = true;
-    return 0;
+
+// 1: this process holds the device's gate (or there is no lock file); 0: another process kept it for kGateWaitUs
+int gate_acquire(int device) {
+    std::lock_guard<std::mutex> lk(g_gate_mu);
+    WalkGate& g = g_walk_gate[device];
+    if (g.fd == -2) g.fd = gate_open(device);
+    if (g.fd >= 0 && g.inflight == 0) {
+        const auto t0 = std::chrono::steady_clock::now();
+        while (flock(g.fd, LOCK_EX | LOCK_NB) != 0) {
+            if (errno != EWOULDBLOCK && errno != EINTR) {  // the file system does not lock: guard 3 alone from now on
+                close(g.fd);
+                g.fd = -1;
+                break;
+            }
+            if (std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > kGateWaitUs) return 0;
+            usleep(20);
+        }
+    }
+    ++g.inflight;
+    return 1;
 }
+void gate_release(int device) {
+    std::lock_guard<std::mutex> lk(g_gate_mu);
+    WalkGate& g = g_walk_gate[device];
+    if (g.inflight > 0 && --g.inflight == 0 && g.fd >= 0) (void)flock(g.fd, LOCK_UN);
+}
+void gate_release_cb(void* p) { gate_release((int)(intptr_t)p); }
+
+// guard 1: constructed before the launch, `launched(s)` records the order event; holds g_walk_mu in between
+struct WalkTurn {
+    std::unique_lock<std::mutex> lk;
+    WalkOrder* o = nullptr;
+    int begin(int device, hipStream_t s) {
+        lk = std::unique_lock<std::mutex>(g_walk_mu);
+        o = &g_walk_order[device];
+        if (!o->done) MVDB_HIP(hipEventCreateWithFlags(&o->done, hipEventDisableTiming));
+        if (o->any && o->last != s) MVDB_HIP(hipStreamWaitEvent(s, o->done, 0));
+        return 0;
+    }
+    int launched(hipStream_t s) {
+        MVDB_HIP(hipEventRecord(o->done, s));
+        o->last = s;
+        o->any = true;
+        return 0;
+    }
+};
 
 // ---- the layer-walking launch for small batches (encoder_walk.hpp) ------------------------------------------------------
 // Eligible: at most walk::kTmax token slots, widths the column units tile (H, F multiples of 16, H <= 1024).
@@ -2754,6 +2849,16 @@ int ensure_walk(mvdb_encoder* e) {
     MVDB_TRY(dev_alloc(&e->walk_pl, planes * walk::kTmax * H));
     MVDB_TRY(dev_alloc(&e->walk_bar, walk::kCtrCount * walk::kReplicas * walk::kCtrStride));
     MVDB_HIP(hipMemset(e->walk_bar, 0, walk::kCtrCount * walk::kReplicas * walk::kCtrStride * sizeof(unsigned int)));
+    MVDB_TRY(dev_alloc(&e->walk_aborts, 1));
+    MVDB_HIP(hipMemset(e->walk_aborts, 0, sizeof(unsigned int)));
+    MVDB_HIP(hipHostMalloc((void**)&e->walk_aborts_host, sizeof(unsigned int), hipHostMallocMapped));
+    *e->walk_aborts_host = 0u;
+    {
+        // no wait of a launch outlasts this (default 20 ms >> the 0.25 - 2.4 ms of a forward, << anything a watchdog would notice)
+        const char* v = getenv("MVDB_WALK_DEADLINE_US");
+        const long long us = v && *v ? atoll(v) : 20000;
+        e->walk_deadline = (unsigned int)std::min<long long>(std::max<long long>(us, 0) * 100, 0x7fffffffLL);  // s_memrealtime: 100 MHz
+    }
     walk::LayerPtrs* dev = nullptr;
     MVDB_TRY(dev_alloc(&dev, (int64_t)lp.size()));
     MVDB_HIP(hipMemcpy(dev, lp.data(), lp.size() * sizeof(walk::LayerPtrs), hipMemcpyHostToDevice));
@@ -2803,6 +2908,9 @@ int launch_walk(mvdb_encoder* e, const int32_t* ids, const int32_t* mask, int B,
     a.out = out;
     a.hidden = hidden;
     a.np3 = e->walk_np3;
+    a.deadline = e->walk_deadline;
+    a.aborts = e->walk_aborts;
+    MVDB_HIP(hipHostGetDevicePointer((void**)&a.aborts_host, e->walk_aborts_host, 0));
     const int ntiles = c.hidden / 16;
     const int slots = B * S;
     // <= 16 / <= 32 token slots: one / two row tiles per column unit; more: two tiles and the units split by row groups of 32 too
@@ -3053,8 +3161,12 @@ int enqueue_forward(mvdb_encoder* e, const int32_t* ids, const int32_t* mask, in
     return 0;
 }
 
+// walk_mode: 0 = per-op kernels whatever the shape; 1 = the walking launch where it applies, the CALLER waits for the stream
+// and then releases the device's gate (when *walked comes back true); 2 = the same, the gate released by a host callback
+// behind the launch (the device entry never waits).
 int forward_core(mvdb_encoder* e, const int32_t* ids, const int32_t* mask, int B, int S, int compute,
-                 float* out, float* hidden, hipStream_t s) {
+                 float* out, float* hidden, hipStream_t s, int walk_mode = 0, bool* walked = nullptr) {
+    if (walked) *walked = false;
     if (compute != 0 && compute != 2)
         return fail(MVDB_ERR_ARG, "unknown compute mode %d (0 = exact-fp32 MFMA, 2 = split-precision fp16 x 3; 1, the single-bf16-product "
                                   "mode of earlier builds, was removed: slower and less exact than 2)", compute);
@@ -3062,17 +3174,39 @@ int forward_core(mvdb_encoder* e, const int32_t* ids, const int32_t* mask, int B
     if (B <= 0 || S <= 0) return fail(MVDB_ERR_ARG, "B and S must be positive");
     if (S + (c.position_offset > 0 ? c.position_offset : 0) > c.max_positions)
         return fail(MVDB_ERR_ARG, "sequence length %d exceeds max_positions %d", S, c.max_positions);
-    if (walk_eligible(e, B, S)) {
-        // <= 128 token slots (one sentence per call is the reference's only shape): ONE launch walks the layers, exact fp32 in
-        // both modes; a plain launch (no graph: one node) that also joins a caller's capture
+    if (walk_mode && walk_eligible(e, B, S)) {
+        // <= walk::kTmax token slots (one sentence per call is the reference's only shape): ONE launch walks the layers, exact
+        // fp32 in both modes — unless the caller captures the stream (a captured launch can take no part in the ordering of
+        // walking launches: per-op kernels, which are capturable), launches of this encoder were abandoned lately, or another
+        // process holds the device's gate.
         hipStreamCaptureStatus cap0 = hipStreamCaptureStatusNone;
         const bool captured = s && hipStreamIsCapturing(s, &cap0) == hipSuccess && cap0 != hipStreamCaptureStatusNone;
-        const int pslot0 = captured ? -1 : prof_begin("encoder", s);
-        if (!captured) MVDB_TRY(walk_serialize_begin(e->device, s));  // (the launch clears the overflow flag itself: exact fp32)
-        const int rc0 = launch_walk(e, ids, mask, B, S, out, hidden, s);
-        if (!captured && !rc0) MVDB_TRY(walk_serialize_end(e->device, s));
-        prof_end(pslot0, s);
-        return rc0;
+        if (e->walk_aborts_host && *e->walk_aborts_host != e->walk_aborts_seen) {  // (mirrors of COMPLETED launches)
+            e->walk_aborts_seen = *e->walk_aborts_host;
+            e->walk_suspended = kWalkSuspendCalls;
+        }
+        if (e->walk_suspended > 0) --e->walk_suspended;
+        else if (!captured && gate_acquire(e->device)) {
+            const int pslot0 = prof_begin("encoder", s);
+            WalkTurn turn;
+            int rc0 = turn.begin(e->device, s);
+            if (!rc0) rc0 = launch_walk(e, ids, mask, B, S, out, hidden, s);  // (clears the overflow flag itself: exact fp32)
+            if (!rc0) rc0 = turn.launched(s);
+            prof_end(pslot0, s);
+            if (rc0 || walk_mode == 2) {
+                if (rc0 || hipLaunchHostFunc(s, gate_release_cb, (void*)(intptr_t)e->device) != hipSuccess) {
+                    (void)hipGetLastError();
+                    if (!rc0) (void)hipStreamSynchronize(s);
+                    gate_release(e->device);
+                }
+            } else if (walked) {
+                *walked = true;
+            } else {
+                (void)hipStreamSynchronize(s);
+                gate_release(e->device);
+            }
+            return rc0;
+        }
     }
     if (compute == 2) {
         if (c.hidden % HBK || c.intermediate % HBK)
@@ -3251,6 +3385,14 @@ int mvdb_encoder_create(const mvdb_encoder_cfg* cfg, const void* const* w, int d
 
 const unsigned int* mvdb_encoder_overflow_flag(const mvdb_encoder* e) { return e ? e->overflow_flag : nullptr; }
 
+int mvdb_encoder_walk_stats(const mvdb_encoder* e, unsigned long long* aborts, unsigned long long* fallbacks, int* suspended_calls) {
+    if (!e) return fail(MVDB_ERR_ARG, "encoder is NULL");
+    if (aborts) *aborts = e->walk_aborts_host ? *e->walk_aborts_host : 0u;
+    if (fallbacks) *fallbacks = e->walk_fallbacks;
+    if (suspended_calls) *suspended_calls = e->walk_suspended;
+    return 0;
+}
+
 int mvdb_encoder_walks(const mvdb_encoder* e, int B, int S) {
     return e && B > 0 && S > 0 && walk_eligible(e, B, S) ? 1 : 0;
 }
@@ -3281,6 +3423,8 @@ int mvdb_encoder_free(mvdb_encoder* e) {
         if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
         if (e->ev_join) (void)hipEventDestroy(e->ev_join);
         if (e->walk_done) (void)hipEventDestroy(e->walk_done);
+        if (e->walk_aborts) (void)hipFree(e->walk_aborts);
+        if (e->walk_aborts_host) (void)hipHostFree(e->walk_aborts_host);
         e->walk_pin.release();
     }
     delete e;
@@ -3318,7 +3462,7 @@ int mvdb_encoder_forward_device(mvdb_encoder* e, const int32_t* ids_dev, const i
     DeviceGuard dg(e->device);
     hipStream_t s = (hipStream_t)stream;
     if (hidden_dev || !s)  // diagnostic output, or the legacy NULL stream (not capturable): plain launches
-        return forward_core(e, ids_dev, mask_dev, B, S, compute, out_dev, hidden_dev, s);
+        return forward_core(e, ids_dev, mask_dev, B, S, compute, out_dev, hidden_dev, s, 2);
     // Route through the encoder's own staging buffers so that the captured graph (keyed by buffer
     // addresses) is reused whatever tensors the caller passes: three small device-to-device copies.
     const int64_t tokens = (int64_t)B * S, outn = (int64_t)B * e->cfg.hidden;
@@ -3333,7 +3477,7 @@ int mvdb_encoder_forward_device(mvdb_encoder* e, const int32_t* ids_dev, const i
     }
     MVDB_HIP(hipMemcpyAsync(e->ids_stage, ids_dev, tokens * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
     MVDB_HIP(hipMemcpyAsync(e->mask_stage, mask_dev, tokens * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
-    MVDB_TRY(forward_core(e, e->ids_stage, e->mask_stage, B, S, compute, e->out_stage, nullptr, s));
+    MVDB_TRY(forward_core(e, e->ids_stage, e->mask_stage, B, S, compute, e->out_stage, nullptr, s, 2));
     MVDB_HIP(hipMemcpyAsync(out_dev, e->out_stage, outn * sizeof(float), hipMemcpyDeviceToDevice, s));
     if (!capturing) MVDB_HIP(hipEventRecord(e->walk_done, s));
     return 0;
@@ -3352,6 +3496,15 @@ int mvdb_encoder_forward(mvdb_encoder* e, const int32_t* ids_host, const int32_t
         if (mask_host[i] && (ids_host[i] < 0 || ids_host[i] >= e->cfg.vocab_size))
             return fail(MVDB_ERR_ARG, "token id %d at %lld outside the vocabulary [0,%d)", ids_host[i],
                         (long long)i, e->cfg.vocab_size);
+    // A walking launch that was abandoned (bounded waits, encoder_walk.hpp) has counted itself in *walk_aborts_host by the
+    // time the stream is idle: the forward runs again, on the per-op kernels, within this call.
+    auto abandoned = [&](unsigned int before) {
+        if (!e->walk_aborts_host || *e->walk_aborts_host == before) return false;
+        ++e->walk_fallbacks;
+        return true;
+    };
+    const unsigned int aborts_before = e->walk_aborts_host ? *e->walk_aborts_host : 0u;
+    bool walked = false;
     if (walk_eligible(e, B, S) && e->opt_walk_pinned) {
         // ONE sentence per call: the launch reads the ids and the mask from host-mapped memory and writes the embedding there —
         // no copy engine work at all around it (two H2D copies, a memset and a D2H copy before: ~20 us of a 0.27 ms call)
@@ -3363,8 +3516,14 @@ int mvdb_encoder_forward(mvdb_encoder* e, const int32_t* ids_host, const int32_t
         memcpy(pin_ids, ids_host, tokens * sizeof(int32_t));
         memcpy(pin_mask, mask_host, tokens * sizeof(int32_t));
         if (e->walk_done) MVDB_HIP(hipStreamWaitEvent(e->stream, e->walk_done, 0));
-        MVDB_TRY(forward_core(e, pin_ids, pin_mask, B, S, compute, pin_out, nullptr, e->stream));
-        MVDB_HIP(hipStreamSynchronize(e->stream));
+        int rc = forward_core(e, pin_ids, pin_mask, B, S, compute, pin_out, nullptr, e->stream, 1, &walked);
+        if (!rc && hipStreamSynchronize(e->stream) != hipSuccess) rc = fail(MVDB_ERR_HIP, "encoder forward failed: %s", hipGetErrorString(hipGetLastError()));
+        if (walked) gate_release(e->device);
+        if (rc) return rc;
+        if (walked && abandoned(aborts_before)) {  // (the per-op kernels read the same host-mapped buffers)
+            MVDB_TRY(forward_core(e, pin_ids, pin_mask, B, S, compute, pin_out, nullptr, e->stream, 0));
+            MVDB_HIP(hipStreamSynchronize(e->stream));
+        }
         memcpy(out_host, pin_out, outn * sizeof(float));
         return 0;
     }
@@ -3372,9 +3531,15 @@ int mvdb_encoder_forward(mvdb_encoder* e, const int32_t* ids_host, const int32_t
     if (e->walk_done) MVDB_HIP(hipStreamWaitEvent(e->stream, e->walk_done, 0));  // a device-entry forward may still be running
     MVDB_HIP(hipMemcpyAsync(e->ids_stage, ids_host, tokens * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
     MVDB_HIP(hipMemcpyAsync(e->mask_stage, mask_host, tokens * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
-    MVDB_TRY(forward_core(e, e->ids_stage, e->mask_stage, B, S, compute, e->out_stage, nullptr, e->stream));
-    MVDB_HIP(hipMemcpyAsync(out_host, e->out_stage, outn * sizeof(float), hipMemcpyDeviceToHost, e->stream));
-    MVDB_HIP(hipStreamSynchronize(e->stream));
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        int rc = forward_core(e, e->ids_stage, e->mask_stage, B, S, compute, e->out_stage, nullptr, e->stream, attempt == 0 ? 1 : 0, &walked);
+        if (!rc && hipMemcpyAsync(out_host, e->out_stage, outn * sizeof(float), hipMemcpyDeviceToHost, e->stream) != hipSuccess)
+            rc = fail(MVDB_ERR_HIP, "copy of the embeddings failed: %s", hipGetErrorString(hipGetLastError()));
+        if (!rc && hipStreamSynchronize(e->stream) != hipSuccess) rc = fail(MVDB_ERR_HIP, "encoder forward failed: %s", hipGetErrorString(hipGetLastError()));
+        if (walked) gate_release(e->device);
+        if (rc) return rc;
+        if (!(walked && abandoned(aborts_before))) break;
+    }
     return 0;
 }
 

@@ -69,6 +69,14 @@ struct Args {
     int nsplit;               // column splits of the out-projection per (sentence, head)
     int off_rows, off_qkv, off_attn, off_ffn;  // first workgroup of the row phases (embeddings, sum + LN, pooling) / QKV / attention / FFN
     unsigned long long* trace;  // NULL, or [G][kTraceSlots] s_memrealtime stamps (ablation build: mvdb_debug_walk_trace)
+    // BOUNDED WAITS.  No wait of the launch outlasts `deadline` ticks of s_memrealtime (100 MHz) counted from the waiting
+    // workgroup's own start: the poller that sees it expire raises kAbortBit in every phase counter, which releases every
+    // other poller (a counter with the bit set is >= any target), every workgroup leaves the phase chain at its next wait,
+    // and the last one out counts the aborted launch in `aborts` (device word), mirrors the count into `aborts_host`
+    // (host-mapped) and fills `out` with NaN before it re-arms the counters.  The host entries then run the per-op kernels.
+    unsigned int deadline;      // ticks
+    unsigned int* aborts;       // device word: launches of this encoder that were aborted
+    unsigned int* aborts_host;  // host-mapped mirror of the count (read by the host entry behind its stream wait)
 };
 constexpr int kTraceSlots = 512;
 
@@ -120,19 +128,44 @@ __device__ __forceinline__ void phase_arrive(unsigned int* bar, int ctr) {
     if (threadIdx.x < kReplicas) __hip_atomic_fetch_add(ctr_word(bar, ctr, threadIdx.x), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// A counter word with this bit set releases every waiter: the launch is being abandoned (Args::deadline).
+constexpr unsigned int kAbortBit = 0x80000000u;
+struct WaitCtx {
+    unsigned long long t0;  // s_memrealtime when this workgroup started
+    unsigned int deadline;  // ticks (100 MHz)
+    int* lds_abort;         // one word of LDS, 0 until a wait of this workgroup was released by kAbortBit
+};
+__device__ __forceinline__ void raise_abort(unsigned int* bar) {
+    for (int c = 0; c < kCtrExit; ++c)
+        for (int rep = 0; rep < kReplicas; ++rep)
+            __hip_atomic_fetch_or(ctr_word(bar, c, rep), kAbortBit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // Wait until the `producers` workgroups of a phase have each arrived `epochs` times at counter `ctr`: one lane polls its
-// replica with L1-bypassing loads, the workgroup meets.
-__device__ __forceinline__ void phase_wait(unsigned int* bar, int ctr, unsigned int epochs, unsigned int producers) {
+// replica with L1-bypassing loads, the workgroup meets.  Returns true (to every thread) when the launch is being abandoned:
+// the caller leaves the phase chain.  The clock is read only after a poll that found the phase incomplete.
+__device__ __forceinline__ bool phase_wait(unsigned int* bar, int ctr, unsigned int epochs, unsigned int producers, const WaitCtx& wc) {
     if (threadIdx.x == 0) {
         const unsigned int target = epochs * producers;
         const unsigned int* w = ctr_word(bar, ctr, blockIdx.x & (kReplicas - 1));
-        while (__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
+        unsigned int v;
+        while ((v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < target) {
+            if (__builtin_amdgcn_s_memrealtime() - wc.t0 > (unsigned long long)wc.deadline) {
+                raise_abort(bar);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the bits have landed before this workgroup can be counted out
+                v = kAbortBit;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        if (v & kAbortBit) *wc.lds_abort = 1;
 #ifdef MVDB_WALK_ACQUIRE_LOADS
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // buffer_inv sc1: this CU's L1 forgets what other CUs have rewritten
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the workgroup barrier below holds until the invalidate has completed
 #endif
     }
     __syncthreads();
+    return *wc.lds_abort != 0;
 }
 
 // sum over the workgroup (all kThreads threads call it); red8: 8 floats of LDS
@@ -407,6 +440,9 @@ __global__ __launch_bounds__(kThreads) void encoder_walk_kernel(const Args a) {
     int* s_slot_p = s_tok_pos + kTmax;              // [128] token slot (b * S + t) -> packed token, or -1
     int* s_seq = s_slot_p + kTmax;                  // [B + 1 <= 129] first packed token of each sentence
     float* red8 = lds + kLdsHead - 8;               // [8]
+    int* s_abort = reinterpret_cast<int*>(lds + kLdsHead - 9);  // set when a wait of this workgroup was released by kAbortBit
+    if (threadIdx.x == 0) *s_abort = 0;
+    const WaitCtx wc{__builtin_amdgcn_s_memrealtime(), a.deadline, s_abort};
     float* work = lds + kLdsHead;                   // phase scratch (16-byte aligned)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wg = blockIdx.x, G = gridDim.x;
@@ -521,7 +557,7 @@ __global__ __launch_bounds__(kThreads) void encoder_walk_kernel(const Args a) {
                             colunit_load_w<HC>(L.wqkv + (int64_t)u * 16 * H, H, wa, lane, wave);
                             if (first) {
                                 stamp(trace, layer, 0, 0);
-                                phase_wait(a.bar, in_ctr, in_epochs, prodRow);
+                                if (phase_wait(a.bar, in_ctr, in_epochs, prodRow, wc)) goto walk_out;
                                 stamp(trace, layer, 0, 1);
                                 first = false;
                             }
@@ -532,7 +568,7 @@ __global__ __launch_bounds__(kThreads) void encoder_walk_kernel(const Args a) {
                             colunit_load_w_batch<CB>(L.wqkv + (int64_t)u * 16 * H, H, H >> 4, 0, w0, lane, wave);
                             if (first) {
                                 stamp(trace, layer, 0, 0);
-                                phase_wait(a.bar, in_ctr, in_epochs, prodRow);
+                                if (phase_wait(a.bar, in_ctr, in_epochs, prodRow, wc)) goto walk_out;
                                 stamp(trace, layer, 0, 1);
                                 first = false;
                             }
@@ -569,7 +605,7 @@ __global__ __launch_bounds__(kThreads) void encoder_walk_kernel(const Args a) {
                         outproj_load_w(L.wo, H, h, hd, min(nt0 + wave, ntiles - 1), wo0, lane);
                         if (first) {
                             stamp(trace, layer, 1, 0);
-                            phase_wait(a.bar, kCtrQkv, lay1, prodQkv);
+                            if (phase_wait(a.bar, kCtrQkv, lay1, prodQkv, wc)) goto walk_out;
                             stamp(trace, layer, 1, 1);
                             first = false;
                         }
@@ -615,7 +651,7 @@ __global__ __launch_bounds__(kThreads) void encoder_walk_kernel(const Args a) {
             if (wr < (int)prodRow) {
                 const LnWeights lw = ln_load_w(L.bo, L.ln1g, L.ln1b, H, tid);
                 stamp(trace, layer, 2, 0);
-                phase_wait(a.bar, kCtrAttn, lay1, prodAttn);
+                if (phase_wait(a.bar, kCtrAttn, lay1, prodAttn, wc)) goto walk_out;
                 stamp(trace, layer, 2, 1);
                 phase_reduce_ln(a, PLr, a.heads, lw, Xr, X1r, T, reinterpret_cast<f32x4*>(work), red8, wr, G, tid, lane, wave, trace, layer);
                 stamp(trace, layer, 2, 2);
@@ -636,7 +672,7 @@ __global__ __launch_bounds__(kThreads) void encoder_walk_kernel(const Args a) {
                         colunit_load_w_batch<CB>(L.w1 + (int64_t)j * 16 * H, H, H >> 4, 0, w0, lane, wave);
                         if (first) {
                             stamp(trace, layer, 5, 0);
-                            phase_wait(a.bar, kCtrLn1, lay1, prodRow);
+                            if (phase_wait(a.bar, kCtrLn1, lay1, prodRow, wc)) goto walk_out;
                             stamp(trace, layer, 5, 1);
                             first = false;
                         }
@@ -670,7 +706,7 @@ __global__ __launch_bounds__(kThreads) void encoder_walk_kernel(const Args a) {
                         colunit_load_w_batch<CB>(L.w2 + (int64_t)nt * 16 * F + (live ? k0 : 0), F, nch, 0, w0, lane, wave);
                         if (first) {
                             stamp(trace, layer, 3, 0);
-                            phase_wait(a.bar, kCtrFfn1, lay1, prodFfn1);
+                            if (phase_wait(a.bar, kCtrFfn1, lay1, prodFfn1, wc)) goto walk_out;
                             stamp(trace, layer, 3, 1);
                             first = false;
                         }
@@ -719,7 +755,7 @@ __global__ __launch_bounds__(kThreads) void encoder_walk_kernel(const Args a) {
                         }
                         if (first) {
                             stamp(trace, layer, 3, 0);
-                            phase_wait(a.bar, kCtrLn1, lay1, prodRow);
+                            if (phase_wait(a.bar, kCtrLn1, lay1, prodRow, wc)) goto walk_out;
                             stamp(trace, layer, 3, 1);
                             first = false;
                         }
@@ -765,7 +801,7 @@ __global__ __launch_bounds__(kThreads) void encoder_walk_kernel(const Args a) {
             if (wr < (int)prodRow) {
                 const LnWeights lw = ln_load_w(L.b2, L.ln2g, L.ln2b, H, tid);
                 stamp(trace, layer, 4, 0);
-                phase_wait(a.bar, kCtrFfn, lay1, prodFfn);
+                if (phase_wait(a.bar, kCtrFfn, lay1, prodFfn, wc)) goto walk_out;
                 stamp(trace, layer, 4, 1);
                 phase_reduce_ln(a, PLr, ffn_planes, lw, X1r, Xr, T, reinterpret_cast<f32x4*>(work), red8, wr, G, tid, lane, wave);
                 stamp(trace, layer, 4, 2);
@@ -776,7 +812,7 @@ __global__ __launch_bounds__(kThreads) void encoder_walk_kernel(const Args a) {
 
     // ---- pooling + L2 normalise (average_pool + F.normalize(eps = 1e-12); pooling 1: first valid token) ------------------------
     if (wr < a.B || (a.hidden && wr < a.B * a.S)) {
-        if (T > 0) phase_wait(a.bar, kCtrLn2, (unsigned int)a.nlayers, prodRow);
+        if (T > 0 && phase_wait(a.bar, kCtrLn2, (unsigned int)a.nlayers, prodRow, wc)) goto walk_out;
         for (int b = wr; b < a.B; b += G) {
             const int s0 = s_seq[b], len = s_seq[b + 1] - s0;
             const int span = a.pooling == 1 ? (len > 0 ? 1 : 0) : len;
@@ -814,14 +850,29 @@ __global__ __launch_bounds__(kThreads) void encoder_walk_kernel(const Args a) {
         trace[kTraceSlots - 1] = __builtin_amdgcn_s_memrealtime();
         trace[kTraceSlots - 3] = __builtin_readcyclecounter();
     }
-    // ---- the last workgroup out re-arms the counters for the next launch ------------------------------------------------------
+walk_out:
+    // ---- the last workgroup out re-arms the counters for the next launch; an abandoned launch is counted and its output ----
+    // ---- poisoned (NaN) so that nobody mistakes it for an embedding ----------------------------------------------------------
     __syncthreads();
     if (tid == 0) {
         const unsigned int left = __hip_atomic_fetch_add(ctr_word(a.bar, kCtrExit, 0), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int last = 0;
         if (left == (unsigned int)G - 1u) {
+            const bool aborted = (__hip_atomic_load(ctr_word(a.bar, kCtrEmbed, 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & kAbortBit) != 0;
+            last = aborted ? 2 : 1;
             for (int i = 0; i < kCtrCount * kReplicas; ++i)
                 __hip_atomic_store(a.bar + i * kCtrStride, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (aborted) {
+                const unsigned int n = __hip_atomic_fetch_add(a.aborts, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+                __hip_atomic_store(a.aborts_host, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (a.flag) *a.flag = 1u;  // what a caller of the device entry tests behind its own stream wait
+            }
         }
+        *s_abort = last;
+    }
+    __syncthreads();
+    if (*s_abort == 2) {  // every other workgroup has left: nobody writes `out` any more
+        for (int i = tid; i < a.B * H; i += kThreads) a.out[i] = __builtin_nanf("");
     }
 }
 

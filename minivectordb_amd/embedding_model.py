@@ -102,8 +102,15 @@ class GpuEncoder:
             pass
 
     def walks(self, B, S):
-        """True when a [B,S] forward runs as the one layer-walking launch (<= 128 token slots, exact fp32 in both modes)."""
+        """True when a [B,S] forward is of the shape the one layer-walking launch serves (exact fp32 in both modes)."""
         return bool(self._native.lib().mvdb_encoder_walks(self._h, int(B), int(S)))
+
+    def walk_stats(self):
+        """Walking launches abandoned by their bounded waits, forwards the host entry re-ran on the per-op kernels, and forwards
+        left on the per-op kernels before the next walking attempt (include/mvdb.h: mvdb_encoder_walk_stats)."""
+        a, f, n = ctypes.c_ulonglong(0), ctypes.c_ulonglong(0), ctypes.c_int(0)
+        self._native.check(self._native.lib().mvdb_encoder_walk_stats(self._h, ctypes.byref(a), ctypes.byref(f), ctypes.byref(n)))
+        return {"aborts": int(a.value), "fallbacks": int(f.value), "suspended_calls": int(n.value)}
 
     def forward(self, ids, mask, compute=None):
         """ids, mask: int arrays [B,S] (host).  Returns pooled + normalised float32 [B,H]."""

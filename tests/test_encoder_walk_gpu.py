@@ -194,3 +194,183 @@ def test_walk_launches_of_two_encoders_are_ordered_on_the_device(gpu):
         np.testing.assert_allclose(o.cpu().numpy(), want[i], atol=2e-5, rtol=0)
     for e in encs:
         e.close()
+
+
+def test_walk_abandoned_by_its_deadline_falls_back_to_the_per_op_kernels(gpu, monkeypatch):
+    """Bounded waits (encoder_walk.hpp, Args::deadline): with a deadline of 0 us the first wait that finds its phase incomplete
+    abandons the launch.  The launch must END (no hang), count itself, poison its output — and the host entry must return the
+    embedding all the same, from the per-op kernels, within the same call.  Then the encoder stays on the per-op kernels for
+    a while and finally walks again."""
+    import torch
+    monkeypatch.setenv("MVDB_WALK_DEADLINE_US", "0")
+    cfg = E.make_config("e5-small-dims")
+    w = E.make_weights(cfg, 41)
+    ids, mask = E.make_inputs(cfg, 1, 40, 42)
+    _, e64 = E.numpy_forward(cfg, w, ids, mask)
+    enc = _model(cfg, w)
+    assert enc.walks(1, 40)
+    got = enc.forward(ids, mask)
+    np.testing.assert_allclose(got, e64, atol=2e-5, rtol=0)
+    st = enc.walk_stats()
+    assert st["aborts"] == 1 and st["fallbacks"] == 1, st
+    # the next calls do not pay the deadline again: they are served by the per-op kernels, identical bits
+    for _ in range(5):
+        assert np.array_equal(enc.forward(ids, mask), got)
+    st = enc.walk_stats()
+    assert st["aborts"] == 1 and st["fallbacks"] == 1 and 0 < st["suspended_calls"] < 256, st
+    # the device entry: the abandoned launch poisons `out` and raises the overflow word; rerun_on_overflow=True recovers
+    enc2 = _model(cfg, w)
+    dev = torch.device("cuda", 0)
+    ti, tm = torch.from_numpy(ids).to(dev), torch.from_numpy(mask).to(dev)
+    out, _ = enc2.forward_device(ti, tm)
+    torch.cuda.synchronize()
+    assert torch.isnan(out).all() and int(enc2.overflow_flag().item()) == 1
+    assert enc2.walk_stats()["aborts"] == 1
+    out, _ = enc2.forward_device(ti, tm, rerun_on_overflow=True)   # (suspended by now: per-op kernels)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(out.cpu().numpy(), e64, atol=2e-5, rtol=0)
+    enc.close()
+    enc2.close()
+    # with the default deadline nothing is abandoned and the walker is back after the suspension
+    monkeypatch.delenv("MVDB_WALK_DEADLINE_US")
+    enc3 = _model(cfg, w)
+    for _ in range(300):
+        g3 = enc3.forward(ids, mask)
+    np.testing.assert_allclose(g3, e64, atol=2e-5, rtol=0)
+    assert enc3.walk_stats() == {"aborts": 0, "fallbacks": 0, "suspended_calls": 0}
+    enc3.close()
+
+
+def test_walk_launches_from_two_host_threads_and_two_encoders_do_not_overlap(gpu):
+    """Two host threads, each with its own encoder and stream, enqueue walking launches as fast as they can: the per-device
+    order (wait for the previous launch's event, launch, record) is taken under ONE lock, so the two threads cannot both
+    enqueue behind the same predecessor and put two persistent grids on the device at once (round-5 advisor finding)."""
+    import threading
+    import torch
+    dev = torch.device("cuda", 0)
+    cfgs = [E.make_config("xlmr-large-dims"), E.make_config("e5-small-dims")]
+    ws = [E.make_weights(cfgs[0], 8), E.make_weights(cfgs[1], 9)]
+    encs = [_model(cfgs[0], ws[0]), _model(cfgs[1], ws[1])]
+    data, want, outs, errs = [], [], [[], []], []
+    for cfg, w in zip(cfgs, ws):
+        ids, mask = E.make_inputs(cfg, 1, 20, 19)
+        data.append((torch.from_numpy(ids).to(dev), torch.from_numpy(mask).to(dev), ids, mask))
+        want.append(E.numpy_forward(cfg, w, ids, mask)[1])
+    torch.cuda.synchronize()
+
+    def run(i):
+        try:
+            st = torch.cuda.Stream(dev)
+            with torch.cuda.stream(st):
+                for rep in range(60):
+                    outs[i].append(encs[i].forward_device(data[i][0], data[i][1])[0])
+                    if rep % 10 == 9:    # and the host entry in between (its own stream, waits for its launch)
+                        outs[i].append(torch.from_numpy(encs[i].forward(data[i][2], data[i][3])).to(dev))
+            st.synchronize()
+        except Exception as ex:  # noqa: BLE001
+            errs.append(ex)
+
+    th = [threading.Thread(target=run, args=(i,)) for i in (0, 1)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(120)
+        assert not t.is_alive(), "walking launches of two threads wedged"
+    assert not errs, errs
+    torch.cuda.synchronize()
+    for i in (0, 1):
+        for o in outs[i]:
+            np.testing.assert_allclose(o.cpu().numpy(), want[i], atol=2e-5, rtol=0)
+        assert encs[i].walk_stats()["aborts"] == 0
+        encs[i].close()
+
+
+_CHILD = r"""
+import json, os, sys, time
+import numpy as np, torch
+sys.path.insert(0, {root!r})
+from oracle import encoder as E
+from minivectordb_amd.embedding_model import GpuEncoder
+cfg = E.make_config("e5-small-dims")
+w = E.make_weights(cfg, 61)
+enc = GpuEncoder(cfg, {{k: torch.from_numpy(v) for k, v in w.items()}}, device=0)
+rs = np.random.RandomState(62)
+lens = rs.randint(4, 61, size={n})
+sents = [rs.randint(5, cfg["vocab_size"], size=(1, int(L))).astype(np.int32) for L in lens]
+enc.forward(sents[0], np.ones_like(sents[0]))
+open({ready!r} + str(os.getpid()), "w").close()
+while len([f for f in os.listdir(os.path.dirname({ready!r})) if f.startswith(os.path.basename({ready!r}))]) < {procs}:
+    time.sleep(0.01)
+t0 = time.perf_counter()
+out = np.concatenate([enc.forward(s, np.ones_like(s)) for s in sents])
+dt = time.perf_counter() - t0
+np.save({out!r} + str(os.getpid()) + ".npy", out)
+print(json.dumps({{"pid": os.getpid(), "seconds": dt, **enc.walk_stats()}}))
+"""
+
+
+def test_two_processes_embedding_on_one_gpu_both_finish_with_identical_results(gpu, tmp_path):
+    """The ordinary way to serve a vector database: two worker processes, one GPU, each embedding one sentence per call.  Their
+    walking launches are persistent grids; the advisory lock keyed by the GPU's UUID keeps two of them from being in flight
+    together, the bounded waits keep a launch that cannot complete from wedging the GPU.  Both children embed the same 2,000
+    sentences concurrently: both finish, and both return bit for bit what a process alone returns."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def spawn(tag, procs, n=2000):
+        ready, out = str(tmp_path / f"ready_{tag}_"), str(tmp_path / f"out_{tag}_")
+        code = _CHILD.format(root=root, n=n, ready=ready, procs=procs, out=out)
+        ps = [subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for _ in range(procs)]
+        res = []
+        for p in ps:
+            try:
+                so, se = p.communicate(timeout=600)
+            except subprocess.TimeoutExpired:
+                for q in ps:
+                    q.kill()
+                raise AssertionError("a child embedding on a shared GPU did not finish")
+            assert p.returncode == 0, se[-2000:]
+            res.append(json.loads(so.strip().splitlines()[-1]))
+        return res, [np.load(out + str(r["pid"]) + ".npy") for r in res]
+
+    alone, ref = spawn("alone", 1)
+    both, outs = spawn("both", 2)
+    for o in outs:
+        assert np.array_equal(o, ref[0])
+    print("one process alone:", alone, "two sharing the GPU:", both)
+
+
+def test_walk_shape_under_stream_capture_takes_the_capturable_kernels(gpu):
+    """A walking launch cannot take part in the per-device ordering while the caller captures the stream (round-5 advisor
+    finding): a captured forward of a walk-sized shape is recorded as the per-op kernels, and replays correctly next to eager
+    walking launches of another encoder."""
+    import torch
+    dev = torch.device("cuda", 0)
+    cfg = E.make_config("e5-small-dims")
+    w = E.make_weights(cfg, 51)
+    ids, mask = E.make_inputs(cfg, 1, 30, 52)
+    _, e64 = E.numpy_forward(cfg, w, ids, mask)
+    enc, other = _model(cfg, w), _model(cfg, w)
+    ti, tm = torch.from_numpy(ids).to(dev), torch.from_numpy(mask).to(dev)
+    assert enc.walks(1, 30)
+    st = torch.cuda.Stream(dev)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(st):
+        # allocation is not capturable: size the per-op workspace (and build the fp16 weight images) with an eager batch that
+        # does not walk and holds more tokens
+        big_ids, big_mask = E.make_inputs(cfg, 40, 30, 53)
+        enc.forward_device(torch.from_numpy(big_ids).to(dev), torch.from_numpy(big_mask).to(dev))
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g, stream=st, capture_error_mode="thread_local"):
+            out, _ = enc.forward_device(ti, tm)
+    for _ in range(3):
+        g.replay()
+        other.forward(ids, mask)     # eager walking launches of another encoder meanwhile
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(out.cpu().numpy(), e64, atol=2e-5, rtol=0)
+    assert enc.walk_stats()["aborts"] == 0 and other.walk_stats()["aborts"] == 0
+    enc.close()
+    other.close()
