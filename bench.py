@@ -305,9 +305,10 @@ def seeded_state_dict(cfg, dev, seed=0):
     return sd
 
 
-def one_sentence_latency(enc, vocab, lengths=(8, 16, 32, 64, 128), calls=200):
+def one_sentence_latency(enc, vocab, lengths=(8, 16, 32, 64, 128, 256, 512), calls=200):
     """ONE sentence per call — the reference's only shape (extract_embeddings(text): minivectordb/embedding_model.py:62-71):
-    host token ids in, host embedding out (GpuEncoder.forward: H2D of the ids, the forward, D2H of the row, one stream wait)."""
+    host token ids in, host embedding out (GpuEncoder.forward: ids and embedding through one host-mapped buffer, the forward,
+    one stream wait), up to the 512 tokens the reference truncates at (embedding_model.py:64,77)."""
     import numpy as np
     rs = np.random.RandomState(1)
     rows = []

@@ -119,6 +119,83 @@ __global__ __launch_bounds__(256) void pack_fill_kernel(const int32_t* __restric
     }
 }
 
+// The three kernels above as ONE launch for small batches (B <= kPackSmallB: one sentence per call is the reference's shape):
+// four waves share the sentences, lane 0 of the workgroup scans the counts.  Also clears the forward's overflow word (a
+// memset node of its own otherwise).  Same outputs, bit for bit.
+constexpr int kPackSmallB = 64;
+__global__ __launch_bounds__(256) void pack_small_kernel(const int32_t* __restrict__ mask, const int32_t* __restrict__ ids, int B, int S,
+                                                         int position_offset, int vocab, int* __restrict__ rank, int* __restrict__ count,
+                                                         int* __restrict__ seq_start, int* __restrict__ tok_id, int* __restrict__ tok_pos,
+                                                         int* __restrict__ tok_src, unsigned int* __restrict__ flag) {
+    __shared__ int s_start[kPackSmallB + 1];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0 && flag) *flag = 0u;
+    // (mask and ids may live in host-mapped memory — the host entry of one sentence per call —: eight words per lane are in
+    //  flight at once, the ids fetched together with the mask; one load -> ballot at a time was 12 us for 256 tokens)
+    const bool one_pass = B <= 4 && S <= 512;  // a wave meets ONE (sentence, 512-slot block): its ids stay in registers
+    int iv0[8];
+    for (int b = wave; b < B; b += 4) {
+        int base = 0;
+        for (int t00 = 0; t00 < S; t00 += 512) {
+            int mv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int t = t00 + 64 * u + lane;
+                mv[u] = t < S ? mask[(int64_t)b * S + t] : 0;
+                iv0[u] = one_pass && t < S ? ids[(int64_t)b * S + t] : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int t = t00 + 64 * u + lane;
+                const bool v = mv[u] != 0;
+                const unsigned long long m = __ballot(v);
+                const int r = base + __popcll(m & ((1ull << lane) - 1ull));
+                if (t < S) rank[(int64_t)b * S + t] = v ? r : -1;  // (read back below by the lane that wrote it)
+                base += __popcll(m);
+            }
+        }
+        if (lane == 0) {
+            count[b] = base;
+            s_start[b] = base;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int i = 0; i < B; ++i) {
+            const int v = s_start[i];
+            s_start[i] = run;
+            seq_start[i] = run;
+            run += v;
+        }
+        s_start[B] = run;
+        seq_start[B] = run;
+    }
+    __syncthreads();
+    for (int b = wave; b < B; b += 4) {
+        const int s0 = s_start[b];
+        for (int t00 = 0; t00 < S; t00 += 512) {
+            int iv[8], rv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int t = t00 + 64 * u + lane;
+                rv[u] = t < S ? rank[(int64_t)b * S + t] : -1;
+                iv[u] = one_pass ? iv0[u] : (t < S ? ids[(int64_t)b * S + t] : 0);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int t = t00 + 64 * u + lane;
+                if (rv[u] >= 0) {
+                    const int p = s0 + rv[u];
+                    tok_id[p] = iv[u] < 0 ? 0 : (iv[u] >= vocab ? vocab - 1 : iv[u]);  // never read outside the table
+                    tok_pos[p] = position_offset > 0 ? rv[u] + position_offset : t;
+                    tok_src[p] = b * S + t;
+                }
+            }
+        }
+    }
+}
+
 // One element per lane of a 32-column group -> the group's (hi | lo) line: `line` = the 128 bytes that hold columns
 // c0 .. c0 + 31 of a row in the [row][K / 32][hi 32 | lo 32] image (as a float pointer: the fp32 position of (row, c0) —
 // the image has the bytes of the fp32 matrix), c = the lane's column in the group.  Lanes c and c ^ 1 trade halves so that
@@ -246,7 +323,9 @@ __global__ __launch_bounds__(256) void ln_kernel(const float* __restrict__ y,
 
 // x[p,:] = LN(P[0][p,:] + ... + P[nparts - 1][p,:] + bias + x[p,:]): the planes of a split-K GEMM (EPI_PARTIAL), summed in plane
 // order, then the bias and the residual row (x itself: read whole before it is overwritten, by the wave that owns the row)
-template <int VPT, bool FULL>
+// NP = planes (1 .. 4; 0: a run-time count): with the count known every load of a row is issued before the first add (the
+// run-time loop compiled to load -> wait -> add per plane: 13.4 us per launch at T = 512, H = 1024)
+template <int VPT, bool FULL, int NP = 0>
 __global__ __launch_bounds__(256) void ln_partials_kernel(const float* __restrict__ P, int nparts, int64_t plane,
                                                           const float* __restrict__ bias, const int* __restrict__ seq_start, int B,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
@@ -256,17 +335,37 @@ __global__ __launch_bounds__(256) void ln_partials_kernel(const float* __restric
     const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (p >= T) return;
     float v[VPT];
+    if constexpr (NP > 0) {
+        float pv[NP][VPT], rv[VPT], bv[VPT];
 #pragma unroll
-    for (int i = 0; i < VPT; ++i) {
-        const int c = lane + i * 64;
-        const bool ok = FULL || c < H;
-        float a = 0.f;
-        if (ok) {
-            a = P[(int64_t)p * H + c];
-            for (int z = 1; z < nparts; ++z) a += P[z * plane + (int64_t)p * H + c];
-            a = (a + bias[c]) + x[(int64_t)p * H + c];
+        for (int i = 0; i < VPT; ++i) {
+            const int c = (FULL || lane + i * 64 < H) ? lane + i * 64 : 0;
+#pragma unroll
+            for (int z = 0; z < NP; ++z) pv[z][i] = P[z * plane + (int64_t)p * H + c];
+            rv[i] = x[(int64_t)p * H + c];
+            bv[i] = bias[c];
         }
-        v[i] = a;
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) {
+            float a = pv[0][i];
+#pragma unroll
+            for (int z = 1; z < NP; ++z) a += pv[z][i];
+            a = (a + bv[i]) + rv[i];
+            v[i] = (FULL || lane + i * 64 < H) ? a : 0.f;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) {
+            const int c = lane + i * 64;
+            const bool ok = FULL || c < H;
+            float a = 0.f;
+            if (ok) {
+                a = P[(int64_t)p * H + c];
+                for (int z = 1; z < nparts; ++z) a += P[z * plane + (int64_t)p * H + c];
+                a = (a + bias[c]) + x[(int64_t)p * H + c];
+            }
+            v[i] = a;
+        }
     }
     wave_layernorm<VPT, FULL>(v, H, lane, eps, gamma, beta, x + (int64_t)p * H, xp ? xp + (int64_t)p * H : nullptr);
 }
@@ -275,30 +374,72 @@ __global__ __launch_bounds__(256) void ln_partials_kernel(const float* __restric
 // pooling == 1: the first valid token (CLS) instead of the mean — BGE-M3's dense_vecs
 // flag: one word the launch ORs 1 into when a pooled row of a NON-empty sentence is not finite (an activation left the fp16 range
 // of the split-precision GEMMs): callers of the device entry test it without reading the embeddings back
+// Sentences of more than kPoolChunk tokens are summed in CHUNKS of kPoolChunk tokens on workgroups of their own (grid.y =
+// ceil(S / kPoolChunk)): chunk partials in token order, then the partials in chunk order by the last workgroup to arrive — a
+// sentence's sum depends on its length only, and up to kPoolChunk tokens it is the plain token-order sum.  (One workgroup
+// walking 512 tokens eight at a time took 47.6 us of a 0.90 ms one-sentence forward; profiles/r06_long_sentence_chain.txt.)
+// part: [B][grid.y][H] chunk partials, ctr: [B] arrival counters (zero between launches: the last workgroup re-arms its own).
+constexpr int kPoolChunk = 64;
 __global__ __launch_bounds__(256) void pool_norm_kernel(const float* __restrict__ x,
                                                         const int* __restrict__ seq_start, int H,
-                                                        int pooling, float* __restrict__ out, unsigned int* __restrict__ flag) {
+                                                        int pooling, float* __restrict__ out, unsigned int* __restrict__ flag,
+                                                        float* part, unsigned int* ctr) {
     __shared__ float red[256];
-    const int b = blockIdx.x;
+    __shared__ int s_last;
+    const int b = blockIdx.x, j = blockIdx.y;
     const int s0 = seq_start[b], len = seq_start[b + 1] - s0;
     const int span = pooling == 1 ? (len > 0 ? 1 : 0) : len;
+    const int nch = max(1, (span + kPoolChunk - 1) / kPoolChunk);  // live chunks of this sentence
+    if (j >= nch) return;
+    const int t0 = j * kPoolChunk, t1 = min(span, t0 + kPoolChunk);
     float sq = 0.f;
-    for (int c = threadIdx.x; c < H; c += blockDim.x) {
+    float ev[4];  // this thread's means (H <= 1024 = 4 x 256 columns): `out` may be host-mapped memory, never read back
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = threadIdx.x + i * 256;
+        ev[i] = 0.f;
+        if (c >= H) continue;
         float s = 0.f;
-        int t = 0;
+        int t = t0;
         // eight loads in flight, added in token order (the same sum as a plain loop, which hipcc compiles to one
         // dependent load -> add per token: 32 serialised round trips at S = 32)
-        for (; t + 8 <= span; t += 8) {
+        for (; t + 8 <= t1; t += 8) {
             float v[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) v[u] = x[(int64_t)(s0 + t + u) * H + c];
 #pragma unroll
             for (int u = 0; u < 8; ++u) s += v[u];
         }
-        for (; t < span; ++t) s += x[(int64_t)(s0 + t) * H + c];
-        const float e = s / (float)span;  // empty sequence -> NaN, as the reference's 0/0
-        out[(int64_t)b * H + c] = e;
-        sq += e * e;
+        for (; t < t1; ++t) s += x[(int64_t)(s0 + t) * H + c];
+        if (nch == 1) {
+            const float e = s / (float)span;  // empty sequence -> NaN, as the reference's 0/0
+            ev[i] = e;
+            sq += e * e;
+        } else {
+            __hip_atomic_store(part + ((int64_t)b * gridDim.y + j) * H + c, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    if (nch > 1) {
+        __threadfence();
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned int seen = __hip_atomic_fetch_add(ctr + b, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = seen == (unsigned int)nch - 1u;
+            if (s_last) __hip_atomic_store(ctr + b, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        if (!s_last) return;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = threadIdx.x + i * 256;
+            if (c >= H) continue;
+            float s = __hip_atomic_load(part + ((int64_t)b * gridDim.y) * H + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int z = 1; z < nch; ++z)
+                s += __hip_atomic_load(part + ((int64_t)b * gridDim.y + z) * H + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const float e = s / (float)span;
+            ev[i] = e;
+            sq += e * e;
+        }
     }
     red[threadIdx.x] = sq;
     __syncthreads();
@@ -308,7 +449,11 @@ __global__ __launch_bounds__(256) void pool_norm_kernel(const float* __restrict_
     }
     const float denom = fmaxf(sqrtf(red[0]), 1e-12f);
     if (flag && threadIdx.x == 0 && span > 0 && !(red[0] < INFINITY)) atomicOr(flag, 1u);  // NaN or inf among the row's squares
-    for (int c = threadIdx.x; c < H; c += blockDim.x) out[(int64_t)b * H + c] /= denom;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = threadIdx.x + i * 256;
+        if (c < H) out[(int64_t)b * H + c] = ev[i] / denom;
+    }
 }
 
 // hidden[b,t,:] = x[packed(b,t),:] for valid tokens, 0 for padding
@@ -2260,12 +2405,14 @@ struct mvdb_encoder {
             *tok_src = nullptr;
         float *x = nullptr, *y = nullptr, *qkv = nullptr, *ctx = nullptr, *ffn = nullptr;
         float* xp = nullptr;  // compute = 2: the (hi | lo) fp16 image of x (same bytes as x)
+        unsigned int* pool_ctr = nullptr;  // [B] arrival counters of pool_norm_kernel's chunks (zero between launches)
         void release() {
-            void* ptrs[] = {rank, count, seq_start, tok_id, tok_pos, tok_src, x, y, qkv, ctx, ffn, xp};
+            void* ptrs[] = {rank, count, seq_start, tok_id, tok_pos, tok_src, x, y, qkv, ctx, ffn, xp, pool_ctr};
             for (void* p : ptrs)
                 if (p) (void)hipFree(p);
             rank = count = seq_start = tok_id = tok_pos = tok_src = nullptr;
             x = y = qkv = ctx = ffn = xp = nullptr;
+            pool_ctr = nullptr;
         }
     } lane[2];
     hipStream_t stream2 = nullptr;             // second half of a split batch
@@ -2354,6 +2501,8 @@ int alloc_lane(mvdb_encoder* e, mvdb_encoder::Lane& w, int64_t B, int64_t tokens
     MVDB_TRY(dev_alloc(&w.ctx, tokens * H));
     MVDB_TRY(dev_alloc(&w.ffn, tokens * std::max(F, H)));
     MVDB_TRY(dev_alloc(&w.xp, tokens * H));
+    MVDB_TRY(dev_alloc(&w.pool_ctr, B));
+    MVDB_HIP(hipMemset(w.pool_ctr, 0, (size_t)std::max<int64_t>(B, 1) * sizeof(unsigned int)));
     return 0;
 }
 
@@ -2689,12 +2838,18 @@ int launch_gemm_x3_splitk(const float* Aimg, const _Float16* Wp, float inv_wscal
 template <int VPT>
 void launch_ln_partials(const float* planes, int parts, int64_t plane, const float* bias, const int* seq_start, int B, const float* g,
                         const float* b, float eps, int H, float* x, float* xp, int64_t Tmax, hipStream_t s) {
-    if (H == VPT * 64)
-        hipLaunchKernelGGL((ln_partials_kernel<VPT, true>), dim3((unsigned)((Tmax + 3) / 4)), dim3(256), 0, s, planes, parts, plane, bias,
-                           seq_start, B, g, b, eps, H, x, xp);
-    else
-        hipLaunchKernelGGL((ln_partials_kernel<VPT, false>), dim3((unsigned)((Tmax + 3) / 4)), dim3(256), 0, s, planes, parts, plane, bias,
-                           seq_start, B, g, b, eps, H, x, xp);
+    const dim3 grid((unsigned)((Tmax + 3) / 4));
+#define MVDB_LNP(FULLV, NPV)                                                                                                          \
+    hipLaunchKernelGGL((ln_partials_kernel<VPT, FULLV, NPV>), grid, dim3(256), 0, s, planes, parts, plane, bias, seq_start, B, g, b, \
+                       eps, H, x, xp)
+    if (H == VPT * 64) {
+        if (parts == 3) MVDB_LNP(true, 3);
+        else MVDB_LNP(true, 0);
+    } else {
+        if (parts == 3) MVDB_LNP(false, 3);
+        else MVDB_LNP(false, 0);
+    }
+#undef MVDB_LNP
 }
 
 template <int VPT>
@@ -2735,6 +2890,7 @@ struct WalkGate {
 std::map<int, WalkOrder> g_walk_order;
 std::map<int, WalkGate> g_walk_gate;
 constexpr int kGateWaitUs = 50000;
+constexpr int kPinSlots = 512;          // token slots the host entry serves from ONE host-mapped buffer (no copies)
 constexpr int kWalkSuspendCalls = 256;  // forwards on the per-op kernels after an abandoned launch, before the next attempt
 
 int gate_open(int device) {
@@ -2818,10 +2974,13 @@ struct WalkTurn {
 };
 
 // ---- the layer-walking launch for small batches (encoder_walk.hpp) ------------------------------------------------------
-// Eligible: at most walk::kTmax token slots, widths the column units tile (H, F multiples of 16, H <= 1024).
+// Eligible: at most walk::kTmax token slots — 64 on the wide shapes (H > 384: e5-large / bge-m3), where the per-op kernels
+// win from 65 slots on (one sentence, host in / host out: 2.17 / 2.24 ms at 96 / 128 tokens against the walking launch's
+// 2.21 / 2.38; profiles/r06_long_sentence_chain.txt) —, widths the column units tile (H, F multiples of 16, H <= 1024).
+int walk_max_slots(const mvdb_encoder_cfg& c) { return c.hidden > 384 ? 64 : walk::kTmax; }
 bool walk_eligible(const mvdb_encoder* e, int B, int S) {
     const mvdb_encoder_cfg& c = e->cfg;
-    return e->opt_walk && (int64_t)B * S <= walk::kTmax && c.hidden % 16 == 0 && c.intermediate % 16 == 0 && c.hidden <= 1024;
+    return e->opt_walk && (int64_t)B * S <= walk_max_slots(c) && c.hidden % 16 == 0 && c.intermediate % 16 == 0 && c.hidden <= 1024;
 }
 
 int ensure_walk(mvdb_encoder* e) {
@@ -2953,24 +3112,30 @@ int launch_walk(mvdb_encoder* e, const int32_t* ids, const int32_t* mask, int B,
 #define MVDB_WALK_CASE(M, C, R) if (mt == M && hc == C && rh == R) return launch_walk_inst<M, C, R>(e, a, lds, grid, s)
     MVDB_WALK_CASE(1, 1, 1); MVDB_WALK_CASE(2, 1, 1); MVDB_WALK_CASE(2, 1, 2); MVDB_WALK_CASE(2, 1, 4);
     MVDB_WALK_CASE(1, 3, 1); MVDB_WALK_CASE(2, 3, 1); MVDB_WALK_CASE(2, 3, 2); MVDB_WALK_CASE(2, 3, 4);
-    MVDB_WALK_CASE(1, 8, 1); MVDB_WALK_CASE(2, 8, 1); MVDB_WALK_CASE(4, 8, 1); MVDB_WALK_CASE(4, 8, 2);
+    MVDB_WALK_CASE(1, 8, 1); MVDB_WALK_CASE(2, 8, 1); MVDB_WALK_CASE(4, 8, 1);
 #undef MVDB_WALK_CASE
     return fail(MVDB_ERR_ARG, "no walker instantiation for this shape");
 }
 
 // Enqueue every kernel of one forward on `s` (no allocation, no host sync: capturable in a hipGraph).
 int enqueue_lane(mvdb_encoder* e, mvdb_encoder::Lane& w, const int32_t* ids, const int32_t* mask, int B, int S,
-                 int compute, float* out, float* hidden, hipStream_t s) {
+                 int compute, float* out, float* hidden, hipStream_t s, bool clear_flag = false) {
     const mvdb_encoder_cfg& c = e->cfg;
     const int H = c.hidden, F = c.intermediate, hd = H / c.heads;
     const int64_t Tmax = (int64_t)B * S;
     const int vpt = (H + 63) / 64;
     const int* Tptr = w.seq_start + B;
 
-    hipLaunchKernelGGL(seq_rank_kernel, dim3(B), dim3(64), 0, s, mask, S, w.rank, w.count);
-    hipLaunchKernelGGL(seq_scan_kernel, dim3(1), dim3(256), 0, s, w.count, B, w.seq_start);
-    hipLaunchKernelGGL(pack_fill_kernel, dim3(B), dim3(256), 0, s, ids, w.rank, w.seq_start, S,
-                       c.position_offset, c.vocab_size, w.tok_id, w.tok_pos, w.tok_src);
+    if (clear_flag && B <= kPackSmallB) {
+        hipLaunchKernelGGL(pack_small_kernel, dim3(1), dim3(256), 0, s, mask, ids, B, S, c.position_offset, c.vocab_size, w.rank, w.count,
+                           w.seq_start, w.tok_id, w.tok_pos, w.tok_src, e->overflow_flag);
+    } else {
+        if (clear_flag) MVDB_HIP(hipMemsetAsync(e->overflow_flag, 0, sizeof(unsigned int), s));  // (a memset node of the captured graph)
+        hipLaunchKernelGGL(seq_rank_kernel, dim3(B), dim3(64), 0, s, mask, S, w.rank, w.count);
+        hipLaunchKernelGGL(seq_scan_kernel, dim3(1), dim3(256), 0, s, w.count, B, w.seq_start);
+        hipLaunchKernelGGL(pack_fill_kernel, dim3(B), dim3(256), 0, s, ids, w.rank, w.seq_start, S,
+                           c.position_offset, c.vocab_size, w.tok_id, w.tok_pos, w.tok_src);
+    }
     const dim3 rowgrid((unsigned)((Tmax + 3) / 4));
     // compute = 2: every GEMM input is a (hi | lo) fp16 image written by its producer — x by the LayerNorms (beside the
     // fp32 x the residuals and the pooling read), the context by the attention kernel, the GELU output by FFN1's epilogue
@@ -3128,7 +3293,9 @@ int enqueue_lane(mvdb_encoder* e, mvdb_encoder::Lane& w, const int32_t* ids, con
 #undef LN2_CALL
     }
 #undef MVDB_VPT_SWITCH
-    hipLaunchKernelGGL(pool_norm_kernel, dim3(B), dim3(256), 0, s, w.x, w.seq_start, H, c.pooling, out, e->overflow_flag);
+    // (w.y is free here: chunk partials of sentences longer than kPoolChunk tokens)
+    hipLaunchKernelGGL(pool_norm_kernel, dim3(B, (S + kPoolChunk - 1) / kPoolChunk), dim3(256), 0, s, w.x, w.seq_start, H, c.pooling, out,
+                       e->overflow_flag, w.y, w.pool_ctr);
     if (hidden)
         hipLaunchKernelGGL(unpack_hidden_kernel, dim3((unsigned)Tmax), dim3(256), 0, s, w.x, w.rank,
                            w.seq_start, S, H, hidden);
@@ -3147,8 +3314,8 @@ int enqueue_forward(mvdb_encoder* e, const int32_t* ids, const int32_t* mask, in
         return v ? atoi(v) : 1;
     }();
     const bool split = split_mode && s && compute == 0 && B >= 64 && (int64_t)B * S >= 32768 && e->stream2;
+    if (!split) return enqueue_lane(e, e->lane[0], ids, mask, B, S, compute, out, hidden, s, true);  // (clears the overflow word)
     MVDB_HIP(hipMemsetAsync(e->overflow_flag, 0, sizeof(unsigned int), s));  // (a memset node of the captured graph)
-    if (!split) return enqueue_lane(e, e->lane[0], ids, mask, B, S, compute, out, hidden, s);
     const int b0 = B / 2, b1 = B - b0;
     const int H = e->cfg.hidden;
     MVDB_HIP(hipEventRecord(e->ev_fork, s));
@@ -3505,13 +3672,15 @@ int mvdb_encoder_forward(mvdb_encoder* e, const int32_t* ids_host, const int32_t
     };
     const unsigned int aborts_before = e->walk_aborts_host ? *e->walk_aborts_host : 0u;
     bool walked = false;
-    if (walk_eligible(e, B, S) && e->opt_walk_pinned) {
-        // ONE sentence per call: the launch reads the ids and the mask from host-mapped memory and writes the embedding there —
-        // no copy engine work at all around it (two H2D copies, a memset and a D2H copy before: ~20 us of a 0.27 ms call)
-        const size_t in_bytes = 2 * (size_t)walk::kTmax * sizeof(int32_t);
-        MVDB_TRY(e->walk_pin.reserve(in_bytes + (size_t)walk::kTmax * e->cfg.hidden * sizeof(float)));
+    if (tokens <= kPinSlots && e->opt_walk_pinned) {
+        // ONE sentence per call (extract_embeddings truncates at 512 tokens, embedding_model.py:64,77): the kernels read the ids
+        // and the mask from host-mapped memory and write the embedding there — no copy engine work at all around the forward
+        // (two H2D copies, a memset and a D2H copy before: ~20 us of a 0.27 ms call).  The walking launch up to its 128 token
+        // slots, the per-op kernels beyond.
+        const size_t in_bytes = 2 * (size_t)kPinSlots * sizeof(int32_t);
+        MVDB_TRY(e->walk_pin.reserve(in_bytes + (size_t)kPinSlots * e->cfg.hidden * sizeof(float)));
         int32_t* pin_ids = reinterpret_cast<int32_t*>(e->walk_pin.p);
-        int32_t* pin_mask = pin_ids + walk::kTmax;
+        int32_t* pin_mask = pin_ids + kPinSlots;
         float* pin_out = reinterpret_cast<float*>(reinterpret_cast<char*>(e->walk_pin.p) + in_bytes);
         memcpy(pin_ids, ids_host, tokens * sizeof(int32_t));
         memcpy(pin_mask, mask_host, tokens * sizeof(int32_t));

@@ -29,15 +29,20 @@ def test_walk_matches_float64(name, B, S, gpu):
     w = E.make_weights(cfg, 31)
     ids, mask = E.make_inputs(cfg, B, S, 32)
     enc = _model(cfg, w)
-    assert enc.walks(B, S)
+    # the walking launch serves 128 token slots, 64 on the wide shapes (where the per-op kernels win beyond); the shapes that
+    # hand over stay in the list: the same float64 restatement holds for whichever kernels answer
+    assert enc.walks(B, S) == (B * S <= (64 if cfg["hidden_size"] > 384 else 128))
     h64, e64 = E.numpy_forward(cfg, w, ids, mask)
-    for compute in (2, 0):          # one exact-fp32 launch serves both modes
-        emb = enc.forward(ids, mask, compute=compute)
+    embs = {}
+    for compute in (0, 2):          # one exact-fp32 launch serves both modes
+        embs[compute] = emb = enc.forward(ids, mask, compute=compute)
         np.testing.assert_allclose(emb, e64, atol=2e-5, rtol=0)
+    if enc.walks(B, S):
+        assert np.array_equal(embs[0], embs[2])
     dev = torch.device("cuda", 0)
     out, hidden = enc.forward_device(torch.from_numpy(ids).to(dev), torch.from_numpy(mask).to(dev), want_hidden=True)
     torch.cuda.synchronize()
-    assert np.array_equal(out.cpu().numpy(), emb)
+    assert np.array_equal(out.cpu().numpy(), emb)   # (the default mode, 2: the last one above)
     hidden = hidden.cpu().numpy()
     m = mask.astype(bool)
     np.testing.assert_allclose(hidden[m], h64[m], atol=1e-4, rtol=0)
