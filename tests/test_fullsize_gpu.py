@@ -1,6 +1,6 @@
 """Oracle comparison AT the BASELINE sizes (configs 2 and 3; config 4 is in test_config4_gpu.py): every search path the
 library picks for 1 / 32 / 128 / 256 queries per call is held against the CPU oracle on the full corpus — 1,000 queries at
-1M x 512, 256 at 10M x 512 (1,000 queries per config, seeds 1234 / 5678) — id for id, every id difference
+1M x 512, 1,000 at 10M x 512, 512 at config 5's 10M x 384 (1,000 queries per config, seeds 1234 / 5678) — id for id, every id difference
 adjudicated in float64 (tests/bigcheck.py).  Reference call site: minivectordb/vector_database.py:497
 (``index.search(embedding, search_k)``), filtered branch :508-523.
 """
@@ -99,36 +99,75 @@ def test_config2_1M_x_512_l2_and_filters_vs_oracle(native):
 
 
 def test_config3_10M_x_512_every_pass_vs_oracle(native):
-    """BASELINE config 3 (the headline) at full size: 256 queries compared with the oracle over all 10M rows through
-    nq = 1 (first 100 queries), 32, 128 and 256 queries per call, and under a bitmap keeping half of the rows."""
-    n, d, k, nq = 10_000_000, 512, 10, 256
+    """BASELINE config 3 (the headline) at full size, BASELINE.md section 4's 1,000 queries: all of them against the oracle over
+    all 10M rows ONE PER CALL (the headline kernel) and 256 per call; the first 256 also 32 and 128 per call and under a bitmap
+    keeping half of the rows."""
+    n, d, k, nq, nb = 10_000_000, 512, 10, 1000, 256
     idx = native.FlatIndex(d)
     idx.reserve(n)
     idx.add_synthetic(n, 1234, normalize=True)
     q = _queries(nq, d)
     keep = (np.random.RandomState(3).rand(n) < 0.5).astype(np.uint8)
-    (everything, half), cost = bigcheck.oracle_topk_streamed(idx, n, q, k, keeps=(None, keep))
+    (everything,), cost = bigcheck.oracle_topk_streamed(idx, n, q, k)
+    (half,), cost_half = bigcheck.oracle_topk_streamed(idx, n, q[:nb], k, keeps=(keep,))
     Do, Io = everything
     reruns = native.split_rerun_count()
-    D, I = _in_chunks(lambda qs: idx.search(qs, k), q[:100], 1)
-    bigcheck.report(dict(bigcheck.compare(idx, q[:100], D, I, Do[:100], Io[:100], "config3 10M x 512, 1 query per call"),
-                         oracle_cost=cost))
-    for per_call in (32, 128, 256):
-        D, I = _in_chunks(lambda qs: idx.search(qs, k), q, per_call)
-        bigcheck.report(bigcheck.compare(idx, q, D, I, Do, Io, f"config3 10M x 512, {per_call} queries per call"))
+    D, I = _in_chunks(lambda qs: idx.search(qs, k), q, 1)
+    bigcheck.report(dict(bigcheck.compare(idx, q, D, I, Do, Io, "config3 10M x 512, 1 query per call"), oracle_cost=cost))
+    D, I = _in_chunks(lambda qs: idx.search(qs, k), q, 256)
+    bigcheck.report(bigcheck.compare(idx, q, D, I, Do, Io, "config3 10M x 512, 256 queries per call"))
+    for per_call in (32, 128):
+        D, I = _in_chunks(lambda qs: idx.search(qs, k), q[:nb], per_call)
+        bigcheck.report(bigcheck.compare(idx, q[:nb], D, I, Do[:nb], Io[:nb], f"config3 10M x 512, {per_call} queries per call"))
     words = _bitmap(keep)
     D, I = _in_chunks(lambda qs: idx.search_masked(qs, k, words), q[:40], 1)
-    bigcheck.report(bigcheck.compare(idx, q[:40], D, I, half[0][:40], half[1][:40], "config3 bitmap keeping 50 %, 1 query per call"))
+    bigcheck.report(dict(bigcheck.compare(idx, q[:40], D, I, half[0][:40], half[1][:40], "config3 bitmap keeping 50 %, 1 query per call"),
+                         oracle_cost=cost_half))
     for per_call in (32, 128):
-        D, I = _in_chunks(lambda qs: idx.search_masked(qs, k, words), q, per_call)
-        bigcheck.report(bigcheck.compare(idx, q, D, I, *half, f"config3 bitmap keeping 50 %, {per_call} queries per call"))
-    # the opt-in single-query route over the fp16 shadow (mvdb_index_set_option "shadow_single_query"): the same 100 queries
+        D, I = _in_chunks(lambda qs: idx.search_masked(qs, k, words), q[:nb], per_call)
+        bigcheck.report(bigcheck.compare(idx, q[:nb], D, I, *half, f"config3 bitmap keeping 50 %, {per_call} queries per call"))
+    # the opt-in single-query route over the fp16 shadow (mvdb_index_set_option "shadow_single_query"): the first 100 queries
     idx.set_option("shadow_single_query", 1)
     D, I = _in_chunks(lambda qs: idx.search(qs, k), q[:100], 1)
     idx.set_option("shadow_single_query", 0)
     bigcheck.report(bigcheck.compare(idx, q[:100], D, I, Do[:100], Io[:100], "config3 10M x 512, 1 query per call over the fp16 shadow (opt-in)"))
     bigcheck.report({"what": "config3 certified-pass re-runs during the comparison",
                      "chunks_rerun": native.split_rerun_count() - reruns})
+    idx.close()
+
+
+@pytest.mark.parametrize("family,name", [(0, "zero-mean"), (flat.SYNTH_CLUSTERED, "clustered")])
+def test_config5_10M_x_384_knn_leg_vs_oracle(native, family, name):
+    """BASELINE config 5's kNN leg at full size — 10M x 384, k = 10: the fp16-shadow kernel at d = 384 is its own instantiation
+    (flat_scan_h16_kernel<24, ...>), as are the d = 384 forms of the single-query scan and of the exact fp32-MFMA pass.  Queries:
+    the 256 golden embeddings of the config-5 batch (transformers' own output for tests/golden/encoder_golden.npz case 8 —
+    what the encoder hands the search) + 256 queries of the corpus' own family; 1 / 32 / 128 / 256 per call, id for id against
+    the streamed oracle, on the zero-mean stream and on the clustered family (where certificates are refused and the rescue /
+    exact re-run tiers answer)."""
+    from encoder_cases import load_cases
+    n, d, k = 10_000_000, 384, 10
+    case = next(c for c in load_cases() if c["B"] == 256)
+    assert case["emb"].shape == (256, d)
+    qs = flat.synth(256, d, 5678 | family)
+    flat.normalize_l2(qs)
+    q = np.ascontiguousarray(np.concatenate([case["emb"].astype(np.float32), qs]))
+    nq = q.shape[0]
+    idx = native.FlatIndex(d)
+    idx.reserve(n)
+    idx.add_synthetic(n, 1234 | family, normalize=True)
+    (oracle,), cost = bigcheck.oracle_topk_streamed(idx, n, q, k)
+    Do, Io = oracle
+    gap = float(np.median(Do[:, 0] - Do[:, k - 1]))
+    pick = np.r_[0:64, 256:320]    # one per call: 64 golden + 64 synthetic
+    D, I = _in_chunks(lambda x: idx.search(x, k), q[pick], 1)
+    bigcheck.report(dict(bigcheck.compare(idx, q[pick], D, I, Do[pick], Io[pick], f"config5 {name} 10M x 384, 1 query per call"),
+                         oracle_cost=cost, median_gap_best_to_kth=gap))
+    for per_call in (32, 128, 256):
+        before = native.split_rerun_count()
+        D, I = _in_chunks(lambda x: idx.search(x, k), q, per_call)
+        rec = bigcheck.compare(idx, q, D, I, Do, Io, f"config5 {name} 10M x 384, {per_call} queries per call")
+        bigcheck.report(dict(rec, chunks_rerun=native.split_rerun_count() - before, calls=(nq + per_call - 1) // per_call))
+    assert idx.shadow_rows == n   # the batches did run over the fp16 shadow
     idx.close()
 
 
