@@ -1178,11 +1178,22 @@ __global__ __launch_bounds__(256) void mask_rank_kernel(int64_t* __restrict__ I,
     if (threadIdx.x == 0) I[blockIdx.x] = part[0];
 }
 
+constexpr int kCoreTile = 1024;      // queries search_core answers per pass over its workspace
+constexpr int kGatedPassGroup = 8;   // exact re-run passes (of 16 / 32 compact queries) one gated launch walks: one list buffer of that many
 int search_core(const mvdb_index* idx, Workspace* ws, const float* q_dev, int nq, int k,
                 int normalize_q, const int64_t* rows_dev, int64_t m, int64_t label_offset,
                 float* D_dev, int64_t* I_dev, bool allow_split = true, const uint64_t* mask_dev = nullptr) {
     KnobScope knobs(&idx->kn);
     hipStream_t s = ws->stream;
+    // Workspace O(1) in nq: a call of more queries is answered kCoreTile at a time on the same stream-ordered workspace (the
+    // compact re-run buffers, per-query floors and flags below are sized by the queries of ONE tile; a tile is a whole number of
+    // every pass's chunk: 32 / 128 / 256).  [round-5 advisor: the re-run workspace grew with the batch — 4 GB at 16k queries]
+    if (nq > kCoreTile) {
+        for (int t0 = 0; t0 < nq; t0 += kCoreTile)
+            MVDB_TRY(search_core(idx, ws, q_dev + (int64_t)t0 * idx->ld, std::min(kCoreTile, nq - t0), k, normalize_q, rows_dev, m, label_offset,
+                                 D_dev + (int64_t)t0 * k, I_dev + (int64_t)t0 * k, allow_split, mask_dev));
+        return 0;
+    }
     if (allow_split) tls_single_suspended = nq == 1 && idx->kn.shadow_single_query && single_route_suspended(idx);
     // row list: its m entries; bitmap: the first m rows when the caller says how many rows the bitmap covers (a resident
     // row set built before later appends), else every row
@@ -1423,37 +1434,42 @@ int search_core(const mvdb_index* idx, Workspace* ws, const float* q_dev, int nq
                 // queries at 10M x 512 where four MFMA passes take 14.
                 const int max_passes = (R + per_pass - 1) / per_pass;
                 {
-                    // ONE launch walks the passes on the device (pass p: compact queries [p per_pass, ...); each enabled by the
-                    // refused count and its `need` word), ONE merge launch covers every compact query
+                    // ONE launch walks up to kGatedPassGroup passes on the device (pass p: compact queries [p per_pass, ...); each
+                    // enabled by the refused count and its `need` word), ONE merge launch covers the group's compact queries; the
+                    // groups share one list buffer in stream order (so the lists are O(1) in the batch: 8 passes x 5 MB at k = 10)
                     const int64_t cand_stride = (int64_t)per_pass * scan_grid_upper_bound(idx->device) * k;
-                    MVDB_TRY(ws->cand.reserve((size_t)max_passes * cand_stride));
-                    MfmaScanArgs ma;
-                    ma.X = idx->X;
-                    ma.n = n;
-                    ma.ld = idx->ld;
-                    ma.q = qc;
-                    ma.nq = std::min(per_pass, R);
-                    ma.k = k;
-                    ma.cand = ws->cand.p;
-                    ma.mask = mask32;
-                    ma.thr0 = idx->kn.disable_rerun_floor ? nullptr : ws->qfloor.p + q0;
-                    int nblocks = 0;
-                    MVDB_TRY(launch_mfma2_gated(KB, ma, idx->device, s, &nblocks, ws->nfail.p, 0, need, max_passes, per_pass, R, cand_stride));
-                    MergeArgs mg;
-                    mg.keys = ws->cand.p;
-                    mg.nlists = nblocks;
-                    mg.k = k;
-                    mg.metric = idx->metric;
-                    mg.label_offset = label_offset;
-                    mg.D = Dt;
-                    mg.I = It;
-                    mg.gate = ws->nfail.p;
-                    mg.gate_lo = 0;
-                    mg.need = need;
-                    mg.per_pass = per_pass;
-                    mg.pass_stride = cand_stride;
-                    hipLaunchKernelGGL(merge_keys_kernel, dim3(R), dim3(kMergeThreads), 0, s, mg);
-                    MVDB_HIP(hipGetLastError());
+                    MVDB_TRY(ws->cand.reserve((size_t)std::min(max_passes, kGatedPassGroup) * cand_stride));
+                    for (int p0 = 0; p0 < max_passes; p0 += kGatedPassGroup) {
+                        const int np = std::min(kGatedPassGroup, max_passes - p0), qoff = p0 * per_pass;
+                        MfmaScanArgs ma;
+                        ma.X = idx->X;
+                        ma.n = n;
+                        ma.ld = idx->ld;
+                        ma.q = qc + (int64_t)qoff * idx->ld;
+                        ma.nq = std::min(per_pass, R - qoff);
+                        ma.k = k;
+                        ma.cand = ws->cand.p;
+                        ma.mask = mask32;
+                        ma.thr0 = idx->kn.disable_rerun_floor ? nullptr : ws->qfloor.p + q0 + qoff;
+                        int nblocks = 0;
+                        MVDB_TRY(launch_mfma2_gated(KB, ma, idx->device, s, &nblocks, ws->nfail.p, qoff, need ? need + p0 : nullptr, np, per_pass,
+                                                    R - qoff, cand_stride));
+                        MergeArgs mg;
+                        mg.keys = ws->cand.p;
+                        mg.nlists = nblocks;
+                        mg.k = k;
+                        mg.metric = idx->metric;
+                        mg.label_offset = label_offset;
+                        mg.D = Dt + (int64_t)qoff * k;
+                        mg.I = It + (int64_t)qoff * k;
+                        mg.gate = ws->nfail.p;
+                        mg.gate_lo = qoff;
+                        mg.need = need ? need + p0 : nullptr;
+                        mg.per_pass = per_pass;
+                        mg.pass_stride = cand_stride;
+                        hipLaunchKernelGGL(merge_keys_kernel, dim3(std::min(np * per_pass, R - qoff)), dim3(kMergeThreads), 0, s, mg);
+                        MVDB_HIP(hipGetLastError());
+                    }
                     off = R;
                 }
             }
@@ -2582,6 +2598,7 @@ static int rowset_check(const mvdb_index* idx, const mvdb_rowset* rs) {
 }
 static int rowset_search_core(const mvdb_index* idx, Workspace* ws, const float* q, int nq, int k, int normalize_q,
                               const mvdb_rowset* rs, int64_t label_offset, float* D_dev, int64_t* I_dev) {
+    tls_single_suspended = false;  // (the routing questions asked here are about batches; search_core decides for its own call)
     const int64_t total = (int64_t)nq * k;
     if (rs->count == 0 || (rs->mask && rs->n_at_create == 0)) {  // nothing selected (search_core reads m == 0 as "every row")
         hipLaunchKernelGGL(fill_missing_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ws->stream, D_dev, I_dev,
