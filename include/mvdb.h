@@ -288,16 +288,11 @@ int mvdb_prof_read(const char* name, int64_t* launches, double* total_ms);
 int mvdb_prof_symbol(const char* name, char* out, int len);
 
 /* Number of chunks (up to 256 queries) of the certified batch passes that held a query which failed certification — those
- * queries, or past MVDB_SPLIT_REQUERY_MAX of them the whole chunks, were re-run on the exact fp32 kernels — since the
- * library was loaded.  Diagnostic only. */
+ * queries were answered by the rescue pass or re-run on the exact fp32 kernels — since the library was loaded.
+ * Diagnostic only. */
 int64_t mvdb_split_rerun_count(void);
 
-/* The certificate's error bound per unit |q| * max|x| at dimension d: operand truncation of the bf16 split,
- * worst-case fp32 accumulation of the 3 d products in any order, the fp32 re-score, |q| and the comparison's own
- * rounding (docs/DESIGN_NOTES.md section 4.3b; tests/test_split_bound.py restates and checks the formula).  Diagnostic. */
-double mvdb_split_eps(int d);
-
-/* Same for the fp16 single-product nomination pass that serves chunks of >= 33 queries where it has a kernel
+/* The certificate's error bound per unit |q| * max|x| at dimension d for the fp16 single-product nomination pass
  * (half_scan.hip: both operands rounded to fp16, d products accumulated in fp32, 64 nominees per query re-scored
  * in fp32): rounding of both operands, elements below fp16's normal range, worst-case fp32 accumulation, the fp32
  * re-score, |q| and the comparison (docs/DESIGN_NOTES.md section 4.3d; tests/test_split_bound.py).  Diagnostic.

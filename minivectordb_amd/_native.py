@@ -103,7 +103,6 @@ PROTOTYPES = {
     "mvdb_synth_fill_device": (ctypes.c_int, [c_vp, ctypes.c_int64, ctypes.c_int, ctypes.c_uint64, ctypes.c_int64,
                                               ctypes.c_int, ctypes.c_int, c_vp]),
     "mvdb_split_rerun_count": (ctypes.c_int64, []),
-    "mvdb_split_eps": (ctypes.c_double, [ctypes.c_int]),
     "mvdb_half_eps": (ctypes.c_double, [ctypes.c_int]),
     "mvdb_half_max_queries": (ctypes.c_int, [ctypes.c_int]),
     "mvdb_prof_enable": (ctypes.c_int, [ctypes.c_int]),
@@ -447,10 +446,6 @@ def pack_row_mask(n, rows=None, excluded=None):
 
 def split_rerun_count():
     return int(lib().mvdb_split_rerun_count())
-
-
-def split_eps(d):
-    return float(lib().mvdb_split_eps(int(d)))
 
 
 def half_eps(d):

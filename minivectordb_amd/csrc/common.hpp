@@ -68,26 +68,17 @@ struct Knobs {
     int mfma_ng2 = -1;               // MVDB_MFMA_NG2 (-1: on for the staged kernel, off otherwise)
     int gemm_scan_min_nq = 104;      // MVDB_GEMM_SCAN_MIN_NQ
     int gemm_scan_blocks_per_cu = 2; // MVDB_GEMM_SCAN_BLOCKS_PER_CU
-    int split_scan_min_nq = -1;      // MVDB_SPLIT_SCAN_MIN_NQ (-1: by corpus size and operand, mvdb.hip half_min_nq; else the value)
-    int split32_min_nq = 14;         // MVDB_SPLIT32_MIN_NQ
-    int split32_blocks_per_cu = 2;   // MVDB_SPLIT32_BLOCKS_PER_CU
-    int split_phase_growth = 8;      // MVDB_SPLIT_PHASE_GROWTH
+    int split_scan_min_nq = -1;      // MVDB_SPLIT_SCAN_MIN_NQ: fewest queries of a call for the certified pass (-1: by corpus size, mvdb.hip half_min_nq)
     bool disable_rescue = false;       // MVDB_DISABLE_RESCUE: refused queries go straight to the exact passes (A/B)
     bool disable_rerun_floor = false;  // MVDB_DISABLE_RERUN_FLOOR: the exact re-run of refused queries starts every list from -inf (A/B)
     int half_phase_growth = 0;       // MVDB_HALF_PHASE_GROWTH (0: by the pass width — 16 / 6 up to 128 queries per pass, 6 / 4 at 256)
     int half_last_growth = 0;        // MVDB_HALF_LAST_GROWTH
-    int split_dbg = 0;               // MVDB_SPLIT_DBG (timing ablation, invalid results)
     bool split_stats = false;        // MVDB_SPLIT_STATS
-    bool split_one_phase = false;    // MVDB_SPLIT_ONE_PHASE
     bool disable_mfma_scan = false, disable_l2_mfma = false, disable_gemm_scan = false, disable_split_scan = false,
-         disable_split32 = false, disable_half_scan = false, disable_masked_batch = false,
+         disable_half_scan = false, disable_masked_batch = false,
          disable_l2_cert = false,    // MVDB_DISABLE_* (L2_CERT: L2 batches back on the exact fp32 kernels)
-         disable_half_shadow = false;  // MVDB_DISABLE_HALF_SHADOW: the fp16 nomination pass converts the fp32 rows on the fly again
+         disable_half_shadow = false;  // MVDB_DISABLE_HALF_SHADOW (index option half_shadow = 0): no fp16 shadow, batches on the exact fp32 passes
     bool shadow_single_query = false;  // MVDB_SHADOW_SINGLE_QUERY (1: single queries through the certified fp16-shadow pass too)
-    bool hq_pipe = true;             // MVDB_HQ_PIPE (0: refill and conversion behind the MFMAs)
-    bool half_ksplit = false;        // MVDB_HALF_KSPLIT
-    bool half_small_stages = false;  // MVDB_HALF_SMALL_STAGES
-    bool hq_w4 = false;              // MVDB_HQ_W4
     long long compact_bytes = 512ll << 20;  // MVDB_COMPACT_BYTES: staging buffer of a row compaction (mvdb_index_remove_rows)
 };
 Knobs read_knobs();

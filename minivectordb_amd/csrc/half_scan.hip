@@ -1,46 +1,32 @@
-// half_scan.hip — query batches of 33+ per corpus pass: ONE fp16 product nominates, fp32 decides, a worst-case
-// bound certifies.
-//
-// The bf16 (hi, lo) split passes (scan_split_kernels.hpp) spend three matrix-core products per
-// corpus element to get a nomination error of 2.3e-4 and then keep 16 nominees per query.  With both units busy the
-// chip sits at its power limit (shader clock 1.77 GHz, 0.58 of the HBM roofline at 128 queries).  This pass trades
-// precision of the NOMINATING score for matrix-core work and makes up for it with more nominees:
+// half_scan.hip — query batches per corpus pass: ONE fp16 product over an fp16 SHADOW of the rows nominates, fp32 decides, a
+// worst-case bound certifies.
 //
 //      a(x) = fp16(s_q q) . fp16(s_x x) / (s_q s_x)        one v_mfma_f32_32x32x16_f16 per 16-k block, fp32 accumulate
 //      |a(x) - q.x| <= half_eps(d) |q| max|x|              (1.04e-3 at d = 512; derivation at half_eps below)
 //
 // s_q, s_x are powers of two that put the largest element at 2^14..2^15 (fp16's range is 2^-14..65504, so elements
 // down to 2^-29 of the largest keep their 11 significant bits; what falls below is bounded as if flushed to zero).
-// One product instead of three, one query image instead of two: the queries of a 128-query pass take 128 VGPRs
-// instead of 256, the matrix cores run a third of the time, and the kernel goes back to being HBM-bound.
 //
 // Nomination and certificate (per query):
 //   * every block keeps a sorted list of its 16 best rows (LDS, gated by a threshold register: the larger of the
 //     list's 16th score and the admission floor of the phase); the corpus is scanned in phases of growing size and
-//     between phases split_seed_kernel folds the lists into the running 16 best and raises the floors (as in the
-//     bf16 passes);
+//     between phases phase_fold_kernel (mvdb.hip) folds the lists into the running 16 best and raises the floors;
 //   * U = max(floor of the last phase, 16th score of every block list that filled up) bounds a(x) of every row that
 //     was ever dropped;
 //   * half_certify_kernel takes the 64 best candidates by a() from (running nominees + last phase's lists) — the set
 //     R —, raises U to a(64th) when more than 64 candidates sit above it, re-scores R in fp32 (score r), emits the
 //     top-k by r and certifies it with
 //         r(k-th) > U + eps |q| max|x|
-//     Every row outside R has a <= U, hence a true score below the k-th result's.  On exchangeable data the last
-//     phase's floor leaves ~100 candidates, so the test compares the k-th score with the ~64th instead of the 16th:
-//     the margin it needs (1.04e-3) is 4.5x the bf16 passes', the margin it has is ~4x theirs.  Queries that fail
-//     (duplicate-heavy neighbourhoods) are flagged one by one and re-run on the exact fp32 kernels (mvdb.hip).
+//     Every row outside R has a <= U, hence a true score below the k-th result's.  Queries that fail (duplicate-heavy
+//     neighbourhoods) are flagged one by one; the rescue pass below or the exact fp32 kernels (mvdb.hip) answer them.
 //
-// Two kernels compute a(x) and keep the per-block lists; both leave the queries' fp16 fragments in registers for the whole
-// launch and stream the corpus through LDS-DMA rings (global_load_lds, non-temporal):
-//   flat_scan_hq_kernel<KT, PAD, G>   d <= 512 (the default there), 128 G queries per pass.  QUERY split: every wave owns
-//       32 G queries over the full K; the block converts each K-half of a 32-row tile to fp16 once, into LDS, and every
-//       wave reads its fragments from there.  One s_barrier per stage, no exchange.  (Description at the kernel.)
-//   flat_scan_half_kernel<KQ, SKB, NG, NST, SEED>   d = 64 KQ up to 1024, 32 NG queries per pass.  K split: wave w of
-//       four owns 16 KQ columns of every row and ALL queries, streams its slice through a private ring, and after each
-//       round of four 32 x 32 partial score tiles hands three of them to their owners through LDS (two s_barriers per
-//       round).  Serves d = 768 / 1024, and — SEED = one tile per block, every score dumped, no lists — the first launch
-//       of every pass at every d.
-// Algorithmic bytes per launch = rows scanned x ld x 4 (the corpus once for all queries of the pass).
+// Kernels (the queries' fp16 fragments stay in registers for the whole launch, the corpus streams through LDS-DMA rings):
+//   flat_scan_h16_kernel<KT, KS, WV, NST, DEPTH>   the pass itself, over the shadow: 128 / 256 queries per pass (32 per wave),
+//       d = 128 .. 1024; DEPTH = 32: the rescue launch.  Algorithmic bytes per launch = rows scanned x d x 2.
+//   flat_scan_seed_kernel<KQ, SKB, NG, NST>   the first launch of every pass: one 32-row tile of the fp32 rows per block (K
+//       split over four waves, partial score tiles exchanged through LDS), every score dumped — it only produces the floors.
+// (Retired in round 6: the forms of the pass that converted the fp32 rows on the fly — flat_scan_hq_kernel and the main-launch
+//  forms of the K-split kernel, ~700 lines — an index without a shadow answers its batches on the exact fp32 passes.)
 #include <cmath>
 #include <cstdlib>
 #include <map>
@@ -52,12 +38,6 @@
 #include "topk_device.hpp"
 
 namespace mvdb {
-
-#ifndef MVDB_HQ_AHEAD_WIDE
-#define MVDB_HQ_AHEAD_WIDE 6
-#endif
-constexpr int kAheadWide = MVDB_HQ_AHEAD_WIDE;  // fragment reads in flight ahead of the MFMAs, 256 queries at d = 512: with 8 (the other
-                                                // forms' value) the kernel spills 28 bytes at 256 registers; 6: none, +1.7 % q/s
 
 typedef _Float16 hs_h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 hs_h2 __attribute__((ext_vector_type(2)));
@@ -133,34 +113,22 @@ struct HsStage {
     __device__ static __forceinline__ int g(int r) { return SKB == 4 ? (r & 15) : ((r >> 1) & 7); }
 };
 
-template <int KQ, int SKB, int NG, int NST, bool SEED>
-__global__ __launch_bounds__(256) void flat_scan_half_kernel(HalfScanArgs a) {
+template <int KQ, int SKB, int NG, int NST>
+__global__ __launch_bounds__(256) void flat_scan_seed_kernel(HalfScanArgs a) {
     constexpr int NW = 4;
-    // the next tile's stages are prefetched under the MFMAs of round 0 (F double-buffered) where the registers allow:
-    // at d = 1024 (256 query registers + 2 x 64 of F) the prefetching form spills, the tile is loaded up front instead
-    constexpr bool PREFETCH = !SEED && KQ <= 12;
-    // (With 256 registers of query fragments — 256 queries at d = 512, 128 at d = 1024 — hipcc parks the fragments in
-    //  AGPRs and copies each back before its MFMA, 3.5 v_accvgpr_read per MFMA.  Hand-written MFMAs that read the B
-    //  operand straight from the AGPR remove all of them and change nothing measurable: 52.6k q/s either way at
-    //  256 x 10M x 512.  The pass is bound by the exchange, 384 KiB of LDS traffic per tile at 256 queries, not by issue.)
     static_assert(NG % NW == 0 && (SKB == 2 || SKB == 4) && KQ % SKB == 0 && NST >= 2, "shape");
     using St = HsStage<SKB>;
     static_assert((NST - 1) * St::kDma <= 63, "vmcnt is a 6-bit counter");
     constexpr int NR = NG / NW;   // rounds per tile = query groups a wave owns
     constexpr int NS = KQ / SKB;  // stages per tile
-    constexpr int HB = SKB / 2;   // 16-k blocks per half stage
     constexpr int kRing = NST * St::kBytes;
     constexpr int K = NW * KQ * 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // NW rings | exchange window
-    __shared__ uint64_t lists[SEED ? 16 : NG * 32 * kHalfKeep];             // [owner wave][round][32 queries][16] keys
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int fr = lane & 31, fk = lane >> 5;
     unsigned char* wbuf = smem + (size_t)wave * kRing;
     unsigned char* exch = smem + (size_t)NW * kRing;
-    uint64_t* mylists = lists + (size_t)wave * NR * 32 * kHalfKeep;
-    if (!SEED)
-        for (int e = lane; e < NR * 32 * kHalfKeep; e += 64) mylists[e] = 0ull;
 
     // ---- query fragments of this wave's columns.  In round r the wave works on the NW physical groups
     // r NW .. r NW + NW - 1, rotated so that local group j = 0 is the one it OWNS (physical r NW + wave) and local
@@ -175,17 +143,9 @@ __global__ __launch_bounds__(256) void flat_scan_half_kernel(HalfScanArgs a) {
                 const int query = (r * NW + (wave + j) % NW) * 32 + fr;
                 Q[kb][r][j] = *reinterpret_cast<const hs_h8*>(a.qf + (int64_t)query * K + (wave * KQ + kb) * 16 + fk * 8);
             }
-    float floor0[NR], thr[NR], inv[NR];
-    uint32_t thr_row[NR];  // row of the list's k-th key while thr is its score (ties are decided by the row: beats_key), else 0
+    float inv[NR];
 #pragma unroll
-    for (int r = 0; r < NR; ++r) thr_row[r] = 0u;
-#pragma unroll
-    for (int r = 0; r < NR; ++r) {
-        const int myq = (r * NW + wave) * 32 + fr;
-        floor0[r] = myq < a.nq ? (a.thr0 ? a.thr0[myq] : -INFINITY) : INFINITY;
-        thr[r] = floor0[r];
-        inv[r] = a.qinv[myq];
-    }
+    for (int r = 0; r < NR; ++r) inv[r] = a.qinv[(r * NW + wave) * 32 + fr];
     // consume every global load here: the hand-placed vmcnt waits below are invisible to hipcc, a first use inside
     // the loop would get a compiler-made s_waitcnt vmcnt(0) that also drains the DMA ring
 #pragma unroll
@@ -195,7 +155,7 @@ __global__ __launch_bounds__(256) void flat_scan_half_kernel(HalfScanArgs a) {
 #pragma unroll
             for (int j = 0; j < NW; ++j) asm volatile("" : "+v"(Q[kb][r][j]));
 #pragma unroll
-    for (int r = 0; r < NR; ++r) asm volatile("" : "+v"(floor0[r]), "+v"(thr[r]), "+v"(inv[r]));
+    for (int r = 0; r < NR; ++r) asm volatile("" : "+v"(inv[r]));
 
     const int64_t ntiles = a.tile1 - a.tile0;
     const int64_t last = a.n - 1;
@@ -230,7 +190,6 @@ __global__ __launch_bounds__(256) void flat_scan_half_kernel(HalfScanArgs a) {
     const int64_t step = gridDim.x;
     int64_t tile = blockIdx.x;
     const hs_f2 xs = {a.xscale, a.xscale};
-    unsigned n_ins = 0, n_slow = 0;
     int rb = 0;  // ring buffer of the stage consumed next
     struct Raw {
         hs_f4 v[SKB][2];
@@ -307,48 +266,21 @@ __global__ __launch_bounds__(256) void flat_scan_half_kernel(HalfScanArgs a) {
             sc[e] = s * inv[r];  // exact: 1 / (s_q s_x) is a power of two
         }
     };
-    // the gate: D[row][query] with the query on the lane (fr), rows rl + 4 fk in the 16 registers
+    // every score of the tile goes out: [query][block][32 rows] keys (rows past the corpus or outside the bitmap: 0)
     auto gate = [&](auto rc, const float (&sc)[16], int64_t m0) {
         constexpr int r = decltype(rc)::value;
-        if (SEED) {
-            const int myq = (r * NW + wave) * 32 + fr;
-            if (myq < a.nq) {
-                uint64_t* out = a.cand + ((int64_t)myq * gridDim.x + blockIdx.x) * 32;
-                const uint32_t mw = a.mask ? a.mask[m0 >> 5] : 0xffffffffu;  // the tile's 32 rows = one word of the bitmap
+        const int myq = (r * NW + wave) * 32 + fr;
+        if (myq < a.nq) {
+            uint64_t* out = a.cand + ((int64_t)myq * gridDim.x + blockIdx.x) * 32;
+            const uint32_t mw = a.mask ? a.mask[m0 >> 5] : 0xffffffffu;  // the tile's 32 rows = one word of the bitmap
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int rl = (e & 3) + 8 * (e >> 2) + 4 * fk;
-                    out[rl] = (m0 + rl <= last && ((mw >> rl) & 1u)) ? make_key(sc[e], (uint32_t)(m0 + rl)) : 0ull;
-                }
-            }
-        } else {
-            float mx = sc[0];
-#pragma unroll
-            for (int e = 1; e < 16; ++e) mx = fmaxf(mx, sc[e]);
-            if (__ballot(mx >= thr[r]) != 0ull) {
-                ++n_slow;
-                uint64_t* rl_lists = mylists + (size_t)r * 32 * kHalfKeep;
-                const uint32_t mw = a.mask ? a.mask[m0 >> 5] : 0xffffffffu;  // row selection: looked at on the slow path only
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int rl = (e & 3) + 8 * (e >> 2);
-                    const float s = sc[e];
-                    uint64_t mask = __ballot(m0 + rl + 4 * fk <= last && ((mw >> (rl + 4 * fk)) & 1u) && beats_key(s, (uint32_t)(m0 + rl + 4 * fk), thr[r], thr_row[r]));
-                    while (mask) {
-                        const int srcl = __ffsll((long long)mask) - 1;
-                        mask &= mask - 1;
-                        ++n_ins;
-                        const int sq = srcl & 31;
-                        const float sv = __uint_as_float(__builtin_amdgcn_readlane((int)__float_as_uint(s), srcl));
-                        const uint32_t rv = (uint32_t)(m0 + rl + 4 * (srcl >> 5));
-                        const uint64_t kth = lds_list_insert(rl_lists + (size_t)sq * kHalfKeep, kHalfKeep, make_key(sv, rv), lane);
-                        if (fr == sq) set_threshold(kth, floor0[r], thr[r], thr_row[r]);  // both lane halves
-                    }
-                }
+            for (int e = 0; e < 16; ++e) {
+                const int rl = (e & 3) + 8 * (e >> 2) + 4 * fk;
+                out[rl] = (m0 + rl <= last && ((mw >> rl) & 1u)) ? make_key(sc[e], (uint32_t)(m0 + rl)) : 0ull;
             }
         }
     };
-    // whole exchange of one finished round, nothing overlapped (seed launch, and the last round of a block)
+    // whole exchange of one finished round
     auto finish_round = [&](auto rc, hs_f16 (&acc)[NW], int64_t m0) {
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();  // every wave has read what the previous round left in the window
@@ -365,32 +297,19 @@ __global__ __launch_bounds__(256) void flat_scan_half_kernel(HalfScanArgs a) {
         gate(rc, sc, m0);
     };
 
-    hs_h8 F[PREFETCH ? 2 : 1][KQ];  // the wave's slice of the current (/ the next) tile as fp16 A fragments
-    if (tile < ntiles) {
+    hs_h8 F[KQ];  // the wave's slice of the tile as fp16 A fragments
+    if (tile < ntiles) {  // ONE tile per block (the launch's grid = its tiles)
 #pragma unroll
-        for (int g = 0; g < NST; ++g) {
-            const int64_t t = tile + (int64_t)(g / NS) * step;
-            issue_stage(t < ntiles ? t : tile, g % NS, g);
-        }
-        // the first tile's fragments: nothing to overlap with yet
+        for (int g = 0; g < NST; ++g) issue_stage(tile, g % NS, g);  // (stages past the tile's NS: re-reads nobody consumes)
 #pragma unroll
         for (int ks = 0; ks < NS; ++ks) {
             Raw x;
             wait_stage();
             read_stage(x);
             refill(tile, ks);
-            convert(x, F[0], ks);
+            convert(x, F, ks);
         }
-    }
-    // One tile: the MFMAs of round 0 run while the NEXT tile's stages are read, converted and refilled (each half
-    // stage of MFMAs shares a scheduling region with the LDS reads / the DMA issue + conversion it hides).
-    // (Tried and dropped, same speed or slower: a second accumulator set so that a round's exchange runs under the
-    //  MFMAs of the round after it, with F overwritten in place — at 256 queries the query fragments then no longer
-    //  fit beside two accumulator sets: 40 spilled registers at d = 512.)
-    auto tile_body = [&](auto pc) {
-        constexpr int P = PREFETCH ? decltype(pc)::value : 0;
         const int64_t m0 = (a.tile0 + tile) * 32;
-        const int64_t next = tile + step;
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
             hs_f16 acc[NW];
@@ -398,418 +317,18 @@ __global__ __launch_bounds__(256) void flat_scan_half_kernel(HalfScanArgs a) {
             for (int j = 0; j < NW; ++j)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
-            auto mfma_kb = [&](int kb) {
 #pragma unroll
-                for (int j = 0; j < NW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F[P][kb], Q[kb][r][j], acc[j], 0, 0, 0);
-            };
-            if (r == 0 && PREFETCH) {
+            for (int kb = 0; kb < KQ; ++kb)
 #pragma unroll
-                for (int ks = 0; ks < NS; ++ks) {
-                    Raw x;
-                    wait_stage();
-                    read_stage(x);
-#pragma unroll
-                    for (int b = 0; b < HB; ++b) mfma_kb(ks * SKB + b);
-                    refill(next, ks);
-#pragma unroll
-                    for (int b = HB; b < SKB; ++b) mfma_kb(ks * SKB + b);
-                    convert(x, F[PREFETCH ? (P ^ 1) : 0], ks);
-                }
-            } else {
-#pragma unroll
-                for (int kb = 0; kb < KQ; ++kb) mfma_kb(kb);
-            }
+                for (int j = 0; j < NW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F[kb], Q[kb][r][j], acc[j], 0, 0, 0);
             if (r == 0)
                 finish_round(std::integral_constant<int, 0>{}, acc, m0);
             else
                 finish_round(std::integral_constant<int, (NR > 1 ? 1 : 0)>{}, acc, m0);
         }
-        if (!PREFETCH && !SEED) {  // the next tile's fragments, nothing overlapped
-#pragma unroll
-            for (int ks = 0; ks < NS; ++ks) {
-                Raw x;
-                wait_stage();
-                read_stage(x);
-                refill(next, ks);
-                convert(x, F[0], ks);
-            }
-        }
-        tile = next;
-    };
+    }
     static_assert(NR <= 2, "finish_round dispatch covers two rounds");
-    while (tile < ntiles) {
-        tile_body(std::integral_constant<int, 0>{});
-        if (SEED || tile >= ntiles) break;
-        tile_body(std::integral_constant<int, 1>{});
-    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the clamped look-ahead DMAs must land before the LDS is released
-    if (SEED) return;
-    if (a.stats && lane == 0) {
-        atomicAdd(a.stats, n_ins);
-        atomicAdd(a.stats + 1, n_slow);
-    }
-    // every query's list lives in exactly one wave: write the block's nominee lists
-#pragma unroll 1
-    for (int r = 0; r < NR; ++r)
-        for (int q = 0; q < 32; ++q) {
-            const int qq = (r * NW + wave) * 32 + q;
-            if (qq >= a.nq) break;
-            if (lane < kHalfKeep)
-                a.cand[((int64_t)qq * gridDim.x + blockIdx.x) * kHalfKeep + lane] = mylists[((size_t)r * 32 + q) * kHalfKeep + lane];
-        }
-}
-
-// ---- d <= 512, 128 or 256 queries per pass, QUERY split: no exchange ------------------------------------------------
-// The K-split kernel above pays for its register-resident queries with the exchange: three of every four partial
-// scores cross LDS, 384 KiB per 32-row tile at 256 queries — at that width the LDS port, not HBM, sets the pace (0.55 of
-// the HBM roofline).  Here every wave owns 32 G QUERIES (G = 1: 128 per pass, G = 2: 256) over the FULL K (G d / 4 VGPRs:
-// 256 at d = 512, G = 2) and all four waves share the corpus tile instead: the block converts each K-half of a tile to fp16 ONCE, into LDS, and
-// every wave reads the fragments it needs from there.
-//   per K-half stage (32 rows x d / 2 columns):
-//     wave w DMAs rows 8w .. 8w + 7 of the raw fp32 stage into a three-stage ring (global_load_lds, nt) and is also the
-//     only reader of those rows: it converts them (v_pk_mul_f32 + v_cvt_pk_f16_f32) and writes them to one of two
-//     fp16 stage images (row pitch padded or XOR-swizzled so that the MFMA fragment reads are conflict-free) — no
-//     barrier is needed for the raw data, only the wave's own vmcnt;
-//     all waves then read the 32 x 16 fragments of that image and run G x d / 32 MFMAs each.
-//   The conversion of stage g + 1 rides under the MFMAs of stage g (two fp16 images): ONE s_barrier per stage, two
-//   per tile, nothing else is shared.  At the end of a tile every wave gates its own 32 x 64 finished scores.
-//   LDS traffic per corpus byte: 1 (DMA) + 1 (raw read) + 0.5 (fp16 write) + 4 x 0.5 (fragment reads) = 4.5 B against the
-//   8 B of the K-split kernel at 256 queries; no partial sums, no exchange additions.
-// The seed launch of a pass is the K-split kernel's (<KQ, 2, NG, ., true>): it only has to produce floors.
-// Measured (10M rows, k = 10): 40.7k / 66.0k q/s at 128 / 256 queries per pass at d = 512 (K split: 39.4k / 53.1k), 52.4k /
-// 84.7k at d = 384 (48.9k / 63.1k), 73.6k / 107.9k at d = 256 (66.1k / 80.9k); 256 queries = eight waves of 32 queries.  PMC at 256 queries, d = 512: shader clock
-// 1.76 GHz (the chip's power limit: matrix cores 35 % busy beside 6 TB/s of HBM traffic), 5,640 cycles per tile, waves
-// active 43 %, parked on barriers / vmcnt 27 %, issue-stalled 29 %, no LDS bank conflicts.
-// WV = waves per workgroup: 4 (one per SIMD), or 8 (two per SIMD, half the rows and half the queries each: the second
-// wave issues MFMAs while the first sits at the stage barrier; 8 x 16 fragment reads per stage instead of 4 x 16)
-#ifdef MVDB_X3_ABLATE
-// ablation build: shader cycles wave 0 of every block spends per phase of a stage, summed over the launch
-// [0] waiting for the raw stage (vmcnt), [1] raw reads + MFMAs (+ what is interleaved), [2] what follows them before the
-// barrier (refill / conversion when not interleaved, gate), [3] barrier (+ lgkmcnt), [4] stages counted
-__device__ unsigned long long g_hq_phase[8];
-#define HQ_STAMP(v) const unsigned long long v = __builtin_readcyclecounter()
-#else
-#define HQ_STAMP(v) do { } while (0)
-#endif
-
-// PIPE: the refill DMAs of the raw ring and the conversion of the next stage are issued BETWEEN the MFMAs of the current one
-// (one DMA instruction after every second MFMA of the first half of the stage, one converted piece after every second MFMA
-// of the rest) instead of behind them: both waves of a SIMD reach the barrier together, so whatever follows the MFMAs in
-// program order is time the matrix cores idle.  10M x 512, 128 / 256 queries per pass: +1.4 % / +1.3 % q/s; 256 at d = 384: +4 %.
-template <int KT, bool PAD, int G, int WV = 4, bool PIPE = false>
-__global__ __launch_bounds__(WV * 64) void flat_scan_hq_kernel(HalfScanArgs a) {
-    constexpr int KH = KT / 2;               // 16-k blocks per stage (one K-half)
-    constexpr int RAWP = KH * 64;            // raw row pitch in bytes (KH x 16 floats)
-    constexpr int kRaw = 32 * RAWP;          // raw stage: 32 KiB at d = 512
-    constexpr int RW = 32 / WV;              // rows a wave DMAs and converts
-    constexpr int kRawW = RW * RAWP;         // a wave's rows of the stage
-    constexpr int DPW = kRawW / 1024;        // DMA instructions per wave and stage
-    constexpr int SPR = RAWP / 16;           // 16-byte slots per raw row
-    constexpr int HSL = KH * 2;              // 16-byte slots (8 fp16) per fp16 row
-    constexpr int HP = (PAD ? HSL + 1 : HSL) * 16;  // fp16 row pitch: odd slot count, or XOR swizzle at powers of two
-    constexpr int kH = 32 * HP;
-    constexpr int K = KT * 16;
-    static_assert(kRawW % 1024 == 0 && KT % 2 == 0, "shape");
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // 3 raw stages | 2 fp16 images
-    __shared__ uint64_t lists[WV * G * 32 * kHalfKeep];                     // [wave][G groups][32 queries][16] keys
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int fr = lane & 31, fk = lane >> 5;
-    unsigned char* hbuf = smem + 3 * kRaw;
-    uint64_t* mylists = lists + (size_t)wave * G * 32 * kHalfKeep;
-    for (int e = lane; e < G * 32 * kHalfKeep; e += 64) mylists[e] = 0ull;
-
-    // ---- this wave's 64 queries over the whole K: B[k = 16 kb + 8 fk + j][query 32 g + fr]
-    hs_h8 Q[KT][G];
-#pragma unroll
-    for (int kb = 0; kb < KT; ++kb)
-#pragma unroll
-        for (int g = 0; g < G; ++g)
-            Q[kb][g] = *reinterpret_cast<const hs_h8*>(a.qf + (int64_t)((wave * G + g) * 32 + fr) * K + kb * 16 + fk * 8);
-    float floor0[G], thr[G], inv[G];
-    uint32_t thr_row[G];
-#pragma unroll
-    for (int g = 0; g < G; ++g) thr_row[g] = 0u;
-#pragma unroll
-    for (int g = 0; g < G; ++g) {
-        const int myq = (wave * G + g) * 32 + fr;
-        floor0[g] = myq < a.nq ? (a.thr0 ? a.thr0[myq] : -INFINITY) : INFINITY;
-        thr[g] = floor0[g];
-        inv[g] = a.qinv[myq];
-    }
-    // consume every global load here (see flat_scan_half_kernel)
-#pragma unroll
-    for (int kb = 0; kb < KT; ++kb)
-#pragma unroll
-        for (int g = 0; g < G; ++g) asm volatile("" : "+v"(Q[kb][g]));
-#pragma unroll
-    for (int g = 0; g < G; ++g) asm volatile("" : "+v"(floor0[g]), "+v"(thr[g]), "+v"(inv[g]));
-
-    const int64_t ntiles = a.tile1 - a.tile0;
-    const int64_t last = a.n - 1;
-    // ---- roles: DMA instruction i of a stage moves the 16-byte slots 64 i .. 64 i + 63 of the wave's 8 rows (row-major,
-    // lane-linear in LDS); the same (i, lane) reads that slot back for the conversion
-    uint32_t voff[DPW];
-    int hdst[DPW];
-#pragma unroll
-    for (int i = 0; i < DPW; ++i) {
-        const int j = i * 64 + lane;
-        const int row = RW * wave + j / SPR, cs = j % SPR;  // tile row, 16-byte slot (4 floats) of the K-half
-        voff[i] = (uint32_t)(((int64_t)row * a.ld + 4 * cs) * 4);
-        const int hs = cs >> 1;  // fp16 slot (8 elements): two raw slots each
-        hdst[i] = row * HP + ((PAD ? hs : (hs ^ (row & 15))) << 4) + (cs & 1) * 8;
-    }
-    auto issue_piece = [&](int64_t tile, int half, int buf, int i) {
-        const int64_t row0 = (a.tile0 + tile) * 32;
-        const char* sbase = reinterpret_cast<const char*>(a.X + row0 * a.ld + half * KH * 16);
-        unsigned char* dst = smem + buf * kRaw + wave * kRawW;
-        __builtin_amdgcn_global_load_lds((hs_gbl_ptr)(sbase + voff[i]), (hs_lds_ptr)(dst + i * 1024), 16, 0, 2 /* nt */);
-    };
-    auto issue_stage = [&](int64_t tile, int half, int buf) {
-#pragma unroll
-        for (int i = 0; i < DPW; ++i) issue_piece(tile, half, buf, i);
-    };
-    const int frow = fr * HP;
-    const int fsw = PAD ? 0 : (fr & 15);
-    const hs_f2 xs = {a.xscale, a.xscale};
-    const int64_t step = gridDim.x;
-    int64_t tile = blockIdx.x;
-    unsigned n_ins = 0, n_slow = 0;
-    int rb = 0;  // raw buffer of the stage converted next
-    // stage c of the block's flat sequence = (tile + (c / 2) step, half c & 1); stages past the last tile are clamped
-    auto stage_tile = [&](int64_t base, int c) {
-        const int64_t t = base + (int64_t)(c >> 1) * step;
-        return t < ntiles ? t : (base < ntiles ? base : tile);
-    };
-    // converts this wave's rows of the raw stage in buffer rb into fp16 image `hb`, then refills the buffer with the
-    // stage three ahead (`base`, `c`: that stage)
-    struct Raw {
-        hs_f4 v[DPW];
-    };
-    auto read_raw = [&](Raw& x) {
-        const unsigned char* src = smem + rb * kRaw + wave * kRawW + lane * 16;
-#pragma unroll
-        for (int i = 0; i < DPW; ++i) x.v[i] = *reinterpret_cast<const hs_f4*>(src + i * 1024);
-    };
-    auto write_piece = [&](const Raw& x, int hb, int i) {
-        unsigned char* dst = hbuf + hb * kH;
-        union {
-            hs_h2 p[2];
-            hs_f2 f;
-        } u;
-        const hs_f2 lo = {x.v[i][0], x.v[i][1]}, hi = {x.v[i][2], x.v[i][3]};
-        u.p[0] = __builtin_convertvector(lo * xs, hs_h2);  // RNE
-        u.p[1] = __builtin_convertvector(hi * xs, hs_h2);
-        *reinterpret_cast<hs_f2*>(dst + hdst[i]) = u.f;
-    };
-    auto write_half = [&](const Raw& x, int hb) {
-#pragma unroll
-        for (int i = 0; i < DPW; ++i) write_piece(x, hb, i);
-    };
-    auto wait_raw = [&]() {
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * DPW) : "memory");  // the oldest of three stages has landed
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    auto refill = [&](int64_t base, int c) {
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the raw rows are in registers (and the image is written)
-        __builtin_amdgcn_sched_barrier(0);
-        issue_stage(stage_tile(base, c), c & 1, rb);
-        rb = rb == 2 ? 0 : rb + 1;
-    };
-    hs_f16 acc[G];
-    auto zero_acc = [&]() {
-#pragma unroll
-        for (int g = 0; g < G; ++g)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[g][e] = 0.f;
-    };
-    // MFMAs of K-half `half` from fp16 image hb
-    auto mfma_half = [&](int half, int hb) {
-        const unsigned char* src = hbuf + hb * kH + frow;
-        auto frag = [&](int kb) { return *reinterpret_cast<const hs_h8*>(src + (((2 * kb + fk) ^ fsw) << 4)); };
-        // fragments three 16-k blocks ahead of the MFMAs that use them (hipcc otherwise reuses ONE register quad and
-        // waits for every read: ds_read, lgkmcnt(0), two MFMAs, ds_read ... with the LDS latency exposed each time)
-        constexpr int AHEAD = (WV == 8 && KT >= 32) ? kAheadWide : (KH < 8 ? KH : 8);
-        hs_h8 f[AHEAD + 1];
-#pragma unroll
-        for (int u = 0; u < AHEAD; ++u) f[u] = frag(u);
-#pragma unroll
-        for (int kb = 0; kb < KH; ++kb) {
-            if (kb + AHEAD < KH) f[(kb + AHEAD) % (AHEAD + 1)] = frag(kb + AHEAD);
-#pragma unroll
-            for (int g = 0; g < G; ++g)
-                acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[kb % (AHEAD + 1)], Q[half * KH + kb][g], acc[g], 0, 0, 0);
-        }
-        // the order the scheduler must keep: the raw reads of the conversion and the first fragments up front, then one
-        // fragment read per pair of MFMAs (the AGPR -> VGPR copies of the query fragments ride in between)
-        __builtin_amdgcn_sched_group_barrier(0x100, AHEAD, 0);
-#pragma unroll
-        for (int kb = 0; kb < KH; ++kb) {
-            if (kb + AHEAD < KH) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, 4 * G, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, G, 0);
-        }
-    };
-    // PIPE: MFMAs of (tile, half) from image hb with, between them, the refill of the raw buffer just read (stage `c` of
-    // `base`) and the conversion of x into the other image
-    // (Measured on top and dropped, 10M x 512, 256 queries per pass, 66.9k q/s with this order: the refill as ONE burst right
-    //  behind the stage's barrier, where nothing of the wave is in flight — 65.1k; the upper half of the block's waves running
-    //  conversion first and DMAs last so that half as many waves queue on the CU's vector-memory path at a time — 40.3k, the
-    //  two code copies spill.  benchmarks/micro/load_issue_cost.hip: a 1-KiB load, LDS-DMA or into VGPRs alike, costs its
-    //  wave ~44 cycles of issue when four waves of a CU issue together and ~97 when eight do — the path takes ~12 cycles per
-    //  KiB CU-wide, and a wave stalled in it issues no MFMA either.  benchmarks/hq_phases.py (ablation build) stamps the
-    //  phases of a stage: at 256 queries wave 0 spends 1,011 cycles on the 16 MFMAs (512 cycles of matrix-core time) with the
-    //  DMAs, the conversion and the fragment reads between them, and 1,042 waiting at the barrier for its SIMD mate to do the same.)
-    auto piped_half = [&](int half, int hb, const Raw& x, int64_t base, int c) {
-        const unsigned char* src = hbuf + hb * kH + frow;
-        auto frag = [&](int kb) { return *reinterpret_cast<const hs_h8*>(src + (((2 * kb + fk) ^ fsw) << 4)); };
-        constexpr int AHEAD = (WV == 8 && KT >= 32) ? kAheadWide : (KH < 8 ? KH : 8);
-        constexpr int D0 = 1, DS = (KH / 2 - D0) / DPW > 0 ? (KH / 2 - D0) / DPW : 1;  // DMA piece i after MFMA block D0 + i DS
-        constexpr int C0 = D0 + DPW * DS, CS = (KH - C0) / DPW > 0 ? (KH - C0) / DPW : 1;  // converted piece i after block C0 + i CS
-        hs_h8 f[AHEAD + 1];
-        const int64_t rt = stage_tile(base, c);
-#pragma unroll
-        for (int u = 0; u < AHEAD; ++u) f[u] = frag(u);
-        __builtin_amdgcn_sched_barrier(0);
-        constexpr int ND = (KH - 1 - D0) / DS + 1 < DPW ? (KH - 1 - D0) / DS + 1 : DPW;              // pieces placed inside the loop
-        constexpr int NC = C0 < KH ? ((KH - 1 - C0) / CS + 1 < DPW ? (KH - 1 - C0) / CS + 1 : DPW) : 0;
-#pragma unroll
-        for (int kb = 0; kb < KH; ++kb) {
-            if (kb + AHEAD < KH) f[(kb + AHEAD) % (AHEAD + 1)] = frag(kb + AHEAD);
-#pragma unroll
-            for (int g = 0; g < G; ++g)
-                acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[kb % (AHEAD + 1)], Q[half * KH + kb][g], acc[g], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (kb >= D0 && (kb - D0) % DS == 0 && (kb - D0) / DS < ND) {
-                // the raw rows are older LDS reads than every fragment read: with at most AHEAD + 1 of the newest outstanding
-                // they are in registers
-                if (kb == D0) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(AHEAD + 1) : "memory");
-                issue_piece(rt, c & 1, rb, (kb - D0) / DS);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if (kb >= C0 && (kb - C0) % CS == 0 && (kb - C0) / CS < NC) {
-                write_piece(x, hb ^ 1, (kb - C0) / CS);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-#pragma unroll
-        for (int i = ND; i < DPW; ++i) issue_piece(rt, c & 1, rb, i);
-#pragma unroll
-        for (int i = NC; i < DPW; ++i) write_piece(x, hb ^ 1, i);
-        rb = rb == 2 ? 0 : rb + 1;
-    };
-    auto gate = [&](int64_t m0) {
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-            float sc[16];
-#pragma unroll
-            for (int e = 0; e < 16; ++e) sc[e] = acc[g][e] * inv[g];  // exact: 1 / (s_q s_x) is a power of two
-            float mx = sc[0];
-#pragma unroll
-            for (int e = 1; e < 16; ++e) mx = fmaxf(mx, sc[e]);
-            if (__ballot(mx >= thr[g]) != 0ull) {
-                ++n_slow;
-                uint64_t* gl = mylists + (size_t)g * 32 * kHalfKeep;
-                const uint32_t mw = a.mask ? a.mask[m0 >> 5] : 0xffffffffu;  // row selection: looked at on the slow path only
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int rl = (e & 3) + 8 * (e >> 2);
-                    const float s = sc[e];
-                    uint64_t mask = __ballot(m0 + rl + 4 * fk <= last && ((mw >> (rl + 4 * fk)) & 1u) && beats_key(s, (uint32_t)(m0 + rl + 4 * fk), thr[g], thr_row[g]));
-                    while (mask) {
-                        const int srcl = __ffsll((long long)mask) - 1;
-                        mask &= mask - 1;
-                        ++n_ins;
-                        const int sq = srcl & 31;
-                        const float sv = __uint_as_float(__builtin_amdgcn_readlane((int)__float_as_uint(s), srcl));
-                        const uint32_t rv = (uint32_t)(m0 + rl + 4 * (srcl >> 5));
-                        const uint64_t kth = lds_list_insert(gl + (size_t)sq * kHalfKeep, kHalfKeep, make_key(sv, rv), lane);
-                        if (fr == sq) set_threshold(kth, floor0[g], thr[g], thr_row[g]);  // both lane halves
-                    }
-                }
-            }
-        }
-    };
-
-    if (tile < ntiles) {
-        // three raw stages in flight; the first is converted with nothing to overlap
-        issue_stage(tile, 0, 0);
-        issue_stage(tile, 1, 1);
-        issue_stage(stage_tile(tile, 2), 0, 2);
-        Raw x;
-        wait_raw();
-        read_raw(x);
-        refill(tile, 3);
-        write_half(x, 0);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();  // image 0 = (tile, half 0) is complete
-        __builtin_amdgcn_sched_barrier(0);
-    }
-#ifdef MVDB_X3_ABLATE
-    unsigned long long ph[5] = {0, 0, 0, 0, 0};
-#endif
-    while (tile < ntiles) {
-        const int64_t m0 = (a.tile0 + tile) * 32;
-        zero_acc();
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            // MFMAs of (tile, half) from image `half`; beside them the conversion of the NEXT stage — (tile, 1) or
-            // (tile + step, 0) — into the other image, whose readers all passed the barrier that ended the last stage
-            Raw x;
-            HQ_STAMP(t0);
-            wait_raw();
-            HQ_STAMP(t1);
-            read_raw(x);
-            __builtin_amdgcn_sched_barrier(0);  // the raw reads go first: their latency and the conversion hide under the MFMAs
-            if (PIPE) {
-                piped_half(half, half, x, tile, half + 4);
-                __builtin_amdgcn_sched_barrier(0);
-            } else {
-                mfma_half(half, half);
-            }
-            HQ_STAMP(t2);
-            if (!PIPE) {
-                refill(tile, half + 4);  // the stage three past the one just read: flat index (half + 1) + 3
-                write_half(x, half ^ 1);
-            }
-            if (half == 1) gate(m0);
-            __builtin_amdgcn_sched_barrier(0);
-            HQ_STAMP(t3);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();  // the other image is complete; every wave is done reading this one
-            __builtin_amdgcn_sched_barrier(0);
-#ifdef MVDB_X3_ABLATE
-            {
-                HQ_STAMP(t4);
-                ph[0] += t1 - t0;
-                ph[1] += t2 - t1;
-                ph[2] += t3 - t2;
-                ph[3] += t4 - t3;
-                ph[4] += 1;
-            }
-#endif
-        }
-        tile += step;
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the clamped look-ahead DMAs must land before the LDS is released
-#ifdef MVDB_X3_ABLATE
-    if (threadIdx.x == 0)
-        for (int i = 0; i < 5; ++i) atomicAdd(&g_hq_phase[i], ph[i]);
-#endif
-    if (a.stats && lane == 0) {
-        atomicAdd(a.stats, n_ins);
-        atomicAdd(a.stats + 1, n_slow);
-    }
-#pragma unroll 1
-    for (int q = 0; q < G * 32; ++q) {
-        const int qq = wave * G * 32 + q;
-        if (qq >= a.nq) break;
-        if (lane < kHalfKeep)
-            a.cand[((int64_t)qq * gridDim.x + blockIdx.x) * kHalfKeep + lane] = mylists[(size_t)q * kHalfKeep + lane];
-    }
 }
 
 // ---- the same pass over the fp16 SHADOW of the corpus (round 4) -------------------------------------------------------
@@ -1052,7 +571,7 @@ int launch_half_norms(const float* X, int64_t ld, int d, int64_t n, float* Hn, i
 
 // d <= 512: 128 and 256 queries per pass; d = 640 .. 1024 (e5-large / bge-m3 widths): 128 queries per pass, one wave per SIMD
 // (160 - 256 registers of query fragments)
-bool half_shadow_dim(int d) { return d == 256 || d == 384 || d == 512 || d == 640 || d == 768 || d == 896 || d == 1024; }
+bool half_shadow_dim(int d) { return d == 128 || d == 256 || d == 384 || d == 512 || d == 640 || d == 768 || d == 896 || d == 1024; }
 
 template <int KT, int KS, int WV, int NST, int BPC = 1>
 static int launch_h16_inst(const HalfScanArgs& a, int device, hipStream_t stream, int* nblocks_out) {
@@ -1091,6 +610,7 @@ static int launch_h16(int d, int nqpad, const HalfScanArgs& a, int device, hipSt
     const bool wide = nqpad == 256;
     if (nqpad != 128 && nqpad != 256) return fail(MVDB_ERR_ARG, "no fp16-shadow kernel for %d queries per pass", nqpad);
     switch (d) {
+        case 128: return wide ? launch_h16_inst<8, 8, 8, 4>(a, device, stream, nb) : launch_h16_inst<8, 8, 4, 4, 2>(a, device, stream, nb);
         case 256: return wide ? launch_h16_inst<16, 16, 8, 4>(a, device, stream, nb) : launch_h16_inst<16, 16, 4, 4, 2>(a, device, stream, nb);
         case 384: return wide ? launch_h16_inst<24, 24, 8, 4>(a, device, stream, nb) : launch_h16_inst<24, 24, 4, 2, 2>(a, device, stream, nb);
         case 512: return wide ? launch_h16_inst<32, 32, 8, 3>(a, device, stream, nb) : launch_h16_inst<32, 32, 4, 2, 2>(a, device, stream, nb);
@@ -1137,6 +657,7 @@ static int launch_h16_rescue_inst(const HalfScanArgs& a, int device, hipStream_t
 bool half_rescue_dim(int d) { return half_shadow_dim(d); }
 int launch_half_rescue_scan(int d, const HalfScanArgs& a, int device, hipStream_t stream, int* nb) {
     switch (d) {
+        case 128: return launch_h16_rescue_inst<8, 4>(a, device, stream, nb);
         case 256: return launch_h16_rescue_inst<16, 4>(a, device, stream, nb);
         case 384: return launch_h16_rescue_inst<24, 3>(a, device, stream, nb);
         case 512: return launch_h16_rescue_inst<32, 3>(a, device, stream, nb);
@@ -1363,17 +884,8 @@ float half_xscale(float row_norm_bound) {
     return std::ldexp(1.f, 15 - e);
 }
 
-// Instantiations: d = 64 KQ.  128 queries per pass: 8-KiB stages x 3 at d = 512 / 768, 4-KiB stages x 6 otherwise;
-// 256 queries per pass (two exchange rounds per tile, 32 KiB of lists): 4-KiB stages x 5.
-static int half_kq(int d) {
-    switch (d) {
-        // even KQ from 4: stages of two 16-k blocks.  (d = 128 was tried in round 3 and is NOT served: the query-split
-        // kernel's swizzled fp16 image needs 16 slots per row — at KT = 8 it certified a wrong id in
-        // test_split_precision_batch_pass_matches_oracle[270001-128-5-130]; it stays on the bf16 split pass)
-        case 256: case 384: case 512: case 640: case 768: case 896: case 1024: return d / 64;
-        default: return 0;
-    }
-}
+// widths the pass serves (d = 64 KQ for the seed launch, whose four waves split K evenly): those with a shadow kernel
+static int half_kq(int d) { return half_shadow_dim(d) ? d / 64 : 0; }
 
 int half_max_queries(int d) {
     if (!half_kq(d)) return 0;
@@ -1395,11 +907,13 @@ int launch_half_queries(const float* q, int64_t ld, int d, int nq, int nqpad, fl
     return 0;
 }
 
-template <int KQ, int SKB, int NG, int NST, bool SEED>
-static int launch_half_inst(const HalfScanArgs& a, int device, hipStream_t stream, int* nblocks_out) {
-    auto kern = flat_scan_half_kernel<KQ, SKB, NG, NST, SEED>;
-    constexpr size_t lds = (size_t)4 * NST * HsStage<SKB>::kBytes + (size_t)4 * 3 * 4096;
-    static_assert(lds + (SEED ? 128 : NG * 32 * kHalfKeep * 8) <= 160 * 1024, "LDS budget of a CU");
+// SEED launch of a pass: one 32-row tile per block over the fp32 rows (K split over the four waves, partial score tiles exchanged
+// through LDS), every score dumped: [nq][blocks][32] keys.  It only has to produce the first admission floors.
+template <int KQ, int NG, int NST>
+static int launch_seed_inst(const HalfScanArgs& a, int device, hipStream_t stream, int* nblocks_out) {
+    auto kern = flat_scan_seed_kernel<KQ, 2, NG, NST>;
+    constexpr size_t lds = (size_t)4 * NST * HsStage<2>::kBytes + (size_t)4 * 3 * 4096;
+    static_assert(lds + 128 <= 160 * 1024, "LDS budget of a CU");
     {
         static std::mutex mu;
         static std::map<int, bool> done;
@@ -1412,79 +926,38 @@ static int launch_half_inst(const HalfScanArgs& a, int device, hipStream_t strea
     const int64_t ntiles = a.tile1 - a.tile0;
     const int nblocks = (int)std::max<int64_t>(1, std::min<int64_t>(ntiles, (int64_t)device_cus(device)));
     *nblocks_out = nblocks;
-    prof_symbol(SEED ? "ip_scan_half_seed" : "ip_scan_half", "flat_scan_half_kernel<%d, %d, %d, %d, %s>", KQ, SKB, NG, NST,
-                SEED ? "true" : "false");
-    int slot = prof_begin(SEED ? "ip_scan_half_seed" : "ip_scan_half", stream);
+    prof_symbol("ip_scan_half_seed", "flat_scan_seed_kernel<%d, 2, %d, %d>", KQ, NG, NST);
+    int slot = prof_begin("ip_scan_half_seed", stream);
     hipLaunchKernelGGL(kern, dim3(nblocks), dim3(256), lds, stream, a);
     prof_end(slot, stream);
     MVDB_HIP(hipGetLastError());
     return 0;
 }
 
-template <int KT, bool PAD, int G, int WV = 4>
-static int launch_hq_inst(const HalfScanArgs& a, bool pipe, int device, hipStream_t stream, int* nblocks_out) {
-    // pipe = false (MVDB_HQ_PIPE=0): DMA refill + conversion behind the MFMAs (A/B)
-    auto kern = pipe ? flat_scan_hq_kernel<KT, PAD, G, WV, true> : flat_scan_hq_kernel<KT, PAD, G, WV, false>;
-    constexpr int KH = KT / 2;
-    constexpr size_t lds = (size_t)3 * 32 * KH * 64 + (size_t)2 * 32 * (PAD ? 2 * KH + 1 : 2 * KH) * 16;
-    static_assert(lds + 32 * WV * G * kHalfKeep * 8 <= 160 * 1024, "LDS budget of a CU");
-    {
-        static std::mutex mu;
-        static std::map<int, bool> done;
-        std::lock_guard<std::mutex> lk(mu);
-        if (!done[device]) {
-            MVDB_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            done[device] = true;
-        }
-    }
-    const int64_t ntiles = a.tile1 - a.tile0;
-    const int nblocks = (int)std::max<int64_t>(1, std::min<int64_t>(ntiles, (int64_t)device_cus(device)));
-    *nblocks_out = nblocks;
-    prof_symbol("ip_scan_half", "flat_scan_hq_kernel<%d, %s, %d, %d, %s>", KT, PAD ? "true" : "false", G, WV, pipe ? "true" : "false");
-    int slot = prof_begin("ip_scan_half", stream);
-    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(WV * 64), lds, stream, a);
-    prof_end(slot, stream);
-    MVDB_HIP(hipGetLastError());
-    return 0;
+template <int KQ>
+static int launch_seed_kq(int nqpad, const HalfScanArgs& a, int device, hipStream_t stream, int* nb) {
+    if (nqpad == 128) return launch_seed_inst<KQ, 4, 6>(a, device, stream, nb);
+    if constexpr (KQ <= 8)
+        if (nqpad == 256) return launch_seed_inst<KQ, 8, 5>(a, device, stream, nb);
+    return fail(MVDB_ERR_ARG, "no seed kernel for %d queries per pass at d = %d", nqpad, KQ * 64);
 }
 
-template <int KQ, int SKB4>
-static int launch_half_kq(int nqpad, bool seed, const HalfScanArgs& a, const Knobs& kn, int device, hipStream_t stream, int* nb) {
-    // SKB4: 8-KiB stages for the 128-query main launch where KQ % 4 == 0 (d = 512: same speed as 4-KiB stages, 0.81 of
-    // the HBM peak; d = 768: 0.84)
-    if (nqpad == 128) {
-        if (seed) return launch_half_inst<KQ, 2, 4, 6, true>(a, device, stream, nb);
-        // d <= 512: the query-split kernel (no exchange) — 40.8k vs 39.4k q/s at d = 512, 51.9k vs 48.9k at 384, 73.6k vs
-        // 66.1k at 256 (10M rows); MVDB_HALF_KSPLIT=1 keeps the K-split form for A/B runs.  d = 768 / 1024: K split (a
-        // three-stage ring of raw K-halves no longer fits beside the fp16 images)
-        if constexpr (KQ <= 8)
-            if (!kn.half_ksplit) return launch_hq_inst<KQ * 4, (KQ & (KQ - 1)) != 0, 1>(a, kn.hq_pipe, device, stream, nb);
-        if (SKB4 && !kn.half_small_stages) return launch_half_inst<KQ, (SKB4 ? 4 : 2), 4, (SKB4 ? 3 : 6), false>(a, device, stream, nb);
-        return launch_half_inst<KQ, 2, 4, 6, false>(a, device, stream, nb);
-    }
-    if constexpr (KQ <= 8) {
-        if (nqpad == 256) {
-            if (seed) return launch_half_inst<KQ, 2, 8, 5, true>(a, device, stream, nb);
-            if (kn.half_ksplit) return launch_half_inst<KQ, 2, 8, 5, false>(a, device, stream, nb);  // A/B: the K-split form
-            // eight waves of 32 queries (two per SIMD) rather than four of 64: 66.0k vs 61.5k q/s at d = 512, 84.7k vs 79.3k
-            // at 384, 107.9k vs 103.7k at 256; MVDB_HQ_W4=1 keeps the four-wave form for A/B runs
-            if (kn.hq_w4) return launch_hq_inst<KQ * 4, (KQ & (KQ - 1)) != 0, 2>(a, kn.hq_pipe, device, stream, nb);
-            return launch_hq_inst<KQ * 4, (KQ & (KQ - 1)) != 0, 1, 8>(a, kn.hq_pipe, device, stream, nb);
-        }
-    }
-    return fail(MVDB_ERR_ARG, "no fp16 nomination kernel for %d queries per pass at d = %d", nqpad, KQ * 64);
-}
-
+// seed = true: the seed launch (fp32 rows); else a main launch over the fp16 shadow a.Xh (which the caller has ensured)
 int launch_half_scan(int d, int nqpad, bool seed, const HalfScanArgs& a, const Knobs& kn, int device, hipStream_t stream, int* nblocks_out) {
-    if (!seed && a.Xh && half_shadow_dim(d)) return launch_h16(d, nqpad, a, device, stream, nblocks_out);
+    (void)kn;
+    if (!seed) {
+        if (!a.Xh || !half_shadow_dim(d)) return fail(MVDB_ERR_ARG, "internal: the certified pass needs the fp16 shadow (d = %d)", d);
+        return launch_h16(d, nqpad, a, device, stream, nblocks_out);
+    }
     switch (half_kq(d)) {
-        case 4: return launch_half_kq<4, 0>(nqpad, seed, a, kn, device, stream, nblocks_out);
-        case 6: return launch_half_kq<6, 0>(nqpad, seed, a, kn, device, stream, nblocks_out);
-        case 8: return launch_half_kq<8, 1>(nqpad, seed, a, kn, device, stream, nblocks_out);
-        case 10: return launch_half_kq<10, 0>(nqpad, seed, a, kn, device, stream, nblocks_out);
-        case 12: return launch_half_kq<12, 1>(nqpad, seed, a, kn, device, stream, nblocks_out);
-        case 14: return launch_half_kq<14, 0>(nqpad, seed, a, kn, device, stream, nblocks_out);
-        case 16: return launch_half_kq<16, 0>(nqpad, seed, a, kn, device, stream, nblocks_out);
+        case 2: return launch_seed_kq<2>(nqpad, a, device, stream, nblocks_out);
+        case 4: return launch_seed_kq<4>(nqpad, a, device, stream, nblocks_out);
+        case 6: return launch_seed_kq<6>(nqpad, a, device, stream, nblocks_out);
+        case 8: return launch_seed_kq<8>(nqpad, a, device, stream, nblocks_out);
+        case 10: return launch_seed_kq<10>(nqpad, a, device, stream, nblocks_out);
+        case 12: return launch_seed_kq<12>(nqpad, a, device, stream, nblocks_out);
+        case 14: return launch_seed_kq<14>(nqpad, a, device, stream, nblocks_out);
+        case 16: return launch_seed_kq<16>(nqpad, a, device, stream, nblocks_out);
         default: return fail(MVDB_ERR_ARG, "no fp16 nomination kernel for d = %d", d);
     }
 }
@@ -1496,14 +969,3 @@ int launch_half_certify(const HalfCertifyArgs& a, int nq, hipStream_t stream) {
 }
 
 }  // namespace mvdb
-
-#ifdef MVDB_X3_ABLATE
-// ablation build only: reads and clears the per-phase cycle sums of the query-split kernel's launches so far
-extern "C" int mvdb_debug_hq_phases(unsigned long long* out) {
-    if (hipDeviceSynchronize() != hipSuccess) return -1;
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(mvdb::g_hq_phase), 8 * sizeof(unsigned long long)) != hipSuccess) return -1;
-    void* sym = nullptr;
-    if (hipGetSymbolAddress(&sym, HIP_SYMBOL(mvdb::g_hq_phase)) != hipSuccess) return -1;
-    return hipMemset(sym, 0, 8 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
-}
-#endif

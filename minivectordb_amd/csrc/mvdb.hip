@@ -16,7 +16,6 @@
 #include "common.hpp"
 #include "scan_kernels.hpp"
 #include "scan_mfma_kernels.hpp"
-#include "scan_split_kernels.hpp"
 #include "select_kernels.hpp"
 #include "half_scan.hpp"
 #include "util_kernels.hpp"
@@ -48,19 +47,13 @@ Knobs read_knobs() {
     k.gemm_scan_min_nq = env_int("MVDB_GEMM_SCAN_MIN_NQ", 104);
     k.gemm_scan_blocks_per_cu = env_int("MVDB_GEMM_SCAN_BLOCKS_PER_CU", 2);
     k.split_scan_min_nq = env_int("MVDB_SPLIT_SCAN_MIN_NQ", -1);
-    k.split32_min_nq = env_int("MVDB_SPLIT32_MIN_NQ", 14);
-    k.split32_blocks_per_cu = env_int("MVDB_SPLIT32_BLOCKS_PER_CU", 2);
-    k.split_phase_growth = env_int("MVDB_SPLIT_PHASE_GROWTH", 8);
     k.half_phase_growth = env_int("MVDB_HALF_PHASE_GROWTH", 0);   // 0: by the pass width (launch_half_pass)
     k.half_last_growth = env_int("MVDB_HALF_LAST_GROWTH", 0);
-    k.split_dbg = env_int("MVDB_SPLIT_DBG", 0);
     k.split_stats = env_int("MVDB_SPLIT_STATS", 0) != 0;
-    k.split_one_phase = env_int("MVDB_SPLIT_ONE_PHASE", 0) != 0;
     k.disable_mfma_scan = env_int("MVDB_DISABLE_MFMA_SCAN", 0) != 0;
     k.disable_l2_mfma = env_int("MVDB_DISABLE_L2_MFMA", 0) != 0;
     k.disable_gemm_scan = env_int("MVDB_DISABLE_GEMM_SCAN", 0) != 0;
     k.disable_split_scan = env_int("MVDB_DISABLE_SPLIT_SCAN", 0) != 0;
-    k.disable_split32 = env_int("MVDB_DISABLE_SPLIT32", 0) != 0;
     k.disable_half_scan = env_int("MVDB_DISABLE_HALF_SCAN", 0) != 0;
     k.disable_rerun_floor = env_int("MVDB_DISABLE_RERUN_FLOOR", 0) != 0;
     k.disable_rescue = env_int("MVDB_DISABLE_RESCUE", 0) != 0;
@@ -68,13 +61,6 @@ Knobs read_knobs() {
     k.disable_l2_cert = env_int("MVDB_DISABLE_L2_CERT", 0) != 0;
     k.disable_half_shadow = env_int("MVDB_DISABLE_HALF_SHADOW", 0) != 0;
     k.shadow_single_query = env_int("MVDB_SHADOW_SINGLE_QUERY", 0) != 0;
-    {
-        const char* v = getenv("MVDB_HQ_PIPE");
-        k.hq_pipe = !(v && *v == '0');
-    }
-    k.half_ksplit = getenv("MVDB_HALF_KSPLIT") != nullptr;
-    k.half_small_stages = getenv("MVDB_HALF_SMALL_STAGES") != nullptr;
-    k.hq_w4 = getenv("MVDB_HQ_W4") != nullptr;
     if (const char* v = getenv("MVDB_COMPACT_BYTES"))
         if (*v) k.compact_bytes = std::max(1ll, atoll(v));
     return k;
@@ -201,7 +187,7 @@ struct Workspace {
     DevBuf<float> scores;
     DevBuf<uint64_t> selkeys;
     DevBuf<int64_t> rows;
-    DevBuf<__bf16> qsplit;  // bf16 (hi | lo) images of one 128-query chunk (split-precision pass)
+    DevBuf<__bf16> qsplit;  // the fp16 image of one chunk of queries (certified pass; 2-byte elements)
     DevBuf<float> qnorm;
     DevBuf<int> flags;      // per-chunk count of uncertified queries
     DevBuf<int> qfail;      // per query: 1 = failed certification; behind them the compact list of those queries
@@ -633,8 +619,12 @@ int launch_mfma2(int KB, const MfmaScanArgs& a, int device, hipStream_t s, int* 
                              : launch_mfma2_inst<32, NG, 8>(a, device, s, nb, metric);
         // d = 768 / 1024 (e5-large, bge-m3 widths): one query group only — the 192 / 256 registers of
         // query fragments leave one wave per SIMD, like two groups at d = 512
+        case 40: if (NG == 1) return launch_mfma2_inst<40, 1, 8>(a, device, s, nb, metric);   // (d = 640 / 896: round 6 — the exact pass
+                 break;                                                                      //  behind the rescue tier at those widths)
         case 48: if (NG == 1) return deep ? launch_mfma2_inst<48, 1, 16>(a, device, s, nb, metric)
                                           : launch_mfma2_inst<48, 1, 8>(a, device, s, nb, metric);
+                 break;
+        case 56: if (NG == 1) return launch_mfma2_inst<56, 1, 8>(a, device, s, nb, metric);
                  break;
         case 64: if (NG == 1) return deep ? launch_mfma2_inst<64, 1, 16>(a, device, s, nb, metric)
                                           : launch_mfma2_inst<64, 1, 8>(a, device, s, nb, metric);
@@ -645,11 +635,11 @@ int launch_mfma2(int KB, const MfmaScanArgs& a, int device, hipStream_t s, int* 
 }
 
 // The exact re-run of uncertified queries (search_core): the same pass, enabled on the device by `*gate > gate_lo`.
-// Returns the queries one launch takes (32 at d <= 512, 16 at d = 768 / 1024), 0 when there is no kernel for d.
+// Returns the queries one launch takes (32 at d <= 512, 16 at d = 640 .. 1024), 0 when there is no kernel for d.
 int mfma_gated_queries(const mvdb_index* idx) {
     const int KB = idx->d / 16;
     if (idx->d % 128 != 0) return 0;  // the staged kernel only
-    return KB <= 32 ? 32 : (KB == 48 || KB == 64) ? 16 : 0;
+    return KB <= 32 ? 32 : KB <= 64 ? 16 : 0;
 }
 int launch_mfma2_gated(int KB, const MfmaScanArgs& a, int device, hipStream_t s, int* nb, const int* gate, int gate_lo,
                        const int* need = nullptr, int npasses = 1, int per_pass = 0, int rtot = 0, int64_t cand_stride = 0) {
@@ -671,7 +661,9 @@ int launch_mfma2_gated(int KB, const MfmaScanArgs& a, int device, hipStream_t s,
         case 16: return launch_mfma2_gated_inst<16, 2, 8>(a, device, s, nb, gate, gate_lo, need, npasses, per_pass, rtot, cand_stride);
         case 24: return launch_mfma2_gated_inst<24, 2, 8>(a, device, s, nb, gate, gate_lo, need, npasses, per_pass, rtot, cand_stride);
         case 32: return launch_mfma2_gated_inst<32, 2, 8>(a, device, s, nb, gate, gate_lo, need, npasses, per_pass, rtot, cand_stride);
+        case 40: return launch_mfma2_gated_inst<40, 1, 8>(a, device, s, nb, gate, gate_lo, need, npasses, per_pass, rtot, cand_stride);
         case 48: return launch_mfma2_gated_inst<48, 1, 8>(a, device, s, nb, gate, gate_lo, need, npasses, per_pass, rtot, cand_stride);
+        case 56: return launch_mfma2_gated_inst<56, 1, 8>(a, device, s, nb, gate, gate_lo, need, npasses, per_pass, rtot, cand_stride);
         case 64: return launch_mfma2_gated_inst<64, 1, 8>(a, device, s, nb, gate, gate_lo, need, npasses, per_pass, rtot, cand_stride);
         default: break;
     }
@@ -691,10 +683,16 @@ int launch_mfma_ng(int KB, const MfmaScanArgs& a, int device, hipStream_t s, int
 }
 
 // nq >= 64, k <= 16: compute-bound tiled GEMM + top-k (scan_mfma_kernels.hpp, last section)
+bool mfma_path_ok(const mvdb_index* idx, int nq, int k, const int64_t* rows_dev);
+// Fewest queries of a call for the GEMM-tiled exact scan (128 queries per launch, compute-bound: one launch costs ~4.7 single
+// scans at 10M x 512): 104 where the fp32-MFMA passes exist (32 queries per HBM-bound pass), 6 at the widths that have neither
+// those nor the certified pass (d % 16 == 0 outside 64 / 128 / ... / 1024: the retired bf16-split generation served them).
+int gemm_min_nq(const mvdb_index* idx, int k) {
+    return mfma_path_ok(idx, 2, k, nullptr) ? idx->kn.gemm_scan_min_nq : std::min(idx->kn.gemm_scan_min_nq, 6);
+}
 bool gemm_path_ok(const mvdb_index* idx, int nq, int k, const int64_t* rows_dev) {
     if (idx->kn.disable_gemm_scan) return false;
-    if (nq < idx->kn.gemm_scan_min_nq || k > kGemmScanMaxK || rows_dev || idx->metric != MVDB_METRIC_IP)
-        return false;
+    if (k > kGemmScanMaxK || rows_dev || idx->metric != MVDB_METRIC_IP || nq < gemm_min_nq(idx, k)) return false;
     return idx->d % 16 == 0 && idx->ld == idx->d;
 }
 
@@ -730,7 +728,6 @@ int launch_gemm_scan(const mvdb_index* idx, const float* q, int nq, int k, int64
     return 0;
 }
 
-// nq >= 33, k <= 12, rows of known norm: split-precision bf16 pass + exact certification (scan_split_kernels.hpp)
 // Chunks that held an uncertified query, counted ON THE DEVICE (split_plan_kernel): the host never reads a certification
 // flag on the search path.  One counter per device, read (with a device synchronise) by mvdb_split_rerun_count().
 std::mutex g_rerun_mu;
@@ -745,31 +742,8 @@ unsigned long long* rerun_counter(int device) {
     return p;
 }
 
-// Worst-case bound, per unit |q| * max|x|, on everything that separates the quantities the certificate compares
-// from the real-number scores t(x) = q.x (derivation: docs/DESIGN_NOTES.md section 4.3b; checked in tests/test_split_bound.py):
-//   (1) the products the split drops:  q x - (qh xh + qh xl + ql xh) = rq (x - rx) + ql xl + rx q  with
-//       |rx| <= 2^-16 |x|, |xl| <= 2^-8 (1 + 2^-8) |x| (bf16 = 8 significand bits, RNE) and the same for q;
-//       summed with Cauchy-Schwarz:  <= 2^-16 (3 + 2^-7 + 2^-15) |q| |x|;
-//   (2) the fp32 accumulation of the 3 d exact bf16 x bf16 products on the matrix cores, in ANY order, every
-//       addition rounded or truncated at fp32 width (unit 2^-23):  gamma(3 d) * sum|terms|, sum|terms| <=
-//       (1 + 2^-8)^2 (1 + 2^-7) |q| |x|;
-//   (3) the fp32 re-score of the nominees (split_certify_kernel): per lane ceil(d4 / 64) * 4 fused multiply-adds,
-//       then a 6-step butterfly:  gamma(depth) at unit 2^-24;
-//   (4) |q| itself (fp32 tree sum + sqrt, <= 4e-6 relative) and the rounding of the certificate's own
-//       comparison (<= 4 * 2^-24 |q| max|x|).
-// A row that was not nominated has t <= approx(16th nominee) + (1) + (2); the k-th result has t >= rescore - (3).
-double split_eps(int d) {
-    const double u8 = std::ldexp(1.0, -8), u16 = std::ldexp(1.0, -16), u23 = std::ldexp(1.0, -23), u24 = std::ldexp(1.0, -24);
-    const double e_op = u16 * ((1.0 + u16) + (1.0 + u8) * (1.0 + u8) + 1.0);
-    const double n = 3.0 * d;
-    const double e_acc = n * u23 / (1.0 - n * u23) * (1.0 + u8) * (1.0 + u8) * (1.0 + 2.0 * u8);
-    const double depth = ((d + 3) / 4 + 63) / 64 * 4 + 6;
-    const double e_re = depth * u24 / (1.0 - depth * u24);
-    return (e_op + e_acc + e_re) * (1.0 + 4e-6) + 4.0 * u24;
-}
-
-// k the certified passes serve: 12 with the 16-nominee bf16 passes; 32 where the fp16 pass exists — it re-scores 64 nominees,
-// so its certificate compares the k-th exact score with the ~64th approximate one: at k = 32 the gap is still ~6 eps on
+// k the certified pass serves: it re-scores 64 nominees, so its certificate compares the k-th exact score with the ~64th
+// approximate one: at k = 32 the gap is still ~6 eps on
 // exchangeable data (10M x 512 random rows: 32nd to 64th score 6.1e-3, eps 1.04e-3; 1.6e-2 at k = 10)
 constexpr int kHalfMaxK = 32;
 bool half_path_ok(const mvdb_index* idx);
@@ -831,192 +805,55 @@ int half_min_nq(const mvdb_index* idx, int64_t n) {
     return 33;
 }
 
+// Does a call of nq queries over n rows go through the CERTIFIED pass (fp16 nomination over the shadow, half_scan.hip)?
+// (Until round 6 a second certified generation — bf16 (hi, lo) split products over the fp32 rows, scan_split_kernels.hpp —
+//  served the widths without an fp16 kernel; it is retired: those widths take the exact passes below.)
 bool split_path_ok(const mvdb_index* idx, int nq, int k, const int64_t* rows_dev, int64_t n) {
-    if (idx->kn.disable_split_scan) return false;
-    const bool single_ok = nq == 1 && idx->kn.shadow_single_query && !tls_single_suspended && half_path_ok(idx) && half_min_nq(idx, n) <= 1;
-    if ((nq < 2 && !single_ok) || rows_dev || (idx->metric != MVDB_METRIC_IP && !l2_cert_ok(idx) && !l2_offsets_ok(idx, nq, n)))
-        return false;
+    if (idx->kn.disable_split_scan || !half_path_ok(idx)) return false;
+    if (nq < half_min_nq(idx, n) || (nq == 1 && !(idx->kn.shadow_single_query && !tls_single_suspended))) return false;
+    if (rows_dev || (idx->metric != MVDB_METRIC_IP && !l2_cert_ok(idx) && !l2_offsets_ok(idx, nq, n))) return false;
     // (k > 16 also needs the gated fp32-MFMA pass for the exact re-runs: the GEMM-tiled scan keeps 16 results per query)
-    if (k > kSplitMaxK && !(k <= kHalfMaxK && nq >= half_min_nq(idx, n) && half_path_ok(idx) &&
-                            (k <= kGemmScanMaxK || mfma_gated_queries(idx) > 0)))
-        return false;
-    // rows of known, sane norm only: the bound scales with max|x|, and bf16 keeps fp32's exponent range only up
-    // to 3.39e38 (a split of larger elements would overflow to infinity)
+    if (k > kHalfMaxK || (k > kGemmScanMaxK && mfma_gated_queries(idx) <= 0)) return false;
+    // rows of known, sane norm only: the bound scales with max|x|
     if (!(idx->row_norm_bound > 0.f) || !(idx->row_norm_bound < 1.0e30f)) return false;
-    return idx->d % 32 == 0 && idx->ld == idx->d;
+    return true;
 }
 
-bool split32_ok(const mvdb_index* idx) {
-    if (idx->kn.disable_split32) return false;
-    const int KB = idx->d / 16;
-    return idx->d % 64 == 0 && (KB == 4 || KB == 8 || KB == 16 || KB == 24 || KB == 32);
-}
-
-template <int KB>
-int launch_split32_inst(const Split32Args& b, int device, hipStream_t stream, int* nblocks_out) {
-    auto kern = flat_scan_split32_kernel<KB>;
-    const size_t lds = (size_t)kScanWaves * 2 * 8192;
-    MVDB_TRY(ensure_dynamic_lds((const void*)kern, lds, device));
-    int nb = cached_occupancy((const void*)kern, kScanThreads, lds, 1);
-    nb = std::min(nb, std::max(1, kn().split32_blocks_per_cu));
-    const int64_t ntiles = b.tile1 - b.tile0;
-    const int64_t want = (ntiles + kScanWaves - 1) / kScanWaves;
-    const int nblocks = (int)std::max<int64_t>(1, std::min<int64_t>(want, (int64_t)device_cus(device) * nb));
-    *nblocks_out = nblocks;
-    prof_symbol("ip_scan_split32", "flat_scan_split32_kernel<%d>", KB);
-    int slot = prof_begin("ip_scan_split32", stream);
-    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(kScanThreads), lds, stream, b);
-    prof_end(slot, stream);
-    MVDB_HIP(hipGetLastError());
-    return 0;
-}
-
-int launch_split32(int KB, const Split32Args& b, int device, hipStream_t s, int* nb) {
-    switch (KB) {
-        case 4: return launch_split32_inst<4>(b, device, s, nb);
-        case 8: return launch_split32_inst<8>(b, device, s, nb);
-        case 16: return launch_split32_inst<16>(b, device, s, nb);
-        case 24: return launch_split32_inst<24>(b, device, s, nb);
-        case 32: return launch_split32_inst<32>(b, device, s, nb);
-        default: return fail(MVDB_ERR_ARG, "no 32-query split kernel for d = %d", KB * 16);
+// Between the launches of a certified pass: merge the per-block lists of a launch (the seed launch: one tile per block) — and
+// the running nominees of the launches before it — into each query's 16
+// best approximate keys, and publish the 16th score as the admission floor of the main launch — every row of the
+// global approximate top-16 scores at least that much, so the main pass only has to insert the few rows above it
+// (without the floor each wave re-learns its threshold from scratch: ~7,000 LDS list inserts per wave at 10M rows,
+// more time than the MFMAs).
+__global__ __launch_bounds__(1024) void phase_fold_kernel(const uint64_t* __restrict__ keys, int nlists,
+                                                          const uint64_t* prev, uint64_t* seed, float* __restrict__ thr0) {
+    // prev: NULL, or the [nq][16] running nominees of the earlier phases (may alias `seed`: read before written)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int qi = blockIdx.x;
+    const int64_t total = (int64_t)nlists * kHalfKeep;
+    const uint64_t* src = keys + (int64_t)qi * total;
+    WaveTopK tk;
+    tk.init(kHalfKeep);
+    for (int64_t base = (int64_t)wave * 64; base < total; base += 1024) {
+        const int64_t i = base + lane;
+        tk.offer(i < total ? src[i] : 0ull);
     }
-}
-
-int launch_split_scan(const mvdb_index* idx, Workspace* ws, const float* q, int nq, int k, int64_t n,
-                      int64_t label_offset, float* D, int64_t* I, int* flag, int* failed) {
-    hipStream_t stream = ws->stream;
-    __bf16* qh = ws->qsplit.p;
-    __bf16* ql = qh + (size_t)128 * idx->d;
-    hipLaunchKernelGGL(split_queries_kernel, dim3(128), dim3(256), 0, stream, q, idx->ld, idx->d, nq, qh, ql,
-                       ws->qnorm.p);
-    MVDB_HIP(hipGetLastError());
-    SplitScanArgs a;
-    a.X = idx->X;
-    a.n = n;
-    a.ld = idx->ld;
-    a.K = idx->d;
-    a.qh = qh;
-    a.ql = ql;
-    a.nq = nq;
-    void (*kern)(SplitScanArgs) = flat_scan_split_kernel<0>;
-    switch (idx->kn.split_dbg) {  // timing ablations (invalid results), benchmarks/split_probe.py
-        case 2: kern = flat_scan_split_kernel<2>; break;
-        case 4: kern = flat_scan_split_kernel<4>; break;
-        case 6: kern = flat_scan_split_kernel<6>; break;
-        case 16: kern = flat_scan_split_kernel<16>; break;
-        case 24: kern = flat_scan_split_kernel<24>; break;
-        case 32: kern = flat_scan_split_kernel<32>; break;
-        default: break;
+    if (prev && wave == 0) tk.offer(lane < kHalfKeep ? prev[(int64_t)qi * kHalfKeep + lane] : 0ull);
+    __shared__ uint64_t sh[15 * 64];
+    block_merge_topk(tk, sh, 16);
+    if (wave == 0) {
+        if (lane < kHalfKeep) seed[(int64_t)qi * kHalfKeep + lane] = tk.key;
+        const uint64_t last = readlane_u64(tk.key, kHalfKeep - 1);
+        if (lane == 0) thr0[qi] = last ? key_score(last) : -INFINITY;
     }
-    void (*seed_kern)(SplitScanArgs) = flat_scan_split_kernel<0, true>;
-    MVDB_TRY(ensure_dynamic_lds((const void*)kern, kSplitLds, idx->device));
-    MVDB_TRY(ensure_dynamic_lds((const void*)seed_kern, kSplitLds, idx->device));
-    const int64_t ntiles = (n + 127) / 128;
-    const int cus = device_cus(idx->device);
-    // Every pass starts with a SEED launch over the first min(ntiles, CUs) tiles, one per block: each wave dumps its
-    // 32 scores per query, the block keeps the 16 best per query, split_seed_kernel merges the blocks and publishes
-    // each query's 16th-best score as the admission floor.  Corpora of up to one tile per CU are finished at that
-    // point; otherwise the MAIN launch scans the remaining tiles and inserts only rows at or above the floor (without
-    // it every wave learns its thresholds through thousands of serial LDS list inserts).
-    uint64_t* seed_keys = ws->cand.p;                                // [128][16]
-    uint64_t* cand = ws->cand.p + (size_t)128 * kSplitKeep;          // [nq][gx][16]
-    a.cand = cand;
-    a.thr0 = nullptr;
-    a.stats = idx->kn.split_stats ? reinterpret_cast<unsigned int*>(ws->flags.p) + (ws->flags.cap - 32) : nullptr;
-    if (a.stats) MVDB_HIP(hipMemsetAsync(a.stats, 0, 8 + 12 * 8, stream));
-    const int64_t seed_tiles = std::min<int64_t>(ntiles, cus);
-    {
-        a.tile0 = 0;
-        a.tile1 = seed_tiles;
-        int slot = prof_begin("ip_scan_split_seed", stream);
-        hipLaunchKernelGGL(seed_kern, dim3((unsigned)seed_tiles, 1), dim3(kSplitThreads), kSplitLds, stream, a);
-        hipLaunchKernelGGL(split_seed_kernel, dim3(nq), dim3(1024), 0, stream, cand, (int)seed_tiles,
-                           (const uint64_t*)nullptr, seed_keys, ws->qnorm.p + 128);
-        prof_end(slot, stream);
-        MVDB_HIP(hipGetLastError());
-    }
-    const uint64_t* seed_arg = seed_keys;
-    a.thr0 = ws->qnorm.p + 128;
-    // The rest of the corpus is scanned in PHASES of growing size (each covers up to 8x the rows seen before it).
-    // Between phases split_seed_kernel merges the phase's per-block lists into the running 16 best per query and
-    // raises the admission floors to the 16th best of ALL rows seen so far.  A block alone sees only n / CUs rows, so
-    // with the seed launch's floors (16th best of 32k rows) its lists take ~600 inserts per wave over a 10M-row scan
-    // — each one a serial LDS round trip that also stalls the three waves it shares an exchange barrier with (1.4 ms
-    // of a 5.2 ms launch); with floors refreshed after 0.26M and 2.1M rows it takes ~35.
-    int gx = 0;
-    const int phase_growth = std::max(2, idx->kn.split_phase_growth);
-    int64_t covered = seed_tiles;  // 128-row tiles scanned so far
-    while (covered < ntiles) {
-        int64_t upto = ntiles;
-        if (!idx->kn.split_one_phase && covered * phase_growth * 2 <= ntiles) upto = covered * phase_growth;
-        a.tile0 = covered;
-        a.tile1 = upto;
-        const int64_t rows_upto = std::min<int64_t>(n, upto * 128);
-        if (nq <= 32 && split32_ok(idx)) {
-            // 14..32 queries: per-wave rings, query fragments in registers (flat_scan_split32_kernel), 32-row tiles
-            Split32Args b;
-            b.X = idx->X;
-            b.n = rows_upto;
-            b.ld = idx->ld;
-            b.qh = qh;
-            b.ql = ql;
-            b.nq = nq;
-            b.cand = cand;
-            b.tile0 = a.tile0 * 4;
-            b.tile1 = (rows_upto + 31) / 32;
-            b.thr0 = a.thr0;
-            MVDB_TRY(launch_split32(idx->d / 16, b, idx->device, stream, &gx));
-        } else {
-            SplitScanArgs c = a;
-            c.n = rows_upto;
-            gx = (int)std::max<int64_t>(1, std::min<int64_t>(a.tile1 - a.tile0, (int64_t)cus));
-            int slot = prof_begin("ip_scan_split", stream);
-            hipLaunchKernelGGL(kern, dim3(gx, 1), dim3(kSplitThreads), kSplitLds, stream, c);
-            prof_end(slot, stream);
-        }
-        MVDB_HIP(hipGetLastError());
-        covered = upto;
-        if (covered < ntiles) {
-            // fold this phase's lists into the running nominees (seed_keys is both an input list and the output)
-            hipLaunchKernelGGL(split_seed_kernel, dim3(nq), dim3(1024), 0, stream, cand, gx, seed_keys, seed_keys,
-                               ws->qnorm.p + 128);
-            MVDB_HIP(hipGetLastError());
-            gx = 0;
-        }
-    }
-    SplitCertifyArgs c;
-    c.keys = cand;
-    c.nlists = gx;
-    c.seed = seed_arg;
-    c.X = idx->X;
-    c.ld = idx->ld;
-    c.d4 = idx->d4;
-    c.q = q;
-    c.qnorm = ws->qnorm.p;
-    c.eps = (float)(split_eps(idx->d) * (double)idx->row_norm_bound * (1.0 + 1e-6));  // rounded up
-    c.k = k;
-    c.label_offset = label_offset;
-    c.D = D;
-    c.I = I;
-    c.uncertified = flag;
-    c.failed = failed;
-    c.l2 = idx->metric == MVDB_METRIC_L2;
-    c.n2lo = idx->norm2_lo;
-    hipLaunchKernelGGL(split_certify_kernel, dim3(nq), dim3(1024), 0, stream, c);
-    MVDB_HIP(hipGetLastError());
-    if (a.stats) {
-        unsigned int st[2 + 24] = {0};
-        MVDB_HIP(hipMemcpyAsync(st, a.stats, sizeof(st), hipMemcpyDeviceToHost, stream));
-        MVDB_HIP(hipStreamSynchronize(stream));
-        fprintf(stderr, "[mvdb split] list inserts %u, slow-path wave-tiles %u (seed + main launch)\n", st[0], st[1]);
-    }
-    return 0;
 }
 
 // ---- fp16 single-product nomination pass (half_scan.hip): 33+ queries per corpus pass where a kernel exists ----------
+// (the pass streams the fp16 SHADOW of the rows: an index that may not keep one — option half_shadow = 0, or the shadow's
+//  allocation failed — answers its batches on the exact fp32 passes)
 bool half_path_ok(const mvdb_index* idx) {
-    if (idx->kn.disable_half_scan) return false;
-    return half_max_queries(idx->d) > 0 && idx->ld == idx->d && half_xscale(idx->row_norm_bound) > 0.f;
+    if (idx->kn.disable_half_scan || idx->kn.disable_half_shadow || idx->xh_failed) return false;
+    return half_max_queries(idx->d) > 0 && half_shadow_dim(idx->d) && idx->ld == idx->d && half_xscale(idx->row_norm_bound) > 0.f;
 }
 
 const _Float16* ensure_shadow(const mvdb_index* idx, hipStream_t s, float xscale);
@@ -1050,7 +887,7 @@ int launch_half_pass(const mvdb_index* idx, Workspace* ws, const float* q, int n
     uint64_t* cand = ws->cand.p + (size_t)nqpad * kHalfKeep;   // [nq][lists][16]
     a.cand = cand;
     // SEED launch: the first min(tiles, CUs) tiles, one per block, every score dumped (32 keys per block and query);
-    // split_seed_kernel keeps each query's 16 best and publishes the 16th score as the first admission floor.
+    // phase_fold_kernel keeps each query's 16 best and publishes the 16th score as the first admission floor.
     const int64_t seed_tiles = std::min<int64_t>(ntiles, cus);
     int gx = 0;
     a.tile0 = 0;
@@ -1066,15 +903,15 @@ int launch_half_pass(const mvdb_index* idx, Workspace* ws, const float* q, int n
     if (l2off) {
         a.hn = hn;
         MVDB_TRY(launch_half_scan(idx->d, nqpad, false, a, idx->kn, idx->device, stream, &gx));
-        hipLaunchKernelGGL(split_seed_kernel, dim3(nq), dim3(1024), 0, stream, cand, gx, (const uint64_t*)nullptr, seed_keys, floors);
+        hipLaunchKernelGGL(phase_fold_kernel, dim3(nq), dim3(1024), 0, stream, cand, gx, (const uint64_t*)nullptr, seed_keys, floors);
     } else {
         MVDB_TRY(launch_half_scan(idx->d, nqpad, true, a, idx->kn, idx->device, stream, &gx));
-        hipLaunchKernelGGL(split_seed_kernel, dim3(nq), dim3(1024), 0, stream, cand, 2 * gx, (const uint64_t*)nullptr,
+        hipLaunchKernelGGL(phase_fold_kernel, dim3(nq), dim3(1024), 0, stream, cand, 2 * gx, (const uint64_t*)nullptr,
                            seed_keys, floors);
     }
     MVDB_HIP(hipGetLastError());
     a.thr0 = floors;
-    // The rest of the corpus is scanned in PHASES of growing size; between phases split_seed_kernel folds the
+    // The rest of the corpus is scanned in PHASES of growing size; between phases phase_fold_kernel folds the
     // per-block lists into the running 16 best and raises the floors (a block alone sees n / CUs rows: without the
     // refreshed floors its lists take hundreds of serial LDS inserts per wave).  Planned backwards: the LAST phase
     // covers at most `last_growth` times the rows before it — that leaves ~16 x last_growth candidates above its
@@ -1103,7 +940,7 @@ int launch_half_pass(const mvdb_index* idx, Workspace* ws, const float* q, int n
         MVDB_TRY(launch_half_scan(idx->d, nqpad, false, a, idx->kn, idx->device, stream, &gx));
         covered = ends[p];
         if (p > 0) {
-            hipLaunchKernelGGL(split_seed_kernel, dim3(nq), dim3(1024), 0, stream, cand, gx, seed_keys, seed_keys, floors);
+            hipLaunchKernelGGL(phase_fold_kernel, dim3(nq), dim3(1024), 0, stream, cand, gx, seed_keys, seed_keys, floors);
             MVDB_HIP(hipGetLastError());
         } else {
             last_lists = gx;
@@ -1154,7 +991,7 @@ bool mfma_path_ok(const mvdb_index* idx, int nq, int k, const int64_t* rows_dev)
     // (d <= 768: at d = 1024 the L2 form of the kernel spills; two 16-query groups only up to d = 384, same reason)
     if (idx->metric != MVDB_METRIC_IP && !(idx->d % 128 == 0 && idx->d <= 768 && idx->kn.mfma_v == 2 && !idx->kn.disable_l2_mfma)) return false;
     const int KB = idx->d / 16;
-    return KB == 4 || KB == 8 || KB == 16 || KB == 24 || KB == 32 || KB == 48 || KB == 64;
+    return KB == 4 || KB == 8 || KB == 16 || KB == 24 || KB == 32 || KB == 40 || KB == 48 || KB == 56 || KB == 64;
 }
 
 // Core: queries already on the device (padded to ld), outputs on the device.  Enqueues on ws.stream.
@@ -1234,10 +1071,10 @@ int search_core(const mvdb_index* idx, Workspace* ws, const float* q_dev, int nq
     a.cand = nullptr;
     a.scores = nullptr;
 
-    // Batches of >= 33 queries (past one 32-query fp32 pass), k <= 12, rows of known norm: split-precision pass on the bf16 matrix cores
-    // (scan_split_kernels.hpp), 128 queries per corpus pass, every result certified against exact fp32
-    // re-scores; chunks holding an uncertified query are re-run on the exact paths below.
-    if (allow_split && split_path_ok(idx, nq, k, rows_dev, n)) {
+    // Batches (2+ queries where the corpus buries the pass's fixed cost, half_min_nq), k <= 32, rows of known norm, a width the
+    // fp16 kernels serve: ONE fp16 product over the shadow nominates, fp32 re-scores decide, a worst-case bound certifies
+    // (half_scan.hip); queries whose certificate is refused are re-run below.
+    if (allow_split && split_path_ok(idx, nq, k, rows_dev, n) && ensure_shadow(idx, s, half_xscale(idx->row_norm_bound))) {
         const float* qsrc = q_dev;
         if (normalize_q) {
             MVDB_TRY(ws->qn.reserve((size_t)nq * idx->ld));
@@ -1246,32 +1083,24 @@ int search_core(const mvdb_index* idx, Workspace* ws, const float* q_dev, int nq
             MVDB_TRY(normalize_range(idx, ws->qn.p, nq, s));
             qsrc = ws->qn.p;
         }
-        // chunk plan: 128 queries per pass while >= 33 remain, then one 14..32-query pass where that kernel exists
-        // (below ~14 queries the fp32 pass, whose cost grows with the query count, is faster than the fixed seed +
-        // certification overhead: measured crossover 11 queries at 100k rows, 14 at 10M)
-        // where the fp16 single-product pass has a kernel (half_scan.hip) it serves the chunks of min_nq queries and more
-        const bool use_half = half_path_ok(idx);
-        const int min_nq = use_half ? half_min_nq(idx, n) : (idx->kn.split_scan_min_nq >= 0 ? idx->kn.split_scan_min_nq : 33);
-        const int chunk = use_half ? half_max_queries(idx->d) : 128;
+        // chunk plan: 128 / 256 queries per pass while at least min_nq remain; what is left takes the exact passes
+        const int min_nq = half_min_nq(idx, n);
+        const int chunk = half_max_queries(idx->d);
         std::vector<std::pair<int, int>> plan;  // (first query, count)
         int q0 = 0;
-        // (L2 over rows of mixed norms: only the shadow pass knows the per-row offsets — the other certified kernels nominate by
-        //  inner product, which ranks like the distance for rows of one norm only)
+        // (L2 over rows of mixed norms: the pass nominates by q.x - |x|^2 / 2 with per-row offsets beside the shadow; rows of one
+        //  norm by inner product, which ranks like the distance then)
         const bool ip_ranks = idx->metric == MVDB_METRIC_IP || l2_cert_ok(idx);
-        while (nq - q0 >= min_nq && ((use_half && (ip_ranks || l2_offsets_ok(idx, nq - q0, n))) || (ip_ranks && k <= kSplitMaxK && !mask_dev))) {
+        while (nq - q0 >= min_nq && (ip_ranks || l2_offsets_ok(idx, nq - q0, n))) {
             plan.emplace_back(q0, std::min(nq - q0, chunk));
             q0 += plan.back().second;
-        }
-        if (ip_ranks && !mask_dev && k <= kSplitMaxK && nq - q0 >= idx->kn.split32_min_nq && nq - q0 <= 32 && split32_ok(idx)) {
-            plan.emplace_back(q0, nq - q0);
-            q0 = nq;
         }
         const int nchunks = (int)plan.size();
         if (nchunks > 0) {
             MVDB_TRY(ws->qsplit.reserve((size_t)std::max(2 * 128, chunk) * idx->d));
-            MVDB_TRY(ws->qnorm.reserve((size_t)std::max(256, 3 * chunk)));  // |q|, admission floors (, fp16 pass: 1 / scale)
+            MVDB_TRY(ws->qnorm.reserve((size_t)std::max(256, 3 * chunk)));  // |q|, admission floors, 1 / scale
             MVDB_TRY(ws->flags.reserve((size_t)std::max(nchunks, 64) + 32));  // + diagnostics counters in the last 32 slots
-            MVDB_TRY(ws->cand.reserve((size_t)std::max(128, chunk) * (scan_grid_upper_bound(idx->device) + 1) * kSplitKeep));
+            MVDB_TRY(ws->cand.reserve((size_t)std::max(128, chunk) * (scan_grid_upper_bound(idx->device) + 1) * kHalfKeep));
             MVDB_TRY(ws->qfail.reserve((size_t)q0));
             MVDB_TRY(ws->qfloor.reserve((size_t)2 * q0 + 128));  // [q0] per query | [q0 + 128] per compact slot
             MVDB_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ws->qfloor.p), 0xff800000u, (size_t)q0, s));  // -inf: no floor
@@ -1279,13 +1108,9 @@ int search_core(const mvdb_index* idx, Workspace* ws, const float* q_dev, int nq
             MVDB_HIP(hipMemsetAsync(ws->qfail.p, 0, (size_t)q0 * sizeof(int), s));
             for (int c = 0; c < nchunks; ++c) {
                 const int c0 = plan[c].first, take = plan[c].second;
-                if (use_half && take >= min_nq)
-                    MVDB_TRY(launch_half_pass(idx, ws, qsrc + (int64_t)c0 * idx->ld, take, half_chunk_queries(idx->d, take), k, n, label_offset,
-                                              D_dev + (int64_t)c0 * k, I_dev + (int64_t)c0 * k, ws->flags.p + c, ws->qfail.p + c0, mask32,
-                                              ws->qfloor.p + c0));
-                else
-                    MVDB_TRY(launch_split_scan(idx, ws, qsrc + (int64_t)c0 * idx->ld, take, k, n, label_offset,
-                                               D_dev + (int64_t)c0 * k, I_dev + (int64_t)c0 * k, ws->flags.p + c, ws->qfail.p + c0));
+                MVDB_TRY(launch_half_pass(idx, ws, qsrc + (int64_t)c0 * idx->ld, take, half_chunk_queries(idx->d, take), k, n, label_offset,
+                                          D_dev + (int64_t)c0 * k, I_dev + (int64_t)c0 * k, ws->flags.p + c, ws->qfail.p + c0, mask32,
+                                          ws->qfloor.p + c0));
             }
             // ---- uncertified queries: re-run on the exact kernels WITHOUT the host ever learning which they were ----------
             // split_plan_kernel compacts the failed queries (ascending) and publishes their number nb; the exact passes below
@@ -1369,7 +1194,7 @@ int search_core(const mvdb_index* idx, Workspace* ws, const float* q_dev, int nq
                 // (k-th exact score of the nominees - margin - eps |q|) kept and re-scored; what it answers the exact passes skip
                 const int* need = nullptr;
                 const float xs = half_xscale(idx->row_norm_bound);
-                if (kRescueQueries % per_pass == 0 && use_half && half_rescue_dim(idx->d) && idx->ld == idx->d && k <= kRescueKeep && !idx->kn.disable_rescue &&
+                if (kRescueQueries % per_pass == 0 && half_rescue_dim(idx->d) && idx->ld == idx->d && k <= kRescueKeep && !idx->kn.disable_rescue &&
                     !idx->kn.disable_rerun_floor && xs > 0.f) {
                     const _Float16* Xh = ensure_shadow(idx, s, xs);
                     if (Xh) {
@@ -1554,7 +1379,7 @@ int search_core(const mvdb_index* idx, Workspace* ws, const float* q_dev, int nq
             qsrc = ws->qn.p;
         }
         MVDB_TRY(ws->cand.reserve((size_t)128 * scan_grid_upper_bound(idx->device) * k));
-        const int min_nq = idx->kn.gemm_scan_min_nq;
+        const int min_nq = gemm_min_nq(idx, k);
         int q0 = 0;
         while (nq - q0 >= min_nq) {
             const int take = std::min(nq - q0, 128);
@@ -2724,7 +2549,6 @@ int mvdb_synth_fill_device(float* out_dev, int64_t n, int d, uint64_t seed, int6
     return 0;
 }
 
-double mvdb_split_eps(int d) { return d > 0 ? split_eps(d) : 0.0; }
 double mvdb_half_eps(int d) { return d > 0 ? half_eps(d) : 0.0; }
 int mvdb_half_max_queries(int d) { return d > 0 ? half_max_queries(d) : 0; }
 

@@ -225,8 +225,8 @@ def test_l2_metric_extension(native):
 def test_l2_batches_share_corpus_passes(native, d, nq, k, normalized):
     """Squared L2 with several queries per call.  Up to 13 queries (and whenever the stored rows' norms differ by more than
     2^-10 — `normalized=False` here): the staged fp32-MFMA pass computes |q|^2 + |x|^2 - 2 q.x (whole rows go through its
-    LDS ring, so |x|^2 costs no extra read).  14+ queries over rows of (nearly) one norm: the certified passes of the inner
-    product — bf16-split / fp16 nomination by q.x, the nominees re-scored as sum (q - x)^2, the certificate bounding every
+    LDS ring, so |x|^2 costs no extra read).  33+ queries: the certified pass of the inner
+    product — fp16 nomination by q.x, the nominees re-scored as sum (q - x)^2, the certificate bounding every
     dropped row's distance through min |x|^2 (mvdb.hip: l2_cert_ok) — at the inner product's speed.  One query at a time the
     scan sums (q - x)^2 directly.  All must agree with the float64 adjudication (the expansion cancels: tolerance scales with
     the magnitude of the distances), ties (a planted duplicate row) resolve to the lower row, and a query equal to a stored
@@ -249,13 +249,10 @@ def test_l2_batches_share_corpus_passes(native, d, nq, k, normalized):
         certified_pass = _split_launches(native) > 0
     finally:
         native.prof_enable(False)
-    # the certified passes serve exactly the batches of 14+ queries (k <= 12, or k <= 32 where the fp16 pass has a kernel)
-    # over rows of one norm
-    small = 14 <= nq <= 32 and k <= 12 and d in (64, 128, 256, 384, 512)          # flat_scan_split32_kernel's widths
-    big = nq >= 33 and ((native.half_max_queries(d) > 0 and k <= 32) or (k <= 12 and d % 32 == 0))
-    # round 4: over the fp16 shadow of the rows the pass nominates by q.x - |x|^2 / 2 with per-row offsets — rows of ANY norms
-    any_norms = nq >= 33 and k <= 32 and d in (256, 384, 512, 640, 768, 896, 1024)
-    expect = (normalized and (small or big)) or any_norms
+    # the certified pass serves the batches of 33+ queries (30,000 rows: below 100k a smaller batch does not bury its fixed cost),
+    # k <= 32, at the widths it has a kernel for: rows of one norm by inner product with the norm-range certificate, rows of
+    # any norms by q.x - |x|^2 / 2 with per-row offsets beside the shadow
+    expect = nq >= 33 and k <= 32 and d in HALF_DIMS
     assert certified_pass == expect, (certified_pass, expect)
     assert I[0, :2].tolist() == [123, 17_000]
     mag = float(max(1.0, np.abs(D).max()))
@@ -482,9 +479,8 @@ def test_config3_10M_x_512_properties(native):
     (6000, 1024, 10, 16), (6000, 1024, 10, 35), (5000, 768, 64, 9),  # e5-large / bge-m3 widths: one group per pass
 ])
 def test_multi_query_mfma_pass_matches_oracle(native, n, d, k, nq):
-    """nq >= 2: one corpus pass serves up to 32 queries — on v_mfma_f32_16x16x4_f32 (exact fp32) for up to 13
-    queries, k > 12 or d > 512, on the bf16 cores with exact certification (flat_scan_split32_kernel) for 14..32
-    queries; every query's result must equal its own single-query search."""
+    """nq >= 2: one corpus pass serves up to 32 queries on v_mfma_f32_16x16x4_f32 (exact fp32); every query's result must
+    equal its own single-query search."""
     x = _corpus(n, d)
     q = _corpus(nq, d, seed=5678)
     idx = native.FlatIndex(d)
@@ -564,12 +560,13 @@ def test_large_batch_gemm_scan_matches_oracle(native, n, d, k, nq):
     idx.close()
 
 
+HALF_DIMS = (128, 256, 384, 512, 640, 768, 896, 1024)   # widths the certified pass (fp16 nomination over the shadow) serves
+
+
 def _split_launches(native):
-    """Chunks that went through the split-precision pass: each one starts with a seed launch."""
-    native.prof_read("ip_scan_split")
-    native.prof_read("ip_scan_split32")
+    """Chunks that went through the certified pass: each one starts with a seed launch."""
     native.prof_read("ip_scan_half")
-    return native.prof_read("ip_scan_split_seed")[0] + native.prof_read("ip_scan_half_seed")[0]
+    return native.prof_read("ip_scan_half_seed")[0]
 
 
 @pytest.mark.parametrize("n,d,k,nq", [
@@ -579,13 +576,14 @@ def _split_launches(native):
     (300000, 64, 10, 64), (270001, 128, 5, 130), (300000, 64, 10, 24), (70000, 128, 12, 100), (70001, 128, 12, 24), (40003, 256, 3, 129),  # seed + main launch
     (70001, 512, 10, 128), (40003, 512, 12, 50), (150003, 512, 5, 100), (33000, 512, 10, 33),  # seed + the K-split d = 512 kernels: ragged last tile, one and two phases
     (9000, 768, 10, 100), (70001, 1024, 10, 128), (150003, 384, 10, 256), (40003, 512, 10, 200), (100000, 256, 10, 255),  # fp16 pass: every dimension it serves, 128- and 256-query passes
-    (60000, 128, 10, 256), (50001, 640, 10, 128), (30000, 896, 10, 70),  # round 3: d = 640, 896 on the fp16 pass too (128: bf16 split)
+    (60000, 128, 10, 256), (50001, 640, 10, 128), (30000, 896, 10, 70),  # d = 640, 896 (round 3) and 128 (round 6) on the fp16 pass too
     (80000, 512, 16, 128), (150003, 512, 32, 256), (60000, 384, 20, 130), (50001, 640, 16, 100), (40000, 1024, 32, 64),  # k up to 32 (64 nominees)
 ])
 def test_split_precision_batch_pass_matches_oracle(native, monkeypatch, n, d, k, nq):
-    """nq >= 33 (24 here), k <= 12: the bf16 split-precision pass nominates 16 rows per query, exact fp32 re-scores
-    decide and certify (scan_split_kernels.hpp).  Results must equal the oracle's and every query's own single-query
-    search."""
+    """Batches of 24+ queries: where the certified pass has a kernel (HALF_DIMS) ONE fp16 product over the shadow nominates,
+    exact fp32 re-scores decide and certify (half_scan.hip); the other widths (64, 96 here — served by the bf16-split
+    generation until round 6) take the exact fp32 passes.  Results must equal the oracle's and every query's own
+    single-query search."""
     monkeypatch.setenv("MVDB_SPLIT_SCAN_MIN_NQ", "24")  # read when the index is created: also cover sparsely filled query tiles
     x = _corpus(n, d)
     q = _corpus(nq, d, seed=777)
@@ -596,7 +594,11 @@ def test_split_precision_batch_pass_matches_oracle(native, monkeypatch, n, d, k,
     try:
         _split_launches(native)  # drain
         D, I = idx.search(q, k)
-        assert _split_launches(native) >= max(1, nq // 256), "the split-precision pass did not run"
+        launches = _split_launches(native)
+        if d in HALF_DIMS:
+            assert launches >= max(1, nq // 256), "the certified pass did not run"
+        else:
+            assert launches == 0
     finally:
         native.prof_enable(False)
     _check(native, x, q, k, D, I, exact_vs_oracle=n < 100000)
@@ -661,10 +663,9 @@ def test_split_certificate_at_the_margin(native, d, frac, must_rerun):
     chunk — never return a wrong id.  With steps of eps / 12 and eps / 48 more than 16 - k rows lie inside the
     margin of the 16 that a block list (or the running list) keeps, so the certificate MUST refuse; with 0.9 eps
     steps the 16th is 5.4 eps below the k-th result and the pass must certify on its own.  eps is the bound of
-    the pass that serves 40 queries at this d: the fp16 nomination pass (1.04e-3 at d = 512) where it has a kernel,
-    the bf16 split (4.2e-4 at d = 1024) otherwise."""
+    the fp16 nomination pass (1.04e-3 at d = 512)."""
     n, k, nq = 20000, 10, 40
-    eps = native.half_eps(d) if native.half_max_queries(d) >= nq else native.split_eps(d)
+    eps = native.half_eps(d)
     assert 3 * 2.0 ** -16 < eps < 2e-3
     spacing = frac * eps
     rs = np.random.RandomState(d + int(frac * 1e4))
@@ -755,10 +756,10 @@ def test_l2_rows_of_mixed_norms_on_the_shadow_pass(native, n, d, nq, k):
     idx.close()
 
 
-@pytest.mark.parametrize("nq", [24, 40])
+@pytest.mark.parametrize("nq", [40, 130])
 @pytest.mark.parametrize("frac,must_rerun", [(1 / 48, True), (0.9, False)])
 def test_l2_certificate_at_the_margin(native, nq, frac, must_rerun):
-    """The L2 metric on the certified passes (24 queries: bf16 split, 16 nominees; 40: fp16 nomination, 64 nominees):
+    """The L2 metric on the certified pass (fp16 nomination, 64 nominees; 40 queries: one 128-query pass, 130: a 256-query one):
     nomination is by inner product, the certificate bounds a dropped row's DISTANCE through min |x|^2.  30 unit rows graded
     `frac * eps` apart in cosine (2 frac eps apart in squared distance), stored contiguously: steps of eps / 48 MUST be
     refused — and come back exact from the device-gated single-query scan —, steps of 0.9 eps must certify.  One stored
@@ -766,7 +767,7 @@ def test_l2_certificate_at_the_margin(native, nq, frac, must_rerun):
     (1 - min |x|^2) / 2 = 2.4e-4 of its margin (a dropped row of that norm would be that much nearer than its inner
     product says) and must still certify the 0.9-eps case."""
     n, d, k = 20000, 512, 10
-    eps = native.half_eps(d) if nq >= 33 else native.split_eps(d)
+    eps = native.half_eps(d)
     spacing = frac * eps
     rs = np.random.RandomState(int(frac * 1e4) + nq)
     x = _corpus(n, d)
@@ -1041,9 +1042,9 @@ def test_batch_search_never_syncs_and_is_capturable(native):
 def test_fp16_shadow_follows_the_index(native):
     """Batches of 33+ queries at d = 256 / 384 / 512 nominate from an fp16 SHADOW of the rows (flat_scan_h16_kernel: half the
     bytes of the fp32 rows, no conversion).  It is built by the first such search, extended by add, emptied by remove_rows and
-    by adds that change the scale (a larger row norm), rebuilt on demand — and every result equals the oracle's and, bit for
-    bit, what the same index returns with the shadow switched off (the nomination arithmetic is the same; the returned scores are
-    fp32 re-scores either way)."""
+    by adds that change the scale (a larger row norm), rebuilt on demand — and every result equals the oracle's and what the same
+    index returns with the shadow switched off (half_shadow = 0: the exact fp32-MFMA passes since round 6 — same ids, scores
+    within fp32 rounding of the certified pass's re-scores)."""
     import os
     for d in (512, 384, 256):
         n, k, nq = 50000, 10, 130
@@ -1069,7 +1070,8 @@ def test_fp16_shadow_follows_the_index(native):
         finally:
             del os.environ["MVDB_DISABLE_HALF_SHADOW"]
             idx.reload_env()
-        assert np.array_equal(I0, I) and np.array_equal(D0, D)
+        assert np.array_equal(I0, I)
+        np.testing.assert_allclose(D0, D, rtol=0, atol=2e-6)
         idx.remove_rows(np.array([5, 40000], np.int64))
         assert idx.shadow_rows == 0
         cur = np.delete(x[:n], [5, 40000], 0)

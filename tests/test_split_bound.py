@@ -1,94 +1,16 @@
-"""The operand-error bound the split-precision batch pass certifies with (minivectordb_amd/csrc/scan_split_kernels.hpp):
+"""The error bound the certified batch pass certifies with (minivectordb_amd/csrc/half_scan.hip: half_eps, exported as
+mvdb_half_eps): ONE product of the fp16 images of the scaled query and row nominates, so
 
-    |q.x - (qh.xh + qh.xl + ql.xh)| <= 3 * 2^-16 * sum|q_i x_i| <= 4.6e-5 * |q| * |x|
+    |a(x) - q.x| <= half_eps(d) |q| max|x|     (1.04e-3 at d = 512)
 
-with (h, l) the bf16 round-to-nearest-even split of an fp32 value.  Checked here in numpy (bf16 emulated bit-exactly,
-sums in float64 so that only the operand error is measured) on random and adversarial inputs.
-
-The certificate itself uses eps(d) (mvdb.hip: split_eps, exported as mvdb_split_eps): operand term + the WORST-CASE
-fp32 accumulation of the 3 d products in any order + the fp32 re-score + |q| and comparison rounding.  The second
-half of this file restates that formula, pins the library's value to it, and checks it against emulations of the
-matrix cores' accumulation (sequential fp32 chains in the kernel's product order, rounded to nearest and truncated).
+covers the rounding of both operands to fp16, elements below fp16's normal range, the WORST-CASE fp32 accumulation of the d
+products in any order, the fp32 re-score, |q| and the comparison's rounding.  This file restates the formula, pins the
+library's value to it, and checks it against emulations of the matrix cores' accumulation (sequential fp32 chains, rounded to
+nearest and truncated; fp16 subnormals kept and flushed).  (Until round 6 it also held the bound of the retired bf16-split
+generation, scan_split_kernels.hpp.)
 """
 import numpy as np
 import pytest
-
-
-def bf16_rne(x):
-    """fp32 -> nearest bf16 (ties to even), returned as fp32."""
-    u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32).astype(np.uint64)
-    r = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16
-    return (r & 0xFFFFFFFF).astype(np.uint32).view(np.float32)
-
-
-def split(x):
-    h = bf16_rne(x)
-    l = bf16_rne((x.astype(np.float32) - h).astype(np.float32))
-    return h, l
-
-
-def cases():
-    rs = np.random.RandomState(7)
-    d = 512
-    yield "gaussian", rs.randn(64, d).astype(np.float32), rs.randn(64, d).astype(np.float32)
-    yield "all positive", rs.rand(64, d).astype(np.float32), rs.rand(64, d).astype(np.float32)
-    # worst rounding: mantissas just below / above the bf16 midpoints, same sign everywhere
-    m = np.float32(1.0) + np.float32(2.0 ** -8) * (1 - 2.0 ** -10)
-    yield "midpoints", np.full((4, d), m, np.float32), np.full((4, d), m, np.float32)
-    yield "wide dynamic range", (rs.randn(64, d) * 10.0 ** rs.randint(-6, 6, (64, d))).astype(np.float32), \
-        (rs.randn(64, d) * 10.0 ** rs.randint(-6, 6, (64, d))).astype(np.float32)
-    yield "sparse", (rs.randn(64, d) * (rs.rand(64, d) < 0.02)).astype(np.float32), rs.randn(64, d).astype(np.float32)
-
-
-@pytest.mark.parametrize("name,q,x", list(cases()), ids=[c[0] for c in cases()])
-def test_split_operand_error_bound(name, q, x):
-    qh, ql = split(q)
-    xh, xl = split(x)
-    # the representation residuals themselves: 16 significant bits
-    for v, h, l in ((q, qh, ql), (x, xh, xl)):
-        res = np.abs(v.astype(np.float64) - h.astype(np.float64) - l.astype(np.float64))
-        assert np.all(res <= 2.0 ** -16 * np.abs(v.astype(np.float64)) + 1e-300)
-    f = lambda a: a.astype(np.float64)
-    exact = np.einsum("id,jd->ij", f(q), f(x))
-    approx = np.einsum("id,jd->ij", f(qh), f(xh)) + np.einsum("id,jd->ij", f(qh), f(xl)) + \
-        np.einsum("id,jd->ij", f(ql), f(xh))
-    l1 = np.einsum("id,jd->ij", np.abs(f(q)), np.abs(f(x)))
-    err = np.abs(exact - approx)
-    assert np.all(err <= 3 * 2.0 ** -16 * l1 + 1e-300), (name, float((err / np.maximum(l1, 1e-300)).max()))
-    # Cauchy-Schwarz: what the certificate uses
-    norms = np.linalg.norm(f(q), axis=1)[:, None] * np.linalg.norm(f(x), axis=1)[None, :]
-    assert np.all(err <= 4.6e-5 * norms + 1e-300)
-
-
-def test_bf16_rne_matches_torch():
-    torch = pytest.importorskip("torch")
-    rs = np.random.RandomState(3)
-    x = (rs.randn(10000) * 10.0 ** rs.randint(-10, 10, 10000)).astype(np.float32)
-    want = torch.from_numpy(x).to(torch.bfloat16).to(torch.float32).numpy()
-    assert np.array_equal(bf16_rne(x), want)
-
-
-# ---- eps(d): the whole certificate bound -----------------------------------------------------------------------------
-def split_eps(d):
-    """Restatement of mvdb.hip: split_eps (per unit |q| * max|x|)."""
-    u8, u16, u23, u24 = 2.0 ** -8, 2.0 ** -16, 2.0 ** -23, 2.0 ** -24
-    e_op = u16 * ((1 + u16) + (1 + u8) ** 2 + 1)
-    n = 3.0 * d
-    e_acc = n * u23 / (1 - n * u23) * (1 + u8) ** 2 * (1 + 2 * u8)
-    depth = ((d + 3) // 4 + 63) // 64 * 4 + 6
-    e_re = depth * u24 / (1 - depth * u24)
-    return (e_op + e_acc + e_re) * (1 + 4e-6) + 4 * u24
-
-
-@pytest.mark.parametrize("d", [32, 64, 128, 256, 384, 512, 768, 1024, 4096])
-def test_library_eps_is_the_documented_formula(d):
-    from minivectordb_amd import _native
-    got = _native.split_eps(d)          # host-only entry point: no device needed
-    assert got == pytest.approx(split_eps(d), rel=1e-12)
-    # the operand term alone (4.6e-5) is not enough: the bound must grow with d
-    assert got > 3 * 2.0 ** -16 + 3 * d * 2.0 ** -24
-    if d >= 64:
-        assert _native.split_eps(d) > _native.split_eps(d // 2)
 
 
 def _fp32_chain(terms, mode):
@@ -105,55 +27,6 @@ def _fp32_chain(terms, mode):
         acc = r
     return acc
 
-
-def _kernel_order_terms(q, x):
-    """The 3 d products in the order flat_scan_split*_kernel issues them: per 16-element block, xl.qh, xh.ql,
-    xh.qh (scan_split_kernels.hpp: mfma_step); within an instruction the elements are taken in k order."""
-    qh, ql = split(q)
-    xh, xl = split(x)
-    f = lambda a: a.astype(np.float64)
-    d = q.shape[-1]
-    out = []
-    for b in range(0, d, 16):
-        sl = slice(b, b + 16)
-        out += [f(xl[..., sl]) * f(qh[..., sl]), f(xh[..., sl]) * f(ql[..., sl]), f(xh[..., sl]) * f(qh[..., sl])]
-    return np.concatenate(out, axis=-1)
-
-
-def _bound_cases(d):
-    rs = np.random.RandomState(100 + d)
-    unit = lambda a: (a / np.linalg.norm(a.astype(np.float64), axis=-1, keepdims=True)).astype(np.float32)
-    g = unit(rs.randn(24, d))
-    yield "gaussian unit", unit(rs.randn(24, d)), g
-    p = unit(rs.rand(24, d) + 0.5)
-    yield "all positive (every addition rounds the same way)", unit(rs.rand(24, d) + 0.5), p
-    yield "parallel (|q.x| = |q||x|)", g, g
-    m = np.float32(1.0) + np.float32(2.0 ** -8) * (1 - 2.0 ** -10)
-    yield "bf16 midpoints", unit(np.full((2, d), m, np.float32)), unit(np.full((2, d), m, np.float32))
-    big_first = unit(np.sort(rs.rand(8, d).astype(np.float32) ** 4, axis=-1)[:, ::-1].copy())
-    yield "decaying magnitudes", big_first, big_first
-
-
-@pytest.mark.parametrize("d", [512, 1024])
-@pytest.mark.parametrize("mode", ["rne", "trunc"])
-def test_eps_covers_emulated_accumulation(d, mode):
-    """approx (fp32 chain over the kernel's 3 d products) and re-score (fp32 chain over the d exact products) both
-    stay within their share of eps(d) of the real-number score — for nearest and for truncating adders."""
-    eps = split_eps(d)
-    worst = 0.0
-    for name, q, x in _bound_cases(d):
-        t = np.sum(q.astype(np.float64) * x.astype(np.float64), axis=-1)
-        approx = _fp32_chain(_kernel_order_terms(q, x), mode).astype(np.float64)
-        scale = np.linalg.norm(q.astype(np.float64), axis=-1) * np.linalg.norm(x.astype(np.float64), axis=-1)
-        e_nom = np.abs(approx - t) / scale
-        # the re-score: fp32 fused multiply-adds = one rounding per exact product added (a d-deep chain here, deeper
-        # than the kernel's per-lane chains + butterfly)
-        resc = _fp32_chain(q.astype(np.float64) * x.astype(np.float64), "rne").astype(np.float64)
-        e_re = np.abs(resc - t) / scale
-        assert np.all(e_nom + e_re <= eps), (name, mode, float((e_nom + e_re).max()), eps)
-        worst = max(worst, float((e_nom + e_re).max()))
-    # the bound is a worst case, not a fit: it must hold with room, and the operand term alone must NOT explain it
-    assert worst < eps
 
 
 # ---- the fp16 single-product nomination pass (half_scan.hip) ----------------------------------------------------------
@@ -175,7 +48,6 @@ def test_library_half_eps_is_the_documented_formula(d):
     got = _native.half_eps(d)
     assert got == pytest.approx(half_eps(d), rel=1e-12)
     assert got > 2.0 ** -10 + d * 2.0 ** -23          # operand rounding + accumulation, nothing fitted away
-    assert got > _native.split_eps(d)                  # one coarse product: a wider margin than the bf16 split's
 
 
 def _pow2_scale(bound):
@@ -243,12 +115,12 @@ def test_half_eps_covers_emulated_nomination(d, mode, flush):
 
 
 def test_half_pass_widths_by_dimension():
-    """Host-only query of the pass table: 256 queries per corpus pass where the query-split kernel
-    exists, 128 where only the K-split kernel does, 0 where the bf16-split kernels still serve."""
+    """Host-only query of the pass table: 256 queries per corpus pass up to d = 512, 128 at the wider
+    dimensions (one wave per SIMD holds the query fragments), 0 where the exact fp32 passes serve."""
     from minivectordb_amd import _native
-    for d in (256, 384, 512):
+    for d in (128, 256, 384, 512):   # d = 128: round 6 (the shadow kernel's 16 slots per row fit KT = 8)
         assert _native.half_max_queries(d) == 256
     for d in (640, 768, 896, 1024):   # round 3: every even multiple of 64 from 256 to 1024
         assert _native.half_max_queries(d) == 128
-    for d in (32, 64, 100, 128, 192, 320, 576, 2048):   # d = 128: tried and dropped (half_scan.hip: half_kq)
+    for d in (32, 64, 100, 192, 320, 576, 1536, 2048):
         assert _native.half_max_queries(d) == 0
