@@ -90,15 +90,16 @@ int64_t mvdb_index_ntotal(const mvdb_index* idx);
 int mvdb_index_dim(const mvdb_index* idx);
 int mvdb_index_device(const mvdb_index* idx);
 
-/* Rows held in the index' fp16 SHADOW (0: none).  An index of width d = 256 / 384 / 512 / 640 / 768 / 896 / 1024 (unpadded rows)
- * that answers a batch the certified passes take — 2+ queries from 500k rows, 8+ from 100k, 33+ below (thresholds measured at
- * d = 512 and applied to every shadow width: the pass is bound by the shadow's bytes at all of them) — keeps, lazily, from the
- * first such search on (that search builds it: one blocking conversion pass and a hipMalloc inside an otherwise asynchronous
+/* Rows held in the index' fp16 SHADOW (0: none).  An index of width d = 128 / 256 / 384 / 512 / 640 / 768 / 896 / 1024 (unpadded
+ * rows) that answers a batch the certified pass takes — 2+ queries from 500k rows, 8+ from 100k, 33+ below (thresholds measured
+ * at d = 512 and applied to every shadow width: the pass is bound by the shadow's bytes at all of them) — keeps, lazily, from
+ * the first such search on (that search builds it: one blocking conversion pass and a hipMalloc inside an otherwise asynchronous
  * call), an fp16 copy of its rows next to the fp32 matrix (2 more bytes per element = +50 % of the index's device memory): the
- * nomination pass of those batches streams it instead of converting fp32 rows on the fly (half the bytes; the fp32 matrix stays
- * the home of the exact scans and of every returned score).  add extends it, remove_rows / reset / a re-allocation drop it (the
- * next batch search rebuilds it: ~5 ms per 10M x 512 rows); an allocation failure simply leaves the fp32 path in charge.
- * MVDB_DISABLE_HALF_SHADOW=1 switches it off.  No reference counterpart. */
+ * nomination pass of those batches streams it (the fp32 matrix stays the home of the exact scans and of every returned score).
+ * add extends it, remove_rows / reset / a re-allocation drop it (the next batch search rebuilds it: ~5 ms per 10M x 512 rows).
+ * Without a shadow — option "half_shadow" = 0, MVDB_DISABLE_HALF_SHADOW=1, or its allocation failed — batches are answered by
+ * the exact fp32 passes (32 queries per corpus pass; until round 6 a second nomination generation read the fp32 rows).
+ * No reference counterpart. */
 int64_t mvdb_index_shadow_rows(const mvdb_index* idx);
 
 /* Reserve device capacity for at least n rows in total (amortises repeated add). */
@@ -135,16 +136,28 @@ int mvdb_index_remove_rows(mvdb_index* idx, const int64_t* rows_host, int64_t m)
 
 /* k nearest rows for nq queries.  q_host[nq,d], D_host[nq,k], I_host[nq,k].
  * normalize_q != 0 L2-normalises each query on the device first.
- * Every path returns exact-fp32 scores of the exact top-k: batches of >= 14 queries (k <= 12) are
- * NOMINATED on the low-precision matrix cores (14..32 queries: bf16 (hi, lo) split-precision product,
- * 16 nominees; 33+ queries (k <= 32) at d = 256 / 384 / 512 / 640 / 768 / 896 / 1024: one fp16 product, 64 nominees,
- * 128 or 256 queries per corpus pass), then re-scored in fp32 and certified per query against the nomination's
- * worst-case error bound; queries that cannot be certified are re-run on the exact fp32 kernels
- * (mvdb_split_rerun_count counts the chunks that held one).  MVDB_METRIC_L2 (an extension: the reference builds
- * IndexFlatIP only): one query sums (q - x)^2 directly; several queries share corpus passes — on the certified passes
- * above where the rows have one norm (nomination by inner product, distance re-score, norm-range certificate) or, over the
- * fp16 shadow of the rows, for ANY norms (nomination by q.x - |x|^2 / 2 with per-row offsets), also under a bitmap; else
- * on the fp32 matrix cores as |q|^2 + |x|^2 - 2 q.x (d % 128 == 0, d <= 768; differences of the two forms are at the
+ * Every path returns exact-fp32 scores of the exact top-k.  Which pass answers a call (csrc/mvdb.hip: search_core):
+ *   1 query                      the exact fp32 scan (the reference's call shape; option "shadow_single_query" sends it through
+ *                                the certified pass too, which suspends itself while its certificates are being refused);
+ *   2+ queries, k <= 32, a width with a shadow (previous comment), enough rows to bury the pass's fixed cost (2 queries from
+ *   500k rows, 8 from 100k, 33 below)
+ *                                the CERTIFIED pass, 128 / 256 queries per pass over the fp16 shadow: ONE fp16 product nominates
+ *                                64 rows per query, fp32 re-scores decide, a worst-case bound (mvdb_half_eps) certifies each
+ *                                query.  A query whose certificate is refused (near-duplicate neighbourhoods) goes to the RESCUE
+ *                                pass — once more over the shadow, every row above its floor kept and re-scored in fp32: exact —
+ *                                and, where that cannot hold its neighbourhood, to a device-gated exact fp32-MFMA pass
+ *                                (mvdb_split_rerun_count counts the chunks that held a refused query);
+ *   other batches                exact fp32 passes on the matrix cores: 32 (d <= 512) / 16 (d <= 1024) queries per corpus pass
+ *                                at d = 64 and the multiples of 128; elsewhere the GEMM-tiled exact scan from 6 queries
+ *                                (128 per launch, k <= 16), else one query at a time;  k > 64: scores + radix select.
+ * A batch returns what nq separate calls return — ids identical AWAY FROM fp32 NEAR-TIES: rows whose scores lie within
+ * ~2e-6 of each other (exact duplicates aside: those tie exactly and come back lowest row first on every path) may be ranked
+ * either way by two fp32 summation orders, so on near-duplicate corpora a batch and a single call can swap such rows
+ * (tests/bigcheck.py adjudicates every difference in float64).
+ * MVDB_METRIC_L2 (an extension: the reference builds IndexFlatIP only): one query sums (q - x)^2 directly; several queries
+ * share corpus passes — on the certified pass where the rows have one norm (nomination by inner product, distance re-score,
+ * norm-range certificate) or, for ANY norms, by q.x - |x|^2 / 2 with per-row offsets beside the shadow, also under a bitmap;
+ * else on the fp32 matrix cores as |q|^2 + |x|^2 - 2 q.x (d % 128 == 0, d <= 768; differences of the two forms are at the
  * rounding level of the norms).
  * Replaces faiss.normalize_L2(embedding) + index.search(embedding, search_k)
  *                                                minivectordb/vector_database.py:475, :497
