@@ -704,15 +704,25 @@ __global__ __launch_bounds__(1024) void half_rescue_certify_kernel(HalfRescueArg
         const uint32_t row = key_row(cand[i]);
         const hs_f4* xr = reinterpret_cast<const hs_f4*>(a.X + (int64_t)row * a.ld);
         float s = 0.f;
-        for (int c = lane; c < a.d4; c += 64) {
-            const hs_f4 x = xr[c], w = qr[c];
-            s = fmaf(x[0], w[0], s);
-            s = fmaf(x[1], w[1], s);
-            s = fmaf(x[2], w[2], s);
-            s = fmaf(x[3], w[3], s);
+        if (a.l2) {
+            for (int c = lane; c < a.d4; c += 64) {
+                const hs_f4 t = qr[c] - xr[c];
+                s = fmaf(t[0], t[0], s);
+                s = fmaf(t[1], t[1], s);
+                s = fmaf(t[2], t[2], s);
+                s = fmaf(t[3], t[3], s);
+            }
+        } else {
+            for (int c = lane; c < a.d4; c += 64) {
+                const hs_f4 x = xr[c], w = qr[c];
+                s = fmaf(x[0], w[0], s);
+                s = fmaf(x[1], w[1], s);
+                s = fmaf(x[2], w[2], s);
+                s = fmaf(x[3], w[3], s);
+            }
         }
         for (int off = 32; off; off >>= 1) s += __shfl_xor(s, off);
-        if (lane == 0) cand[i] = make_key(s, row);
+        if (lane == 0) cand[i] = make_key(a.l2 ? -s : s, row);   // larger key = better: the smaller distance
     }
     __syncthreads();
     // k rounds of a block-wide maximum over the exact keys (unique: the row is part of the key)
@@ -729,7 +739,7 @@ __global__ __launch_bounds__(1024) void half_rescue_certify_kernel(HalfRescueArg
 #pragma unroll
         for (int w = 1; w < 16; ++w) best = wmax[w] > best ? wmax[w] : best;
         if (threadIdx.x == 0) {
-            a.D[(int64_t)slot * a.k + r] = key_score(best);
+            a.D[(int64_t)slot * a.k + r] = a.l2 ? -key_score(best) : key_score(best);
             a.I[(int64_t)slot * a.k + r] = a.label_offset + (int64_t)key_row(best);
         }
         for (int i = threadIdx.x; i < cnt; i += 1024)
@@ -831,7 +841,21 @@ __global__ __launch_bounds__(1024) void half_certify_kernel(HalfCertifyArgs a) {
             float fl = -INFINITY;
             // (one ulp further down: a floor admits nothing that merely TIES with it, and with |q| = 0 the margin is 0 and every
             //  row ties with the k-th score)
-            if (holder && !a.l2) fl = nextafterf(key_score(exact[__ffsll((long long)holder) - 1]) - a.floor_margin * a.qnorm[qi], -INFINITY);
+            if (holder) {
+                const float t = key_score(exact[__ffsll((long long)holder) - 1]);   // IP: the k-th exact score; L2: minus the k-th distance
+                const float qn = a.qnorm[qi];
+                if (!a.l2) {
+                    fl = t - a.floor_margin * qn;
+                } else {
+                    // every row of the top k is at most r = -t away (up to the re-score's rounding): in the units of the keys
+                    // that is a score of at least (|q|^2 + n2lo - r) / 2 (keys = q.x, rows of norm^2 >= n2lo) resp.
+                    // (|q|^2 - r) / 2 - eps_h (keys = q.x - |x|^2 / 2); the factors are l2_certified's
+                    const float n2 = a.l2 == 2 ? 0.f : a.n2lo;
+                    fl = 0.5f * (fmaf(qn * 0.99999f, qn, n2) - (-t) * 1.00002f) - (a.l2 == 2 ? a.eps_h : 0.f) -
+                         1e-6f * (qn * qn + fabsf(n2) + fabsf(t));
+                }
+                fl = nextafterf(fl, -INFINITY);
+            }
             a.floor_out[qi] = fl == fl ? fl : -INFINITY;
         }
         if (lane == 0 && u > -INFINITY) {

@@ -65,7 +65,10 @@ struct HalfCertifyArgs {
     float eps_h = 0.f;     // l2 == 2: bound on the error of the stored |x|^2 / 2 and of the subtraction, absolute
     float* floor_out = nullptr;  // NULL, or [nq]: for a REFUSED query the k-th exact score of its nominees less floor_margin |q| — a
                                  // lower bound of its k-th result in any fp32 summation order, the admission floor of its exact
-                                 // re-run (inner-product index only; -inf where fewer than k nominees were re-scored)
+                                 // re-run and of the rescue pass (-inf where fewer than k nominees were re-scored).  L2 forms
+                                 // (round 6): with r the k-th exact DISTANCE of the nominees, every row of the top k has
+                                 // q.x >= (|q|^2 + n2lo - r) / 2 (l2 = 1) resp. q.x - |x|^2 / 2 >= (|q|^2 - r) / 2 (l2 = 2): the
+                                 // floor in the units the nomination keys are in, rounded down like l2_certified's bound
     float floor_margin = 0.f;    // 2 d 2^-24 max|x|: the two fp32 dot products (this kernel's, the re-run's) may differ by that much
 };
 
@@ -87,7 +90,8 @@ struct HalfRescueArgs {
     const int* gate;        // number of refused queries of the call
     int gate_lo;            // first compact query of this launch
     int* need;              // one word per exact pass of per_pass queries: raised when one of its queries stays unanswered
-    int per_pass = 32;      // queries per exact pass (32 up to d = 512, 16 at the wider dimensions)
+    int per_pass = 32;      // queries per exact pass (32 up to d = 512, 16 at the wider dimensions; L2: 1 — one gated scan per query)
+    int l2 = 0;             // != 0: squared-L2 index — candidates are re-scored as sum (q - x)^2, smallest first
 };
 int launch_half_rescue_scan(int d, const HalfScanArgs& a, int device, hipStream_t stream, int* nblocks_out);
 int launch_half_rescue_certify(const HalfRescueArgs& a, hipStream_t stream);

@@ -1160,9 +1160,85 @@ int search_core(const mvdb_index* idx, Workspace* ws, const float* q_dev, int nq
             const int per_pass = mfma_gated_queries(idx);
             const int KB = idx->d / 16;
             int off = 0;
+            // ---- the RESCUE pass (half_scan.hip): refused queries once more over the shadow, 128 at a time, every row above
+            // the query's floor — what the k-th exact score (L2: distance) of its nominees admits, less the nomination error —
+            // kept and re-scored in fp32; what it answers the exact passes skip.  need_per = compact queries per `need` word:
+            // the queries of one exact pass (inner product: a gated fp32-MFMA pass of 32 / 16), or 1 (L2: one gated scan each).
+            auto rescue = [&](int need_per, const int** need_out) -> int {
+                *need_out = nullptr;
+                const float xs = half_xscale(idx->row_norm_bound);
+                if (need_per <= 0 || kRescueQueries % need_per != 0 || !half_rescue_dim(idx->d) || idx->ld != idx->d || k > kRescueKeep ||
+                    idx->kn.disable_rescue || idx->kn.disable_rerun_floor || !(xs > 0.f))
+                    return 0;
+                const _Float16* Xh = ensure_shadow(idx, s, xs);
+                if (!Xh) return 0;
+                // (L2: the same nomination form the certified pass used — per-row offsets where the rows' norms differ)
+                const bool l2 = idx->metric == MVDB_METRIC_L2;
+                const float* hn = l2 && !l2_cert_ok(idx) && !idx->kn.disable_l2_cert ? ensure_offsets(idx, s) : nullptr;
+                if (l2 && !l2_cert_ok(idx) && !hn) return 0;
+                const int grid_ub = device_cus(idx->device);  // the rescue launch is one workgroup per CU
+                const size_t nwords = (size_t)(R + kRescueQueries) / need_per + 8;
+                MVDB_TRY(ws->need.reserve(nwords));
+                MVDB_TRY(ws->cand.reserve((size_t)kRescueQueries * (grid_ub + 1) * kRescueKeep));
+                MVDB_TRY(ws->qsplit.reserve((size_t)2 * kRescueQueries * idx->d));
+                MVDB_TRY(ws->qnorm.reserve((size_t)3 * kRescueQueries));
+                MVDB_HIP(hipMemsetAsync(ws->need.p, 0, nwords * sizeof(int), s));
+                _Float16* qf = reinterpret_cast<_Float16*>(ws->qsplit.p);
+                float* qn2 = ws->qnorm.p;
+                float* qinv = qn2 + 2 * kRescueQueries;
+                float eps = (float)(half_eps(idx->d) * (double)idx->row_norm_bound * (1.0 + 1e-6));
+                if (hn) eps = (float)((double)eps + std::ldexp(1.0, -22) * (double)idx->row_norm_bound * (1.0 + 1e-6));  // (launch_half_pass: the subtraction)
+                for (int off2 = 0; off2 < R; off2 += kRescueQueries) {
+                    MVDB_TRY(launch_half_queries(qc + (int64_t)off2 * idx->ld, idx->ld, idx->d, kRescueQueries, kRescueQueries, xs, qf, qn2,
+                                                 qinv, s));
+                    HalfScanArgs ra;
+                    ra.X = idx->X;
+                    ra.n = n;
+                    ra.ld = idx->ld;
+                    ra.qf = qf;
+                    ra.qinv = qinv;
+                    ra.xscale = xs;
+                    ra.nq = std::min(kRescueQueries, R - off2);  // (slots past the call's queries can never be live)
+                    ra.mask = mask32;
+                    ra.Xh = Xh;
+                    ra.hn = hn;
+                    ra.stats = nullptr;
+                    ra.cand = ws->cand.p;
+                    ra.tile0 = 0;
+                    ra.tile1 = (n + 31) / 32;
+                    ra.thr0 = ws->qfloor.p + q0 + off2;
+                    ra.thr_eps = eps;
+                    ra.thr_qn = qn2;
+                    ra.gate = ws->nfail.p;
+                    ra.gate_lo = off2;
+                    int gx = 0;
+                    MVDB_TRY(launch_half_rescue_scan(idx->d, ra, idx->device, s, &gx));
+                    HalfRescueArgs rc;
+                    rc.keys = ws->cand.p;
+                    rc.nlists = gx;
+                    rc.X = idx->X;
+                    rc.ld = idx->ld;
+                    rc.d4 = idx->d4;
+                    rc.q = qc + (int64_t)off2 * idx->ld;
+                    rc.k = k;
+                    rc.label_offset = label_offset;
+                    rc.D = Dt + (int64_t)off2 * k;
+                    rc.I = It + (int64_t)off2 * k;
+                    rc.gate = ws->nfail.p;
+                    rc.gate_lo = off2;
+                    rc.need = ws->need.p + off2 / need_per;
+                    rc.per_pass = need_per;
+                    rc.l2 = l2 ? 1 : 0;
+                    MVDB_TRY(launch_half_rescue_certify(rc, s));
+                }
+                *need_out = ws->need.p;
+                return 0;
+            };
             if (idx->metric == MVDB_METRIC_L2) {
-                // L2: the exact single-query scan (sum (q - x)^2 directly), 32 compact queries per launch, each query's
-                // blocks enabled on the device
+                // L2: the rescue pass, then — for what it could not hold — the exact single-query scan (sum (q - x)^2 directly),
+                // 32 compact queries per launch, each query's blocks enabled on the device (refused count and `need` word)
+                const int* need = nullptr;
+                MVDB_TRY(rescue(1, &need));
                 const int per = 32;
                 MVDB_TRY(ws->cand.reserve((size_t)per * scan_grid_upper_bound(idx->device) * k));
                 for (; off < R; off += per) {
@@ -1173,6 +1249,7 @@ int search_core(const mvdb_index* idx, Workspace* ws, const float* q_dev, int nq
                     ga.cand = ws->cand.p;
                     ga.gate = ws->nfail.p;
                     ga.gate_lo = off;
+                    ga.need = need ? need + off : nullptr;
                     int nblocks = 0;
                     MVDB_TRY(launch_scan(idx->metric, kModeTopK, ga, take, idx->device, s, &nblocks));
                     MergeArgs mg;
@@ -1185,73 +1262,18 @@ int search_core(const mvdb_index* idx, Workspace* ws, const float* q_dev, int nq
                     mg.I = It + (int64_t)off * k;
                     mg.gate = ws->nfail.p;
                     mg.gate_lo = off;
+                    if (need) {   // one word per query: "pass" = query, its lists nblocks * k keys after the query before
+                        mg.need = need + off;
+                        mg.per_pass = 1;
+                        mg.pass_stride = (int64_t)nblocks * k;
+                    }
                     hipLaunchKernelGGL(merge_keys_kernel, dim3(take), dim3(kMergeThreads), 0, s, mg);
                     MVDB_HIP(hipGetLastError());
                 }
                 off = R;
             } else if (per_pass > 0 && !idx->kn.disable_mfma_scan) {
-                // ---- the RESCUE pass (half_scan.hip): refused queries once more over the shadow, 128 at a time, every row above
-                // (k-th exact score of the nominees - margin - eps |q|) kept and re-scored; what it answers the exact passes skip
                 const int* need = nullptr;
-                const float xs = half_xscale(idx->row_norm_bound);
-                if (kRescueQueries % per_pass == 0 && half_rescue_dim(idx->d) && idx->ld == idx->d && k <= kRescueKeep && !idx->kn.disable_rescue &&
-                    !idx->kn.disable_rerun_floor && xs > 0.f) {
-                    const _Float16* Xh = ensure_shadow(idx, s, xs);
-                    if (Xh) {
-                        const int grid_ub = device_cus(idx->device);  // the rescue launch is one workgroup per CU
-                        MVDB_TRY(ws->need.reserve((size_t)(R + kRescueQueries) / per_pass + 8));
-                        MVDB_TRY(ws->cand.reserve((size_t)kRescueQueries * (grid_ub + 1) * kRescueKeep));
-                        MVDB_TRY(ws->qsplit.reserve((size_t)2 * kRescueQueries * idx->d));
-                        MVDB_TRY(ws->qnorm.reserve((size_t)3 * kRescueQueries));
-                        MVDB_HIP(hipMemsetAsync(ws->need.p, 0, ((size_t)(R + kRescueQueries) / per_pass + 8) * sizeof(int), s));
-                        _Float16* qf = reinterpret_cast<_Float16*>(ws->qsplit.p);
-                        float* qn2 = ws->qnorm.p;
-                        float* qinv = qn2 + 2 * kRescueQueries;
-                        const float eps = (float)(half_eps(idx->d) * (double)idx->row_norm_bound * (1.0 + 1e-6));
-                        for (int off2 = 0; off2 < R; off2 += kRescueQueries) {
-                            MVDB_TRY(launch_half_queries(qc + (int64_t)off2 * idx->ld, idx->ld, idx->d, kRescueQueries, kRescueQueries, xs, qf, qn2,
-                                                         qinv, s));
-                            HalfScanArgs ra;
-                            ra.X = idx->X;
-                            ra.n = n;
-                            ra.ld = idx->ld;
-                            ra.qf = qf;
-                            ra.qinv = qinv;
-                            ra.xscale = xs;
-                            ra.nq = std::min(kRescueQueries, R - off2);  // (slots past the call's queries can never be live)
-                            ra.mask = mask32;
-                            ra.Xh = Xh;
-                            ra.stats = nullptr;
-                            ra.cand = ws->cand.p;
-                            ra.tile0 = 0;
-                            ra.tile1 = (n + 31) / 32;
-                            ra.thr0 = ws->qfloor.p + q0 + off2;
-                            ra.thr_eps = eps;
-                            ra.thr_qn = qn2;
-                            ra.gate = ws->nfail.p;
-                            ra.gate_lo = off2;
-                            int gx = 0;
-                            MVDB_TRY(launch_half_rescue_scan(idx->d, ra, idx->device, s, &gx));
-                            HalfRescueArgs rc;
-                            rc.keys = ws->cand.p;
-                            rc.nlists = gx;
-                            rc.X = idx->X;
-                            rc.ld = idx->ld;
-                            rc.d4 = idx->d4;
-                            rc.q = qc + (int64_t)off2 * idx->ld;
-                            rc.k = k;
-                            rc.label_offset = label_offset;
-                            rc.D = Dt + (int64_t)off2 * k;
-                            rc.I = It + (int64_t)off2 * k;
-                            rc.gate = ws->nfail.p;
-                            rc.gate_lo = off2;
-                            rc.need = ws->need.p + off2 / per_pass;
-                            rc.per_pass = per_pass;
-                            MVDB_TRY(launch_half_rescue_certify(rc, s));
-                        }
-                        need = ws->need.p;
-                    }
-                }
+                MVDB_TRY(rescue(per_pass, &need));
                 MVDB_TRY(ws->cand.reserve((size_t)32 * scan_grid_upper_bound(idx->device) * k));
                 // (the GEMM scan keeps k <= 16 and takes no bitmap: those re-runs are all fp32-MFMA passes)
                 // every refused query through the gated fp32-MFMA pass, 32 at a time (launches beyond the refused count return at

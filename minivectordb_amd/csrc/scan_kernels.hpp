@@ -44,6 +44,8 @@ struct ScanArgs {
     float* scores;        // kModeScores: [nq, n]
     const int* gate = nullptr;  // GATED instantiations only: query blockIdx.y is scanned iff *gate > gate_lo + blockIdx.y
     int gate_lo = 0;
+    const int* need = nullptr;  // GATED, optional: one word per query of the launch — a query whose word is 0 is skipped (the
+                                // rescue pass has answered it, mvdb.hip)
 };
 
 template <int G>
@@ -67,7 +69,7 @@ __device__ __forceinline__ float group_reduce_add(float v) {
 //          not certify, mvdb.hip): a separate instantiation — the ungated kernels carry no test.
 template <int G, int C, int U, int METRIC, int MODE, bool NT = true, int SEL = 0, bool MASKED = true, bool GATED = false>
 __global__ __launch_bounds__(kScanThreads) void flat_scan_kernel(ScanArgs a) {
-    if (GATED && *a.gate <= a.gate_lo + (int)blockIdx.y) return;
+    if (GATED && (*a.gate <= a.gate_lo + (int)blockIdx.y || (a.need && a.need[blockIdx.y] == 0))) return;
     constexpr bool SUBSET = SEL == 1;
     constexpr int RPI = kWave / G;  // rows per wave-instruction
     constexpr int RB = RPI * U;     // rows per wave batch

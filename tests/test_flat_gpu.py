@@ -1801,3 +1801,63 @@ def test_a_call_of_thousands_of_queries_keeps_its_workspace_bounded_and_its_resu
         ok, msg = flat.adjudicate(stored, q[i], k, D[i], I[i], tol=1e-4, tie_eps=2e-6)
         assert ok, (i, msg)
     idx.close()
+
+
+@pytest.mark.parametrize("d,metric,mixed_norms", [(640, "ip", False), (896, "ip", False), (512, "l2", False), (384, "l2", True), (640, "l2", False)])
+def test_rescue_tier_at_the_wide_dimensions_and_for_the_l2_metric(native, monkeypatch, d, metric, mixed_norms):
+    """Round 6 closes two holes of the rescue tier (round 5: inner product, d = 256 .. 512 and 768 / 1024 only).  d = 640 / 896 now
+    have the gated exact fp32-MFMA pass behind them, so a rescue launch has somewhere to send a full list.  L2: a refused
+    query's floor is stated in the units of the nomination keys — q.x >= (|q|^2 + min|x|^2 - r) / 2 for rows of one norm,
+    q.x - |x|^2 / 2 >= (|q|^2 - r) / 2 with per-row offsets, r = the k-th exact distance of its nominees — and the queries the
+    rescue pass answers skip their exact single-query scan (one `need` word per query).  Clustered corpus: every batch holds
+    refused queries; results stand the float64 adjudication, the rescue launches ran, and the exact tier did (almost) nothing."""
+    n, k, nq = 300_000, 10, 96
+    l2 = metric == "l2"
+    q = flat.synth(nq, d, 5678 | flat.SYNTH_CLUSTERED)
+    flat.normalize_l2(q)
+    idx = native.FlatIndex(d, metric=native.METRIC_L2 if l2 else native.METRIC_IP)
+    idx.reserve(n)
+    idx.add_synthetic(n, 1234 | flat.SYNTH_CLUSTERED, normalize=True)
+    stored = idx.get_rows(0, n)
+    if mixed_norms:   # rows of TWO norms (beyond the norm-range certificate: the offsets form of the L2 pass); the near-duplicates
+        #               of a class stay near-duplicates, so certificates are still refused
+        scale = np.where(np.arange(n) % 2 == 0, 1.0, 1.002).astype(np.float32)[:, None]   # (|x|^2 spread 4e-3 > 2^-10)
+        stored = (stored * scale).astype(np.float32)
+        idx.close()
+        idx = native.FlatIndex(d, metric=native.METRIC_L2)
+        idx.reserve(n)
+        idx.add(stored)
+    idx.search(q, k)   # shadow, workspaces
+    got = {}
+    for mode in ("rescue", "exact"):
+        if mode == "exact":
+            monkeypatch.setenv("MVDB_DISABLE_RESCUE", "1")
+            idx.reload_env()
+        native.prof_enable(True)
+        try:
+            for f in ("ip_scan_rescue", "ip_scan_rerun", "ip_scan"):
+                native.prof_read(f)
+            before = native.split_rerun_count()
+            D, I = idx.search(q, k)
+            assert native.split_rerun_count() > before, "the clustered corpus must refuse some certificates"
+            rescue, rerun, single = native.prof_read("ip_scan_rescue"), native.prof_read("ip_scan_rerun"), native.prof_read("ip_scan")
+        finally:
+            native.prof_enable(False)
+        exact_ms = single[1] if l2 else rerun[1]      # the exact tier: gated single-query scans (L2) / gated fp32-MFMA passes
+        if mode == "rescue":
+            assert rescue[0] >= 1 and rescue[1] > 0.02, rescue
+            t_rescue_mode = exact_ms
+        else:
+            assert rescue[0] == 0, rescue
+            assert exact_ms > 4 * max(t_rescue_mode, 0.01), (exact_ms, t_rescue_mode)   # what the rescue pass saved
+        mag = float(max(1.0, np.abs(D).max()))
+        for i in range(0, nq, 3):
+            ok, msg = flat.adjudicate(stored, q[i], k, D[i], I[i], metric=flat.METRIC_L2 if l2 else flat.METRIC_IP,
+                                      tol=1e-4 * mag, tie_eps=4e-6 * mag)
+            assert ok, (mode, i, msg)
+        got[mode] = (D.copy(), I.copy())
+    monkeypatch.delenv("MVDB_DISABLE_RESCUE")
+    idx.reload_env()
+    assert (got["rescue"][1] == got["exact"][1]).mean() > 0.9
+    np.testing.assert_allclose(np.sort(got["rescue"][0], axis=1), np.sort(got["exact"][0], axis=1), rtol=0, atol=4e-6 * mag)
+    idx.close()
