@@ -221,6 +221,14 @@ __device__ __forceinline__ void x3_pair_store(float* line, int c, float v, bool 
 // =================================================================================================
 // row kernels: one wave per token row, VPT = ceil(H/64) values per lane in registers
 // =================================================================================================
+#ifdef MVDB_X3_ABLATE
+// ablation build only (MVDB_LN_SKIP_X=1, results INVALID): the LayerNorm kernels do not store the fp32 row — the upper bound of
+// what keeping the residual stream ONLY as the (hi | lo) image could save (round-5 review item; profiles/r06_residual_image_bound.txt)
+__device__ int g_ln_skip_x = 0;
+#define MVDB_LN_STORE_X (!g_ln_skip_x)
+#else
+#define MVDB_LN_STORE_X true
+#endif
 template <int VPT, bool FULL = false>
 __device__ __forceinline__ void wave_layernorm(float (&v)[VPT], int H, int lane, float eps,
                                                const float* __restrict__ gamma,
@@ -258,7 +266,7 @@ __device__ __forceinline__ void wave_layernorm(float (&v)[VPT], int H, int lane,
 #pragma unroll
         for (int i = 0; i < VPT; ++i) {
             const float r = (v[i] - mean) * rstd * g[i] + bt[i];
-            out[lane + i * 64] = r;
+            if (MVDB_LN_STORE_X) out[lane + i * 64] = r;
             if (outp) x3_pair_store(outp + i * 64 + (lane & 32), lane & 31, r, true);
         }
         return;
@@ -3494,6 +3502,11 @@ int mvdb_encoder_create(const mvdb_encoder_cfg* cfg, const void* const* w, int d
         e->opt_walk_roles = !(v && *v == '0');
         v = getenv("MVDB_WALK_PINNED");
         e->opt_walk_pinned = !(v && *v == '0');
+#ifdef MVDB_X3_ABLATE
+        v = getenv("MVDB_LN_SKIP_X");
+        const int skip = v && *v == '1';
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_ln_skip_x), &skip, sizeof(int));
+#endif
     }
     e->word = (const float*)w[0];
     e->pos = (const float*)w[1];
