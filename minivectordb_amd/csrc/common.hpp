@@ -64,7 +64,6 @@ struct Knobs {
     int scan_blocks_per_cu = 0;      // MVDB_SCAN_BLOCKS_PER_CU (0: the measured default per shape)
     int mfma_blocks_per_cu = 0;      // MVDB_MFMA_BLOCKS_PER_CU (0: 4 for the fragment-load kernel, 2 for the staged ones)
     int mfma_stage = 16;             // MVDB_MFMA_STAGE (8 | 16)
-    int mfma_v = 2;                  // MVDB_MFMA_V (1 = fragment loads, 2 = LDS-DMA staged)
     int mfma_ng2 = -1;               // MVDB_MFMA_NG2 (-1: on for the staged kernel, off otherwise)
     int gemm_scan_min_nq = 104;      // MVDB_GEMM_SCAN_MIN_NQ
     int gemm_scan_blocks_per_cu = 2; // MVDB_GEMM_SCAN_BLOCKS_PER_CU

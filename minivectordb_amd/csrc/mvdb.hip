@@ -42,7 +42,6 @@ Knobs read_knobs() {
     k.scan_blocks_per_cu = env_int("MVDB_SCAN_BLOCKS_PER_CU", 0);
     k.mfma_blocks_per_cu = env_int("MVDB_MFMA_BLOCKS_PER_CU", 0);
     k.mfma_stage = env_int("MVDB_MFMA_STAGE", 16);
-    k.mfma_v = env_int("MVDB_MFMA_V", 2);
     k.mfma_ng2 = env_int("MVDB_MFMA_NG2", -1);
     k.gemm_scan_min_nq = env_int("MVDB_GEMM_SCAN_MIN_NQ", 104);
     k.gemm_scan_blocks_per_cu = env_int("MVDB_GEMM_SCAN_BLOCKS_PER_CU", 2);
@@ -351,9 +350,9 @@ struct Shape {
     int G, C;
 };
 Shape choose_shape(int d4) {
-    // one chunk per lane, 4 / 16 / 32 / 64 lanes per row (rows of up to 16 / 64 / 128 / 256 floats; the 1-, 2- and 8-lane
+    // one chunk per lane, 16 / 32 / 64 lanes per row (rows of up to 64 / 128 / 256 floats; the 1-, 2-, 4- and 8-lane
     // shapes of rounds 1 - 4 served rows of <= 4, 8 and 32 floats only: 84 instantiations for toy widths)
-    if (d4 <= 64) return {d4 <= 4 ? 4 : d4 <= 16 ? 16 : d4 <= 32 ? 32 : 64, 1};
+    if (d4 <= 64) return {d4 <= 16 ? 16 : d4 <= 32 ? 32 : 64, 1};  // (rows of <= 16 floats ride the 16-lane shape, lanes masked)
     if (d4 % 64 == 0 && d4 / 64 <= 8) return {64, d4 / 64};
     if (d4 == 96) return {32, 3};  // d = 384 (e5-small, config 5): three exact chunks on 32 lanes, two rows per wave-instruction
     // more than eight chunks per lane (d > 2048): ONE shape, sixteen chunks with the lanes beyond the row masked off — the
@@ -440,6 +439,18 @@ int launch_scan_gcu(int metric, int mode, const ScanArgs& a, int nq, int device,
     return launch_scan_inst<G, C, U, 1, kModeScores>(a, nq, device, s, nb);
 }
 
+// the row-list (SEL 1) forms of a shape only: the gather variants of the two- and three-chunk shapes exist for nothing else
+template <int G, int C, int U>
+int launch_scan_rows(int metric, int mode, const ScanArgs& a, int nq, int device, hipStream_t s, int* nb) {
+    const bool masked = a.d4 != G * C;
+#define MVDB_ROWS_CASE(M, MD)                                                                              \
+    (masked ? launch_scan_kern<G, C, U, M, MD, true, 1, true>(a, nq, device, s, nb) \
+            : launch_scan_kern<G, C, U, M, MD, true, 1, false>(a, nq, device, s, nb))
+    if (metric == MVDB_METRIC_IP) return mode == kModeTopK ? MVDB_ROWS_CASE(0, kModeTopK) : MVDB_ROWS_CASE(0, kModeScores);
+    return mode == kModeTopK ? MVDB_ROWS_CASE(1, kModeTopK) : MVDB_ROWS_CASE(1, kModeScores);
+#undef MVDB_ROWS_CASE
+}
+
 // Grid size the scan will use for (shape, n): needed up front to size the candidate buffer.
 int scan_grid_upper_bound(int device) { return device_cus(device) * 8; }
 
@@ -467,11 +478,10 @@ int launch_scan(int metric, int mode, const ScanArgs& a, int nq, int device, hip
     // Row-list (gather) scans of two- and three-chunk rows keep FOUR rows in flight per wave (the streaming scan: two): a
     // gathered row is a fresh DRAM page, so more rows must be outstanding to cover its latency — 10M x 512 rows resident,
     // ids on the device: 10 % of the rows 5.74 -> 6.23 TB/s of rows touched, 50 % 6.37 -> 6.78, 99 % 6.54 -> 6.95.
-    if (a.rows && sh.G == 64 && sh.C == 2) return launch_scan_gcu<64, 2, 4>(metric, mode, a, nq, device, s, nblocks);
-    if (a.rows && sh.G == 64 && sh.C == 3) return launch_scan_gcu<64, 3, 4>(metric, mode, a, nq, device, s, nblocks);
+    if (a.rows && sh.G == 64 && sh.C == 2) return launch_scan_rows<64, 2, 4>(metric, mode, a, nq, device, s, nblocks);
+    if (a.rows && sh.G == 64 && sh.C == 3) return launch_scan_rows<64, 3, 4>(metric, mode, a, nq, device, s, nblocks);
 #define MVDB_SCAN_CASE(G_, C_, U_) \
     if (sh.G == G_ && sh.C == C_) return launch_scan_gcu<G_, C_, U_>(metric, mode, a, nq, device, s, nblocks);
-    MVDB_SCAN_CASE(4, 1, 4)
     MVDB_SCAN_CASE(16, 1, 4)
     MVDB_SCAN_CASE(32, 1, 4)
     MVDB_SCAN_CASE(32, 3, 4)
@@ -673,11 +683,7 @@ int launch_mfma2_gated(int KB, const MfmaScanArgs& a, int device, hipStream_t s,
 template <int NG>
 int launch_mfma_ng(int KB, const MfmaScanArgs& a, int device, hipStream_t s, int* nb) {
     switch (KB) {
-        case 4: return launch_mfma_inst<4, NG>(a, device, s, nb);
-        case 8: return launch_mfma_inst<8, NG>(a, device, s, nb);
-        case 16: return launch_mfma_inst<16, NG>(a, device, s, nb);
-        case 24: return launch_mfma_inst<24, NG>(a, device, s, nb);
-        case 32: return launch_mfma_inst<32, NG>(a, device, s, nb);
+        case 4: return launch_mfma_inst<4, NG>(a, device, s, nb);   // (d = 64: the one width the staged kernel — d % 128 == 0 — does not serve)
         default: return fail(MVDB_ERR_ARG, "no multi-query kernel for d = %d", KB * 16);
     }
 }
@@ -989,7 +995,7 @@ bool mfma_path_ok(const mvdb_index* idx, int nq, int k, const int64_t* rows_dev)
     if (idx->d % 16 || idx->ld != idx->d) return false;
     // squared L2 as |q|^2 + |x|^2 - 2 q.x: the staged kernel only (it sees whole rows go by)
     // (d <= 768: at d = 1024 the L2 form of the kernel spills; two 16-query groups only up to d = 384, same reason)
-    if (idx->metric != MVDB_METRIC_IP && !(idx->d % 128 == 0 && idx->d <= 768 && idx->kn.mfma_v == 2 && !idx->kn.disable_l2_mfma)) return false;
+    if (idx->metric != MVDB_METRIC_IP && !(idx->d % 128 == 0 && idx->d <= 768 && !idx->kn.disable_l2_mfma)) return false;
     const int KB = idx->d / 16;
     return KB == 4 || KB == 8 || KB == 16 || KB == 24 || KB == 32 || KB == 40 || KB == 48 || KB == 56 || KB == 64;
 }
@@ -1441,7 +1447,7 @@ int search_core(const mvdb_index* idx, Workspace* ws, const float* q_dev, int nq
             const int left = nq - q0;
             // staged kernel: 32 queries per pass (two query groups share each B fragment); the v1
             // kernel with two groups runs at one wave per SIMD and loses to two 16-query passes
-            const bool staged = idx->d % 128 == 0 && idx->kn.mfma_v == 2;
+            const bool staged = idx->d % 128 == 0;
             const bool two_groups = left > 16 && idx->d <= (idx->metric == MVDB_METRIC_IP ? 512 : 384) && (idx->kn.mfma_ng2 >= 0 ? idx->kn.mfma_ng2 != 0 : staged);
             const int take = two_groups ? std::min(left, 32) : std::min(left, 16);
             MfmaScanArgs ma;
