@@ -13,8 +13,8 @@ import numpy as np  # noqa: E402
 
 from minivectordb_amd import _native as native  # noqa: E402
 
-FAMILIES = ("ip_scan", "ip_scan_scores", "ip_scan_mfma", "ip_scan_gemm", "ip_scan_split", "ip_scan_split32", "ip_scan_half",
-            "ip_scan_half_seed", "ip_scan_split_seed")
+FAMILIES = ("ip_scan", "ip_scan_scores", "ip_scan_mfma", "ip_scan_gemm", "ip_scan_half", "ip_scan_half_seed", "ip_scan_rescue",
+            "ip_scan_rerun")
 out = {"grid": [], "families": list(FAMILIES)}
 native.prof_enable(True)
 for d in (64, 128, 192, 256, 384, 512, 768, 1024, 1536):

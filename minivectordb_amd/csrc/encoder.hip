@@ -2899,6 +2899,7 @@ std::map<int, WalkOrder> g_walk_order;
 std::map<int, WalkGate> g_walk_gate;
 constexpr int kGateWaitUs = 50000;
 constexpr int kPinSlots = 512;          // token slots the host entry serves from ONE host-mapped buffer (no copies)
+constexpr int kGateBusyCalls = 64;      // forwards on the per-op kernels after the gate could not be had within kGateWaitUs
 constexpr int kWalkSuspendCalls = 256;  // forwards on the per-op kernels after an abandoned launch, before the next attempt
 
 int gate_open(int device) {
@@ -3361,7 +3362,8 @@ int forward_core(mvdb_encoder* e, const int32_t* ids, const int32_t* mask, int B
             e->walk_suspended = kWalkSuspendCalls;
         }
         if (e->walk_suspended > 0) --e->walk_suspended;
-        else if (!captured && gate_acquire(e->device)) {
+        else if (!captured && !gate_acquire(e->device)) e->walk_suspended = kGateBusyCalls;  // (do not pay kGateWaitUs on every call)
+        else if (!captured) {
             const int pslot0 = prof_begin("encoder", s);
             WalkTurn turn;
             int rc0 = turn.begin(e->device, s);
