@@ -2233,13 +2233,6 @@ __global__ __launch_bounds__(WV * 64) void attention_x3i_kernel(const float* __r
     for (int t = 0; t < DT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
-#ifdef MVDB_ATTN_ILP
-    f32x16 o2[DT];  // the two small products of O^T on an accumulator of their own
-#pragma unroll
-    for (int t = 0; t < DT; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o2[t][r] = 0.f;
-#endif
     float m = -INFINITY, l = 0.f;
     const bool wave_active = q0 + wave * 32 < len;  // wave-uniform
 
@@ -2264,28 +2257,14 @@ __global__ __launch_bounds__(WV * 64) void attention_x3i_kernel(const float* __r
             f32x16 st;
 #pragma unroll
             for (int r = 0; r < 16; ++r) st[r] = 0.f;
-#ifdef MVDB_ATTN_ILP
-            f32x16 st2;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) st2[r] = 0.f;
-#endif
 #pragma unroll
             for (int kb = 0; kb < KB; ++kb) {
                 const x3_h8 kh = *reinterpret_cast<const x3_h8*>(kbp + k_off[kb][0]);
                 const x3_h8 kl = *reinterpret_cast<const x3_h8*>(kbp + k_off[kb][1]);
-#ifdef MVDB_ATTN_ILP   // A/B build: the two small products on an accumulator of their own (two independent MFMA chains)
-                st2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[kb], st2, 0, 0, 0);
-                st2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[kb], st2, 0, 0, 0);
-                st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[kb], st, 0, 0, 0);
-#else
                 st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[kb], st, 0, 0, 0);
                 st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[kb], st, 0, 0, 0);
                 st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[kb], st, 0, 0, 0);
-#endif
             }
-#ifdef MVDB_ATTN_ILP
-            st += st2;
-#endif
             // the V^T fragments of this key block do not depend on P: their reads fly under the softmax
             union VF {
                 x3_h8 v;
@@ -2329,12 +2308,7 @@ __global__ __launch_bounds__(WV * 64) void attention_x3i_kernel(const float* __r
 #pragma unroll
                 for (int t = 0; t < DT; ++t)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        o[t][r] *= alpha;
-#ifdef MVDB_ATTN_ILP
-                        o2[t][r] *= alpha;
-#endif
-                    }
+                    for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
             }
             // ---- O^T += V^T . P^T: k-block kb16 = accumulator registers 8 kb16 .. + 7 ------------------
 #pragma unroll
@@ -2347,23 +2321,13 @@ __global__ __launch_bounds__(WV * 64) void attention_x3i_kernel(const float* __r
                 for (int e = 0; e < 4; ++e) x3_split2(st[8 * kb16 + 2 * e], st[8 * kb16 + 2 * e + 1], ph.w[e], pl.w[e]);
 #pragma unroll
                 for (int t = 0; t < DT; ++t) {
-#ifdef MVDB_ATTN_ILP
-                    o2[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl[kb16][t].v, ph.v, o2[t], 0, 0, 0);
-                    o2[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[kb16][t].v, pl.v, o2[t], 0, 0, 0);
-                    o[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[kb16][t].v, ph.v, o[t], 0, 0, 0);
-#else
                     o[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl[kb16][t].v, ph.v, o[t], 0, 0, 0);
                     o[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[kb16][t].v, pl.v, o[t], 0, 0, 0);
                     o[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[kb16][t].v, ph.v, o[t], 0, 0, 0);
-#endif
                 }
             }
         }
     }
-#ifdef MVDB_ATTN_ILP
-#pragma unroll
-    for (int t = 0; t < DT; ++t) o[t] += o2[t];
-#endif
     if (!wave_active || !qvalid) return;
     // O^T tile t: col = query fr (lane), row d = t*32 + (r&3) + 8(r>>2) + 4fh -> the (hi | lo) lines of the context image
     // (see attention_x3_kernel: lane halves trade pieces so that every store writes whole 32-byte sectors)
