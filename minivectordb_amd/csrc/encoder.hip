@@ -344,23 +344,34 @@ __global__ __launch_bounds__(256) void ln_partials_kernel(const float* __restric
     if (p >= T) return;
     float v[VPT];
     if constexpr (NP > 0) {
-        float pv[NP][VPT], rv[VPT], bv[VPT];
+        constexpr int GP = NP <= 4 ? NP : NP / 2;   // planes per group: every load of a group in flight before its adds
+        float rv[VPT], bv[VPT];
 #pragma unroll
         for (int i = 0; i < VPT; ++i) {
             const int c = (FULL || lane + i * 64 < H) ? lane + i * 64 : 0;
-#pragma unroll
-            for (int z = 0; z < NP; ++z) pv[z][i] = P[z * plane + (int64_t)p * H + c];
             rv[i] = x[(int64_t)p * H + c];
             bv[i] = bias[c];
+            v[i] = 0.f;
         }
 #pragma unroll
-        for (int i = 0; i < VPT; ++i) {
-            float a = pv[0][i];
+        for (int g0 = 0; g0 < NP; g0 += GP) {
+            float pv[GP][VPT];
 #pragma unroll
-            for (int z = 1; z < NP; ++z) a += pv[z][i];
-            a = (a + bv[i]) + rv[i];
-            v[i] = (FULL || lane + i * 64 < H) ? a : 0.f;
+            for (int i = 0; i < VPT; ++i) {
+                const int c = (FULL || lane + i * 64 < H) ? lane + i * 64 : 0;
+#pragma unroll
+                for (int z = 0; z < GP; ++z) pv[z][i] = P[(g0 + z) * plane + (int64_t)p * H + c];
+            }
+#pragma unroll
+            for (int i = 0; i < VPT; ++i) {
+                float a = g0 == 0 ? pv[0][i] : v[i] + pv[0][i];   // plane order throughout
+#pragma unroll
+                for (int z = 1; z < GP; ++z) a += pv[z][i];
+                v[i] = a;
+            }
         }
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) v[i] = (FULL || lane + i * 64 < H) ? (v[i] + bv[i]) + rv[i] : 0.f;
     } else {
 #pragma unroll
         for (int i = 0; i < VPT; ++i) {
@@ -2375,6 +2386,10 @@ struct LayerW {
 
 }  // namespace
 
+// split-K GEMMs of small batches (x3_splitk_parts): most planes, and the packed tokens the lanes' plane buffer serves
+constexpr int kSplitKMax = 8;
+constexpr int64_t kSplitKRows = 2048;
+
 struct GraphKey {
     int B, S, compute;
     const void *ids, *mask, *out;
@@ -2414,13 +2429,15 @@ struct mvdb_encoder {
         float *x = nullptr, *y = nullptr, *qkv = nullptr, *ctx = nullptr, *ffn = nullptr;
         float* xp = nullptr;  // compute = 2: the (hi | lo) fp16 image of x (same bytes as x)
         unsigned int* pool_ctr = nullptr;  // [B] arrival counters of pool_norm_kernel's chunks (zero between launches)
+        float* planes = nullptr;           // [kSplitKMax][min(tokens, kSplitKRows)][H] partial planes of the split-K GEMMs
         void release() {
-            void* ptrs[] = {rank, count, seq_start, tok_id, tok_pos, tok_src, x, y, qkv, ctx, ffn, xp, pool_ctr};
+            void* ptrs[] = {rank, count, seq_start, tok_id, tok_pos, tok_src, x, y, qkv, ctx, ffn, xp, pool_ctr, planes};
             for (void* p : ptrs)
                 if (p) (void)hipFree(p);
             rank = count = seq_start = tok_id = tok_pos = tok_src = nullptr;
             x = y = qkv = ctx = ffn = xp = nullptr;
             pool_ctr = nullptr;
+            planes = nullptr;
         }
     } lane[2];
     hipStream_t stream2 = nullptr;             // second half of a split batch
@@ -2509,6 +2526,7 @@ int alloc_lane(mvdb_encoder* e, mvdb_encoder::Lane& w, int64_t B, int64_t tokens
     MVDB_TRY(dev_alloc(&w.ctx, tokens * H));
     MVDB_TRY(dev_alloc(&w.ffn, tokens * std::max(F, H)));
     MVDB_TRY(dev_alloc(&w.xp, tokens * H));
+    MVDB_TRY(dev_alloc(&w.planes, (int64_t)kSplitKMax * std::min<int64_t>(tokens, kSplitKRows) * H));
     MVDB_TRY(dev_alloc(&w.pool_ctr, B));
     MVDB_HIP(hipMemset(w.pool_ctr, 0, (size_t)std::max<int64_t>(B, 1) * sizeof(unsigned int)));
     return 0;
@@ -2824,11 +2842,19 @@ int ensure_x3_weights(mvdb_encoder* e, hipStream_t s) {
 // Used when the unsplit grid would leave three quarters of the CUs idle and K is long (x3_splitk_parts); the summation order over K
 // then differs from the unsplit kernel's (rounding-level differences between a sentence embedded alone and in a large batch).
 // MVDB_GEMM_X3_SPLITK=0 switches it off.
+// Planes: K-steps are a latency chain (one barrier + one DMA round trip each, ~0.4 us): as many planes as leave each >= 8 K-steps,
+// at most kSplitKMax and at most one workgroup per CU in all.  Round 6 (one long sentence on the wide shapes: FFN2 walks
+// F / 32 = 128 K-steps): 3 -> 8 planes at K = 4096, 6 at K = 1536, 4 at K = 1024.  MVDB_GEMM_X3_SPLITK_PARTS=3 keeps three (A/B).
 int x3_splitk_parts(int64_t Tmax, int N, int K, int cus) {
     static const bool on = []() { const char* v = getenv("MVDB_GEMM_X3_SPLITK"); return !(v && *v == '0'); }();
+    static const int forced = []() { const char* v = getenv("MVDB_GEMM_X3_SPLITK_PARTS"); return v && *v ? atoi(v) : 0; }();
     if (!on || K < 32 * 24) return 0;   // three planes of >= 8 K-steps each (ceil(K / 96) K-steps per plane, the last one the rest)
     const int64_t tiles = ((Tmax + 63) / 64) * ((N + 127) / 128);
-    return tiles * 4 <= cus ? 3 : 0;
+    if (tiles * 4 > cus || Tmax > kSplitKRows) return 0;
+    if (forced >= 3) return std::min(forced, kSplitKMax);
+    int parts = std::min(kSplitKMax, K / 32 / 8);
+    while (parts > 3 && tiles * parts > (int64_t)cus) --parts;   // (one workgroup per CU: 8 planes x 64 tiles were slower than 3 at T = 512)
+    return parts == 5 ? 4 : parts == 7 ? 6 : std::max(parts, 3);   // (ln_partials_kernel's unrolled forms: 3, 4, 6, 8)
 }
 
 int launch_gemm_x3_splitk(const float* Aimg, const _Float16* Wp, float inv_wscale, float* planes, const int* Tptr, int64_t Tmax,
@@ -2851,8 +2877,14 @@ void launch_ln_partials(const float* planes, int parts, int64_t plane, const flo
     hipLaunchKernelGGL((ln_partials_kernel<VPT, FULLV, NPV>), grid, dim3(256), 0, s, planes, parts, plane, bias, seq_start, B, g, b, \
                        eps, H, x, xp)
     if (H == VPT * 64) {
-        if (parts == 3) MVDB_LNP(true, 3);
-        else MVDB_LNP(true, 0);
+        if (parts == 3) { MVDB_LNP(true, 3); return; }
+        // (the wider unrolled forms only at the widths of the reference's models: H = 384 / 768 / 1024)
+        if constexpr (VPT == 6 || VPT == 12 || VPT == 16) {
+            if (parts == 4) { MVDB_LNP(true, 4); return; }
+            if (parts == 6) { MVDB_LNP(true, 6); return; }
+            if (parts == 8) { MVDB_LNP(true, 8); return; }
+        }
+        MVDB_LNP(true, 0);
     } else {
         if (parts == 3) MVDB_LNP(false, 3);
         else MVDB_LNP(false, 0);
@@ -3270,14 +3302,14 @@ int enqueue_lane(mvdb_encoder* e, mvdb_encoder::Lane& w, const int32_t* ids, con
             if (ln_fused)
                 MVDB_TRY(launch_gemm_x3_ln(ctx_img, L.wo_p, L.wo_is, L.bo, L.ln1g, L.ln1b, c.ln_eps, w.x, xp, Tptr, Tmax, H, H, e->device, s));
             else if (wo_parts)  // small batch, long K (H >= 768): split over K like FFN2 (attention is done with qkv)
-                MVDB_TRY(launch_gemm_x3_splitk(ctx_img, L.wo_p, L.wo_is, w.qkv, Tptr, Tmax, H, H, wo_parts, e->device, s));
+                MVDB_TRY(launch_gemm_x3_splitk(ctx_img, L.wo_p, L.wo_is, w.planes, Tptr, Tmax, H, H, wo_parts, e->device, s));
             else
                 MVDB_TRY(launch_gemm_x3<EPI_BIAS_RESIDUAL>(ctx_img, L.wo_p, L.wo_is, L.bo, w.x, w.y, Tptr, Tmax, H, H, e->device, s));
         }
         else
             launch_gemm<EPI_BIAS_RESIDUAL>(w.ctx, L.wo, L.bo, w.x, w.y, Tptr, Tmax, H, H, cus, s);
 #define LN1_CALL(V) launch_ln<V>(w.y, w.seq_start, B, L.ln1g, L.ln1b, c.ln_eps, H, w.x, xp, Tmax, s)
-#define LN1P_CALL(V) launch_ln_partials<V>(w.qkv, wo_parts, Tmax * H, L.bo, w.seq_start, B, L.ln1g, L.ln1b, c.ln_eps, H, w.x, xp, Tmax, s)
+#define LN1P_CALL(V) launch_ln_partials<V>(w.planes, wo_parts, Tmax * H, L.bo, w.seq_start, B, L.ln1g, L.ln1b, c.ln_eps, H, w.x, xp, Tmax, s)
         if (!ln_fused && wo_parts) { MVDB_VPT_SWITCH(LN1P_CALL) }
         else if (!ln_fused) { MVDB_VPT_SWITCH(LN1_CALL) }
 #undef LN1P_CALL
@@ -3286,8 +3318,8 @@ int enqueue_lane(mvdb_encoder* e, mvdb_encoder::Lane& w, const int32_t* ids, con
             MVDB_TRY(launch_gemm_x3<EPI_BIAS_GELU>(xp, L.w1_p, L.w1_is, L.b1, nullptr, w.ffn, Tptr, Tmax, F, H, e->device, s));
             if (ln_fused)
                 MVDB_TRY(launch_gemm_x3_ln(w.ffn, L.w2_p, L.w2_is, L.b2, L.ln2g, L.ln2b, c.ln_eps, w.x, xp, Tptr, Tmax, H, F, e->device, s));
-            else if (ffn2_parts)  // small batch: split over K into planes (the qkv buffer is free here: 3 H floats per token)
-                MVDB_TRY(launch_gemm_x3_splitk(w.ffn, L.w2_p, L.w2_is, w.qkv, Tptr, Tmax, H, F, ffn2_parts, e->device, s));
+            else if (ffn2_parts)  // small batch: split over K into planes
+                MVDB_TRY(launch_gemm_x3_splitk(w.ffn, L.w2_p, L.w2_is, w.planes, Tptr, Tmax, H, F, ffn2_parts, e->device, s));
             else
                 MVDB_TRY(launch_gemm_x3<EPI_BIAS_RESIDUAL>(w.ffn, L.w2_p, L.w2_is, L.b2, w.x, w.y, Tptr, Tmax, H, F, e->device, s));
         } else {
@@ -3295,7 +3327,7 @@ int enqueue_lane(mvdb_encoder* e, mvdb_encoder::Lane& w, const int32_t* ids, con
             launch_gemm<EPI_BIAS_RESIDUAL>(w.ffn, L.w2, L.b2, w.x, w.y, Tptr, Tmax, H, F, cus, s);
         }
 #define LN2_CALL(V) launch_ln<V>(w.y, w.seq_start, B, L.ln2g, L.ln2b, c.ln_eps, H, w.x, xp, Tmax, s)
-#define LN2P_CALL(V) launch_ln_partials<V>(w.qkv, ffn2_parts, Tmax * H, L.b2, w.seq_start, B, L.ln2g, L.ln2b, c.ln_eps, H, w.x, xp, Tmax, s)
+#define LN2P_CALL(V) launch_ln_partials<V>(w.planes, ffn2_parts, Tmax * H, L.b2, w.seq_start, B, L.ln2g, L.ln2b, c.ln_eps, H, w.x, xp, Tmax, s)
         if (!ln_fused && ffn2_parts) { MVDB_VPT_SWITCH(LN2P_CALL) }
         else if (!ln_fused) { MVDB_VPT_SWITCH(LN2_CALL) }
 #undef LN2P_CALL
