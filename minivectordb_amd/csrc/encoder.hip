@@ -2842,17 +2842,20 @@ int ensure_x3_weights(mvdb_encoder* e, hipStream_t s) {
 // Used when the unsplit grid would leave three quarters of the CUs idle and K is long (x3_splitk_parts); the summation order over K
 // then differs from the unsplit kernel's (rounding-level differences between a sentence embedded alone and in a large batch).
 // MVDB_GEMM_X3_SPLITK=0 switches it off.
-// Planes: K-steps are a latency chain (one barrier + one DMA round trip each, ~0.4 us): as many planes as leave each >= 8 K-steps,
-// at most kSplitKMax and at most one workgroup per CU in all.  Round 6 (one long sentence on the wide shapes: FFN2 walks
-// F / 32 = 128 K-steps): 3 -> 8 planes at K = 4096, 6 at K = 1536, 4 at K = 1024.  MVDB_GEMM_X3_SPLITK_PARTS=3 keeps three (A/B).
+// Planes: K-steps are a latency chain (one barrier + one DMA round trip each, ~0.4 us): as many planes as leave each >= 4 K-steps
+// (MVDB_GEMM_X3_SPLITK_MINSTEPS; 8 / 3 / 2 measured: 8 loses 4-7 % on the e5-small shape, whose K = 384 GEMM then stays unsplit,
+// 3 and 2 change nothing), at most kSplitKMax and at most one workgroup per CU in all.  Round 6 (one long sentence: FFN2 of the
+// wide shapes walked F / 32 = 128 K-steps in three planes): 8 planes at K = 4096 / 1536 / 1024, 3 at K = 384.
+// MVDB_GEMM_X3_SPLITK_PARTS=3 keeps three planes (A/B).
 int x3_splitk_parts(int64_t Tmax, int N, int K, int cus) {
     static const bool on = []() { const char* v = getenv("MVDB_GEMM_X3_SPLITK"); return !(v && *v == '0'); }();
     static const int forced = []() { const char* v = getenv("MVDB_GEMM_X3_SPLITK_PARTS"); return v && *v ? atoi(v) : 0; }();
-    if (!on || K < 32 * 24) return 0;   // three planes of >= 8 K-steps each (ceil(K / 96) K-steps per plane, the last one the rest)
+    static const int min_steps = []() { const char* v = getenv("MVDB_GEMM_X3_SPLITK_MINSTEPS"); return v && *v ? std::max(1, atoi(v)) : 4; }();
+    if (!on || K < 32 * 3 * min_steps) return 0;   // three planes of >= min_steps K-steps each
     const int64_t tiles = ((Tmax + 63) / 64) * ((N + 127) / 128);
     if (tiles * 4 > cus || Tmax > kSplitKRows) return 0;
     if (forced >= 3) return std::min(forced, kSplitKMax);
-    int parts = std::min(kSplitKMax, K / 32 / 8);
+    int parts = std::min(kSplitKMax, K / 32 / min_steps);
     while (parts > 3 && tiles * parts > (int64_t)cus) --parts;   // (one workgroup per CU: 8 planes x 64 tiles were slower than 3 at T = 512)
     return parts == 5 ? 4 : parts == 7 ? 6 : std::max(parts, 3);   // (ln_partials_kernel's unrolled forms: 3, 4, 6, 8)
 }
