@@ -2386,9 +2386,10 @@ struct LayerW {
 
 }  // namespace
 
-// split-K GEMMs of small batches (x3_splitk_parts): most planes, and the packed tokens the lanes' plane buffer serves
+// split-K GEMMs of small batches (x3_splitk_parts): most planes, and the floats of a lane's plane buffer — planes x tokens x N
+// never pass one 64 x 128 tile per CU (tiles x planes <= CUs), whatever the width
 constexpr int kSplitKMax = 8;
-constexpr int64_t kSplitKRows = 2048;
+inline int64_t x3_plane_floats(int cus) { return (int64_t)cus * 64 * 128 + 64 * 1024; }
 
 struct GraphKey {
     int B, S, compute;
@@ -2429,7 +2430,7 @@ struct mvdb_encoder {
         float *x = nullptr, *y = nullptr, *qkv = nullptr, *ctx = nullptr, *ffn = nullptr;
         float* xp = nullptr;  // compute = 2: the (hi | lo) fp16 image of x (same bytes as x)
         unsigned int* pool_ctr = nullptr;  // [B] arrival counters of pool_norm_kernel's chunks (zero between launches)
-        float* planes = nullptr;           // [kSplitKMax][min(tokens, kSplitKRows)][H] partial planes of the split-K GEMMs
+        float* planes = nullptr;           // x3_plane_floats(CUs): [planes][padded tokens][H] partial sums of the split-K GEMMs
         void release() {
             void* ptrs[] = {rank, count, seq_start, tok_id, tok_pos, tok_src, x, y, qkv, ctx, ffn, xp, pool_ctr, planes};
             for (void* p : ptrs)
@@ -2526,7 +2527,7 @@ int alloc_lane(mvdb_encoder* e, mvdb_encoder::Lane& w, int64_t B, int64_t tokens
     MVDB_TRY(dev_alloc(&w.ctx, tokens * H));
     MVDB_TRY(dev_alloc(&w.ffn, tokens * std::max(F, H)));
     MVDB_TRY(dev_alloc(&w.xp, tokens * H));
-    MVDB_TRY(dev_alloc(&w.planes, (int64_t)kSplitKMax * std::min<int64_t>(tokens, kSplitKRows) * H));
+    MVDB_TRY(dev_alloc(&w.planes, x3_plane_floats(device_cus(e->device))));
     MVDB_TRY(dev_alloc(&w.pool_ctr, B));
     MVDB_HIP(hipMemset(w.pool_ctr, 0, (size_t)std::max<int64_t>(B, 1) * sizeof(unsigned int)));
     return 0;
@@ -2842,22 +2843,24 @@ int ensure_x3_weights(mvdb_encoder* e, hipStream_t s) {
 // Used when the unsplit grid would leave three quarters of the CUs idle and K is long (x3_splitk_parts); the summation order over K
 // then differs from the unsplit kernel's (rounding-level differences between a sentence embedded alone and in a large batch).
 // MVDB_GEMM_X3_SPLITK=0 switches it off.
-// Planes: K-steps are a latency chain (one barrier + one DMA round trip each, ~0.4 us): as many planes as leave each >= 4 K-steps
-// (MVDB_GEMM_X3_SPLITK_MINSTEPS; 8 / 3 / 2 measured: 8 loses 4-7 % on the e5-small shape, whose K = 384 GEMM then stays unsplit,
-// 3 and 2 change nothing), at most kSplitKMax and at most one workgroup per CU in all.  Round 6 (one long sentence: FFN2 of the
-// wide shapes walked F / 32 = 128 K-steps in three planes): 8 planes at K = 4096 / 1536 / 1024, 3 at K = 384.
-// MVDB_GEMM_X3_SPLITK_PARTS=3 keeps three planes (A/B).
+// Planes: K-steps are a latency chain (one barrier + one DMA round trip each, ~0.4 us), so a GEMM whose 64 x 128 tiles do not fill
+// the CUs is split over K into as many planes as (a) leave each >= 4 K-steps (MVDB_GEMM_X3_SPLITK_MINSTEPS; 8 / 3 / 2 measured:
+// 8 loses 4-7 % on the e5-small shape, whose K = 384 GEMM then stays unsplit, 3 and 2 change nothing), (b) keep the launch at
+// one workgroup per CU (tiles x planes <= CUs: 8 planes x 64 tiles were slower than 3 at T = 512) and (c) ln_partials_kernel
+// has an unrolled form for (2, 3, 4, 6, 8).  Until round 6: three planes, only below a quarter of the CUs in tiles.  One long
+// sentence (profiles/r06_long_sentence_chain.txt): e5-small 256 tokens 0.71 -> 0.65 ms, large 129 tokens 2.22 -> 2.02; batches
+// of 32 - 64 short sentences (benchmarks/mid_batch_probe.py): e5-small 64 x 32 tokens 0.92 -> 0.78 ms, large 32 x 32 3.93 -> 3.20.
+// MVDB_GEMM_X3_SPLITK_PARTS=3 forces three planes (A/B), MVDB_GEMM_X3_SPLITK=0 switches the split off.
 int x3_splitk_parts(int64_t Tmax, int N, int K, int cus) {
     static const bool on = []() { const char* v = getenv("MVDB_GEMM_X3_SPLITK"); return !(v && *v == '0'); }();
     static const int forced = []() { const char* v = getenv("MVDB_GEMM_X3_SPLITK_PARTS"); return v && *v ? atoi(v) : 0; }();
     static const int min_steps = []() { const char* v = getenv("MVDB_GEMM_X3_SPLITK_MINSTEPS"); return v && *v ? std::max(1, atoi(v)) : 4; }();
-    if (!on || K < 32 * 3 * min_steps) return 0;   // three planes of >= min_steps K-steps each
+    if (!on) return 0;
     const int64_t tiles = ((Tmax + 63) / 64) * ((N + 127) / 128);
-    if (tiles * 4 > cus || Tmax > kSplitKRows) return 0;
-    if (forced >= 3) return std::min(forced, kSplitKMax);
-    int parts = std::min(kSplitKMax, K / 32 / min_steps);
-    while (parts > 3 && tiles * parts > (int64_t)cus) --parts;   // (one workgroup per CU: 8 planes x 64 tiles were slower than 3 at T = 512)
-    return parts == 5 ? 4 : parts == 7 ? 6 : std::max(parts, 3);   // (ln_partials_kernel's unrolled forms: 3, 4, 6, 8)
+    int64_t parts = std::min<int64_t>({(int64_t)kSplitKMax, (int64_t)(K / 32 / min_steps), (int64_t)cus / std::max<int64_t>(tiles, 1)});
+    if (forced >= 2) parts = std::min<int64_t>({(int64_t)forced, (int64_t)kSplitKMax, (int64_t)(K / 32)});
+    if (parts < 2 || parts * Tmax * N > x3_plane_floats(cus)) return 0;
+    return parts == 5 ? 4 : parts == 7 ? 6 : (int)parts;
 }
 
 int launch_gemm_x3_splitk(const float* Aimg, const _Float16* Wp, float inv_wscale, float* planes, const int* Tptr, int64_t Tmax,
@@ -2881,8 +2884,9 @@ void launch_ln_partials(const float* planes, int parts, int64_t plane, const flo
                        eps, H, x, xp)
     if (H == VPT * 64) {
         if (parts == 3) { MVDB_LNP(true, 3); return; }
-        // (the wider unrolled forms only at the widths of the reference's models: H = 384 / 768 / 1024)
+        // (the other unrolled forms only at the widths of the reference's models: H = 384 / 768 / 1024)
         if constexpr (VPT == 6 || VPT == 12 || VPT == 16) {
+            if (parts == 2) { MVDB_LNP(true, 2); return; }
             if (parts == 4) { MVDB_LNP(true, 4); return; }
             if (parts == 6) { MVDB_LNP(true, 6); return; }
             if (parts == 8) { MVDB_LNP(true, 8); return; }
