@@ -1132,6 +1132,39 @@ __device__ __forceinline__ void x3_epilogue(const f32x16 (&acc)[TM][TN], int row
     }
 }
 
+// The planes of a split-K QKV / FFN1 GEMM (EPI_PARTIAL) -> the (hi | lo) image the fused epilogues write: sum in plane order,
+// + bias, then EPI_BIAS_QKV's query scale (columns < qcols) resp. EPI_BIAS_GELU's erf-GELU (x3_epilogue's arithmetic).  One wave
+// per (row, 256 columns): every load of the NP x 4 column groups in flight before the first add.  N % 64 == 0.
+template <int EPI, int NP>
+__global__ __launch_bounds__(256) void partials_image_kernel(const float* __restrict__ P, int64_t plane, const float* __restrict__ bias,
+                                                             const int* __restrict__ seq_start, int B, int N, int qcols, float qscale,
+                                                             float* __restrict__ Cimg) {
+    const int T = seq_start[B];
+    const int lane = threadIdx.x & 63;
+    const int p = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (p >= T) return;
+    const int c0 = blockIdx.x * 256;
+    float pv[NP][4], bv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int c = c0 + u * 64 < N ? c0 + u * 64 + lane : lane;   // (a group past N: re-reads the first, never stored)
+        bv[u] = bias[c];
+#pragma unroll
+        for (int z = 0; z < NP; ++z) pv[z][u] = P[z * plane + (int64_t)p * N + c];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int cb = c0 + u * 64;          // wave-uniform
+        float a = pv[0][u];
+#pragma unroll
+        for (int z = 1; z < NP; ++z) a += pv[z][u];
+        a += bv[u];
+        if (EPI == EPI_BIAS_GELU) a = 0.5f * a * (1.0f + x3_erf(a * 0.70710678118654752440f));
+        if (EPI == EPI_BIAS_QKV) a = cb + (lane & 32) < qcols ? a * qscale : a;   // (qcols % 32 == 0: uniform per 32-column line)
+        x3_pair_store(Cimg + (int64_t)p * N + cb + (lane & 32), lane & 31, a, cb < N);
+    }
+}
+
 // Block tile 64 x 128 x 32, four waves 2 x 2.  BOTH operands arrive as (hi | lo) fp16 lines — A from the kernel that
 // produced the activations (LayerNorm, attention, the GELU epilogue below: x3_pair_store), W from the one-time split of
 // the weights — and go global -> LDS by global_load_lds into a three-stage ring (two K-steps in flight, ONE bare
@@ -2875,6 +2908,33 @@ int launch_gemm_x3_splitk(const float* Aimg, const _Float16* Wp, float inv_wscal
     return 0;
 }
 
+// the planes of a split-K QKV / FFN1 GEMM -> bias (+ query scale / GELU) -> (hi | lo) image (partials_image_kernel)
+template <int EPI>
+int launch_partials_image(const float* planes, int parts, const float* bias, const int* seq_start, int B, int64_t Tmax, int N, int qcols,
+                          float qscale, float* Cimg, hipStream_t s) {
+    const dim3 grid((unsigned)((N + 255) / 256), (unsigned)((Tmax + 3) / 4));
+    const int64_t plane = Tmax * N;
+#define MVDB_PI(NPV) hipLaunchKernelGGL((partials_image_kernel<EPI, NPV>), grid, dim3(256), 0, s, planes, plane, bias, seq_start, B, N, qcols, qscale, Cimg)
+    switch (parts) {
+        case 2: MVDB_PI(2); break;
+        case 3: MVDB_PI(3); break;
+        case 4: MVDB_PI(4); break;
+        case 6: MVDB_PI(6); break;
+        case 8: MVDB_PI(8); break;
+        default: return fail(MVDB_ERR_ARG, "internal: no partials_image_kernel for %d planes", parts);
+    }
+#undef MVDB_PI
+    MVDB_HIP(hipGetLastError());
+    return 0;
+}
+// ... worth its extra launch (~5 us) where the GEMM walks many K-steps: K >= 768 (the wide shapes) and three planes or more
+int x3_splitk_parts_wide(int64_t Tmax, int N, int K, int cus) {
+    static const bool on = []() { const char* v = getenv("MVDB_GEMM_X3_SPLITK_WIDE"); return !(v && *v == '0'); }();
+    if (!on || K < 768 || N % 64) return 0;
+    const int parts = x3_splitk_parts(Tmax, N, K, cus);
+    return parts >= 3 ? parts : 0;
+}
+
 template <int VPT>
 void launch_ln_partials(const float* planes, int parts, int64_t plane, const float* bias, const int* seq_start, int B, const float* g,
                         const float* b, float eps, int H, float* x, float* xp, int64_t Tmax, hipStream_t s) {
@@ -3241,9 +3301,15 @@ int enqueue_lane(mvdb_encoder* e, mvdb_encoder::Lane& w, const int32_t* ids, con
     const int ln_env = e->opt_ln_fused;  // MVDB_GEMM_LN_FUSED as read when the encoder was created
     const bool ln_fused = compute == 2 && x3_ln_fusable(H) && ln_env != 0 && (ln_env == 2 || Tmax >= 128 * (int64_t)cus);
     const int ffn2_parts = compute == 2 && !ln_fused ? x3_splitk_parts(Tmax, H, F, cus) : 0;
-    const int wo_parts = compute == 2 && !ln_fused ? x3_splitk_parts(Tmax, H, H, cus) : 0;   // (H >= 768 only: e5-large / bge-m3)
+    const int wo_parts = compute == 2 && !ln_fused ? x3_splitk_parts(Tmax, H, H, cus) : 0;
+    // QKV and FFN1 the same way on the wide shapes (K = H >= 768: 32 K-steps), their epilogues as a launch of their own
+    const int qkv_parts = compute == 2 ? x3_splitk_parts_wide(Tmax, 3 * H, H, cus) : 0;
+    const int ffn1_parts = compute == 2 ? x3_splitk_parts_wide(Tmax, F, H, cus) : 0;
     for (const LayerW& L : e->layers) {
-        if (compute == 2 && img_attn)
+        if (compute == 2 && img_attn && qkv_parts) {   // small batch, K >= 768: split over K, then bias + query scale + image
+            MVDB_TRY(launch_gemm_x3_splitk(xp, L.wqkv_p, L.wqkv_is, w.planes, Tptr, Tmax, 3 * H, H, qkv_parts, e->device, s));
+            MVDB_TRY(launch_partials_image<EPI_BIAS_QKV>(w.planes, qkv_parts, L.bqkv, w.seq_start, B, Tmax, 3 * H, H, scale * kLog2e, w.qkv, s));
+        } else if (compute == 2 && img_attn)
             MVDB_TRY(launch_gemm_x3<EPI_BIAS_QKV>(xp, L.wqkv_p, L.wqkv_is, L.bqkv, nullptr, w.qkv, Tptr, Tmax, 3 * H, H, e->device, s,
                                                   H, scale * kLog2e));
         else if (compute == 2)
@@ -3322,7 +3388,11 @@ int enqueue_lane(mvdb_encoder* e, mvdb_encoder::Lane& w, const int32_t* ids, con
 #undef LN1P_CALL
 #undef LN1_CALL
         if (compute == 2) {
-            MVDB_TRY(launch_gemm_x3<EPI_BIAS_GELU>(xp, L.w1_p, L.w1_is, L.b1, nullptr, w.ffn, Tptr, Tmax, F, H, e->device, s));
+            if (ffn1_parts) {
+                MVDB_TRY(launch_gemm_x3_splitk(xp, L.w1_p, L.w1_is, w.planes, Tptr, Tmax, F, H, ffn1_parts, e->device, s));
+                MVDB_TRY(launch_partials_image<EPI_BIAS_GELU>(w.planes, ffn1_parts, L.b1, w.seq_start, B, Tmax, F, 0, 1.f, w.ffn, s));
+            } else
+                MVDB_TRY(launch_gemm_x3<EPI_BIAS_GELU>(xp, L.w1_p, L.w1_is, L.b1, nullptr, w.ffn, Tptr, Tmax, F, H, e->device, s));
             if (ln_fused)
                 MVDB_TRY(launch_gemm_x3_ln(w.ffn, L.w2_p, L.w2_is, L.b2, L.ln2g, L.ln2b, c.ln_eps, w.x, xp, Tptr, Tmax, H, F, e->device, s));
             else if (ffn2_parts)  // small batch: split over K into planes
