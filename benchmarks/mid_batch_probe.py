@@ -1,7 +1,7 @@
 """Encoder forward of mid-size batches (4 .. 256 sentences), ms per forward through the device entry, best of 5 x 30: where the
 split-K rule of the N = H GEMMs applies (x3_splitk_parts).  usage: mid_batch_probe.py [--large]"""
 import os, sys, time
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from minivectordb_amd.embedding_model import GpuEncoder
 from oracle.encoder import make_weights

@@ -299,6 +299,10 @@ class ShardedVectorDatabase(FilterAndRerankMixin):
     def find_most_similar(self, embedding, metadata_filter=None, exclude_filter=None, or_filters=None, k=5,
                           autocut=False):
         uids = self._ids.uids
-        hits = [(uids[row], score, self.metadata[row])
-                for row, score in self._nearest_rows(embedding, metadata_filter, exclude_filter, or_filters, k)]
+        hits = []
+        for row, score in self._nearest_rows(embedding, metadata_filter, exclude_filter, or_filters, k):
+            try:  # a row a concurrent delete has just renumbered away is skipped, as in VectorDatabase.find_most_similar
+                hits.append((uids[row], score, self.metadata[row]))
+            except (KeyError, IndexError):
+                pass
         return self._package(hits, autocut)
