@@ -3286,10 +3286,7 @@ int enqueue_lane(mvdb_encoder* e, mvdb_encoder::Lane& w, const int32_t* ids, con
         const char* v = getenv("MVDB_ATTENTION_X3_SHORT");
         return !(v && *v == '0');
     }();
-    static const int x3_attn_spread = []() {   // 0: off; n: one-wave workgroups while the 256-query form would fill < 1 / n of the CUs
-        const char* v = getenv("MVDB_ATTENTION_X3_SPREAD");
-        return v && *v ? atoi(v) : 0;
-    }();
+
     const dim3 agrid((S + ATT_Q - 1) / ATT_Q, c.heads, B);
     const bool ctx_is_image = compute == 2 && x3_attention && !attn_valu;
     // Q / K / V as (hi | lo) images straight from the QKV GEMM's epilogue (Q pre-scaled), attention_x3i_kernel on them:
@@ -3328,12 +3325,8 @@ int enqueue_lane(mvdb_encoder* e, mvdb_encoder::Lane& w, const int32_t* ids, con
                 hipLaunchKernelGGL(attention_kernel<64>, agrid, dim3(ATT_Q), 0, s, w.qkv, w.seq_start, H, scale,
                                    w.ctx);
         } else if (img_attn) {
-            // few (sentence, head) pairs — one long sentence, a handful of them —: 32-query workgroups of ONE wave, so that the
-            // queries spread over the CUs (256 queries per workgroup put a 256-token sentence on 12 CUs at two waves per SIMD:
-            // the tile's MFMAs, not their latency, were what a tile cost)
-            const bool spread = x3_attn_spread > 0 && (int64_t)B * c.heads * ((S + 255) / 256) * x3_attn_spread <= cus;
-            if ((S <= 32 && x3_short) || spread) {  // one wave per (sentence, head, 32 queries)
-                const dim3 sgrid((S + 31) / 32, c.heads, B);
+            if (S <= 32 && x3_short) {  // one wave per (sentence, head)
+                const dim3 sgrid(1, c.heads, B);
                 if (hd == 32)
                     hipLaunchKernelGGL((attention_x3i_kernel<32, 1>), sgrid, dim3(64), 0, s, w.qkv, w.seq_start, H, w.ctx);
                 else
