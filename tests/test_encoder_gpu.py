@@ -104,8 +104,9 @@ def test_gemm_tile_forms_match_golden_in_a_fresh_process(env, gpu):
 
 def test_batch_composition_does_not_change_a_row(gpu, monkeypatch):
     """A sentence's embedding is bit-for-bit the same whatever else is in the batch and wherever its rows fall in a tile
-    (the reference semantics are B = 1) — among batches served by the same GEMM form (here: up to 320 token slots, all on the
-    small-batch form; across the form boundaries at ~1,400 and 32,768 token slots the K sums associate differently, <= 1.2e-7).  Round 3 found hipcc contracting `a * b + c` INTO the fp16 conversion of the
+    (the reference semantics are B = 1) — among batches served by the same GEMM form (here: 160 .. 320 token slots, all split over
+    K into the same number of planes; across the form boundaries — where the plane count changes: 640 / 832 / 1,344 / ... token
+    slots on this shape, x3_splitk_parts — and at 32,768 slots the K sums associate differently, <= 1.2e-7).  Round 3 found hipcc contracting `a * b + c` INTO the fp16 conversion of the
     (hi | lo) split (v_fma_mixlo_f16) on one epilogue path and not on another: the inputs of the split are opaque now."""
     for fused in ("2", "0"):
         monkeypatch.setenv("MVDB_GEMM_LN_FUSED", fused)
