@@ -386,6 +386,13 @@ int mvdb_encoder_walk_stats(const mvdb_encoder* enc, unsigned long long* aborts,
  * count, inside the paired launches of a forward; exported so that the rule is testable without a GPU. */
 int mvdb_encoder_gemm_tile_form(int64_t tokens, int n, int compute_units);
 
+/* Planes a SMALL batch's N = H GEMM (attention output projection, FFN2; on the wide shapes also QKV and FFN1) is split into over
+ * K (0: not split): a K-step of the GEMM is a latency step — one barrier and one DMA round trip — so while the 64 x 128 tiles of
+ * a batch leave CUs idle, K is cut into min(8, (k / 32) / 4, compute_units / tiles) planes (snapped to 2 / 3 / 4 / 6 / 8), summed in
+ * plane order by the LayerNorm / image kernel behind the GEMM.  The same rule on the host, from the padded token count; exported
+ * so that it is testable without a GPU (tests/test_encoder_tiles.py).  MVDB_GEMM_X3_SPLITK* environment switches: csrc/encoder.hip. */
+int mvdb_encoder_splitk_planes(int64_t tokens, int n, int k, int compute_units);
+
 #ifdef __cplusplus
 }
 #endif

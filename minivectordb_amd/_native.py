@@ -116,6 +116,7 @@ PROTOTYPES = {
                                            ctypes.POINTER(c_vp)]),
     "mvdb_encoder_free": (ctypes.c_int, [c_vp]),
     "mvdb_encoder_gemm_tile_form": (ctypes.c_int, [ctypes.c_int64, ctypes.c_int, ctypes.c_int]),
+    "mvdb_encoder_splitk_planes": (ctypes.c_int, [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "mvdb_index_single_route_suspensions": (ctypes.c_longlong, [c_vp]),
     "mvdb_encoder_walks": (ctypes.c_int, [c_vp, ctypes.c_int, ctypes.c_int]),
     "mvdb_encoder_walk_stats": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp]),
@@ -454,6 +455,11 @@ def half_eps(d):
 
 def half_max_queries(d):
     return int(lib().mvdb_half_max_queries(int(d)))
+
+
+def encoder_splitk_planes(tokens, n, k, compute_units=256):
+    """Planes a small batch's [tokens, n] = A [tokens, k] W^T GEMM of the encoder is split into over K (0: not split)."""
+    return int(lib().mvdb_encoder_splitk_planes(int(tokens), int(n), int(k), int(compute_units)))
 
 
 def encoder_gemm_tile_form(tokens, n, compute_units=256):

@@ -3689,6 +3689,11 @@ int mvdb_encoder_walks(const mvdb_encoder* e, int B, int S) {
     return e && B > 0 && S > 0 && walk_eligible(e, B, S) ? 1 : 0;
 }
 
+int mvdb_encoder_splitk_planes(int64_t tokens, int n, int k, int compute_units) {
+    if (tokens <= 0 || n <= 0 || k <= 0 || compute_units <= 0) return 0;
+    return x3_splitk_parts(tokens, n, k, compute_units);
+}
+
 int mvdb_encoder_gemm_tile_form(int64_t tokens, int n, int compute_units) {
     if (tokens <= 0 || n <= 0 || compute_units <= 0) return 0;
     const int bn = n % 256 == 0 ? 256 : n % 192 == 0 ? 192 : 0;

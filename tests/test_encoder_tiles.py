@@ -44,3 +44,34 @@ def test_tile_form_matches_restatement_on_a_grid():
     assert native.encoder_gemm_tile_form(0, 1024, 256) == 0
     assert native.encoder_gemm_tile_form(4096, 0, 256) == 0
     assert native.encoder_gemm_tile_form(4096, 1024, 0) == 0
+
+
+def _planes(tokens, n, k, cus):
+    """Restatement of encoder.hip: x3_splitk_parts (default switches)."""
+    tiles = ((tokens + 63) // 64) * ((n + 127) // 128)
+    parts = min(8, k // 32 // 4, cus // max(tiles, 1))
+    if parts < 2 or parts * tokens * n > cus * 64 * 128 + 64 * 1024:
+        return 0
+    return {5: 4, 7: 6}.get(parts, parts)
+
+
+@pytest.mark.parametrize("tokens,n,k,want", [
+    # one long sentence, e5-small shape (H 384, FFN 1536) on 256 CUs
+    (256, 384, 1536, 8),    # FFN2: 48 K-steps, 12 tiles
+    (256, 384, 384, 3),     # attention output projection: 12 K-steps -> three planes of four
+    (512, 384, 1536, 8), (1024, 384, 1536, 4), (2048, 384, 1536, 2), (8192, 384, 1536, 0),   # the 256 x 32 batch is not split
+    # bge-m3 / e5-large shape (H 1024, FFN 4096)
+    (129, 1024, 4096, 8), (256, 1024, 4096, 8), (384, 1024, 4096, 4), (512, 1024, 4096, 4),
+    (129, 3072, 1024, 3), (129, 4096, 1024, 2),   # QKV / FFN1 (the library uses them from three planes on)
+    (1024, 1024, 4096, 2), (2048, 1024, 4096, 0),
+])
+def test_splitk_planes_of_quoted_shapes(tokens, n, k, want):
+    assert native.encoder_splitk_planes(tokens, n, k, 256) == want == _planes(tokens, n, k, 256)
+
+
+def test_splitk_planes_match_restatement_on_a_grid():
+    for cus in (64, 256, 304):
+        for n, k in ((384, 384), (384, 1536), (1152, 384), (1536, 384), (1024, 1024), (1024, 4096), (3072, 1024), (4096, 1024), (768, 3072)):
+            for tokens in list(range(1, 3000, 97)) + [4096, 8192, 131072]:
+                assert native.encoder_splitk_planes(tokens, n, k, cus) == _planes(tokens, n, k, cus), (tokens, n, k, cus)
+    assert native.encoder_splitk_planes(0, 384, 384, 256) == 0
