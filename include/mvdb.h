@@ -344,8 +344,9 @@ int mvdb_encoder_free(mvdb_encoder* enc);
  * (h, l) the fp16 RNE split of an fp32 value — 22 significant bits —, weights scaled per tensor by a power of two,
  * fp32 accumulate; needs |activation| <= 65504; embeddings within 6e-7 of transformers' fp32 output like the exact
  * mode's; the two attention products run the same split, softmax / LayerNorm / pooling stay fp32) — what the Python
- * drop-in uses by default;
- * 1 = single bf16 product with fp32 accumulate (opt-in speed mode, ~1e-3). */
+ * drop-in uses by default.  (1, the single-bf16-product mode of earlier builds, was removed: MVDB_ERR_ARG.)
+ * Up to 128 token slots (64 on H > 384) the forward is ONE layer-walking launch in exact fp32 whatever `compute` says
+ * (mvdb_encoder_walks below). */
 int mvdb_encoder_forward(mvdb_encoder* enc, const int32_t* ids_host, const int32_t* mask_host,
                          int B, int S, int compute, float* out_host);
 int mvdb_encoder_forward_device(mvdb_encoder* enc, const int32_t* ids_dev, const int32_t* mask_dev,
