@@ -131,9 +131,12 @@ __device__ __forceinline__ void phase_arrive(unsigned int* bar, int ctr) {
 // A counter word with this bit set releases every waiter: the launch is being abandoned (Args::deadline).
 constexpr unsigned int kAbortBit = 0x80000000u;
 struct WaitCtx {
-    unsigned long long t0;  // s_memrealtime when this workgroup started
-    unsigned int deadline;  // ticks (100 MHz)
-    int* lds_abort;         // one word of LDS, 0 until a wait of this workgroup was released by kAbortBit
+    unsigned long long t0;    // s_memrealtime when this workgroup started
+    unsigned int deadline;    // ticks (100 MHz)
+    unsigned int check_mask;  // the clock is read on every failed poll whose count & check_mask == 0: 1023 in production (a wait
+                              // of a healthy launch fails a handful of polls and never reads it: reading it on every failed
+                              // poll cost 2 - 4 % of a forward), 0 for deadlines under 1 ms (tests)
+    int* lds_abort;           // one word of LDS, 0 until a wait of this workgroup was released by kAbortBit
 };
 __device__ __forceinline__ void raise_abort(unsigned int* bar) {
     for (int c = 0; c < kCtrExit; ++c)
@@ -143,14 +146,14 @@ __device__ __forceinline__ void raise_abort(unsigned int* bar) {
 
 // Wait until the `producers` workgroups of a phase have each arrived `epochs` times at counter `ctr`: one lane polls its
 // replica with L1-bypassing loads, the workgroup meets.  Returns true (to every thread) when the launch is being abandoned:
-// the caller leaves the phase chain.  The clock is read only after a poll that found the phase incomplete.
+// the caller leaves the phase chain.  The clock is read on every 1024th poll that found the phase incomplete (WaitCtx::check_mask).
 __device__ __forceinline__ bool phase_wait(unsigned int* bar, int ctr, unsigned int epochs, unsigned int producers, const WaitCtx& wc) {
     if (threadIdx.x == 0) {
         const unsigned int target = epochs * producers;
         const unsigned int* w = ctr_word(bar, ctr, blockIdx.x & (kReplicas - 1));
-        unsigned int v;
+        unsigned int v, spins = 0;
         while ((v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < target) {
-            if (__builtin_amdgcn_s_memrealtime() - wc.t0 > (unsigned long long)wc.deadline) {
+            if ((++spins & wc.check_mask) == 0 && __builtin_amdgcn_s_memrealtime() - wc.t0 > (unsigned long long)wc.deadline) {
                 raise_abort(bar);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the bits have landed before this workgroup can be counted out
                 v = kAbortBit;
@@ -442,7 +445,7 @@ __global__ __launch_bounds__(kThreads) void encoder_walk_kernel(const Args a) {
     float* red8 = lds + kLdsHead - 8;               // [8]
     int* s_abort = reinterpret_cast<int*>(lds + kLdsHead - 9);  // set when a wait of this workgroup was released by kAbortBit
     if (threadIdx.x == 0) *s_abort = 0;
-    const WaitCtx wc{__builtin_amdgcn_s_memrealtime(), a.deadline, s_abort};
+    const WaitCtx wc{__builtin_amdgcn_s_memrealtime(), a.deadline, a.deadline < 100000u ? 0u : 1023u, s_abort};
     float* work = lds + kLdsHead;                   // phase scratch (16-byte aligned)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wg = blockIdx.x, G = gridDim.x;
