@@ -82,15 +82,16 @@ def test_split_precision_kernel_variants_match_golden(i, switches, gpu, monkeypa
 
 @pytest.mark.parametrize("env", [{"MVDB_GEMM_X3_BIG": "1"}, {"MVDB_GEMM_X3_BIG": "1", "MVDB_GEMM_X3_PERSIST": "0"},
                                  {"MVDB_GEMM_X3_SPREAD": "0", "MVDB_GEMM_X3_SPREAD_SMALL": "0", "MVDB_GEMM_LN_SPREAD": "0"},
-                                 {"MVDB_GEMM_X3_SPLITK": "0"}],
+                                 {"MVDB_GEMM_X3_SPLITK": "0"}, {"MVDB_GEMM_X3_SPLITK_PARTS": "3", "MVDB_GEMM_X3_SPLITK_WIDE": "0"}],
                          ids=["persistent-256-row-tiles-forced", "one-tile-per-workgroup-256-row-tiles-forced", "dma-burst",
-                              "ffn2-unsplit-at-small-batches"])
+                              "ffn2-unsplit-at-small-batches", "three-split-k-planes-as-in-round-5"])
 def test_gemm_tile_forms_match_golden_in_a_fresh_process(env, gpu):
     """The tile-form switches of the split-precision GEMMs are read once per process: a child pytest runs every split-mode
     golden case with (a) the persistent 256-row kernel FORCED onto batches it would never be chosen for (fewer tiles than
     CUs, a last row band of a few rows), (b) its one-tile-per-workgroup predecessor, (c) the LDS-DMA instructions issued as
     one burst per K-step instead of between the MFMAs, (d) FFN2 unsplit at small batches (round 4: by default it runs split
-    over K there — which every golden case of the parent process exercises)."""
+    over K there — which every golden case of the parent process exercises), (e) round 5's split-K rule (three planes, QKV /
+    FFN1 of the wide shapes unsplit) beside round 6's (as many planes as leave each four K-steps: the parent process)."""
     import os
     import subprocess
     import sys
