@@ -236,6 +236,16 @@ def test_walk_abandoned_by_its_deadline_falls_back_to_the_per_op_kernels(gpu, mo
     np.testing.assert_allclose(out.cpu().numpy(), e64, atol=2e-5, rtol=0)
     enc.close()
     enc2.close()
+    # the same on a GOLDEN case (transformers' own BertModel output, tests/golden/encoder_golden.npz: 4 x 32 = 128 token slots):
+    # the abandoned launch's fallback returns the golden embeddings
+    from encoder_cases import load_cases
+    gc = next(c for c in load_cases() if c["name"] == "e5-small-dims" and c["B"] * c["S"] == 128)
+    gcfg = E.make_config(gc["name"])
+    enc4 = _model(gcfg, E.make_weights(gcfg, gc["wseed"]))
+    assert enc4.walks(gc["B"], gc["S"])
+    np.testing.assert_allclose(enc4.forward(gc["ids"], gc["mask"]), gc["emb"], atol=2e-5, rtol=0)
+    assert enc4.walk_stats()["aborts"] == 1 and enc4.walk_stats()["fallbacks"] == 1
+    enc4.close()
     # with the default deadline nothing is abandoned and the walker is back after the suspension
     monkeypatch.delenv("MVDB_WALK_DEADLINE_US")
     enc3 = _model(cfg, w)
