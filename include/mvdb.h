@@ -345,7 +345,7 @@ int mvdb_encoder_free(mvdb_encoder* enc);
  * fp32 accumulate; needs |activation| <= 65504; embeddings within 6e-7 of transformers' fp32 output like the exact
  * mode's; the two attention products run the same split, softmax / LayerNorm / pooling stay fp32) — what the Python
  * drop-in uses by default.  (1, the single-bf16-product mode of earlier builds, was removed: MVDB_ERR_ARG.)
- * Up to 128 token slots (64 on H > 384) the forward is ONE layer-walking launch in exact fp32 whatever `compute` says
+ * Up to 64 token slots the forward is ONE layer-walking launch in exact fp32 whatever `compute` says
  * (mvdb_encoder_walks below). */
 int mvdb_encoder_forward(mvdb_encoder* enc, const int32_t* ids_host, const int32_t* mask_host,
                          int B, int S, int compute, float* out_host);
@@ -360,11 +360,12 @@ int mvdb_encoder_forward_device(mvdb_encoder* enc, const int32_t* ids_dev, const
  * which is what mvdb_encoder_forward's Python wrapper does on the host path.  Valid until mvdb_encoder_free. */
 const unsigned int* mvdb_encoder_overflow_flag(const mvdb_encoder* enc);
 
-/* 1 when a forward of B x S token slots is of the shape the ONE layer-walking launch serves (csrc/encoder_walk.hpp: at most 128
- * token slots — one sentence per call is the reference's only shape, embedding_model.py:62-71 —, exact fp32 matrix cores
- * whatever `compute` says), 0 when it runs the per-op kernels.  MVDB_ENCODER_WALK=0 (read at mvdb_encoder_create) switches the
- * launch off.  A forward of that shape still takes the per-op kernels when the caller is CAPTURING the stream, while another
- * process holds the GPU's walking gate, and for a while after a launch was abandoned (next paragraph). */
+/* 1 when a forward of B x S token slots is of the shape the ONE layer-walking launch serves (csrc/encoder_walk.hpp: at most 64
+ * token slots — one sentence per call is the reference's only shape, embedding_model.py:62-71; beyond 64 slots the per-op kernels
+ * are faster since round 6 —, exact fp32 matrix cores whatever `compute` says), 0 when it runs the per-op kernels.
+ * MVDB_ENCODER_WALK=0 (read at mvdb_encoder_create) switches the launch off.  A forward of that shape still takes the per-op
+ * kernels when the caller is CAPTURING the stream, while another process holds the GPU's walking gate, and for a while after a
+ * launch was abandoned (next paragraph). */
 int mvdb_encoder_walks(const mvdb_encoder* enc, int B, int S);
 
 /* The walking launch is a persistent grid whose workgroups wait for each other, so it completes only when all of them are

@@ -2764,6 +2764,18 @@ int launch_gemm_x3(const float* Aimg, const _Float16* Wp, float inv_wscale, cons
         hipLaunchKernelGGL(kern8, grid8, dim3(512), lds8, s, A, Wp, inv_wscale, bias, R, C, Tptr, N, K, sel_bn, cus, qcols, qscale);
         return 0;
     }
+    // Few tiles (one long sentence, a handful of short ones): 64 x 64 tiles, twice the workgroups — a K-step of a 64 x 128 tile is
+    // 12 MFMAs per wave (~0.33 us), and with a quarter of the CUs busy that, not the memory system, is what the GEMM takes
+    static const bool bn64 = []() { const char* v = getenv("MVDB_GEMM_X3_BN64"); return !(v && *v == '0'); }();
+    // (one workgroup per CU at most; up to 1.5 / 2 per CU measured: +-2 %, benchmarks/mid_batch_probe.py)
+    if (bn64 && sel_bn == 0 && N % 64 == 0 && (int64_t)grid.x * grid.y * 2 <= cus) {
+        auto kern64 = X3_KERN(EPI, 64, 3, 4, 64, 1);
+        constexpr int lds64 = 3 * (64 * 128 + 64 * 128);
+        MVDB_TRY(x3_set_lds((const void*)kern64, lds64, device));
+        dim3 grid64(N / 64, (unsigned)((Tmax + 63) / 64));
+        hipLaunchKernelGGL(kern64, grid64, dim3(256), lds64, s, A, Wp, inv_wscale, bias, R, C, Tptr, N, K, 0, cus, qcols, qscale);
+        return 0;
+    }
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, A, Wp, inv_wscale, bias, R, C, Tptr, N, K, sel_bn, cus, qcols, qscale);
     return 0;
 }
@@ -3082,10 +3094,13 @@ struct WalkTurn {
 };
 
 // ---- the layer-walking launch for small batches (encoder_walk.hpp) ------------------------------------------------------
-// Eligible: at most walk::kTmax token slots — 64 on the wide shapes (H > 384: e5-large / bge-m3), where the per-op kernels
-// win from 65 slots on (one sentence, host in / host out: 2.17 / 2.24 ms at 96 / 128 tokens against the walking launch's
-// 2.21 / 2.38; profiles/r06_long_sentence_chain.txt) —, widths the column units tile (H, F multiples of 16, H <= 1024).
-int walk_max_slots(const mvdb_encoder_cfg& c) { return c.hidden > 384 ? 64 : walk::kTmax; }
+// Eligible: at most kWalkSlots = 64 token slots (the kernel itself serves walk::kTmax = 128: row groups of 32) — beyond, the per-op
+// kernels win since round 6 gave them split-K planes and 64 x 64 tiles for small batches: one sentence, host in / host out,
+// e5-small shape 96 / 128 tokens 0.49 / 0.51 ms against the walking launch's 0.53 / 0.56 (64 tokens: 0.47 against 0.38); wide
+// shapes 96 / 128 tokens 1.57 / 1.83 against 2.21 / 2.38 (profiles/r06_long_sentence_chain.txt) —, widths the column units tile
+// (H, F multiples of 16, H <= 1024).
+constexpr int kWalkSlots = 64;
+int walk_max_slots(const mvdb_encoder_cfg&) { return kWalkSlots; }
 bool walk_eligible(const mvdb_encoder* e, int B, int S) {
     const mvdb_encoder_cfg& c = e->cfg;
     return e->opt_walk && (int64_t)B * S <= walk_max_slots(c) && c.hidden % 16 == 0 && c.intermediate % 16 == 0 && c.hidden <= 1024;
@@ -3218,8 +3233,8 @@ int launch_walk(mvdb_encoder* e, const int32_t* ids, const int32_t* mask, int B,
 #endif
     const size_t lds = walk::lds_bytes(mt, rh, c.hidden, a.hd);
 #define MVDB_WALK_CASE(M, C, R) if (mt == M && hc == C && rh == R) return launch_walk_inst<M, C, R>(e, a, lds, grid, s)
-    MVDB_WALK_CASE(1, 1, 1); MVDB_WALK_CASE(2, 1, 1); MVDB_WALK_CASE(2, 1, 2); MVDB_WALK_CASE(2, 1, 4);
-    MVDB_WALK_CASE(1, 3, 1); MVDB_WALK_CASE(2, 3, 1); MVDB_WALK_CASE(2, 3, 2); MVDB_WALK_CASE(2, 3, 4);
+    MVDB_WALK_CASE(1, 1, 1); MVDB_WALK_CASE(2, 1, 1); MVDB_WALK_CASE(2, 1, 2);
+    MVDB_WALK_CASE(1, 3, 1); MVDB_WALK_CASE(2, 3, 1); MVDB_WALK_CASE(2, 3, 2);
     MVDB_WALK_CASE(1, 8, 1); MVDB_WALK_CASE(2, 8, 1); MVDB_WALK_CASE(4, 8, 1);
 #undef MVDB_WALK_CASE
     return fail(MVDB_ERR_ARG, "no walker instantiation for this shape");

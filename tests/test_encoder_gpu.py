@@ -117,13 +117,13 @@ def test_batch_composition_does_not_change_a_row(gpu, monkeypatch):
         ref = enc.forward(ids, mask)
         for nb in (4, 5, 7):
             assert np.array_equal(enc.forward(ids[:nb], mask[:nb]), ref[:nb]), (fused, nb)
-        # batches of <= 128 token slots run the layer-walking launch (exact fp32, its own summation order): another form
+        # batches of <= 64 token slots run the layer-walking launch (exact fp32, its own summation order): another form
         # boundary, rounding-level agreement — and bit-for-bit agreement among themselves (tests/test_encoder_walk_gpu.py)
-        assert enc.walks(1, 40) and enc.walks(3, 40) and not enc.walks(4, 40)
+        assert enc.walks(1, 40) and not enc.walks(2, 40)
         one = enc.forward(ids[:1], mask[:1])
-        three = enc.forward(ids[:3], mask[:3])
+        np.testing.assert_allclose(one, ref[:1], atol=5e-7, rtol=0)
+        three = enc.forward(ids[:3], mask[:3])      # (120 slots: the per-op kernels, another plane count than 160+ slots)
         np.testing.assert_allclose(three, ref[:3], atol=5e-7, rtol=0)
-        assert np.array_equal(one, three[:1])
         enc.close()
 
 
