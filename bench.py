@@ -78,7 +78,7 @@ def pmc_traffic(n, d, nq=1, scan_name=None, launched=""):
     best, refused = None, None
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")))
     files.sort(key=lambda f: f"nq{nq}_" in os.path.basename(f))  # the pass profiled at this nq wins
-    batch = any(t in launched for t in ("split", "half", "hq", "h16"))
+    batch = "h16" in launched
     elem = 2.0 if launched.startswith("flat_scan_h16_kernel") else 4.0  # the h16 pass streams the fp16 shadow of the rows
     for f in files:
         try:
@@ -685,7 +685,7 @@ def main():
     n, d, k, nq = args.rows, args.dim, args.k, args.nq
     W, K = args.warmup, args.steps
     # dominant kernel by batch size: GEMV scan (nq = 1), 16/32-query MFMA pass, 128-query GEMM-tiled scan
-    scan_names = ("ip_scan", "ip_scan_mfma", "ip_scan_gemm", "ip_scan_split", "ip_scan_split32", "ip_scan_half")
+    scan_names = ("ip_scan", "ip_scan_mfma", "ip_scan_gemm", "ip_scan_half")
     idx = native.FlatIndex(d, device=local_rank)
     idx.reserve(n)
     idx.add_synthetic(n, 1234, first_row=rank * n, normalize=True)
@@ -776,8 +776,8 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     native.prof_enable(False)
-    # dominant kernel by batch size: GEMV scan (nq = 1), 16-query fp32-MFMA pass, 32- / 128-query split-precision
-    # bf16 passes (k <= 12) or their exact fp32 fallbacks — whichever took the most time in the timed region
+    # dominant kernel by batch size: GEMV scan (nq = 1), fp32-MFMA pass, the certified pass over the fp16 shadow, the
+    # GEMM-tiled exact scan — whichever took the most time in the timed region
     prof = {name: native.prof_read(name) for name in scan_names}
     scan_name = max(prof, key=lambda name: prof[name][1])
     launches, scan_ms = prof[scan_name]
@@ -815,11 +815,6 @@ def main():
         bytes_per_launch = n * d * 4  # algorithmic: every stored row of this rank's shard once
         cus = torch.cuda.get_device_properties(dev).multi_processor_count
         chunk = 128  # queries per corpus pass of the batch passes
-        if scan_name in ("ip_scan_split", "ip_scan_split32"):
-            # the seed launch (first 128-row tile of every CU, timed separately as ip_scan_split_seed) takes
-            # its rows out of the main launch when the corpus has >= 8 tiles per CU
-            if (n + 127) // 128 >= 8 * cus:
-                bytes_per_launch = (n - cus * 128) * d * 4
         if scan_name == "ip_scan_half":
             # fp16 nomination pass: the seed launch (ip_scan_half_seed) covers the first 32-row tile of every CU
             chunk = native.half_max_queries(d)
@@ -828,8 +823,8 @@ def main():
             shadow = native.prof_symbol(scan_name).startswith("flat_scan_h16_kernel")
             bytes_per_launch = (n - min((n + 31) // 32, cus) * 32) * d * (2 if shadow else 4)
         passes = K * ((nq + chunk - 1) // chunk)
-        if scan_name in ("ip_scan_split", "ip_scan_split32", "ip_scan_half"):
-            # one corpus pass = the seed launch + up to three main launches of growing size (phases, admission floors
+        if scan_name == "ip_scan_half":
+            # one corpus pass = the seed launch + up to four main launches of growing size (phases, admission floors
             # refreshed in between): the per-launch figures below are averages over those launches
             bytes_per_launch = bytes_per_launch * passes / max(launches, 1)
         avg_ms = scan_ms / max(launches, 1)
@@ -846,8 +841,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": ("f32 (fp16 single-product nomination, f32 re-score + certificate)" if scan_name == "ip_scan_half" else
-                      "f32 (bf16 split-precision nomination, f32 re-score + certificate)" if scan_name.startswith("ip_scan_split") else "f32"),
+            "dtype": "f32 (fp16 single-product nomination, f32 re-score + certificate)" if scan_name == "ip_scan_half" else "f32",
             "data": "synthetic",
             "config": {
                 "workload": (f"{world * n} x {d} fp32 corpus ({n} rows resident per GPU), IP, k={k}, "
@@ -886,10 +880,8 @@ def main():
                 "traffic_note": ("HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (FETCH_SIZE x 2 per "
                                  "the guide + WRITE_SIZE) — not a counter of this run: counters cannot be collected inside the timed process"),
                 "launched": launched,
-                "kernel": {"ip_scan": "flat_scan_kernel", "ip_scan_mfma": "flat_scan_mfma2_kernel",
-                           "ip_scan_split": "flat_scan_split_kernel",
-                           "ip_scan_split32": "flat_scan_split32_kernel",
-                           "ip_scan_half": (launched.split("<")[0] or "flat_scan_half_kernel")}[scan_name],
+                "kernel": {"ip_scan": "flat_scan_kernel", "ip_scan_mfma": "flat_scan_mfma2_kernel", "ip_scan_gemm": "flat_scan_gemm_kernel",
+                           "ip_scan_half": (launched.split("<")[0] or "flat_scan_h16_kernel")}[scan_name],
                 "operand": ("fp16 shadow of the corpus (2 B per element; the fp32 matrix stays resident beside it)"
                             if launched.startswith("flat_scan_h16_kernel") else "fp32 corpus (4 B per element)"),
                 "launches": launches,

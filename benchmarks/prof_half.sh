@@ -1,4 +1,4 @@
-# PMC passes over flat_scan_half_kernel (bench.py --nq N --dim D): per corpus pass sums of the main launches.
+# PMC passes over the certified pass's main launches, flat_scan_h16_kernel (bench.py --nq N --dim D): per corpus pass sums.
 # usage (GPU box): bash benchmarks/prof_half.sh "128 256" 512 [tag]
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
@@ -28,7 +28,7 @@ f = glob.glob("/tmp/hpmc_${nq}_${tag}/**/*_counter_collection.csv", recursive=Tr
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for fn in f:
     for r in csv.DictReader(open(fn)):
-        if ("flat_scan_half_kernel" in r["Kernel_Name"] and ("false>" in r["Kernel_Name"] or "Lb0E" in r["Kernel_Name"])) or "flat_scan_hq_kernel" in r["Kernel_Name"]:
+        if "flat_scan_h16_kernel" in r["Kernel_Name"]:
             agg["main"][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, c in agg.items():
     # launches: (warmup + steps + latency loop) passes x 3 phases; report the sum per corpus pass

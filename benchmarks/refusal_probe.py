@@ -14,7 +14,7 @@ stream = torch.cuda.current_stream().cuda_stream
 native.check(native.lib().mvdb_synth_fill_device(q.data_ptr(), nq, d, 5678 | fam, 0, 1, 0, stream))
 D = torch.empty((nq, k), dtype=torch.float32, device=dev)
 I = torch.empty((nq, k), dtype=torch.int64, device=dev)
-FAM = ("ip_scan", "ip_scan_mfma", "ip_scan_gemm", "ip_scan_half", "ip_scan_half_seed", "ip_scan_split", "ip_scan_split32")
+FAM = ("ip_scan", "ip_scan_mfma", "ip_scan_gemm", "ip_scan_half", "ip_scan_half_seed", "ip_scan_rescue", "ip_scan_rerun")
 def run(a, m):
     idx.search_device(q[a:a+m].data_ptr(), m, k, D[a:a+m].data_ptr(), I[a:a+m].data_ptr(), stream=stream)
 run(0, 32); torch.cuda.synchronize()

@@ -7,8 +7,8 @@ from minivectordb_amd import _native as native
 dev = torch.device("cuda", 0)
 d, k = 512, 10
 fam = 2 << 56
-FAM = ("ip_scan", "ip_scan_scores", "ip_scan_mfma", "ip_scan_mfma_masked", "ip_scan_gemm", "ip_scan_half", "ip_scan_half_seed", "ip_scan_split",
-       "ip_scan_split32", "ip_scan_split_seed", "ip_scan_rescue", "ip_scan_rerun")
+FAM = ("ip_scan", "ip_scan_scores", "ip_scan_mfma", "ip_scan_mfma_masked", "ip_scan_gemm", "ip_scan_half", "ip_scan_half_seed", "ip_scan_rescue",
+       "ip_scan_rerun")
 for n in (1_000_000, 10_000_000):
     idx = native.FlatIndex(d)
     idx.reserve(n)

@@ -332,9 +332,9 @@ __global__ __launch_bounds__(256) void flat_scan_seed_kernel(HalfScanArgs a) {
 }
 
 // ---- the same pass over the fp16 SHADOW of the corpus (round 4) -------------------------------------------------------
-// flat_scan_hq_kernel reads fp32 rows and converts every 32-row tile to fp16 on its way to the matrix cores: for a
+// (The forms of rounds 3 - 5 read fp32 rows and converted every 32-row tile to fp16 on its way to the matrix cores: for a
 // nomination pass that is twice the bytes the arithmetic needs, plus a raw staging ring, the conversion's VALU work and a
-// second LDS round trip per element.  An index that answers batches keeps — lazily, from its first 33+-query search on — an
+// second LDS round trip per element; retired in round 6.)  An index that answers batches keeps — lazily, from its first batch search on — an
 // fp16 copy of its rows, Xh[n][d] = fp16(s_x x) (mvdb.hip: shadow; exactly the values the conversion produces, so the
 // certificate and its bound are unchanged; 2 bytes per element on top of the 4 of the fp32 matrix, which stays the home of
 // the exact scans and of the re-scores).  This kernel streams THAT:
@@ -343,8 +343,9 @@ __global__ __launch_bounds__(256) void flat_scan_seed_kernel(HalfScanArgs a) {
 //     so the bank swizzle (16-byte slot p of row r holds the row's logical slot p ^ (r & 15), inside aligned groups of 16
 //     slots: conflict-free b128 fragment reads for any multiple of 16 slots per row) is applied to the per-lane SOURCE address;
 //   * NST stages in flight per workgroup (each wave issues its share and waits for its own with a counted vmcnt; one bare
-//     s_barrier per stage), the queries' fragments in registers for the whole launch as in flat_scan_hq_kernel;
-//   * gate, lists, bitmap: flat_scan_hq_kernel's.
+//     s_barrier per stage), the queries' fragments in registers for the whole launch;
+//   * gate: a threshold register per query (the larger of the list's 16th score and the admission floor), lists of 16 keys per
+//     (wave, query) in LDS with wave-cooperative sorted inserts, the row bitmap looked at on the slow path only.
 // ALGORITHMIC bytes per launch = rows scanned x d x 2 (the pass's operand is the shadow).  At 256 queries per pass and d = 512
 // the matrix cores bound (2 x 32 MFMAs per SIMD and tile = 2,048 cycles against ~2,400 for the tile's 32 KiB at the HBM
 // rate ... at a clock the chip lowers under this load); at 128 queries HBM bounds.
@@ -378,7 +379,7 @@ __global__ __launch_bounds__(WV * 64) void flat_scan_h16_kernel(HalfScanArgs a) 
     float thr = floor0;
     uint32_t thr_row = 0u;
     float inv = a.qinv[myq];
-    // consume every global load here (see flat_scan_half_kernel)
+    // consume every global load here: the hand-placed vmcnt waits below are invisible to hipcc (see flat_scan_seed_kernel)
 #pragma unroll
     for (int kb = 0; kb < KT; ++kb) asm volatile("" : "+v"(Q[kb]));
     asm volatile("" : "+v"(floor0), "+v"(thr), "+v"(inv));
@@ -515,7 +516,7 @@ __global__ __launch_bounds__(WV * 64) void flat_scan_h16_kernel(HalfScanArgs a) 
 }
 
 // fp32 rows -> the shadow: Xh[r][c] = fp16(s_x X[r][c]) (RNE; s_x a power of two: the product is exact) — the values
-// flat_scan_hq_kernel's conversion produces
+// the on-the-fly conversion of rounds 3 - 5 produced
 __global__ __launch_bounds__(256) void half_shadow_kernel(const float* __restrict__ X, int64_t ld, int d, int64_t n, float xscale,
                                                           _Float16* __restrict__ Xh) {
     const int64_t total = n * (int64_t)(d / 4);
