@@ -389,3 +389,42 @@ def test_walk_shape_under_stream_capture_takes_the_capturable_kernels(gpu):
     assert enc.walk_stats()["aborts"] == 0 and other.walk_stats()["aborts"] == 0
     enc.close()
     other.close()
+
+
+@pytest.mark.parametrize("deadline_us", [None, 1000, 200])
+def test_walk_under_cu_pressure_from_another_stream_never_hangs(gpu, monkeypatch, deadline_us):
+    """The walking launch needs all of its workgroups resident.  Here a foreign stream keeps every CU busy with large GEMMs
+    (torch.mm, ~10 ms each, queued back to back) while sentences are embedded one per call: whether the launch gets its CUs in
+    time or its bounded waits abandon it and the per-op kernels answer, every call returns the right embedding — and returns.
+    With the deadline cut to 1 ms / 0.2 ms the waits do run out in the middle of a forward, at whatever phase the starved
+    workgroups have reached (the deadline-0 test above abandons at the very first wait only)."""
+    import time
+    import torch
+    if deadline_us is not None:
+        monkeypatch.setenv("MVDB_WALK_DEADLINE_US", str(deadline_us))
+    dev = torch.device("cuda", 0)
+    cfg = E.make_config("e5-small-dims")
+    w = E.make_weights(cfg, 91)
+    enc = _model(cfg, w)
+    ids, mask = E.make_inputs(cfg, 1, 48, 92)
+    _, e64 = E.numpy_forward(cfg, w, ids, mask)
+    a = torch.randn((8192, 8192), device=dev)
+    b = torch.randn((8192, 8192), device=dev)
+    side = torch.cuda.Stream(dev)
+    enc.forward(ids, mask)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    lat = []
+    for rep in range(12):
+        with torch.cuda.stream(side):
+            for _ in range(4):
+                torch.mm(a, b)             # ~40 ms of every CU on the other stream
+        t1 = time.perf_counter()
+        got = enc.forward(ids, mask)
+        lat.append(time.perf_counter() - t1)
+        np.testing.assert_allclose(got, e64, atol=2e-5, rtol=0)
+    torch.cuda.synchronize()
+    st = enc.walk_stats()
+    print(f"under CU pressure (deadline {deadline_us or 20000} us): 12 forwards in {time.perf_counter() - t0:.2f} s, slowest {max(lat) * 1e3:.1f} ms, walker stats {st}")
+    assert max(lat) < 5.0
+    enc.close()
