@@ -82,7 +82,7 @@ def main():
                           "tokens": int(lens.sum()), "encoder_ms": round(t_enc * 1e3, 3),
                           "knn_ms": round((t_all - t_enc) * 1e3, 3), "end_to_end_ms": round(t_all * 1e3, 3),
                           "sentences_per_s": round(B / t_all, 1),
-                          # 128 queries per corpus pass on the split-precision bf16 kernel (k <= 12)
+                          # up to 256 queries per corpus pass on the certified fp16 pass (k <= 12)
                           "encoder_compute": {0: "fp32", 2: "fp16x3"}[enc.default_compute],
                           "knn_corpus_passes": -(-B // max(native.half_max_queries(H), 128)),
                           "knn_GBps": round(-(-B // max(native.half_max_queries(H), 128)) * n * H * 4 / (t_all - t_enc) / 1e9, 1)}), flush=True)

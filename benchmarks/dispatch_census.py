@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Which kernel generation answers which call: a grid of (rows, width, queries per call, k, metric, filter) through the
 product's own dispatcher with the library's profiling hooks on, launches counted per kernel family (mvdb_prof_read).
-Round 4's review asked what still reaches the bf16-split kernels (scan_split_kernels.hpp) and the fp16 nomination over
-fp32 rows (flat_scan_half / hq) now that batches of 2+ queries stream the fp16 shadow.  One JSON line."""
+Round 4's review asked what still reached the bf16-split kernels and the fp16 nomination over fp32 rows once batches of
+2+ queries streamed the fp16 shadow; both were retired in round 6 on this census (profiles/r06_dispatch_census.json).  One JSON line."""
 import json
 import os
 import sys

@@ -1,6 +1,6 @@
 """Whole-corpus-on-one-GPU check (BASELINE config 4's 80M x 512 fits one MI355X's 288 GB): plant a scaled copy of
 each query far into the corpus, then require it back first from the single-query scan and from the batch passes
-(split-precision bf16 for >= 40 queries, fp32 MFMA below), with scores equal to the float64 dot products of the rows
+(the certified fp16 pass over the shadow from 2 queries), with scores equal to the float64 dot products of the rows
 fetched back.  usage: scale_check.py [rows] [dim] [nq]"""
 import sys, os, json, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

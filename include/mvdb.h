@@ -292,7 +292,8 @@ int mvdb_synth_fill_device(float* out_dev, int64_t n, int d, uint64_t seed, int6
 /* ---- profiling hooks (bench.py's roofline leg) ---------------------------------------------
  * When enabled, every launch of the dominant kernels is bracketed by hipEvents on the launch
  * stream.  mvdb_prof_read drains the finished pairs of kernel `name` ("ip_scan", "ip_scan_mfma",
- * "ip_scan_gemm", "ip_scan_split", "encoder") and returns the number of launches and their summed duration. */
+ * "ip_scan_gemm", "ip_scan_half", "ip_scan_half_seed", "ip_scan_rescue", "ip_scan_rerun", "ip_scan_scores",
+ * "encoder") and returns the number of launches and their summed duration. */
 int mvdb_prof_enable(int on);
 int mvdb_prof_read(const char* name, int64_t* launches, double* total_ms);
 /* The kernel instantiation last launched under label `name` while profiling was on, as rocprofv3 prints it

@@ -778,7 +778,7 @@ bool l2_offsets_ok(const mvdb_index* idx, int nq, int64_t n) {
 // (seed launch, phase merges, certification: ~0.1 ms).  Measured, device time per call, default / certified
 // (profiles/r04_small_batch_crossover.jsonl): 10M x 512: 2 queries 2.93 / 1.61 ms, 32 queries 3.06 / 1.63; 1M rows: 2 queries
 // 0.33 / 0.26, 13 queries 0.44 / 0.27; 100k rows: 2 queries 0.068 / 0.114, 8 queries 0.123 / 0.122, 13 queries 0.170 / 0.126.
-// Elsewhere: 33 (and the bf16-split pass from 14).  MVDB_SPLIT_SCAN_MIN_NQ overrides.
+// MVDB_SPLIT_SCAN_MIN_NQ overrides (the name dates from the retired split-precision passes).
 thread_local bool tls_single_suspended = false;  // decided once per search (search_core), read by every routing question of that call
 constexpr int kSingleWindow = 32, kSingleSuspend = 512;
 // One decision per single-query search that asks for the shadow route: true = this call takes the exact scan.
