@@ -129,8 +129,10 @@ int mvdb_index_get_rows(const mvdb_index* idx, int64_t row0, int64_t n, float* o
 
 /* Remove the given rows (ascending or not, duplicates rejected) and compact the matrix so the
  * remaining rows keep their relative order — the numbering np.delete leaves behind.  Rows before
- * the first deleted one do not move; the tail is compacted in place through a bounded staging
- * buffer (512 MiB, kept by the index), so the call needs no memory proportional to the index.
+ * the first deleted one do not move.  One row (the reference's own delete), a run of rows or up to 8
+ * scattered rows: the tail is shifted in place in ONE pass, every byte read once and written once
+ * (row 5 of 10M x 512: 8.2 ms).  More: the tail is compacted in place through a bounded staging buffer
+ * (512 MiB, kept by the index; 14.5 - 18 ms there).  Neither needs memory proportional to the index.
  *                                                minivectordb/vector_database.py:126, :139-152 */
 int mvdb_index_remove_rows(mvdb_index* idx, const int64_t* rows_host, int64_t m);
 

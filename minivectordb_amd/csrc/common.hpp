@@ -79,6 +79,7 @@ struct Knobs {
          disable_half_shadow = false;  // MVDB_DISABLE_HALF_SHADOW (index option half_shadow = 0): no fp16 shadow, batches on the exact fp32 passes
     bool shadow_single_query = false;  // MVDB_SHADOW_SINGLE_QUERY (1: single queries through the certified fp16-shadow pass too)
     long long compact_bytes = 512ll << 20;  // MVDB_COMPACT_BYTES: staging buffer of a row compaction (mvdb_index_remove_rows)
+    bool compact_inplace = true;            // MVDB_COMPACT_INPLACE (0: a few deleted rows take the staging path too)
 };
 Knobs read_knobs();
 

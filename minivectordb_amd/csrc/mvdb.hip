@@ -62,6 +62,7 @@ Knobs read_knobs() {
     k.shadow_single_query = env_int("MVDB_SHADOW_SINGLE_QUERY", 0) != 0;
     if (const char* v = getenv("MVDB_COMPACT_BYTES"))
         if (*v) k.compact_bytes = std::max(1ll, atoll(v));
+    k.compact_inplace = env_int("MVDB_COMPACT_INPLACE", 1) != 0;
     return k;
 }
 
@@ -1022,6 +1023,8 @@ __global__ __launch_bounds__(256) void mask_rank_kernel(int64_t* __restrict__ I,
 }
 
 constexpr int kCoreTile = 1024;      // queries search_core answers per pass over its workspace
+constexpr int64_t kShiftMaxRows = 8;           // most scattered deleted rows of a call the one-pass compaction takes (a run of any length qualifies)
+constexpr size_t kShiftSideBytes = 64u << 20;   // ... and the most its side copies may occupy
 constexpr int kGatedPassGroup = 8;   // exact re-run passes (of 16 / 32 compact queries) one gated launch walks: one list buffer of that many
 int search_core(const mvdb_index* idx, Workspace* ws, const float* q_dev, int nq, int k,
                 int normalize_q, const int64_t* rows_dev, int64_t m, int64_t label_offset,
@@ -2083,6 +2086,64 @@ int mvdb_index_remove_rows(mvdb_index* idx, const int64_t* rows_host, int64_t m)
     // needed another 164 GB.)  The source row of a new row is found by binary search in the sorted list of deleted rows.
     const int64_t first = del[0];
     const int64_t tail_new = n_new - first;
+    // A handful of rows (the reference deletes ONE per call, vector_database.py:119): the tail is shifted in place in one pass —
+    // every byte read once and written once — with a side copy of m rows per workgroup boundary (util_kernels.hpp:
+    // shift_rows_kernel); delete of an early row of 10M x 512: 14.5 -> 8.2 ms (profiles/r06_delete_probe.jsonl).  MVDB_COMPACT_INPLACE=0: always the staging path.
+    if (tail_new > 0 && idx->kn.compact_inplace && (m <= kShiftMaxRows || del[m - 1] - del[0] == m - 1)) {
+        const bool run = del[m - 1] - del[0] == m - 1;
+        const int64_t rowunits = idx->ld / 4;  // 16-byte units per row (ld is a multiple of 4 floats)
+        const int64_t new_units = tail_new * rowunits, old_units = (idx->n - first) * rowunits;
+        const int64_t slice = 256 * kShiftUnits;
+        const int64_t side_units = m * rowunits;
+        const int64_t cus = device_cus(idx->device);
+        // eight workgroups per CU; fewer (down to two) where the side copies of that many boundaries would outgrow their bound
+        int64_t groups = std::min<int64_t>(cus * 8, (new_units + slice - 1) / slice);
+        const int64_t fit = (int64_t)(kShiftSideBytes / ((size_t)side_units * 16)) + 1;
+        const bool fits = fit >= std::min<int64_t>(groups, cus * 2);
+        groups = std::min(groups, fit);
+        const int64_t range = ((new_units + groups - 1) / groups + slice - 1) / slice * slice;
+        groups = (new_units + range - 1) / range;
+        const size_t side_bytes = (size_t)std::max<int64_t>(groups - 1, 1) * side_units * 16;
+        if (fits && side_bytes <= kShiftSideBytes) {
+            if (idx->ctmp_bytes < side_bytes) {
+                if (idx->ctmp) (void)hipFree(idx->ctmp);
+                idx->ctmp = nullptr;
+                idx->ctmp_bytes = 0;
+                if (hipMalloc((void**)&idx->ctmp, side_bytes) != hipSuccess) {
+                    (void)hipGetLastError();
+                    return fail(MVDB_ERR_OOM, "device allocation for row compaction failed (%zu bytes)", side_bytes);
+                }
+                idx->ctmp_bytes = side_bytes;
+            }
+            int64_t* del_dev = nullptr;
+            hipError_t e = hipSuccess;
+            if (!run) {
+                MVDB_HIP(hipMallocAsync((void**)&del_dev, (size_t)m * sizeof(int64_t), idx->mut));
+                for (auto& v : del) v -= first;  // positions relative to the tail
+                e = hipMemcpyAsync(del_dev, del.data(), (size_t)m * sizeof(int64_t), hipMemcpyHostToDevice, idx->mut);
+            }
+            f32x4u* tail = reinterpret_cast<f32x4u*>(idx->X + first * idx->ld);
+            f32x4u* side = reinterpret_cast<f32x4u*>(idx->ctmp);
+            if (groups > 1) {
+                const unsigned gx = (unsigned)std::min<int64_t>((side_units + 255) / 256, 64);
+                hipLaunchKernelGGL(shift_save_kernel, dim3(gx, (unsigned)(groups - 1)), dim3(256), 0, idx->mut, side, tail, range, side_units,
+                                   old_units);
+            }
+            if (run)
+                hipLaunchKernelGGL(shift_rows_kernel<true>, dim3((unsigned)groups), dim3(256), 0, idx->mut, tail, side, del_dev, m, new_units,
+                                   range, rowunits, side_units);
+            else
+                hipLaunchKernelGGL(shift_rows_kernel<false>, dim3((unsigned)groups), dim3(256), 0, idx->mut, tail, side, del_dev, m, new_units,
+                                   range, rowunits, side_units);
+            if (del_dev) (void)hipFreeAsync(del_dev, idx->mut);
+            if (e == hipSuccess) e = hipGetLastError();
+            const hipError_t es = hipStreamSynchronize(idx->mut);
+            if (e == hipSuccess) e = es;
+            if (e != hipSuccess) return fail(MVDB_ERR_HIP, "row compaction failed: %s", hipGetErrorString(e));
+            idx->n = n_new;
+            return 0;
+        }
+    }
     if (tail_new > 0) {
         const size_t row_bytes = (size_t)idx->ld * sizeof(float);
         const size_t want = std::min<size_t>((size_t)tail_new * row_bytes, std::max<size_t>((size_t)idx->kn.compact_bytes, row_bytes));

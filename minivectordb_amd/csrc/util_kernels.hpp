@@ -259,6 +259,75 @@ __global__ __launch_bounds__(256) void gather_kept_rows_kernel(float* __restrict
     }
 }
 
+// ---- row compaction in ONE pass for a handful of deleted rows (round 6) ---------------------------------------------------
+// The staging path above moves every byte of the tail twice (gather into the buffer, copy back).  For the reference's own
+// delete — ONE row (`delete_embedding`, vector_database.py:119) — or any few rows, the tail is shifted in place instead, in
+// 16-byte units: new unit u of the tail comes from old unit u + lo(row of u) x (units per row), a source that always lies
+// ABOVE its destination by at most m rows.  Every workgroup owns one contiguous range of the new tail and walks it upwards in
+// slices of 256 x U units: load the slice's sources into registers, barrier (the slice's destinations overlap its own
+// sources), store.  A later slice's sources lie above everything stored so far, so slices need no other ordering.  The one
+// cross-workgroup hazard — the sources of the last rows of a range lie in the NEXT range, which its owner overwrites at its own
+// pace — is removed before the launch: shift_save_kernel copies the first m rows' worth of units of every range but the first
+// into `side`, and sources at or above the owner's upper boundary are read from there.  No workgroup ever waits for another.
+constexpr int kShiftUnits = 8;  // 16-byte units per thread and slice (32 KiB per workgroup and slice)
+
+__global__ __launch_bounds__(256) void shift_save_kernel(f32x4u* __restrict__ side, const f32x4u* __restrict__ tail, int64_t range,
+                                                         int64_t side_units, int64_t old_units) {
+    // side[b][j] = tail[(b + 1) range + j], j < side_units (clamped to the old tail): boundary b = blockIdx.y
+    const int64_t base = ((int64_t)blockIdx.y + 1) * range;
+    for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < side_units; j += (int64_t)gridDim.x * 256)
+        if (base + j < old_units) side[(int64_t)blockIdx.y * side_units + j] = tail[base + j];
+}
+
+template <bool UNIFORM>
+__global__ __launch_bounds__(256) void shift_rows_kernel(f32x4u* tail, const f32x4u* __restrict__ side,
+                                                         const int64_t* __restrict__ del, int64_t m, int64_t new_units,
+                                                         int64_t range, int64_t rowunits, int64_t side_units) {
+    constexpr int U = kShiftUnits;
+    const int64_t a = (int64_t)blockIdx.x * range;
+    const int64_t b = a + range < new_units ? a + range : new_units;
+    const bool has_next = blockIdx.x + 1 < gridDim.x;
+    const int64_t bound = a + range;  // the next range's first unit: sources from here on come from `side`
+    const f32x4u* myside = side + (int64_t)blockIdx.x * side_units;
+    auto shift_of = [&](int64_t r) {  // smallest j with del[j] - j > r (gather_kept_rows_kernel's rule)
+        int64_t l = 0, h = m;
+        while (l < h) {
+            const int64_t mid = (l + h) >> 1;
+            if (del[mid] - mid > r)
+                h = mid;
+            else
+                l = mid + 1;
+        }
+        return l;
+    };
+    for (int64_t p = a; p < b; p += 256 * U) {
+        f32x4u v[U];
+        // the shift is non-decreasing along the tail: equal at both ends of the slice (all but m slices) = one value for the slice;
+        // UNIFORM: one run of m deleted rows at the head of the tail, every kept row moves up by m
+        int64_t lo0 = m, lo1 = m;
+        if (!UNIFORM) {
+            const int64_t pe = (p + 256 * U < b ? p + 256 * U : b) - 1;
+            lo0 = shift_of(p / rowunits);
+            lo1 = shift_of(pe / rowunits);
+        }
+#pragma unroll
+        for (int i = 0; i < U; ++i) {
+            const int64_t u = p + i * 256 + threadIdx.x;
+            if (u < b) {
+                const int64_t lo = lo0 == lo1 ? lo0 : shift_of(u / rowunits);
+                const int64_t s = u + lo * rowunits;
+                v[i] = (has_next && s >= bound) ? myside[s - bound] : tail[s];
+            }
+        }
+        __syncthreads();  // (s_waitcnt vmcnt(0) + barrier: every source of the slice is in registers)
+#pragma unroll
+        for (int i = 0; i < U; ++i) {
+            const int64_t u = p + i * 256 + threadIdx.x;
+            if (u < b) tail[u] = v[i];
+        }
+    }
+}
+
 // dense [n,d] -> padded [n,ld] copy (device to device), zero padding
 __global__ __launch_bounds__(256) void pad_rows_kernel(float* __restrict__ dst,
                                                        const float* __restrict__ src, int64_t n,

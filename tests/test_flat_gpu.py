@@ -271,8 +271,9 @@ def test_l2_batches_share_corpus_passes(native, d, nq, k, normalized):
 
 @pytest.mark.parametrize("staging_bytes", [None, 256, 1792, 100_000])
 def test_remove_rows_matches_np_delete(native, monkeypatch, staging_bytes):
-    """mvdb_index_remove_rows compacts the tail in place, chunk by chunk through a bounded staging buffer (512 MiB;
-    MVDB_COMPACT_BYTES): one row per chunk (256 B = a 64-float row), 7 rows, 390 rows and the whole tail at once."""
+    """mvdb_index_remove_rows compacts the tail in place; many scattered rows (the last case here) go chunk by chunk through a
+    bounded staging buffer (512 MiB; MVDB_COMPACT_BYTES): one row per chunk (256 B = a 64-float row), 7 rows, 390 rows and the
+    whole tail at once.  (Single rows take the one-pass shift: test_remove_a_few_rows_compacts_in_one_pass.)"""
     n, d = 3000, 64
     x = _corpus(n, d)
     idx = native.FlatIndex(d)
@@ -292,6 +293,40 @@ def test_remove_rows_matches_np_delete(native, monkeypatch, staging_bytes):
     _check(native, cur, q, 10, D, I)
     with pytest.raises(ValueError):
         idx.remove_rows(np.array([1, 1], np.int64))
+    idx.close()
+
+
+@pytest.mark.parametrize("inplace", [True, False])
+@pytest.mark.parametrize("n,d", [(3000, 64), (70001, 100), (300_000, 128), (40_000, 512), (9000, 2050)])
+def test_remove_a_few_rows_compacts_in_one_pass(native, monkeypatch, n, d, inplace):
+    """The reference deletes ONE row per call (vector_database.py:119-131: np.delete on the matrix, index rebuilt).  A single row,
+    a run of rows, or up to 8 scattered rows shift the tail in place in ONE pass (shift_rows_kernel: each workgroup walks its
+    range upwards, sources beyond its range come from a side copy taken before the launch); more scattered rows, and everything
+    under MVDB_COMPACT_INPLACE=0, go through the staging buffer.  Both must leave exactly np.delete's matrix, bit for bit."""
+    x = _corpus(n, d)
+    idx = native.FlatIndex(d)
+    if not inplace:
+        monkeypatch.setenv("MVDB_COMPACT_INPLACE", "0")
+        idx.reload_env()
+    idx.add(x)
+    rng = np.random.RandomState(n + d)
+    cur = x
+    cases = [lambda m: [0], lambda m: [1], lambda m: [m - 1], lambda m: [m // 2], lambda m: list(range(10, 17)), lambda m: list(range(0, 3)),
+             lambda m: sorted(rng.choice(m // 2, 64, replace=False).tolist()), lambda m: [5, 6, 7, m // 3],
+             lambda m: rng.choice(m // 2, 8, replace=False).tolist(), lambda m: rng.choice(m // 2, 9, replace=False).tolist(), lambda m: list(range(100, 400)),
+             lambda m: sorted(rng.choice(m // 2, 65, replace=False).tolist()), lambda m: [m - 2, m - 1], lambda m: [3, m - 1]]
+    for case in cases:
+        dels = case(cur.shape[0])
+        idx.remove_rows(np.array(dels, np.int64))
+        cur = np.delete(cur, dels, 0)
+        assert idx.ntotal == cur.shape[0]
+        got = idx.get_rows(0, idx.ntotal)
+        if got.tobytes() != cur.tobytes():
+            bad = np.flatnonzero((got != cur).any(axis=1))
+            raise AssertionError(f"rows differ after deleting {dels[:8]}... ({len(dels)} rows): first bad rows {bad[:10]}, {bad.size} in all")
+    q = _corpus(3, d, seed=3)
+    D, I = idx.search(q, 10)
+    _check(native, cur, q, 10, D, I)
     idx.close()
 
 
