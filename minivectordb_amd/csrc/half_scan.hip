@@ -631,11 +631,12 @@ static int launch_h16(int d, int nqpad, const HalfScanArgs& a, int device, hipSt
 // (block, query): unless a list fills, the lists hold EVERY row that can be in the top k; half_rescue_certify_kernel re-scores
 // all of them in fp32 and takes the top k — exact, no certificate needed.  A full list (a neighbourhood of more than ~30 rows per
 // block inside the band) raises the query's `need` word and its 32-query exact pass runs as before.
-template <int KT, int NST>
+template <int KT, int KS, int NST, int BPC>
 static int launch_h16_rescue_inst(const HalfScanArgs& a, int device, hipStream_t stream, int* nblocks_out) {
-    auto kern = flat_scan_h16_kernel<KT, KT, 4, NST, kRescueKeep>;
-    constexpr size_t lds = (size_t)NST * 32 * KT * 2 * 16;
-    static_assert(lds + 4 * 32 * kRescueKeep * 8 <= 160 * 1024, "LDS budget of a CU");
+    auto kern = flat_scan_h16_kernel<KT, KS, 4, NST, kRescueKeep>;
+    constexpr size_t lds = (size_t)NST * 32 * KS * 2 * 16;
+    static_assert(BPC * (lds + 4 * 32 * kRescueKeep * 8) <= 160 * 1024, "LDS budget of a CU");
+    static_assert(BPC <= kRescueBlocksPerCu, "mvdb.hip sizes the lists by kRescueBlocksPerCu");
     {
         static std::mutex mu;
         static std::map<int, bool> done;
@@ -646,9 +647,9 @@ static int launch_h16_rescue_inst(const HalfScanArgs& a, int device, hipStream_t
         }
     }
     const int64_t ntiles = a.tile1 - a.tile0;
-    const int nblocks = (int)std::max<int64_t>(1, std::min<int64_t>(ntiles, (int64_t)device_cus(device)));
+    const int nblocks = (int)std::max<int64_t>(1, std::min<int64_t>(ntiles, (int64_t)device_cus(device) * BPC));
     *nblocks_out = nblocks;
-    prof_symbol("ip_scan_rescue", "flat_scan_h16_kernel<%d, %d, 4, %d, %d>", KT, KT, NST, kRescueKeep);
+    prof_symbol("ip_scan_rescue", "flat_scan_h16_kernel<%d, %d, 4, %d, %d>", KT, KS, NST, kRescueKeep);
     int slot = prof_begin("ip_scan_rescue", stream);
     hipLaunchKernelGGL(kern, dim3(nblocks), dim3(256), lds, stream, a);
     prof_end(slot, stream);
@@ -657,15 +658,25 @@ static int launch_h16_rescue_inst(const HalfScanArgs& a, int device, hipStream_t
 }
 bool half_rescue_dim(int d) { return half_shadow_dim(d); }
 int launch_half_rescue_scan(int d, const HalfScanArgs& a, int device, hipStream_t stream, int* nb) {
+    // MVDB_RESCUE_FORM=1 (A/B): half-tile stages, a ring of three, TWO workgroups per CU
+    static const int form = []() { const char* v = getenv("MVDB_RESCUE_FORM"); return v && *v ? atoi(v) : 0; }();
+    if (form == 1) {
+        switch (d) {
+            case 256: return launch_h16_rescue_inst<16, 16, 3, 2>(a, device, stream, nb);
+            case 384: return launch_h16_rescue_inst<24, 24, 2, 2>(a, device, stream, nb);
+            case 512: return launch_h16_rescue_inst<32, 16, 3, 2>(a, device, stream, nb);
+            default: break;
+        }
+    }
     switch (d) {
-        case 128: return launch_h16_rescue_inst<8, 4>(a, device, stream, nb);
-        case 256: return launch_h16_rescue_inst<16, 4>(a, device, stream, nb);
-        case 384: return launch_h16_rescue_inst<24, 3>(a, device, stream, nb);
-        case 512: return launch_h16_rescue_inst<32, 3>(a, device, stream, nb);
-        case 640: return launch_h16_rescue_inst<40, 3>(a, device, stream, nb);   // (e5-large / bge-m3 widths: two-stage rings from 768 on)
-        case 768: return launch_h16_rescue_inst<48, 2>(a, device, stream, nb);
-        case 896: return launch_h16_rescue_inst<56, 2>(a, device, stream, nb);
-        case 1024: return launch_h16_rescue_inst<64, 2>(a, device, stream, nb);
+        case 128: return launch_h16_rescue_inst<8, 8, 4, 1>(a, device, stream, nb);
+        case 256: return launch_h16_rescue_inst<16, 16, 4, 1>(a, device, stream, nb);
+        case 384: return launch_h16_rescue_inst<24, 24, 3, 1>(a, device, stream, nb);
+        case 512: return launch_h16_rescue_inst<32, 32, 3, 1>(a, device, stream, nb);
+        case 640: return launch_h16_rescue_inst<40, 40, 3, 1>(a, device, stream, nb);   // (e5-large / bge-m3 widths: two-stage rings from 768 on)
+        case 768: return launch_h16_rescue_inst<48, 48, 2, 1>(a, device, stream, nb);
+        case 896: return launch_h16_rescue_inst<56, 56, 2, 1>(a, device, stream, nb);
+        case 1024: return launch_h16_rescue_inst<64, 64, 2, 1>(a, device, stream, nb);
         default: return fail(MVDB_ERR_ARG, "no rescue kernel for d = %d", d);
     }
 }

@@ -74,6 +74,7 @@ struct HalfCertifyArgs {
 
 // ---- the RESCUE pass: refused queries once more over the shadow, every row above the floor kept and re-scored ----------------
 constexpr int kRescueKeep = 32;      // rows per (block, query) list of the rescue pass: a FULL list sends the query on to the exact pass
+constexpr int kRescueBlocksPerCu = 2; // most workgroups per CU a rescue launch runs (its lists are sized by it)
 constexpr int kRescueQueries = 128;  // compact queries per rescue launch
 constexpr int kRescueCap = 8192;     // candidates per query the re-score holds (256 lists x 32)
 struct HalfRescueArgs {

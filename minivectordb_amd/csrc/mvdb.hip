@@ -1185,7 +1185,7 @@ int search_core(const mvdb_index* idx, Workspace* ws, const float* q_dev, int nq
                 const bool l2 = idx->metric == MVDB_METRIC_L2;
                 const float* hn = l2 && !l2_cert_ok(idx) && !idx->kn.disable_l2_cert ? ensure_offsets(idx, s) : nullptr;
                 if (l2 && !l2_cert_ok(idx) && !hn) return 0;
-                const int grid_ub = device_cus(idx->device);  // the rescue launch is one workgroup per CU
+                const int grid_ub = device_cus(idx->device) * kRescueBlocksPerCu;  // the rescue launch: one or two workgroups per CU
                 const size_t nwords = (size_t)(R + kRescueQueries) / need_per + 8;
                 MVDB_TRY(ws->need.reserve(nwords));
                 MVDB_TRY(ws->cand.reserve((size_t)kRescueQueries * (grid_ub + 1) * kRescueKeep));
