@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""A/B of the rescue launch's shape (MVDB_RESCUE_FORM): clustered corpus, 256 queries per call; wall time per call and the
-launch's own duration from the library's profiling hooks.  usage: rescue_form_probe.py [rows] [dim]"""
+"""The rescue tier under a switch (MVDB_DISABLE_TILE_SKIP=1: the rescue launches scan the whole shadow; round 6's launch-shape A/B
+used MVDB_RESCUE_FORM): clustered corpus (PROBE_FAMILY=0: zero-mean, 1: all-positive), 256 queries per call; wall time per call,
+the launches' own durations from the library's profiling hooks, tiles listed.  usage: rescue_form_probe.py [rows] [dim]"""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -9,7 +10,7 @@ dev = torch.device("cuda", 0)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
 d = int(sys.argv[2]) if len(sys.argv) > 2 else 512
 k, nq = 10, 256
-fam = 2 << 56
+fam = int(os.environ.get("PROBE_FAMILY", "2")) << 56
 idx = native.FlatIndex(d)
 idx.reserve(n)
 idx.add_synthetic(n, 1234 | fam, normalize=True)
@@ -33,7 +34,10 @@ for name in ("ip_scan_rescue", "ip_scan_half", "ip_scan_half_seed", "ip_scan_rer
 for _ in range(10):
     idx.search_device(q.data_ptr(), nq, k, D.data_ptr(), I.data_ptr(), stream=stream)
 torch.cuda.synchronize()
-out = {"rows": n, "d": d, "form": os.environ.get("MVDB_RESCUE_FORM", "0"), "call_ms": round(wall, 3), "checksum": int(I.sum().item())}
+out = {"rows": n, "d": d, "tile_skip": os.environ.get("MVDB_DISABLE_TILE_SKIP", "0") != "1", "family": os.environ.get("PROBE_FAMILY", "2"),
+       "call_ms": round(wall, 3), "checksum": int(I.sum().item()), "dsum": float(D.double().sum().item())}
+listed, total = native.rescue_tile_stats()
+out["rescue_tiles_listed_of_total"] = [listed, total, round(listed / max(total, 1), 4)]
 for name in ("ip_scan_rescue", "ip_scan_half", "ip_scan_half_seed", "ip_scan_rerun"):
     l, ms = native.prof_read(name)
     out[name] = [l, round(ms / max(l, 1), 4)]

@@ -308,6 +308,10 @@ int mvdb_prof_symbol(const char* name, char* out, int len);
  * Diagnostic only. */
 int64_t mvdb_split_rerun_count(void);
 
+/* Tiles (32 rows) the rescue launches were handed since the library was loaded, and the tiles they would have scanned without
+ * the tile flags the certified pass keeps (inner product, k <= 16, 1M rows and more).  Diagnostic only; synchronises the devices. */
+int mvdb_rescue_tile_stats(int64_t* listed, int64_t* total);
+
 /* The certificate's error bound per unit |q| * max|x| at dimension d for the fp16 single-product nomination pass
  * (half_scan.hip: both operands rounded to fp16, d products accumulated in fp32, 64 nominees per query re-scored
  * in fp32): rounding of both operands, elements below fp16's normal range, worst-case fp32 accumulation, the fp32

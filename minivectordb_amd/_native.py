@@ -103,6 +103,7 @@ PROTOTYPES = {
     "mvdb_synth_fill_device": (ctypes.c_int, [c_vp, ctypes.c_int64, ctypes.c_int, ctypes.c_uint64, ctypes.c_int64,
                                               ctypes.c_int, ctypes.c_int, c_vp]),
     "mvdb_split_rerun_count": (ctypes.c_int64, []),
+    "mvdb_rescue_tile_stats": (ctypes.c_int, [ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]),
     "mvdb_half_eps": (ctypes.c_double, [ctypes.c_int]),
     "mvdb_half_max_queries": (ctypes.c_int, [ctypes.c_int]),
     "mvdb_prof_enable": (ctypes.c_int, [ctypes.c_int]),
@@ -447,6 +448,13 @@ def pack_row_mask(n, rows=None, excluded=None):
 
 def split_rerun_count():
     return int(lib().mvdb_split_rerun_count())
+
+
+def rescue_tile_stats():
+    """(tiles the rescue launches were handed, tiles they would have scanned without the tile flags) since the library was loaded."""
+    a, b = ctypes.c_int64(0), ctypes.c_int64(0)
+    check(lib().mvdb_rescue_tile_stats(ctypes.byref(a), ctypes.byref(b)))
+    return int(a.value), int(b.value)
 
 
 def half_eps(d):

@@ -69,6 +69,9 @@ struct Knobs {
     int gemm_scan_blocks_per_cu = 2; // MVDB_GEMM_SCAN_BLOCKS_PER_CU
     int split_scan_min_nq = -1;      // MVDB_SPLIT_SCAN_MIN_NQ: fewest queries of a call for the certified pass (-1: by corpus size, mvdb.hip half_min_nq)
     bool disable_rescue = false;       // MVDB_DISABLE_RESCUE: refused queries go straight to the exact passes (A/B)
+    bool disable_tile_skip = false;    // MVDB_DISABLE_TILE_SKIP: the rescue launches scan every tile of the shadow (A/B)
+    int tile_flag_min_tiles = 32768;   // MVDB_TILE_FLAG_MIN_TILES: rows / 32 from which the certified pass keeps tile flags for the rescue pass
+                                       // (1M rows: below, the rescue launch is short and the flags' memset is not)
     bool disable_rerun_floor = false;  // MVDB_DISABLE_RERUN_FLOOR: the exact re-run of refused queries starts every list from -inf (A/B)
     int half_phase_growth = 0;       // MVDB_HALF_PHASE_GROWTH (0: by the pass width — 16 / 6 up to 128 queries per pass, 6 / 4 at 256)
     int half_last_growth = 0;        // MVDB_HALF_LAST_GROWTH

@@ -46,6 +46,7 @@ typedef float hs_f4 __attribute__((ext_vector_type(4)));
 typedef float hs_f16 __attribute__((ext_vector_type(16)));
 typedef __attribute__((address_space(3))) void* hs_lds_ptr;
 typedef const __attribute__((address_space(1))) void* hs_gbl_ptr;
+typedef const __attribute__((address_space(4))) int* hs_cst_i32;
 
 // ---- queries: fp16 image, |q|, scale -----------------------------------------------------------------------------
 // One block per (padded) query.  s_q = 2^(15 - e) with max|q_i| = m 2^e, m in [0.5, 1): the largest element lands in
@@ -379,12 +380,26 @@ __global__ __launch_bounds__(WV * 64) void flat_scan_h16_kernel(HalfScanArgs a) 
     float thr = floor0;
     uint32_t thr_row = 0u;
     float inv = a.qinv[myq];
+    // LIST: the rescue launch walks the tiles rescue_tiles_kernel listed (tile_list[0 .. *tile_count)), in list order
+    constexpr bool LIST = DEPTH != kHalfKeep;
+    constexpr int LA = (NSTG - 1 + NST - 1) / NSTG;  // the look-ahead stage of a tile's last stage lies this many tiles ahead
+    // main launches: the tile's bit of the query's flag row is raised when a score comes within fband of the running threshold
+    float fband = 0.f;
+    uint32_t* myflags = nullptr;
+    if constexpr (!LIST) {
+        if (a.tflags && myq < a.nq) {
+            fband = a.flag_coef * a.flag_qn[myq];
+            myflags = a.tflags + (int64_t)myq * a.twords;
+        }
+    }
+    int listed = 0;
+    if constexpr (LIST) listed = *a.tile_count;
     // consume every global load here: the hand-placed vmcnt waits below are invisible to hipcc (see flat_scan_seed_kernel)
 #pragma unroll
     for (int kb = 0; kb < KT; ++kb) asm volatile("" : "+v"(Q[kb]));
-    asm volatile("" : "+v"(floor0), "+v"(thr), "+v"(inv));
+    asm volatile("" : "+v"(floor0), "+v"(thr), "+v"(inv), "+v"(fband), "+v"(listed));
 
-    const int64_t ntiles = a.tile1 - a.tile0;
+    const int64_t ntiles = LIST ? (int64_t)__builtin_amdgcn_readfirstlane(listed) : a.tile1 - a.tile0;
     const int64_t last = a.n - 1;
     // DMA roles: piece p = wave DPW + i of a stage fills LDS bytes [1024 p, 1024 p + 1024) = rows (64 p + lane) / HSL
     uint32_t voff[DPW];
@@ -396,10 +411,18 @@ __global__ __launch_bounds__(WV * 64) void flat_scan_h16_kernel(HalfScanArgs a) 
     }
     const int64_t step = gridDim.x;
     int64_t tile = blockIdx.x;
+    // (LIST) the tiles at list positions tile, tile + step, ..., tile + LA step: scalar loads through the constant address space —
+    // the vector-memory counter stays the DMA ring's alone; positions past the end repeat the last entry (re-reads nobody consumes)
+    hs_cst_i32 tl = (hs_cst_i32)a.tile_list;
+    auto list_at = [&](int64_t t) { return tl[t < ntiles ? t : (ntiles > 0 ? ntiles - 1 : 0)]; };
+    int rq[LA + 1];
+#pragma unroll
+    for (int i = 0; i <= LA; ++i) rq[i] = LIST ? list_at(tile + i * step) : 0;
     // stage c of the block's flat sequence = (tile + (c / NSTG) step, K part c % NSTG); tiles past the end are clamped
     auto issue_piece = [&](int64_t base, int c, int buf, int i) {
         int64_t t = base + (int64_t)(c / NSTG) * step;
         t = t < ntiles ? t : (base < ntiles ? base : 0);
+        if constexpr (LIST) t = rq[c / NSTG];
         const char* sbase = reinterpret_cast<const char*>(a.Xh) + ((a.tile0 + t) * 32 * (int64_t)K + (c % NSTG) * KS * 16) * 2;
         unsigned char* dst = smem + buf * kStage + wave * DPW * 1024;
         __builtin_amdgcn_global_load_lds((hs_gbl_ptr)(sbase + voff[i]), (hs_lds_ptr)(dst + i * 1024), 16, 0, 2 /* nt */);
@@ -436,6 +459,15 @@ __global__ __launch_bounds__(WV * 64) void flat_scan_h16_kernel(HalfScanArgs a) 
         float mx = sc[0];
 #pragma unroll
         for (int e = 1; e < 16; ++e) mx = fmaxf(mx, sc[e]);
+        if constexpr (!LIST) {
+            // a score within fband of the threshold this wave holds BEFORE the tile: the tile may hold a row the rescue pass has to
+            // see, should the query be refused (mvdb.hip: the band's derivation).  NaN scores flag too.
+            const bool hit = myflags != nullptr && !(mx < thr - fband);
+            if (__ballot(hit) != 0ull) {
+                const int64_t gt = m0 >> 5;
+                if (hit) atomicOr(myflags + (gt >> 5), 1u << (gt & 31));
+            }
+        }
         if (__ballot(mx >= thr) != 0ull) {
             ++n_slow;
             const uint32_t mw = a.mask ? a.mask[m0 >> 5] : 0xffffffffu;  // row selection: looked at on the slow path only
@@ -464,7 +496,7 @@ __global__ __launch_bounds__(WV * 64) void flat_scan_h16_kernel(HalfScanArgs a) 
     }
     int buf = 0;
     while (tile < ntiles) {
-        const int64_t m0 = (a.tile0 + tile) * 32;
+        const int64_t m0 = (LIST ? (int64_t)rq[0] : a.tile0 + tile) * 32;
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[e] = 0.f;
 #pragma unroll
@@ -500,6 +532,11 @@ __global__ __launch_bounds__(WV * 64) void flat_scan_h16_kernel(HalfScanArgs a) 
         }
         gate(m0);   // (timing ablation, 256 queries at 10M x 512: without the gate the launch takes 0.91 ms instead of 0.89 — not what bounds it)
         tile += step;
+        if constexpr (LIST) {
+#pragma unroll
+            for (int i = 0; i < LA; ++i) rq[i] = rq[i + 1];
+            rq[LA] = list_at(tile + LA * step);
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the clamped look-ahead DMAs must land before the LDS is released
     if (a.stats && lane == 0) {
@@ -656,23 +693,54 @@ static int launch_h16_rescue_inst(const HalfScanArgs& a, int device, hipStream_t
     MVDB_HIP(hipGetLastError());
     return 0;
 }
+// The rescue launches' tile lists: thread w of slot s = blockIdx.y ORs word w of the flag rows of the slot's refused queries, adds
+// the seed's tiles, drops the bits past the last tile and appends the set bits to the slot's list (order: as the atomics fall).
+__global__ __launch_bounds__(256) void rescue_tiles_kernel(RescueTilesArgs a) {
+    const int nb = *a.nfail;
+    const int r0 = blockIdx.y * kRescueQueries;
+    if (nb <= r0) return;
+    const int r1 = nb < r0 + kRescueQueries ? nb : r0 + kRescueQueries;
+    const int64_t w = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t t0 = w * 32;
+    if (a.stats && w == 0) atomicAdd(a.stats + 1, (unsigned long long)a.ntiles);
+    if (t0 >= a.ntiles) return;
+    uint32_t word = a.tflags ? 0u : 0xffffffffu;
+    if (a.tflags)
+        for (int r = r0; r < r1; ++r) word |= a.tflags[a.map[r] * a.twords + w];
+    if (t0 < a.seed_tiles) word |= a.seed_tiles - t0 >= 32 ? 0xffffffffu : (1u << (a.seed_tiles - t0)) - 1u;
+    if (t0 + 32 > a.ntiles) word &= (1u << (a.ntiles - t0)) - 1u;
+    const int c = __popc(word);
+    if (c == 0) return;
+    int at = atomicAdd(a.counts + blockIdx.y, c);
+    if (a.stats) atomicAdd(a.stats, (unsigned long long)c);
+    int* list = a.lists + (int64_t)blockIdx.y * a.ntiles;
+    while (word) {
+        const int b = __ffs(word) - 1;
+        word &= word - 1;
+        list[at++] = (int)(t0 + b);
+    }
+}
+int launch_rescue_tiles(const RescueTilesArgs& a, int slots, hipStream_t stream) {
+    const int64_t words = (a.ntiles + 31) / 32;
+    hipLaunchKernelGGL(rescue_tiles_kernel, dim3((unsigned)((words + 255) / 256), (unsigned)slots), dim3(256), 0, stream, a);
+    MVDB_HIP(hipGetLastError());
+    return 0;
+}
+
 bool half_rescue_dim(int d) { return half_shadow_dim(d); }
 int launch_half_rescue_scan(int d, const HalfScanArgs& a, int device, hipStream_t stream, int* nb) {
-    // MVDB_RESCUE_FORM=1 (A/B): half-tile stages, a ring of three, TWO workgroups per CU
-    static const int form = []() { const char* v = getenv("MVDB_RESCUE_FORM"); return v && *v ? atoi(v) : 0; }();
-    if (form == 1) {
-        switch (d) {
-            case 256: return launch_h16_rescue_inst<16, 16, 3, 2>(a, device, stream, nb);
-            case 384: return launch_h16_rescue_inst<24, 24, 2, 2>(a, device, stream, nb);
-            case 512: return launch_h16_rescue_inst<32, 16, 3, 2>(a, device, stream, nb);
-            default: break;
-        }
-    }
+    // d <= 512: TWO workgroups per CU (80 KiB each: the 32 KiB of lists + a ring of 48 KiB — three half-tile stages at d = 512, two
+    // whole tiles at 384, three at 256) — as in the 128-query main launch, one workgroup's waves issue while the other's sit at
+    // their barrier or in the gate.  Against one workgroup per CU on a ring of three whole tiles (round 5), clustered corpus, 256
+    // queries per call: live rescue launch 1.86 -> 1.61 ms at 10M x 512 (10.24 GB: 0.69 -> 0.80 of HBM), 1.39 -> 1.15 at 10M x 384,
+    // 0.59 -> 0.41 at 1M x 512, 1.49 -> 0.92 at 4M x 256, 0.97 -> 0.57 at 4M x 128 (both launches live there); the call 4.82 -> 4.65 / 3.81 -> 3.63 /
+    // 1.16 -> 1.00 / 2.46 -> 1.90 / 1.72 -> 1.34 ms (profiles/r06_rescue_form_ab.jsonl).  The
+    // wide shapes keep one workgroup per CU: their query fragments alone are 160 - 256 registers per lane.
     switch (d) {
-        case 128: return launch_h16_rescue_inst<8, 8, 4, 1>(a, device, stream, nb);
-        case 256: return launch_h16_rescue_inst<16, 16, 4, 1>(a, device, stream, nb);
-        case 384: return launch_h16_rescue_inst<24, 24, 3, 1>(a, device, stream, nb);
-        case 512: return launch_h16_rescue_inst<32, 32, 3, 1>(a, device, stream, nb);
+        case 128: return launch_h16_rescue_inst<8, 8, 4, 2>(a, device, stream, nb);
+        case 256: return launch_h16_rescue_inst<16, 16, 3, 2>(a, device, stream, nb);
+        case 384: return launch_h16_rescue_inst<24, 24, 2, 2>(a, device, stream, nb);
+        case 512: return launch_h16_rescue_inst<32, 16, 3, 2>(a, device, stream, nb);
         case 640: return launch_h16_rescue_inst<40, 40, 3, 1>(a, device, stream, nb);   // (e5-large / bge-m3 widths: two-stage rings from 768 on)
         case 768: return launch_h16_rescue_inst<48, 48, 2, 1>(a, device, stream, nb);
         case 896: return launch_h16_rescue_inst<56, 56, 2, 1>(a, device, stream, nb);

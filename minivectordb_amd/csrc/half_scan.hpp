@@ -35,6 +35,15 @@ struct HalfScanArgs {
     const float* thr_qn = nullptr;
     const float* hn = nullptr;       // NULL, or [n + slack] |x_r|^2 / 2 per row (L2 metric over the shadow): rows are nominated by
                                      // q.x - |x|^2 / 2, which ranks exactly like the squared distance |q|^2 - 2 (q.x - |x|^2 / 2)
+    // tile flags for the rescue pass (round 6, inner product, k <= 16).  A MAIN launch (tflags != NULL) raises bit t of its
+    // query's row whenever tile t holds a score within flag_coef |q| below the query's running threshold; the rescue launch walks
+    // the tiles some refused query flagged (tile_list / tile_count, written by rescue_tiles_kernel) instead of the whole shadow.
+    uint32_t* tflags = nullptr;      // [nq][twords], zeroed by the caller
+    int twords = 0;
+    const float* flag_qn = nullptr;  // [nq] |q|
+    float flag_coef = 0.f;
+    const int* tile_list = nullptr;  // rescue launch: the tiles to scan ...
+    const int* tile_count = nullptr; // ... and how many
 };
 
 struct HalfCertifyArgs {
@@ -95,6 +104,20 @@ struct HalfRescueArgs {
     int l2 = 0;             // != 0: squared-L2 index — candidates are re-scored as sum (q - x)^2, smallest first
 };
 int launch_half_rescue_scan(int d, const HalfScanArgs& a, int device, hipStream_t stream, int* nblocks_out);
+// The tile lists of a call's rescue launches (one per kRescueQueries compact refused queries: grid.y = slots): slot s lists the
+// tiles whose bit some refused query [128 s, 128 s + 128) of the call raised (tflags == NULL: every tile), plus the seed's tiles.
+struct RescueTilesArgs {
+    const uint32_t* tflags;   // [queries of the call][twords] or NULL
+    int twords;
+    const int64_t* map;       // compact refused query -> query of the call
+    const int* nfail;         // refused queries of the call
+    int64_t seed_tiles;       // tiles [0, seed_tiles) were scanned by the seed launch only: always listed
+    int64_t ntiles;
+    int* lists;               // [slots][ntiles]
+    int* counts;              // [slots], zeroed by the caller
+    unsigned long long* stats;  // NULL, or [2]: tiles listed / tiles there were, summed over live slots (diagnostics)
+};
+int launch_rescue_tiles(const RescueTilesArgs& a, int slots, hipStream_t stream);
 int launch_half_rescue_certify(const HalfRescueArgs& a, hipStream_t stream);
 bool half_rescue_dim(int d);
 

@@ -56,6 +56,8 @@ Knobs read_knobs() {
     k.disable_half_scan = env_int("MVDB_DISABLE_HALF_SCAN", 0) != 0;
     k.disable_rerun_floor = env_int("MVDB_DISABLE_RERUN_FLOOR", 0) != 0;
     k.disable_rescue = env_int("MVDB_DISABLE_RESCUE", 0) != 0;
+    k.disable_tile_skip = env_int("MVDB_DISABLE_TILE_SKIP", 0) != 0;
+    k.tile_flag_min_tiles = env_int("MVDB_TILE_FLAG_MIN_TILES", 32768);
     k.disable_masked_batch = env_int("MVDB_DISABLE_MASKED_BATCH", 0) != 0;
     k.disable_l2_cert = env_int("MVDB_DISABLE_L2_CERT", 0) != 0;
     k.disable_half_shadow = env_int("MVDB_DISABLE_HALF_SHADOW", 0) != 0;
@@ -196,6 +198,8 @@ struct Workspace {
     DevBuf<int> nfail;      // number of uncertified queries of the call (device-side gate of the exact re-run)
     DevBuf<int> need;       // one word per 32-query exact re-run pass: raised by the rescue pass where a query stays unanswered
     DevBuf<float> qfloor;   // per query: the admission floor of its exact re-run (half_certify_kernel), behind them the compact copy
+    DevBuf<uint32_t> tflags;  // certified pass: one bit per (query of the call, 32-row tile) that may matter to the rescue pass
+    DevBuf<int> tlist;        // the rescue launches' tile lists
     SelectState* st = nullptr;
     PinnedBuf pin;
     std::mutex use_mu;  // stream workspaces are shared by every host thread that names the stream: one search at a time
@@ -744,7 +748,8 @@ unsigned long long* rerun_counter(int device) {
     auto it = g_rerun_ctr.find(device);
     if (it != g_rerun_ctr.end()) return it->second;
     unsigned long long* p = nullptr;
-    if (hipMalloc((void**)&p, sizeof(*p)) != hipSuccess || hipMemset(p, 0, sizeof(*p)) != hipSuccess) return nullptr;
+    // [0] refused chunks, [1] tiles the rescue launches were handed, [2] tiles they would have scanned without the tile flags
+    if (hipMalloc((void**)&p, 3 * sizeof(*p)) != hipSuccess || hipMemset(p, 0, 3 * sizeof(*p)) != hipSuccess) return nullptr;
     g_rerun_ctr[device] = p;
     return p;
 }
@@ -868,7 +873,7 @@ const float* ensure_offsets(const mvdb_index* idx, hipStream_t s);
 
 int launch_half_pass(const mvdb_index* idx, Workspace* ws, const float* q, int nq, int nqpad, int k, int64_t n,
                      int64_t label_offset, float* D, int64_t* I, int* flag, int* failed, const uint32_t* mask = nullptr,
-                     float* floor_out = nullptr) {
+                     float* floor_out = nullptr, uint32_t* tflags = nullptr, int twords = 0) {
     hipStream_t stream = ws->stream;
     _Float16* qf = reinterpret_cast<_Float16*>(ws->qsplit.p);
     float* qnorm = ws->qnorm.p;
@@ -941,6 +946,20 @@ int launch_half_pass(const mvdb_index* idx, Workspace* ws, const float* q, int n
     }
     int last_lists = 0;
     int64_t covered = seed_tiles;
+    // Tile flags for the rescue pass (inner product, k <= 16; search_core decides).  With B = max|x| and e = half_eps(d) B: a
+    // refused query's rescue launch admits rows with a(x) >= F = fl - e |q|, fl = t - m |q| (one ulp down), t the k-th fp32
+    // re-score among the 64 nominees R, m = floor_margin = 2 d 2^-24 B.  At ANY moment of ANY main launch the threshold `thr` a
+    // wave holds for the query (the larger of the phase's floor — the 16th best a() of the rows before the phase — and the 16th
+    // of its list) is reached by at least 16 >= k candidates that are folded into R's pool, so R's k-th best a() is >= thr; a
+    // nominee's re-score is >= a(x) - (e + m / 2) |q|; hence t >= thr - (e + m / 2) |q| and F >= thr - (2 e + 3 m / 2) |q| - ulp.
+    // A tile whose best score stays below thr - flag_coef |q|, flag_coef = 2.25 e + 2 m, cannot hold an admitted row.
+    if (tflags && !l2off && idx->metric == MVDB_METRIC_IP && k <= kHalfKeep) {
+        a.tflags = tflags;
+        a.twords = twords;
+        a.flag_qn = qnorm;
+        const double B = (double)idx->row_norm_bound;
+        a.flag_coef = (float)((2.25 * half_eps(idx->d) + 4.0 * idx->d * std::ldexp(1.0, -24)) * B * (1.0 + 1e-6));
+    }
     for (size_t p = ends.size(); p-- > 0;) {
         a.tile0 = covered;
         a.tile1 = ends[p];
@@ -1025,6 +1044,7 @@ __global__ __launch_bounds__(256) void mask_rank_kernel(int64_t* __restrict__ I,
 constexpr int kCoreTile = 1024;      // queries search_core answers per pass over its workspace
 constexpr int64_t kShiftMaxRows = 8;           // most scattered deleted rows of a call the one-pass compaction takes (a run of any length qualifies)
 constexpr size_t kShiftSideBytes = 64u << 20;   // ... and the most its side copies may occupy
+constexpr size_t kTileFlagMaxBytes = 512u << 20;  // the most the certified pass's tile flags may occupy (queries of the call x tiles / 8)
 constexpr int kGatedPassGroup = 8;   // exact re-run passes (of 16 / 32 compact queries) one gated launch walks: one list buffer of that many
 int search_core(const mvdb_index* idx, Workspace* ws, const float* q_dev, int nq, int k,
                 int normalize_q, const int64_t* rows_dev, int64_t m, int64_t label_offset,
@@ -1115,11 +1135,24 @@ int search_core(const mvdb_index* idx, Workspace* ws, const float* q_dev, int nq
             MVDB_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ws->qfloor.p), 0xff800000u, (size_t)q0, s));  // -inf: no floor
             MVDB_HIP(hipMemsetAsync(ws->flags.p, 0, (size_t)nchunks * sizeof(int), s));
             MVDB_HIP(hipMemsetAsync(ws->qfail.p, 0, (size_t)q0 * sizeof(int), s));
+            // Tile flags (round 6): the main launches note, per query, which 32-row tiles came near its running threshold; should the
+            // query be refused, its rescue launch walks those tiles only (clustered 10M x 512: ~30 % of the shadow for ~40 refused
+            // queries).  Inner product, k <= 16 (the floors are 16th-best scores), from 1M rows on (below, the rescue launch is
+            // short and the flags' memset is not), at most 512 MiB of flags.
+            const int64_t ntiles_all = (n + 31) / 32;
+            const int twords = (int)((ntiles_all + 31) / 32);
+            const bool tile_flags = idx->metric == MVDB_METRIC_IP && k <= kHalfKeep && ntiles_all >= idx->kn.tile_flag_min_tiles && !idx->kn.disable_tile_skip &&
+                                    !idx->kn.disable_rescue && !idx->kn.disable_rerun_floor && half_rescue_dim(idx->d) &&
+                                    (size_t)q0 * twords * sizeof(uint32_t) <= kTileFlagMaxBytes;
+            if (tile_flags) {
+                MVDB_TRY(ws->tflags.reserve((size_t)q0 * twords));
+                MVDB_HIP(hipMemsetAsync(ws->tflags.p, 0, (size_t)q0 * twords * sizeof(uint32_t), s));
+            }
             for (int c = 0; c < nchunks; ++c) {
                 const int c0 = plan[c].first, take = plan[c].second;
                 MVDB_TRY(launch_half_pass(idx, ws, qsrc + (int64_t)c0 * idx->ld, take, half_chunk_queries(idx->d, take), k, n, label_offset,
                                           D_dev + (int64_t)c0 * k, I_dev + (int64_t)c0 * k, ws->flags.p + c, ws->qfail.p + c0, mask32,
-                                          ws->qfloor.p + c0));
+                                          ws->qfloor.p + c0, tile_flags ? ws->tflags.p + (size_t)c0 * twords : nullptr, twords));
             }
             // ---- uncertified queries: re-run on the exact kernels WITHOUT the host ever learning which they were ----------
             // split_plan_kernel compacts the failed queries (ascending) and publishes their number nb; the exact passes below
@@ -1186,8 +1219,11 @@ int search_core(const mvdb_index* idx, Workspace* ws, const float* q_dev, int nq
                 const float* hn = l2 && !l2_cert_ok(idx) && !idx->kn.disable_l2_cert ? ensure_offsets(idx, s) : nullptr;
                 if (l2 && !l2_cert_ok(idx) && !hn) return 0;
                 const int grid_ub = device_cus(idx->device) * kRescueBlocksPerCu;  // the rescue launch: one or two workgroups per CU
-                const size_t nwords = (size_t)(R + kRescueQueries) / need_per + 8;
+                const int slots = (R + kRescueQueries - 1) / kRescueQueries;
+                const size_t nneed = (size_t)(R + kRescueQueries) / need_per + 8;
+                const size_t nwords = nneed + slots;  // ... and the tile lists' lengths behind the need words (one memset)
                 MVDB_TRY(ws->need.reserve(nwords));
+                MVDB_TRY(ws->tlist.reserve((size_t)slots * ntiles_all));
                 MVDB_TRY(ws->cand.reserve((size_t)kRescueQueries * (grid_ub + 1) * kRescueKeep));
                 MVDB_TRY(ws->qsplit.reserve((size_t)2 * kRescueQueries * idx->d));
                 MVDB_TRY(ws->qnorm.reserve((size_t)3 * kRescueQueries));
@@ -1197,6 +1233,19 @@ int search_core(const mvdb_index* idx, Workspace* ws, const float* q_dev, int nq
                 float* qinv = qn2 + 2 * kRescueQueries;
                 float eps = (float)(half_eps(idx->d) * (double)idx->row_norm_bound * (1.0 + 1e-6));
                 if (hn) eps = (float)((double)eps + std::ldexp(1.0, -22) * (double)idx->row_norm_bound * (1.0 + 1e-6));  // (launch_half_pass: the subtraction)
+                {   // the launches' tile lists: what the refused queries' flags name (no flags: every tile)
+                    RescueTilesArgs ta;
+                    ta.tflags = tile_flags ? ws->tflags.p : nullptr;
+                    ta.twords = twords;
+                    ta.map = map;
+                    ta.nfail = ws->nfail.p;
+                    ta.seed_tiles = std::min<int64_t>(ntiles_all, device_cus(idx->device));  // (launch_half_pass: the seed launch's tiles)
+                    ta.ntiles = ntiles_all;
+                    ta.lists = ws->tlist.p;
+                    ta.counts = ws->need.p + nneed;
+                    ta.stats = ctr + 1;
+                    MVDB_TRY(launch_rescue_tiles(ta, slots, s));
+                }
                 for (int off2 = 0; off2 < R; off2 += kRescueQueries) {
                     MVDB_TRY(launch_half_queries(qc + (int64_t)off2 * idx->ld, idx->ld, idx->d, kRescueQueries, kRescueQueries, xs, qf, qn2,
                                                  qinv, s));
@@ -1220,6 +1269,8 @@ int search_core(const mvdb_index* idx, Workspace* ws, const float* q_dev, int nq
                     ra.thr_qn = qn2;
                     ra.gate = ws->nfail.p;
                     ra.gate_lo = off2;
+                    ra.tile_list = ws->tlist.p + (size_t)(off2 / kRescueQueries) * ntiles_all;
+                    ra.tile_count = ws->need.p + nneed + off2 / kRescueQueries;
                     int gx = 0;
                     MVDB_TRY(launch_half_rescue_scan(idx->d, ra, idx->device, s, &gx));
                     HalfRescueArgs rc;
@@ -2653,6 +2704,21 @@ int64_t mvdb_split_rerun_count(void) {
             total += (int64_t)v;
     }
     return total;
+}
+
+int mvdb_rescue_tile_stats(int64_t* listed, int64_t* total) {
+    if (!listed || !total) return fail(MVDB_ERR_ARG, "NULL argument");
+    std::lock_guard<std::mutex> lk(g_rerun_mu);
+    *listed = *total = 0;
+    for (auto& kv : g_rerun_ctr) {
+        DeviceGuard dg(kv.first);
+        unsigned long long v[2] = {0, 0};
+        if (hipDeviceSynchronize() == hipSuccess && hipMemcpy(v, kv.second + 1, sizeof(v), hipMemcpyDeviceToHost) == hipSuccess) {
+            *listed += (int64_t)v[0];
+            *total += (int64_t)v[1];
+        }
+    }
+    return 0;
 }
 
 int mvdb_prof_enable(int on) {

@@ -1896,3 +1896,56 @@ def test_rescue_tier_at_the_wide_dimensions_and_for_the_l2_metric(native, monkey
     assert (got["rescue"][1] == got["exact"][1]).mean() > 0.9
     np.testing.assert_allclose(np.sort(got["rescue"][0], axis=1), np.sort(got["exact"][0], axis=1), rtol=0, atol=4e-6 * mag)
     idx.close()
+
+
+@pytest.mark.parametrize("n,d,k,nq,masked", [(400_000, 256, 10, 256, False), (300_000, 512, 16, 200, False), (400_000, 384, 10, 130, True),
+                                             (1_100_000, 128, 10, 256, False), (250_000, 512, 10, 640, False)])
+def test_rescue_launches_skip_tiles_no_refused_query_flagged(native, monkeypatch, n, d, k, nq, masked):
+    """Round 6: the certified pass's main launches raise, per query, the bit of every 32-row tile that comes within
+    (2.25 eps + 2 margin) |q| of the threshold the scanning wave holds at that moment — a lower bound of the rescue pass's admission
+    floor, should the query be refused (launch_half_pass: the derivation).  The rescue launch then walks only the tiles some refused
+    query of its batch flagged (+ the seed's tiles) instead of the whole shadow.  Results must be the same BITS as with every tile
+    scanned (MVDB_DISABLE_TILE_SKIP=1) — the rescue lists hold every row above the floor either way — and stand the float64
+    adjudication; on the clustered corpus some certificates are refused and the launches are handed a fraction of the tiles.
+    (The flags are kept from 1M rows on; MVDB_TILE_FLAG_MIN_TILES=1 brings smaller corpora in.)"""
+    monkeypatch.setenv("MVDB_TILE_FLAG_MIN_TILES", "1")
+    q = flat.synth(nq, d, 5678 | flat.SYNTH_CLUSTERED)
+    flat.normalize_l2(q)
+    idx = native.FlatIndex(d)
+    idx.reserve(n)
+    idx.add_synthetic(n, 1234 | flat.SYNTH_CLUSTERED, normalize=True)
+    stored = idx.get_rows(0, n)
+    mask = None
+    if masked:
+        rng = np.random.RandomState(3)
+        keep = rng.rand(n) < 0.6
+        mask = native.pack_row_mask(n, rows=np.flatnonzero(keep))
+    def run():
+        return idx.search_masked(q, k, mask, labels="positions") if masked else idx.search(q, k)
+    run()   # shadow, workspaces
+    got = {}
+    for mode in ("skip", "all"):
+        if mode == "all":
+            monkeypatch.setenv("MVDB_DISABLE_TILE_SKIP", "1")
+            idx.reload_env()
+        l0, t0 = native.rescue_tile_stats()
+        before = native.split_rerun_count()
+        D, I = run()
+        assert native.split_rerun_count() > before, "the clustered corpus must refuse some certificates"
+        l1, t1 = native.rescue_tile_stats()
+        assert t1 > t0, "no rescue launch ran"
+        if mode == "skip":
+            assert (l1 - l0) < 0.9 * (t1 - t0), (l1 - l0, t1 - t0)
+            print(f"rescue launches were handed {l1 - l0} of {t1 - t0} tiles")
+        else:
+            assert l1 - l0 == t1 - t0
+        got[mode] = (D.copy(), I.copy())
+    monkeypatch.delenv("MVDB_DISABLE_TILE_SKIP")
+    idx.reload_env()
+    assert got["skip"][0].tobytes() == got["all"][0].tobytes() and got["skip"][1].tobytes() == got["all"][1].tobytes()
+    D, I = got["skip"]
+    src = stored if not masked else stored[keep]
+    for i in range(0, nq, 5):
+        ok, msg = flat.adjudicate(src, q[i], k, D[i], I[i], tol=1e-4, tie_eps=4e-6)
+        assert ok, (i, msg)
+    idx.close()
