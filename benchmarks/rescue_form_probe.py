@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The rescue tier under a switch (MVDB_DISABLE_TILE_SKIP=1: the rescue launches scan the whole shadow; round 6's launch-shape A/B
 used MVDB_RESCUE_FORM): clustered corpus (PROBE_FAMILY=0: zero-mean, 1: all-positive), 256 queries per call; wall time per call,
-the launches' own durations from the library's profiling hooks, tiles listed.  usage: rescue_form_probe.py [rows] [dim]"""
+the launches' own durations from the library's profiling hooks, tiles listed.  usage: rescue_form_probe.py [rows] [dim] [queries per call]"""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -9,7 +9,8 @@ from minivectordb_amd import _native as native
 dev = torch.device("cuda", 0)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
 d = int(sys.argv[2]) if len(sys.argv) > 2 else 512
-k, nq = 10, 256
+k = 10
+nq = int(sys.argv[3]) if len(sys.argv) > 3 else 256
 fam = int(os.environ.get("PROBE_FAMILY", "2")) << 56
 idx = native.FlatIndex(d)
 idx.reserve(n)
@@ -34,7 +35,7 @@ for name in ("ip_scan_rescue", "ip_scan_half", "ip_scan_half_seed", "ip_scan_rer
 for _ in range(10):
     idx.search_device(q.data_ptr(), nq, k, D.data_ptr(), I.data_ptr(), stream=stream)
 torch.cuda.synchronize()
-out = {"rows": n, "d": d, "tile_skip": os.environ.get("MVDB_DISABLE_TILE_SKIP", "0") != "1", "family": os.environ.get("PROBE_FAMILY", "2"),
+out = {"rows": n, "d": d, "nq": nq, "tile_skip": os.environ.get("MVDB_DISABLE_TILE_SKIP", "0") != "1", "family": os.environ.get("PROBE_FAMILY", "2"),
        "call_ms": round(wall, 3), "checksum": int(I.sum().item()), "dsum": float(D.double().sum().item())}
 listed, total = native.rescue_tile_stats()
 out["rescue_tiles_listed_of_total"] = [listed, total, round(listed / max(total, 1), 4)]

@@ -146,8 +146,10 @@ int mvdb_index_remove_rows(mvdb_index* idx, const int64_t* rows_host, int64_t m)
  *                                the CERTIFIED pass, 128 / 256 queries per pass over the fp16 shadow: ONE fp16 product nominates
  *                                64 rows per query, fp32 re-scores decide, a worst-case bound (mvdb_half_eps) certifies each
  *                                query.  A query whose certificate is refused (near-duplicate neighbourhoods) goes to the RESCUE
- *                                pass — once more over the shadow, every row above its floor kept and re-scored in fp32: exact —
- *                                and, where that cannot hold its neighbourhood, to a device-gated exact fp32-MFMA pass
+ *                                pass — once more over the shadow (inner product, k <= 16, 1M rows and more: over the 32-row
+ *                                tiles the certified pass flagged for it, a few percent of them), every row above its floor kept
+ *                                and re-scored in fp32: exact — and, where that cannot hold its neighbourhood, to a device-gated
+ *                                exact fp32-MFMA pass
  *                                (mvdb_split_rerun_count counts the chunks that held a refused query);
  *   other batches                exact fp32 passes on the matrix cores: 32 (d <= 512) / 16 (d <= 1024) queries per corpus pass
  *                                at d = 64 and the multiples of 128; elsewhere the GEMM-tiled exact scan from 6 queries

@@ -22,7 +22,8 @@
 //
 // Kernels (the queries' fp16 fragments stay in registers for the whole launch, the corpus streams through LDS-DMA rings):
 //   flat_scan_h16_kernel<KT, KS, WV, NST, DEPTH>   the pass itself, over the shadow: 128 / 256 queries per pass (32 per wave),
-//       d = 128 .. 1024; DEPTH = 32: the rescue launch.  Algorithmic bytes per launch = rows scanned x d x 2.
+//       d = 128 .. 1024; DEPTH = 32: the rescue launch, which walks a LIST of tiles (rescue_tiles_kernel: the tiles the main launches
+//       flagged for its refused queries — HalfScanArgs::tflags — or every tile).  Algorithmic bytes per launch = rows scanned x d x 2.
 //   flat_scan_seed_kernel<KQ, SKB, NG, NST>   the first launch of every pass: one 32-row tile of the fp32 rows per block (K
 //       split over four waves, partial score tiles exchanged through LDS), every score dumped — it only produces the floors.
 // (Retired in round 6: the forms of the pass that converted the fp32 rows on the fly — flat_scan_hq_kernel and the main-launch
@@ -664,7 +665,9 @@ static int launch_h16(int d, int nqpad, const HalfScanArgs& a, int device, hipSt
 // ---- the rescue pass (round 5) -----------------------------------------------------------------------------------------
 // A refused query is not an unknown one: half_certify_kernel has re-scored its 64 nominees exactly, and the k-th of those scores,
 // t, bounds the k-th result from below.  Every row of the top k therefore has an APPROXIMATE score >= t - margin - eps |q| =: f.
-// The rescue launch streams the shadow ONCE more for up to 128 refused queries with f as the admission floor and 32-deep lists per
+// The rescue launch streams the shadow ONCE more — since round 6 only the 32-row tiles some refused query of the launch was flagged for
+// by the certified pass's main launches (mvdb.hip: launch_half_pass has the bound; L2, k > 16, small corpora: every tile) — for up to
+// 128 refused queries with f as the admission floor and 32-deep lists per
 // (block, query): unless a list fills, the lists hold EVERY row that can be in the top k; half_rescue_certify_kernel re-scores
 // all of them in fp32 and takes the top k — exact, no certificate needed.  A full list (a neighbourhood of more than ~30 rows per
 // block inside the band) raises the query's `need` word and its 32-query exact pass runs as before.
