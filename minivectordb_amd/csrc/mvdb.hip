@@ -873,8 +873,9 @@ const float* ensure_offsets(const mvdb_index* idx, hipStream_t s);
 
 int launch_half_pass(const mvdb_index* idx, Workspace* ws, const float* q, int nq, int nqpad, int k, int64_t n,
                      int64_t label_offset, float* D, int64_t* I, int* flag, int* failed, const uint32_t* mask = nullptr,
-                     float* floor_out = nullptr, uint32_t* tflags = nullptr, int twords = 0) {
+                     float* floor_out = nullptr, uint32_t* tflags = nullptr, int twords = 0, bool* flags_written = nullptr) {
     hipStream_t stream = ws->stream;
+    if (flags_written) *flags_written = false;
     _Float16* qf = reinterpret_cast<_Float16*>(ws->qsplit.p);
     float* qnorm = ws->qnorm.p;
     float* floors = qnorm + nqpad;
@@ -959,6 +960,7 @@ int launch_half_pass(const mvdb_index* idx, Workspace* ws, const float* q, int n
         a.flag_qn = qnorm;
         const double B = (double)idx->row_norm_bound;
         a.flag_coef = (float)((2.25 * half_eps(idx->d) + 4.0 * idx->d * std::ldexp(1.0, -24)) * B * (1.0 + 1e-6));
+        if (flags_written) *flags_written = true;  // (the caller hands the rescue pass tile lists only if EVERY chunk's launches wrote flags)
     }
     for (size_t p = ends.size(); p-- > 0;) {
         a.tile0 = covered;
@@ -1136,8 +1138,7 @@ int search_core(const mvdb_index* idx, Workspace* ws, const float* q_dev, int nq
             MVDB_HIP(hipMemsetAsync(ws->flags.p, 0, (size_t)nchunks * sizeof(int), s));
             MVDB_HIP(hipMemsetAsync(ws->qfail.p, 0, (size_t)q0 * sizeof(int), s));
             // Tile flags (round 6): the main launches note, per query, which 32-row tiles came near its running threshold; should the
-            // query be refused, its rescue launch walks those tiles only (clustered 10M x 512: ~30 % of the shadow for ~40 refused
-            // queries).  Inner product, k <= 16 (the floors are 16th-best scores), from 1M rows on (below, the rescue launch is
+            // query be refused, its rescue launch walks those tiles only (clustered 10M x 512, 256 per call: 2.6 % of the shadow).  Inner product, k <= 16 (the floors are 16th-best scores), from 1M rows on (below, the rescue launch is
             // short and the flags' memset is not), at most 512 MiB of flags.
             const int64_t ntiles_all = (n + 31) / 32;
             const int twords = (int)((ntiles_all + 31) / 32);
@@ -1148,11 +1149,14 @@ int search_core(const mvdb_index* idx, Workspace* ws, const float* q_dev, int nq
                 MVDB_TRY(ws->tflags.reserve((size_t)q0 * twords));
                 MVDB_HIP(hipMemsetAsync(ws->tflags.p, 0, (size_t)q0 * twords * sizeof(uint32_t), s));
             }
+            bool flags_ok = tile_flags;  // ... and every chunk's main launches did write them (launch_half_pass decides per chunk)
             for (int c = 0; c < nchunks; ++c) {
                 const int c0 = plan[c].first, take = plan[c].second;
+                bool wrote = false;
                 MVDB_TRY(launch_half_pass(idx, ws, qsrc + (int64_t)c0 * idx->ld, take, half_chunk_queries(idx->d, take), k, n, label_offset,
                                           D_dev + (int64_t)c0 * k, I_dev + (int64_t)c0 * k, ws->flags.p + c, ws->qfail.p + c0, mask32,
-                                          ws->qfloor.p + c0, tile_flags ? ws->tflags.p + (size_t)c0 * twords : nullptr, twords));
+                                          ws->qfloor.p + c0, tile_flags ? ws->tflags.p + (size_t)c0 * twords : nullptr, twords, &wrote));
+                flags_ok = flags_ok && wrote;
             }
             // ---- uncertified queries: re-run on the exact kernels WITHOUT the host ever learning which they were ----------
             // split_plan_kernel compacts the failed queries (ascending) and publishes their number nb; the exact passes below
@@ -1235,7 +1239,7 @@ int search_core(const mvdb_index* idx, Workspace* ws, const float* q_dev, int nq
                 if (hn) eps = (float)((double)eps + std::ldexp(1.0, -22) * (double)idx->row_norm_bound * (1.0 + 1e-6));  // (launch_half_pass: the subtraction)
                 {   // the launches' tile lists: what the refused queries' flags name (no flags: every tile)
                     RescueTilesArgs ta;
-                    ta.tflags = tile_flags ? ws->tflags.p : nullptr;
+                    ta.tflags = flags_ok ? ws->tflags.p : nullptr;
                     ta.twords = twords;
                     ta.map = map;
                     ta.nfail = ws->nfail.p;
