@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised check of the rescue launches' tile lists at their real sizes (1M rows and more, where the certified pass keeps tile
 flags by default): random (rows, width, family, queries per call, k, bitmap) cases, each searched with the tile lists and with
-every tile scanned (MVDB_DISABLE_TILE_SKIP=1) — results must be the same bits — and a few queries per case adjudicated against the
+every tile scanned (MVDB_TILE_FLAGS=1 / 0) — results must be the same bits — and a few queries per case adjudicated against the
 float64 oracle.  usage: fuzz_tile_flags.py SEED SECONDS"""
 import os, sys, time
 for _v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
@@ -34,11 +34,11 @@ while time.time() < t_end:
     def run():
         return idx.search_masked(q, k, mask, labels="rows") if masked else idx.search(q, k)
     before = native.split_rerun_count()
-    os.environ.pop("MVDB_DISABLE_TILE_SKIP", None)
+    os.environ["MVDB_TILE_FLAGS"] = "1"          # always (the default keeps them only while the index has been refusing certificates)
     idx.reload_env()
     D1, I1 = run()
     refused = native.split_rerun_count() > before
-    os.environ["MVDB_DISABLE_TILE_SKIP"] = "1"
+    os.environ["MVDB_TILE_FLAGS"] = "0"
     idx.reload_env()
     D0, I0 = run()
     ok = D1.tobytes() == D0.tobytes() and I1.tobytes() == I0.tobytes()

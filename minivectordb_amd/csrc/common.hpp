@@ -70,6 +70,7 @@ struct Knobs {
     int split_scan_min_nq = -1;      // MVDB_SPLIT_SCAN_MIN_NQ: fewest queries of a call for the certified pass (-1: by corpus size, mvdb.hip half_min_nq)
     bool disable_rescue = false;       // MVDB_DISABLE_RESCUE: refused queries go straight to the exact passes (A/B)
     bool disable_tile_skip = false;    // MVDB_DISABLE_TILE_SKIP: the rescue launches scan every tile of the shadow (A/B)
+    int tile_flags_mode = -1;          // MVDB_TILE_FLAGS: -1 kept while the index refuses certificates (mvdb.hip: tile_flags_wanted), 1 always, 0 never
     int tile_flag_min_tiles = 32768;   // MVDB_TILE_FLAG_MIN_TILES: rows / 32 from which the certified pass keeps tile flags for the rescue pass
                                        // (1M rows: below, the rescue launch is short and the flags' memset is not)
     bool disable_rerun_floor = false;  // MVDB_DISABLE_RERUN_FLOOR: the exact re-run of refused queries starts every list from -inf (A/B)

@@ -58,6 +58,7 @@ Knobs read_knobs() {
     k.disable_rescue = env_int("MVDB_DISABLE_RESCUE", 0) != 0;
     k.disable_tile_skip = env_int("MVDB_DISABLE_TILE_SKIP", 0) != 0;
     k.tile_flag_min_tiles = env_int("MVDB_TILE_FLAG_MIN_TILES", 32768);
+    k.tile_flags_mode = env_int("MVDB_TILE_FLAGS", -1);
     k.disable_masked_batch = env_int("MVDB_DISABLE_MASKED_BATCH", 0) != 0;
     k.disable_l2_cert = env_int("MVDB_DISABLE_L2_CERT", 0) != 0;
     k.disable_half_shadow = env_int("MVDB_DISABLE_HALF_SHADOW", 0) != 0;
@@ -280,6 +281,12 @@ struct mvdb_index {
     mutable PinnedBuf sq_fail_host;
     mutable std::atomic<unsigned int> sq_calls{0}, sq_window_calls{0}, sq_window_fail{0};
     mutable std::atomic<int> sq_suspend_left{0};
+    // adaptive tile flags (search_core): a running count of refused certificates of ANY certified call, mirrored into a
+    // host-mapped word; the certified pass keeps tile flags only while that count has been moving
+    mutable unsigned int* rf_dev = nullptr;
+    mutable PinnedBuf rf_host;
+    mutable std::atomic<unsigned int> rf_seen{0};
+    mutable std::atomic<int> rf_calls_left{0};
     mutable std::atomic<unsigned long long> sq_suspensions{0};
     mutable std::shared_mutex mu;  // search: shared; add/reset/remove/free: exclusive
     mutable std::mutex ws_mu;
@@ -785,6 +792,25 @@ bool l2_offsets_ok(const mvdb_index* idx, int nq, int64_t n) {
 // (profiles/r04_small_batch_crossover.jsonl): 10M x 512: 2 queries 2.93 / 1.61 ms, 32 queries 3.06 / 1.63; 1M rows: 2 queries
 // 0.33 / 0.26, 13 queries 0.44 / 0.27; 100k rows: 2 queries 0.068 / 0.114, 8 queries 0.123 / 0.122, 13 queries 0.170 / 0.126.
 // MVDB_SPLIT_SCAN_MIN_NQ overrides (the name dates from the retired split-precision passes).
+// Tile flags cost a call that refuses nothing ~0.8 % (one compare + ballot per tile and wave, the flags' memset), so they are kept
+// adaptively: split_plan_kernel mirrors a running count of refused certificates into a host-mapped word; when the word has moved
+// since this index last looked, the next kTileFlagCalls certified calls keep flags (the call that FIRST meets refusals pays a
+// whole-shadow rescue launch, the following ones walk tile lists).  MVDB_TILE_FLAGS=1: always, 0 (or MVDB_DISABLE_TILE_SKIP=1): never.
+constexpr int kTileFlagCalls = 1024;
+bool tile_flags_wanted(const mvdb_index* idx) {
+    if (idx->kn.disable_tile_skip || idx->kn.tile_flags_mode == 0) return false;
+    if (idx->kn.tile_flags_mode == 1) return true;
+    if (!idx->rf_dev || !idx->rf_host.p) return false;
+    const unsigned int v = *reinterpret_cast<volatile unsigned int*>(idx->rf_host.p);
+    if (v != idx->rf_seen.load(std::memory_order_relaxed)) {
+        idx->rf_seen.store(v, std::memory_order_relaxed);
+        idx->rf_calls_left.store(kTileFlagCalls, std::memory_order_relaxed);
+    }
+    if (idx->rf_calls_left.load(std::memory_order_relaxed) <= 0) return false;
+    idx->rf_calls_left.fetch_sub(1, std::memory_order_relaxed);
+    return true;
+}
+
 thread_local bool tls_single_suspended = false;  // decided once per search (search_core), read by every routing question of that call
 constexpr int kSingleWindow = 32, kSingleSuspend = 512;
 // One decision per single-query search that asks for the shadow route: true = this call takes the exact scan.
@@ -1139,10 +1165,11 @@ int search_core(const mvdb_index* idx, Workspace* ws, const float* q_dev, int nq
             MVDB_HIP(hipMemsetAsync(ws->qfail.p, 0, (size_t)q0 * sizeof(int), s));
             // Tile flags (round 6): the main launches note, per query, which 32-row tiles came near its running threshold; should the
             // query be refused, its rescue launch walks those tiles only (clustered 10M x 512, 256 per call: 2.6 % of the shadow).  Inner product, k <= 16 (the floors are 16th-best scores), from 1M rows on (below, the rescue launch is
-            // short and the flags' memset is not), at most 512 MiB of flags.
+            // short and the flags' memset is not), at most 512 MiB of flags — and only while the index has been refusing
+            // certificates (tile_flags_wanted): a corpus that certifies everything never pays for them.
             const int64_t ntiles_all = (n + 31) / 32;
             const int twords = (int)((ntiles_all + 31) / 32);
-            const bool tile_flags = idx->metric == MVDB_METRIC_IP && k <= kHalfKeep && ntiles_all >= idx->kn.tile_flag_min_tiles && !idx->kn.disable_tile_skip &&
+            const bool tile_flags = idx->metric == MVDB_METRIC_IP && k <= kHalfKeep && ntiles_all >= idx->kn.tile_flag_min_tiles && tile_flags_wanted(idx) &&
                                     !idx->kn.disable_rescue && !idx->kn.disable_rerun_floor && half_rescue_dim(idx->d) &&
                                     (size_t)q0 * twords * sizeof(uint32_t) <= kTileFlagMaxBytes;
             if (tile_flags) {
@@ -1194,8 +1221,10 @@ int search_core(const mvdb_index* idx, Workspace* ws, const float* q_dev, int nq
                     sq_host = reinterpret_cast<unsigned int*>(idx->sq_fail_host.p);
                 }
             }
+            unsigned int* rf_dev = idx->rf_dev && idx->rf_host.p ? idx->rf_dev : nullptr;
             hipLaunchKernelGGL(split_plan_kernel, dim3(1), dim3(64), 0, s, (const int*)ws->flags.p, nchunks, (const int*)ws->qfail.p, q0,
-                               map, ws->nfail.p, ctr, sq_dev, (volatile unsigned int*)sq_host);
+                               map, ws->nfail.p, ctr, sq_dev, (volatile unsigned int*)sq_host, rf_dev,
+                               (volatile unsigned int*)(rf_dev ? idx->rf_host.p : nullptr));
             {
                 const int64_t rows = R + 128, gtotal = rows * (idx->ld / 4);
                 const int ggrid = (int)std::min<int64_t>((gtotal + 255) / 256, (int64_t)device_cus(idx->device) * 8);
@@ -1700,6 +1729,16 @@ const _Float16* ensure_shadow(const mvdb_index* idx, hipStream_t s, float xscale
         idx->xh_cap = cap;
         idx->xh_rows = 0;
         idx->xh_scale = xscale;
+        // (with the shadow — never inside a capture, once per index —: the refusal count and its host-mapped mirror, tile_flags_wanted)
+        if (!idx->rf_dev && hipMalloc((void**)&idx->rf_dev, sizeof(unsigned int)) == hipSuccess) {
+            if (hipMemset(idx->rf_dev, 0, sizeof(unsigned int)) != hipSuccess || idx->rf_host.reserve(64) != 0) {
+                (void)hipFree(idx->rf_dev);
+                idx->rf_dev = nullptr;
+            } else {
+                *reinterpret_cast<volatile unsigned int*>(idx->rf_host.p) = 0u;
+            }
+        }
+        (void)hipGetLastError();
     }
     if (launch_half_shadow(idx->X + idx->xh_rows * idx->ld, idx->ld, idx->d, idx->n - idx->xh_rows, xscale,
                            idx->Xh + idx->xh_rows * idx->d, idx->device, s) != 0 ||
@@ -1867,6 +1906,8 @@ int mvdb_index_free(mvdb_index* idx) {
         if (idx->ctmp) (void)hipFree(idx->ctmp);
         if (idx->sq_fail_dev) (void)hipFree(idx->sq_fail_dev);
         idx->sq_fail_host.release();
+        if (idx->rf_dev) (void)hipFree(idx->rf_dev);
+        idx->rf_host.release();
         drop_shadow(idx);
         for (Workspace* w : idx->free_ws) {
             w->destroy();

@@ -177,7 +177,9 @@ __global__ __launch_bounds__(64) void split_plan_kernel(const int* __restrict__ 
                                                         const int* __restrict__ qfail, int nq, int64_t* __restrict__ map,
                                                         int* __restrict__ nb_out, unsigned long long* __restrict__ rerun_ctr,
                                                         unsigned int* __restrict__ fail_dev = nullptr,
-                                                        volatile unsigned int* fail_host = nullptr) {
+                                                        volatile unsigned int* fail_host = nullptr,
+                                                        unsigned int* __restrict__ any_dev = nullptr,
+                                                        volatile unsigned int* any_host = nullptr) {
     const int lane = threadIdx.x;
     int bad = 0;
     for (int c = lane; c < nchunks; c += 64) bad += chunk_flags[c] != 0;
@@ -196,6 +198,8 @@ __global__ __launch_bounds__(64) void split_plan_kernel(const int* __restrict__ 
         // the opt-in single-query route: a running count of refused certificates, mirrored into a host-mapped word that the
         // routing reads WITHOUT synchronising (mvdb.hip: single_route_suspended)
         if (fail_dev && run) *fail_host = atomicAdd(fail_dev, (unsigned int)run) + (unsigned int)run;
+        // every certified call: the same for the adaptive tile flags (mvdb.hip: tile_flags_wanted)
+        if (any_dev && run) *any_host = atomicAdd(any_dev, (unsigned int)run) + (unsigned int)run;
     }
 }
 
