@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Randomised check of the rescue launches' tile lists at their real sizes (1M rows and more, where the certified pass keeps tile
+"""Randomised check of the rescue launches' tile lists at their real sizes (1M rows and more; the certified pass keeps tile
 flags by default): random (rows, width, family, queries per call, k, bitmap) cases, each searched with the tile lists and with
 every tile scanned (MVDB_TILE_FLAGS=1 / 0) — results must be the same bits — and a few queries per case adjudicated against the
 float64 oracle.  usage: fuzz_tile_flags.py SEED SECONDS"""

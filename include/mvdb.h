@@ -146,7 +146,7 @@ int mvdb_index_remove_rows(mvdb_index* idx, const int64_t* rows_host, int64_t m)
  *                                the CERTIFIED pass, 128 / 256 queries per pass over the fp16 shadow: ONE fp16 product nominates
  *                                64 rows per query, fp32 re-scores decide, a worst-case bound (mvdb_half_eps) certifies each
  *                                query.  A query whose certificate is refused (near-duplicate neighbourhoods) goes to the RESCUE
- *                                pass — once more over the shadow (inner product, k <= 16, 1M rows and more, from the second
+ *                                pass — once more over the shadow (inner product, k <= 16, ~400k rows and more, from the second
  *                                refused call of an index on: over the 32-row tiles the certified pass flagged for it, a few
  *                                percent of them — the flags are kept only while the index refuses certificates), every row above its floor kept
  *                                and re-scored in fp32: exact — and, where that cannot hold its neighbourhood, to a device-gated
@@ -312,7 +312,7 @@ int mvdb_prof_symbol(const char* name, char* out, int len);
 int64_t mvdb_split_rerun_count(void);
 
 /* Tiles (32 rows) the rescue launches were handed since the library was loaded, and the tiles they would have scanned without
- * the tile flags the certified pass keeps (inner product, k <= 16, 1M rows and more, while the index has been refusing
+ * the tile flags the certified pass keeps (inner product, k <= 16, ~400k rows and more, while the index has been refusing
  * certificates; MVDB_TILE_FLAGS=1 / 0: always / never).  Diagnostic only; synchronises the devices. */
 int mvdb_rescue_tile_stats(int64_t* listed, int64_t* total);
 

@@ -57,7 +57,7 @@ Knobs read_knobs() {
     k.disable_rerun_floor = env_int("MVDB_DISABLE_RERUN_FLOOR", 0) != 0;
     k.disable_rescue = env_int("MVDB_DISABLE_RESCUE", 0) != 0;
     k.disable_tile_skip = env_int("MVDB_DISABLE_TILE_SKIP", 0) != 0;
-    k.tile_flag_min_tiles = env_int("MVDB_TILE_FLAG_MIN_TILES", 32768);
+    k.tile_flag_min_tiles = env_int("MVDB_TILE_FLAG_MIN_TILES", 12288);
     k.tile_flags_mode = env_int("MVDB_TILE_FLAGS", -1);
     k.disable_masked_batch = env_int("MVDB_DISABLE_MASKED_BATCH", 0) != 0;
     k.disable_l2_cert = env_int("MVDB_DISABLE_L2_CERT", 0) != 0;
@@ -1164,7 +1164,7 @@ int search_core(const mvdb_index* idx, Workspace* ws, const float* q_dev, int nq
             MVDB_HIP(hipMemsetAsync(ws->flags.p, 0, (size_t)nchunks * sizeof(int), s));
             MVDB_HIP(hipMemsetAsync(ws->qfail.p, 0, (size_t)q0 * sizeof(int), s));
             // Tile flags (round 6): the main launches note, per query, which 32-row tiles came near its running threshold; should the
-            // query be refused, its rescue launch walks those tiles only (clustered 10M x 512, 256 per call: 2.6 % of the shadow).  Inner product, k <= 16 (the floors are 16th-best scores), from 1M rows on (below, the rescue launch is
+            // query be refused, its rescue launch walks those tiles only (clustered 10M x 512, 256 per call: 2.6 % of the shadow).  Inner product, k <= 16 (the floors are 16th-best scores), from ~400k rows on (below, the rescue launch is
             // short and the flags' memset is not), at most 512 MiB of flags — and only while the index has been refusing
             // certificates (tile_flags_wanted): a corpus that certifies everything never pays for them.
             const int64_t ntiles_all = (n + 31) / 32;

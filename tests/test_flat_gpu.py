@@ -1907,7 +1907,7 @@ def test_rescue_launches_skip_tiles_no_refused_query_flagged(native, monkeypatch
     query of its batch flagged (+ the seed's tiles) instead of the whole shadow.  Results must be the same BITS as with every tile
     scanned (MVDB_DISABLE_TILE_SKIP=1) — the rescue lists hold every row above the floor either way — and stand the float64
     adjudication; on the clustered corpus some certificates are refused and the launches are handed a fraction of the tiles.
-    (The flags are kept from 1M rows on — MVDB_TILE_FLAG_MIN_TILES=1 brings smaller corpora in — and only while the index has been
+    (The flags are kept from ~400k rows on — MVDB_TILE_FLAG_MIN_TILES=1 brings smaller corpora in — and only while the index has been
     refusing certificates: the first call of a fresh index scans every tile, a corpus that certifies everything never pays.)"""
     monkeypatch.setenv("MVDB_TILE_FLAG_MIN_TILES", "1")
     q = flat.synth(nq, d, 5678 | flat.SYNTH_CLUSTERED)
